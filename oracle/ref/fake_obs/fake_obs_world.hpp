@@ -1,0 +1,51 @@
+/*
+ * fake_obs_world.hpp -- TEST INFRASTRUCTURE.
+ * The harness-facing side of the fake libobs (see obs-module.h): concrete
+ * definitions of the "opaque" handles and the knobs a real OBS process would
+ * own (audio configuration, frame rate, clock, audio sources).
+ */
+#pragma once
+#include "obs-module.h"
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace fakeobs {
+struct Value {
+    enum Kind { STRING, INT, DOUBLE, BOOL } kind = STRING;
+    std::string s;
+    long long i = 0;
+    double d = 0.0;
+    bool b = false;
+};
+}
+
+struct obs_data {
+    std::map<std::string, fakeobs::Value> vals;
+    std::map<std::string, fakeobs::Value> defaults;
+};
+
+struct obs_source {
+    std::string name;
+    uint32_t flags = 0;
+    bool showing = true;
+    std::vector<std::pair<obs_source_audio_capture_t, void *>> audio_cbs;
+};
+
+namespace fakeobs {
+void set_audio_info(uint32_t samples_per_sec, int channels);
+void set_video_fps(uint32_t num, uint32_t den);
+void set_clock_ns(uint64_t ns); // thread-local
+uint64_t clock_ns();
+void set_log_level(int level);
+const obs_source_info *registered_source_info();
+
+obs_source *create_source(const char *name, uint32_t flags);
+void destroy_source(obs_source *src);
+void push_audio(obs_source *src, const audio_data *audio, bool muted);
+
+obs_data *data_create();
+void data_destroy(obs_data *d);
+void data_set_from_text(obs_data *d, const char *name, const char *text);
+}

@@ -1,0 +1,295 @@
+/*
+ * ref_harness.cpp -- TEST INFRASTRUCTURE (see wfref.h).
+ *
+ * Drives the reference plugin's WAVSource exactly as OBS does, through the
+ * reference's own public entry points:
+ *   obs_module_load()            src/module.cpp:35-39  -> WAVSource::register_source()
+ *   WAVSource{Generic,AVX,AVX2}  src/source.hpp:349-386 (chosen like callbacks::create,
+ *                                src/source.cpp:87-102, but by the caller, not CPUID)
+ *   update(settings)             src/source.cpp:1077-1322
+ *   capture_audio callback       src/source.cpp:490-493 / 1817-1888
+ *   tick(seconds)                src/source.cpp:1324-1344 -> tick_spectrum
+ *   render(effect)               src/source.cpp:1346-1358 -> render_bars / render_curve
+ * The only liberty taken is reading protected members (this TU alone is compiled
+ * with `protected` spelled `public`; the reference TUs are compiled untouched).
+ */
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <numbers>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <vector>
+#include <cassert>
+#include <cstdint>
+
+#define protected public
+#define private public
+#include "source.hpp"
+#undef protected
+#undef private
+
+#include "fake_obs_world.hpp"
+#include "wfref.h"
+#include "wf_synth.h"
+
+namespace {
+
+std::mutex g_create_mtx; // FFTW's planner and the fake world registry are not thread-safe
+std::once_flag g_load_once;
+std::atomic<uint64_t> g_next_id{1};
+
+void ensure_loaded()
+{
+    std::call_once(g_load_once, [] { obs_module_load(); });
+}
+
+void apply_settings(obs_data *d, const char *settings)
+{
+    if(settings == nullptr)
+        return;
+    std::string s(settings);
+    size_t pos = 0;
+    while(pos < s.size()) {
+        auto end = s.find(';', pos);
+        if(end == std::string::npos)
+            end = s.size();
+        auto item = s.substr(pos, end - pos);
+        auto eq = item.find('=');
+        if(eq != std::string::npos) {
+            auto key = item.substr(0, eq);
+            auto val = item.substr(eq + 1);
+            fakeobs::data_set_from_text(d, key.c_str(), val.c_str());
+        }
+        pos = end + 1;
+    }
+}
+
+} // namespace
+
+struct wfref {
+    WAVSource *obj = nullptr;
+    obs_source *self = nullptr;   // the visualiser source OBS would own
+    obs_source *audio = nullptr;  // the audio source it captures
+    obs_data *settings = nullptr;
+    uint32_t sample_rate = 48000;
+    int channels = 2;
+};
+
+extern "C" {
+
+wfref_t *wfref_create(const char *isa, const char *settings, uint32_t sample_rate, int channels, uint32_t fps_num, uint32_t fps_den)
+{
+    ensure_loaded();
+    auto info = fakeobs::registered_source_info();
+    if(info == nullptr)
+        return nullptr;
+
+    std::lock_guard lock(g_create_mtx);
+    auto h = new wfref();
+    h->sample_rate = sample_rate;
+    h->channels = channels;
+    const auto id = g_next_id.fetch_add(1);
+    const auto self_name = "wf_self_" + std::to_string(id);
+    const auto audio_name = "wf_audio_" + std::to_string(id);
+    h->self = fakeobs::create_source(self_name.c_str(), OBS_SOURCE_VIDEO | OBS_SOURCE_CUSTOM_DRAW);
+    h->audio = fakeobs::create_source(audio_name.c_str(), OBS_SOURCE_AUDIO);
+
+    h->settings = fakeobs::data_create();
+    info->get_defaults(h->settings);
+    fakeobs::data_set_from_text(h->settings, "audio_source", audio_name.c_str());
+    apply_settings(h->settings, settings);
+
+    fakeobs::set_audio_info(sample_rate, channels);
+    fakeobs::set_video_fps(fps_num ? fps_num : 60, fps_den ? fps_den : 1);
+
+    std::string which = isa ? isa : "generic";
+    if(which == "avx2")
+        h->obj = new WAVSourceAVX2(h->self);
+    else if(which == "avx")
+        h->obj = new WAVSourceAVX(h->self);
+    else
+        h->obj = new WAVSourceGeneric(h->self);
+    h->obj->update(h->settings);
+    return h;
+}
+
+void wfref_destroy(wfref_t *h)
+{
+    if(h == nullptr)
+        return;
+    std::lock_guard lock(g_create_mtx);
+    delete h->obj;
+    fakeobs::destroy_source(h->audio);
+    fakeobs::destroy_source(h->self);
+    fakeobs::data_destroy(h->settings);
+    delete h;
+}
+
+void wfref_update(wfref_t *h, const char *settings)
+{
+    std::lock_guard lock(g_create_mtx);
+    apply_settings(h->settings, settings);
+    fakeobs::set_audio_info(h->sample_rate, h->channels);
+    h->obj->update(h->settings);
+}
+
+void wfref_set_clock_ns(uint64_t ns) { fakeobs::set_clock_ns(ns); }
+uint64_t wfref_clock_ns(void) { return fakeobs::clock_ns(); }
+
+void wfref_push_audio(wfref_t *h, const float *ch0, const float *ch1, uint32_t frames, uint64_t timestamp_ns, int muted)
+{
+    audio_data pkt{};
+    pkt.data[0] = (uint8_t *)ch0;
+    pkt.data[1] = (uint8_t *)ch1;
+    pkt.frames = frames;
+    pkt.timestamp = timestamp_ns;
+    fakeobs::push_audio(h->audio, &pkt, muted != 0);
+}
+
+void wfref_feed_and_tick(wfref_t *h, const float *ch0, const float *ch1, uint32_t frames, uint64_t now_ns, float seconds)
+{
+    fakeobs::set_clock_ns(now_ns);
+    if(frames > 0) {
+        const auto len = audio_frames_to_ns(h->sample_rate, frames);
+        wfref_push_audio(h, ch0, ch1, frames, now_ns - len, 0);
+    }
+    h->obj->tick(seconds);
+}
+
+void wfref_tick(wfref_t *h, float seconds) { h->obj->tick(seconds); }
+void wfref_render(wfref_t *h) { h->obj->render(nullptr); }
+void wfref_show(wfref_t *h, int show)
+{
+    h->self->showing = (show != 0);
+    if(show)
+        h->obj->show();
+    else
+        h->obj->hide();
+}
+
+size_t wfref_fft_size(wfref_t *h) { return h->obj->m_fft_size; }
+uint32_t wfref_capture_channels(wfref_t *h) { return h->obj->m_capture_channels; }
+uint32_t wfref_output_channels(wfref_t *h) { return h->obj->m_output_channels; }
+int wfref_stereo(wfref_t *h) { return h->obj->m_stereo ? 1 : 0; }
+int wfref_last_silent(wfref_t *h) { return h->obj->m_last_silent ? 1 : 0; }
+size_t wfref_ring_bytes(wfref_t *h, int ch) { return h->obj->m_capturebufs[ch & 1].size(); }
+float wfref_gravity(wfref_t *h, float seconds) { return h->obj->get_gravity(seconds); }
+float wfref_db_min(void) { return WAVSource::DB_MIN; }
+const float *wfref_decibels(wfref_t *h, int ch) { return h->obj->m_decibels[ch & 1].get(); }
+const float *wfref_tsmooth(wfref_t *h, int ch) { return h->obj->m_tsmooth_buf[ch & 1].get(); }
+const float *wfref_window(wfref_t *h) { return h->obj->m_window_coefficients.get(); }
+float wfref_window_sum(wfref_t *h) { return h->obj->m_window_sum; }
+const float *wfref_slope(wfref_t *h) { return h->obj->m_slope_modifiers.get(); }
+const float *wfref_rolloff(wfref_t *h) { return h->obj->m_rolloff_modifiers.get(); }
+int wfref_num_bars(wfref_t *h) { return h->obj->m_num_bars; }
+size_t wfref_interp_indices(wfref_t *h, const float **out)
+{
+    *out = h->obj->m_interp_indices.data();
+    return h->obj->m_interp_indices.size();
+}
+size_t wfref_band_widths(wfref_t *h, const int **out)
+{
+    *out = h->obj->m_band_widths.data();
+    return h->obj->m_band_widths.size();
+}
+size_t wfref_interp_kernel(wfref_t *h, const float **out, int *radius, int *size)
+{
+    auto &k = h->obj->m_interp_kernel;
+    *out = k.weights.get();
+    if(radius) *radius = k.radius;
+    if(size) *size = k.size;
+    return (k.weights.get() == nullptr) ? 0 : h->obj->m_interp_indices.size() * (size_t)k.size;
+}
+size_t wfref_bars(wfref_t *h, int ch, const float **out)
+{
+    auto &v = h->obj->m_interp_bufs[ch & 1];
+    *out = v.data();
+    return v.size();
+}
+
+float wfref_noise(uint64_t seed, uint32_t stream, uint32_t channel, uint64_t index)
+{
+    return wf_synth_noise(seed, stream, channel, index);
+}
+
+double wfref_bench(const char *isa, const char *settings, uint32_t sample_rate, int channels, int n_streams, int n_threads,
+                   int warmup_ticks, int timed_ticks, int hop, uint64_t seed, double *elapsed_s)
+{
+    if(n_streams <= 0 || n_threads <= 0 || hop <= 0)
+        return 0.0;
+    n_threads = std::min(n_threads, n_streams);
+    std::vector<wfref_t *> streams((size_t)n_streams, nullptr);
+    for(int s = 0; s < n_streams; ++s) {
+        streams[(size_t)s] = wfref_create(isa, settings, sample_rate, channels, 60, 1);
+        if(streams[(size_t)s] == nullptr)
+            return 0.0;
+    }
+    const int cap_ch = (int)wfref_capture_channels(streams[0]);
+    const int total_ticks = warmup_ticks + timed_ticks;
+    const uint64_t tick_ns = audio_frames_to_ns(sample_rate, (uint64_t)hop);
+
+    // Noise is generated outside the timed region: one pool per thread, long enough that
+    // every (stream, tick) sees a different slice.  Generating it is not part of the
+    // reference's path; pushing it through capture_audio (CircularBuffer) is.
+    const size_t pool = (size_t)hop * 64 + 1024;
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<double> t_elapsed((size_t)n_threads, 0.0);
+    std::vector<std::thread> threads;
+    for(int t = 0; t < n_threads; ++t) {
+        threads.emplace_back([&, t] {
+            const int lo = (int)((int64_t)n_streams * t / n_threads);
+            const int hi = (int)((int64_t)n_streams * (t + 1) / n_threads);
+            std::vector<float> noise[2];
+            for(int c = 0; c < 2; ++c) {
+                noise[c].resize(pool);
+                const auto key = wf_synth_key(seed, (uint32_t)(0x40000000u + (uint32_t)t), (uint32_t)c);
+                for(size_t i = 0; i < pool; ++i)
+                    noise[c][i] = wf_synth_sample(key, i);
+            }
+            uint64_t now = 1000000000ull;
+            auto run = [&](int ticks, int tick0) {
+                for(int k = 0; k < ticks; ++k) {
+                    now += tick_ns;
+                    for(int s = lo; s < hi; ++s) {
+                        const size_t off = ((size_t)(tick0 + k) * 7919u + (size_t)s * 104729u) % (pool - (size_t)hop);
+                        wfref_feed_and_tick(streams[(size_t)s], noise[0].data() + off, (cap_ch > 1) ? noise[1].data() + off : nullptr,
+                                            (uint32_t)hop, now, 1.0f / 60.0f);
+                    }
+                }
+            };
+            run(warmup_ticks, 0);
+            ready.fetch_add(1);
+            while(!go.load(std::memory_order_acquire))
+                std::this_thread::yield();
+            const auto t0 = std::chrono::steady_clock::now();
+            run(timed_ticks, warmup_ticks);
+            const auto t1 = std::chrono::steady_clock::now();
+            t_elapsed[(size_t)t] = std::chrono::duration<double>(t1 - t0).count();
+        });
+    }
+    while(ready.load() < n_threads)
+        std::this_thread::yield();
+    const auto w0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for(auto &th : threads)
+        th.join();
+    const auto w1 = std::chrono::steady_clock::now();
+    (void)total_ticks;
+    const double wall = std::chrono::duration<double>(w1 - w0).count();
+    if(elapsed_s != nullptr)
+        *elapsed_s = wall;
+    for(auto s : streams)
+        wfref_destroy(s);
+    const double spectra = (double)n_streams * (double)cap_ch * (double)timed_ticks;
+    return (wall > 0.0) ? spectra / wall : 0.0;
+}
+
+} // extern "C"

@@ -1,0 +1,90 @@
+/*
+ * wfref.h -- C API of oracle/_ref/libwfref.so (TEST INFRASTRUCTURE).
+ *
+ * libwfref.so IS the reference: phandasm/waveform v1.9.1's own translation
+ * units (src/source.cpp, source_generic.cpp, source_avx.cpp, source_avx2.cpp,
+ * filter_fma3.cpp, module.cpp) compiled verbatim from /root/reference together
+ * with the vendored FFTW 3.3.11, linked against the headless fake libobs in
+ * fake_obs/.  This API drives a WAVSource the way OBS does (create -> update ->
+ * audio callback -> video_tick -> video_render) and exposes the protected
+ * members the hot path reads and writes (src/source.hpp:101-247) so tests can
+ * compare them with the oracle restatement and with the HIP path.
+ *
+ * Only tests/, tools/make_golden.py, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product never does.
+ */
+#ifndef WFREF_H
+#define WFREF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wfref wfref_t;
+
+/* isa: "generic" | "avx" | "avx2" -> WAVSourceGeneric / WAVSourceAVX / WAVSourceAVX2
+ *      (the classes callbacks::create picks from, src/source.cpp:87-102).
+ * settings: "key=value;key=value" over the plugin's own setting keys
+ *      (src/settings.hpp), applied on top of get_defaults (src/source.cpp:119-174).
+ * channels: OBS audio channel count (1 = mono, 2 = stereo, ...).
+ * Returns NULL on failure. */
+wfref_t *wfref_create(const char *isa, const char *settings, uint32_t sample_rate, int channels,
+                      uint32_t fps_num, uint32_t fps_den);
+void wfref_destroy(wfref_t *h);
+/* re-run WAVSource::update() with new overrides (keeps earlier overrides) */
+void wfref_update(wfref_t *h, const char *settings);
+
+/* fake clock (thread-local): what os_gettime_ns() returns */
+void wfref_set_clock_ns(uint64_t ns);
+uint64_t wfref_clock_ns(void);
+
+/* deliver one audio packet through the registered capture callback
+ * (src/source.cpp:1817-1888). ch1 may be NULL. timestamp_ns = audio_data.timestamp. */
+void wfref_push_audio(wfref_t *h, const float *ch0, const float *ch1, uint32_t frames, uint64_t timestamp_ns, int muted);
+/* convenience used by every test: advance the clock to `now_ns`, push `frames`
+ * samples whose end-of-audio timestamp equals now_ns (so get_audio_sync() == 0),
+ * then call video_tick(seconds). */
+void wfref_feed_and_tick(wfref_t *h, const float *ch0, const float *ch1, uint32_t frames, uint64_t now_ns, float seconds);
+void wfref_tick(wfref_t *h, float seconds);
+void wfref_render(wfref_t *h);
+void wfref_show(wfref_t *h, int show);
+
+/* ---- state of the object (valid until the next update/destroy) ---- */
+size_t wfref_fft_size(wfref_t *h);
+uint32_t wfref_capture_channels(wfref_t *h);
+uint32_t wfref_output_channels(wfref_t *h);
+int wfref_stereo(wfref_t *h);
+int wfref_last_silent(wfref_t *h);
+size_t wfref_ring_bytes(wfref_t *h, int ch);
+float wfref_gravity(wfref_t *h, float seconds);    /* get_gravity(), src/source.hpp:301-312 */
+float wfref_db_min(void);
+const float *wfref_decibels(wfref_t *h, int ch);   /* m_decibels[ch], fft_size/2 floats */
+const float *wfref_tsmooth(wfref_t *h, int ch);    /* m_tsmooth_buf[ch] or NULL */
+const float *wfref_window(wfref_t *h);             /* m_window_coefficients or NULL */
+float wfref_window_sum(wfref_t *h);
+const float *wfref_slope(wfref_t *h);              /* m_slope_modifiers or NULL */
+const float *wfref_rolloff(wfref_t *h);            /* m_rolloff_modifiers or NULL */
+int wfref_num_bars(wfref_t *h);
+size_t wfref_interp_indices(wfref_t *h, const float **out); /* m_interp_indices */
+size_t wfref_band_widths(wfref_t *h, const int **out);      /* m_band_widths */
+size_t wfref_interp_kernel(wfref_t *h, const float **out, int *radius, int *size); /* m_interp_kernel.weights */
+size_t wfref_bars(wfref_t *h, int ch, const float **out);   /* m_interp_bufs[ch] after render(): pixel y */
+
+/* ---- CPU baseline ----
+ * n_streams WAVSource objects split statically over n_threads std::threads; each tick
+ * every stream receives `hop` new frames/channel of counter-hash white noise through
+ * the capture callback and then video_tick(seconds).  Returns spectra per second over
+ * the timed ticks (1 spectrum = 1 channel of 1 stream-tick). */
+double wfref_bench(const char *isa, const char *settings, uint32_t sample_rate, int channels,
+                   int n_streams, int n_threads, int warmup_ticks, int timed_ticks, int hop,
+                   uint64_t seed, double *elapsed_s);
+
+/* counter-hash white noise shared by oracle, harness and device generator */
+float wfref_noise(uint64_t seed, uint32_t stream, uint32_t channel, uint64_t index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
