@@ -1,0 +1,69 @@
+/*
+ * wf_config.h -- plain-C description of one WAVSource configuration.
+ *
+ * These are the WAVSource members the spectrum hot path reads
+ * (reference src/source.hpp:101-247), with the values WAVSource::get_settings
+ * leaves in them (src/source.cpp:501-674; defaults src/source.cpp:119-174).
+ * A host that embeds the library (the OBS plugin) fills one
+ * of these in WAVSource::update() right after get_settings().
+ */
+#ifndef WF_CONFIG_H
+#define WF_CONFIG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum FFTWindow, src/source.hpp:33-41 */
+typedef enum wf_window {
+    WF_WINDOW_NONE = 0, WF_WINDOW_HANN, WF_WINDOW_HAMMING, WF_WINDOW_BLACKMAN,
+    WF_WINDOW_BLACKMAN_HARRIS, WF_WINDOW_POWER_OF_SINE
+} wf_window;
+/* enum TSmoothingMode, src/source.hpp:56-61 */
+typedef enum wf_tsmoothing { WF_TSMOOTH_NONE = 0, WF_TSMOOTH_EXPONENTIAL, WF_TSMOOTH_TVEXPONENTIAL } wf_tsmoothing;
+/* enum InterpMode, src/source.hpp:43-48 */
+typedef enum wf_interp { WF_INTERP_POINT = 0, WF_INTERP_LANCZOS, WF_INTERP_CATROM } wf_interp;
+
+typedef struct wf_config {
+    uint32_t fft_size;          /* m_fft_size: power of two, 1024..16384 (the reference accepts any multiple of 16 >= 128) */
+    uint32_t sample_rate;       /* m_audio_info.samples_per_sec */
+    uint32_t capture_channels;  /* m_capture_channels: 1 or 2 */
+    uint32_t stereo;            /* m_stereo (channel_mode == "stereo") */
+    int32_t window;             /* m_window_func (wf_window) */
+    int32_t sine_exponent;      /* m_sine_exponent */
+    int32_t tsmoothing;         /* m_tsmoothing (wf_tsmoothing) */
+    float gravity;              /* m_gravity */
+    uint32_t fast_peaks;        /* m_fast_peaks */
+    float slope;                /* m_slope */
+    float rolloff_q;            /* m_rolloff_q */
+    float rolloff_rate;         /* m_rolloff_rate */
+    int32_t cutoff_low;         /* m_cutoff_low  (Hz) */
+    int32_t cutoff_high;        /* m_cutoff_high (Hz) */
+    int32_t floor_db;           /* m_floor */
+    int32_t ceiling_db;         /* m_ceiling */
+    uint32_t normalize_volume;  /* m_normalize_volume */
+    float volume_target;        /* m_volume_target */
+    float max_gain;             /* m_max_gain */
+    /* bar display (render_bars, src/source.cpp:1473-1567); bars are produced only when bars != 0 */
+    uint32_t bars;              /* display_mode is BAR or STEPPED_BAR */
+    int32_t interp_mode;        /* m_interp_mode (wf_interp) */
+    uint32_t log_scale;         /* m_log_scale */
+    uint32_t mirror_freq_axis;  /* m_mirror_freq_axis */
+    uint32_t width;             /* m_width */
+    uint32_t height;            /* m_height */
+    int32_t bar_width;          /* m_bar_width */
+    int32_t bar_gap;            /* m_bar_gap */
+    int32_t channel_spacing;    /* m_channel_spacing */
+    int32_t min_bar_height;     /* m_min_bar_height */
+    uint32_t rounded_caps;      /* m_rounded_caps (changes border_top / border_bottom) */
+} wf_config;
+
+/* get_defaults (src/source.cpp:119-174) + what update() derives for 48 kHz stereo OBS audio,
+ * in bar display mode off.  Callers then override what the configuration under test needs. */
+void wf_config_defaults(wf_config *cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,159 @@
+/*
+ * wf_hip.h -- C ABI of libwaveform_hip.so, the MI355X (gfx950) implementation of
+ * phandasm/waveform's per-tick spectrum path.
+ *
+ * Boundary.  The reference selects its DSP kernels through four virtuals on
+ * WAVSource (src/source.hpp:273-277); callbacks::create (src/source.cpp:87-102)
+ * instantiates WAVSourceAVX2 / WAVSourceAVX / WAVSourceGeneric.  This library is
+ * what a fourth subclass, WAVSourceHIP, calls from its tick_spectrum() override
+ * (host/wav_source_hip.hpp; the binding a maintainer adds is in INTEGRATION.md).
+ * One wf_hip handle serves a *batch* of independent sources ("streams") that share
+ * one configuration, because a GPU only pays off batched.
+ *
+ * Mapping of entry points to the reference code they replace:
+ *   wf_hip_create        WAVSource::update(): buffers, FFTW plan, window/slope/rolloff/
+ *                        interp tables (src/source.cpp:1169-1290, :837-918)
+ *   wf_hip_destroy       WAVSource::free_bufs() (src/source.cpp:782-808)
+ *   wf_hip_reset         state init in update(): m_tsmooth_buf = 0, m_decibels = DB_MIN,
+ *                        rings pre-filled with N zero samples (:1170-1182, :1243-1248)
+ *   wf_hip_push_audio*   WAVSource::capture_audio(): CircularBuffer::push_back per channel
+ *                        (src/source.cpp:1873-1886, src/circular_buffer.hpp:42-63)
+ *   wf_hip_tick          WAVSource*::tick_spectrum(seconds) for every stream of the batch
+ *                        (src/source_generic.cpp:26-180 -- the parity target; AVX variants
+ *                        src/source_avx.cpp:29-200, src/source_avx2.cpp:24-209), plus, when
+ *                        the configuration displays bars, the bar reduction of render_bars
+ *                        (src/source.cpp:1500-1557; src/filter.hpp:160-211)
+ *   wf_hip_read_*        reading m_decibels / m_interp_bufs / m_tsmooth_buf
+ *
+ * Conventions: plain C types only; every function returns WF_HIP_OK (0) or a negative
+ * wf_hip_status, never throws, never aborts; wf_hip_last_error() gives the text.  A handle
+ * is used by one thread at a time (the reference holds m_mtx around tick/update,
+ * src/source.cpp:1326,1079); different handles may be used concurrently.  Host buffers
+ * passed in are borrowed for the duration of the call.  All work of a handle is issued on
+ * its own HIP stream; functions that return data to the host synchronise that stream.
+ *
+ * There is NO CPU fallback in this library: without a usable gfx950 device
+ * wf_hip_create fails with WF_HIP_ERR_NO_DEVICE and the caller keeps using its
+ * CPU class (WAVSourceGeneric) -- the reference's own failure mode for a missing
+ * FFTW plan is to skip the channel (src/source_generic.cpp:105-108).
+ */
+#ifndef WF_HIP_H
+#define WF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#include "wf_config.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF_HIP_ABI_VERSION 1
+
+typedef enum wf_hip_status {
+    WF_HIP_OK = 0,
+    WF_HIP_ERR_INVALID = -1,     /* bad argument / configuration */
+    WF_HIP_ERR_UNSUPPORTED = -2, /* legal for the reference, not implemented here (e.g. non power-of-two FFT size) */
+    WF_HIP_ERR_NO_DEVICE = -3,   /* no usable HIP device */
+    WF_HIP_ERR_RUNTIME = -4,     /* a HIP call failed; see wf_hip_last_error */
+    WF_HIP_ERR_NOMEM = -5
+} wf_hip_status;
+
+typedef struct wf_hip wf_hip; /* opaque */
+
+/* ---- library ---------------------------------------------------------------------- */
+int wf_hip_abi_version(void);
+/* number of usable HIP devices (0 when there is none; never fails) */
+int wf_hip_device_count(void);
+/* text of the last error on this handle (or of the last failed create when h == NULL) */
+const char *wf_hip_last_error(const wf_hip *h);
+
+/* ---- lifetime ----------------------------------------------------------------------- */
+/* max_streams: batch size (independent WAVSource instances sharing cfg).
+ * ring_frames: capacity of each per-channel device ring in samples; 0 = default
+ *              (smallest power of two >= 2 * fft_size). Rounded up to a power of two. */
+int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32_t ring_frames, wf_hip **out);
+void wf_hip_destroy(wf_hip *h);
+/* re-initialise streams [first, first+count): smoothing state 0, decibels DB_MIN, rings = N zeros */
+int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count);
+
+/* ---- geometry of the batch ---------------------------------------------------------- */
+uint32_t wf_hip_fft_size(const wf_hip *h);
+uint32_t wf_hip_num_streams(const wf_hip *h);
+uint32_t wf_hip_capture_channels(const wf_hip *h);
+uint32_t wf_hip_output_channels(const wf_hip *h);  /* m_output_channels */
+uint32_t wf_hip_display_channels(const wf_hip *h); /* m_stereo ? 2 : 1 */
+uint32_t wf_hip_num_bars(const wf_hip *h);         /* m_num_bars (0 when cfg.bars == 0) */
+uint32_t wf_hip_ring_frames(const wf_hip *h);
+
+/* ---- audio ingest ------------------------------------------------------------------- */
+/* Append `frames` samples per channel to streams [first, first+count).
+ * Layout of `samples` (host memory): [count][capture_channels][frames], planar float32 --
+ * what capture_audio receives per source in audio_data::data[] (src/source.cpp:1873-1882). */
+int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames);
+/* Same, from a device pointer on the handle's device (no PCIe crossing). */
+int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const float *d_samples, uint32_t frames);
+/* Same, but the samples are generated on the device by the counter hash of wf_synth.h:
+ * stream s, channel c receives wf_synth_noise(seed, stream_id0 + s, c, index0 + i), i < frames. */
+int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, uint32_t stream_id0,
+                      uint64_t index0, uint32_t frames);
+/* muted / silent packet: CircularBuffer::push_back_zero (src/source.cpp:1879-1880) */
+int wf_hip_push_silence(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames);
+
+/* ---- the tick ------------------------------------------------------------------------- */
+typedef struct wf_hip_tick_params {
+    float seconds;          /* tick_spectrum(seconds): only TVEXPONENTIAL smoothing uses it */
+    uint32_t delay_frames;  /* audio already captured beyond the tick time: the window is the fft_size
+                               samples ending delay_frames before the newest one
+                               (dtaudio > 0 in src/source_generic.cpp:50-51) */
+    float input_rms;        /* m_input_rms, only read when cfg.normalize_volume */
+    uint32_t flags;         /* WF_HIP_TICK_* */
+} wf_hip_tick_params;
+#define WF_HIP_TICK_NO_DECIBELS 1u /* bars-only batch mode: skip the m_decibels store (cfg.bars must be set) */
+
+/* Asynchronous: enqueues the fused kernel for all streams on the handle's stream. */
+int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
+/* show()/hide()/capture-timeout per stream: hidden streams take the reset branch of
+ * tick_spectrum (src/source_generic.cpp:34-48).  mask[i] != 0 -> hidden. */
+int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *mask);
+int wf_hip_sync(wf_hip *h);
+
+/* ---- results ----------------------------------------------------------------------------- */
+/* m_decibels of streams [first, first+count): [count][output_channels][fft_size/2] */
+int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out);
+/* bar tops in pixels (m_interp_bufs after the dB->y mapping of render_bars,
+ * src/source.cpp:1548-1557): [count][display_channels][num_bars] */
+int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out);
+/* m_tsmooth_buf: [count][capture_channels][fft_size/2] */
+int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out);
+int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in);
+/* m_last_silent per stream */
+int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *out);
+/* device pointers for zero-copy consumers on the same device (e.g. an RCCL all-gather of
+ * the bars, or a renderer): valid until wf_hip_destroy */
+float *wf_hip_decibels_device(wf_hip *h);
+float *wf_hip_bars_device(wf_hip *h);
+void *wf_hip_stream(wf_hip *h); /* hipStream_t */
+
+/* ---- host tables (what update() precomputes), for tests and for hosts that render themselves */
+size_t wf_hip_table_window(const wf_hip *h, const float **out, float *window_sum);
+size_t wf_hip_table_slope(const wf_hip *h, const float **out);
+size_t wf_hip_table_rolloff(const wf_hip *h, const float **out);
+size_t wf_hip_table_interp_indices(const wf_hip *h, const float **out);
+size_t wf_hip_table_band_widths(const wf_hip *h, const int **out);
+size_t wf_hip_table_interp_weights(const wf_hip *h, const float **out, int *radius, int *taps);
+float wf_hip_gravity(const wf_hip *h, float seconds); /* get_gravity(), src/source.hpp:301-312 */
+float wf_hip_db_min(void);                            /* DB_MIN, src/source.cpp:43 */
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Runs `ticks` ticks back to back (each `hop` frames further into audio that must already be in
+ * the rings: delay_frames = first_delay - i*hop) and returns the average duration of the fused
+ * kernel in milliseconds, measured with hipEvents on the handle's stream. */
+int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, uint32_t hop, float *avg_kernel_ms);
+const char *wf_hip_kernel_name(const wf_hip *h);
+/* algorithmic HBM bytes one tick moves: per spectrum 4N in + state r/w + dB out */
+uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

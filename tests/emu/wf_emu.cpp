@@ -1,0 +1,212 @@
+// wf_emu.cpp -- TEST HARNESS: a lane-by-lane wavefront emulator for the tick kernel.
+//
+// Compiles the *same* phase functions the gfx950 kernel is made of
+// (waveform_amd/csrc/wf_tick_phases.hpp) with g++ and runs them thread by thread on
+// the host, phase by phase, so that on the GPU-less build box we can check the FFT
+// index algebra / epilogue against the oracle and count LDS bank conflicts with the
+// bank model of MI355X_MICROARCH.md (LDS section).  Nothing here is part of the
+// product: libwaveform_hip.so never links this file and has no CPU path.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <map>
+#include <algorithm>
+
+// ---- LDS access trace ---------------------------------------------------------------------
+namespace emu {
+struct Access { int idx; int bytes; int is_write; };
+static thread_local std::vector<Access> *g_trace = nullptr;
+inline void trace(int idx, int bytes, int is_write)
+{
+    if(g_trace)
+        g_trace->push_back({idx, bytes, is_write});
+}
+}
+#define WF_LDS_TRACE(idx, bytes, is_write) ::emu::trace((idx), (bytes), (is_write))
+
+#include "../../waveform_amd/csrc/wf_geometry.hpp"
+#include "../../waveform_amd/csrc/wf_tick_phases.hpp"
+#include "../../waveform_amd/csrc/wf_host_tables.hpp"
+#include "../../include/wf_hip.h"
+
+namespace {
+
+// lane groups serviced together, per instruction kind (MI355X_MICROARCH.md §LDS)
+// returns group id of lane l (0..63) and the bank modulus
+struct Rule { int ngroups; int modulus; int (*group)(int lane); };
+int grp_half(int l) { return l >> 5; }
+int grp_b128_read(int l)
+{
+    // 4 x 16: {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63}
+    const int h = l >> 5, m = l & 31;
+    const bool first = (m < 4) || (m >= 12 && m < 16) || (m >= 20 && m < 28);
+    return h * 2 + (first ? 0 : 1);
+}
+int grp_contig16(int l) { return l >> 4; }
+int grp_contig8(int l) { return l >> 3; }
+
+Rule rule_for(int bytes, int is_write)
+{
+    if(!is_write) {
+        if(bytes == 8) return {2, 64, grp_half};          // ds_read_b64
+        return {4, 64, grp_b128_read};                    // ds_read_b128
+    }
+    if(bytes == 8) return {4, 32, grp_contig16};          // ds_write_b64
+    return {8, 32, grp_contig8};                          // ds_write_b128
+}
+
+struct ConflictStats { uint64_t instr = 0, ideal_cycles = 0, actual_cycles = 0; };
+
+// per-wave census: traces[lane] = sequence of accesses of that lane in this phase
+void census(const std::vector<std::vector<emu::Access>> &traces, ConflictStats st[2])
+{
+    const size_t n = traces[0].size();
+    for(size_t i = 0; i < n; ++i) {
+        const auto a0 = traces[0][i];
+        const Rule r = rule_for(a0.bytes, a0.is_write);
+        ConflictStats &s = st[a0.is_write ? 1 : 0];
+        s.instr++;
+        for(int g = 0; g < r.ngroups; ++g) {
+            // bank -> set of distinct dword addresses
+            std::map<int, std::vector<int>> banks;
+            for(int l = 0; l < 64; ++l) {
+                if(r.group(l) != g)
+                    continue;
+                const auto a = traces[(size_t)l][i];
+                const int dw0 = a.idx * 2; // cf index -> dword index
+                for(int d = 0; d < a.bytes / 4; ++d) {
+                    const int dw = dw0 + d;
+                    auto &v = banks[dw % r.modulus];
+                    if(std::find(v.begin(), v.end(), dw) == v.end())
+                        v.push_back(dw);
+                }
+            }
+            size_t worst = 1;
+            for(auto &kv : banks)
+                worst = std::max(worst, kv.second.size());
+            s.ideal_cycles += 1;
+            s.actual_cycles += worst;
+        }
+    }
+}
+
+template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &tab, uint32_t n_streams, uint32_t ring_cap,
+                                   const float *ring, const uint32_t *wpos, uint32_t delay, float seconds, float *tsmooth,
+                                   float *decibels, uint64_t *stats)
+{
+    using namespace wf;
+    std::vector<cfloat> tw1, tw2, tws;
+    build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
+
+    TickArgs a{};
+    a.ring = ring;
+    a.wpos = wpos;
+    a.ring_cap = ring_cap;
+    a.ring_mask = ring_cap - 1;
+    a.delay = delay;
+    a.window = tab.window.empty() ? nullptr : tab.window.data();
+    a.tw1 = reinterpret_cast<const cf *>(tw1.data());
+    a.tw2 = reinterpret_cast<const cf *>(tw2.data());
+    a.tws = reinterpret_cast<const cf *>(tws.data());
+    a.slope = tab.slope.empty() ? nullptr : tab.slope.data();
+    a.rolloff = tab.rolloff.empty() ? nullptr : tab.rolloff.data();
+    a.tsmooth = tsmooth;
+    a.decibels = decibels;
+    a.half_coef = 0.5f * (2.0f / tab.window_sum);
+    a.g = gravity_for(cfg, seconds);
+    a.g2 = 1.0f - a.g;
+    a.db_min = db_min();
+    a.n_streams = n_streams;
+    a.cap_ch = cfg.capture_channels;
+    a.out_ch = tab.output_channels;
+    a.mode = 0;
+    if(cfg.tsmoothing != WF_TSMOOTH_NONE) a.mode |= WF_MODE_TSMOOTH;
+    if(cfg.fast_peaks) a.mode |= WF_MODE_FAST_PEAKS;
+    if(cfg.stereo) a.mode |= WF_MODE_STEREO;
+    if(!tab.slope.empty()) a.mode |= WF_MODE_SLOPE;
+    if(!tab.rolloff.empty()) a.mode |= WF_MODE_ROLLOFF;
+    if(!tab.window.empty()) a.mode |= WF_MODE_WINDOW;
+
+    constexpr int T = G::T, P = G::P, M = G::M;
+    ConflictStats st[2];
+    std::vector<cf> lds((size_t)G::LDS_CF);
+    std::vector<std::vector<emu::Access>> traces((size_t)T);
+    struct Regs { cf v[P]; float mag[P]; };
+    std::vector<Regs> regs((size_t)T);
+
+    auto census_waves = [&](bool enable) {
+        if(!enable) return;
+        for(int w = 0; w < T / 64; ++w) {
+            std::vector<std::vector<emu::Access>> sub(traces.begin() + w * 64, traces.begin() + (w + 1) * 64);
+            census(sub, st);
+        }
+    };
+    auto phase = [&](bool do_census, auto &&fn) {
+        for(int t = 0; t < T; ++t) {
+            traces[(size_t)t].clear();
+            emu::g_trace = &traces[(size_t)t];
+            fn(t);
+        }
+        emu::g_trace = nullptr;
+        census_waves(do_census);
+    };
+
+    const uint32_t n_spec = n_streams * cfg.capture_channels;
+    for(uint32_t spec = 0; spec < n_spec; ++spec) {
+        const uint32_t stream = spec / cfg.capture_channels, ch = spec % cfg.capture_channels;
+        const float *x = ring + (size_t)spec * ring_cap;
+        const uint32_t start = (wpos[stream] - delay - (uint32_t)G::N) & a.ring_mask;
+        float *ts = tsmooth ? tsmooth + (size_t)spec * M : nullptr;
+        float *out = decibels + ((size_t)stream * a.out_ch + ch) * M;
+        const bool c = (spec == 0);
+        const bool aligned = (start % 4u) == 0;
+        std::fill(lds.begin(), lds.end(), cf{1e30f, 1e30f}); // poison: unwritten reads show up
+        phase(c, [&](int t) {
+            if(aligned) p1_fetch_pass1<G, true>(a, t, x, start, lds.data());
+            else p1_fetch_pass1<G, false>(a, t, x, start, lds.data());
+        });
+        phase(c, [&](int t) { p2_read<G>(t, lds.data(), regs[(size_t)t].v); });
+        phase(c, [&](int t) { p2_pass2_write<G>(a, t, lds.data(), regs[(size_t)t].v); });
+        phase(c, [&](int t) { p3_read<G>(t, lds.data(), regs[(size_t)t].v); });
+        phase(c, [&](int t) { p3_pass3_write<G>(t, lds.data(), regs[(size_t)t].v); });
+        phase(c, [&](int t) { p4_split_smooth<G>(a, t, lds.data(), ts, regs[(size_t)t].mag); });
+        phase(false, [&](int t) { p4_db_store<G>(a, t, out, regs[(size_t)t].mag); });
+    }
+    if(stats) {
+        stats[0] = st[0].instr; stats[1] = st[0].ideal_cycles; stats[2] = st[0].actual_cycles;
+        stats[3] = st[1].instr; stats[4] = st[1].ideal_cycles; stats[5] = st[1].actual_cycles;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+// Emulates wf_hip_tick for n_streams streams on host memory.  Mono mixdown is not emulated
+// (the emulator checks per-spectrum math; the cross-wave paths are covered on the GPU).
+// stats[6] = {read instr, read ideal cycles, read actual cycles, write instr, ideal, actual}
+int wfemu_tick(const wf_config *cfg, uint32_t n_streams, uint32_t ring_cap, const float *ring, const uint32_t *wpos,
+               uint32_t delay, float seconds, float *tsmooth, float *decibels, uint64_t *stats)
+{
+    wf::HostTables tab;
+    const int rc = wf::build_host_tables(*cfg, tab);
+    if(rc != 0)
+        return rc;
+    int ret = -1;
+    const bool ok = wf::dispatch_geometry(cfg->fft_size, [&](auto g) {
+        using G = decltype(g);
+        ret = run_geometry<G>(*cfg, tab, n_streams, ring_cap, ring, wpos, delay, seconds, tsmooth, decibels, stats);
+    });
+    return ok ? ret : WF_HIP_ERR_UNSUPPORTED;
+}
+
+int wfemu_lds_bytes(uint32_t fft_size)
+{
+    int r = -1;
+    wf::dispatch_geometry(fft_size, [&](auto g) { r = decltype(g)::LDS_CF * 8; });
+    return r;
+}
+
+} // extern "C"

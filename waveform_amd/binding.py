@@ -1,0 +1,277 @@
+"""ctypes binding of libwaveform_hip.so (include/wf_hip.h).  Thin by design: argument
+marshalling only, no numerics and no fallbacks."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+WINDOW = dict(none=0, hann=1, hamming=2, blackman=3, blackman_harris=4, power_of_sine=5)
+TSMOOTH = dict(none=0, exponential=1, tvexponential=2)
+INTERP = dict(point=0, lanczos=1, catrom=2)
+
+
+class WfHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"wf_hip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    """struct wf_config (include/wf_config.h)."""
+    _fields_ = [
+        ("fft_size", C.c_uint32), ("sample_rate", C.c_uint32), ("capture_channels", C.c_uint32), ("stereo", C.c_uint32),
+        ("window", C.c_int32), ("sine_exponent", C.c_int32), ("tsmoothing", C.c_int32), ("gravity", C.c_float),
+        ("fast_peaks", C.c_uint32), ("slope", C.c_float), ("rolloff_q", C.c_float), ("rolloff_rate", C.c_float),
+        ("cutoff_low", C.c_int32), ("cutoff_high", C.c_int32), ("floor_db", C.c_int32), ("ceiling_db", C.c_int32),
+        ("normalize_volume", C.c_uint32), ("volume_target", C.c_float), ("max_gain", C.c_float),
+        ("bars", C.c_uint32), ("interp_mode", C.c_int32), ("log_scale", C.c_uint32), ("mirror_freq_axis", C.c_uint32),
+        ("width", C.c_uint32), ("height", C.c_uint32), ("bar_width", C.c_int32), ("bar_gap", C.c_int32),
+        ("channel_spacing", C.c_int32), ("min_bar_height", C.c_int32), ("rounded_caps", C.c_uint32),
+    ]
+
+    @classmethod
+    def defaults(cls, **overrides) -> "Config":
+        cfg = cls()
+        lib().wf_config_defaults(C.byref(cfg))
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise AttributeError(f"wf_config has no field {k!r}")
+            setattr(cfg, k, v)
+        return cfg
+
+
+class TickParams(C.Structure):
+    _fields_ = [("seconds", C.c_float), ("delay_frames", C.c_uint32), ("input_rms", C.c_float), ("flags", C.c_uint32)]
+
+
+TICK_NO_DECIBELS = 1
+
+
+def library_path() -> Path:
+    return _HERE / "libwaveform_hip.so"
+
+
+def lib():
+    """Loads libwaveform_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = library_path()
+    if not p.exists():
+        raise FileNotFoundError(f"{p} not built: run `make -C waveform_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(str(p))
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    fp = C.POINTER(C.c_float)
+    L.wf_config_defaults.argtypes = [C.POINTER(Config)]
+    L.wf_hip_abi_version.restype = C.c_int
+    L.wf_hip_device_count.restype = C.c_int
+    L.wf_hip_last_error.restype = C.c_char_p
+    L.wf_hip_last_error.argtypes = [vp]
+    L.wf_hip_create.argtypes = [C.POINTER(Config), C.c_int, u32, u32, C.POINTER(vp)]
+    L.wf_hip_destroy.argtypes = [vp]
+    L.wf_hip_reset.argtypes = [vp, u32, u32]
+    for n in ("fft_size", "num_streams", "capture_channels", "output_channels", "display_channels", "num_bars", "ring_frames"):
+        f = getattr(L, "wf_hip_" + n)
+        f.restype = u32
+        f.argtypes = [vp]
+    L.wf_hip_push_audio.argtypes = [vp, u32, u32, fp, u32]
+    L.wf_hip_push_audio_device.argtypes = [vp, u32, u32, vp, u32]
+    L.wf_hip_push_synth.argtypes = [vp, u32, u32, u64, u32, u64, u32]
+    L.wf_hip_push_silence.argtypes = [vp, u32, u32, u32]
+    L.wf_hip_tick.argtypes = [vp, C.POINTER(TickParams)]
+    L.wf_hip_set_hidden.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
+    L.wf_hip_sync.argtypes = [vp]
+    L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_read_tsmooth.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_write_tsmooth.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
+    for n in ("decibels_device", "bars_device", "stream"):
+        f = getattr(L, "wf_hip_" + n)
+        f.restype = vp
+        f.argtypes = [vp]
+    L.wf_hip_table_window.restype = C.c_size_t
+    L.wf_hip_table_window.argtypes = [vp, C.POINTER(fp), fp]
+    for n in ("slope", "rolloff", "interp_indices"):
+        f = getattr(L, "wf_hip_table_" + n)
+        f.restype = C.c_size_t
+        f.argtypes = [vp, C.POINTER(fp)]
+    L.wf_hip_table_band_widths.restype = C.c_size_t
+    L.wf_hip_table_band_widths.argtypes = [vp, C.POINTER(C.POINTER(C.c_int))]
+    L.wf_hip_table_interp_weights.restype = C.c_size_t
+    L.wf_hip_table_interp_weights.argtypes = [vp, C.POINTER(fp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.wf_hip_gravity.restype = C.c_float
+    L.wf_hip_gravity.argtypes = [vp, C.c_float]
+    L.wf_hip_db_min.restype = C.c_float
+    L.wf_hip_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, fp]
+    L.wf_hip_kernel_name.restype = C.c_char_p
+    L.wf_hip_kernel_name.argtypes = [vp]
+    L.wf_hip_algorithmic_bytes_per_tick.restype = u64
+    L.wf_hip_algorithmic_bytes_per_tick.argtypes = [vp, u32]
+    _LIB = L
+    return L
+
+
+def device_count() -> int:
+    return int(lib().wf_hip_device_count())
+
+
+def db_min() -> float:
+    return float(lib().wf_hip_db_min())
+
+
+def _copy(ptr, n, dtype=np.float32):
+    if not ptr or n == 0:
+        return None
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class SpectrumBatch:
+    """A batch of `streams` independent sources sharing one configuration, resident on one GPU."""
+
+    def __init__(self, cfg: Config, streams: int, device: int = 0, ring_frames: int = 0):
+        self.L = lib()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.L.wf_hip_create(C.byref(cfg), device, streams, ring_frames, C.byref(h))
+        if rc != 0:
+            raise WfHipError(rc, self.L.wf_hip_last_error(None).decode())
+        self.h = h
+        self.streams = streams
+        self.fft_size = self.L.wf_hip_fft_size(h)
+        self.bins = self.fft_size // 2
+        self.capture_channels = self.L.wf_hip_capture_channels(h)
+        self.output_channels = self.L.wf_hip_output_channels(h)
+        self.display_channels = self.L.wf_hip_display_channels(h)
+        self.num_bars = self.L.wf_hip_num_bars(h)
+        self.ring_frames = self.L.wf_hip_ring_frames(h)
+
+    # -- plumbing -----------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise WfHipError(rc, self.L.wf_hip_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.wf_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- audio ----------------------------------------------------------------------
+    def push_audio(self, samples: np.ndarray, first: int = 0):
+        """samples: float32 [count, capture_channels, frames]"""
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        assert s.ndim == 3 and s.shape[1] == self.capture_channels, s.shape
+        self._ck(self.L.wf_hip_push_audio(self.h, first, s.shape[0], s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[2]))
+
+    def push_audio_device(self, dev_ptr: int, count: int, frames: int, first: int = 0):
+        self._ck(self.L.wf_hip_push_audio_device(self.h, first, count, C.c_void_p(dev_ptr), frames))
+
+    def push_synth(self, seed: int, index0: int, frames: int, first: int = 0, count: int | None = None, stream_id0: int = 0):
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_push_synth(self.h, first, count, seed, stream_id0, index0, frames))
+
+    def push_silence(self, frames: int, first: int = 0, count: int | None = None):
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_push_silence(self.h, first, count, frames))
+
+    def reset(self, first: int = 0, count: int | None = None):
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_reset(self.h, first, count))
+
+    # -- tick -------------------------------------------------------------------------
+    def tick(self, seconds: float = 1.0 / 60.0, delay_frames: int = 0, input_rms: float = 0.0, flags: int = 0):
+        p = TickParams(seconds, delay_frames, input_rms, flags)
+        self._ck(self.L.wf_hip_tick(self.h, C.byref(p)))
+
+    def sync(self):
+        self._ck(self.L.wf_hip_sync(self.h))
+
+    def time_ticks(self, ticks: int, hop: int, first_delay: int, seconds: float = 1.0 / 60.0, flags: int = 0) -> float:
+        """average fused-kernel duration in ms over `ticks` back-to-back ticks (hipEvents on the handle's stream)"""
+        p = TickParams(seconds, first_delay, 0.0, flags)
+        ms = C.c_float(0.0)
+        self._ck(self.L.wf_hip_time_ticks(self.h, C.byref(p), ticks, hop, C.byref(ms)))
+        return float(ms.value)
+
+    # -- results ------------------------------------------------------------------------
+    def decibels(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty((count, self.output_channels, self.bins), np.float32)
+        self._ck(self.L.wf_hip_read_decibels(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def bars(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty((count, self.display_channels, self.num_bars), np.float32)
+        self._ck(self.L.wf_hip_read_bars(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def tsmooth(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty((count, self.capture_channels, self.bins), np.float32)
+        self._ck(self.L.wf_hip_read_tsmooth(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_tsmooth(self, state: np.ndarray, first: int = 0):
+        s = np.ascontiguousarray(state, dtype=np.float32)
+        self._ck(self.L.wf_hip_write_tsmooth(self.h, first, s.shape[0], s.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def last_silent(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty(count, np.uint8)
+        self._ck(self.L.wf_hip_read_last_silent(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out.astype(bool)
+
+    def decibels_device_ptr(self) -> int:
+        return int(self.L.wf_hip_decibels_device(self.h) or 0)
+
+    def bars_device_ptr(self) -> int:
+        return int(self.L.wf_hip_bars_device(self.h) or 0)
+
+    def stream_ptr(self) -> int:
+        return int(self.L.wf_hip_stream(self.h) or 0)
+
+    # -- tables / measurement ---------------------------------------------------------------
+    def table_window(self):
+        p, s = C.POINTER(C.c_float)(), C.c_float(0)
+        n = self.L.wf_hip_table_window(self.h, C.byref(p), C.byref(s))
+        return _copy(p, n), float(s.value)
+
+    def table(self, name: str):
+        if name == "band_widths":
+            p = C.POINTER(C.c_int)()
+            n = self.L.wf_hip_table_band_widths(self.h, C.byref(p))
+            return _copy(p, n, np.int32)
+        if name == "interp_weights":
+            p, r, t = C.POINTER(C.c_float)(), C.c_int(0), C.c_int(0)
+            n = self.L.wf_hip_table_interp_weights(self.h, C.byref(p), C.byref(r), C.byref(t))
+            return _copy(p, n), r.value, t.value
+        p = C.POINTER(C.c_float)()
+        n = getattr(self.L, "wf_hip_table_" + name)(self.h, C.byref(p))
+        return _copy(p, n)
+
+    def gravity(self, seconds: float) -> float:
+        return float(self.L.wf_hip_gravity(self.h, seconds))
+
+    def kernel_name(self) -> str:
+        return self.L.wf_hip_kernel_name(self.h).decode()
+
+    def algorithmic_bytes_per_tick(self, flags: int = 0) -> int:
+        return int(self.L.wf_hip_algorithmic_bytes_per_tick(self.h, flags))

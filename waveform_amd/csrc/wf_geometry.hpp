@@ -1,0 +1,26 @@
+// wf_geometry.hpp -- the FFT decompositions the library ships, one per supported FFT size.
+// T threads per spectrum: one wavefront for N <= 4096, two for 8192, four for 16384; every
+// thread owns P = N/(2T) complex points (8, 16 or 32) so pass 1 fetches 8/16-byte vectors.
+#pragma once
+#include "wf_fft_core.hpp"
+
+namespace wf {
+using G1024 = Geom<1024, 64, 8, 8, 8>;
+using G2048 = Geom<2048, 64, 8, 16, 8>;
+using G4096 = Geom<4096, 64, 16, 16, 8>;
+using G8192 = Geom<8192, 128, 16, 16, 16>;
+using G16384 = Geom<16384, 256, 16, 16, 32>;
+
+// calls f(G{}) for the geometry of fft_size n; returns false for unsupported sizes
+template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)
+{
+    switch(n) {
+    case 1024: f(G1024{}); return true;
+    case 2048: f(G2048{}); return true;
+    case 4096: f(G4096{}); return true;
+    case 8192: f(G8192{}); return true;
+    case 16384: f(G16384{}); return true;
+    default: return false;
+    }
+}
+} // namespace wf

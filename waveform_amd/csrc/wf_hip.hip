@@ -1,0 +1,649 @@
+// wf_hip.hip -- implementation of the C ABI in include/wf_hip.h (host side + kernel launches).
+// gfx950 only.  There is no CPU fallback: every entry point either drives the device or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "wf_hip.h"
+#include "wf_host_tables.hpp"
+#include "wf_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct wf_hip {
+    wf_config cfg{};
+    wf::HostTables tab;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t n_streams = 0;
+    uint32_t ring_cap = 0;
+    uint32_t N = 0, M = 0;
+    uint32_t cap_ch = 1, out_ch = 1, disp_ch = 1;
+    uint32_t num_bars = 0;
+    bool all_aligned = true; // every push so far was a multiple of 4 frames
+    // device memory
+    float *d_ring = nullptr;
+    uint32_t *d_wpos = nullptr;
+    float *d_tsmooth = nullptr;
+    float *d_decibels = nullptr;
+    uint32_t *d_flags = nullptr;
+    float *d_bars = nullptr;
+    float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
+    wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
+    float *d_stage = nullptr;
+    size_t stage_floats = 0;
+    std::vector<void *> allocs;
+    std::string last_error;
+    std::string kernel_name;
+    // launch description, fixed at create
+    void (*launch)(wf_hip *, const wf::TickArgs &, bool aligned) = nullptr;
+};
+
+namespace {
+
+int fail(wf_hip *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if(h)
+        h->last_error = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define WF_HIP_TRY(h, expr)                                                                                       \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if(e_ != hipSuccess)                                                                                      \
+            return fail((h), WF_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                                \
+    } while(0)
+
+template<class T> int dev_alloc(wf_hip *h, T **out, size_t count)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T) + 256);
+    if(e != hipSuccess)
+        return fail(h, WF_HIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    h->allocs.push_back(p);
+    *out = static_cast<T *>(p);
+    return WF_HIP_OK;
+}
+
+template<class T> int upload(wf_hip *h, T **out, const std::vector<T> &v)
+{
+    *out = nullptr;
+    if(v.empty())
+        return WF_HIP_OK;
+    int rc = dev_alloc(h, out, v.size());
+    if(rc)
+        return rc;
+    WF_HIP_TRY(h, hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return WF_HIP_OK;
+}
+
+template<class G, int SPW> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
+{
+    const uint32_t n_spec = a.n_streams * a.cap_ch;
+    const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
+    const size_t lds = (size_t)SPW * G::LDS_CF * sizeof(wf::cf);
+    if(aligned)
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true>), grid, block, lds, h->stream, a);
+    else
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false>), grid, block, lds, h->stream, a);
+}
+
+template<class G, int SPW> int setup_launch(wf_hip *h)
+{
+    const int lds = (int)((size_t)SPW * G::LDS_CF * sizeof(wf::cf));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick<G, SPW>;
+    char name[96];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=%d>", G::N, G::T, G::R1, G::R2, G::R3, SPW);
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
+uint32_t next_pow2(uint32_t v)
+{
+    uint32_t p = 1;
+    while(p < v)
+        p <<= 1;
+    return p;
+}
+
+wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
+{
+    wf::TickArgs a{};
+    a.ring = h->d_ring;
+    a.wpos = h->d_wpos;
+    a.ring_cap = h->ring_cap;
+    a.ring_mask = h->ring_cap - 1;
+    a.delay = p->delay_frames;
+    a.window = h->d_window;
+    a.tw1 = h->d_tw1;
+    a.tw2 = h->d_tw2;
+    a.tws = h->d_tws;
+    a.slope = h->d_slope;
+    a.rolloff = h->d_rolloff;
+    a.tsmooth = h->d_tsmooth;
+    a.decibels = h->d_decibels;
+    a.stream_flags = h->d_flags;
+    a.bars = h->d_bars;
+    a.half_coef = 0.5f * (2.0f / h->tab.window_sum); // mag_coefficient (reference src/source_generic.cpp:110), halved: the
+                                                     // kernel produces 2X[k] from the real split
+    a.g = wf::gravity_for(h->cfg, p->seconds);
+    a.g2 = 1.0f - a.g;
+    a.db_min = wf::db_min();
+    a.silent_floor = (float)(h->cfg.floor_db - 10);
+    a.vol_comp = 0.0f;
+    a.n_streams = h->n_streams;
+    a.cap_ch = h->cap_ch;
+    a.out_ch = h->out_ch;
+    uint32_t mode = 0;
+    if(h->cfg.tsmoothing != WF_TSMOOTH_NONE) mode |= wf::WF_MODE_TSMOOTH;
+    if(h->cfg.fast_peaks) mode |= wf::WF_MODE_FAST_PEAKS;
+    if(h->cfg.stereo) mode |= wf::WF_MODE_STEREO;
+    if(h->d_slope) mode |= wf::WF_MODE_SLOPE;
+    if(h->d_rolloff) mode |= wf::WF_MODE_ROLLOFF;
+    if(h->d_window) mode |= wf::WF_MODE_WINDOW;
+    if(!h->cfg.stereo && h->cap_ch > 1) mode |= wf::WF_MODE_MONO_MIX;
+    if(h->cfg.normalize_volume) {
+        mode |= wf::WF_MODE_NORMALIZE;
+        // volume_compensation, reference src/source_generic.cpp:163
+        const float rms_db = (p->input_rms > 0.0f) ? 20.0f * std::log10(p->input_rms) : wf::db_min();
+        a.vol_comp = std::min(h->cfg.volume_target - rms_db, h->cfg.max_gain);
+    }
+    a.mode = mode;
+    return a;
+}
+
+int check_range(wf_hip *h, uint32_t first, uint32_t count)
+{
+    if(h == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if(count == 0 || first >= h->n_streams || count > h->n_streams - first)
+        return fail(h, WF_HIP_ERR_INVALID, "stream range [%u, %u+%u) outside 0..%u", first, first, count, h->n_streams);
+    return WF_HIP_OK;
+}
+
+int ensure_stage(wf_hip *h, size_t floats)
+{
+    if(h->stage_floats >= floats)
+        return WF_HIP_OK;
+    // grow: the old block stays in allocs and is released at destroy
+    float *p = nullptr;
+    int rc = dev_alloc(h, &p, floats);
+    if(rc)
+        return rc;
+    h->d_stage = p;
+    h->stage_floats = floats;
+    return WF_HIP_OK;
+}
+
+int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, uint32_t frames)
+{
+    if(frames == 0)
+        return WF_HIP_OK;
+    if(frames > h->ring_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the ring capacity %u", frames, h->ring_cap);
+    const dim3 grid((frames + 255) / 256 > 64 ? 64 : (frames + 255) / 256, count * h->cap_ch), block(256);
+    hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->cap_ch, first,
+                       d_src, frames);
+    hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
+                       frames);
+    WF_HIP_TRY(h, hipGetLastError());
+    if(frames % 4u)
+        h->all_aligned = false;
+    return WF_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int wf_hip_abi_version(void) { return WF_HIP_ABI_VERSION; }
+
+int wf_hip_device_count(void)
+{
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *wf_hip_last_error(const wf_hip *h) { return h ? h->last_error.c_str() : g_create_error.c_str(); }
+
+int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32_t ring_frames, wf_hip **out)
+{
+    if(out == nullptr)
+        return WF_HIP_ERR_INVALID;
+    *out = nullptr;
+    if(cfg == nullptr || max_streams == 0)
+        return fail(nullptr, WF_HIP_ERR_INVALID, "cfg is NULL or max_streams is 0");
+    wf::HostTables tab;
+    int rc = wf::build_host_tables(*cfg, tab);
+    if(rc == WF_HIP_ERR_UNSUPPORTED)
+        return fail(nullptr, rc, "fft_size %u: only powers of two in 1024..16384 are implemented", cfg->fft_size);
+    if(rc)
+        return fail(nullptr, rc, "invalid configuration");
+    const int ndev = wf_hip_device_count();
+    if(ndev <= 0)
+        return fail(nullptr, WF_HIP_ERR_NO_DEVICE, "no HIP device available");
+    if(device < 0 || device >= ndev)
+        return fail(nullptr, WF_HIP_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+
+    wf_hip *h = new(std::nothrow) wf_hip();
+    if(h == nullptr)
+        return fail(nullptr, WF_HIP_ERR_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->tab = std::move(tab);
+    h->device = device;
+    h->n_streams = max_streams;
+    h->N = cfg->fft_size;
+    h->M = cfg->fft_size / 2;
+    h->cap_ch = cfg->capture_channels;
+    h->out_ch = h->tab.output_channels;
+    h->disp_ch = h->tab.display_channels;
+    h->num_bars = (uint32_t)h->tab.num_bars;
+    h->ring_cap = next_pow2(ring_frames ? std::max(ring_frames, h->N) : 2 * h->N);
+
+    auto bail = [&](int code) {
+        g_create_error = h->last_error;
+        wf_hip_destroy(h);
+        return code;
+    };
+#define WF_CREATE_TRY(expr)                  \
+    do {                                     \
+        int rc_ = (expr);                    \
+        if(rc_ != WF_HIP_OK)                 \
+            return bail(rc_);                \
+    } while(0)
+#define WF_CREATE_HIP(expr)                                                                              \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if(e_ != hipSuccess) {                                                                           \
+            fail(h, WF_HIP_ERR_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e_));                  \
+            return bail(WF_HIP_ERR_RUNTIME);                                                             \
+        }                                                                                                \
+    } while(0)
+
+    WF_CREATE_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop{};
+    WF_CREATE_HIP(hipGetDeviceProperties(&prop, device));
+    if(std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(h, WF_HIP_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
+        return bail(WF_HIP_ERR_NO_DEVICE);
+    }
+    WF_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    WF_CREATE_HIP(hipEventCreate(&h->ev0));
+    WF_CREATE_HIP(hipEventCreate(&h->ev1));
+
+    const size_t n_spec = (size_t)h->n_streams * h->cap_ch;
+    WF_CREATE_TRY(dev_alloc(h, &h->d_ring, n_spec * h->ring_cap));
+    WF_CREATE_TRY(dev_alloc(h, &h->d_wpos, (size_t)h->n_streams));
+    WF_CREATE_TRY(dev_alloc(h, &h->d_tsmooth, n_spec * h->M));
+    WF_CREATE_TRY(dev_alloc(h, &h->d_decibels, (size_t)h->n_streams * h->out_ch * h->M));
+    WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->n_streams));
+    if(h->num_bars)
+        WF_CREATE_TRY(dev_alloc(h, &h->d_bars, (size_t)h->n_streams * h->disp_ch * h->num_bars));
+
+    WF_CREATE_TRY(upload(h, &h->d_window, h->tab.window));
+    WF_CREATE_TRY(upload(h, &h->d_slope, h->tab.slope));
+    WF_CREATE_TRY(upload(h, &h->d_rolloff, h->tab.rolloff));
+
+    // FFT plan: twiddle tables for the geometry of this fft_size + the kernel instantiation
+    int setup_rc = WF_HIP_ERR_UNSUPPORTED;
+    std::vector<wf::cfloat> tw1, tw2, tws;
+    const bool mono_mix = !cfg->stereo && cfg->capture_channels > 1;
+    wf::dispatch_geometry(h->N, [&](auto g) {
+        using G = decltype(g);
+        wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
+        if constexpr(G::T >= 256)
+            setup_rc = mono_mix ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
+        else
+            setup_rc = setup_launch<G, 2>(h);
+    });
+    WF_CREATE_TRY(setup_rc);
+    static_assert(sizeof(wf::cfloat) == sizeof(wf::cf), "twiddle layout");
+    {
+        std::vector<wf::cf> t1(tw1.size()), t2(tw2.size()), t3(tws.size());
+        std::memcpy(t1.data(), tw1.data(), tw1.size() * sizeof(wf::cf));
+        std::memcpy(t2.data(), tw2.data(), tw2.size() * sizeof(wf::cf));
+        std::memcpy(t3.data(), tws.data(), tws.size() * sizeof(wf::cf));
+        WF_CREATE_TRY(upload(h, &h->d_tw1, t1));
+        WF_CREATE_TRY(upload(h, &h->d_tw2, t2));
+        WF_CREATE_TRY(upload(h, &h->d_tws, t3));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
+    }
+    WF_CREATE_TRY(wf_hip_reset(h, 0, h->n_streams));
+    WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+#undef WF_CREATE_TRY
+#undef WF_CREATE_HIP
+    *out = h;
+    return WF_HIP_OK;
+}
+
+void wf_hip_destroy(wf_hip *h)
+{
+    if(h == nullptr)
+        return;
+    (void)hipSetDevice(h->device);
+    if(h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    for(void *p : h->allocs)
+        (void)hipFree(p);
+    if(h->ev0) (void)hipEventDestroy(h->ev0);
+    if(h->ev1) (void)hipEventDestroy(h->ev1);
+    if(h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    const size_t spec0 = (size_t)first * h->cap_ch, nspec = (size_t)count * h->cap_ch;
+    // m_tsmooth_buf = 0, rings = zeros with N samples "written", m_decibels = DB_MIN, m_last_silent = false
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_tsmooth + spec0 * h->M, 0, nspec * h->M * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_cap, 0, nspec * h->ring_cap * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+    const size_t ndb = (size_t)count * h->out_ch * h->M;
+    hipLaunchKernelGGL(wf::fill_f32_kernel, dim3((unsigned)std::min<size_t>((ndb + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                       h->d_decibels + (size_t)first * h->out_ch * h->M, ndb, wf::db_min());
+    hipLaunchKernelGGL(wf::fill_u32_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos + first, (size_t)count,
+                       h->N);
+    if(h->d_bars)
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_bars + (size_t)first * h->disp_ch * h->num_bars, 0,
+                                     (size_t)count * h->disp_ch * h->num_bars * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipGetLastError());
+    return WF_HIP_OK;
+}
+
+uint32_t wf_hip_fft_size(const wf_hip *h) { return h ? h->N : 0; }
+uint32_t wf_hip_num_streams(const wf_hip *h) { return h ? h->n_streams : 0; }
+uint32_t wf_hip_capture_channels(const wf_hip *h) { return h ? h->cap_ch : 0; }
+uint32_t wf_hip_output_channels(const wf_hip *h) { return h ? h->out_ch : 0; }
+uint32_t wf_hip_display_channels(const wf_hip *h) { return h ? h->disp_ch : 0; }
+uint32_t wf_hip_num_bars(const wf_hip *h) { return h ? h->num_bars : 0; }
+uint32_t wf_hip_ring_frames(const wf_hip *h) { return h ? h->ring_cap : 0; }
+
+int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(samples == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "samples is NULL");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)count * h->cap_ch * frames;
+    // the staging block may still feed a previous push: the copy below is ordered after it on the same stream
+    rc = ensure_stage(h, n);
+    if(rc)
+        return rc;
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_stage, samples, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = push_common(h, first, count, h->d_stage, frames);
+    if(rc)
+        return rc;
+    // `samples` is borrowed only for the duration of the call (pageable memory: the copy has been staged by the
+    // runtime when hipMemcpyAsync returns; pinned memory: wait for it)
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WF_HIP_OK;
+}
+
+int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const float *d_samples, uint32_t frames)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(d_samples == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "d_samples is NULL");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    return push_common(h, first, count, d_samples, frames);
+}
+
+int wf_hip_push_silence(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    return push_common(h, first, count, nullptr, frames);
+}
+
+int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, uint32_t stream_id0, uint64_t index0,
+                      uint32_t frames)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(frames == 0)
+        return WF_HIP_OK;
+    if(frames > h->ring_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the ring capacity %u", frames, h->ring_cap);
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    const uint32_t gx = std::min<uint32_t>((frames + 255) / 256, 256);
+    hipLaunchKernelGGL(wf::ring_synth_kernel, dim3(gx, count * h->cap_ch), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,
+                       h->ring_cap, h->cap_ch, first, seed, stream_id0, index0, frames);
+    hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
+                       frames);
+    WF_HIP_TRY(h, hipGetLastError());
+    if(frames % 4u)
+        h->all_aligned = false;
+    return WF_HIP_OK;
+}
+
+int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
+{
+    if(h == nullptr || p == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if((uint64_t)p->delay_frames + h->N > h->ring_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u + fft_size %u exceeds the ring capacity %u", p->delay_frames, h->N,
+                    h->ring_cap);
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    const wf::TickArgs a = make_args(h, p);
+    const bool aligned = h->all_aligned && (p->delay_frames % 4u) == 0;
+    h->launch(h, a, aligned);
+    WF_HIP_TRY(h, hipGetLastError());
+    return WF_HIP_OK;
+}
+
+int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *mask)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    (void)mask;
+    return fail(h, WF_HIP_ERR_UNSUPPORTED, "hidden/timeout streams are not implemented yet");
+}
+
+int wf_hip_sync(wf_hip *h)
+{
+    if(h == nullptr)
+        return WF_HIP_ERR_INVALID;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WF_HIP_OK;
+}
+
+static int read_back(wf_hip *h, const void *d, void *out, size_t bytes)
+{
+    if(out == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream));
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WF_HIP_OK;
+}
+
+int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    const size_t per = (size_t)h->out_ch * h->M;
+    return read_back(h, h->d_decibels + first * per, out, count * per * sizeof(float));
+}
+
+int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_bars == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
+    const size_t per = (size_t)h->disp_ch * h->num_bars;
+    return read_back(h, h->d_bars + first * per, out, count * per * sizeof(float));
+}
+
+int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    const size_t per = (size_t)h->cap_ch * h->M;
+    return read_back(h, h->d_tsmooth + first * per, out, count * per * sizeof(float));
+}
+
+int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(in == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "input pointer is NULL");
+    const size_t per = (size_t)h->cap_ch * h->M;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_tsmooth + first * per, in, count * per * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WF_HIP_OK;
+}
+
+int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    std::vector<uint32_t> tmp(count);
+    rc = read_back(h, h->d_flags + first, tmp.data(), count * sizeof(uint32_t));
+    if(rc)
+        return rc;
+    for(uint32_t i = 0; i < count; ++i)
+        out[i] = (tmp[i] & wf::WF_STREAM_LAST_SILENT) ? 1 : 0;
+    return WF_HIP_OK;
+}
+
+float *wf_hip_decibels_device(wf_hip *h) { return h ? h->d_decibels : nullptr; }
+float *wf_hip_bars_device(wf_hip *h) { return h ? h->d_bars : nullptr; }
+void *wf_hip_stream(wf_hip *h) { return h ? (void *)h->stream : nullptr; }
+
+size_t wf_hip_table_window(const wf_hip *h, const float **out, float *window_sum)
+{
+    if(window_sum) *window_sum = h->tab.window_sum;
+    if(out) *out = h->tab.window.empty() ? nullptr : h->tab.window.data();
+    return h->tab.window.size();
+}
+size_t wf_hip_table_slope(const wf_hip *h, const float **out)
+{
+    if(out) *out = h->tab.slope.empty() ? nullptr : h->tab.slope.data();
+    return h->tab.slope.size();
+}
+size_t wf_hip_table_rolloff(const wf_hip *h, const float **out)
+{
+    if(out) *out = h->tab.rolloff.empty() ? nullptr : h->tab.rolloff.data();
+    return h->tab.rolloff.size();
+}
+size_t wf_hip_table_interp_indices(const wf_hip *h, const float **out)
+{
+    if(out) *out = h->tab.interp_indices.empty() ? nullptr : h->tab.interp_indices.data();
+    return h->tab.interp_indices.size();
+}
+size_t wf_hip_table_band_widths(const wf_hip *h, const int **out)
+{
+    if(out) *out = h->tab.band_widths.empty() ? nullptr : h->tab.band_widths.data();
+    return h->tab.band_widths.size();
+}
+size_t wf_hip_table_interp_weights(const wf_hip *h, const float **out, int *radius, int *taps)
+{
+    if(radius) *radius = h->tab.interp_radius;
+    if(taps) *taps = h->tab.interp_taps;
+    if(out) *out = h->tab.interp_weights.empty() ? nullptr : h->tab.interp_weights.data();
+    return h->tab.interp_weights.size();
+}
+float wf_hip_gravity(const wf_hip *h, float seconds) { return wf::gravity_for(h->cfg, seconds); }
+float wf_hip_db_min(void) { return wf::db_min(); }
+
+int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, uint32_t hop, float *avg_kernel_ms)
+{
+    if(h == nullptr || p == nullptr || ticks == 0 || avg_kernel_ms == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if((uint64_t)hop * (ticks - 1) > p->delay_frames)
+        return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u too small for %u ticks of hop %u", p->delay_frames, ticks, hop);
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    // events recorded on the handle's own stream, around the fused kernels only
+    WF_HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    wf_hip_tick_params q = *p;
+    for(uint32_t i = 0; i < ticks; ++i) {
+        q.delay_frames = p->delay_frames - i * hop;
+        int rc = wf_hip_tick(h, &q);
+        if(rc)
+            return rc;
+    }
+    WF_HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    WF_HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float ms = 0.0f;
+    WF_HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_kernel_ms = ms / (float)ticks;
+    return WF_HIP_OK;
+}
+
+const char *wf_hip_kernel_name(const wf_hip *h) { return h ? h->kernel_name.c_str() : ""; }
+
+uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags)
+{
+    if(h == nullptr)
+        return 0;
+    // read the N-sample window of every captured channel, read + write the smoothing
+    // state (M floats each way) when temporal smoothing is on, write M dB values per displayed/output channel
+    // (stereo: both channels; mono mixdown: one), plus the bar heights when the configuration has bars.
+    const uint64_t n_spec = (uint64_t)h->n_streams * h->cap_ch;
+    uint64_t bytes = n_spec * 4ull * h->N;
+    if(h->cfg.tsmoothing != WF_TSMOOTH_NONE)
+        bytes += n_spec * 8ull * h->M;
+    const bool mono_mix = !h->cfg.stereo && h->cap_ch > 1;
+    const uint64_t out_rows = (uint64_t)h->n_streams * (mono_mix ? 1u : h->out_ch);
+    if(!(flags & WF_HIP_TICK_NO_DECIBELS))
+        bytes += out_rows * 4ull * h->M;
+    bytes += (uint64_t)h->n_streams * h->disp_ch * h->num_bars * 4ull;
+    return bytes;
+}
+
+} // extern "C"

@@ -1,0 +1,325 @@
+// wf_host_tables.cpp -- see wf_host_tables.hpp.  Host-only (compiled by g++ with
+// -ffp-contract=off so float expressions round exactly where the reference's do).
+#include "wf_host_tables.hpp"
+#include "wf_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <numbers>
+
+namespace wf {
+
+namespace {
+
+// src/math_funcs.hpp:25-29
+inline float log_interp(float a, float b, float t) { return a * std::pow(b / a, t); }
+// src/math_funcs.hpp:37-44
+inline float sinc(float x)
+{
+    if(x == 0.0f)
+        return 1.0f;
+    const float tmp = std::numbers::pi_v<float> * x;
+    return std::sin(tmp) / tmp;
+}
+// src/math_funcs.hpp:46-52
+inline float lanczos(float x, float w)
+{
+    if(std::abs(x) < w)
+        return sinc(x) * sinc(x / w);
+    return 0.0f;
+}
+
+bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+// window table + m_window_sum, src/source.cpp:1190-1234
+void build_window(const wf_config &cfg, HostTables &t)
+{
+    const size_t n = cfg.fft_size;
+    if(cfg.window == WF_WINDOW_NONE) {
+        t.window.clear();
+        t.window_sum = (float)n;
+        return;
+    }
+    t.window.resize(n);
+    constexpr float pi = std::numbers::pi_v<float>;
+    const size_t N = n - 1;
+    constexpr float pi2 = 2 * pi;
+    constexpr float pi4 = 4 * pi;
+    constexpr float pi6 = 6 * pi;
+    float *w = t.window.data();
+    switch(cfg.window) {
+    case WF_WINDOW_HAMMING:
+        for(size_t i = 0; i < n; ++i)
+            w[i] = 0.53836f - (0.46164f * std::cos((pi2 * i) / N));
+        break;
+    case WF_WINDOW_BLACKMAN:
+        for(size_t i = 0; i < n; ++i)
+            w[i] = 0.42f - (0.5f * std::cos((pi2 * i) / N)) + (0.08f * std::cos((pi4 * i) / N));
+        break;
+    case WF_WINDOW_BLACKMAN_HARRIS:
+        for(size_t i = 0; i < n; ++i)
+            w[i] = 0.35875f - (0.48829f * std::cos((pi2 * i) / N)) + (0.14128f * std::cos((pi4 * i) / N)) -
+                   (0.01168f * std::cos((pi6 * i) / N));
+        break;
+    case WF_WINDOW_POWER_OF_SINE:
+        for(size_t i = 0; i < n; ++i)
+            w[i] = std::pow(std::sin((pi * i) / N), (float)cfg.sine_exponent);
+        break;
+    case WF_WINDOW_HANN:
+    default:
+        for(size_t i = 0; i < n; ++i)
+            w[i] = 0.5f * (1 - std::cos((pi2 * i) / N));
+        break;
+    }
+    float sum = 0.0f;
+    for(size_t i = 0; i < n; ++i)
+        sum += w[i];
+    t.window_sum = sum;
+}
+
+// slope table, src/source.cpp:1282-1290
+void build_slope(const wf_config &cfg, HostTables &t)
+{
+    t.slope.clear();
+    if(!(cfg.slope > 0.0f))
+        return;
+    const size_t num_mods = cfg.fft_size / 2;
+    const float maxmod = (float)(num_mods - 1);
+    t.slope.resize(num_mods);
+    for(size_t i = 0; i < num_mods; ++i)
+        t.slope[i] = std::log10(log_interp(10.0f, 10000.0f, ((float)i * cfg.slope) / maxmod));
+}
+
+// init_rolloff, src/source.cpp:898-918
+void build_rolloff(const wf_config &cfg, HostTables &t)
+{
+    t.rolloff.clear();
+    if(!((cfg.rolloff_q > 0.0f) && (cfg.rolloff_rate > 0.0f)))
+        return;
+    const size_t sz = cfg.fft_size / 2;
+    const float sr = (float)cfg.sample_rate;
+    const float coeff = sr / (float)cfg.fft_size;
+    const float ratio = std::exp2(cfg.rolloff_q);
+    const float freq_low = (float)cfg.cutoff_low * ratio;
+    const float freq_high = (float)cfg.cutoff_high / ratio;
+    t.rolloff.resize(sz);
+    t.rolloff[0] = 0.0f;
+    for(size_t i = 1u; i < sz; ++i) {
+        const float freq = i * coeff;
+        const float ratio_low = freq_low / freq;
+        const float ratio_high = freq / freq_high;
+        const float low_attenuation = (ratio_low > 1.0f) ? (cfg.rolloff_rate * std::log2(ratio_low)) : 0.0f;
+        const float high_attenuation = (ratio_high > 1.0f) ? (cfg.rolloff_rate * std::log2(ratio_high)) : 0.0f;
+        t.rolloff[i] = low_attenuation + high_attenuation;
+    }
+}
+
+// make_lanczos_kernel, src/filter.hpp:106-131 (radius 4 -> 8 taps per sample)
+void build_lanczos(const std::vector<float> &indices, HostTables &t)
+{
+    const intmax_t radius = 4;
+    const intmax_t size = (intmax_t)indices.size();
+    t.interp_radius = (int)radius;
+    t.interp_taps = (int)(radius * 2);
+    t.interp_weights.assign((size_t)(size * radius * 2), 0.0f);
+    const float fradius = (float)radius;
+    for(intmax_t i = 0; i < size; ++i) {
+        const float x = indices[(size_t)i];
+        const intmax_t ix = (intmax_t)x;
+        const intmax_t start = ix - radius + 1;
+        const intmax_t stop = ix + radius;
+        const intmax_t base = i * radius * 2;
+        for(intmax_t j = start; j <= stop; ++j)
+            t.interp_weights[(size_t)(base + (j - start))] = lanczos(x - j, fradius);
+    }
+}
+
+// make_catrom_kernel, src/filter.hpp:67-104 (tension 0.5 -> 4 taps per sample)
+void build_catrom(const std::vector<float> &indices, HostTables &t)
+{
+    const float tt = 0.5f;
+    const float matrix[4][4] = {{0, -tt, 2 * tt, -tt}, {1, 0, tt - 3, 2 - tt}, {0, tt, 3 - (2 * tt), tt - 2}, {0, 0, -tt, tt}};
+    const intmax_t size = (intmax_t)indices.size();
+    t.interp_radius = 2;
+    t.interp_taps = 4;
+    t.interp_weights.assign((size_t)(size * 4), 0.0f);
+    for(intmax_t i = 0; i < size; ++i) {
+        const float u = indices[(size_t)i] - std::floor(indices[(size_t)i]);
+        const float row[4] = {1, u, u * u, u * u * u};
+        for(intmax_t j = 0; j < 4; ++j) {
+            float sum = 0;
+            for(intmax_t k = 0; k < 4; ++k)
+                sum += row[k] * matrix[j][k];
+            t.interp_weights[(size_t)((i * 4) + j)] = sum;
+        }
+    }
+}
+
+// bar layout: update() :1267-1276, init_interp :837-896, render_bars geometry :1476-1494
+void build_bars(const wf_config &cfg, HostTables &t)
+{
+    t.num_bars = 0;
+    t.interp_indices.clear();
+    t.band_widths.clear();
+    t.interp_weights.clear();
+    t.interp_radius = t.interp_taps = 0;
+    if(!cfg.bars)
+        return;
+    const int bar_stride = cfg.bar_width + cfg.bar_gap;
+    int num_bars = (int)(cfg.width / (unsigned int)bar_stride);
+    if(((int)cfg.width - (num_bars * bar_stride)) >= cfg.bar_width)
+        ++num_bars;
+    t.num_bars = num_bars;
+    const unsigned int sz = (unsigned int)(num_bars + 1);
+
+    const size_t fft_size = cfg.fft_size;
+    const size_t maxbin = (fft_size / 2) - 1;
+    const float sr = (float)cfg.sample_rate;
+    const float lowbin = std::clamp((float)cfg.cutoff_low * fft_size / sr, 1.0f, (float)maxbin);
+    const float highbin = std::clamp((float)cfg.cutoff_high * fft_size / sr, 1.0f, (float)maxbin);
+
+    std::vector<float> idx(sz);
+    if(cfg.log_scale) {
+        for(unsigned int i = 0u; i < sz; ++i)
+            idx[i] = std::clamp(log_interp(lowbin, highbin, (cfg.mirror_freq_axis ? i * 2.0f : (float)i) / (float)(sz - 1)), lowbin, highbin);
+    } else {
+        for(unsigned int i = 0u; i < sz; ++i)
+            idx[i] = std::clamp(std::lerp(lowbin, highbin, (cfg.mirror_freq_axis ? i * 2.0f : (float)i) / (float)(sz - 1)), lowbin, highbin);
+    }
+    t.band_widths.resize((size_t)num_bars);
+    for(int i = 0; i < num_bars; ++i)
+        t.band_widths[(size_t)i] = std::max((int)(idx[(size_t)i + 1] - idx[(size_t)i]), 1);
+
+    if(cfg.interp_mode != WF_INTERP_POINT) {
+        std::vector<float> samples;
+        for(int i = 0; i < num_bars; ++i) {
+            const int count = t.band_widths[(size_t)i];
+            for(int j = 0; j < count; ++j)
+                samples.push_back(idx[(size_t)i] + j);
+        }
+        t.interp_indices = std::move(samples);
+        if(cfg.interp_mode == WF_INTERP_LANCZOS)
+            build_lanczos(t.interp_indices, t);
+        else
+            build_catrom(t.interp_indices, t);
+    } else {
+        t.interp_indices = std::move(idx);
+    }
+
+    // render_bars geometry
+    const float center = (float)cfg.height / 2;
+    const float bottom = (float)cfg.height;
+    const float cpos = cfg.stereo ? center : bottom;
+    const float cap_radius = (float)cfg.bar_width / 2.0f;
+    const float channel_offset = cfg.channel_spacing * 0.5f;
+    float border_top = cfg.rounded_caps ? cap_radius : 0.0f;
+    float border_bottom = (cfg.rounded_caps && (!cfg.stereo || (cfg.channel_spacing > 0))) ? cpos - cap_radius : cpos;
+    if(cfg.channel_spacing > 0)
+        border_bottom -= channel_offset;
+    if(cfg.min_bar_height > 0)
+        border_bottom -= cfg.min_bar_height;
+    border_bottom = std::clamp(border_bottom, border_top, cpos);
+    t.border_top = border_top;
+    t.border_bottom = border_bottom;
+    t.cpos = cpos;
+}
+
+} // namespace
+
+float db_min()
+{
+    // const float WAVSource::DB_MIN = 20.0f * std::log10(std::numeric_limits<float>::min()); (src/source.cpp:43)
+    static const float v = 20.0f * std::log10(std::numeric_limits<float>::min());
+    return v;
+}
+
+float gravity_for(const wf_config &cfg, float seconds)
+{
+    constexpr float denom = 0.03868924705242879469662125316986f;
+    constexpr float hi = denom * 5.0f;
+    constexpr float lo = 0.0f;
+    if((cfg.tsmoothing == WF_TSMOOTH_NONE) || (cfg.gravity <= 0.0f))
+        return 0.0f;
+    return (cfg.tsmoothing == WF_TSMOOTH_TVEXPONENTIAL) ? std::exp(-seconds / std::lerp(lo, hi, cfg.gravity)) : cfg.gravity;
+}
+
+int build_host_tables(const wf_config &cfg, HostTables &out)
+{
+    if(!is_pow2(cfg.fft_size) || cfg.fft_size < 1024 || cfg.fft_size > 16384)
+        return WF_HIP_ERR_UNSUPPORTED;
+    if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0)
+        return WF_HIP_ERR_INVALID;
+    if(cfg.bars && ((cfg.bar_width + cfg.bar_gap) <= 0 || cfg.width == 0))
+        return WF_HIP_ERR_INVALID;
+    build_window(cfg, out);
+    build_slope(cfg, out);
+    build_rolloff(cfg, out);
+    out.output_channels = ((cfg.capture_channels > 1) || cfg.stereo) ? 2u : 1u; // src/source.cpp:1171
+    out.display_channels = cfg.stereo ? 2u : 1u;
+    build_bars(cfg, out);
+    return WF_HIP_OK;
+}
+
+void build_twiddles(int M, int R1, int R2, int R3, std::vector<cfloat> &tw1, std::vector<cfloat> &tw2, std::vector<cfloat> &tws)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    const int M1 = M / R1;
+    tw1.resize((size_t)M);
+    for(int k1 = 0; k1 < R1; ++k1)
+        for(int np = 0; np < M1; ++np) {
+            const double a = -two_pi * (double)(((int64_t)np * k1) % M) / (double)M;
+            tw1[(size_t)(k1 * M1 + np)] = {(float)std::cos(a), (float)std::sin(a)};
+        }
+    const int M2 = R2 * R3;
+    tw2.resize((size_t)M2);
+    for(int k2 = 0; k2 < R2; ++k2)
+        for(int n3 = 0; n3 < R3; ++n3) {
+            const double a = -two_pi * (double)((n3 * k2) % M2) / (double)M2;
+            tw2[(size_t)(k2 * R3 + n3)] = {(float)std::cos(a), (float)std::sin(a)};
+        }
+    tws.resize((size_t)M);
+    for(int k = 0; k < M; ++k) {
+        const double a = -two_pi * (double)k / (double)(2 * M);
+        tws[(size_t)k] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+}
+
+} // namespace wf
+
+extern "C" void wf_config_defaults(wf_config *cfg)
+{
+    // get_defaults, src/source.cpp:119-174
+    *cfg = wf_config{};
+    cfg->fft_size = 4096;
+    cfg->sample_rate = 48000;
+    cfg->capture_channels = 2;
+    cfg->stereo = 0;               // channel_mode "mono"
+    cfg->window = WF_WINDOW_HANN;
+    cfg->sine_exponent = 2;
+    cfg->tsmoothing = WF_TSMOOTH_EXPONENTIAL;
+    cfg->gravity = 0.65f;
+    cfg->fast_peaks = 0;
+    cfg->slope = 0.0f;
+    cfg->rolloff_q = 0.0f;
+    cfg->rolloff_rate = 0.0f;
+    cfg->cutoff_low = 30;
+    cfg->cutoff_high = 17500;
+    cfg->floor_db = -65;
+    cfg->ceiling_db = 0;
+    cfg->normalize_volume = 0;
+    cfg->volume_target = -8.0f;
+    cfg->max_gain = 30.0f;
+    cfg->bars = 0;                 // display_mode "curve"
+    cfg->interp_mode = WF_INTERP_CATROM;
+    cfg->log_scale = 1;
+    cfg->mirror_freq_axis = 0;
+    cfg->width = 800;
+    cfg->height = 225;
+    cfg->bar_width = 24;
+    cfg->bar_gap = 6;
+    cfg->channel_spacing = 0;
+    cfg->min_bar_height = 0;
+    cfg->rounded_caps = 0;
+}

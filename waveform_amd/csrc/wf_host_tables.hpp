@@ -1,0 +1,47 @@
+// wf_host_tables.hpp -- host-side, per-configuration precompute for the spectrum path.
+//
+// Everything WAVSource::update() derives once per settings change and the hot loop then
+// only reads (reference src/source.cpp:1169-1290, init_interp :837-896, init_rolloff
+// :898-918, get_gravity src/source.hpp:301-312).  Computed on the host in float with the
+// reference's expression order so the tables are bit-identical to the reference's, then
+// uploaded once; the FFT twiddles are computed in double and rounded once, as FFTW does
+// for its single-precision build (deps/fftw-3.3.11/kernel/trig.c:48-80).
+#pragma once
+#include "wf_config.h"
+#include <cstdint>
+#include <vector>
+
+namespace wf {
+
+struct HostTables {
+    // spectrum
+    std::vector<float> window;   // [N], empty when FFTWindow::NONE
+    float window_sum = 1.0f;     // m_window_sum
+    std::vector<float> slope;    // [M], empty when m_slope <= 0
+    std::vector<float> rolloff;  // [M], empty unless rolloff_q > 0 && rolloff_rate > 0
+    uint32_t output_channels = 1; // m_output_channels
+    uint32_t display_channels = 1; // m_stereo ? 2 : 1
+    // bars
+    int num_bars = 0;                    // m_num_bars
+    std::vector<float> interp_indices;   // m_interp_indices after init_interp()
+    std::vector<int> band_widths;        // m_band_widths
+    std::vector<float> interp_weights;   // m_interp_kernel.weights (Lanczos: 8/sample, Catmull-Rom: 4/sample)
+    int interp_radius = 0;               // m_interp_kernel.radius
+    int interp_taps = 0;                 // m_interp_kernel.size
+    float border_top = 0.0f, border_bottom = 0.0f, cpos = 0.0f; // render_bars geometry (:1480-1494)
+};
+
+// returns 0 on success, a negative wf_hip error code otherwise
+int build_host_tables(const wf_config &cfg, HostTables &out);
+
+// get_gravity(seconds), src/source.hpp:301-312
+float gravity_for(const wf_config &cfg, float seconds);
+// DB_MIN, src/source.cpp:43
+float db_min();
+
+// FFT twiddle tables for the (R1, R2, R3) decomposition of the M-point complex FFT
+struct cfloat { float re, im; };
+void build_twiddles(int M, int R1, int R2, int R3, std::vector<cfloat> &tw1, std::vector<cfloat> &tw2,
+                    std::vector<cfloat> &tws);
+
+} // namespace wf

@@ -1,0 +1,347 @@
+// wf_tick_phases.hpp -- thread-level phases of the fused spectrum tick.
+//
+// One spectrum (= one channel of one stream, one call of the per-channel loop at
+// reference src/source_generic.cpp:53-136) is processed by T threads in phases; a
+// phase boundary is a point where threads exchange data through LDS:
+//
+//   P1  fetch the latest N samples of the channel ring (reference :55-59), multiply by
+//       the window (:97-103), radix-R1 butterflies, twiddle            -> write ex1
+//   P2  read ex1, radix-R2 butterflies, twiddle                         -> write ex2
+//   P3  read ex2, radix-R3 butterflies                                  -> write ex3 (Z, natural order)
+//   P4  read Z[k], Z[M-k]; real split; |X|*2/sum(w) (:110-119); slope (:121-122);
+//       temporal smoothing incl. fast peaks (:124-132); dBFS (:144-159, src/source.hpp:293-299);
+//       volume normalisation (:161-167); roll-off (:169-179)            -> HBM
+//
+// Each P*_read / P*_write split below marks where a block barrier is needed when
+// T > 64 (several wavefronts share the spectrum); with T == 64 program order inside
+// the wavefront is enough.
+#pragma once
+#include "wf_fft_core.hpp"
+
+namespace wf {
+
+enum : uint32_t {
+    WF_MODE_TSMOOTH = 1u << 0,      // m_tsmoothing != NONE
+    WF_MODE_FAST_PEAKS = 1u << 1,   // m_fast_peaks
+    WF_MODE_STEREO = 1u << 2,       // m_stereo
+    WF_MODE_NORMALIZE = 1u << 3,    // m_normalize_volume
+    WF_MODE_ROLLOFF = 1u << 4,      // m_rolloff_q > 0 && m_rolloff_rate > 0
+    WF_MODE_SLOPE = 1u << 5,        // m_slope > 0
+    WF_MODE_WINDOW = 1u << 6,       // m_window_func != NONE
+    WF_MODE_MONO_MIX = 1u << 7,     // !m_stereo && m_capture_channels > 1
+};
+
+// per-stream state bits kept in HBM between ticks
+enum : uint32_t {
+    WF_STREAM_LAST_SILENT = 1u << 0, // m_last_silent
+    WF_STREAM_HIDDEN = 1u << 1,      // !m_show or capture timed out (host sets it)
+};
+
+struct TickArgs {
+    // audio rings: one per (stream, captured channel), ring_cap samples each (power of two)
+    const float *ring;
+    const uint32_t *wpos;      // [n_streams] samples written so far, modulo 2^32
+    uint32_t ring_mask;        // ring_cap - 1
+    uint32_t ring_cap;
+    uint32_t delay;            // frames between the end of the window and wpos (A/V sync, reference :50-51)
+    // per-configuration tables (read-only, shared by every stream)
+    const float *window;       // [N]
+    const cf *tw1;             // [R1][M/R1]   W_M^(n' k1)
+    const cf *tw2;             // [R2][R3]     W_(R2 R3)^(n3 k2)
+    const cf *tws;             // [M]          W_N^k
+    const float *slope;        // [M]
+    const float *rolloff;      // [M]
+    // per-spectrum state and outputs
+    float *tsmooth;            // [n_streams * cap_ch][M]   m_tsmooth_buf
+    float *decibels;           // [n_streams][out_ch][M]    m_decibels
+    uint32_t *stream_flags;    // [n_streams]
+    // scalars
+    float half_coef;           // 0.5f * (2.0f / m_window_sum)
+    float g, g2;               // get_gravity(seconds), 1 - g
+    float vol_comp;            // min(m_volume_target - dbfs(m_input_rms), m_max_gain)
+    float db_min;              // DB_MIN
+    float silent_floor;        // (float)(m_floor - 10)
+    uint32_t n_streams;
+    uint32_t cap_ch;           // m_capture_channels (1 or 2)
+    uint32_t out_ch;           // m_output_channels
+    uint32_t mode;
+    // bars (optional)
+    float *bars;               // [n_streams][disp_ch][num_bars] or nullptr
+};
+
+// ---- small helpers ------------------------------------------------------------------------
+WF_DEV f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+WF_DEV f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
+WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+
+// All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
+// WF_LDS_TRACE is defined only by the g++ wavefront emulator in tests/emu to record
+// (address, width, direction) per access for the bank-conflict census; it is empty here.
+#ifndef WF_LDS_TRACE
+#define WF_LDS_TRACE(idx, bytes, is_write)
+#endif
+WF_DEV cf lds_ld2(const cf *lds, int idx) { WF_LDS_TRACE(idx, 8, 0); return lds[idx]; }
+WF_DEV void lds_st2(cf *lds, int idx, cf a) { WF_LDS_TRACE(idx, 8, 1); lds[idx] = a; }
+WF_DEV f4 lds_ld4(const cf *lds, int idx) { WF_LDS_TRACE(idx, 16, 0); return *reinterpret_cast<const f4 *>(lds + idx); }
+WF_DEV void lds_st4(cf *lds, int idx, cf a, cf b) { WF_LDS_TRACE(idx, 16, 1); *reinterpret_cast<f4 *>(lds + idx) = f4{a.x, a.y, b.x, b.y}; }
+
+// (g * oldval) + (g2 * mag) with every operation rounded separately, as the reference's generic
+// translation unit is built (no -mfma, -ffp-contract=off: SURVEY.md Appendix C.9)
+#if defined(__HIPCC__)
+WF_DEV float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+WF_DEV float add_rn(float a, float b) { return __fadd_rn(a, b); }
+#else
+WF_DEV float mul_rn(float a, float b) { volatile float r = a * b; return r; }
+WF_DEV float add_rn(float a, float b) { volatile float r = a + b; return r; }
+#endif
+
+// dbfs(), reference src/source.hpp:293-299
+WF_DEV float dbfs(float mag, float db_min) { return (mag > 0.0f) ? 20.0f * log10f(mag) : db_min; }
+
+// ---- P1: fetch + window + pass 1 ---------------------------------------------------------------
+// x      : base of this spectrum's ring
+// start  : ring index of the first sample of the window
+// ALIGNED: start % 4 == 0 (vector loads never straddle the ring wrap)
+template<class G, bool ALIGNED>
+WF_DEV void p1_fetch_pass1(const TickArgs &a, int t, const float *x, uint32_t start, cf *lds)
+{
+    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    cf u[B1][R1];
+    // fetch (+ window)
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        const int c0 = j * M1 + B1 * t; // first complex point of this thread in row j
+        const uint32_t s0 = 2u * (uint32_t)c0;
+        float smp[2 * B1];
+        if(ALIGNED) {
+            if(B1 == 2) {
+                const f4 q = ld4(x + ((start + s0) & a.ring_mask));
+                smp[0] = q.x; smp[1] = q.y; smp[2] = q.z; smp[3] = q.w;
+            } else {
+                const f2 q = ld2(x + ((start + s0) & a.ring_mask));
+                smp[0] = q.x; smp[1] = q.y;
+            }
+        } else {
+            WF_UNROLL
+            for(int e = 0; e < 2 * B1; ++e)
+                smp[e] = x[(start + s0 + (uint32_t)e) & a.ring_mask];
+        }
+        if(a.mode & WF_MODE_WINDOW) {
+            if(B1 == 2) {
+                const f4 w = ld4(a.window + s0);
+                smp[0] *= w.x; smp[1] *= w.y; smp[2] *= w.z; smp[3] *= w.w;
+            } else {
+                const f2 w = ld2(a.window + s0);
+                smp[0] *= w.x; smp[1] *= w.y;
+            }
+        }
+        WF_UNROLL
+        for(int b = 0; b < B1; ++b)
+            u[b][j] = cf{smp[2 * b], smp[2 * b + 1]};
+    }
+    // butterflies over n1 (= j), twiddle by W_M^(n' k1), store A'[k1][n']
+    WF_UNROLL
+    for(int b = 0; b < B1; ++b)
+        dft_dif<R1>(u[b]);
+    constexpr int LB = ilog2(R1);
+    WF_UNROLL
+    for(int k1 = 0; k1 < R1; ++k1) {
+        const int np = B1 * t;
+        cf o[B1];
+        if(k1 == 0) {
+            WF_UNROLL
+            for(int b = 0; b < B1; ++b)
+                o[b] = u[b][0];
+        } else if(B1 == 2) {
+            const f4 w = ld4(reinterpret_cast<const float *>(a.tw1 + k1 * M1 + np));
+            o[0] = cmul(u[0][brev(k1, LB)], cf{w.x, w.y});
+            o[1] = cmul(u[1][brev(k1, LB)], cf{w.z, w.w});
+        } else {
+            const f2 w = ld2(reinterpret_cast<const float *>(a.tw1 + k1 * M1 + np));
+            o[0] = cmul(u[0][brev(k1, LB)], cf{w.x, w.y});
+        }
+        if(B1 == 2)
+            lds_st4(lds, ex1_addr<G>(k1, np), o[0], o[B1 - 1]);
+        else
+            lds_st2(lds, ex1_addr<G>(k1, np), o[0]);
+    }
+}
+
+// ---- P2: pass 2 ---------------------------------------------------------------------------------
+template<class G> WF_DEV void p2_read(int t, const cf *lds, cf (&v)[G::P])
+{
+    constexpr int R2 = G::R2, R3 = G::R3, B2 = G::B2;
+    const int q0 = B2 * t;
+    const int k1 = q0 / R3, n30 = q0 % R3;
+    WF_UNROLL
+    for(int n2 = 0; n2 < R2; ++n2) {
+        const int base = ex1_addr<G>(k1, n2 * R3 + n30);
+        if(B2 == 1) {
+            v[n2] = lds_ld2(lds, base);
+        } else {
+            WF_UNROLL
+            for(int b = 0; b < B2; b += 2) {
+                const f4 q = lds_ld4(lds, base + b);
+                v[b * R2 + n2] = cf{q.x, q.y};
+                v[(b + 1) * R2 + n2] = cf{q.z, q.w};
+            }
+        }
+    }
+}
+
+template<class G> WF_DEV void p2_pass2_write(const TickArgs &a, int t, cf *lds, cf (&v)[G::P])
+{
+    constexpr int R1 = G::R1, R2 = G::R2, R3 = G::R3, B2 = G::B2;
+    constexpr int LB = ilog2(R2);
+    const int q0 = B2 * t;
+    const int k1 = q0 / R3, n30 = q0 % R3;
+    cf u[B2][R2];
+    WF_UNROLL
+    for(int b = 0; b < B2; ++b) {
+        WF_UNROLL
+        for(int n2 = 0; n2 < R2; ++n2)
+            u[b][n2] = v[b * R2 + n2];
+        dft_dif<R2>(u[b]);
+    }
+    WF_UNROLL
+    for(int k2 = 0; k2 < R2; ++k2) {
+        cf o[B2];
+        if(k2 == 0) {
+            WF_UNROLL
+            for(int b = 0; b < B2; ++b)
+                o[b] = u[b][0];
+        } else if(B2 == 1) {
+            const f2 w = ld2(reinterpret_cast<const float *>(a.tw2 + k2 * R3 + n30));
+            o[0] = cmul(u[0][brev(k2, LB)], cf{w.x, w.y});
+        } else {
+            WF_UNROLL
+            for(int b = 0; b < B2; b += 2) {
+                const f4 w = ld4(reinterpret_cast<const float *>(a.tw2 + k2 * R3 + n30 + b));
+                o[b] = cmul(u[b][brev(k2, LB)], cf{w.x, w.y});
+                o[b + 1] = cmul(u[b + 1][brev(k2, LB)], cf{w.z, w.w});
+            }
+        }
+        const int q = k1 + R1 * k2;
+        if(B2 == 1) {
+            lds_st2(lds, ex2_addr<G>(q, n30), o[0]);
+        } else {
+            WF_UNROLL
+            for(int b = 0; b < B2; b += 2)
+                lds_st4(lds, ex2_addr<G>(q, n30 + b), o[b], o[b + 1]);
+        }
+    }
+}
+
+// ---- P3: pass 3 ---------------------------------------------------------------------------------
+template<class G> WF_DEV void p3_read(int t, const cf *lds, cf (&v)[G::P])
+{
+    constexpr int R3 = G::R3, B3 = G::B3, T = G::T;
+    WF_UNROLL
+    for(int b = 0; b < B3; ++b) {
+        const int q = t + T * b;
+        WF_UNROLL
+        for(int n3 = 0; n3 < R3; n3 += 2) {
+            const f4 w = lds_ld4(lds, ex2_addr<G>(q, n3));
+            v[b * R3 + n3] = cf{w.x, w.y};
+            v[b * R3 + n3 + 1] = cf{w.z, w.w};
+        }
+    }
+}
+
+template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
+{
+    constexpr int R1 = G::R1, R2 = G::R2, R3 = G::R3, B3 = G::B3, T = G::T;
+    constexpr int LB = ilog2(R3);
+    WF_UNROLL
+    for(int b = 0; b < B3; ++b) {
+        cf u[R3];
+        WF_UNROLL
+        for(int n3 = 0; n3 < R3; ++n3)
+            u[n3] = v[b * R3 + n3];
+        dft_dif<R3>(u);
+        const int q = t + T * b;
+        WF_UNROLL
+        for(int k3 = 0; k3 < R3; ++k3)
+            lds_st2(lds, ex3_addr<G>(q + R1 * R2 * k3), u[brev(k3, LB)]);
+    }
+}
+
+// ---- P4: real split + epilogue ------------------------------------------------------------------
+// Produces the smoothed linear magnitudes of bins 4g..4g+3 (g = t + T*u) in mag[u][0..3],
+// updating the temporal-smoothing state on the way (reference :110-135).
+template<class G> WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
+{
+    constexpr int M = G::M, T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u) {
+        const int k0 = 4 * (t + T * u);
+        const f4 za = lds_ld4(lds, ex3_addr<G>(k0));
+        const f4 zb = lds_ld4(lds, ex3_addr<G>(k0 + 2));
+        const cf A[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
+        const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + k0));
+        const f4 wb = ld4(reinterpret_cast<const float *>(a.tws + k0 + 2));
+        const cf W[4] = {{wa.x, wa.y}, {wa.z, wa.w}, {wb.x, wb.y}, {wb.z, wb.w}};
+        float m4[4];
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i) {
+            const cf B = lds_ld2(lds, ex3_addr<G>((M - k0 - i) & (M - 1)));
+            // 2X[k] = (A + conj B) - i W (A - conj B)
+            const float er = A[i].x + B.x, ei = A[i].y - B.y;
+            const float dr = A[i].x - B.x, di = A[i].y + B.y;
+            const float pr = fmaf(W[i].x, dr, -(W[i].y * di)); // Re(W D)
+            const float pi = fmaf(W[i].x, di, W[i].y * dr);    // Im(W D)
+            const float xr = er + pi, xi = ei - pr;
+            m4[i] = sqrtf(fmaf(xi, xi, xr * xr)) * a.half_coef;
+        }
+        if(a.mode & WF_MODE_SLOPE) {
+            const f4 s = ld4(a.slope + k0);
+            m4[0] *= s.x; m4[1] *= s.y; m4[2] *= s.z; m4[3] *= s.w;
+        }
+        if(a.mode & WF_MODE_TSMOOTH) {
+            const f4 o = ld4(ts + k0);
+            float old[4] = {o.x, o.y, o.z, o.w};
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i) {
+                if(a.mode & WF_MODE_FAST_PEAKS)
+                    old[i] = fmaxf(m4[i], old[i]);
+                // (g * oldval) + (g2 * mag), each product rounded (reference :130, no contraction)
+                m4[i] = add_rn(mul_rn(a.g, old[i]), mul_rn(a.g2, m4[i]));
+            }
+            st4(ts + k0, f4{m4[0], m4[1], m4[2], m4[3]});
+        }
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i)
+            mag[4 * u + i] = m4[i];
+    }
+}
+
+// dB conversion + volume normalisation + roll-off for bins 4g..4g+3, then store (reference :144-179)
+template<class G> WF_DEV void p4_db_store(const TickArgs &a, int t, float *out, const float (&mag)[G::P])
+{
+    constexpr int T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u) {
+        const int k0 = 4 * (t + T * u);
+        float d[4];
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i)
+            d[i] = dbfs(mag[4 * u + i], a.db_min);
+        if(a.mode & WF_MODE_NORMALIZE) {
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i)
+                if(k0 + i >= 1) // the generic path starts at i = 1 (reference :165)
+                    d[i] += a.vol_comp;
+        }
+        if(a.mode & WF_MODE_ROLLOFF) {
+            const f4 r = ld4(a.rolloff + k0);
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i)
+                if(k0 + i >= 1) // reference :173
+                    d[i] = fmaxf(d[i] - rr[i], a.db_min);
+        }
+        st4(out + k0, f4{d[0], d[1], d[2], d[3]});
+    }
+}
+
+} // namespace wf
