@@ -1,0 +1,589 @@
+/*
+ * wf_oracle.c -- see wf_oracle.h.  TEST INFRASTRUCTURE (CPU restatement of the reference path).
+ * Build: gcc -O2 -std=c11 -ffp-contract=off (no FMA contraction: the reference's generic TU is
+ * built without -mfma and with -std=c++20, i.e. -ffp-contract=off).
+ */
+#include "wf_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PI_F 3.14159274101257324219f /* std::numbers::pi_v<float> */
+
+struct wfo_source {
+    wf_config cfg;
+    uint32_t n, m;              /* m_fft_size, m_fft_size / 2 */
+    uint32_t cap_ch, out_ch;    /* m_capture_channels, m_output_channels */
+    /* rings (CircularBuffer, in samples) */
+    float *ring[2];
+    size_t ring_len[2], ring_cap[2];
+    uint32_t sync_delay;
+    int hidden;
+    int last_silent;            /* m_last_silent */
+    float input_rms;
+    /* tables */
+    float *window;              /* NULL when FFTWindow::NONE */
+    float window_sum;
+    float *slope;               /* NULL unless m_slope > 0 */
+    float *rolloff;             /* NULL unless rolloff active */
+    /* buffers */
+    float *fft_in;              /* m_fft_input */
+    float *fft_out;             /* m_fft_output: interleaved re,im, m bins */
+    float *tsmooth[2];
+    float *decibels[2];
+    /* bars */
+    int num_bars;
+    float *interp_indices; size_t n_indices;
+    int *band_widths;
+    float *weights; int radius, taps;
+    float *bars[2];
+    float border_top, border_bottom, cpos;
+    /* FFT work */
+    double *wr, *wi;            /* work arrays, n each */
+    double *twr, *twi;          /* exp(-2 pi i k / n), k < n/2 */
+};
+
+/* ---- math_funcs.hpp ------------------------------------------------------------------------- */
+static float log_interp_f(float a, float b, float t) { return a * powf(b / a, t); } /* :25-29 */
+/* std::lerp as libstdc++ implements it (src/math_funcs.hpp:31-35 forwards to it) */
+static float lerp_f(float a, float b, float t)
+{
+    if((a <= 0 && b >= 0) || (a >= 0 && b <= 0))
+        return t * b + (1 - t) * a;
+    if(t == 1)
+        return b;
+    const float x = a + t * (b - a);
+    return ((t > 1) == (b > a)) ? (b < x ? x : b) : (b > x ? x : b);
+}
+static float sinc_f(float x) /* :37-44 */
+{
+    if(x == 0.0f)
+        return 1.0f;
+    const float tmp = PI_F * x;
+    return sinf(tmp) / tmp;
+}
+static float lanczos_f(float x, float w) /* :46-52 */
+{
+    if(fabsf(x) < w)
+        return sinc_f(x) * sinc_f(x / w);
+    return 0.0f;
+}
+static float clamp_f(float v, float lo, float hi) { return (v < lo) ? lo : (hi < v) ? hi : v; } /* std::clamp */
+
+float wfo_db_min(void) { return 20.0f * log10f(FLT_MIN); } /* src/source.cpp:43 */
+static float dbfs(float mag) { return (mag > 0.0f) ? 20.0f * log10f(mag) : wfo_db_min(); } /* src/source.hpp:293-299 */
+
+/* get_gravity, src/source.hpp:301-312 */
+float wfo_gravity(const wfo_source *s, float seconds)
+{
+    const float denom = 0.03868924705242879469662125316986f;
+    const float hi = denom * 5.0f;
+    const float lo = 0.0f;
+    if((s->cfg.tsmoothing == WF_TSMOOTH_NONE) || (s->cfg.gravity <= 0.0f))
+        return 0.0f;
+    return (s->cfg.tsmoothing == WF_TSMOOTH_TVEXPONENTIAL) ? expf(-seconds / lerp_f(lo, hi, s->cfg.gravity)) : s->cfg.gravity;
+}
+
+/* ---- the DFT stage (stands in for fftwf_execute of an r2c plan) ---------------------------------- */
+static void fft_prepare(wfo_source *s)
+{
+    const uint32_t n = s->n;
+    s->wr = (double *)malloc(sizeof(double) * n);
+    s->wi = (double *)malloc(sizeof(double) * n);
+    s->twr = (double *)malloc(sizeof(double) * (n / 2));
+    s->twi = (double *)malloc(sizeof(double) * (n / 2));
+    for(uint32_t k = 0; k < n / 2; ++k) {
+        const double a = -2.0 * 3.14159265358979323846264338327950288 * (double)k / (double)n;
+        s->twr[k] = cos(a);
+        s->twi[k] = sin(a);
+    }
+}
+
+/* iterative radix-2 decimation-in-time complex FFT in double; n is a power of two */
+static void fft_double(double *re, double *im, const double *twr, const double *twi, uint32_t n)
+{
+    for(uint32_t i = 1, j = 0; i < n; ++i) {
+        uint32_t bit = n >> 1;
+        for(; j & bit; bit >>= 1)
+            j ^= bit;
+        j ^= bit;
+        if(i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for(uint32_t len = 2; len <= n; len <<= 1) {
+        const uint32_t half = len >> 1, step = n / len;
+        for(uint32_t i = 0; i < n; i += len)
+            for(uint32_t k = 0; k < half; ++k) {
+                const double cr = twr[k * step], ci = twi[k * step];
+                const double xr = re[i + k + half] * cr - im[i + k + half] * ci;
+                const double xi = re[i + k + half] * ci + im[i + k + half] * cr;
+                re[i + k + half] = re[i + k] - xr;
+                im[i + k + half] = im[i + k] - xi;
+                re[i + k] += xr;
+                im[i + k] += xi;
+            }
+    }
+}
+
+static void r2c(wfo_source *s)
+{
+    const uint32_t n = s->n;
+    for(uint32_t i = 0; i < n; ++i) {
+        s->wr[i] = (double)s->fft_in[i];
+        s->wi[i] = 0.0;
+    }
+    fft_double(s->wr, s->wi, s->twr, s->twi, n);
+    for(uint32_t k = 0; k < s->m; ++k) {
+        s->fft_out[2 * k] = (float)s->wr[k];
+        s->fft_out[2 * k + 1] = (float)s->wi[k];
+    }
+}
+
+void wfo_r2c(const float *in, uint32_t n, float *out_interleaved)
+{
+    wfo_source tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    tmp.n = n;
+    tmp.m = n / 2;
+    tmp.fft_in = (float *)in;
+    tmp.fft_out = out_interleaved;
+    fft_prepare(&tmp);
+    r2c(&tmp);
+    free(tmp.wr); free(tmp.wi); free(tmp.twr); free(tmp.twi);
+}
+
+/* ---- setup: WAVSource::update() ------------------------------------------------------------------- */
+static void build_window(wfo_source *s) /* src/source.cpp:1190-1234 */
+{
+    const size_t n = s->n;
+    if(s->cfg.window == WF_WINDOW_NONE) {
+        s->window = NULL;
+        s->window_sum = (float)n;
+        return;
+    }
+    s->window = (float *)malloc(sizeof(float) * n);
+    const size_t N = n - 1;
+    const float pi = PI_F;
+    const float pi2 = 2 * pi, pi4 = 4 * pi, pi6 = 6 * pi;
+    for(size_t i = 0; i < n; ++i) {
+        float w;
+        switch(s->cfg.window) {
+        case WF_WINDOW_HAMMING:
+            w = 0.53836f - (0.46164f * cosf((pi2 * i) / N));
+            break;
+        case WF_WINDOW_BLACKMAN:
+            w = 0.42f - (0.5f * cosf((pi2 * i) / N)) + (0.08f * cosf((pi4 * i) / N));
+            break;
+        case WF_WINDOW_BLACKMAN_HARRIS:
+            w = 0.35875f - (0.48829f * cosf((pi2 * i) / N)) + (0.14128f * cosf((pi4 * i) / N)) - (0.01168f * cosf((pi6 * i) / N));
+            break;
+        case WF_WINDOW_POWER_OF_SINE:
+            w = powf(sinf((pi * i) / N), (float)s->cfg.sine_exponent);
+            break;
+        case WF_WINDOW_HANN:
+        default:
+            w = 0.5f * (1 - cosf((pi2 * i) / N));
+            break;
+        }
+        s->window[i] = w;
+    }
+    float sum = 0.0f;
+    for(size_t i = 0; i < n; ++i)
+        sum += s->window[i];
+    s->window_sum = sum;
+}
+
+static void build_slope(wfo_source *s) /* src/source.cpp:1282-1290 */
+{
+    s->slope = NULL;
+    if(!(s->cfg.slope > 0.0f))
+        return;
+    const size_t num_mods = s->m;
+    const float maxmod = (float)(num_mods - 1);
+    s->slope = (float *)malloc(sizeof(float) * num_mods);
+    for(size_t i = 0; i < num_mods; ++i)
+        s->slope[i] = log10f(log_interp_f(10.0f, 10000.0f, ((float)i * s->cfg.slope) / maxmod));
+}
+
+static void build_rolloff(wfo_source *s) /* init_rolloff, src/source.cpp:898-918 */
+{
+    s->rolloff = NULL;
+    if(!((s->cfg.rolloff_q > 0.0f) && (s->cfg.rolloff_rate > 0.0f)))
+        return;
+    const size_t sz = s->m;
+    const float sr = (float)s->cfg.sample_rate;
+    const float coeff = sr / (float)s->n;
+    const float ratio = exp2f(s->cfg.rolloff_q);
+    const float freq_low = (float)s->cfg.cutoff_low * ratio;
+    const float freq_high = (float)s->cfg.cutoff_high / ratio;
+    s->rolloff = (float *)malloc(sizeof(float) * sz);
+    s->rolloff[0] = 0.0f;
+    for(size_t i = 1u; i < sz; ++i) {
+        const float freq = i * coeff;
+        const float ratio_low = freq_low / freq;
+        const float ratio_high = freq / freq_high;
+        const float low_attenuation = (ratio_low > 1.0f) ? (s->cfg.rolloff_rate * log2f(ratio_low)) : 0.0f;
+        const float high_attenuation = (ratio_high > 1.0f) ? (s->cfg.rolloff_rate * log2f(ratio_high)) : 0.0f;
+        s->rolloff[i] = low_attenuation + high_attenuation;
+    }
+}
+
+static void build_bars(wfo_source *s) /* update() :1267-1276, init_interp :837-896, render_bars :1476-1494 */
+{
+    const wf_config *c = &s->cfg;
+    s->num_bars = 0;
+    if(!c->bars)
+        return;
+    const int bar_stride = c->bar_width + c->bar_gap;
+    int num_bars = (int)(c->width / (unsigned int)bar_stride);
+    if(((int)c->width - (num_bars * bar_stride)) >= c->bar_width)
+        ++num_bars;
+    s->num_bars = num_bars;
+    const unsigned int sz = (unsigned int)(num_bars + 1);
+    const size_t maxbin = (size_t)s->m - 1;
+    const float sr = (float)c->sample_rate;
+    const float lowbin = clamp_f((float)c->cutoff_low * (float)s->n / sr, 1.0f, (float)maxbin);
+    const float highbin = clamp_f((float)c->cutoff_high * (float)s->n / sr, 1.0f, (float)maxbin);
+    float *idx = (float *)malloc(sizeof(float) * sz);
+    for(unsigned int i = 0u; i < sz; ++i) {
+        const float t = (c->mirror_freq_axis ? i * 2.0f : (float)i) / (float)(sz - 1);
+        const float v = c->log_scale ? log_interp_f(lowbin, highbin, t) : lerp_f(lowbin, highbin, t);
+        idx[i] = clamp_f(v, lowbin, highbin);
+    }
+    s->band_widths = (int *)malloc(sizeof(int) * (size_t)num_bars);
+    size_t total = 0;
+    for(int i = 0; i < num_bars; ++i) {
+        const int w = (int)(idx[i + 1] - idx[i]);
+        s->band_widths[i] = (w > 1) ? w : 1;
+        total += (size_t)s->band_widths[i];
+    }
+    if(c->interp_mode != WF_INTERP_POINT) {
+        s->interp_indices = (float *)malloc(sizeof(float) * total);
+        s->n_indices = total;
+        size_t k = 0;
+        for(int i = 0; i < num_bars; ++i)
+            for(int j = 0; j < s->band_widths[i]; ++j)
+                s->interp_indices[k++] = idx[i] + j;
+        free(idx);
+        if(c->interp_mode == WF_INTERP_LANCZOS) { /* make_lanczos_kernel, src/filter.hpp:106-131 */
+            const intmax_t radius = 4;
+            s->radius = 4;
+            s->taps = 8;
+            s->weights = (float *)malloc(sizeof(float) * total * 8);
+            for(size_t i = 0; i < total; ++i) {
+                const float x = s->interp_indices[i];
+                const intmax_t ix = (intmax_t)x;
+                const intmax_t start = ix - radius + 1, stop = ix + radius;
+                for(intmax_t j = start; j <= stop; ++j)
+                    s->weights[i * 8 + (size_t)(j - start)] = lanczos_f(x - j, (float)radius);
+            }
+        } else { /* make_catrom_kernel, src/filter.hpp:67-104, t = 0.5 */
+            const float t = 0.5f;
+            const float matrix[4][4] = {{0, -t, 2 * t, -t}, {1, 0, t - 3, 2 - t}, {0, t, 3 - (2 * t), t - 2}, {0, 0, -t, t}};
+            s->radius = 2;
+            s->taps = 4;
+            s->weights = (float *)malloc(sizeof(float) * total * 4);
+            for(size_t i = 0; i < total; ++i) {
+                const float u = s->interp_indices[i] - floorf(s->interp_indices[i]);
+                const float row[4] = {1, u, u * u, u * u * u};
+                for(int j = 0; j < 4; ++j) {
+                    float sum = 0;
+                    for(int k = 0; k < 4; ++k)
+                        sum += row[k] * matrix[j][k];
+                    s->weights[i * 4 + (size_t)j] = sum;
+                }
+            }
+        }
+    } else {
+        s->interp_indices = idx;
+        s->n_indices = sz;
+    }
+    for(int ch = 0; ch < 2; ++ch)
+        s->bars[ch] = (float *)calloc((size_t)num_bars, sizeof(float));
+    /* render_bars geometry, src/source.cpp:1480-1494 */
+    const float center = (float)c->height / 2;
+    const float bottom = (float)c->height;
+    const float cpos = c->stereo ? center : bottom;
+    const float cap_radius = (float)c->bar_width / 2.0f;
+    const float channel_offset = c->channel_spacing * 0.5f;
+    float border_top = c->rounded_caps ? cap_radius : 0.0f;
+    float border_bottom = (c->rounded_caps && (!c->stereo || (c->channel_spacing > 0))) ? cpos - cap_radius : cpos;
+    if(c->channel_spacing > 0)
+        border_bottom -= channel_offset;
+    if(c->min_bar_height > 0)
+        border_bottom -= c->min_bar_height;
+    border_bottom = clamp_f(border_bottom, border_top, cpos);
+    s->border_top = border_top;
+    s->border_bottom = border_bottom;
+    s->cpos = cpos;
+}
+
+/* ---- CircularBuffer (src/circular_buffer.hpp), in samples ------------------------------------------ */
+static void ring_push(wfo_source *s, int ch, const float *src, size_t frames)
+{
+    if(s->ring_len[ch] + frames > s->ring_cap[ch]) {
+        size_t cap = s->ring_cap[ch] ? s->ring_cap[ch] : 1024;
+        while(cap < s->ring_len[ch] + frames)
+            cap *= 2;
+        s->ring[ch] = (float *)realloc(s->ring[ch], cap * sizeof(float));
+        s->ring_cap[ch] = cap;
+    }
+    if(src != NULL)
+        memcpy(s->ring[ch] + s->ring_len[ch], src, frames * sizeof(float));
+    else
+        memset(s->ring[ch] + s->ring_len[ch], 0, frames * sizeof(float)); /* push_back_zero */
+    s->ring_len[ch] += frames;
+}
+static void ring_pop_front(wfo_source *s, int ch, size_t frames)
+{
+    if(frames > s->ring_len[ch])
+        frames = s->ring_len[ch];
+    memmove(s->ring[ch], s->ring[ch] + frames, (s->ring_len[ch] - frames) * sizeof(float));
+    s->ring_len[ch] -= frames;
+}
+
+wfo_source *wfo_create(const wf_config *cfg)
+{
+    if(cfg == NULL || cfg->fft_size < 128 || (cfg->fft_size & 15) || (cfg->fft_size & (cfg->fft_size - 1)))
+        return NULL; /* the restated DFT needs a power of two */
+    wfo_source *s = (wfo_source *)calloc(1, sizeof(*s));
+    s->cfg = *cfg;
+    s->n = cfg->fft_size;
+    s->m = cfg->fft_size / 2;
+    s->cap_ch = cfg->capture_channels;
+    s->out_ch = ((s->cap_ch > 1) || cfg->stereo) ? 2u : 1u; /* src/source.cpp:1171 */
+    for(uint32_t i = 0; i < s->out_ch; ++i) {             /* :1172-1182 */
+        s->decibels[i] = (float *)malloc(sizeof(float) * s->m);
+        for(uint32_t k = 0; k < s->m; ++k)
+            s->decibels[i][k] = wfo_db_min();
+        if(cfg->tsmoothing != WF_TSMOOTH_NONE)
+            s->tsmooth[i] = (float *)calloc(s->m, sizeof(float));
+    }
+    s->fft_in = (float *)calloc(s->n, sizeof(float));
+    s->fft_out = (float *)calloc((size_t)s->n * 2, sizeof(float));
+    fft_prepare(s);
+    build_window(s);
+    s->last_silent = 0;                                   /* :1236 */
+    for(uint32_t i = 0; i < s->cap_ch; ++i)                /* :1243-1248: N samples of silence */
+        ring_push(s, (int)i, NULL, s->n);
+    build_bars(s);
+    build_slope(s);
+    build_rolloff(s);
+    return s;
+}
+
+void wfo_destroy(wfo_source *s)
+{
+    if(s == NULL)
+        return;
+    for(int i = 0; i < 2; ++i) {
+        free(s->ring[i]); free(s->tsmooth[i]); free(s->decibels[i]); free(s->bars[i]);
+    }
+    free(s->window); free(s->slope); free(s->rolloff); free(s->fft_in); free(s->fft_out);
+    free(s->interp_indices); free(s->band_widths); free(s->weights);
+    free(s->wr); free(s->wi); free(s->twr); free(s->twi);
+    free(s);
+}
+
+void wfo_set_sync_delay(wfo_source *s, uint32_t frames) { s->sync_delay = frames; }
+void wfo_set_hidden(wfo_source *s, int hidden) { s->hidden = hidden; }
+void wfo_set_input_rms(wfo_source *s, float rms) { s->input_rms = rms; }
+
+/* capture_audio, src/source.cpp:1873-1886 (the A/V-sync amount is supplied by the caller in frames) */
+void wfo_push_audio(wfo_source *s, const float *ch0, const float *ch1, uint32_t frames, int muted)
+{
+    const float *data[2] = {ch0, ch1};
+    for(uint32_t j = 0; j < s->cap_ch; ++j) {
+        if(muted || data[j] == NULL)
+            ring_push(s, (int)j, NULL, frames);
+        else
+            ring_push(s, (int)j, data[j], frames);
+        const size_t max_size = (size_t)s->sync_delay + s->n;
+        if(s->ring_len[j] > max_size)
+            ring_pop_front(s, (int)j, s->ring_len[j] - max_size);
+    }
+}
+
+/* WAVSourceGeneric::tick_spectrum, src/source_generic.cpp:26-180 */
+void wfo_tick(wfo_source *s, float seconds)
+{
+    const uint32_t outsz = s->m;
+    const float DB_MIN = wfo_db_min();
+    if(s->hidden) { /* :34-48 */
+        if(s->last_silent)
+            return;
+        for(uint32_t ch = 0; ch < s->cap_ch; ++ch)
+            if(s->tsmooth[ch] != NULL)
+                memset(s->tsmooth[ch], 0, outsz * sizeof(float));
+        for(int ch = 0; ch < (s->cfg.stereo ? 2 : 1); ++ch)
+            for(uint32_t i = 0; i < outsz; ++i)
+                s->decibels[ch][i] = DB_MIN;
+        s->last_silent = 1;
+        return;
+    }
+    const size_t dtsize = (size_t)s->sync_delay + s->n; /* :50-51, in samples */
+    unsigned silent_channels = 0;
+    for(uint32_t channel = 0; channel < s->cap_ch; ++channel) {
+        if(s->ring_len[channel] >= dtsize) { /* :55-59 */
+            ring_pop_front(s, (int)channel, s->ring_len[channel] - dtsize);
+            memcpy(s->fft_in, s->ring[channel], s->n * sizeof(float));
+        } else
+            continue;
+
+        int silent = 1; /* :63-72 */
+        for(uint32_t i = 0; i < s->n; ++i)
+            if(s->fft_in[i] != 0.0f) {
+                silent = 0;
+                s->last_silent = 0;
+                break;
+            }
+        if(silent) { /* :74-95 */
+            if(s->last_silent)
+                continue;
+            int outsilent = 1;
+            const float floor = (float)(s->cfg.floor_db - 10);
+            const uint32_t ch = s->cfg.stereo ? channel : 0u;
+            for(uint32_t i = 0; i < outsz; ++i)
+                if(s->decibels[ch][i] > floor) {
+                    outsilent = 0;
+                    break;
+                }
+            if(outsilent) {
+                if(++silent_channels >= s->cap_ch)
+                    s->last_silent = 1;
+                continue;
+            }
+        }
+        if(s->window != NULL) /* :97-103 */
+            for(uint32_t i = 0; i < s->n; ++i)
+                s->fft_in[i] *= s->window[i];
+        r2c(s); /* :105-106 */
+
+        const float mag_coefficient = 2.0f / s->window_sum; /* :110-135 */
+        const float g = wfo_gravity(s, seconds);
+        const float g2 = 1.0f - g;
+        const int slope = s->cfg.slope > 0.0f;
+        for(uint32_t i = 0; i < outsz; ++i) {
+            const float real = s->fft_out[2 * i];
+            const float imag = s->fft_out[2 * i + 1];
+            float mag = hypotf(real, imag) * mag_coefficient;
+            if(slope)
+                mag *= s->slope[i];
+            if(s->cfg.tsmoothing != WF_TSMOOTH_NONE) {
+                float oldval = s->tsmooth[channel][i];
+                if(s->cfg.fast_peaks)
+                    oldval = (mag > oldval) ? mag : oldval; /* std::max(mag, oldval) */
+                mag = (g * oldval) + (g2 * mag);
+                s->tsmooth[channel][i] = mag;
+            }
+            s->decibels[channel][i] = mag;
+        }
+    }
+    if(s->last_silent) /* :138-139 */
+        return;
+    if(s->out_ch > s->cap_ch) /* :141-142 */
+        memcpy(s->decibels[1], s->decibels[0], outsz * sizeof(float));
+    if(s->cfg.stereo) { /* :144-159 */
+        for(int ch = 0; ch < 2; ++ch)
+            for(uint32_t i = 0; i < outsz; ++i)
+                s->decibels[ch][i] = dbfs(s->decibels[ch][i]);
+    } else if(s->cap_ch > 1) {
+        for(uint32_t i = 0; i < outsz; ++i)
+            s->decibels[0][i] = dbfs((s->decibels[0][i] + s->decibels[1][i]) * 0.5f);
+    } else {
+        for(uint32_t i = 0; i < outsz; ++i)
+            s->decibels[0][i] = dbfs(s->decibels[0][i]);
+    }
+    if(s->cfg.normalize_volume) { /* :161-167 */
+        const float a = s->cfg.volume_target - dbfs(s->input_rms);
+        const float volume_compensation = (s->cfg.max_gain < a) ? s->cfg.max_gain : a; /* std::min(a, max_gain) */
+        for(int ch = 0; ch < (s->cfg.stereo ? 2 : 1); ++ch)
+            for(uint32_t i = 1; i < outsz; ++i)
+                s->decibels[ch][i] += volume_compensation;
+    }
+    if((s->cfg.rolloff_q > 0.0f) && (s->cfg.rolloff_rate > 0.0f)) { /* :169-179 */
+        for(int ch = 0; ch < (s->cfg.stereo ? 2 : 1); ++ch)
+            for(uint32_t i = 1; i < outsz; ++i) {
+                const float val = s->decibels[ch][i] - s->rolloff[i];
+                s->decibels[ch][i] = (val < DB_MIN) ? DB_MIN : val; /* std::max(val, DB_MIN) */
+            }
+    }
+}
+
+/* kernel_convolve, src/filter.hpp:160-169 */
+static float kernel_convolve(const float *samples, size_t sz, const float *weights, int radius, intmax_t index, intmax_t kernel_base)
+{
+    const intmax_t start = (index - radius) + 1;
+    intmax_t stop = index + radius + 1;
+    if((intmax_t)sz < stop)
+        stop = (intmax_t)sz;
+    float sum = 0;
+    for(intmax_t i = (start > 0 ? start : 0); i < stop; ++i)
+        sum += samples[i] * weights[kernel_base + (i - start)];
+    return sum;
+}
+
+/* render_bars: interpolation :1500-1533 and the dB -> pixel mapping :1548-1557 */
+void wfo_render_bars(wfo_source *s)
+{
+    if(s->num_bars <= 0)
+        return;
+    const int dbrange = s->cfg.ceiling_db - s->cfg.floor_db;
+    for(int channel = 0; channel < (s->cfg.stereo ? 2 : 1); ++channel) {
+        const float *db = s->decibels[channel];
+        float *out = s->bars[channel];
+        if(s->cfg.interp_mode != WF_INTERP_POINT) { /* apply_interp_filter (bars), src/filter.hpp:194-211 */
+            const intmax_t d = (intmax_t)s->radius * 2;
+            intmax_t k = 0, l = 0;
+            for(int i = 0; i < s->num_bars; ++i) {
+                float sum = 0;
+                const intmax_t count = s->band_widths[i];
+                for(intmax_t j = 0; j < count; ++j, ++k, l += d)
+                    sum += kernel_convolve(db, s->m, s->weights, s->radius, (intmax_t)s->interp_indices[k], l);
+                out[i] = sum / (float)count;
+            }
+        } else { /* :1525-1532 */
+            for(int i = 0; i < s->num_bars; ++i) {
+                float sum = 0.0f;
+                const size_t count = (size_t)s->band_widths[i];
+                for(size_t j = 0; j < count; ++j)
+                    sum += db[(size_t)s->interp_indices[i] + j];
+                out[i] = sum / (float)count;
+            }
+        }
+        for(int i = 0; i < s->num_bars; ++i) /* :1548-1557 */
+            out[i] = lerp_f(s->border_top, s->border_bottom, clamp_f(s->cfg.ceiling_db - out[i], 0.0f, (float)dbrange) / dbrange);
+        if(s->cfg.mirror_freq_axis) { /* :1559-1564 */
+            const unsigned half = (unsigned)s->num_bars / 2u;
+            for(unsigned i = half + 1; i < (unsigned)s->num_bars; ++i)
+                out[i] = out[half - (i - half)];
+        }
+    }
+}
+
+/* ---- accessors ------------------------------------------------------------------------------------- */
+uint32_t wfo_fft_size(const wfo_source *s) { return s->n; }
+uint32_t wfo_output_channels(const wfo_source *s) { return s->out_ch; }
+int wfo_last_silent(const wfo_source *s) { return s->last_silent; }
+size_t wfo_ring_samples(const wfo_source *s, int ch) { return s->ring_len[ch & 1]; }
+const float *wfo_decibels(const wfo_source *s, int ch) { return s->decibels[ch & 1]; }
+const float *wfo_tsmooth(const wfo_source *s, int ch) { return s->tsmooth[ch & 1]; }
+float *wfo_tsmooth_mut(wfo_source *s, int ch) { return s->tsmooth[ch & 1]; }
+const float *wfo_window(const wfo_source *s, float *sum) { if(sum) *sum = s->window_sum; return s->window; }
+const float *wfo_slope(const wfo_source *s) { return s->slope; }
+const float *wfo_rolloff(const wfo_source *s) { return s->rolloff; }
+int wfo_num_bars(const wfo_source *s) { return s->num_bars; }
+size_t wfo_interp_indices(const wfo_source *s, const float **out) { *out = s->interp_indices; return s->n_indices; }
+size_t wfo_band_widths(const wfo_source *s, const int **out) { *out = s->band_widths; return (size_t)s->num_bars; }
+size_t wfo_interp_weights(const wfo_source *s, const float **out, int *radius, int *taps)
+{
+    *out = s->weights;
+    if(radius) *radius = s->radius;
+    if(taps) *taps = s->taps;
+    return s->weights ? s->n_indices * (size_t)s->taps : 0;
+}
+const float *wfo_bars(const wfo_source *s, int ch) { return s->bars[ch & 1]; }

@@ -202,6 +202,35 @@ int wfemu_tick(const wf_config *cfg, uint32_t n_streams, uint32_t ring_cap, cons
     return ok ? ret : WF_HIP_ERR_UNSUPPORTED;
 }
 
+// host tables of the product (waveform_amd/csrc/wf_host_tables.cpp) without a device.
+// which: 0 window, 1 slope, 2 rolloff, 3 interp_indices, 4 interp_weights, 5 band_widths (as float),
+//        6 scalars {window_sum, gravity(seconds), db_min, num_bars, radius, taps, border_top, border_bottom, out_ch}
+// returns the element count (copies at most cap elements), or a negative error
+long wfemu_host_table(const wf_config *cfg, int which, float seconds, float *out, long cap)
+{
+    wf::HostTables tab;
+    const int rc = wf::build_host_tables(*cfg, tab);
+    if(rc != 0)
+        return rc;
+    std::vector<float> v;
+    switch(which) {
+    case 0: v = tab.window; break;
+    case 1: v = tab.slope; break;
+    case 2: v = tab.rolloff; break;
+    case 3: v = tab.interp_indices; break;
+    case 4: v = tab.interp_weights; break;
+    case 5: v.assign(tab.band_widths.begin(), tab.band_widths.end()); break;
+    case 6:
+        v = {tab.window_sum, wf::gravity_for(*cfg, seconds), wf::db_min(), (float)tab.num_bars, (float)tab.interp_radius,
+             (float)tab.interp_taps, tab.border_top, tab.border_bottom, (float)tab.output_channels};
+        break;
+    default: return -1;
+    }
+    for(long i = 0; i < (long)v.size() && i < cap; ++i)
+        out[i] = v[(size_t)i];
+    return (long)v.size();
+}
+
 int wfemu_lds_bytes(uint32_t fft_size)
 {
     int r = -1;

@@ -1,0 +1,57 @@
+"""ctypes binding of build/libwfemu.so (the wavefront emulator, tests/emu/wf_emu.cpp)."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB_PATH = ROOT / "build" / "libwfemu.so"
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            subprocess.run(["make", "-C", str(ROOT / "tests" / "emu")], check=True, capture_output=True)
+        L = C.CDLL(str(LIB_PATH))
+        fp = C.POINTER(C.c_float)
+        L.wfemu_tick.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, fp, C.POINTER(C.c_uint32), C.c_uint32, C.c_float, fp, fp,
+                                 C.POINTER(C.c_uint64)]
+        L.wfemu_host_table.restype = C.c_long
+        L.wfemu_host_table.argtypes = [C.c_void_p, C.c_int, C.c_float, fp, C.c_long]
+        L.wfemu_lds_bytes.argtypes = [C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def host_table(cfg, which: int, seconds: float = 1 / 60):
+    L = lib()
+    n = L.wfemu_host_table(C.cast(C.byref(cfg), C.c_void_p), which, seconds, None, 0)
+    if n < 0:
+        raise ValueError(f"build_host_tables failed: {n}")
+    out = np.zeros(max(n, 1), np.float32)
+    L.wfemu_host_table(C.cast(C.byref(cfg), C.c_void_p), which, seconds, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+    return out[:n]
+
+
+def tick(cfg, ring: np.ndarray, wpos: int, tsmooth: np.ndarray, delay: int = 0, seconds: float = 1 / 60):
+    """ring: float32 [spectra, ring_cap]; tsmooth: float32 [spectra, M] (updated in place).
+    Returns (decibels [streams, out_ch, M], stats[6])"""
+    L = lib()
+    n_spec, cap = ring.shape
+    streams = n_spec // cfg.capture_channels
+    out_ch = 2 if (cfg.capture_channels > 1 or cfg.stereo) else 1
+    M = cfg.fft_size // 2
+    db = np.zeros((streams, out_ch, M), np.float32)
+    w = (C.c_uint32 * streams)(*([wpos] * streams))
+    stats = (C.c_uint64 * 6)()
+    fp = C.POINTER(C.c_float)
+    rc = L.wfemu_tick(C.cast(C.byref(cfg), C.c_void_p), streams, cap, ring.ctypes.data_as(fp), w, delay, seconds,
+                      tsmooth.ctypes.data_as(fp), db.ctypes.data_as(fp), stats)
+    if rc != 0:
+        raise RuntimeError(f"wfemu_tick rc={rc}")
+    return db, list(stats)

@@ -1,0 +1,233 @@
+"""Scenario scripts shared by every parity test.
+
+A scenario is a configuration plus a list of steps that drive ONE source the way OBS drives
+the plugin (audio packets in, video ticks, show/hide).  The same script can be played on
+  * RefBackend     the reference itself (oracle/_ref/libwfref.so)     -> tools/make_golden.py
+  * OracleBackend  the CPU restatement (oracle/libwforacle.so)         -> CPU tests
+  * HipBackend     libwaveform_hip.so through its C ABI               -> GPU tests
+and every backend records the same observables after each tick:
+  db    float32 [display_channels, fft_size/2]   m_decibels
+  bars  float32 [display_channels, num_bars]     m_interp_bufs after render_bars (if cfg.bars)
+  silent bool                                    m_last_silent
+Audio is the counter-hash noise of include/wf_synth.h (tools/synth.py), so fixtures only store
+outputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from tools import synth
+
+SEED = 0x5741564546524D31
+
+
+def _steps(n_ticks, hop=800, seconds=1.0 / 60.0):
+    out = []
+    for _ in range(n_ticks):
+        out += [("noise", hop), ("tick", seconds)]
+    return out
+
+
+# name -> dict(cfg=<wf_config overrides>, steps=[...], record=<"all" | int: last k ticks>)
+SCENARIOS = {
+    # BASELINE.json configs[0]: 1ch mono, FFT=1024, Hann (OBS mono layout: one captured channel)
+    "cfg1_mono_1024": dict(cfg=dict(fft_size=1024, stereo=0, capture_channels=1), steps=_steps(6), record="all"),
+    # configs[1]: stereo, FFT=2048, Hann + magnitude + dB, no smoothing
+    "cfg2_stereo_2048_nosmooth": dict(cfg=dict(fft_size=2048, stereo=1, tsmoothing=0), steps=_steps(4), record="all"),
+    # configs[2]: FFT=4096, EMA + slope
+    "cfg3_stereo_4096_ema_slope": dict(cfg=dict(fft_size=4096, stereo=1, slope=1.0), steps=_steps(8), record=3),
+    # configs[3]: FFT=16384, gravity (TV-EMA) smoothing + Lanczos bars
+    "cfg4_16384_tv_lanczos_bars": dict(cfg=dict(fft_size=16384, stereo=1, tsmoothing=2, bars=1, interp_mode=1),
+                                       steps=_steps(4), record=1),
+    # configs[4] per-stream shape: FFT=4096 EMA + slope + bars (the all-gathered quantity)
+    "cfg5_4096_bars": dict(cfg=dict(fft_size=4096, stereo=1, slope=1.0, bars=1, interp_mode=1), steps=_steps(6), record=2),
+    # mono mixdown of two captured channels after smoothing, TV-EMA, fast peaks (Appendix C.5)
+    "mono_mix_4096_tv_fastpeaks": dict(cfg=dict(fft_size=4096, stereo=0, tsmoothing=2, fast_peaks=1, slope=0.5),
+                                       steps=_steps(6), record=2),
+    "fft8192_stereo": dict(cfg=dict(fft_size=8192, stereo=1, slope=2.0), steps=_steps(4), record=1),
+    # every window function
+    "win_hamming": dict(cfg=dict(fft_size=2048, stereo=0, capture_channels=1, window=2), steps=_steps(3), record=1),
+    "win_blackman": dict(cfg=dict(fft_size=2048, stereo=0, capture_channels=1, window=3), steps=_steps(3), record=1),
+    "win_blackman_harris": dict(cfg=dict(fft_size=2048, stereo=0, capture_channels=1, window=4), steps=_steps(3), record=1),
+    "win_sine3": dict(cfg=dict(fft_size=2048, stereo=0, capture_channels=1, window=5, sine_exponent=3), steps=_steps(3), record=1),
+    "win_none": dict(cfg=dict(fft_size=2048, stereo=0, capture_channels=1, window=0), steps=_steps(3), record=1),
+    # roll-off + catmull-rom bars on a linear axis, single captured channel shown as stereo (channel dup)
+    "rolloff_catrom_linear": dict(cfg=dict(fft_size=2048, stereo=1, capture_channels=1, rolloff_q=1.5, rolloff_rate=12.0, bars=1,
+                                           interp_mode=2, log_scale=0), steps=_steps(4), record=2),
+    "point_bars_mirror": dict(cfg=dict(fft_size=4096, stereo=0, bars=1, interp_mode=0, mirror_freq_axis=1, bar_width=10, bar_gap=2),
+                              steps=_steps(4), record=1),
+    # ragged packets: 441-frame hops (window start not 16-byte aligned), then a 1024 packet
+    "ragged_hops": dict(cfg=dict(fft_size=2048, stereo=1),
+                        steps=[("noise", 441), ("tick",), ("noise", 441), ("tick",), ("noise", 1024), ("tick",), ("noise", 3), ("tick",),
+                               ("tick",)], record="all"),
+    # silence state machine (src/source_generic.cpp:63-95,138-139): noise, then digital silence until the
+    # display decays below floor-10 and the source goes silent, then noise again
+    "silence_cycle": dict(cfg=dict(fft_size=1024, stereo=1, gravity=0.2),
+                          steps=_steps(3) + [("silence", 1200), ("tick",)] + [("silence", 800), ("tick",)] * 14 + _steps(2), record="all"),
+    "silence_cycle_mono": dict(cfg=dict(fft_size=1024, stereo=0, gravity=0.2),
+                               steps=_steps(2) + [("silence", 1200), ("tick",)] + [("silence", 800), ("tick",)] * 14 + _steps(2), record="all"),
+    # one channel silent, the other live (Appendix C.3 quirk: the skipped channel is re-dBFS'ed)
+    "half_silent_stereo": dict(cfg=dict(fft_size=1024, stereo=1, gravity=0.2),
+                               steps=_steps(2) + [("noise_ch0_only", 1200), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 12, record="all"),
+    # hidden / capture timeout branch (src/source_generic.cpp:34-48)
+    "hide_show": dict(cfg=dict(fft_size=1024, stereo=1), steps=_steps(3) + [("hide",), ("noise", 800), ("tick",), ("noise", 800), ("tick",),
+                                                                           ("show",)] + _steps(3), record="all"),
+    # muted packets are pushed as zeros (src/source.cpp:1879-1880)
+    "muted_packets": dict(cfg=dict(fft_size=1024, stereo=1, tsmoothing=0), steps=_steps(2) + [("mute", 800), ("tick",), ("noise", 800), ("tick",)],
+                          record="all"),
+}
+
+
+def make_config(overrides: dict):
+    """wf_config ctypes struct from defaults + overrides (works without a GPU)."""
+    import waveform_amd as wf
+    return wf.Config.defaults(**overrides)
+
+
+class _Feeder:
+    """turns ('noise', n) etc. into sample blocks; the stream index in the hash is always 0"""
+
+    def __init__(self, channels):
+        self.channels = channels
+        self.pos = 0
+
+    def block(self, kind, frames):
+        a = synth.block(SEED, 0, 1, 2, self.pos, frames)[0]
+        self.pos += frames
+        if kind == "silence" or kind == "mute":
+            a[:] = 0.0
+        elif kind == "noise_ch0_only":
+            a[1] = 0.0
+        return a[: self.channels]
+
+
+def play(backend, scenario: dict):
+    """returns list of per-tick records: dict(db=..., bars=... | None, silent=bool)"""
+    feeder = _Feeder(backend.capture_channels)
+    records = []
+    for step in scenario["steps"]:
+        op = step[0]
+        if op in ("noise", "silence", "noise_ch0_only"):
+            backend.push(feeder.block(op, step[1]), muted=False)
+        elif op == "mute":
+            backend.push(feeder.block(op, step[1]), muted=True)
+        elif op == "tick":
+            seconds = step[1] if len(step) > 1 else 1.0 / 60.0
+            backend.tick(seconds)
+            records.append(backend.observe())
+        elif op == "hide":
+            backend.set_hidden(True)
+        elif op == "show":
+            backend.set_hidden(False)
+        else:
+            raise ValueError(op)
+    return records
+
+
+def recorded(records, record):
+    if record == "all":
+        return list(enumerate(records))
+    return list(enumerate(records))[-int(record):]
+
+
+# ---- backends --------------------------------------------------------------------------------------
+class RefBackend:
+    def __init__(self, cfg, isa="generic"):
+        from helpers import ref_settings
+        from oracle import wfref
+        self.cfg = cfg
+        self.src = wfref.RefSource(ref_settings(cfg), isa=isa, channels=int(cfg.capture_channels))
+        assert self.src.capture_channels == cfg.capture_channels
+        self.capture_channels = int(cfg.capture_channels)
+        self.disp = 2 if cfg.stereo else 1
+        self.now = 1_000_000_000
+
+    def push(self, audio, muted):
+        import ctypes as C
+        n = audio.shape[1]
+        self.now += n * 1_000_000_000 // 48000 + 1
+        L = self.src.L
+        L.wfref_set_clock_ns(self.now)
+        a = np.ascontiguousarray(audio, np.float32)
+        fp = C.POINTER(C.c_float)
+        p0 = a[0].ctypes.data_as(fp)
+        p1 = a[1].ctypes.data_as(fp) if a.shape[0] > 1 else fp()
+        # end-of-audio timestamp == now  ->  get_audio_sync() == 0 at the following tick
+        length = n * 1_000_000_000 // 48000
+        L.wfref_push_audio(self.src.h, p0, p1, n, self.now - length, 1 if muted else 0)
+
+    def tick(self, seconds):
+        self.src.L.wfref_set_clock_ns(self.now)
+        self.src.L.wfref_tick(self.src.h, seconds)
+
+    def set_hidden(self, hidden):
+        self.src.show(not hidden)
+
+    def observe(self):
+        db = np.stack([self.src.decibels(c) for c in range(self.disp)])
+        bars = None
+        if self.cfg.bars:
+            self.src.render()
+            bars = np.stack([self.src.bars(c) for c in range(self.disp)])
+        return dict(db=db, bars=bars, silent=self.src.last_silent)
+
+
+class OracleBackend:
+    def __init__(self, cfg):
+        from oracle import restate
+        self.cfg = cfg
+        self.src = restate.OracleSource(cfg)
+        self.capture_channels = self.src.capture_channels
+
+    def push(self, audio, muted):
+        self.src.push_audio(audio, muted=muted)
+
+    def tick(self, seconds):
+        self.src.tick(seconds)
+
+    def set_hidden(self, hidden):
+        self.src.set_hidden(hidden)
+
+    def observe(self):
+        bars = None
+        if self.cfg.bars:
+            self.src.render_bars()
+            bars = self.src.bars()
+        return dict(db=self.src.decibels(), bars=bars, silent=self.src.last_silent)
+
+
+class HipBackend:
+    """`streams` identical copies of the scenario run in one batch (they must all agree);
+    observe() returns stream `probe`."""
+
+    def __init__(self, cfg, streams=3, probe=1):
+        import waveform_amd as wf
+        self.cfg = cfg
+        self.batch = wf.SpectrumBatch(cfg, streams)
+        self.capture_channels = self.batch.capture_channels
+        self.streams = streams
+        self.probe = probe
+        self.disp = self.batch.display_channels
+
+    def push(self, audio, muted):
+        if muted:
+            self.batch.push_silence(audio.shape[1])
+        else:
+            self.batch.push_audio(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
+
+    def tick(self, seconds):
+        self.batch.tick(seconds=seconds)
+
+    def set_hidden(self, hidden):
+        self.batch.set_hidden(np.full(self.streams, 1 if hidden else 0, np.uint8))
+
+    def observe(self):
+        db = self.batch.decibels()
+        bars = self.batch.bars() if self.cfg.bars else None
+        silent = self.batch.last_silent()
+        # every copy of the scenario must produce the same bits
+        assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"
+        return dict(db=db[self.probe][: self.disp], bars=None if bars is None else bars[self.probe], silent=bool(silent[self.probe]))
+
+    def close(self):
+        self.batch.close()

@@ -1,0 +1,180 @@
+"""CPU-side unit tests (no GPU): synthetic-audio hash, host tables of the product vs the oracle,
+the kernel's phase functions run in the wavefront emulator vs the oracle, C-ABI export list."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import scenarios
+import emu_binding as emu
+from helpers import assert_db_close
+from oracle import restate
+from tools import synth
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+# ---- wf_synth.h -----------------------------------------------------------------------------------
+def test_synth_numpy_matches_c():
+    from oracle import wfref
+    if not wfref.available():
+        pytest.skip("libwfref.so not built")
+    L = wfref.lib()
+    for stream, ch, i0 in ((0, 0, 0), (7, 1, 12345), (65535, 1, 2**33 + 5)):
+        a = synth.noise(synth.DEFAULT_SEED, stream, ch, i0, 257)
+        b = np.array([L.wfref_noise(synth.DEFAULT_SEED, stream, ch, i0 + i) for i in range(257)], np.float32)
+        assert np.array_equal(a, b)
+    x = synth.noise(1, 2, 0, 0, 1 << 16)
+    assert x.min() >= -1.0 and x.max() < 1.0 and abs(float(x.mean())) < 0.01
+    assert abs(float(x.var()) - 1 / 3) < 0.01
+
+
+# ---- host tables: product code (wf_host_tables.cpp) must be bit-identical to the oracle --------------
+TABLE_CFGS = [
+    dict(fft_size=4096, stereo=1, slope=1.0),
+    dict(fft_size=1024, window=2, slope=0.37, rolloff_q=2.0, rolloff_rate=6.5, cutoff_low=120, cutoff_high=9000),
+    dict(fft_size=2048, window=3, bars=1, interp_mode=1),
+    dict(fft_size=8192, window=4, bars=1, interp_mode=2, log_scale=0, bar_width=3, bar_gap=1, width=1280),
+    dict(fft_size=16384, window=5, sine_exponent=4, tsmoothing=2, gravity=0.9, bars=1, interp_mode=0, mirror_freq_axis=1),
+    dict(fft_size=2048, window=0, tsmoothing=0, bars=1, interp_mode=1, stereo=1, channel_spacing=8, min_bar_height=4, rounded_caps=1),
+]
+
+
+@pytest.mark.parametrize("ov", TABLE_CFGS)
+def test_host_tables_bit_identical_to_oracle(ov):
+    cfg = scenarios.make_config(ov)
+    o = restate.OracleSource(cfg)
+    w, wsum = o.window()
+    scal = emu.host_table(cfg, 6, 1 / 75)
+    assert scal[0] == np.float32(wsum)
+    assert scal[1] == np.float32(o.gravity(1 / 75))
+    assert scal[2] == np.float32(restate.db_min())
+    assert int(scal[3]) == o.num_bars
+    for which, want in ((0, w), (1, o.slope()), (2, o.rolloff())):
+        got = emu.host_table(cfg, which)
+        if want is None:
+            assert got.size == 0
+        else:
+            assert np.array_equal(got, want), f"table {which}"
+    if cfg.bars:
+        assert np.array_equal(emu.host_table(cfg, 3), o.interp_indices())
+        assert np.array_equal(emu.host_table(cfg, 5).astype(np.int32), o.band_widths())
+        kw, radius, taps = o.interp_weights()
+        got = emu.host_table(cfg, 4)
+        if kw is None:
+            assert got.size == 0
+        else:
+            assert np.array_equal(got, kw) and int(scal[4]) == radius and int(scal[5]) == taps
+
+
+def test_unsupported_fft_sizes_are_rejected():
+    for n in (800, 512, 32768, 3000):
+        cfg = scenarios.make_config(dict(fft_size=n))
+        with pytest.raises(ValueError):
+            emu.host_table(cfg, 0)
+
+
+# ---- kernel phases in the wavefront emulator vs the oracle --------------------------------------------
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("hop", [800, 441])
+def test_emulated_kernel_matches_oracle(n, hop):
+    cfg = scenarios.make_config(dict(fft_size=n, stereo=1, slope=1.0, fast_peaks=1))
+    o = restate.OracleSource(cfg)
+    ticks = 4
+    cap = 1
+    while cap < n + ticks * hop:
+        cap *= 2
+    ring = np.zeros((2, cap), np.float32)
+    ts = np.zeros((2, n // 2), np.float32)
+    w = n
+    for t in range(ticks):
+        a = synth.block(99, 0, 1, 2, t * hop, hop)[0]
+        ring[:, w:w + hop] = a
+        w += hop
+        o.feed_and_tick(a)
+        db, stats = emu.tick(cfg, ring, w, ts)
+        assert_db_close(db[0], o.decibels(), f"N={n} hop={hop} tick {t}")
+        for c in range(2):
+            want = o.tsmooth(c)
+            assert np.allclose(ts[c], want, rtol=2e-5, atol=1e-12)
+
+
+def test_emulated_kernel_window_delay():
+    """the A/V-sync delay: the window ends `delay` frames before the newest sample"""
+    n, hop = 2048, 800
+    cfg = scenarios.make_config(dict(fft_size=n, stereo=1, tsmoothing=0))
+    audio = synth.block(5, 0, 1, 2, 0, 4 * hop)[0]
+    ring = np.zeros((2, 8192), np.float32)
+    ring[:, n:n + 4 * hop] = audio
+    ts = np.zeros((2, n // 2), np.float32)
+    o = restate.OracleSource(cfg)
+    for t in range(4):
+        o.feed_and_tick(audio[:, t * hop:(t + 1) * hop])
+        db, _ = emu.tick(cfg, ring, n + 4 * hop, ts, delay=(3 - t) * hop)
+        assert_db_close(db[0], o.decibels(), f"delay tick {t}")
+
+
+def test_lds_budget_and_conflicts():
+    """LDS per spectrum stays within the occupancy plan and writes stay conflict-free"""
+    budget = {1024: 5 * 1024, 2048: 9 * 1024, 4096: 17408, 8192: 34 * 1024, 16384: 68 * 1024}
+    for n, b in budget.items():
+        assert 0 < emu.lib().wfemu_lds_bytes(n) <= b
+    cfg = scenarios.make_config(dict(fft_size=4096, stereo=1))
+    ring = np.zeros((2, 8192), np.float32)
+    ring[:, :] = synth.block(1, 0, 1, 2, 0, 8192)[0]
+    ts = np.zeros((2, 2048), np.float32)
+    _, st = emu.tick(cfg, ring, 8192, ts)
+    rd_instr, rd_ideal, rd_actual, wr_instr, wr_ideal, wr_actual = st
+    assert wr_actual == wr_ideal, "LDS writes must be bank-conflict free"
+    assert rd_actual <= 1.35 * rd_ideal, (rd_ideal, rd_actual)
+
+
+# ---- C ABI -----------------------------------------------------------------------------------------------
+def _declared_functions(header: Path):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    text = re.sub(r"//.*", "", text)
+    names = set()
+    for m in re.finditer(r"\b(wf_[a-z0-9_]+)\s*\(", text):
+        names.add(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    so = ROOT / "waveform_amd" / "libwaveform_hip.so"
+    assert so.exists(), "build the library first: make -C waveform_amd/csrc"
+    declared = _declared_functions(ROOT / "include" / "wf_hip.h") | _declared_functions(ROOT / "include" / "wf_config.h")
+    declared -= {"wf_synth_mix64", "wf_synth_key", "wf_synth_sample", "wf_synth_noise"}
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if " T " in line}
+    missing = sorted(declared - exported)
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    L = C.CDLL(str(so))  # loads without a GPU
+    for name in declared:
+        assert hasattr(L, name)
+    L.wf_hip_abi_version.restype = C.c_int
+    assert L.wf_hip_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    import waveform_amd as wf
+    if wf.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(wf.WfHipError) as e:
+        wf.SpectrumBatch(wf.Config.defaults(), 4)
+    assert e.value.code == -3  # WF_HIP_ERR_NO_DEVICE: no CPU fallback exists
+
+
+def test_product_does_not_reference_the_oracle():
+    """the product tree must not import, include or link anything under oracle/"""
+    bad = []
+    for p in (ROOT / "waveform_amd").rglob("*"):
+        if p.suffix in (".py", ".hpp", ".cpp", ".hip", ".h") or p.name == "Makefile":
+            txt = p.read_text(errors="ignore")
+            if re.search(r"oracle[/.]|wforacle|wfref|wfemu", txt) and p.name not in ("wf_fft_core.hpp", "wf_tick_phases.hpp"):
+                bad.append(str(p))
+    assert not bad, bad
+    ldd = subprocess.run(["ldd", str(ROOT / "waveform_amd" / "libwaveform_hip.so")], capture_output=True, text=True).stdout
+    assert "wforacle" not in ldd and "wfref" not in ldd and "fftw" not in ldd
