@@ -132,7 +132,7 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
     ConflictStats st[2];
     std::vector<cf> lds((size_t)G::LDS_CF);
     std::vector<std::vector<emu::Access>> traces((size_t)T);
-    struct Regs { cf v[P]; float mag[P]; };
+    struct Regs { cf v[P]; float mag[P]; float d[P]; float smp[G::R1][2 * G::B1]; };
     std::vector<Regs> regs((size_t)T);
 
     auto census_waves = [&](bool enable) {
@@ -163,15 +163,19 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
         const bool aligned = (start % 4u) == 0;
         std::fill(lds.begin(), lds.end(), cf{1e30f, 1e30f}); // poison: unwritten reads show up
         phase(c, [&](int t) {
-            if(aligned) p1_fetch_pass1<G, true>(a, t, x, start, lds.data());
-            else p1_fetch_pass1<G, false>(a, t, x, start, lds.data());
+            if(aligned) p1_fetch<G, true>(a, t, x, start, regs[(size_t)t].smp);
+            else p1_fetch<G, false>(a, t, x, start, regs[(size_t)t].smp);
+            p1_window_pass1<G>(a, t, regs[(size_t)t].smp, lds.data());
         });
         phase(c, [&](int t) { p2_read<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p2_pass2_write<G>(a, t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p3_read<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p3_pass3_write<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p4_split_smooth<G>(a, t, lds.data(), ts, regs[(size_t)t].mag); });
-        phase(false, [&](int t) { p4_db_store<G>(a, t, out, regs[(size_t)t].mag); });
+        phase(false, [&](int t) {
+            p4_db<G>(a, t, regs[(size_t)t].mag, regs[(size_t)t].d);
+            store_row<G>(out, t, regs[(size_t)t].d);
+        });
     }
     if(stats) {
         stats[0] = st[0].instr; stats[1] = st[0].ideal_cycles; stats[2] = st[0].actual_cycles;

@@ -200,6 +200,11 @@ class SpectrumBatch:
         p = TickParams(seconds, delay_frames, input_rms, flags)
         self._ck(self.L.wf_hip_tick(self.h, C.byref(p)))
 
+    def set_hidden(self, mask, first: int = 0):
+        """mask: uint8[count]; non-zero = hidden / capture timed out (reset branch of tick_spectrum)"""
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._ck(self.L.wf_hip_set_hidden(self.h, first, len(m), m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
     def sync(self):
         self._ck(self.L.wf_hip_sync(self.h))
 

@@ -47,6 +47,10 @@ struct wf_hip {
     float *d_bars = nullptr;
     float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
+    float *d_interp_indices = nullptr, *d_interp_weights = nullptr;
+    int *d_band_widths = nullptr, *d_band_start = nullptr;
+    uint8_t *d_mask = nullptr;
+    size_t mask_bytes = 0;
     float *d_stage = nullptr;
     size_t stage_floats = 0;
     std::vector<void *> allocs;
@@ -107,7 +111,7 @@ template<class G, int SPW> void launch_tick(wf_hip *h, const wf::TickArgs &a, bo
 {
     const uint32_t n_spec = a.n_streams * a.cap_ch;
     const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
-    const size_t lds = (size_t)SPW * G::LDS_CF * sizeof(wf::cf);
+    const size_t lds = wf::tick_lds_bytes<G, SPW>();
     if(aligned)
         hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true>), grid, block, lds, h->stream, a);
     else
@@ -116,7 +120,7 @@ template<class G, int SPW> void launch_tick(wf_hip *h, const wf::TickArgs &a, bo
 
 template<class G, int SPW> int setup_launch(wf_hip *h)
 {
-    const int lds = (int)((size_t)SPW * G::LDS_CF * sizeof(wf::cf));
+    const int lds = (int)wf::tick_lds_bytes<G, SPW>();
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false>),
@@ -153,7 +157,24 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     a.tsmooth = h->d_tsmooth;
     a.decibels = h->d_decibels;
     a.stream_flags = h->d_flags;
-    a.bars = h->d_bars;
+    a.skip_decibels = (p->flags & WF_HIP_TICK_NO_DECIBELS) ? 1u : 0u;
+    a.bar = wf::BarArgs{};
+    if(h->d_bars) {
+        a.bar.indices = h->d_interp_indices;
+        a.bar.weights = h->d_interp_weights;
+        a.bar.band_widths = h->d_band_widths;
+        a.bar.band_start = h->d_band_start;
+        a.bar.out = h->d_bars;
+        a.bar.num_bars = (int)h->num_bars;
+        a.bar.taps = h->tab.interp_taps;
+        a.bar.radius = h->tab.interp_radius;
+        a.bar.mirror = h->cfg.mirror_freq_axis ? 1 : 0;
+        a.bar.border_top = h->tab.border_top;
+        a.bar.border_bottom = h->tab.border_bottom;
+        a.bar.ceiling = (float)h->cfg.ceiling_db;
+        a.bar.dbrange = (float)(h->cfg.ceiling_db - h->cfg.floor_db);
+        a.bar.disp_ch = h->disp_ch;
+    }
     a.half_coef = 0.5f * (2.0f / h->tab.window_sum); // mag_coefficient (reference src/source_generic.cpp:110), halved: the
                                                      // kernel produces 2X[k] from the real split
     a.g = wf::gravity_for(h->cfg, p->seconds);
@@ -317,16 +338,29 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     WF_CREATE_TRY(upload(h, &h->d_window, h->tab.window));
     WF_CREATE_TRY(upload(h, &h->d_slope, h->tab.slope));
     WF_CREATE_TRY(upload(h, &h->d_rolloff, h->tab.rolloff));
+    std::vector<int> band_start;
+    if(h->num_bars) {
+        WF_CREATE_TRY(upload(h, &h->d_interp_indices, h->tab.interp_indices));
+        WF_CREATE_TRY(upload(h, &h->d_interp_weights, h->tab.interp_weights));
+        WF_CREATE_TRY(upload(h, &h->d_band_widths, h->tab.band_widths));
+        band_start.resize(h->tab.band_widths.size());
+        int acc = 0;
+        for(size_t i = 0; i < band_start.size(); ++i) {
+            band_start[i] = acc;
+            acc += h->tab.band_widths[i];
+        }
+        WF_CREATE_TRY(upload(h, &h->d_band_start, band_start));
+    }
 
     // FFT plan: twiddle tables for the geometry of this fft_size + the kernel instantiation
     int setup_rc = WF_HIP_ERR_UNSUPPORTED;
     std::vector<wf::cfloat> tw1, tw2, tws;
-    const bool mono_mix = !cfg->stereo && cfg->capture_channels > 1;
     wf::dispatch_geometry(h->N, [&](auto g) {
         using G = decltype(g);
         wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
+        // the channels of a stream share a workgroup (silence state machine, mono mixdown)
         if constexpr(G::T >= 256)
-            setup_rc = mono_mix ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
+            setup_rc = (cfg->capture_channels > 1) ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
         else
             setup_rc = setup_launch<G, 2>(h);
     });
@@ -381,9 +415,12 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
                        h->d_decibels + (size_t)first * h->out_ch * h->M, ndb, wf::db_min());
     hipLaunchKernelGGL(wf::fill_u32_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos + first, (size_t)count,
                        h->N);
-    if(h->d_bars)
-        WF_HIP_TRY(h, hipMemsetAsync(h->d_bars + (size_t)first * h->disp_ch * h->num_bars, 0,
-                                     (size_t)count * h->disp_ch * h->num_bars * sizeof(float), h->stream));
+    if(h->d_bars) {
+        // what render_bars shows for rows of DB_MIN: every bar at border_bottom (zero height)
+        const size_t nb = (size_t)count * h->disp_ch * h->num_bars;
+        hipLaunchKernelGGL(wf::fill_f32_kernel, dim3((unsigned)std::min<size_t>((nb + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           h->d_bars + (size_t)first * h->disp_ch * h->num_bars, nb, h->tab.border_bottom);
+    }
     WF_HIP_TRY(h, hipGetLastError());
     return WF_HIP_OK;
 }
@@ -481,8 +518,21 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
     int rc = check_range(h, first, count);
     if(rc)
         return rc;
-    (void)mask;
-    return fail(h, WF_HIP_ERR_UNSUPPORTED, "hidden/timeout streams are not implemented yet");
+    if(mask == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "mask is NULL");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->mask_bytes < count) {
+        rc = dev_alloc(h, &h->d_mask, (size_t)count);
+        if(rc)
+            return rc;
+        h->mask_bytes = count;
+    }
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, count, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(wf::set_hidden_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_flags, first, count,
+                       h->d_mask);
+    WF_HIP_TRY(h, hipGetLastError());
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `mask` is borrowed for the call only
+    return WF_HIP_OK;
 }
 
 int wf_hip_sync(wf_hip *h)

@@ -30,79 +30,166 @@ template<class G> __device__ __forceinline__ void spectrum_sync()
         __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for(int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Dynamic LDS: SPW exchange buffers of G::LDS_CF complex each, then one int of per-wavefront facts per wave.
+template<class G, int SPW> constexpr size_t tick_lds_bytes() { return (size_t)SPW * G::LDS_CF * sizeof(cf) + (size_t)SPW * (G::T / 64) * sizeof(int) + 16; }
+
 template<class G, int SPW, bool ALIGNED>
 __global__ __launch_bounds__(G::T *SPW) void spectrum_tick_kernel(const TickArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int T = G::T, M = G::M, P = G::P;
+    constexpr int T = G::T, M = G::M, P = G::P, WPS = G::T / 64;
     const int tid = (int)threadIdx.x;
-    const int sub = tid / T; // which spectrum of the workgroup
-    const int t = tid % T;   // thread within the spectrum
+    const int sub = tid / T;          // which spectrum of the workgroup
+    const int t = tid % T;            // thread within the spectrum
+    const int lane = tid & 63;
+    const int wave_in_block = tid >> 6;
     const uint32_t n_spec = a.n_streams * a.cap_ch;
     const uint32_t spec = blockIdx.x * SPW + (uint32_t)sub;
     const bool active = spec < n_spec;
     const uint32_t stream = active ? spec / a.cap_ch : 0u;
     const uint32_t ch = active ? spec % a.cap_ch : 0u;
+    const bool stereo = (a.mode & WF_MODE_STEREO) != 0;
+    const bool mono_mix = (a.mode & WF_MODE_MONO_MIX) != 0;
 
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * G::LDS_CF;
+    int *facts = reinterpret_cast<int *>(reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF);
     const float *x = a.ring + (size_t)(active ? spec : 0u) * a.ring_cap;
     const uint32_t start = (a.wpos[stream] - a.delay - (uint32_t)G::N) & a.ring_mask;
     float *ts = a.tsmooth + (size_t)(active ? spec : 0u) * M;
+    float *rows = a.decibels + (size_t)stream * a.out_ch * M; // m_decibels[0..out_ch) of this stream
 
+    const uint32_t sflags = active ? a.stream_flags[stream] : 0u;
+    const bool hidden = (sflags & WF_STREAM_HIDDEN) != 0;
+    const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
+
+    // ---- fetch the window; per-wavefront facts for the silence state machine (reference :55-95) ----------
+    float smp[G::R1][2 * G::B1];
+    bool nz = false;
+    if(active && !hidden)
+        nz = p1_fetch<G, ALIGNED>(a, t, x, start, smp);
+    const bool wave_nz = __any(nz) != 0;
+    bool wave_below = true;
+    if(active && !hidden && !wave_nz) // wave-uniform and rare: the whole slice of this wave is digital silence
+        wave_below = __all(row_all_below<G>(rows + (size_t)(stereo ? ch : 0u) * M, t, a.silent_floor)) != 0;
+
+    bool nzc[2] = {false, false}, belowc[2] = {true, true};
+    if(T > 64 || a.cap_ch > 1) {
+        if(lane == 0)
+            facts[wave_in_block] = (wave_nz ? 1 : 0) | (wave_below ? 2 : 0);
+        __syncthreads();
+        for(uint32_t c = 0; c < a.cap_ch; ++c) {
+            const int sb = sub - (int)ch + (int)c; // the subgroup that owns channel c of this stream
+            bool n = false, bl = true;
+#pragma unroll
+            for(int w = 0; w < WPS; ++w) {
+                const int f = facts[sb * WPS + w];
+                n = n || (f & 1);
+                bl = bl && (f & 2);
+            }
+            nzc[c] = n;
+            belowc[c] = bl;
+        }
+    } else {
+        nzc[0] = wave_nz;
+        belowc[0] = wave_below;
+    }
+    const StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nzc, belowc);
+    const bool process = active && !hidden && plan.process[ch];
+    const bool do_db = active && !hidden && !plan.last_silent; // reference :138-139
+
+    // ---- the FFT path --------------------------------------------------------------------------------------
     cf v[P];
     float mag[P];
-
-    if(active)
-        p1_fetch_pass1<G, ALIGNED>(a, t, x, start, lds);
+    if(process)
+        p1_window_pass1<G>(a, t, smp, lds);
     spectrum_sync<G>();
-    if(active)
+    if(process)
         p2_read<G>(t, lds, v);
     spectrum_sync<G>();
-    if(active)
+    if(process)
         p2_pass2_write<G>(a, t, lds, v);
     spectrum_sync<G>();
-    if(active)
+    if(process)
         p3_read<G>(t, lds, v);
     spectrum_sync<G>();
-    if(active)
+    if(process)
         p3_pass3_write<G>(t, lds, v);
     spectrum_sync<G>();
-    if(active)
+    if(process)
         p4_split_smooth<G>(a, t, lds, ts, mag);
+    else if(do_db && !(mono_mix && ch == 1))
+        load_row<G>(rows + (size_t)ch * M, t, mag); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
 
-    if(a.mode & WF_MODE_MONO_MIX) {
-        // reference :150-154: dB[0][i] = dbfs((dB[0][i] + dB[1][i]) * 0.5f); channel 1 keeps its linear
-        // magnitudes in the reference (never displayed) and is not written here.
-        // The two channels of a stream are adjacent spectra of this workgroup (SPW is even).
-        float *xch = reinterpret_cast<float *>(lds); // reuse this spectrum's exchange buffer as float[M]
-        __syncthreads();
-        if(active && ch == 1) {
+    // ---- hidden / capture timeout: reset branch (reference :34-48) ---------------------------------------------
+    bool have_row = false; // this subgroup produces row `ch` (and row 1 too when one captured channel is shown as stereo)
+    float d[P];
+    if(active && hidden && !was_silent) {
+        if(a.mode & WF_MODE_TSMOOTH)
+            fill_row<G>(ts, t, 0.0f);
+        if(ch < (stereo ? 2u : 1u)) {
 #pragma unroll
-            for(int u = 0; u < P / 4; ++u) {
-                const int k0 = 4 * (t + T * u);
-                *reinterpret_cast<f4 *>(xch + k0) = f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]};
-            }
+            for(int i = 0; i < P; ++i)
+                d[i] = a.db_min;
+            have_row = true;
+        }
+    }
+
+    // ---- end-of-tick dB pass (reference :141-179) ------------------------------------------------------------------
+    if(mono_mix) {
+        // dB[0][i] = dbfs((dB[0][i] + dB[1][i]) * 0.5f): channel 1 hands its magnitudes to channel 0 through LDS
+        float *xch = reinterpret_cast<float *>(lds);
+        __syncthreads();
+        if(do_db && ch == 1) {
+#pragma unroll
+            for(int u = 0; u < P / 4; ++u)
+                *reinterpret_cast<f4 *>(xch + 4 * (t + T * u)) = f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]};
         }
         __syncthreads();
-        if(active && ch == 0) {
-            const float *other = reinterpret_cast<const float *>(lds + G::LDS_CF); // the ch-1 spectrum's buffer
+        if(do_db && ch == 0) {
+            const float *other = reinterpret_cast<const float *>(lds + G::LDS_CF);
 #pragma unroll
             for(int u = 0; u < P / 4; ++u) {
-                const int k0 = 4 * (t + T * u);
-                const f4 o = *reinterpret_cast<const f4 *>(other + k0);
+                const f4 o = *reinterpret_cast<const f4 *>(other + 4 * (t + T * u));
                 mag[4 * u] = (mag[4 * u] + o.x) * 0.5f;
                 mag[4 * u + 1] = (mag[4 * u + 1] + o.y) * 0.5f;
                 mag[4 * u + 2] = (mag[4 * u + 2] + o.z) * 0.5f;
                 mag[4 * u + 3] = (mag[4 * u + 3] + o.w) * 0.5f;
             }
-            p4_db_store<G>(a, t, a.decibels + ((size_t)stream * a.out_ch) * M, mag);
         }
-    } else if(active) {
-        // stereo: both channels converted; single captured channel shown as stereo: channel 0 is
-        // duplicated into channel 1 (reference :141-142)
-        p4_db_store<G>(a, t, a.decibels + ((size_t)stream * a.out_ch + ch) * M, mag);
-        if(a.out_ch > a.cap_ch)
-            p4_db_store<G>(a, t, a.decibels + ((size_t)stream * a.out_ch + 1) * M, mag);
+    }
+    if(do_db && !(mono_mix && ch == 1)) {
+        p4_db<G>(a, t, mag, d);
+        have_row = true;
+    }
+    const bool dup_row = have_row && (a.out_ch > a.cap_ch); // one captured channel, two rows (reference :141-142)
+    if(have_row && !a.skip_decibels) {
+        store_row<G>(rows + (size_t)ch * M, t, d);
+        if(dup_row)
+            store_row<G>(rows + (size_t)M, t, d);
+    }
+    if(active && ch == 0 && t == 0)
+        a.stream_flags[stream] = (sflags & WF_STREAM_HIDDEN) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
+
+    // ---- bars: what render_bars derives from the rows just written (reference src/source.cpp:1500-1557) ---------------
+    if(a.bar.out != nullptr) {
+        float *dbl = reinterpret_cast<float *>(lds);
+        spectrum_sync<G>(); // every thread of the spectrum is done reading its exchange buffer
+        if(have_row)
+            store_row<G>(dbl, t, d);
+        spectrum_sync<G>();
+        if(have_row) {
+            float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+            bars_reduce_row<G>(a.bar, dbl, t >> 6, WPS, lane, out0, dup_row ? out0 + a.bar.num_bars : nullptr,
+                               [](float s) { return wave_sum(s); });
+        }
     }
 }
 
@@ -137,6 +224,16 @@ __global__ void wpos_advance_kernel(uint32_t *wpos, uint32_t first, uint32_t cou
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < count)
         wpos[first + i] += frames;
+}
+
+// show()/hide()/capture timeout: set or clear WF_STREAM_HIDDEN, keep m_last_silent
+__global__ void set_hidden_kernel(uint32_t *flags, uint32_t first, uint32_t count, const uint8_t *mask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < count) {
+        const uint32_t f = flags[first + i];
+        flags[first + i] = mask[i] ? (f | WF_STREAM_HIDDEN) : (f & ~WF_STREAM_HIDDEN);
+    }
 }
 
 __global__ void fill_f32_kernel(float *p, size_t n, float v)

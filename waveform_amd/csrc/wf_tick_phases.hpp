@@ -37,6 +37,21 @@ enum : uint32_t {
     WF_STREAM_HIDDEN = 1u << 1,      // !m_show or capture timed out (host sets it)
 };
 
+// bars (render_bars interpolation + dB -> pixel mapping); out == nullptr: the configuration shows no bars
+struct BarArgs {
+    const float *indices;      // m_interp_indices (per sample; per bar edge in POINT mode)
+    const float *weights;      // m_interp_kernel.weights [samples][taps]
+    const int *band_widths;    // m_band_widths [num_bars]
+    const int *band_start;     // exclusive prefix sum of band_widths
+    float *out;                // [n_streams][disp_ch][num_bars]
+    int num_bars;
+    int taps, radius;          // 8/4 Lanczos, 4/2 Catmull-Rom, 0/0 POINT
+    int mirror;
+    float border_top, border_bottom;
+    float ceiling, dbrange;    // m_ceiling, m_ceiling - m_floor
+    uint32_t disp_ch;
+};
+
 struct TickArgs {
     // audio rings: one per (stream, captured channel), ring_cap samples each (power of two)
     const float *ring;
@@ -65,8 +80,8 @@ struct TickArgs {
     uint32_t cap_ch;           // m_capture_channels (1 or 2)
     uint32_t out_ch;           // m_output_channels
     uint32_t mode;
-    // bars (optional)
-    float *bars;               // [n_streams][disp_ch][num_bars] or nullptr
+    uint32_t skip_decibels;    // WF_HIP_TICK_NO_DECIBELS: bars-only batch mode
+    BarArgs bar;
 };
 
 // ---- small helpers ------------------------------------------------------------------------
@@ -102,42 +117,60 @@ WF_DEV float dbfs(float mag, float db_min) { return (mag > 0.0f) ? 20.0f * log10
 // x      : base of this spectrum's ring
 // start  : ring index of the first sample of the window
 // ALIGNED: start % 4 == 0 (vector loads never straddle the ring wrap)
+// p1_fetch copies this thread's share of the window into registers (the reference's peek_front into
+// m_fft_input, :55-59) as smp[j][e] = x[start + 2*(j*M1 + B1*t) + e] and reports whether any of them is
+// non-zero (the reference's silence scan, :63-72).
 template<class G, bool ALIGNED>
-WF_DEV void p1_fetch_pass1(const TickArgs &a, int t, const float *x, uint32_t start, cf *lds)
+WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, float (&smp)[G::R1][2 * G::B1])
 {
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
-    cf u[B1][R1];
-    // fetch (+ window)
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
-        const int c0 = j * M1 + B1 * t; // first complex point of this thread in row j
-        const uint32_t s0 = 2u * (uint32_t)c0;
-        float smp[2 * B1];
+        const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
         if(ALIGNED) {
             if(B1 == 2) {
                 const f4 q = ld4(x + ((start + s0) & a.ring_mask));
-                smp[0] = q.x; smp[1] = q.y; smp[2] = q.z; smp[3] = q.w;
+                smp[j][0] = q.x; smp[j][1] = q.y; smp[j][2 * B1 - 2] = q.z; smp[j][2 * B1 - 1] = q.w;
             } else {
                 const f2 q = ld2(x + ((start + s0) & a.ring_mask));
-                smp[0] = q.x; smp[1] = q.y;
+                smp[j][0] = q.x; smp[j][1] = q.y;
             }
         } else {
             WF_UNROLL
             for(int e = 0; e < 2 * B1; ++e)
-                smp[e] = x[(start + s0 + (uint32_t)e) & a.ring_mask];
+                smp[j][e] = x[(start + s0 + (uint32_t)e) & a.ring_mask];
         }
-        if(a.mode & WF_MODE_WINDOW) {
+    }
+    bool nz = false;
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        WF_UNROLL
+        for(int e = 0; e < 2 * B1; ++e)
+            nz = nz || (smp[j][e] != 0.0f);
+    }
+    return nz;
+}
+
+template<class G>
+WF_DEV void p1_window_pass1(const TickArgs &a, int t, float (&smp)[G::R1][2 * G::B1], cf *lds)
+{
+    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    cf u[B1][R1];
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
+        if(a.mode & WF_MODE_WINDOW) { // reference :97-103
             if(B1 == 2) {
                 const f4 w = ld4(a.window + s0);
-                smp[0] *= w.x; smp[1] *= w.y; smp[2] *= w.z; smp[3] *= w.w;
+                smp[j][0] *= w.x; smp[j][1] *= w.y; smp[j][2 * B1 - 2] *= w.z; smp[j][2 * B1 - 1] *= w.w;
             } else {
                 const f2 w = ld2(a.window + s0);
-                smp[0] *= w.x; smp[1] *= w.y;
+                smp[j][0] *= w.x; smp[j][1] *= w.y;
             }
         }
         WF_UNROLL
         for(int b = 0; b < B1; ++b)
-            u[b][j] = cf{smp[2 * b], smp[2 * b + 1]};
+            u[b][j] = cf{smp[j][2 * b], smp[j][2 * b + 1]};
     }
     // butterflies over n1 (= j), twiddle by W_M^(n' k1), store A'[k1][n']
     WF_UNROLL
@@ -155,7 +188,7 @@ WF_DEV void p1_fetch_pass1(const TickArgs &a, int t, const float *x, uint32_t st
         } else if(B1 == 2) {
             const f4 w = ld4(reinterpret_cast<const float *>(a.tw1 + k1 * M1 + np));
             o[0] = cmul(u[0][brev(k1, LB)], cf{w.x, w.y});
-            o[1] = cmul(u[1][brev(k1, LB)], cf{w.z, w.w});
+            o[B1 - 1] = cmul(u[B1 - 1][brev(k1, LB)], cf{w.z, w.w});
         } else {
             const f2 w = ld2(reinterpret_cast<const float *>(a.tw1 + k1 * M1 + np));
             o[0] = cmul(u[0][brev(k1, LB)], cf{w.x, w.y});
@@ -315,22 +348,22 @@ template<class G> WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf
     }
 }
 
-// dB conversion + volume normalisation + roll-off for bins 4g..4g+3, then store (reference :144-179)
-template<class G> WF_DEV void p4_db_store(const TickArgs &a, int t, float *out, const float (&mag)[G::P])
+// dB conversion + volume normalisation + roll-off of this thread's bins (reference :144-179); d[] is the
+// final m_decibels content, stored by store_row()
+template<class G> WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P])
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         const int k0 = 4 * (t + T * u);
-        float d[4];
         WF_UNROLL
         for(int i = 0; i < 4; ++i)
-            d[i] = dbfs(mag[4 * u + i], a.db_min);
+            d[4 * u + i] = dbfs(mag[4 * u + i], a.db_min);
         if(a.mode & WF_MODE_NORMALIZE) {
             WF_UNROLL
             for(int i = 0; i < 4; ++i)
                 if(k0 + i >= 1) // the generic path starts at i = 1 (reference :165)
-                    d[i] += a.vol_comp;
+                    d[4 * u + i] += a.vol_comp;
         }
         if(a.mode & WF_MODE_ROLLOFF) {
             const f4 r = ld4(a.rolloff + k0);
@@ -338,9 +371,154 @@ template<class G> WF_DEV void p4_db_store(const TickArgs &a, int t, float *out, 
             WF_UNROLL
             for(int i = 0; i < 4; ++i)
                 if(k0 + i >= 1) // reference :173
-                    d[i] = fmaxf(d[i] - rr[i], a.db_min);
+                    d[4 * u + i] = fmaxf(d[4 * u + i] - rr[i], a.db_min);
         }
-        st4(out + k0, f4{d[0], d[1], d[2], d[3]});
+    }
+}
+
+template<class G> WF_DEV void store_row(float *row, int t, const float (&d)[G::P])
+{
+    constexpr int T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u)
+        st4(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
+}
+
+// ---- silence state machine helpers (reference :63-95, :138-139) ------------------------------------
+// "outsilent": every value of the previously displayed row is <= floor - 10.  Each thread looks at the
+// bins it owns in the P4 layout; the caller and-reduces over the spectrum's threads.
+template<class G> WF_DEV bool row_all_below(const float *row, int t, float limit)
+{
+    constexpr int T = G::T, P = G::P;
+    bool below = true;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u) {
+        const f4 d = ld4(row + 4 * (t + T * u));
+        below = below && !(d.x > limit) && !(d.y > limit) && !(d.z > limit) && !(d.w > limit);
+    }
+    return below;
+}
+
+// a skipped channel of a stream that is not silent: the reference's end-of-tick dB pass runs over its
+// *stale* m_decibels row again; load that row as the "magnitudes"
+template<class G> WF_DEV void load_row(const float *row, int t, float (&mag)[G::P])
+{
+    constexpr int T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u) {
+        const f4 d = ld4(row + 4 * (t + T * u));
+        mag[4 * u] = d.x; mag[4 * u + 1] = d.y; mag[4 * u + 2] = d.z; mag[4 * u + 3] = d.w;
+    }
+}
+
+template<class G> WF_DEV void fill_row(float *row, int t, float v)
+{
+    constexpr int T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u)
+        st4(row + 4 * (t + T * u), f4{v, v, v, v});
+}
+
+// The per-stream decision of the channel loop, replayed from the per-channel facts.
+//   last_silent : m_last_silent on entry
+//   nz[c]       : channel c's window has a non-zero sample
+//   below[c]    : the row the reference inspects for channel c (m_decibels[stereo ? c : 0] as left by the
+//                 previous tick) is entirely <= floor - 10
+// Outputs process[c] (run the FFT path for channel c) and the new m_last_silent.
+struct StreamPlan { bool process[2]; bool last_silent; };
+WF_DEV StreamPlan plan_stream(bool last_silent, uint32_t cap_ch, bool stereo, const bool (&nz)[2], const bool (&below)[2])
+{
+    StreamPlan p;
+    p.process[0] = p.process[1] = false;
+    bool ls = last_silent;
+    uint32_t silent_channels = 0;
+    for(uint32_t c = 0; c < cap_ch; ++c) {
+        if(nz[c]) {
+            ls = false;          // reference :68-69
+            p.process[c] = true;
+            continue;
+        }
+        if(ls)
+            continue;            // :76-77
+        // :78-94.  In mono display mode channel 1 inspects row 0, which channel 0 has just overwritten with
+        // linear magnitudes (>= 0 > floor - 10) if it was processed in this tick.
+        bool outsilent = below[c];
+        if(!stereo && c == 1 && p.process[0])
+            outsilent = false;
+        if(outsilent) {
+            if(++silent_channels >= cap_ch)
+                ls = true;
+            continue;
+        }
+        p.process[c] = true;
+    }
+    p.last_silent = ls;
+    return p;
+}
+
+// ---- bars (render_bars interpolation + dB -> pixel mapping, reference src/source.cpp:1500-1557) -------
+
+// std::lerp as libstdc++ evaluates it (reference src/math_funcs.hpp:31-35)
+WF_DEV float lerp_std(float a, float b, float t)
+{
+    if((a <= 0 && b >= 0) || (a >= 0 && b <= 0))
+        return t * b + (1 - t) * a;
+    if(t == 1)
+        return b;
+    const float x = a + t * (b - a);
+    return ((t > 1) == (b > a)) ? (b < x ? x : b) : (b > x ? x : b);
+}
+
+// One wavefront reduces bars wave_id, wave_id + n_waves, ... of one displayed row.
+// db: the row's dB values (LDS, float[M]); lane in [0,64).  The caller supplies wave_sum(), the
+// wavefront all-reduce (+); in the emulator it is a no-op over a single "lane".
+template<class G, class WaveSum>
+WF_DEV void bars_reduce_row(const BarArgs &b, const float *db, int wave_id, int n_waves, int lane, float *out_row, float *dup_row,
+                            WaveSum wave_sum)
+{
+    constexpr int M = G::M;
+    for(int bar = wave_id; bar < b.num_bars; bar += n_waves) {
+        const int count = b.band_widths[bar];
+        float acc = 0.0f;
+        if(b.taps == 0) { // InterpMode::POINT, reference :1525-1532
+            const int base = (int)b.indices[bar];
+            for(int k = lane; k < count; k += 64)
+                acc += db[base + k];
+        } else {          // apply_interp_filter (bars), reference src/filter.hpp:194-211
+            const int start = b.band_start[bar];
+            for(int k = lane; k < count; k += 64) {
+                const int s = start + k;
+                const int ix = (int)b.indices[s];
+                const int first = ix - b.radius + 1;
+                const float *w = b.weights + (size_t)s * b.taps;
+                float sum = 0.0f;
+                for(int tap = 0; tap < b.taps; ++tap) {
+                    const int i = first + tap;
+                    if(i >= 0 && i < M)
+                        sum = fmaf(db[i], w[tap], sum);
+                }
+                acc += sum;
+            }
+        }
+        acc = wave_sum(acc);
+        if(lane == 0) {
+            const float v = acc / (float)count;
+            float tt = b.ceiling - v;                     // reference :1550
+            tt = (tt < 0.0f) ? 0.0f : (b.dbrange < tt) ? b.dbrange : tt;
+            const float y = lerp_std(b.border_top, b.border_bottom, tt / b.dbrange);
+            const int half = b.num_bars / 2;
+            const int img = 2 * half - bar;                // reference :1559-1564: bars above the middle mirror the lower ones
+            const bool own = !b.mirror || bar <= half;
+            const bool image = b.mirror && bar < half && img > half && img < b.num_bars;
+            if(own) {
+                out_row[bar] = y;
+                if(dup_row) dup_row[bar] = y;
+            }
+            if(image) {
+                out_row[img] = y;
+                if(dup_row) dup_row[img] = y;
+            }
+        }
     }
 }
 
