@@ -180,7 +180,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.fft, os.cpu_count() or 1, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(args.fft, len(os.sched_getaffinity(0)) or 1, args.cpu_seconds)
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = None
                 print(f"bench.py: cpu_baseline failed: {e}", file=sys.stderr)

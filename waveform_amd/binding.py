@@ -53,7 +53,10 @@ TICK_NO_DECIBELS = 1
 
 
 def library_path() -> Path:
-    return _HERE / "libwaveform_hip.so"
+    # WF_HIP_LIB: development aid for A/B-ing kernel builds; the default is the in-tree library
+    import os
+    override = os.environ.get("WF_HIP_LIB")
+    return Path(override) if override else _HERE / "libwaveform_hip.so"
 
 
 def lib():

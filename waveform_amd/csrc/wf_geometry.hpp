@@ -7,7 +7,14 @@
 namespace wf {
 using G1024 = Geom<1024, 64, 8, 8, 8>;
 using G2048 = Geom<2048, 64, 8, 16, 8>;
-using G4096 = Geom<4096, 64, 16, 16, 8>;
+#ifndef WF_G4096_T
+#define WF_G4096_T 128
+#endif
+#if WF_G4096_T == 64
+using G4096 = Geom<4096, 64, 16, 16, 8>;   // one wavefront, 32 points per thread
+#else
+using G4096 = Geom<4096, 128, 8, 16, 16>;  // two wavefronts, 16 points per thread: half the registers, twice the waves
+#endif
 using G8192 = Geom<8192, 128, 16, 16, 16>;
 using G16384 = Geom<16384, 256, 16, 16, 32>;
 

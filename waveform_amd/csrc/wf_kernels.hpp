@@ -80,29 +80,31 @@ __global__ __launch_bounds__(G::T *SPW) void spectrum_tick_kernel(const TickArgs
     if(active && !hidden && !wave_nz) // wave-uniform and rare: the whole slice of this wave is digital silence
         wave_below = __all(row_all_below<G>(rows + (size_t)(stereo ? ch : 0u) * M, t, a.silent_floor)) != 0;
 
-    bool nzc[2] = {false, false}, belowc[2] = {true, true};
+    bool nz0 = wave_nz, nz1 = false, below0 = wave_below, below1 = true;
     if(T > 64 || a.cap_ch > 1) {
         if(lane == 0)
             facts[wave_in_block] = (wave_nz ? 1 : 0) | (wave_below ? 2 : 0);
         __syncthreads();
-        for(uint32_t c = 0; c < a.cap_ch; ++c) {
-            const int sb = sub - (int)ch + (int)c; // the subgroup that owns channel c of this stream
-            bool n = false, bl = true;
+        const int sb0 = (sub - (int)ch) * WPS; // first wavefront of the subgroup that owns channel 0 of this stream
+        int or0 = 0, and0 = 3, or1 = 0, and1 = 3;
 #pragma unroll
-            for(int w = 0; w < WPS; ++w) {
-                const int f = facts[sb * WPS + w];
-                n = n || (f & 1);
-                bl = bl && (f & 2);
+        for(int w = 0; w < WPS; ++w) {
+            const int f0 = facts[sb0 + w];
+            or0 |= f0;
+            and0 &= f0;
+            if(a.cap_ch > 1) {
+                const int f1 = facts[sb0 + WPS + w];
+                or1 |= f1;
+                and1 &= f1;
             }
-            nzc[c] = n;
-            belowc[c] = bl;
         }
-    } else {
-        nzc[0] = wave_nz;
-        belowc[0] = wave_below;
+        nz0 = (or0 & 1) != 0;
+        below0 = (and0 & 2) != 0;
+        nz1 = (or1 & 1) != 0;
+        below1 = (and1 & 2) != 0;
     }
-    const StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nzc, belowc);
-    const bool process = active && !hidden && plan.process[ch];
+    const StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nz0, nz1, below0, below1);
+    const bool process = active && !hidden && (ch == 0 ? plan.process0 : plan.process1);
     const bool do_db = active && !hidden && !plan.last_silent; // reference :138-139
 
     // ---- the FFT path --------------------------------------------------------------------------------------

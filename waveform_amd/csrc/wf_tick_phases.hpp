@@ -110,8 +110,41 @@ WF_DEV float mul_rn(float a, float b) { volatile float r = a * b; return r; }
 WF_DEV float add_rn(float a, float b) { volatile float r = a + b; return r; }
 #endif
 
-// dbfs(), reference src/source.hpp:293-299
-WF_DEV float dbfs(float mag, float db_min) { return (mag > 0.0f) ? 20.0f * log10f(mag) : db_min; }
+// dbfs(), reference src/source.hpp:293-299: mag > 0 ? 20*log10f(mag) : DB_MIN.
+// Device form: 20*log10(m) = (20*log10(2)) * log2(m) on the hardware log2 (v_log_f32, <= 1 ulp of its result):
+// relative error of the dB value <= ~2e-7, two instructions instead of ocml's ~15.  v_log_f32 does not take
+// denormals, so magnitudes below FLT_MIN (dB < -758, only reachable by a decaying smoothing tail) go through
+// the accurate ocml log10f.
+#ifndef WF_FAST_DB
+#define WF_FAST_DB 1
+#endif
+WF_DEV float dbfs(float mag, float db_min)
+{
+#if defined(__HIPCC__) && WF_FAST_DB
+    float r;
+    if(__builtin_expect(mag < 1.17549435e-38f, 0))
+        r = (mag > 0.0f) ? 20.0f * log10f(mag) : db_min;
+    else
+        r = __builtin_amdgcn_logf(mag) * 6.02059991327962390f;
+    return r;
+#else
+    return (mag > 0.0f) ? 20.0f * log10f(mag) : db_min;
+#endif
+}
+
+// |2X| from its parts.  hypotf in the reference (:119); here sqrt(fma) on the hardware square root (1 ulp).
+#ifndef WF_FAST_SQRT
+#define WF_FAST_SQRT 1
+#endif
+WF_DEV float mag2(float xr, float xi)
+{
+    const float s = fmaf(xi, xi, xr * xr);
+#if defined(__HIPCC__) && WF_FAST_SQRT
+    return __builtin_amdgcn_sqrtf(s);
+#else
+    return sqrtf(s);
+#endif
+}
 
 // ---- P1: fetch + window + pass 1 ---------------------------------------------------------------
 // x      : base of this spectrum's ring
@@ -324,7 +357,7 @@ template<class G> WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf
             const float pr = fmaf(W[i].x, dr, -(W[i].y * di)); // Re(W D)
             const float pi = fmaf(W[i].x, di, W[i].y * dr);    // Im(W D)
             const float xr = er + pi, xi = ei - pr;
-            m4[i] = sqrtf(fmaf(xi, xi, xr * xr)) * a.half_coef;
+            m4[i] = mag2(xr, xi) * a.half_coef;
         }
         if(a.mode & WF_MODE_SLOPE) {
             const f4 s = ld4(a.slope + k0);
@@ -425,32 +458,39 @@ template<class G> WF_DEV void fill_row(float *row, int t, float v)
 //   below[c]    : the row the reference inspects for channel c (m_decibels[stereo ? c : 0] as left by the
 //                 previous tick) is entirely <= floor - 10
 // Outputs process[c] (run the FFT path for channel c) and the new m_last_silent.
-struct StreamPlan { bool process[2]; bool last_silent; };
-WF_DEV StreamPlan plan_stream(bool last_silent, uint32_t cap_ch, bool stereo, const bool (&nz)[2], const bool (&below)[2])
+struct StreamPlan { bool process0, process1; bool last_silent; };
+WF_DEV StreamPlan plan_stream(bool last_silent, uint32_t cap_ch, bool stereo, bool nz0, bool nz1, bool below0, bool below1)
 {
     StreamPlan p;
-    p.process[0] = p.process[1] = false;
+    p.process0 = p.process1 = false;
     bool ls = last_silent;
     uint32_t silent_channels = 0;
-    for(uint32_t c = 0; c < cap_ch; ++c) {
-        if(nz[c]) {
-            ls = false;          // reference :68-69
-            p.process[c] = true;
-            continue;
-        }
-        if(ls)
-            continue;            // :76-77
-        // :78-94.  In mono display mode channel 1 inspects row 0, which channel 0 has just overwritten with
-        // linear magnitudes (>= 0 > floor - 10) if it was processed in this tick.
-        bool outsilent = below[c];
-        if(!stereo && c == 1 && p.process[0])
-            outsilent = false;
-        if(outsilent) {
+    // channel 0
+    if(nz0) {
+        ls = false;              // reference :68-69
+        p.process0 = true;
+    } else if(!ls) {             // :76-77
+        if(below0) {             // :78-94
             if(++silent_channels >= cap_ch)
                 ls = true;
-            continue;
+        } else
+            p.process0 = true;
+    }
+    // channel 1
+    if(cap_ch > 1) {
+        if(nz1) {
+            ls = false;
+            p.process1 = true;
+        } else if(!ls) {
+            // In mono display mode channel 1 inspects row 0, which channel 0 has just overwritten with linear
+            // magnitudes (>= 0 > floor - 10) if it was processed in this tick.
+            const bool outsilent = below1 && !(!stereo && p.process0);
+            if(outsilent) {
+                if(++silent_channels >= cap_ch)
+                    ls = true;
+            } else
+                p.process1 = true;
         }
-        p.process[c] = true;
     }
     p.last_silent = ls;
     return p;
