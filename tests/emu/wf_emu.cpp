@@ -105,11 +105,12 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
     a.ring_cap = ring_cap;
     a.ring_mask = ring_cap - 1;
     a.delay = delay;
-    a.window = tab.window.empty() ? nullptr : tab.window.data();
+    const std::vector<float> ones_n((size_t)G::N, 1.0f), ones_m((size_t)G::M, 1.0f);
+    a.window = tab.window.empty() ? ones_n.data() : tab.window.data();
     a.tw1 = reinterpret_cast<const cf *>(tw1.data());
     a.tw2 = reinterpret_cast<const cf *>(tw2.data());
     a.tws = reinterpret_cast<const cf *>(tws.data());
-    a.slope = tab.slope.empty() ? nullptr : tab.slope.data();
+    a.slope = tab.slope.empty() ? ones_m.data() : tab.slope.data();
     a.rolloff = tab.rolloff.empty() ? nullptr : tab.rolloff.data();
     a.tsmooth = tsmooth;
     a.decibels = decibels;
@@ -132,7 +133,7 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
     ConflictStats st[2];
     std::vector<cf> lds((size_t)G::LDS_CF);
     std::vector<std::vector<emu::Access>> traces((size_t)T);
-    struct Regs { cf v[P]; float mag[P]; float d[P]; float smp[G::R1][2 * G::B1]; };
+    struct Regs { cf v[P]; float mag[P]; float d[P]; P1Regs<G> r1; P4Regs<G> r4; };
     std::vector<Regs> regs((size_t)T);
 
     auto census_waves = [&](bool enable) {
@@ -163,15 +164,16 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
         const bool aligned = (start % 4u) == 0;
         std::fill(lds.begin(), lds.end(), cf{1e30f, 1e30f}); // poison: unwritten reads show up
         phase(c, [&](int t) {
-            if(aligned) p1_fetch<G, true>(a, t, x, start, regs[(size_t)t].smp);
-            else p1_fetch<G, false>(a, t, x, start, regs[(size_t)t].smp);
-            p1_window_pass1<G>(a, t, regs[(size_t)t].smp, lds.data());
+            if(aligned) p1_fetch<G, true>(a, t, x, start, regs[(size_t)t].r1);
+            else p1_fetch<G, false>(a, t, x, start, regs[(size_t)t].r1);
+            p1_window_pass1<G>(a, t, regs[(size_t)t].r1, lds.data());
+            p4_prefetch<G>(a, t, ts, regs[(size_t)t].r4);
         });
         phase(c, [&](int t) { p2_read<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p2_pass2_write<G>(a, t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p3_read<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p3_pass3_write<G>(t, lds.data(), regs[(size_t)t].v); });
-        phase(c, [&](int t) { p4_split_smooth<G>(a, t, lds.data(), ts, regs[(size_t)t].mag); });
+        phase(c, [&](int t) { p4_split_smooth<G>(a, t, lds.data(), ts, regs[(size_t)t].r1.wb, regs[(size_t)t].r4, regs[(size_t)t].mag); });
         phase(false, [&](int t) {
             p4_db<G>(a, t, regs[(size_t)t].mag, regs[(size_t)t].d);
             store_row<G>(out, t, regs[(size_t)t].d);

@@ -49,6 +49,7 @@ struct wf_hip {
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
     float *d_interp_indices = nullptr, *d_interp_weights = nullptr;
     int *d_band_widths = nullptr, *d_band_start = nullptr;
+    unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;
     float *d_stage = nullptr;
@@ -189,9 +190,9 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     if(h->cfg.tsmoothing != WF_TSMOOTH_NONE) mode |= wf::WF_MODE_TSMOOTH;
     if(h->cfg.fast_peaks) mode |= wf::WF_MODE_FAST_PEAKS;
     if(h->cfg.stereo) mode |= wf::WF_MODE_STEREO;
-    if(h->d_slope) mode |= wf::WF_MODE_SLOPE;
+    if(!h->tab.slope.empty()) mode |= wf::WF_MODE_SLOPE;
     if(h->d_rolloff) mode |= wf::WF_MODE_ROLLOFF;
-    if(h->d_window) mode |= wf::WF_MODE_WINDOW;
+    if(!h->tab.window.empty()) mode |= wf::WF_MODE_WINDOW;
     if(!h->cfg.stereo && h->cap_ch > 1) mode |= wf::WF_MODE_MONO_MIX;
     if(h->cfg.normalize_volume) {
         mode |= wf::WF_MODE_NORMALIZE;
@@ -200,6 +201,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.vol_comp = std::min(h->cfg.volume_target - rms_db, h->cfg.max_gain);
     }
     a.mode = mode;
+    a.phase_clock = h->d_phase_clock;
     return a;
 }
 
@@ -335,8 +337,16 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(h->num_bars)
         WF_CREATE_TRY(dev_alloc(h, &h->d_bars, (size_t)h->n_streams * h->disp_ch * h->num_bars));
 
-    WF_CREATE_TRY(upload(h, &h->d_window, h->tab.window));
-    WF_CREATE_TRY(upload(h, &h->d_slope, h->tab.slope));
+#ifdef WF_PHASE_TIMING
+    WF_CREATE_TRY(dev_alloc(h, &h->d_phase_clock, n_spec * 16));
+#endif
+    // the kernel always multiplies by the window and slope tables; a disabled feature is a table of ones (x * 1.0f == x)
+    {
+        const std::vector<float> ones_n(h->N, 1.0f), ones_m(h->M, 1.0f);
+        WF_CREATE_TRY(upload(h, &h->d_window, h->tab.window.empty() ? ones_n : h->tab.window));
+        WF_CREATE_TRY(upload(h, &h->d_slope, h->tab.slope.empty() ? ones_m : h->tab.slope));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+    }
     WF_CREATE_TRY(upload(h, &h->d_rolloff, h->tab.rolloff));
     std::vector<int> band_start;
     if(h->num_bars) {
@@ -674,6 +684,16 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
     *avg_kernel_ms = ms / (float)ticks;
     return WF_HIP_OK;
 }
+
+#ifdef WF_PHASE_TIMING
+// development aid: copies the per-workgroup s_memtime stamps of the last tick (16 per workgroup)
+extern "C" int wf_hip_debug_phase_clock(wf_hip *h, unsigned long long *out, size_t n)
+{
+    if(hipMemcpy(out, h->d_phase_clock, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return WF_HIP_ERR_RUNTIME;
+    return WF_HIP_OK;
+}
+#endif
 
 const char *wf_hip_kernel_name(const wf_hip *h) { return h ? h->kernel_name.c_str() : ""; }
 

@@ -41,8 +41,18 @@ __device__ __forceinline__ float wave_sum(float v)
 // Dynamic LDS: SPW exchange buffers of G::LDS_CF complex each, then one int of per-wavefront facts per wave.
 template<class G, int SPW> constexpr size_t tick_lds_bytes() { return (size_t)SPW * G::LDS_CF * sizeof(cf) + (size_t)SPW * (G::T / 64) * sizeof(int) + 16; }
 
+#ifdef WF_PHASE_TIMING
+#define WF_STAMP(i)                                                                      \
+    do {                                                                                 \
+        if(threadIdx.x == 0 && a.phase_clock)                                            \
+            a.phase_clock[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while(0)
+#else
+#define WF_STAMP(i)
+#endif
+
 template<class G, int SPW, bool ALIGNED>
-__global__ __launch_bounds__(G::T *SPW) void spectrum_tick_kernel(const TickArgs a)
+__global__ __launch_bounds__(G::T *SPW, ((G::P <= 8) ? 4 : 3) * (G::T * SPW) / 256 > 0 ? ((G::P <= 8) ? 4 : 3) : 1) void spectrum_tick_kernel(const TickArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int T = G::T, M = G::M, P = G::P, WPS = G::T / 64;
@@ -70,12 +80,14 @@ __global__ __launch_bounds__(G::T *SPW) void spectrum_tick_kernel(const TickArgs
     const bool hidden = (sflags & WF_STREAM_HIDDEN) != 0;
     const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
 
+    WF_STAMP(0);
     // ---- fetch the window; per-wavefront facts for the silence state machine (reference :55-95) ----------
-    float smp[G::R1][2 * G::B1];
+    P1Regs<G> r1;
     bool nz = false;
     if(active && !hidden)
-        nz = p1_fetch<G, ALIGNED>(a, t, x, start, smp);
+        nz = p1_fetch<G, ALIGNED>(a, t, x, start, r1);
     const bool wave_nz = __any(nz) != 0;
+    WF_STAMP(1);
     bool wave_below = true;
     if(active && !hidden && !wave_nz) // wave-uniform and rare: the whole slice of this wave is digital silence
         wave_below = __all(row_all_below<G>(rows + (size_t)(stereo ? ch : 0u) * M, t, a.silent_floor)) != 0;
@@ -110,26 +122,38 @@ __global__ __launch_bounds__(G::T *SPW) void spectrum_tick_kernel(const TickArgs
     // ---- the FFT path --------------------------------------------------------------------------------------
     cf v[P];
     float mag[P];
-    if(process)
-        p1_window_pass1<G>(a, t, smp, lds);
+    WF_STAMP(2);
+    P4Regs<G> r4;
+    if(process) {
+        p1_window_pass1<G>(a, t, r1, lds);
+        p4_prefetch<G>(a, t, ts, r4);
+    }
+    __builtin_amdgcn_sched_barrier(0); // keep the prefetch up here: do not sink it to its first use in P4
+    WF_STAMP(3);
     spectrum_sync<G>();
     if(process)
         p2_read<G>(t, lds, v);
     spectrum_sync<G>();
+    WF_STAMP(4);
     if(process)
         p2_pass2_write<G>(a, t, lds, v);
+    WF_STAMP(5);
     spectrum_sync<G>();
     if(process)
         p3_read<G>(t, lds, v);
     spectrum_sync<G>();
+    WF_STAMP(6);
     if(process)
         p3_pass3_write<G>(t, lds, v);
+    WF_STAMP(7);
     spectrum_sync<G>();
+    WF_STAMP(8);
     if(process)
-        p4_split_smooth<G>(a, t, lds, ts, mag);
+        p4_split_smooth<G>(a, t, lds, ts, r1.wb, r4, mag);
     else if(do_db && !(mono_mix && ch == 1))
         load_row<G>(rows + (size_t)ch * M, t, mag); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
 
+    WF_STAMP(9);
     // ---- hidden / capture timeout: reset branch (reference :34-48) ---------------------------------------------
     bool have_row = false; // this subgroup produces row `ch` (and row 1 too when one captured channel is shown as stereo)
     float d[P];
@@ -173,10 +197,11 @@ __global__ __launch_bounds__(G::T *SPW) void spectrum_tick_kernel(const TickArgs
     }
     const bool dup_row = have_row && (a.out_ch > a.cap_ch); // one captured channel, two rows (reference :141-142)
     if(have_row && !a.skip_decibels) {
-        store_row<G>(rows + (size_t)ch * M, t, d);
+        store_row_stream<G>(rows + (size_t)ch * M, t, d);
         if(dup_row)
-            store_row<G>(rows + (size_t)M, t, d);
+            store_row_stream<G>(rows + (size_t)M, t, d);
     }
+    WF_STAMP(10);
     if(active && ch == 0 && t == 0)
         a.stream_flags[stream] = (sflags & WF_STREAM_HIDDEN) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
 

@@ -60,11 +60,11 @@ struct TickArgs {
     uint32_t ring_cap;
     uint32_t delay;            // frames between the end of the window and wpos (A/V sync, reference :50-51)
     // per-configuration tables (read-only, shared by every stream)
-    const float *window;       // [N]
+    const float *window;       // [N]; all ones when FFTWindow::NONE
     const cf *tw1;             // [R1][M/R1]   W_M^(n' k1)
     const cf *tw2;             // [R2][R3]     W_(R2 R3)^(n3 k2)
     const cf *tws;             // [M]          W_N^k
-    const float *slope;        // [M]
+    const float *slope;        // [M]; all ones when m_slope <= 0
     const float *rolloff;      // [M]
     // per-spectrum state and outputs
     float *tsmooth;            // [n_streams * cap_ch][M]   m_tsmooth_buf
@@ -82,12 +82,44 @@ struct TickArgs {
     uint32_t mode;
     uint32_t skip_decibels;    // WF_HIP_TICK_NO_DECIBELS: bars-only batch mode
     BarArgs bar;
+    unsigned long long *phase_clock; // development aid (builds with -DWF_PHASE_TIMING): s_memtime stamps per workgroup
 };
 
 // ---- small helpers ------------------------------------------------------------------------
 WF_DEV f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 WF_DEV f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
 WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+// Streaming variants for data that is touched once per tick (audio window, smoothing state, dB rows):
+// non-temporal, so the ~60 KB of per-configuration tables (window, twiddles, slope) stay in L2 instead of
+// being evicted by the 335 MB/tick stream.
+#ifndef WF_NT_STREAM
+#define WF_NT_STREAM 0 // measured on MI355X: non-temporal streaming is slower here (consecutive ticks' windows overlap by
+                       // 80 % and the state is re-read every tick; both are served by the 256 MB Infinity Cache)
+#endif
+#if defined(__HIPCC__) && WF_NT_STREAM
+typedef float wf_v4f __attribute__((ext_vector_type(4)));
+typedef float wf_v2f __attribute__((ext_vector_type(2)));
+WF_DEV f4 ld4_stream(const float *p)
+{
+    const wf_v4f v = __builtin_nontemporal_load(reinterpret_cast<const wf_v4f *>(p));
+    return f4{v.x, v.y, v.z, v.w};
+}
+WF_DEV f2 ld2_stream(const float *p)
+{
+    const wf_v2f v = __builtin_nontemporal_load(reinterpret_cast<const wf_v2f *>(p));
+    return f2{v.x, v.y};
+}
+WF_DEV float ld1_stream(const float *p) { return __builtin_nontemporal_load(p); }
+WF_DEV void st4_stream(float *p, f4 v)
+{
+    __builtin_nontemporal_store(wf_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<wf_v4f *>(p));
+}
+#else
+WF_DEV f4 ld4_stream(const float *p) { return ld4(p); }
+WF_DEV f2 ld2_stream(const float *p) { return ld2(p); }
+WF_DEV float ld1_stream(const float *p) { return *p; }
+WF_DEV void st4_stream(float *p, f4 v) { st4(p, v); }
+#endif
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
 // WF_LDS_TRACE is defined only by the g++ wavefront emulator in tests/emu to record
@@ -153,8 +185,60 @@ WF_DEV float mag2(float xr, float xi)
 // p1_fetch copies this thread's share of the window into registers (the reference's peek_front into
 // m_fft_input, :55-59) as smp[j][e] = x[start + 2*(j*M1 + B1*t) + e] and reports whether any of them is
 // non-zero (the reference's silence scan, :63-72).
+// Everything pass 1 and the real split need from HBM/L2, issued back to back so the latencies overlap:
+//   smp   this thread's share of the window (the reference's peek_front into m_fft_input, :55-59):
+//         smp[j][e] = x[start + 2*(j*M1 + B1*t) + e]
+//   win   the window coefficients of the same samples (:97-103)
+//   tw1   W_M^(n' k1) for this thread's n' (k1 = 1..R1-1)
+//   wb    W_N^(4t+i), i = 0..3: the real-split twiddles of this thread's first bin group; the other groups
+//         are wb * W_N^(4Tu) = wb * W_32^(u*64/P) (exact multiples of 1/32 turn)
+// Prefetch policy.  Threads that own 32 points (N >= 8192) have no registers to spare: they load the window and
+// twiddles where they are used.  Threads with <= 16 points hold them from the start (EARLY_TABLES) and prefetch the
+// smoothing state (and, optionally, the slope table) while passes 2-3 run.
+#ifndef WF_PREFETCH_SLOPE
+#define WF_PREFETCH_SLOPE 1
+#endif
+template<class G> struct Policy {
+    static constexpr bool EARLY_TABLES = (G::P <= 16);
+    static constexpr bool PREFETCH_STATE = (G::P <= 16);
+    static constexpr bool PREFETCH_SLOPE = (G::P <= 16) && WF_PREFETCH_SLOPE;
+};
+template<class G> struct P1Regs {
+    float smp[G::R1][2 * G::B1];
+    float win[Policy<G>::EARLY_TABLES ? G::R1 : 1][2 * G::B1];
+    float tw1[Policy<G>::EARLY_TABLES ? G::R1 : 1][2 * G::B1];
+    cf wb[4];
+};
+
+// window coefficients / pass-1 twiddles of row j of this thread
+template<class G> WF_DEV void p1_load_window(const TickArgs &a, int t, int j, float (&win)[2 * G::B1])
+{
+    constexpr int B1 = G::B1, M1 = G::M1;
+    const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
+    if(B1 == 2) {
+        const f4 w = ld4(a.window + s0);
+        win[0] = w.x; win[1] = w.y; win[2 * B1 - 2] = w.z; win[2 * B1 - 1] = w.w;
+    } else {
+        const f2 w = ld2(a.window + s0);
+        win[0] = w.x; win[1] = w.y;
+    }
+}
+template<class G> WF_DEV void p1_load_tw1(const TickArgs &a, int t, int k1, float (&tw1)[2 * G::B1])
+{
+    constexpr int B1 = G::B1, M1 = G::M1;
+    const float *tw = reinterpret_cast<const float *>(a.tw1 + k1 * M1 + B1 * t);
+    if(B1 == 2) {
+        const f4 w = ld4(tw);
+        tw1[0] = w.x; tw1[1] = w.y; tw1[2 * B1 - 2] = w.z; tw1[2 * B1 - 1] = w.w;
+    } else {
+        const f2 w = ld2(tw);
+        tw1[0] = w.x; tw1[1] = w.y;
+    }
+}
+
+// returns whether any sample of this thread is non-zero (the reference's silence scan, :63-72)
 template<class G, bool ALIGNED>
-WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, float (&smp)[G::R1][2 * G::B1])
+WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
 {
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
     WF_UNROLL
@@ -162,48 +246,59 @@ WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, f
         const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
         if(ALIGNED) {
             if(B1 == 2) {
-                const f4 q = ld4(x + ((start + s0) & a.ring_mask));
-                smp[j][0] = q.x; smp[j][1] = q.y; smp[j][2 * B1 - 2] = q.z; smp[j][2 * B1 - 1] = q.w;
+                const f4 q = ld4_stream(x + ((start + s0) & a.ring_mask));
+                r.smp[j][0] = q.x; r.smp[j][1] = q.y; r.smp[j][2 * B1 - 2] = q.z; r.smp[j][2 * B1 - 1] = q.w;
             } else {
-                const f2 q = ld2(x + ((start + s0) & a.ring_mask));
-                smp[j][0] = q.x; smp[j][1] = q.y;
+                const f2 q = ld2_stream(x + ((start + s0) & a.ring_mask));
+                r.smp[j][0] = q.x; r.smp[j][1] = q.y;
             }
         } else {
             WF_UNROLL
             for(int e = 0; e < 2 * B1; ++e)
-                smp[j][e] = x[(start + s0 + (uint32_t)e) & a.ring_mask];
+                r.smp[j][e] = ld1_stream(x + ((start + s0 + (uint32_t)e) & a.ring_mask));
         }
+    }
+    if(Policy<G>::EARLY_TABLES) {
+        WF_UNROLL
+        for(int j = 0; j < R1; ++j) {
+            p1_load_window<G>(a, t, j, r.win[Policy<G>::EARLY_TABLES ? j : 0]);
+            if(j >= 1)
+                p1_load_tw1<G>(a, t, j, r.tw1[Policy<G>::EARLY_TABLES ? j : 0]);
+        }
+    }
+    if(Policy<G>::EARLY_TABLES) {
+        const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + 4 * t));
+        const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + 4 * t + 2));
+        r.wb[0] = cf{wa.x, wa.y}; r.wb[1] = cf{wa.z, wa.w}; r.wb[2] = cf{wc.x, wc.y}; r.wb[3] = cf{wc.z, wc.w};
     }
     bool nz = false;
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
         WF_UNROLL
         for(int e = 0; e < 2 * B1; ++e)
-            nz = nz || (smp[j][e] != 0.0f);
+            nz = nz || (r.smp[j][e] != 0.0f);
     }
     return nz;
 }
 
 template<class G>
-WF_DEV void p1_window_pass1(const TickArgs &a, int t, float (&smp)[G::R1][2 * G::B1], cf *lds)
+WF_DEV void p1_window_pass1(const TickArgs &a, int t, P1Regs<G> &r, cf *lds)
 {
-    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    constexpr int R1 = G::R1, B1 = G::B1;
+    constexpr bool EARLY = Policy<G>::EARLY_TABLES;
     cf u[B1][R1];
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
-        const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
-        if(a.mode & WF_MODE_WINDOW) { // reference :97-103
-            if(B1 == 2) {
-                const f4 w = ld4(a.window + s0);
-                smp[j][0] *= w.x; smp[j][1] *= w.y; smp[j][2 * B1 - 2] *= w.z; smp[j][2 * B1 - 1] *= w.w;
-            } else {
-                const f2 w = ld2(a.window + s0);
-                smp[j][0] *= w.x; smp[j][1] *= w.y;
-            }
-        }
+        float win_late[2 * B1];
+        if(!EARLY)
+            p1_load_window<G>(a, t, j, win_late);
+        // in[i] *= window[i] (reference :97-103); the table is all ones for FFTWindow::NONE (x * 1.0f == x)
+        WF_UNROLL
+        for(int e = 0; e < 2 * B1; ++e)
+            r.smp[j][e] *= EARLY ? r.win[EARLY ? j : 0][e] : win_late[e];
         WF_UNROLL
         for(int b = 0; b < B1; ++b)
-            u[b][j] = cf{smp[j][2 * b], smp[j][2 * b + 1]};
+            u[b][j] = cf{r.smp[j][2 * b], r.smp[j][2 * b + 1]};
     }
     // butterflies over n1 (= j), twiddle by W_M^(n' k1), store A'[k1][n']
     WF_UNROLL
@@ -214,22 +309,43 @@ WF_DEV void p1_window_pass1(const TickArgs &a, int t, float (&smp)[G::R1][2 * G:
     for(int k1 = 0; k1 < R1; ++k1) {
         const int np = B1 * t;
         cf o[B1];
-        if(k1 == 0) {
-            WF_UNROLL
-            for(int b = 0; b < B1; ++b)
-                o[b] = u[b][0];
-        } else if(B1 == 2) {
-            const f4 w = ld4(reinterpret_cast<const float *>(a.tw1 + k1 * M1 + np));
-            o[0] = cmul(u[0][brev(k1, LB)], cf{w.x, w.y});
-            o[B1 - 1] = cmul(u[B1 - 1][brev(k1, LB)], cf{w.z, w.w});
-        } else {
-            const f2 w = ld2(reinterpret_cast<const float *>(a.tw1 + k1 * M1 + np));
-            o[0] = cmul(u[0][brev(k1, LB)], cf{w.x, w.y});
-        }
+        float tw_late[2 * B1];
+        if(!EARLY && k1 >= 1)
+            p1_load_tw1<G>(a, t, k1, tw_late);
+        WF_UNROLL
+        for(int b = 0; b < B1; ++b)
+            o[b] = (k1 == 0) ? u[b][0]
+                             : cmul(u[b][brev(k1, LB)], EARLY ? cf{r.tw1[EARLY ? k1 : 0][2 * b], r.tw1[EARLY ? k1 : 0][2 * b + 1]}
+                                                            : cf{tw_late[2 * b], tw_late[2 * b + 1]});
         if(B1 == 2)
             lds_st4(lds, ex1_addr<G>(k1, np), o[0], o[B1 - 1]);
         else
             lds_st2(lds, ex1_addr<G>(k1, np), o[0]);
+    }
+}
+
+// Issued as soon as pass 1 has freed its registers so that the HBM latency of the smoothing state (and the
+// L2 latency of the slope table) is covered by passes 2 and 3 instead of being paid in P4.
+template<class G> struct P4Regs {
+    float st[Policy<G>::PREFETCH_STATE ? G::P : 1]; // m_tsmooth_buf of this thread's bins
+    float sl[Policy<G>::PREFETCH_SLOPE ? G::P : 1]; // m_slope_modifiers of this thread's bins
+};
+template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float *ts, P4Regs<G> &q)
+{
+    constexpr int T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u) {
+        const int k0 = 4 * (t + T * u);
+        if(Policy<G>::PREFETCH_STATE && (a.mode & WF_MODE_TSMOOTH)) {
+            constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
+            const f4 o = ld4_stream(ts + k0);
+            q.st[S * (4 * u)] = o.x; q.st[S * (4 * u + 1)] = o.y; q.st[S * (4 * u + 2)] = o.z; q.st[S * (4 * u + 3)] = o.w;
+        }
+        if(Policy<G>::PREFETCH_SLOPE) {
+            constexpr int S = Policy<G>::PREFETCH_SLOPE ? 1 : 0;
+            const f4 o = ld4(a.slope + k0);
+            q.sl[S * (4 * u)] = o.x; q.sl[S * (4 * u + 1)] = o.y; q.sl[S * (4 * u + 2)] = o.z; q.sl[S * (4 * u + 3)] = o.w;
+        }
     }
 }
 
@@ -335,7 +451,8 @@ template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
 // ---- P4: real split + epilogue ------------------------------------------------------------------
 // Produces the smoothed linear magnitudes of bins 4g..4g+3 (g = t + T*u) in mag[u][0..3],
 // updating the temporal-smoothing state on the way (reference :110-135).
-template<class G> WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
+template<class G>
+WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[G::P])
 {
     constexpr int M = G::M, T = G::T, P = G::P;
     WF_UNROLL
@@ -344,36 +461,60 @@ template<class G> WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf
         const f4 za = lds_ld4(lds, ex3_addr<G>(k0));
         const f4 zb = lds_ld4(lds, ex3_addr<G>(k0 + 2));
         const cf A[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
-        const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + k0));
-        const f4 wb = ld4(reinterpret_cast<const float *>(a.tws + k0 + 2));
-        const cf W[4] = {{wa.x, wa.y}, {wa.z, wa.w}, {wb.x, wb.y}, {wb.z, wb.w}};
         float m4[4];
+        cf Wl[4];
+        if(!Policy<G>::EARLY_TABLES) { // threads short of registers read the split twiddles where they are used
+            const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + k0));
+            const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + k0 + 2));
+            Wl[0] = cf{wa.x, wa.y}; Wl[1] = cf{wa.z, wa.w}; Wl[2] = cf{wc.x, wc.y}; Wl[3] = cf{wc.z, wc.w};
+        }
         WF_UNROLL
         for(int i = 0; i < 4; ++i) {
+            const cf W = Policy<G>::EARLY_TABLES ? mul_w32(wb[i], u * (64 / P)) : Wl[i]; // W_N^(k0 + i)
             const cf B = lds_ld2(lds, ex3_addr<G>((M - k0 - i) & (M - 1)));
             // 2X[k] = (A + conj B) - i W (A - conj B)
             const float er = A[i].x + B.x, ei = A[i].y - B.y;
             const float dr = A[i].x - B.x, di = A[i].y + B.y;
-            const float pr = fmaf(W[i].x, dr, -(W[i].y * di)); // Re(W D)
-            const float pi = fmaf(W[i].x, di, W[i].y * dr);    // Im(W D)
+            const float pr = fmaf(W.x, dr, -(W.y * di)); // Re(W D)
+            const float pi = fmaf(W.x, di, W.y * dr);    // Im(W D)
             const float xr = er + pi, xi = ei - pr;
             m4[i] = mag2(xr, xi) * a.half_coef;
         }
-        if(a.mode & WF_MODE_SLOPE) {
-            const f4 s = ld4(a.slope + k0);
-            m4[0] *= s.x; m4[1] *= s.y; m4[2] *= s.z; m4[3] *= s.w;
+        { // mag *= m_slope_modifiers[i] (reference :121-122); the table is all ones when m_slope <= 0
+            float sl4[4];
+            if(Policy<G>::PREFETCH_SLOPE) {
+                constexpr int S = Policy<G>::PREFETCH_SLOPE ? 1 : 0;
+                WF_UNROLL
+                for(int i = 0; i < 4; ++i)
+                    sl4[i] = q.sl[S * (4 * u + i)];
+            } else {
+                const f4 o = ld4(a.slope + k0);
+                sl4[0] = o.x; sl4[1] = o.y; sl4[2] = o.z; sl4[3] = o.w;
+            }
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i)
+                m4[i] *= sl4[i];
         }
         if(a.mode & WF_MODE_TSMOOTH) {
-            const f4 o = ld4(ts + k0);
-            float old[4] = {o.x, o.y, o.z, o.w};
+            float st4v[4];
+            if(Policy<G>::PREFETCH_STATE) {
+                constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
+                WF_UNROLL
+                for(int i = 0; i < 4; ++i)
+                    st4v[i] = q.st[S * (4 * u + i)];
+            } else {
+                const f4 o = ld4_stream(ts + k0);
+                st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
+            }
             WF_UNROLL
             for(int i = 0; i < 4; ++i) {
+                float old = st4v[i];
                 if(a.mode & WF_MODE_FAST_PEAKS)
-                    old[i] = fmaxf(m4[i], old[i]);
+                    old = fmaxf(m4[i], old);
                 // (g * oldval) + (g2 * mag), each product rounded (reference :130, no contraction)
-                m4[i] = add_rn(mul_rn(a.g, old[i]), mul_rn(a.g2, m4[i]));
+                m4[i] = add_rn(mul_rn(a.g, old), mul_rn(a.g2, m4[i]));
             }
-            st4(ts + k0, f4{m4[0], m4[1], m4[2], m4[3]});
+            st4_stream(ts + k0, f4{m4[0], m4[1], m4[2], m4[3]});
         }
         WF_UNROLL
         for(int i = 0; i < 4; ++i)
@@ -415,6 +556,14 @@ template<class G> WF_DEV void store_row(float *row, int t, const float (&d)[G::P
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u)
         st4(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
+}
+// the same to an m_decibels row in HBM (streaming store)
+template<class G> WF_DEV void store_row_stream(float *row, int t, const float (&d)[G::P])
+{
+    constexpr int T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u)
+        st4_stream(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
 }
 
 // ---- silence state machine helpers (reference :63-95, :138-139) ------------------------------------
