@@ -170,7 +170,7 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
             p4_prefetch<G>(a, t, ts, regs[(size_t)t].r4);
         });
         phase(c, [&](int t) { p2_read<G>(t, lds.data(), regs[(size_t)t].v); });
-        phase(c, [&](int t) { p2_pass2_write<G>(a, t, lds.data(), regs[(size_t)t].v); });
+        phase(false, [&](int t) { p2_pass2_write<G>(a.tw2, t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p3_read<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p3_pass3_write<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p4_split_smooth<G>(a, t, lds.data(), ts, regs[(size_t)t].r1.wb, regs[(size_t)t].r4, regs[(size_t)t].mag); });

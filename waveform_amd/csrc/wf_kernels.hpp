@@ -38,8 +38,18 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// Dynamic LDS: SPW exchange buffers of G::LDS_CF complex each, then one int of per-wavefront facts per wave.
-template<class G, int SPW> constexpr size_t tick_lds_bytes() { return (size_t)SPW * G::LDS_CF * sizeof(cf) + (size_t)SPW * (G::T / 64) * sizeof(int) + 16; }
+// Dynamic LDS: SPW exchange buffers of G::LDS_CF complex each, the pass-2 twiddle table [R2][R3], then one int of
+// per-wavefront facts per wave.
+template<class G, int SPW> constexpr size_t tick_lds_bytes()
+{
+    return (size_t)SPW * G::LDS_CF * sizeof(cf) + (size_t)G::R2 * G::R3 * sizeof(cf) + (size_t)SPW * (G::T / 64) * sizeof(int) + 16;
+}
+
+// register budget: waves per SIMD the kernel is compiled for (launch_bounds' second argument)
+#ifndef WF_WPS_P16
+#define WF_WPS_P16 3
+#endif
+#define WF_WAVES_PER_SIMD(G) ((G::P <= 8) ? 4 : (G::P <= 16) ? WF_WPS_P16 : 3)
 
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \
@@ -52,12 +62,12 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes() { return (size_t)SP
 #endif
 
 template<class G, int SPW, bool ALIGNED>
-__global__ __launch_bounds__(G::T *SPW, ((G::P <= 8) ? 4 : 3) * (G::T * SPW) / 256 > 0 ? ((G::P <= 8) ? 4 : 3) : 1) void spectrum_tick_kernel(const TickArgs a)
+__global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int T = G::T, M = G::M, P = G::P, WPS = G::T / 64;
     const int tid = (int)threadIdx.x;
-    const int sub = tid / T;          // which spectrum of the workgroup
+    const int sub = __builtin_amdgcn_readfirstlane(tid / T); // which spectrum of the workgroup (wave-uniform: T % 64 == 0)
     const int t = tid % T;            // thread within the spectrum
     const int lane = tid & 63;
     const int wave_in_block = tid >> 6;
@@ -70,7 +80,10 @@ __global__ __launch_bounds__(G::T *SPW, ((G::P <= 8) ? 4 : 3) * (G::T * SPW) / 2
     const bool mono_mix = (a.mode & WF_MODE_MONO_MIX) != 0;
 
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * G::LDS_CF;
-    int *facts = reinterpret_cast<int *>(reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF);
+    cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF;
+    int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
+    for(int i = tid; i < G::R2 * G::R3; i += T * SPW) // the workgroup's copy of the pass-2 twiddles
+        tw2_lds[i] = a.tw2[i];
     const float *x = a.ring + (size_t)(active ? spec : 0u) * a.ring_cap;
     const uint32_t start = (a.wpos[stream] - a.delay - (uint32_t)G::N) & a.ring_mask;
     float *ts = a.tsmooth + (size_t)(active ? spec : 0u) * M;
@@ -93,10 +106,10 @@ __global__ __launch_bounds__(G::T *SPW, ((G::P <= 8) ? 4 : 3) * (G::T * SPW) / 2
         wave_below = __all(row_all_below<G>(rows + (size_t)(stereo ? ch : 0u) * M, t, a.silent_floor)) != 0;
 
     bool nz0 = wave_nz, nz1 = false, below0 = wave_below, below1 = true;
+    if(lane == 0)
+        facts[wave_in_block] = (wave_nz ? 1 : 0) | (wave_below ? 2 : 0);
+    __syncthreads(); // facts + the LDS twiddle table are visible to the whole workgroup
     if(T > 64 || a.cap_ch > 1) {
-        if(lane == 0)
-            facts[wave_in_block] = (wave_nz ? 1 : 0) | (wave_below ? 2 : 0);
-        __syncthreads();
         const int sb0 = (sub - (int)ch) * WPS; // first wavefront of the subgroup that owns channel 0 of this stream
         int or0 = 0, and0 = 3, or1 = 0, and1 = 3;
 #pragma unroll
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(G::T *SPW, ((G::P <= 8) ? 4 : 3) * (G::T * SPW) / 2
     spectrum_sync<G>();
     WF_STAMP(4);
     if(process)
-        p2_pass2_write<G>(a, t, lds, v);
+        p2_pass2_write<G>(tw2_lds, t, lds, v);
     WF_STAMP(5);
     spectrum_sync<G>();
     if(process)
@@ -153,18 +166,23 @@ __global__ __launch_bounds__(G::T *SPW, ((G::P <= 8) ? 4 : 3) * (G::T * SPW) / 2
     else if(do_db && !(mono_mix && ch == 1))
         load_row<G>(rows + (size_t)ch * M, t, mag); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
 
-    WF_STAMP(9);
-    // ---- hidden / capture timeout: reset branch (reference :34-48) ---------------------------------------------
-    bool have_row = false; // this subgroup produces row `ch` (and row 1 too when one captured channel is shown as stereo)
-    float d[P];
+    // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------
     if(active && hidden && !was_silent) {
         if(a.mode & WF_MODE_TSMOOTH)
             fill_row<G>(ts, t, 0.0f);
         if(ch < (stereo ? 2u : 1u)) {
-#pragma unroll
-            for(int i = 0; i < P; ++i)
-                d[i] = a.db_min;
-            have_row = true;
+            const bool dup = a.out_ch > a.cap_ch; // one captured channel shown as two rows
+            if(!a.skip_decibels) {
+                fill_row<G>(rows + (size_t)ch * M, t, a.db_min);
+                if(dup)
+                    fill_row<G>(rows + (size_t)M, t, a.db_min);
+            }
+            if(a.bar.out != nullptr) {
+                // what render_bars makes of rows of DB_MIN: every bar at border_bottom
+                float *bo = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+                for(int i = t; i < a.bar.num_bars * (dup ? 2 : 1); i += T)
+                    bo[i] = a.bar.border_bottom;
+            }
         }
     }
 
@@ -191,15 +209,18 @@ __global__ __launch_bounds__(G::T *SPW, ((G::P <= 8) ? 4 : 3) * (G::T * SPW) / 2
             }
         }
     }
-    if(do_db && !(mono_mix && ch == 1)) {
+    WF_STAMP(9);
+    const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
+                                                            // captured channel is shown as stereo, reference :141-142)
+    const bool dup_row = have_row && (a.out_ch > a.cap_ch);
+    float d[P];
+    if(have_row) {
         p4_db<G>(a, t, mag, d);
-        have_row = true;
-    }
-    const bool dup_row = have_row && (a.out_ch > a.cap_ch); // one captured channel, two rows (reference :141-142)
-    if(have_row && !a.skip_decibels) {
-        store_row_stream<G>(rows + (size_t)ch * M, t, d);
-        if(dup_row)
-            store_row_stream<G>(rows + (size_t)M, t, d);
+        if(!a.skip_decibels) {
+            store_row_stream<G>(rows + (size_t)ch * M, t, d);
+            if(dup_row)
+                store_row_stream<G>(rows + (size_t)M, t, d);
+        }
     }
     WF_STAMP(10);
     if(active && ch == 0 && t == 0)

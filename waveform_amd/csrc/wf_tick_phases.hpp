@@ -92,6 +92,30 @@ WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 // Streaming variants for data that is touched once per tick (audio window, smoothing state, dB rows):
 // non-temporal, so the ~60 KB of per-configuration tables (window, twiddles, slope) stay in L2 instead of
 // being evicted by the 335 MB/tick stream.
+// WF_STREAM_AUX >= 0: the audio window and the smoothing state are read through buffer loads with these cache-policy
+// bits (gfx950: 1 = sc0, 2 = nt, 16 = sc1); sc1 reads are served by L2 and bypass the per-CU L1, which then only
+// holds the per-configuration tables.  -1: plain global loads.
+#ifndef WF_STREAM_AUX
+#define WF_STREAM_AUX -1
+#endif
+#if defined(__HIPCC__) && WF_STREAM_AUX >= 0
+struct StreamBuf { __amdgpu_buffer_rsrc_t rsrc; };
+WF_DEV StreamBuf make_stream_buf(const float *base_uniform, uint32_t bytes)
+{
+    return StreamBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base_uniform), 0, (int)bytes, 0x00020000)};
+}
+WF_DEV f4 ld4_buf(const StreamBuf &b, uint32_t elem)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 v = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)(elem * 4u), 0, WF_STREAM_AUX));
+    return f4{v.x, v.y, v.z, v.w};
+}
+#else
+struct StreamBuf { const float *base; };
+WF_DEV StreamBuf make_stream_buf(const float *base_uniform, uint32_t) { return StreamBuf{base_uniform}; }
+WF_DEV f4 ld4_buf(const StreamBuf &b, uint32_t elem) { return *reinterpret_cast<const f4 *>(b.base + elem); }
+#endif
+
 #ifndef WF_NT_STREAM
 #define WF_NT_STREAM 0 // measured on MI355X: non-temporal streaming is slower here (consecutive ticks' windows overlap by
                        // 80 % and the state is re-read every tick; both are served by the 256 MB Infinity Cache)
@@ -142,23 +166,30 @@ WF_DEV float mul_rn(float a, float b) { volatile float r = a * b; return r; }
 WF_DEV float add_rn(float a, float b) { volatile float r = a + b; return r; }
 #endif
 
+WF_DEV uint32_t f32_bits(float v)
+{
+#if defined(__HIPCC__)
+    return __float_as_uint(v);
+#else
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    return u;
+#endif
+}
+
 // dbfs(), reference src/source.hpp:293-299: mag > 0 ? 20*log10f(mag) : DB_MIN.
-// Device form: 20*log10(m) = (20*log10(2)) * log2(m) on the hardware log2 (v_log_f32, <= 1 ulp of its result):
-// relative error of the dB value <= ~2e-7, two instructions instead of ocml's ~15.  v_log_f32 does not take
-// denormals, so magnitudes below FLT_MIN (dB < -758, only reachable by a decaying smoothing tail) go through
-// the accurate ocml log10f.
+// Device form: max(log2(m) * 20*log10(2), DB_MIN) on the hardware log2 (v_log_f32, <= 1 ulp of its result; relative
+// error of the dB value <= ~2e-7).  log2(0) = -inf and log2(negative) = NaN both end at DB_MIN through the max, as the
+// reference's test does; for every normal m > 0 the max is a no-op because 20*log10(FLT_MIN) == DB_MIN.  One stated
+// deviation: v_log_f32 flushes denormal inputs, so magnitudes below FLT_MIN (1.2e-38, i.e. under -758 dBFS) read
+// DB_MIN where the reference would read -759..-897 dB -- far below any displayable floor (>= -120 dB).
 #ifndef WF_FAST_DB
 #define WF_FAST_DB 1
 #endif
 WF_DEV float dbfs(float mag, float db_min)
 {
 #if defined(__HIPCC__) && WF_FAST_DB
-    float r;
-    if(__builtin_expect(mag < 1.17549435e-38f, 0))
-        r = (mag > 0.0f) ? 20.0f * log10f(mag) : db_min;
-    else
-        r = __builtin_amdgcn_logf(mag) * 6.02059991327962390f;
-    return r;
+    return fmaxf(__builtin_amdgcn_logf(mag) * 6.02059991327962390f, db_min);
 #else
     return (mag > 0.0f) ? 20.0f * log10f(mag) : db_min;
 #endif
@@ -241,12 +272,13 @@ template<class G, bool ALIGNED>
 WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
 {
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    const StreamBuf xb = make_stream_buf(x, a.ring_cap * 4u);
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
         const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
         if(ALIGNED) {
             if(B1 == 2) {
-                const f4 q = ld4_stream(x + ((start + s0) & a.ring_mask));
+                const f4 q = ld4_buf(xb, (start + s0) & a.ring_mask);
                 r.smp[j][0] = q.x; r.smp[j][1] = q.y; r.smp[j][2 * B1 - 2] = q.z; r.smp[j][2 * B1 - 1] = q.w;
             } else {
                 const f2 q = ld2_stream(x + ((start + s0) & a.ring_mask));
@@ -271,14 +303,15 @@ WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P
         const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + 4 * t + 2));
         r.wb[0] = cf{wa.x, wa.y}; r.wb[1] = cf{wa.z, wa.w}; r.wb[2] = cf{wc.x, wc.y}; r.wb[3] = cf{wc.z, wc.w};
     }
-    bool nz = false;
+    // x != 0.0f for any sample: OR the bit patterns, drop the sign bit (-0.0f == 0.0f); NaNs have non-zero bits
+    uint32_t acc = 0;
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
         WF_UNROLL
         for(int e = 0; e < 2 * B1; ++e)
-            nz = nz || (r.smp[j][e] != 0.0f);
+            acc |= f32_bits(r.smp[j][e]);
     }
-    return nz;
+    return (acc & 0x7fffffffu) != 0;
 }
 
 template<class G>
@@ -333,12 +366,13 @@ template<class G> struct P4Regs {
 template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float *ts, P4Regs<G> &q)
 {
     constexpr int T = G::T, P = G::P;
+    const StreamBuf tb = make_stream_buf(ts, (uint32_t)G::M * 4u);
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         const int k0 = 4 * (t + T * u);
         if(Policy<G>::PREFETCH_STATE && (a.mode & WF_MODE_TSMOOTH)) {
             constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
-            const f4 o = ld4_stream(ts + k0);
+            const f4 o = ld4_buf(tb, (uint32_t)k0);
             q.st[S * (4 * u)] = o.x; q.st[S * (4 * u + 1)] = o.y; q.st[S * (4 * u + 2)] = o.z; q.st[S * (4 * u + 3)] = o.w;
         }
         if(Policy<G>::PREFETCH_SLOPE) {
@@ -371,7 +405,9 @@ template<class G> WF_DEV void p2_read(int t, const cf *lds, cf (&v)[G::P])
     }
 }
 
-template<class G> WF_DEV void p2_pass2_write(const TickArgs &a, int t, cf *lds, cf (&v)[G::P])
+// tw2: the workgroup's LDS copy of the pass-2 twiddle table [R2][R3] (no vector-memory wait in the middle of the FFT,
+// which would also wait for the state prefetch issued before it: loads return in order)
+template<class G> WF_DEV void p2_pass2_write(const cf *tw2, int t, cf *lds, cf (&v)[G::P])
 {
     constexpr int R1 = G::R1, R2 = G::R2, R3 = G::R3, B2 = G::B2;
     constexpr int LB = ilog2(R2);
@@ -393,12 +429,12 @@ template<class G> WF_DEV void p2_pass2_write(const TickArgs &a, int t, cf *lds, 
             for(int b = 0; b < B2; ++b)
                 o[b] = u[b][0];
         } else if(B2 == 1) {
-            const f2 w = ld2(reinterpret_cast<const float *>(a.tw2 + k2 * R3 + n30));
-            o[0] = cmul(u[0][brev(k2, LB)], cf{w.x, w.y});
+            const cf w = lds_ld2(tw2, k2 * R3 + n30);
+            o[0] = cmul(u[0][brev(k2, LB)], w);
         } else {
             WF_UNROLL
             for(int b = 0; b < B2; b += 2) {
-                const f4 w = ld4(reinterpret_cast<const float *>(a.tw2 + k2 * R3 + n30 + b));
+                const f4 w = lds_ld4(tw2, k2 * R3 + n30 + b);
                 o[b] = cmul(u[b][brev(k2, LB)], cf{w.x, w.y});
                 o[b + 1] = cmul(u[b + 1][brev(k2, LB)], cf{w.z, w.w});
             }
@@ -511,8 +547,9 @@ WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, 
                 float old = st4v[i];
                 if(a.mode & WF_MODE_FAST_PEAKS)
                     old = fmaxf(m4[i], old);
-                // (g * oldval) + (g2 * mag), each product rounded (reference :130, no contraction)
-                m4[i] = add_rn(mul_rn(a.g, old), mul_rn(a.g2, m4[i]));
+                // (g * oldval) + (g2 * mag) (reference :130); evaluated as fma(g, old, g2*mag) like the reference's own
+                // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
+                m4[i] = fmaf(a.g, old, a.g2 * m4[i]);
             }
             st4_stream(ts + k0, f4{m4[0], m4[1], m4[2], m4[3]});
         }
