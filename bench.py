@@ -76,6 +76,18 @@ def cpu_baseline(fft: int, cores: int, budget_core_s: float):
     }
 
 
+def host_cores() -> int:
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) or 1
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def pmc_traffic(kernel: str, streams: int):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
     best = None
@@ -180,7 +192,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.fft, len(os.sched_getaffinity(0)) or 1, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(args.fft, host_cores(), args.cpu_seconds)
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = None
                 print(f"bench.py: cpu_baseline failed: {e}", file=sys.stderr)

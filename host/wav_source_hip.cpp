@@ -1,0 +1,195 @@
+/*
+ * wav_source_hip.cpp -- see wav_source_hip.hpp.  Reference-side binding (compiled with the plugin, or here with the
+ * oracle harness).  libwaveform_hip.so is loaded with dlopen so that the plugin still loads on machines without it;
+ * when it is missing, or no gfx950 device is present, every call falls through to WAVSourceGeneric -- the reference's
+ * own CPU path -- which is the reference's failure style (degrade and log, never throw across the C boundary,
+ * src/source_generic.cpp:105-108).
+ */
+#include "wav_source_hip.hpp"
+#include "log.hpp"
+
+#include <dlfcn.h>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct HipApi {
+    void *lib = nullptr;
+    decltype(&wf_hip_device_count) device_count = nullptr;
+    decltype(&wf_hip_create) create = nullptr;
+    decltype(&wf_hip_destroy) destroy = nullptr;
+    decltype(&wf_hip_push_audio) push_audio = nullptr;
+    decltype(&wf_hip_tick) tick = nullptr;
+    decltype(&wf_hip_set_hidden) set_hidden = nullptr;
+    decltype(&wf_hip_read_decibels) read_decibels = nullptr;
+    decltype(&wf_hip_read_last_silent) read_last_silent = nullptr;
+    decltype(&wf_hip_last_error) last_error = nullptr;
+    bool ok = false;
+};
+
+HipApi &api()
+{
+    static HipApi a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *path = std::getenv("WF_HIP_LIBRARY");
+        a.lib = dlopen(path ? path : "libwaveform_hip.so", RTLD_NOW | RTLD_LOCAL);
+        if(a.lib == nullptr)
+            return;
+#define WF_SYM(name)                                                           \
+    a.name = reinterpret_cast<decltype(a.name)>(dlsym(a.lib, "wf_hip_" #name)); \
+    if(a.name == nullptr)                                                      \
+        return;
+        WF_SYM(device_count)
+        WF_SYM(create)
+        WF_SYM(destroy)
+        WF_SYM(push_audio)
+        WF_SYM(tick)
+        WF_SYM(set_hidden)
+        WF_SYM(read_decibels)
+        WF_SYM(read_last_silent)
+        WF_SYM(last_error)
+#undef WF_SYM
+        a.ok = true;
+    });
+    return a;
+}
+
+} // namespace
+
+bool WAVSourceHIP::available()
+{
+    auto &a = api();
+    return a.ok && a.device_count() > 0;
+}
+
+WAVSourceHIP::~WAVSourceHIP()
+{
+    std::lock_guard lock(m_mtx);
+    hip_release();
+}
+
+void WAVSourceHIP::hip_release()
+{
+    if(m_hip != nullptr) {
+        api().destroy(m_hip);
+        m_hip = nullptr;
+    }
+}
+
+// WAVSource members -> wf_config (include/wf_config.h lists the member behind every field)
+bool WAVSourceHIP::hip_configure()
+{
+    hip_release();
+    if(!available() || m_meter_mode || (m_display_mode == DisplayMode::WAVEFORM) || (m_capture_channels == 0))
+        return false;
+    wf_config c{};
+    c.fft_size = (uint32_t)m_fft_size;
+    c.sample_rate = m_audio_info.samples_per_sec;
+    c.capture_channels = m_capture_channels;
+    c.stereo = m_stereo ? 1u : 0u;
+    c.window = (int32_t)m_window_func;       // FFTWindow and wf_window share their numbering
+    c.sine_exponent = m_sine_exponent;
+    c.tsmoothing = (int32_t)m_tsmoothing;    // TSmoothingMode / wf_tsmoothing likewise
+    c.gravity = m_gravity;
+    c.fast_peaks = m_fast_peaks ? 1u : 0u;
+    c.slope = m_slope;
+    c.rolloff_q = m_rolloff_q;
+    c.rolloff_rate = m_rolloff_rate;
+    c.cutoff_low = m_cutoff_low;
+    c.cutoff_high = m_cutoff_high;
+    c.floor_db = m_floor;
+    c.ceiling_db = m_ceiling;
+    c.normalize_volume = m_normalize_volume ? 1u : 0u;
+    c.volume_target = m_volume_target;
+    c.max_gain = m_max_gain;
+    c.bars = 0; // render_bars keeps running on the host from m_decibels in drop-in mode
+    c.interp_mode = (int32_t)m_interp_mode;
+    c.log_scale = m_log_scale ? 1u : 0u;
+    c.mirror_freq_axis = m_mirror_freq_axis ? 1u : 0u;
+    c.width = m_width;
+    c.height = m_height;
+    c.bar_width = m_bar_width;
+    c.bar_gap = m_bar_gap;
+    c.channel_spacing = m_channel_spacing;
+    c.min_bar_height = m_min_bar_height;
+    c.rounded_caps = m_rounded_caps ? 1u : 0u;
+    const int rc = api().create(&c, 0, 1, 0, &m_hip);
+    if(rc != WF_HIP_OK) {
+        // e.g. WF_HIP_ERR_UNSUPPORTED for an FFT size that is not a power of two in 1024..16384
+        LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
+        m_hip = nullptr;
+        return false;
+    }
+    m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
+    m_hip_out.assign((size_t)m_output_channels * (m_fft_size / 2), 0.0f);
+    m_hip_hidden = false;
+    return true;
+}
+
+void WAVSourceHIP::update(obs_data_t *settings)
+{
+    std::lock_guard lock(m_mtx);
+    WAVSourceGeneric::update(settings); // tables, rings, render state: unchanged reference code
+    hip_configure();
+}
+
+// Same observable behaviour as WAVSourceGeneric::tick_spectrum (src/source_generic.cpp:26-180): the A/V-synchronised
+// window of each channel goes to the device, the device runs the whole per-tick state machine (hidden/timeout reset,
+// silence detection, window, FFT, magnitude, slope, smoothing, dBFS, normalisation, roll-off) and m_decibels /
+// m_last_silent come back.
+void WAVSourceHIP::tick_spectrum(float seconds)
+{
+    if(m_hip == nullptr) {
+        WAVSourceGeneric::tick_spectrum(seconds);
+        return;
+    }
+    auto &a = api();
+    const auto bufsz = m_fft_size * sizeof(float);
+    const auto outsz = m_fft_size / 2;
+
+    const auto dtcapture = m_tick_ts - m_capture_ts;
+    const bool hidden = !m_show || (dtcapture > CAPTURE_TIMEOUT); // reference :34
+    if(hidden != m_hip_hidden) {
+        const uint8_t mask = hidden ? 1 : 0;
+        a.set_hidden(m_hip, 0, 1, &mask);
+        m_hip_hidden = hidden;
+    }
+    if(!hidden) {
+        // reference :50-59: keep dtsize bytes, look at the first fft_size samples of what is left
+        const int64_t dtaudio = get_audio_sync(m_tick_ts);
+        const size_t dtsize = ((dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) * sizeof(float) : 0) + bufsz;
+        for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+            if(m_capturebufs[channel].size() < dtsize) {
+                // underflow: the reference leaves this channel untouched; without a full window there is nothing to send
+                WAVSourceGeneric::tick_spectrum(seconds);
+                return;
+            }
+            m_capturebufs[channel].pop_front(nullptr, m_capturebufs[channel].size() - dtsize);
+            m_capturebufs[channel].peek_front(m_hip_window.data() + (size_t)channel * m_fft_size, bufsz);
+        }
+        // the whole window replaces the device ring's newest fft_size samples
+        if(a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)m_fft_size) != WF_HIP_OK) {
+            WAVSourceGeneric::tick_spectrum(seconds);
+            return;
+        }
+    }
+    wf_hip_tick_params p{};
+    p.seconds = seconds;
+    p.delay_frames = 0;
+    p.input_rms = m_input_rms;
+    p.flags = 0;
+    uint8_t silent = 0;
+    if(a.tick(m_hip, &p) != WF_HIP_OK || a.read_decibels(m_hip, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
+       a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
+        LogWarn << "HIP tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
+        hip_release();
+        WAVSourceGeneric::tick_spectrum(seconds);
+        return;
+    }
+    for(auto channel = 0u; channel < m_output_channels; ++channel)
+        std::memcpy(m_decibels[channel].get(), m_hip_out.data() + (size_t)channel * outsz, outsz * sizeof(float));
+    m_last_silent = silent != 0;
+}

@@ -1,0 +1,42 @@
+/*
+ * wav_source_hip.hpp -- the reference-side binding: a fourth WAVSource implementation that runs
+ * tick_spectrum on an MI355X through the C ABI of libwaveform_hip.so (include/wf_hip.h).
+ *
+ * This file is written against the REFERENCE's own headers (phandasm/waveform src/source.hpp); it is what a
+ * maintainer adds to the plugin tree.  It is not part of libwaveform_hip.so.  In this repository
+ * it is compiled only into the oracle harness (oracle/ref, `isa = "hip"`), so that the drop-in can be tested
+ * end to end: the reference's update() / capture_audio() / tick() / render() run verbatim and only the
+ * per-tick DSP virtual is replaced.
+ *
+ * Interface replaced: WAVSource::tick_spectrum(float) (pure virtual, src/source.hpp:275), implemented in the
+ * reference by WAVSourceGeneric (src/source_generic.cpp:26-180), WAVSourceAVX (src/source_avx.cpp:29-200) and
+ * WAVSourceAVX2 (src/source_avx2.cpp:24-209); selected in callbacks::create (src/source.cpp:87-102).
+ */
+#pragma once
+#include "source.hpp"   // the reference's
+#include "wf_hip.h"
+
+class WAVSourceHIP : public WAVSourceGeneric
+{
+protected:
+    void tick_spectrum(float seconds) override;
+
+    // one batch of 1 stream: a plugin that hosts several sources would share one handle per configuration
+    wf_hip *m_hip = nullptr;
+    bool m_hip_hidden = false;
+    std::vector<float> m_hip_window;   // [capture_channels][fft_size] staging for the H2D copy
+    std::vector<float> m_hip_out;      // [output_channels][fft_size/2]
+
+    void hip_release();
+    bool hip_configure();              // (re)creates m_hip from the members update() has just set
+
+public:
+    using WAVSourceGeneric::WAVSourceGeneric;
+    ~WAVSourceHIP() override;
+
+    void update(obs_data_t *settings) override;
+
+    // true when a gfx950 device and libwaveform_hip.so are available (callbacks::create asks this first)
+    static bool available();
+    bool using_hip() const { return m_hip != nullptr; }
+};

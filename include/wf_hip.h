@@ -123,6 +123,9 @@ int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* bar tops in pixels (m_interp_bufs after the dB->y mapping of render_bars,
  * src/source.cpp:1548-1557): [count][display_channels][num_bars] */
 int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out);
+/* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
+ * all-gather); ordered on the handle's stream and synchronised before returning */
+int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);
 /* m_tsmooth_buf: [count][capture_channels][fft_size/2] */
 int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out);
 int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in);

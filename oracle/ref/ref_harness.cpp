@@ -35,6 +35,7 @@
 #undef protected
 #undef private
 
+#include "wav_source_hip.hpp" // the reference-side binding under test when isa == "hip"
 #include "fake_obs_world.hpp"
 #include "wfref.h"
 #include "wf_synth.h"
@@ -110,7 +111,9 @@ wfref_t *wfref_create(const char *isa, const char *settings, uint32_t sample_rat
     fakeobs::set_video_fps(fps_num ? fps_num : 60, fps_den ? fps_den : 1);
 
     std::string which = isa ? isa : "generic";
-    if(which == "avx2")
+    if(which == "hip")
+        h->obj = new WAVSourceHIP(h->self);
+    else if(which == "avx2")
         h->obj = new WAVSourceAVX2(h->self);
     else if(which == "avx")
         h->obj = new WAVSourceAVX(h->self);
@@ -212,6 +215,12 @@ size_t wfref_bars(wfref_t *h, int ch, const float **out)
     auto &v = h->obj->m_interp_bufs[ch & 1];
     *out = v.data();
     return v.size();
+}
+
+int wfref_using_hip(wfref_t *h)
+{
+    auto p = dynamic_cast<WAVSourceHIP *>(h->obj);
+    return (p != nullptr && p->using_hip()) ? 1 : 0;
 }
 
 float wfref_noise(uint64_t seed, uint32_t stream, uint32_t channel, uint64_t index)

@@ -24,7 +24,9 @@ extern "C" {
 
 typedef struct wfref wfref_t;
 
-/* isa: "generic" | "avx" | "avx2" -> WAVSourceGeneric / WAVSourceAVX / WAVSourceAVX2
+/* isa: "hip" -> WAVSourceHIP (host/wav_source_hip.cpp: the reference-side binding of libwaveform_hip.so, loaded with
+ *      dlopen from $WF_HIP_LIBRARY); wfref_using_hip() tells whether the device path is really active.
+ * isa: "generic" | "avx" | "avx2" -> WAVSourceGeneric / WAVSourceAVX / WAVSourceAVX2
  *      (the classes callbacks::create picks from, src/source.cpp:87-102).
  * settings: "key=value;key=value" over the plugin's own setting keys
  *      (src/settings.hpp), applied on top of get_defaults (src/source.cpp:119-174).
@@ -58,6 +60,7 @@ uint32_t wfref_output_channels(wfref_t *h);
 int wfref_stereo(wfref_t *h);
 int wfref_last_silent(wfref_t *h);
 size_t wfref_ring_bytes(wfref_t *h, int ch);
+int wfref_using_hip(wfref_t *h);
 float wfref_gravity(wfref_t *h, float seconds);    /* get_gravity(), src/source.hpp:301-312 */
 float wfref_db_min(void);
 const float *wfref_decibels(wfref_t *h, int ch);   /* m_decibels[ch], fft_size/2 floats */

@@ -48,7 +48,7 @@ def lib():
     for name in ("wfref_capture_channels", "wfref_output_channels"):
         getattr(L, name).restype = u32
         getattr(L, name).argtypes = [vp]
-    for name in ("wfref_stereo", "wfref_last_silent", "wfref_num_bars"):
+    for name in ("wfref_stereo", "wfref_last_silent", "wfref_num_bars", "wfref_using_hip"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp]
     L.wfref_ring_bytes.restype = C.c_size_t
@@ -167,6 +167,10 @@ class RefSource:
     @property
     def stereo(self):
         return bool(self.L.wfref_stereo(self.h))
+
+    @property
+    def using_hip(self):
+        return bool(self.L.wfref_using_hip(self.h))
 
     @property
     def last_silent(self):

@@ -62,3 +62,25 @@ def test_hip_reproduces_reference(name):
         _check(name, be)
     finally:
         be.close()
+
+
+# ---- the drop-in: the reference plugin itself, with only tick_spectrum replaced by the HIP binding -----------------
+DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4096_ema_slope", "cfg4_16384_tv_lanczos_bars",
+          "mono_mix_4096_tv_fastpeaks", "rolloff_catrom_linear", "ragged_hops", "silence_cycle", "half_silent_stereo",
+          "hide_show", "muted_packets"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", DROPIN)
+def test_reference_plugin_with_hip_tick(name):
+    """oracle/_ref's WAVSource (update / capture_audio / tick / render_bars run verbatim) with WAVSourceHIP
+    (host/wav_source_hip.cpp) as the tick_spectrum implementation, against the same golden vectors."""
+    import os
+    from oracle import wfref
+    if not wfref.available():
+        pytest.skip("oracle/_ref/libwfref.so not built")
+    os.environ["WF_HIP_LIBRARY"] = str(Path(__file__).resolve().parent.parent / "waveform_amd" / "libwaveform_hip.so")
+    cfg = scenarios.make_config(scenarios.SCENARIOS[name]["cfg"])
+    be = scenarios.RefBackend(cfg, isa="hip")
+    assert be.src.using_hip, "WAVSourceHIP fell back to the CPU path: the HIP library did not load or no gfx950 device"
+    _check(name, be)

@@ -1,0 +1,142 @@
+"""GPU tests at BASELINE.json's full batch sizes, through size-independent properties (the oracle cannot run
+8192 spectra per tick in seconds) plus oracle spot checks on the first/last streams of the batch."""
+import numpy as np
+import pytest
+
+import waveform_amd as wf
+from helpers import assert_db_close
+from oracle import restate
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+SEED = synth.DEFAULT_SEED
+
+
+def _oracle_rows(cfg, stream_ids, ticks, hop, bars=False):
+    out, outb = [], []
+    for s in stream_ids:
+        o = restate.OracleSource(cfg)
+        for t in range(ticks):
+            o.feed_and_tick(synth.block(SEED, s, 1, cfg.capture_channels, t * hop, hop)[0])
+        out.append(o.decibels())
+        if bars:
+            o.render_bars()
+            outb.append(o.bars())
+    return np.stack(out), (np.stack(outb) if bars else None)
+
+
+def test_cfg3_full_batch_spot_checks_and_determinism():
+    """configs[2]: 4096 stereo streams, FFT 4096, EMA + slope.  Device-generated audio (wf_synth) for every stream;
+    first/last 16 streams against the oracle; two identical batches must agree bit for bit."""
+    cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0)
+    streams, ticks, hop = 4096, 5, 800
+    res = []
+    for rep in range(2):
+        with wf.SpectrumBatch(cfg, streams, ring_frames=4096 + hop * (ticks + 1)) as b:
+            b.push_synth(SEED, 0, hop * ticks)
+            for t in range(ticks):
+                b.tick(delay_frames=hop * (ticks - 1 - t))
+            res.append(b.decibels())
+    assert np.array_equal(res[0], res[1]), "two identical runs differ: the kernel is not deterministic"
+    ids = list(range(16)) + list(range(streams - 16, streams))
+    want, _ = _oracle_rows(cfg, ids, ticks, hop)
+    assert_db_close(res[0][ids], want, "cfg3 full batch vs oracle (first/last 16 streams)")
+    assert np.all(np.isfinite(res[0]))
+
+
+def test_cfg3_gain_invariance_full_batch():
+    """linearity of the path up to the dB stage: doubling every sample adds exactly 20*log10(2) dB
+    (float scaling by 2 is exact through window, FFT, |X|, slope and the EMA)."""
+    cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0)
+    streams, ticks, hop = 512, 4, 800
+    audio = [synth.block(SEED, 0, streams, 2, t * hop, hop) for t in range(ticks)]
+    outs = []
+    for gain in (1.0, 2.0):
+        with wf.SpectrumBatch(cfg, streams) as b:
+            for t in range(ticks):
+                b.push_audio(audio[t] * np.float32(gain))
+                b.tick()
+            outs.append(b.decibels())
+    diff = outs[1].astype(np.float64) - outs[0].astype(np.float64)
+    assert np.max(np.abs(diff - 20 * np.log10(2.0))) < 3e-5
+
+
+def test_batch_position_independence():
+    """stream i computes the same bits whether it sits in a batch of 3 or of 4096 (different workgroup, same math)"""
+    cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0)
+    ticks, hop = 4, 800
+    with wf.SpectrumBatch(cfg, 4096, ring_frames=4096 + hop * (ticks + 1)) as big:
+        big.push_synth(SEED, 0, hop * ticks)
+        for t in range(ticks):
+            big.tick(delay_frames=hop * (ticks - 1 - t))
+        full = big.decibels(first=4000, count=3)
+    with wf.SpectrumBatch(cfg, 3, ring_frames=4096 + hop * (ticks + 1)) as small:
+        small.push_synth(SEED, 0, hop * ticks, stream_id0=4000)
+        for t in range(ticks):
+            small.tick(delay_frames=hop * (ticks - 1 - t))
+        part = small.decibels()
+    assert np.array_equal(full, part)
+
+
+def test_cfg4_full_batch_bars():
+    """configs[3]: FFT 16384, gravity (TV-EMA) smoothing, Lanczos bars, 1024 streams; oracle spot checks"""
+    cfg = wf.Config.defaults(fft_size=16384, stereo=1, tsmoothing=wf.TSMOOTH["tvexponential"], bars=1, interp_mode=wf.INTERP["lanczos"])
+    streams, ticks, hop = 1024, 3, 800
+    with wf.SpectrumBatch(cfg, streams, ring_frames=16384 + hop * (ticks + 1)) as b:
+        b.push_synth(SEED, 0, hop * ticks)
+        for t in range(ticks):
+            b.tick(delay_frames=hop * (ticks - 1 - t))
+        db, bars = b.decibels(), b.bars()
+    ids = [0, 1, 2, 3, streams - 2, streams - 1]
+    want, wantb = _oracle_rows(cfg, ids, ticks, hop, bars=True)
+    assert_db_close(db[ids], want, "cfg4 decibels vs oracle")
+    err = np.abs(bars[ids].astype(np.float64) - wantb)
+    assert np.all(err <= 1e-5 * np.abs(wantb) + 2e-3), f"cfg4 bars: max err {err.max():.3e} px"
+    assert bars.shape == (streams, 2, 26)
+
+
+def test_bars_only_mode_matches_full_mode():
+    """WF_HIP_TICK_NO_DECIBELS (configs[4]'s batch mode): the bars are the same, the m_decibels rows are left untouched"""
+    cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    streams, ticks, hop = 64, 3, 800
+    res = []
+    for flags in (0, 1):
+        with wf.SpectrumBatch(cfg, streams) as b:
+            for t in range(ticks):
+                b.push_synth(SEED, t * hop, hop)
+                b.tick(flags=flags)
+            res.append((b.bars(), b.decibels()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.all(res[1][1] == np.float32(wf.db_min()))
+
+
+def test_delay_frames_is_the_av_sync_window():
+    """tick(delay_frames=d) analyses the window that ends d frames before the newest sample (reference :50-59)"""
+    cfg = wf.Config.defaults(fft_size=2048, stereo=1, tsmoothing=wf.TSMOOTH["none"])
+    hop, ticks = 800, 4
+    audio = synth.block(SEED, 0, 2, 2, 0, hop * ticks)
+    with wf.SpectrumBatch(cfg, 2, ring_frames=2048 + hop * (ticks + 1)) as b:
+        b.push_audio(audio)
+        got = []
+        for t in range(ticks):
+            b.tick(delay_frames=hop * (ticks - 1 - t))
+            got.append(b.decibels())
+    for s in range(2):
+        o = restate.OracleSource(cfg)
+        for t in range(ticks):
+            o.feed_and_tick(audio[s][:, t * hop:(t + 1) * hop])
+            assert_db_close(got[t][s], o.decibels(), f"delay tick {t} stream {s}")
+
+
+def test_errors_are_reported_not_thrown():
+    with pytest.raises(wf.WfHipError) as e:
+        wf.SpectrumBatch(wf.Config.defaults(fft_size=800), 1)
+    assert e.value.code == -2  # WF_HIP_ERR_UNSUPPORTED: legal for the reference (multiple of 16), not implemented here
+    cfg = wf.Config.defaults(fft_size=1024)
+    with wf.SpectrumBatch(cfg, 2) as b:
+        with pytest.raises(wf.WfHipError):
+            b.tick(delay_frames=10**6)
+        with pytest.raises(wf.WfHipError):
+            b.bars()
+        with pytest.raises(wf.WfHipError):
+            b.decibels(first=2, count=1)

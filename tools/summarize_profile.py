@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs of tools/profile_gpu.sh (gpurun_out/prof/<tag>/) into the small, committed
+summaries under profiles/:  <name>_kernel_stats.csv  (the --kernel-trace --stats table, verbatim),
+<name>_pmc.json (per-launch means of every counter + HBM bytes per launch, corrected as
+MI355X_MICROARCH.md prescribes: FETCH_SIZE counts 64 B per 128 B request on gfx950 -> x2; both are in KiB)."""
+import csv, glob, json, collections, shutil, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def main(tag, name, streams=4096, fft=4096):
+    src = ROOT / "gpurun_out" / "prof" / tag
+    dst = ROOT / "profiles"
+    dst.mkdir(exist_ok=True)
+    shutil.copy(src / "stats" / "stats_kernel_stats.csv", dst / f"{name}_kernel_stats.csv")
+    tot, kname, res = {}, None, {}
+    for f in sorted(glob.glob(str(src / "pmc_*" / "pmc_counter_collection.csv"))):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "spectrum_tick" in r["Kernel_Name"]:
+                kname = r["Kernel_Name"]
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                res = {k: r[k] for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
+        for k, v in agg.items():
+            tot[k] = sum(v) / len(v)
+    stats = {}
+    for r in csv.DictReader(open(src / "stats" / "stats_kernel_stats.csv")):
+        if "spectrum_tick" in r["Name"]:
+            stats = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    fetch_b = tot.get("FETCH_SIZE", 0) * 1024 * 2
+    write_b = tot.get("WRITE_SIZE", 0) * 1024
+    cyc = tot.get("GRBM_GUI_ACTIVE", 0) / 8
+    out = {
+        "tag": tag, "command": "python bench.py --steps 30 --warmup 3 --no-cpu-baseline (tools/profile_gpu.sh)",
+        "kernel_rocprof_name": kname, "streams": streams, "fft_size": fft,
+        "kernel": f"spectrum_tick_kernel<N={fft},T=128,R=8x16x16,SPW=2>" if fft == 4096 else None,
+        "kernel_stats": stats, "dispatch": res,
+        "hbm_bytes_per_launch": fetch_b + write_b,
+        "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
+        "correction": "FETCH_SIZE (KiB) x2 per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE (KiB) as reported",
+        "counters_mean_per_launch": tot,
+        "derived": {
+            "valu_insts_per_wave": tot.get("SQ_INSTS_VALU", 0) / max(tot.get("SQ_WAVES", 1), 1),
+            "valu_busy_frac": tot.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * cyc) if cyc else None,
+            "avg_waves_per_simd": tot.get("SQ_WAVE_CYCLES", 0) * 4 / (1024 * cyc) if cyc else None,
+            "wait_any_frac": tot.get("SQ_WAIT_ANY", 0) / max(tot.get("SQ_WAVE_CYCLES", 1), 1),
+            "lds_bank_conflict_frac": tot.get("SQ_LDS_BANK_CONFLICT", 0) / max(tot.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+            "kernel_cycles": cyc,
+        },
+    }
+    (dst / f"{name}_pmc.json").write_text(json.dumps(out, indent=1))
+    print(json.dumps({k: out[k] for k in ("kernel_stats", "hbm_bytes_per_launch", "derived")}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

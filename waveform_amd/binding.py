@@ -91,6 +91,7 @@ def lib():
     L.wf_hip_sync.argtypes = [vp]
     L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_copy_bars_device.argtypes = [vp, u32, u32, vp]
     L.wf_hip_read_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_write_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
@@ -230,6 +231,11 @@ class SpectrumBatch:
         out = np.empty((count, self.display_channels, self.num_bars), np.float32)
         self._ck(self.L.wf_hip_read_bars(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def copy_bars_to_device(self, dev_ptr: int, first: int = 0, count: int | None = None):
+        """device-to-device copy of the bar tops into a caller-owned buffer (e.g. a torch tensor's data_ptr())"""
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_copy_bars_device(self.h, first, count, C.c_void_p(dev_ptr)))
 
     def tsmooth(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.streams - first if count is None else count

@@ -584,6 +584,22 @@ int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out)
     return read_back(h, h->d_bars + first * per, out, count * per * sizeof(float));
 }
 
+int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_bars == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
+    if(d_out == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL");
+    const size_t per = (size_t)h->disp_ch * h->num_bars;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipMemcpyAsync(d_out, h->d_bars + first * per, count * per * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WF_HIP_OK;
+}
+
 int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out)
 {
     int rc = check_range(h, first, count);
