@@ -47,9 +47,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 
 // register budget: waves per SIMD the kernel is compiled for (launch_bounds' second argument)
 #ifndef WF_WPS_P16
-#define WF_WPS_P16 3
+#define WF_WPS_P16 4
 #endif
-#define WF_WAVES_PER_SIMD(G) ((G::P <= 8) ? 4 : (G::P <= 16) ? WF_WPS_P16 : 3)
+#define WF_WAVES_PER_SIMD(G) ((G::P <= 8) ? 4 : (G::P <= 16) ? ((G::T <= 64) ? 3 : WF_WPS_P16) : 3)
 
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \
@@ -161,9 +161,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(7);
     spectrum_sync<G>();
     WF_STAMP(8);
-    if(process)
+    if(process) {
         p4_split_smooth<G>(a, t, lds, ts, r1.wb, r4, mag);
-    else if(do_db && !(mono_mix && ch == 1))
+        if(Policy<G>::TOUCH_STATE)
+            asm volatile("" ::"v"(r4.touch[0]), "v"(r4.touch[1])); // the touched dwords are only ever waited for
+    } else if(do_db && !(mono_mix && ch == 1))
         load_row<G>(rows + (size_t)ch * M, t, mag); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
 
     // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------

@@ -229,10 +229,22 @@ WF_DEV float mag2(float xr, float xi)
 #ifndef WF_PREFETCH_SLOPE
 #define WF_PREFETCH_SLOPE 1
 #endif
+// WF_PREFETCH_STATE: 1 = smoothing state prefetched into registers behind passes 2-3 (16 VGPRs at P = 16);
+//                    2 = "touch": one dword per 64-byte line of the state row (and of the slope table) is requested right
+//                        after pass 1 so that P4's real loads are served from L2; costs 2 VGPRs instead of 32, which
+//                        keeps the kernel under 128 VGPRs = 4 workgroups per CU;  0 = load in P4.
+//                    -1 (default) = measured choice per geometry on MI355X (interleaved A/B, same box): registers for the
+//                        one-wavefront geometries (N = 1024: 68 vs 75 us, N = 2048: 72.3 vs 75 us), touch for N = 4096
+//                        (77.1-79.1 vs 79.3-80.4 us; 122 instead of 156 VGPRs -> 4 workgroups per CU).
+#ifndef WF_PREFETCH_STATE
+#define WF_PREFETCH_STATE -1
+#endif
 template<class G> struct Policy {
+    static constexpr int MODE = (WF_PREFETCH_STATE >= 0) ? WF_PREFETCH_STATE : (G::T <= 64 ? 1 : 2);
     static constexpr bool EARLY_TABLES = (G::P <= 16);
-    static constexpr bool PREFETCH_STATE = (G::P <= 16);
-    static constexpr bool PREFETCH_SLOPE = (G::P <= 16) && WF_PREFETCH_SLOPE;
+    static constexpr bool PREFETCH_STATE = (G::P <= 16) && (MODE == 1);
+    static constexpr bool PREFETCH_SLOPE = (G::P <= 16) && WF_PREFETCH_SLOPE && (MODE == 1);
+    static constexpr bool TOUCH_STATE = (G::P <= 16) && (MODE == 2);
 };
 template<class G> struct P1Regs {
     float smp[G::R1][2 * G::B1];
@@ -362,10 +374,19 @@ WF_DEV void p1_window_pass1(const TickArgs &a, int t, P1Regs<G> &r, cf *lds)
 template<class G> struct P4Regs {
     float st[Policy<G>::PREFETCH_STATE ? G::P : 1]; // m_tsmooth_buf of this thread's bins
     float sl[Policy<G>::PREFETCH_SLOPE ? G::P : 1]; // m_slope_modifiers of this thread's bins
+    float touch[2];                                 // TOUCH_STATE: the two requested dwords (kept only to be waited for)
 };
 template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float *ts, P4Regs<G> &q)
 {
     constexpr int T = G::T, P = G::P;
+    if(Policy<G>::TOUCH_STATE) {
+        // M floats per row = M/16 lines of 64 bytes; T threads cover them in ceil(M/16/T) = 1 step for every shipped geometry
+        static_assert(G::M / 16 <= G::T || !Policy<G>::TOUCH_STATE, "one touch per thread covers the row");
+        const int line = (t < G::M / 16) ? t : 0;
+        q.touch[0] = (a.mode & WF_MODE_TSMOOTH) ? ts[16 * line] : 0.0f;
+        q.touch[1] = a.slope[16 * line];
+        return;
+    }
     const StreamBuf tb = make_stream_buf(ts, (uint32_t)G::M * 4u);
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
