@@ -508,17 +508,90 @@ template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
 // ---- P4: real split + epilogue ------------------------------------------------------------------
 // Produces the smoothed linear magnitudes of bins 4g..4g+3 (g = t + T*u) in mag[u][0..3],
 // updating the temporal-smoothing state on the way (reference :110-135).
+// slope (reference :121-122) and temporal smoothing incl. fast peaks (:124-132) of bin group u; the slope table is all ones
+// when m_slope <= 0.  The operands come from the registers they were fetched into: P4Regs (prefetched behind passes 2-3),
+// st_all/sl_all (fetched at the top of P4) or straight from memory (threads with 32 points).
+template<class G, int NA>
+WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, const P4Regs<G> &q, const float (&st_all)[NA],
+                                  const float (&sl_all)[NA], float (&mag)[G::P])
+{
+    constexpr int T = G::T;
+    constexpr bool ALL = (NA > 1);
+    const int k0 = 4 * (t + T * u);
+    float sl4[4];
+    if(Policy<G>::PREFETCH_SLOPE) {
+        constexpr int S = Policy<G>::PREFETCH_SLOPE ? 1 : 0;
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i)
+            sl4[i] = q.sl[S * (4 * u + i)];
+    } else if(ALL) {
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i)
+            sl4[i] = sl_all[(ALL ? 1 : 0) * (4 * u + i)];
+    } else {
+        const f4 o = ld4(a.slope + k0);
+        sl4[0] = o.x; sl4[1] = o.y; sl4[2] = o.z; sl4[3] = o.w;
+    }
+    WF_UNROLL
+    for(int i = 0; i < 4; ++i)
+        mag[4 * u + i] *= sl4[i];
+    if(a.mode & WF_MODE_TSMOOTH) {
+        float st4v[4];
+        if(Policy<G>::PREFETCH_STATE) {
+            constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i)
+                st4v[i] = q.st[S * (4 * u + i)];
+        } else if(ALL) {
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i)
+                st4v[i] = st_all[(ALL ? 1 : 0) * (4 * u + i)];
+        } else {
+            const f4 o = ld4_stream(ts + k0);
+            st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
+        }
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i) {
+            float old = st4v[i];
+            if(a.mode & WF_MODE_FAST_PEAKS)
+                old = fmaxf(mag[4 * u + i], old);
+            // (g * oldval) + (g2 * mag) (reference :130); evaluated as fma(g, old, g2*mag) like the reference's own
+            // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
+            mag[4 * u + i] = fmaf(a.g, old, a.g2 * mag[4 * u + i]);
+        }
+        st4_stream(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+    }
+}
+
 template<class G>
 WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[G::P])
 {
     constexpr int M = G::M, T = G::T, P = G::P;
+    // Threads with register headroom (P <= 16) that did not prefetch state/slope earlier issue ALL of those loads now and
+    // consume them only after the whole real split (two loops), so the split math covers their latency.  Threads with
+    // 32 points load group by group.
+    constexpr bool LOAD_ALL_FIRST = Policy<G>::EARLY_TABLES && !Policy<G>::PREFETCH_STATE;
+    float st_all[LOAD_ALL_FIRST ? P : 1], sl_all[LOAD_ALL_FIRST ? P : 1];
+    if(LOAD_ALL_FIRST) {
+        constexpr int S = LOAD_ALL_FIRST ? 1 : 0;
+        WF_UNROLL
+        for(int u = 0; u < P / 4; ++u) {
+            const int k0 = 4 * (t + T * u);
+            if(a.mode & WF_MODE_TSMOOTH) {
+                const f4 o = ld4_stream(ts + k0);
+                st_all[S * (4 * u)] = o.x; st_all[S * (4 * u + 1)] = o.y; st_all[S * (4 * u + 2)] = o.z; st_all[S * (4 * u + 3)] = o.w;
+            }
+            const f4 sv = ld4(a.slope + k0);
+            sl_all[S * (4 * u)] = sv.x; sl_all[S * (4 * u + 1)] = sv.y; sl_all[S * (4 * u + 2)] = sv.z; sl_all[S * (4 * u + 3)] = sv.w;
+        }
+    }
+    // ---- loop 1: real split -> |2X| * coef/2 -------------------------------------------------------------------------
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         const int k0 = 4 * (t + T * u);
         const f4 za = lds_ld4(lds, ex3_addr<G>(k0));
         const f4 zb = lds_ld4(lds, ex3_addr<G>(k0 + 2));
         const cf A[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
-        float m4[4];
         cf Wl[4];
         if(!Policy<G>::EARLY_TABLES) { // threads short of registers read the split twiddles where they are used
             const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + k0));
@@ -535,48 +608,16 @@ WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, 
             const float pr = fmaf(W.x, dr, -(W.y * di)); // Re(W D)
             const float pi = fmaf(W.x, di, W.y * dr);    // Im(W D)
             const float xr = er + pi, xi = ei - pr;
-            m4[i] = mag2(xr, xi) * a.half_coef;
+            mag[4 * u + i] = mag2(xr, xi) * a.half_coef;
         }
-        { // mag *= m_slope_modifiers[i] (reference :121-122); the table is all ones when m_slope <= 0
-            float sl4[4];
-            if(Policy<G>::PREFETCH_SLOPE) {
-                constexpr int S = Policy<G>::PREFETCH_SLOPE ? 1 : 0;
-                WF_UNROLL
-                for(int i = 0; i < 4; ++i)
-                    sl4[i] = q.sl[S * (4 * u + i)];
-            } else {
-                const f4 o = ld4(a.slope + k0);
-                sl4[0] = o.x; sl4[1] = o.y; sl4[2] = o.z; sl4[3] = o.w;
-            }
-            WF_UNROLL
-            for(int i = 0; i < 4; ++i)
-                m4[i] *= sl4[i];
-        }
-        if(a.mode & WF_MODE_TSMOOTH) {
-            float st4v[4];
-            if(Policy<G>::PREFETCH_STATE) {
-                constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
-                WF_UNROLL
-                for(int i = 0; i < 4; ++i)
-                    st4v[i] = q.st[S * (4 * u + i)];
-            } else {
-                const f4 o = ld4_stream(ts + k0);
-                st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
-            }
-            WF_UNROLL
-            for(int i = 0; i < 4; ++i) {
-                float old = st4v[i];
-                if(a.mode & WF_MODE_FAST_PEAKS)
-                    old = fmaxf(m4[i], old);
-                // (g * oldval) + (g2 * mag) (reference :130); evaluated as fma(g, old, g2*mag) like the reference's own
-                // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
-                m4[i] = fmaf(a.g, old, a.g2 * m4[i]);
-            }
-            st4_stream(ts + k0, f4{m4[0], m4[1], m4[2], m4[3]});
-        }
+        if(!LOAD_ALL_FIRST)
+            p4_slope_smooth_group<G>(a, t, u, ts, q, st_all, sl_all, mag);
+    }
+    // ---- loop 2: slope, temporal smoothing, state store ----------------------------------------------------------------
+    if(LOAD_ALL_FIRST) {
         WF_UNROLL
-        for(int i = 0; i < 4; ++i)
-            mag[4 * u + i] = m4[i];
+        for(int u = 0; u < P / 4; ++u)
+            p4_slope_smooth_group<G>(a, t, u, ts, q, st_all, sl_all, mag);
     }
 }
 
