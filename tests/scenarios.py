@@ -56,6 +56,11 @@ SCENARIOS = {
                                            interp_mode=2, log_scale=0), steps=_steps(4), record=2),
     "point_bars_mirror": dict(cfg=dict(fft_size=4096, stereo=0, bars=1, interp_mode=0, mirror_freq_axis=1, bar_width=10, bar_gap=2),
                               steps=_steps(4), record=1),
+    # many narrow bars: more bars than threads per spectrum and more products than one LDS scratch holds (chunked reduction)
+    "many_bars_1024": dict(cfg=dict(fft_size=1024, stereo=1, bars=1, interp_mode=1, width=1920, bar_width=1, bar_gap=0, log_scale=0),
+                           steps=_steps(3), record=1),
+    "many_bars_4096_catrom": dict(cfg=dict(fft_size=4096, stereo=0, bars=1, interp_mode=2, width=600, bar_width=2, bar_gap=1),
+                                  steps=_steps(3), record=1),
     # ragged packets: 441-frame hops (window start not 16-byte aligned), then a 1024 packet
     "ragged_hops": dict(cfg=dict(fft_size=2048, stereo=1),
                         steps=[("noise", 441), ("tick",), ("noise", 441), ("tick",), ("noise", 1024), ("tick",), ("noise", 3), ("tick",),

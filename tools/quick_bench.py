@@ -20,6 +20,9 @@ def run(n, streams, ticks=30, hop=800, stereo=1, reps=3, **kw):
                               frac=round(byt / best / 1e6 / 8000, 4))), flush=True)
 
 if __name__ == "__main__":
+    extra = {}
+    if os.environ.get("WF_BENCH_BARS"):
+        extra = dict(bars=1, interp_mode=int(os.environ["WF_BENCH_BARS"]))
     jobs = [a.split(":") for a in sys.argv[1:]] or [("1024", "16384"), ("2048", "8192"), ("4096", "4096"), ("8192", "2048"), ("16384", "1024")]
     for n, s in jobs:
-        run(int(n), int(s))
+        run(int(n), int(s), **extra)

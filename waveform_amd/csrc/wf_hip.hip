@@ -47,8 +47,9 @@ struct wf_hip {
     float *d_bars = nullptr;
     float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
-    float *d_interp_indices = nullptr, *d_interp_weights = nullptr;
-    int *d_band_widths = nullptr, *d_band_start = nullptr;
+    float *d_bar_coef = nullptr;
+    int *d_bar_bin = nullptr, *d_bar_off = nullptr, *d_band_widths = nullptr, *d_bar_chunk = nullptr;
+    int bar_chunks = 0, bar_lpb = 1;
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;
@@ -161,14 +162,16 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     a.skip_decibels = (p->flags & WF_HIP_TICK_NO_DECIBELS) ? 1u : 0u;
     a.bar = wf::BarArgs{};
     if(h->d_bars) {
-        a.bar.indices = h->d_interp_indices;
-        a.bar.weights = h->d_interp_weights;
-        a.bar.band_widths = h->d_band_widths;
-        a.bar.band_start = h->d_band_start;
+        a.bar.coef = h->d_bar_coef;
+        a.bar.bin = h->d_bar_bin;
+        a.bar.off = h->d_bar_off;
+        a.bar.count = h->d_band_widths;
+        a.bar.chunk = h->d_bar_chunk;
+        a.bar.num_chunks = h->bar_chunks;
+        a.bar.entries = (int)h->tab.bar_coef.size();
+        a.bar.lanes_per_bar = h->bar_lpb;
         a.bar.out = h->d_bars;
         a.bar.num_bars = (int)h->num_bars;
-        a.bar.taps = h->tab.interp_taps;
-        a.bar.radius = h->tab.interp_radius;
         a.bar.mirror = h->cfg.mirror_freq_axis ? 1 : 0;
         a.bar.border_top = h->tab.border_top;
         a.bar.border_bottom = h->tab.border_bottom;
@@ -348,18 +351,27 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
     WF_CREATE_TRY(upload(h, &h->d_rolloff, h->tab.rolloff));
-    std::vector<int> band_start;
+    std::vector<int> chunks;
     if(h->num_bars) {
-        WF_CREATE_TRY(upload(h, &h->d_interp_indices, h->tab.interp_indices));
-        WF_CREATE_TRY(upload(h, &h->d_interp_weights, h->tab.interp_weights));
+        WF_CREATE_TRY(upload(h, &h->d_bar_coef, h->tab.bar_coef));
+        WF_CREATE_TRY(upload(h, &h->d_bar_bin, h->tab.bar_bin));
+        WF_CREATE_TRY(upload(h, &h->d_bar_off, h->tab.bar_off));
         WF_CREATE_TRY(upload(h, &h->d_band_widths, h->tab.band_widths));
-        band_start.resize(h->tab.band_widths.size());
-        int acc = 0;
-        for(size_t i = 0; i < band_start.size(); ++i) {
-            band_start[i] = acc;
-            acc += h->tab.band_widths[i];
-        }
-        WF_CREATE_TRY(upload(h, &h->d_band_start, band_start));
+        // LDS scratch for the products: what is left of a spectrum's exchange buffer behind the M dB values
+        size_t lds_floats = 0;
+        int threads = 64;
+        wf::dispatch_geometry(h->N, [&](auto g) {
+            using G = decltype(g);
+            lds_floats = (size_t)G::LDS_CF * 2;
+            threads = G::T;
+        });
+        chunks = wf::bar_chunks(h->tab, lds_floats - h->M);
+        WF_CREATE_TRY(upload(h, &h->d_bar_chunk, chunks));
+        h->bar_chunks = (int)chunks.size() - 1;
+        int lpb = 1;
+        while(lpb < 64 && (uint32_t)(threads / (lpb * 2)) >= h->num_bars)
+            lpb *= 2;
+        h->bar_lpb = lpb;
     }
 
     // FFT plan: twiddle tables for the geometry of this fft_size + the kernel instantiation

@@ -224,9 +224,65 @@ void build_bars(const wf_config &cfg, HostTables &t)
     t.border_top = border_top;
     t.border_bottom = border_bottom;
     t.cpos = cpos;
+
+    // ---- composite per-bar kernels for the device (see BarArgs in wf_tick_phases.hpp) ---------------------------------
+    const intmax_t M = (intmax_t)(cfg.fft_size / 2);
+    t.bar_coef.clear();
+    t.bar_bin.clear();
+    t.bar_off.assign((size_t)num_bars + 1, 0);
+    size_t k = 0; // running sample index (interpolating modes)
+    for(int i = 0; i < num_bars; ++i) {
+        const intmax_t count = t.band_widths[(size_t)i];
+        intmax_t lo, hi; // bin range [lo, hi)
+        std::vector<double> acc;
+        if(cfg.interp_mode == WF_INTERP_POINT) {
+            // sum += m_decibels[(size_t)m_interp_indices[i] + j], src/source.cpp:1529-1530
+            lo = std::clamp<intmax_t>((intmax_t)t.interp_indices[(size_t)i], 0, M);
+            hi = std::clamp<intmax_t>(lo + count, 0, M);
+            acc.assign((size_t)(hi - lo), 1.0);
+        } else {
+            const intmax_t radius = t.interp_radius, taps = t.interp_taps;
+            const intmax_t ix_first = (intmax_t)t.interp_indices[k];
+            const intmax_t ix_last = (intmax_t)t.interp_indices[k + (size_t)count - 1];
+            lo = std::clamp<intmax_t>(ix_first - radius + 1, 0, M);
+            hi = std::clamp<intmax_t>(std::max(ix_last, ix_first) + radius + 1, 0, M);
+            acc.assign((size_t)(hi - lo), 0.0);
+            for(intmax_t s = 0; s < count; ++s, ++k) {
+                // kernel_convolve(samples, sz, kernel, (intmax_t)x[k], l), src/filter.hpp:160-169
+                const intmax_t index = (intmax_t)t.interp_indices[k];
+                const intmax_t start = (index - radius) + 1;
+                const intmax_t stop = std::min(index + radius + 1, M);
+                for(intmax_t j = std::max<intmax_t>(start, 0); j < stop; ++j) {
+                    if(j >= lo && j < hi && (j - start) < taps)
+                        acc[(size_t)(j - lo)] += (double)t.interp_weights[k * (size_t)taps + (size_t)(j - start)];
+                }
+            }
+        }
+        t.bar_off[(size_t)i] = (int)t.bar_coef.size();
+        for(size_t j = 0; j < acc.size(); ++j) {
+            t.bar_coef.push_back((float)acc[j]);
+            t.bar_bin.push_back((int)(lo + (intmax_t)j));
+        }
+    }
+    t.bar_off[(size_t)num_bars] = (int)t.bar_coef.size();
 }
 
 } // namespace
+
+std::vector<int> bar_chunks(const HostTables &t, size_t cap_floats)
+{
+    std::vector<int> chunks{0};
+    int begin = 0;
+    for(int b = 0; b < t.num_bars; ++b) {
+        const size_t upto = (size_t)(t.bar_off[(size_t)b + 1] - t.bar_off[(size_t)begin]);
+        if(upto > cap_floats && b > begin) {
+            chunks.push_back(b);
+            begin = b;
+        }
+    }
+    chunks.push_back(t.num_bars);
+    return chunks;
+}
 
 float db_min()
 {

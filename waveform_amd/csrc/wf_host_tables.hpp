@@ -29,10 +29,16 @@ struct HostTables {
     int interp_radius = 0;               // m_interp_kernel.radius
     int interp_taps = 0;                 // m_interp_kernel.size
     float border_top = 0.0f, border_bottom = 0.0f, cpos = 0.0f; // render_bars geometry (:1480-1494)
+    // device form of the bar reduction: one dot product per bar over a contiguous bin range (see BarArgs)
+    std::vector<float> bar_coef;   // [entries]
+    std::vector<int> bar_bin;      // [entries] the bin each coefficient multiplies
+    std::vector<int> bar_off;      // [num_bars + 1]
 };
 
 // returns 0 on success, a negative wf_hip error code otherwise
 int build_host_tables(const wf_config &cfg, HostTables &out);
+// bar ranges whose entries fit `cap_floats` of LDS scratch together (every single bar fits: len <= M + 7 <= cap)
+std::vector<int> bar_chunks(const HostTables &t, size_t cap_floats);
 
 // get_gravity(seconds), src/source.hpp:301-312
 float gravity_for(const wf_config &cfg, float seconds);

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     bool nz = false;
     if(active && !hidden)
         nz = p1_fetch<G, ALIGNED>(a, t, x, start, r1);
+    const BarPre bar_pre = bars_preload<G>(a.bar, t);
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
     bool wave_below = true;
@@ -235,11 +236,10 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         if(have_row)
             store_row<G>(dbl, t, d);
         spectrum_sync<G>();
-        if(have_row) {
-            float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
-            bars_reduce_row<G>(a.bar, dbl, t >> 6, WPS, lane, out0, dup_row ? out0 + a.bar.num_bars : nullptr,
-                               [](float s) { return wave_sum(s); });
-        }
+        float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+        bars_reduce_row<G>(
+            a.bar, bar_pre, have_row, dbl, dbl + M, t, out0, dup_row ? out0 + a.bar.num_bars : nullptr, [] { spectrum_sync<G>(); },
+            [](float v, int m) { return v + __shfl_xor(v, m, 64); });
     }
 }
 
