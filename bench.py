@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
     ap.add_argument("--fft", type=int, default=FFT_SIZE)
+    ap.add_argument("--bars-allgather", action="store_true",
+                    help="BASELINE configs[4] shape: bars (26 Lanczos bars per channel) computed in the tick and all-gathered "
+                         "across ranks (RCCL over xGMI) after every step; changes the workload, so it is off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget (core-seconds) of the baseline leg")
     return ap.parse_args()
@@ -127,6 +130,9 @@ def main():
 
     cfg = wf.Config.defaults(fft_size=args.fft, stereo=1, slope=1.0, window=wf.WINDOW["hann"],
                              tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)
+    if args.bars_allgather:
+        cfg.bars = 1
+        cfg.interp_mode = wf.INTERP["lanczos"]
     total_ticks = args.warmup + args.steps
     ring_frames = args.fft + HOP * (total_ticks + 1)
     batch = wf.SpectrumBatch(cfg, args.streams, device=local_rank, ring_frames=ring_frames)
@@ -142,13 +148,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gather = None
+    if args.bars_allgather:
+        from waveform_amd.dist import shard_streams, allgather_bars
+        shard = shard_streams(args.streams * world, rank, world)
+        local_bars = torch.empty((args.streams, batch.display_channels, batch.num_bars), dtype=torch.float32, device="cuda")
+
+        def gather():
+            batch.copy_bars_to_device(local_bars.data_ptr())       # D2D on the library's stream (synchronised)
+            return allgather_bars(local_bars, shard)               # one all_gather_into_tensor
+
+    def run(n_ticks, first_delay):
+        """n_ticks steps; returns the average fused-kernel duration in ms"""
+        if gather is None:
+            return batch.time_ticks(n_ticks, HOP, first_delay)
+        ms = 0.0
+        for i in range(n_ticks):
+            ms += batch.time_ticks(1, HOP, first_delay - i * HOP)
+            gather()
+        return ms / n_ticks
+
     # warm-up: W untimed steps
     if args.warmup > 0:
-        batch.time_ticks(args.warmup, HOP, HOP * (total_ticks - 1))
+        run(args.warmup, HOP * (total_ticks - 1))
     barrier()
     t0 = time.perf_counter()
     # K timed steps: K launches of the fused kernel, HIP events around them on the library's stream
-    kernel_ms = batch.time_ticks(args.steps, HOP, HOP * (args.steps - 1))
+    kernel_ms = run(args.steps, HOP * (args.steps - 1))
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -179,10 +205,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]: {args.streams} independent stereo streams per GPU ({spectra_per_step} spectra/tick), "
-                            f"FFT={args.fft}, Hann, EMA g=0.65 + slope 1.0, 48 kHz counter-hash white noise, hop {HOP}",
+                "workload": (f"BASELINE configs[{4 if args.bars_allgather else 2}]{' shape (per GPU)' if args.bars_allgather else ''}: "
+                             f"{args.streams} independent stereo streams per GPU ({spectra_per_step} spectra/tick), "
+                             f"FFT={args.fft}, Hann, EMA g=0.65 + slope 1.0"
+                             f"{', 26 Lanczos bars per channel all-gathered' if args.bars_allgather else ''}, "
+                             f"48 kHz counter-hash white noise, hop {HOP}"),
                 "streams_per_gpu": args.streams, "fft_size": args.fft, "hop": HOP,
-                "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
+                "parallelism": (f"streams sharded over {world} GPU(s); bar heights all-gathered after every step" if args.bars_allgather
+                                else f"streams sharded over {world} GPU(s), no data-path collective"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

@@ -6,7 +6,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -18,11 +17,6 @@
 namespace {
 
 thread_local std::string g_create_error;
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
 
 } // namespace
 
@@ -444,6 +438,8 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
                            h->d_bars + (size_t)first * h->disp_ch * h->num_bars, nb, h->tab.border_bottom);
     }
     WF_HIP_TRY(h, hipGetLastError());
+    if(first == 0 && count == h->n_streams)
+        h->all_aligned = true; // every write position is back at fft_size
     return WF_HIP_OK;
 }
 
