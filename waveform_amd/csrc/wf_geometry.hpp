@@ -15,7 +15,14 @@ using G4096 = Geom<4096, 64, 16, 16, 8>;   // one wavefront, 32 points per threa
 #else
 using G4096 = Geom<4096, 128, 8, 16, 16>;  // two wavefronts, 16 points per thread: half the registers, twice the waves
 #endif
-using G8192 = Geom<8192, 128, 16, 16, 16>;
+#ifndef WF_G8192_T
+#define WF_G8192_T 256
+#endif
+#if WF_G8192_T == 128
+using G8192 = Geom<8192, 128, 16, 16, 16>;  // two wavefronts, 32 points per thread
+#else
+using G8192 = Geom<8192, 256, 16, 16, 16>;  // four wavefronts, 16 points per thread (one radix-16 butterfly per pass)
+#endif
 using G16384 = Geom<16384, 256, 16, 16, 32>;
 
 // calls f(G{}) for the geometry of fft_size n; returns false for unsupported sizes
