@@ -75,6 +75,15 @@ WF_DEV cf mul_w32(cf d, int q)
     return {fmaf(d.x, wr, -(d.y * wi)), fmaf(d.x, wi, d.y * wr)};
 }
 
+// (hf ? W_32^j : 1) for hf in {0.0f, 1.0f}, j in [0, 16) a compile-time constant after unrolling
+WF_DEV cf half_twiddle32(int j, float hf)
+{
+    float wr, wi; // W_32^j = (cos t, -sin t), t = 2 pi j / 32
+    if(j <= 8) { wr = cos32(j); wi = -cos32(8 - j); }
+    else { wr = -cos32(16 - j); wi = -cos32(j - 8); }
+    return {fmaf(hf, wr, 1.0f - hf), hf * wi}; // exact for both values of hf
+}
+
 constexpr int ilog2(int v) { return (v <= 1) ? 0 : 1 + ilog2(v >> 1); }
 constexpr int brev(int v, int bits) { return (bits == 0) ? 0 : ((v & 1) << (bits - 1)) | brev(v >> 1, bits - 1); }
 
@@ -109,7 +118,8 @@ template<int N_, int T_, int R1_, int R2_, int R3_> struct Geom {
     static constexpr int R1 = R1_, R2 = R2_, R3 = R3_;
     static constexpr int B1 = P / R1_;      // pass-1 butterflies per thread (1 or 2)
     static constexpr int B2 = P / R2_;
-    static constexpr int B3 = P / R3_;
+    static constexpr int H3 = (R3_ > P) ? R3_ / P : 1; // threads sharing one pass-3 butterfly (radix 32 with 16 points per thread)
+    static constexpr int B3 = (R3_ > P) ? 1 : P / R3_;
     static constexpr int M1 = M / R1_;      // = R2*R3 = T*B1
     // LDS exchange layouts (complex units).  ex1: [k1][n'] with padded row stride S1;
     // ex2: [q' = k1 + R1*k2][n3] rows of R3 with an XOR swizzle on 16-byte chunks;
@@ -123,7 +133,8 @@ template<int N_, int T_, int R1_, int R2_, int R3_> struct Geom {
     static_assert(B1 == 1 || B1 == 2, "pass 1 loads 8 or 16 bytes per thread");
     static_assert(T_ * B1 == M1, "pass-1 butterflies must tile the threads");
     static_assert(B2 >= 1 && (R3_ % B2) == 0, "pass-2 butterflies of a thread share k1");
-    static_assert(B3 >= 1 && T_ * B3 == R1_ * R2_, "pass-3 butterflies must tile the threads");
+    static_assert(H3 == 1 || H3 == 2, "a pass-3 butterfly is split over at most two threads");
+    static_assert(B3 >= 1 && T_ * B3 == R1_ * R2_ * H3, "pass-3 butterflies must tile the threads");
     static_assert((P % 4) == 0, "epilogue handles 4 bins per step");
 };
 

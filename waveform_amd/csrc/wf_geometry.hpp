@@ -1,6 +1,6 @@
 // wf_geometry.hpp -- the FFT decompositions the library ships, one per supported FFT size.
-// T threads per spectrum: one wavefront for N <= 4096, two for 8192, four for 16384; every
-// thread owns P = N/(2T) complex points (8, 16 or 32) so pass 1 fetches 8/16-byte vectors.
+// T threads per spectrum (1, 1, 2, 4, 8 wavefronts for N = 1024 ... 16384); every thread owns
+// P = N/(2T) complex points (8 or 16) so pass 1 fetches 8/16-byte vectors.
 #pragma once
 #include "wf_fft_core.hpp"
 
@@ -23,7 +23,14 @@ using G8192 = Geom<8192, 128, 16, 16, 16>;  // two wavefronts, 32 points per thr
 #else
 using G8192 = Geom<8192, 256, 16, 16, 16>;  // four wavefronts, 16 points per thread (one radix-16 butterfly per pass)
 #endif
-using G16384 = Geom<16384, 256, 16, 16, 32>;
+#ifndef WF_G16384_T
+#define WF_G16384_T 512
+#endif
+#if WF_G16384_T == 256
+using G16384 = Geom<16384, 256, 16, 16, 32>; // four wavefronts, 32 points per thread
+#else
+using G16384 = Geom<16384, 512, 16, 16, 32>; // eight wavefronts, 16 points per thread; the radix-32 pass is shared by thread pairs
+#endif
 
 // calls f(G{}) for the geometry of fft_size n; returns false for unsupported sizes
 template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)

@@ -484,6 +484,26 @@ template<class G> WF_DEV void p2_pass2_write(const cf *tw2, int t, cf *lds, cf (
 template<class G> WF_DEV void p3_read(int t, const cf *lds, cf (&v)[G::P])
 {
     constexpr int R3 = G::R3, B3 = G::B3, T = G::T;
+    if constexpr(G::H3 == 2) {
+        // radix 32 with 16 points per thread: threads 2q and 2q+1 share row q.  Both read the whole row; thread h
+        // keeps the first radix-2 stage's half that feeds the outputs k3 = 2k' + h:
+        //   h = 0: s[j] = v[j] + v[j+16]        h = 1: d[j] = (v[j] - v[j+16]) * W_32^j
+        // written select-free: u[j] = (v[j] + sg * v[j+16]) * (h ? W_32^j : 1).
+        constexpr int HALF = R3 / 2;
+        const int q = t >> 1;
+        const float hf = (float)(t & 1);
+        const float sg = 1.0f - 2.0f * hf;
+        WF_UNROLL
+        for(int j = 0; j < HALF; j += 2) {
+            const f4 lo = lds_ld4(lds, ex2_addr<G>(q, j));
+            const f4 hi = lds_ld4(lds, ex2_addr<G>(q, j + HALF));
+            const cf e0 = cf{fmaf(sg, hi.x, lo.x), fmaf(sg, hi.y, lo.y)};
+            const cf e1 = cf{fmaf(sg, hi.z, lo.z), fmaf(sg, hi.w, lo.w)};
+            v[j] = cmul(e0, half_twiddle32(j, hf));
+            v[j + 1] = cmul(e1, half_twiddle32(j + 1, hf));
+        }
+        return;
+    }
     WF_UNROLL
     for(int b = 0; b < B3; ++b) {
         const int q = t + T * b;
@@ -499,6 +519,19 @@ template<class G> WF_DEV void p3_read(int t, const cf *lds, cf (&v)[G::P])
 template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
 {
     constexpr int R1 = G::R1, R2 = G::R2, R3 = G::R3, B3 = G::B3, T = G::T;
+    if constexpr(G::H3 == 2) {
+        constexpr int HALF = R3 / 2, LBH = ilog2(HALF);
+        const int q = t >> 1, h = t & 1;
+        cf u[HALF];
+        WF_UNROLL
+        for(int j = 0; j < HALF; ++j)
+            u[j] = v[j];
+        dft_dif<HALF>(u);
+        WF_UNROLL
+        for(int kk = 0; kk < HALF; ++kk)
+            lds_st2(lds, ex3_addr<G>(q + R1 * R2 * (2 * kk + h)), u[brev(kk, LBH)]);
+        return;
+    }
     constexpr int LB = ilog2(R3);
     WF_UNROLL
     for(int b = 0; b < B3; ++b) {
