@@ -5,7 +5,9 @@ sys.path.insert(0, ".")
 os.environ.setdefault("WF_HIP_LIB", os.path.abspath("build/variants/lib_timing.so"))
 import waveform_amd as wf
 from tools import synth
-n, streams, hop, ticks = 4096, 4096, 800, 6
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+streams = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+hop, ticks = 800, 6
 cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=1.0)
 b = wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * (ticks + 2))
 b.push_synth(synth.DEFAULT_SEED, 0, hop * (ticks + 1))
@@ -25,4 +27,31 @@ tot = (s[:, 10] - s[:, 0])
 print("block lifetime: mean %.0f  p10 %.0f  p90 %.0f" % (tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
 for i, nm in enumerate(names):
     print(f"{nm:18s} mean {d[:, i].mean():9.1f}  ({100 * d[:, i].mean() / tot.mean():5.1f} %)   p90 {np.percentile(d[:, i], 90):9.1f}")
-print("kernel span (max end - min start):", s[:, 10].max() - s[:, 0].min())
+
+# ---- where and when: per-CU residency from HW_ID (slot 11) / XCC_ID (slot 12) ------------------------------
+hw, xcc = s[:, 11], s[:, 12] & 0xF
+cu = ((xcc << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF))
+# the cycle counters of different CUs are not synchronised: normalise per CU (the launch ramp is not visible this way)
+ids = np.unique(cu)
+start, end = np.zeros(nblk), np.zeros(nblk)
+for i in ids:
+    m = cu == i
+    start[m], end[m] = s[m, 0] - s[m, 0].min(), s[m, 10] - s[m, 0].min()
+span = np.median([end[cu == i].max() for i in ids])
+print(f"CUs seen: {len(ids)}  workgroups per CU: min {min((cu == i).sum() for i in ids)} max {max((cu == i).sum() for i in ids)}")
+print("per-CU span (first start -> last stamp-10): p10 %.0f p50 %.0f p90 %.0f ticks" %
+      tuple(np.percentile([end[cu == i].max() for i in ids], [10, 50, 90])))
+conc, gaps, first, last = [], [], [], []
+for i in ids:
+    m = cu == i
+    st, en = np.sort(start[m]), np.sort(end[m])
+    conc.append((end[m] - start[m]).sum() / en[-1])
+    first.append(st[0]); last.append(en[-1])
+    # k-th end is followed by the (slots + k)-th start when the CU refills a freed slot
+    slots = int((st < en[0]).sum())
+    for k in range(len(st) - slots):
+        gaps.append(st[slots + k] - en[k])
+print("mean resident workgroups per CU over the kernel span: %.2f" % np.mean(conc))
+if gaps:
+    print("slot refill gap (next start - freed end, stamp 10 is before the final stores drain): mean %.0f  p50 %.0f  p90 %.0f" %
+          (np.mean(gaps), np.percentile(gaps, 50), np.percentile(gaps, 90)))

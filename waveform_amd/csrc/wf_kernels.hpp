@@ -38,6 +38,30 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// global -> LDS copy of a BYTES-sized table by the LDS-DMA path (global_load_lds: destination = wave-uniform base +
+// lane * width, no VGPR staging); the waves of the workgroup share the chunks.  Tracked by vmcnt: complete after the
+// next wait for vector memory + barrier.
+template<int BYTES> __device__ __forceinline__ void lds_dma_copy(const void *src, void *lds_dst, int wave, int n_waves, int lane)
+{
+    constexpr int W = (BYTES % 1024 == 0) ? 16 : 4; // bytes per lane
+    constexpr int PER = 64 * W;                      // bytes per wave-wide request
+    static_assert(BYTES % PER == 0, "table size must be a multiple of the request size");
+    constexpr int CALLS = BYTES / PER;
+#pragma unroll
+    for(int c = 0; c < CALLS; ++c) {
+        if((c % n_waves) == wave) { // wave-uniform
+            const char *g = static_cast<const char *>(src) + c * PER + lane * W;
+            char *l = static_cast<char *>(lds_dst) + c * PER;
+            if constexpr(W == 16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)l, 4, 0, 0);
+        }
+    }
+}
+
 // Dynamic LDS: SPW exchange buffers of G::LDS_CF complex each, the pass-2 twiddle table [R2][R3], then one int of
 // per-wavefront facts per wave.
 template<class G, int SPW> constexpr size_t tick_lds_bytes()
@@ -57,8 +81,17 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
         if(threadIdx.x == 0 && a.phase_clock)                                            \
             a.phase_clock[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
     } while(0)
+// where the workgroup ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID, for per-CU residency timelines
+#define WF_STAMP_HWID()                                                                                          \
+    do {                                                                                                         \
+        if(threadIdx.x == 0 && a.phase_clock) {                                                                  \
+            a.phase_clock[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4); \
+            a.phase_clock[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20); \
+        }                                                                                                        \
+    } while(0)
 #else
 #define WF_STAMP(i)
+#define WF_STAMP_HWID()
 #endif
 
 template<class G, int SPW, bool ALIGNED>
@@ -71,34 +104,43 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const int t = tid % T;            // thread within the spectrum
     const int lane = tid & 63;
     const int wave_in_block = tid >> 6;
+    // Prologue: nothing here may wait for memory before the window fetch is in flight.  The spectrum index is clamped
+    // (no branch), stream/channel come from a shift (cap_ch is 1 or 2), and the two per-stream words (write position,
+    // flags) are scalar loads issued together.
     const uint32_t n_spec = a.n_streams * a.cap_ch;
-    const uint32_t spec = blockIdx.x * SPW + (uint32_t)sub;
-    const bool active = spec < n_spec;
-    const uint32_t stream = active ? spec / a.cap_ch : 0u;
-    const uint32_t ch = active ? spec % a.cap_ch : 0u;
+    const uint32_t spec_raw = blockIdx.x * SPW + (uint32_t)sub;
+    const bool active = spec_raw < n_spec;
+    const uint32_t spec = active ? spec_raw : n_spec - 1;
+    const uint32_t cap_shift = a.cap_ch - 1;
+    const uint32_t stream = spec >> cap_shift;
+    const uint32_t ch = spec & cap_shift;
     const bool stereo = (a.mode & WF_MODE_STEREO) != 0;
     const bool mono_mix = (a.mode & WF_MODE_MONO_MIX) != 0;
+    const uint32_t wpos = a.wpos[stream];
+    const uint32_t sflags = a.stream_flags[stream];
 
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * G::LDS_CF;
     cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF;
     int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
-    for(int i = tid; i < G::R2 * G::R3; i += T * SPW) // the workgroup's copy of the pass-2 twiddles
-        tw2_lds[i] = a.tw2[i];
-    const float *x = a.ring + (size_t)(active ? spec : 0u) * a.ring_cap;
-    const uint32_t start = (a.wpos[stream] - a.delay - (uint32_t)G::N) & a.ring_mask;
-    float *ts = a.tsmooth + (size_t)(active ? spec : 0u) * M;
+    const float *x = a.ring + (size_t)spec * a.ring_cap;
+    const uint32_t start = (wpos - a.delay - (uint32_t)G::N) & a.ring_mask;
+    float *ts = a.tsmooth + (size_t)spec * M;
     float *rows = a.decibels + (size_t)stream * a.out_ch * M; // m_decibels[0..out_ch) of this stream
 
-    const uint32_t sflags = active ? a.stream_flags[stream] : 0u;
     const bool hidden = (sflags & WF_STREAM_HIDDEN) != 0;
     const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
 
     WF_STAMP(0);
+    WF_STAMP_HWID();
     // ---- fetch the window; per-wavefront facts for the silence state machine (reference :55-95) ----------
+    // (hidden streams are fetched too: the flags word is not waited for before the loads are issued)
     P1Regs<G> r1;
     bool nz = false;
-    if(active && !hidden)
-        nz = p1_fetch<G, ALIGNED>(a, t, x, start, r1);
+    if(active)
+        nz = p1_fetch<G, ALIGNED>(a, t, x, start, r1) && !hidden;
+    // the workgroup's copy of the pass-2 twiddles: LDS-DMA (no staging registers), requested behind the window so that it
+    // costs no round trip of its own; complete at the barrier below
+    lds_dma_copy<G::R2 * G::R3 * (int)sizeof(cf)>(a.tw2, tw2_lds, wave_in_block, T * SPW / 64, lane);
     const BarPre bar_pre = bars_preload<G>(a.bar, t);
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
