@@ -22,6 +22,9 @@ assert L.wf_hip_debug_phase_clock(b.h, buf.ctypes.data, buf.size) == 0
 s = buf.reshape(nblk, 16).astype(np.int64)
 d = np.diff(s[:, :11], axis=1)
 names = ["fetch+nz", "facts xchg", "p1 win+pass1", "sync+p2 read", "p2 dft+write", "sync+p3 read", "p3 dft+write", "sync", "p4 split+smooth", "dB+store"]
+if os.environ.get("WF_HIP_KERNEL") == "pipe":
+    names = ["tables+wait window", "samples+facts xchg", "p1 win+pass1", "sync+p2 read", "p2 dft+write", "sync+p3 read", "p3 dft+write+sync",
+             "p4 loads+sync+dma issue", "p4 math", "dB+store"]
 print("stamps are s_memtime ticks (100 MHz constant clock?) -- relative shares matter")
 tot = (s[:, 10] - s[:, 0])
 print("block lifetime: mean %.0f  p10 %.0f  p90 %.0f" % (tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
