@@ -155,4 +155,21 @@ template<class G> WF_DEV int ex2_addr(int q, int n3)
 }
 template<class G> WF_DEV int ex3_addr(int k) { return k + (k >> 6) * 2; }
 
+// Address algebra the compiler does not find by itself (every helper below is checked against the plain formulas by
+// tests/emu, which replays the kernel's phase functions lane by lane):
+//  * ex3 is affine in steps that are multiples of 64 bins:  ex3_addr(k + 64*m) == ex3_addr(k) + 66*m
+//  * ex2: for q = k1 + R1*k2 the swizzle term of a thread's store is its k2 = 0 address XOR a compile-time constant:
+//        ex2_addr(k1 + R1*k2, n3) == (ex2_addr(k1, n3) ^ ex2_xor<G>(k2)) + k2*R1*R3
+//    (R1 is a multiple of the rows per bank row, so swz(q) = (k1/RPB + (R1/RPB)*k2) mod CH, and k1/RPB < R1/RPB has no
+//    bit in common with (R1/RPB)*k2.)
+template<class G> constexpr int ex3_step(int bins) { return bins + (bins / 64) * 2; } // bins % 64 == 0
+template<class G> constexpr int ex2_xor(int k2)
+{
+    constexpr int CH = G::R3 / 2;
+    constexpr int RPB = (32 / G::R3) > 0 ? (32 / G::R3) : 1;
+    static_assert(G::R1 % RPB == 0, "ex2 swizzle algebra needs R1 to be a multiple of the rows per bank row");
+    if(CH < 2) return 0;
+    return (((G::R1 / RPB) * k2) & (CH - 1)) * 2;
+}
+
 } // namespace wf

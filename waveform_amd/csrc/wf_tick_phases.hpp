@@ -397,14 +397,17 @@ template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float 
         return;
     }
     const StreamBuf tb = make_stream_buf(ts, (uint32_t)G::M * 4u);
+    if(Policy<G>::PREFETCH_STATE && (a.mode & WF_MODE_TSMOOTH)) { // one scalar branch around all of the state loads
+        constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
+        WF_UNROLL
+        for(int u = 0; u < P / 4; ++u) {
+            const f4 o = ld4_buf(tb, (uint32_t)(4 * (t + T * u)));
+            q.st[S * (4 * u)] = o.x; q.st[S * (4 * u + 1)] = o.y; q.st[S * (4 * u + 2)] = o.z; q.st[S * (4 * u + 3)] = o.w;
+        }
+    }
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         const int k0 = 4 * (t + T * u);
-        if(Policy<G>::PREFETCH_STATE && (a.mode & WF_MODE_TSMOOTH)) {
-            constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
-            const f4 o = ld4_buf(tb, (uint32_t)k0);
-            q.st[S * (4 * u)] = o.x; q.st[S * (4 * u + 1)] = o.y; q.st[S * (4 * u + 2)] = o.z; q.st[S * (4 * u + 3)] = o.w;
-        }
         if(Policy<G>::PREFETCH_SLOPE) {
             constexpr int S = Policy<G>::PREFETCH_SLOPE ? 1 : 0;
             const f4 o = ld4(a.slope + k0);
@@ -443,6 +446,7 @@ template<class G> WF_DEV void p2_pass2_write(const cf *tw2, int t, cf *lds, cf (
     constexpr int LB = ilog2(R2);
     const int q0 = B2 * t;
     const int k1 = q0 / R3, n30 = q0 % R3;
+    const int a20 = ex2_addr<G>(k1, n30);
     cf u[B2][R2];
     WF_UNROLL
     for(int b = 0; b < B2; ++b) {
@@ -471,7 +475,8 @@ template<class G> WF_DEV void p2_pass2_write(const cf *tw2, int t, cf *lds, cf (
         }
         const int q = k1 + R1 * k2;
         if(B2 == 1) {
-            lds_st2(lds, ex2_addr<G>(q, n30), o[0]);
+            // == ex2_addr<G>(q, n30): two distinct base registers per thread, the rest is an immediate offset
+            lds_st2(lds, (a20 ^ ex2_xor<G>(k2)) + k2 * R1 * R3, o[0]);
         } else {
             WF_UNROLL
             for(int b = 0; b < B2; b += 2)
@@ -521,15 +526,17 @@ template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
     constexpr int R1 = G::R1, R2 = G::R2, R3 = G::R3, B3 = G::B3, T = G::T;
     if constexpr(G::H3 == 2) {
         constexpr int HALF = R3 / 2, LBH = ilog2(HALF);
+        static_assert((R1 * R2) % 64 == 0, "ex3 stride algebra");
         const int q = t >> 1, h = t & 1;
         cf u[HALF];
         WF_UNROLL
         for(int j = 0; j < HALF; ++j)
             u[j] = v[j];
         dft_dif<HALF>(u);
+        const int a3 = ex3_addr<G>(q + R1 * R2 * h); // == ex3_addr<G>(q + R1*R2*(2*kk + h)) - kk * ex3_step(2*R1*R2)
         WF_UNROLL
         for(int kk = 0; kk < HALF; ++kk)
-            lds_st2(lds, ex3_addr<G>(q + R1 * R2 * (2 * kk + h)), u[brev(kk, LBH)]);
+            lds_st2(lds, a3 + kk * ex3_step<G>(2 * R1 * R2), u[brev(kk, LBH)]);
         return;
     }
     constexpr int LB = ilog2(R3);
@@ -540,62 +547,37 @@ template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
         for(int n3 = 0; n3 < R3; ++n3)
             u[n3] = v[b * R3 + n3];
         dft_dif<R3>(u);
+        static_assert((R1 * R2) % 64 == 0, "ex3 stride algebra");
         const int q = t + T * b;
+        const int a3 = ex3_addr<G>(q); // == ex3_addr<G>(q + R1*R2*k3) - k3 * ex3_step(R1*R2)
         WF_UNROLL
         for(int k3 = 0; k3 < R3; ++k3)
-            lds_st2(lds, ex3_addr<G>(q + R1 * R2 * k3), u[brev(k3, LB)]);
+            lds_st2(lds, a3 + k3 * ex3_step<G>(R1 * R2), u[brev(k3, LB)]);
     }
 }
 
 // ---- P4: real split + epilogue ------------------------------------------------------------------
-// Produces the smoothed linear magnitudes of bins 4g..4g+3 (g = t + T*u) in mag[u][0..3],
-// updating the temporal-smoothing state on the way (reference :110-135).
+// Produces the smoothed linear magnitudes of bins 4g..4g+3 (g = t + T*u) in mag[u][0..3], updating the temporal-smoothing
+// state on the way (reference :110-135).  The smoothing mode is a property of the configuration: the kernel branches on it
+// once (a scalar branch) into a body compiled for it -- TS: m_tsmoothing != NONE, FPK: m_fast_peaks -- instead of testing
+// mode bits per bin (which also made every conditionally loaded register a zero-initialised one).
+//
 // slope (reference :121-122) and temporal smoothing incl. fast peaks (:124-132) of bin group u; the slope table is all ones
-// when m_slope <= 0.  The operands come from the registers they were fetched into: P4Regs (prefetched behind passes 2-3),
-// st_all/sl_all (fetched at the top of P4) or straight from memory (threads with 32 points).
-template<class G, int NA>
-WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, const P4Regs<G> &q, const float (&st_all)[NA],
-                                  const float (&sl_all)[NA], float (&mag)[G::P])
+// when m_slope <= 0.  st4v/sl4 are this group's m_tsmooth_buf / m_slope_modifiers values.
+template<class G, bool TS, bool FPK>
+WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, const float (&st4v)[4], const float (&sl4)[4],
+                                  float (&mag)[G::P])
 {
     constexpr int T = G::T;
-    constexpr bool ALL = (NA > 1);
     const int k0 = 4 * (t + T * u);
-    float sl4[4];
-    if(Policy<G>::PREFETCH_SLOPE) {
-        constexpr int S = Policy<G>::PREFETCH_SLOPE ? 1 : 0;
-        WF_UNROLL
-        for(int i = 0; i < 4; ++i)
-            sl4[i] = q.sl[S * (4 * u + i)];
-    } else if(ALL) {
-        WF_UNROLL
-        for(int i = 0; i < 4; ++i)
-            sl4[i] = sl_all[(ALL ? 1 : 0) * (4 * u + i)];
-    } else {
-        const f4 o = ld4(a.slope + k0);
-        sl4[0] = o.x; sl4[1] = o.y; sl4[2] = o.z; sl4[3] = o.w;
-    }
     WF_UNROLL
     for(int i = 0; i < 4; ++i)
         mag[4 * u + i] *= sl4[i];
-    if(a.mode & WF_MODE_TSMOOTH) {
-        float st4v[4];
-        if(Policy<G>::PREFETCH_STATE) {
-            constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
-            WF_UNROLL
-            for(int i = 0; i < 4; ++i)
-                st4v[i] = q.st[S * (4 * u + i)];
-        } else if(ALL) {
-            WF_UNROLL
-            for(int i = 0; i < 4; ++i)
-                st4v[i] = st_all[(ALL ? 1 : 0) * (4 * u + i)];
-        } else {
-            const f4 o = ld4_stream(ts + k0);
-            st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
-        }
+    if(TS) {
         WF_UNROLL
         for(int i = 0; i < 4; ++i) {
             float old = st4v[i];
-            if(a.mode & WF_MODE_FAST_PEAKS)
+            if(FPK)
                 old = fmaxf(mag[4 * u + i], old);
             // (g * oldval) + (g2 * mag) (reference :130); evaluated as fma(g, old, g2*mag) like the reference's own
             // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
@@ -605,34 +587,76 @@ WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, co
     }
 }
 
-template<class G>
-WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[G::P])
+template<class G, bool TS, bool FPK>
+WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q,
+                                 float (&mag)[G::P])
 {
     constexpr int M = G::M, T = G::T, P = G::P;
     // Threads with register headroom (P <= 16) that did not prefetch state/slope earlier issue ALL of those loads now and
     // consume them only after the whole real split (two loops), so the split math covers their latency.  Threads with
     // 32 points load group by group.
     constexpr bool LOAD_ALL_FIRST = Policy<G>::EARLY_TABLES && !Policy<G>::PREFETCH_STATE;
-    float st_all[LOAD_ALL_FIRST ? P : 1], sl_all[LOAD_ALL_FIRST ? P : 1];
+    float st_all[LOAD_ALL_FIRST ? P : 4], sl_all[LOAD_ALL_FIRST ? P : 4];
     if(LOAD_ALL_FIRST) {
-        constexpr int S = LOAD_ALL_FIRST ? 1 : 0;
         WF_UNROLL
         for(int u = 0; u < P / 4; ++u) {
             const int k0 = 4 * (t + T * u);
-            if(a.mode & WF_MODE_TSMOOTH) {
+            if(TS) {
                 const f4 o = ld4_stream(ts + k0);
-                st_all[S * (4 * u)] = o.x; st_all[S * (4 * u + 1)] = o.y; st_all[S * (4 * u + 2)] = o.z; st_all[S * (4 * u + 3)] = o.w;
+                st_all[4 * u] = o.x; st_all[4 * u + 1] = o.y; st_all[4 * u + 2] = o.z; st_all[4 * u + 3] = o.w;
             }
             const f4 sv = ld4(a.slope + k0);
-            sl_all[S * (4 * u)] = sv.x; sl_all[S * (4 * u + 1)] = sv.y; sl_all[S * (4 * u + 2)] = sv.z; sl_all[S * (4 * u + 3)] = sv.w;
+            sl_all[4 * u] = sv.x; sl_all[4 * u + 1] = sv.y; sl_all[4 * u + 2] = sv.z; sl_all[4 * u + 3] = sv.w;
         }
     }
+    // this group's state / slope operands, from wherever the policy put them
+    auto group = [&](int u) {
+        const int k0 = 4 * (t + T * u);
+        float st4v[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sl4[4];
+        if(Policy<G>::PREFETCH_SLOPE) {
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i)
+                sl4[i] = q.sl[(Policy<G>::PREFETCH_SLOPE ? 1 : 0) * (4 * u + i)];
+        } else if(LOAD_ALL_FIRST) {
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i)
+                sl4[i] = sl_all[(LOAD_ALL_FIRST ? 1 : 0) * (4 * u + i)];
+        } else {
+            const f4 o = ld4(a.slope + k0);
+            sl4[0] = o.x; sl4[1] = o.y; sl4[2] = o.z; sl4[3] = o.w;
+        }
+        if(TS) {
+            if(Policy<G>::PREFETCH_STATE) {
+                WF_UNROLL
+                for(int i = 0; i < 4; ++i)
+                    st4v[i] = q.st[(Policy<G>::PREFETCH_STATE ? 1 : 0) * (4 * u + i)];
+            } else if(LOAD_ALL_FIRST) {
+                WF_UNROLL
+                for(int i = 0; i < 4; ++i)
+                    st4v[i] = st_all[(LOAD_ALL_FIRST ? 1 : 0) * (4 * u + i)];
+            } else {
+                const f4 o = ld4_stream(ts + k0);
+                st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
+            }
+        }
+        p4_slope_smooth_group<G, TS, FPK>(a, t, u, ts, st4v, sl4, mag);
+    };
     // ---- loop 1: real split -> |2X| * coef/2 -------------------------------------------------------------------------
+    // LDS addresses: bins advance by 4T (a multiple of 64) per group, so every group is the first one's address plus a
+    // compile-time step.  Z[k0 + i] sits at aA (+2 for the second pair); the mirrored bins M - k0 - i at aB[i] - u*step,
+    // except bin M - 0 = 0 for the very first bin of thread 0.
+    static_assert((4 * T) % 64 == 0, "ex3 stride algebra");
+    const int aA = ex3_addr<G>(4 * t);
+    int aB[4];
+    WF_UNROLL
+    for(int i = 0; i < 4; ++i)
+        aB[i] = ex3_addr<G>(M - 4 * t - i - 4 * T * (P / 4 - 1)); // the LAST group's address: offsets below stay non-negative
+    const int aB00 = ex3_addr<G>((M - 4 * t) & (M - 1));
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         const int k0 = 4 * (t + T * u);
-        const f4 za = lds_ld4(lds, ex3_addr<G>(k0));
-        const f4 zb = lds_ld4(lds, ex3_addr<G>(k0 + 2));
+        const f4 za = lds_ld4(lds, aA + u * ex3_step<G>(4 * T));
+        const f4 zb = lds_ld4(lds, aA + u * ex3_step<G>(4 * T) + 2);
         const cf A[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
         cf Wl[4];
         if(!Policy<G>::EARLY_TABLES) { // threads short of registers read the split twiddles where they are used
@@ -643,7 +667,7 @@ WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, 
         WF_UNROLL
         for(int i = 0; i < 4; ++i) {
             const cf W = Policy<G>::EARLY_TABLES ? mul_w32(wb[i], u * (64 / P)) : Wl[i]; // W_N^(k0 + i)
-            const cf B = lds_ld2(lds, ex3_addr<G>((M - k0 - i) & (M - 1)));
+            const cf B = lds_ld2(lds, (u == 0 && i == 0) ? aB00 : aB[i] + (P / 4 - 1 - u) * ex3_step<G>(4 * T));
             // 2X[k] = (A + conj B) - i W (A - conj B)
             const float er = A[i].x + B.x, ei = A[i].y - B.y;
             const float dr = A[i].x - B.x, di = A[i].y + B.y;
@@ -653,14 +677,26 @@ WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, 
             mag[4 * u + i] = mag2(xr, xi) * a.half_coef;
         }
         if(!LOAD_ALL_FIRST)
-            p4_slope_smooth_group<G>(a, t, u, ts, q, st_all, sl_all, mag);
+            group(u);
     }
     // ---- loop 2: slope, temporal smoothing, state store ----------------------------------------------------------------
     if(LOAD_ALL_FIRST) {
         WF_UNROLL
         for(int u = 0; u < P / 4; ++u)
-            p4_slope_smooth_group<G>(a, t, u, ts, q, st_all, sl_all, mag);
+            group(u);
     }
+}
+
+template<class G>
+WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[G::P])
+{
+    if(a.mode & WF_MODE_TSMOOTH) {
+        if(a.mode & WF_MODE_FAST_PEAKS)
+            p4_split_smooth_impl<G, true, true>(a, t, lds, ts, wb, q, mag);
+        else
+            p4_split_smooth_impl<G, true, false>(a, t, lds, ts, wb, q, mag);
+    } else
+        p4_split_smooth_impl<G, false, false>(a, t, lds, ts, wb, q, mag);
 }
 
 // dB conversion + volume normalisation + roll-off of this thread's bins (reference :144-179); d[] is the
