@@ -8,7 +8,8 @@ from tools import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 streams = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 hop, ticks = 800, 6
-cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=1.0)
+extra = dict(bars=1, interp_mode=1) if os.environ.get("WF_BENCH_BARS") else {}
+cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=1.0, **extra)
 b = wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * (ticks + 2))
 b.push_synth(synth.DEFAULT_SEED, 0, hop * (ticks + 1))
 for i in range(ticks):
@@ -31,8 +32,12 @@ print("block lifetime: mean %.0f  p10 %.0f  p90 %.0f" % (tot.mean(), np.percenti
 for i, nm in enumerate(names):
     print(f"{nm:18s} mean {d[:, i].mean():9.1f}  ({100 * d[:, i].mean() / tot.mean():5.1f} %)   p90 {np.percentile(d[:, i], 90):9.1f}")
 
+print("after stamp 10 (flags store, bars if any) until the end of the kernel: mean %.0f ticks" % (s[:, 13] - s[:, 10]).mean())
+if os.environ.get("WF_BENCH_BARS"):
+    print("bars: row->LDS+syncs %.0f | A products+sync %.0f | B1 segment sums+sync %.0f | B2 bar sums+stores %.0f" %
+          ((s[:, 12] - s[:, 10]).mean(), (s[:, 14] - s[:, 12]).mean(), (s[:, 15] - s[:, 14]).mean(), (s[:, 13] - s[:, 15]).mean()))
 # ---- where and when: per-CU residency from HW_ID (slot 11) / XCC_ID (slot 12) ------------------------------
-hw, xcc = s[:, 11], s[:, 12] & 0xF
+hw, xcc = s[:, 11], 0 * s[:, 11]
 cu = ((xcc << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF))
 # the cycle counters of different CUs are not synchronised: normalise per CU (the launch ramp is not visible this way)
 ids = np.unique(cu)

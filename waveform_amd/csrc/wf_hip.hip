@@ -43,7 +43,10 @@ struct wf_hip {
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
     float *d_bar_coef = nullptr;
     int *d_bar_bin = nullptr, *d_bar_off = nullptr, *d_band_widths = nullptr, *d_bar_chunk = nullptr;
-    int bar_chunks = 0, bar_lpb = 1;
+    int bar_chunks = 0, bar_lpb = 1, bar_segs = 0;
+    int bar_blocks = 0;
+    float *d_lane_coef = nullptr;
+    int *d_lane_bin = nullptr, *d_bar_seg = nullptr;
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;
@@ -162,6 +165,11 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.count = h->d_band_widths;
         a.bar.chunk = h->d_bar_chunk;
         a.bar.num_chunks = h->bar_chunks;
+        a.bar.lane_coef = h->d_lane_coef;
+        a.bar.lane_bin = h->d_lane_bin;
+        a.bar.bar_seg = h->d_bar_seg;
+        a.bar.num_segs = h->bar_segs;
+        a.bar.lane_blocks = h->bar_blocks;
         a.bar.entries = (int)h->tab.bar_coef.size();
         a.bar.lanes_per_bar = h->bar_lpb;
         a.bar.out = h->d_bars;
@@ -366,6 +374,17 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         while(lpb < 64 && (uint32_t)(threads / (lpb * 2)) >= h->num_bars)
             lpb *= 2;
         h->bar_lpb = lpb;
+        wf::BarLaneTables lanes;
+        int points = 16;
+        wf::dispatch_geometry(h->N, [&](auto g) { points = decltype(g)::P; });
+        if(wf::bar_segments(h->tab, threads, points / 4 + 1, lanes)) {
+            h->bar_segs = lanes.num_segs;
+            h->bar_blocks = lanes.blocks;
+            WF_CREATE_TRY(upload(h, &h->d_lane_coef, lanes.coef));
+            WF_CREATE_TRY(upload(h, &h->d_lane_bin, lanes.bin));
+            WF_CREATE_TRY(upload(h, &h->d_bar_seg, lanes.bar_seg));
+            WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
+        }
     }
 
     // FFT plan: twiddle tables for the geometry of this fft_size + the kernel instantiation

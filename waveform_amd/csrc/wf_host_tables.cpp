@@ -284,6 +284,52 @@ std::vector<int> bar_chunks(const HostTables &t, size_t cap_floats)
     return chunks;
 }
 
+bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out)
+{
+    out = BarLaneTables{};
+    if(t.num_bars <= 0 || t.num_bars > threads)
+        return false;
+    auto count_for = [&](int L) {
+        long n = 0;
+        for(int b = 0; b < t.num_bars; ++b) {
+            const int len = t.bar_off[(size_t)b + 1] - t.bar_off[(size_t)b];
+            n += len == 0 ? 1 : (len + L - 1) / L;
+        }
+        return n;
+    };
+    int L = 4;
+    while(count_for(L) > threads) // smallest multiple of 4 whose segment count fits the threads (num_bars <= threads)
+        L += 4;
+    if(L / 4 > max_blocks)
+        return false;
+    std::vector<int> seg_start, seg_len;
+    for(int b = 0; b < t.num_bars; ++b) {
+        out.bar_seg.push_back((int)seg_start.size());
+        const int o = t.bar_off[(size_t)b], len = t.bar_off[(size_t)b + 1] - o;
+        if(len == 0) {
+            seg_start.push_back(o);
+            seg_len.push_back(0);
+        }
+        for(int k = 0; k < len; k += L) {
+            seg_start.push_back(o + k);
+            seg_len.push_back(len - k < L ? len - k : L);
+        }
+    }
+    out.bar_seg.push_back((int)seg_start.size());
+    out.num_segs = (int)seg_start.size();
+    out.blocks = L / 4;
+    // lane-major: block c of lane s at [(c * threads + s) * 4, +4)  ->  one coalesced 16-byte load per lane and block
+    out.coef.assign((size_t)out.blocks * threads * 4, 0.0f);
+    out.bin.assign((size_t)out.blocks * threads * 4, 0);
+    for(int s = 0; s < out.num_segs; ++s)
+        for(int k = 0; k < seg_len[(size_t)s]; ++k) {
+            const size_t dst = ((size_t)(k / 4) * threads + s) * 4 + (size_t)(k % 4);
+            out.coef[dst] = t.bar_coef[(size_t)seg_start[(size_t)s] + k];
+            out.bin[dst] = t.bar_bin[(size_t)seg_start[(size_t)s] + k];
+        }
+    return true;
+}
+
 float db_min()
 {
     // const float WAVSource::DB_MIN = 20.0f * std::log10(std::numeric_limits<float>::min()); (src/source.cpp:43)

@@ -40,6 +40,18 @@ int build_host_tables(const wf_config &cfg, HostTables &out);
 // bar ranges whose entries fit `cap_floats` of LDS scratch together (every single bar fits: len <= M + 7 <= cap)
 std::vector<int> bar_chunks(const HostTables &t, size_t cap_floats);
 
+// Device form of the bar tables when every thread of a spectrum can own one segment: the entries cut into at most
+// `threads` segments of near-equal length (a multiple of 4, at most 4 * max_blocks) that never straddle a bar; bar b owns
+// segments [bar_seg[b], bar_seg[b+1]); coefficient/bin tables re-laid lane-major and zero-padded.  false if the bars
+// outnumber the threads or the segments would be longer than the kernel holds in registers.
+struct BarLaneTables {
+    std::vector<float> coef;  // [blocks][threads][4]
+    std::vector<int> bin;     // [blocks][threads][4]
+    std::vector<int> bar_seg; // [num_bars + 1]
+    int num_segs = 0, blocks = 0;
+};
+bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out);
+
 // get_gravity(seconds), src/source.hpp:301-312
 float gravity_for(const wf_config &cfg, float seconds);
 // DB_MIN, src/source.cpp:43

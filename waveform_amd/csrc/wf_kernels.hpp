@@ -255,6 +255,9 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         }
     }
     WF_STAMP(9);
+    // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
+    BarEntries<G> bar_entries;
+    bars_fetch_entries<G>(a.bar, t, bar_entries);
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
@@ -279,10 +282,18 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             store_row<G>(dbl, t, d);
         spectrum_sync<G>();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+#ifdef WF_PHASE_TIMING
+        BarArgs bar_args = a.bar;
+        bar_args.clk = (a.phase_clock && threadIdx.x == 0) ? a.phase_clock + (size_t)blockIdx.x * 16 : nullptr;
+        WF_STAMP(12);
+#else
+        const BarArgs &bar_args = a.bar;
+#endif
         bars_reduce_row<G>(
-            a.bar, bar_pre, have_row, dbl, dbl + M, t, out0, dup_row ? out0 + a.bar.num_bars : nullptr, [] { spectrum_sync<G>(); },
-            [](float v, int m) { return v + __shfl_xor(v, m, 64); });
+            bar_args, bar_pre, bar_entries, have_row, dbl, dbl + M, t, out0, dup_row ? out0 + a.bar.num_bars : nullptr,
+            [] { spectrum_sync<G>(); }, [](float v, int m) { return v + __shfl_xor(v, m, 64); });
     }
+    WF_STAMP(13);
 }
 
 // ---- ring maintenance ---------------------------------------------------------------------------

@@ -50,6 +50,18 @@ struct BarArgs {
     const int *off;            // [num_bars + 1]
     const int *count;          // [num_bars] m_band_widths
     const int *chunk;          // [num_chunks + 1] bar ranges whose entries fit the LDS scratch together
+    // Usual case (bars <= threads per spectrum): every thread owns one segment of the entries -- near-equal lengths,
+    // never straddling a bar (the bars' own lengths differ by two orders of magnitude on a log axis) -- with its
+    // (coefficient, bin) pairs laid lane-major: block c of thread s at [(c*T + s)*4, +4), zero-padded.  Bar b owns
+    // segments [bar_seg[b], bar_seg[b+1]).  num_segs == 0: not built, the flat tables above are used chunk by chunk.
+    const float *lane_coef;    // [lane_blocks][T][4]
+    const int *lane_bin;       // [lane_blocks][T][4]
+    const int *bar_seg;        // [num_bars + 1]
+    int num_segs;
+    int lane_blocks;
+#ifdef WF_PHASE_TIMING
+    unsigned long long *clk;   // development aid: this workgroup's stamp slots
+#endif
     float *out;                // [n_streams][disp_ch][num_bars]
     int num_bars;
     int num_chunks;
@@ -60,6 +72,12 @@ struct BarArgs {
     float ceiling, dbrange;    // m_ceiling, m_ceiling - m_floor
     uint32_t disp_ch;
 };
+
+#ifdef WF_PHASE_TIMING
+#define WF_BAR_STAMP(i) do { if(t == 0 && b.clk) b.clk[i] = __builtin_readcyclecounter(); } while(0)
+#else
+#define WF_BAR_STAMP(i)
+#endif
 
 struct TickArgs {
     // audio rings: one per (stream, captured channel), ring_cap samples each (power of two)
@@ -841,40 +859,129 @@ WF_DEV float lerp_std(float a, float b, float t)
 // What a thread needs to know about "its" bar in the first pass of the first chunk (bar = t / lanes_per_bar).  Fetched at
 // the very start of the kernel with the audio window, so that the bars phase at the end does not begin with a chain of
 // dependent table loads.
-struct BarPre { int off, len, count; };
+struct BarPre { int off, len, count; int s0, s1; };
 template<class G> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 {
-    BarPre p{0, 0, 1};
+    BarPre p{0, 0, 1, 0, 0};
     if(b.out != nullptr) {
-        const int bar = t / b.lanes_per_bar;
-        if(bar < b.num_bars) {
-            p.off = b.off[bar];
-            p.len = b.off[bar + 1] - p.off;
-            p.count = b.count[bar];
+        if(b.num_segs > 0) { // bar t's segment range
+            if(t < b.num_bars) {
+                p.s0 = b.bar_seg[t];
+                p.s1 = b.bar_seg[t + 1];
+                p.count = b.count[t];
+            }
+        } else {
+            const int bar = t / b.lanes_per_bar;
+            if(bar < b.num_bars) {
+                p.off = b.off[bar];
+                p.len = b.off[bar + 1] - p.off;
+                p.count = b.count[bar];
+            }
         }
     }
     return p;
 }
 
-// Called by every thread of the workgroup (sync may be a block barrier); `has_row` says whether this spectrum produced one.
-template<class G, class Sync, class XorSum>
-WF_DEV void bars_reduce_row(const BarArgs &b, const BarPre &pre, bool has_row, const float *db, float *prod, int t, float *out_row,
-                            float *dup_row, Sync sync, XorSum xor_sum)
+// The (coefficient, bin) pairs of this thread's segment: 16-byte loads, coalesced across the threads, requested before
+// the dB math so that their L2 latency is off the critical path.
+template<class G> struct BarEntries {
+    static constexpr int CMAX = G::P / 4 + 1; // the host builds segments of at most 4 * CMAX entries
+    f4 coef[CMAX];
+    int bin[CMAX][4];
+};
+template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be)
 {
     constexpr int T = G::T;
+    if(b.out == nullptr || b.num_segs == 0)
+        return;
+    WF_UNROLL
+    for(int c = 0; c < BarEntries<G>::CMAX; ++c) {
+        if(c < b.lane_blocks) { // uniform
+            const int e = (c * T + t) * 4;
+            be.coef[c] = ld4(b.lane_coef + e);
+            const f4 raw = ld4(reinterpret_cast<const float *>(b.lane_bin + e));
+            be.bin[c][0] = (int)f32_bits(raw.x); be.bin[c][1] = (int)f32_bits(raw.y);
+            be.bin[c][2] = (int)f32_bits(raw.z); be.bin[c][3] = (int)f32_bits(raw.w);
+        }
+    }
+}
+
+// Called by every thread of the workgroup (sync may be a block barrier); `has_row` says whether this spectrum produced one.
+template<class G, class Sync, class XorSum>
+WF_DEV void bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntries<G> &be, bool has_row, float *db, float *prod, int t,
+                            float *out_row, float *dup_row, Sync sync, XorSum xor_sum)
+{
+    constexpr int T = G::T;
+    // band mean -> pixel row of bar `bar` (reference src/source.cpp:1548-1564), incl. the mirrored image
+    auto emit = [&](int bar, float sum, int cnt) {
+        const float v = sum / (float)cnt;
+        float tt = b.ceiling - v;                     // reference src/source.cpp:1550
+        tt = (tt < 0.0f) ? 0.0f : (b.dbrange < tt) ? b.dbrange : tt;
+        const float y = lerp_std(b.border_top, b.border_bottom, tt / b.dbrange);
+        const int half = b.num_bars / 2;
+        const int img = 2 * half - bar;                // reference :1559-1564: bars above the middle mirror the lower ones
+        const bool own = !b.mirror || bar <= half;
+        const bool image = b.mirror && bar < half && img > half && img < b.num_bars;
+        if(own) {
+            out_row[bar] = y;
+            if(dup_row) dup_row[bar] = y;
+        }
+        if(image) {
+            out_row[img] = y;
+            if(dup_row) dup_row[img] = y;
+        }
+    };
+    if(b.num_segs > 0) {
+        // A: every thread forms the dot product of its own segment (padded pairs have coefficient 0 and bin 0) -- four
+        // independent partial sums in entry order -- and parks it behind the dB row
+        if(has_row) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            WF_UNROLL
+            for(int cc = 0; cc < BarEntries<G>::CMAX; ++cc) {
+                if(cc < b.lane_blocks) { // uniform
+                    const f4 w = be.coef[cc];
+                    a0 = fmaf(db[be.bin[cc][0]], w.x, a0);
+                    a1 = fmaf(db[be.bin[cc][1]], w.y, a1);
+                    a2 = fmaf(db[be.bin[cc][2]], w.z, a2);
+                    a3 = fmaf(db[be.bin[cc][3]], w.w, a3);
+                }
+            }
+            prod[t] = (a0 + a1) + (a2 + a3);
+        }
+        sync();
+        WF_BAR_STAMP(14);
+        WF_BAR_STAMP(15);
+        // B: one thread per bar adds the bar's partials in segment order
+        if(has_row) {
+            for(int bar = t; bar < b.num_bars; bar += T) {
+                const bool first = bar == t;
+                const int s0 = first ? pre.s0 : b.bar_seg[bar], s1 = first ? pre.s1 : b.bar_seg[bar + 1];
+                const int cnt = first ? pre.count : b.count[bar];
+                float a0 = 0.0f, a1 = 0.0f;
+                int k = s0;
+                for(; k + 1 < s1; k += 2) {
+                    a0 += prod[k];
+                    a1 += prod[k + 1];
+                }
+                if(k < s1)
+                    a0 += prod[k];
+                emit(bar, a0 + a1, cnt);
+            }
+        }
+        return;
+    }
+    // ---- tables larger than the scratch (very many bars): chunk by chunk, lanes_per_bar threads per bar ---------------
     const int lpb = b.lanes_per_bar;
     const int bars_per_pass = T / lpb;
     for(int c = 0; c < b.num_chunks; ++c) {
         const bool single = (b.num_chunks == 1);
         const int bar_lo = single ? 0 : b.chunk[c], bar_hi = single ? b.num_bars : b.chunk[c + 1];
         const int e_lo = single ? 0 : b.off[bar_lo], e_hi = single ? b.entries : b.off[bar_hi];
-        // A: one product per entry, every load independent of the others
         if(has_row) {
             for(int e = e_lo + t; e < e_hi; e += T)
                 prod[e - e_lo] = db[b.bin[e]] * b.coef[e];
         }
         sync();
-        // B: segmented sums, lanes_per_bar threads per bar
         for(int b0 = bar_lo; b0 < bar_hi; b0 += bars_per_pass) {
             const int bar = b0 + t / lpb;
             const int sub = t % lpb;
@@ -887,8 +994,6 @@ WF_DEV void bars_reduce_row(const BarArgs &b, const BarPre &pre, bool has_row, c
                 const int n = first_pass ? pre.len : b.off[bar + 1] - boff;
                 cnt = first_pass ? pre.count : b.count[bar];
                 const int o = boff - e_lo;
-                // four independent partial sums: the LDS reads of one step are in flight together (a single running sum
-                // would pay the LDS latency once per element of the longest bar)
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
                 int k = sub;
                 for(; k + 3 * lpb < n; k += 4 * lpb) {
@@ -903,24 +1008,8 @@ WF_DEV void bars_reduce_row(const BarArgs &b, const BarPre &pre, bool has_row, c
             }
             for(int m = lpb >> 1; m >= 1; m >>= 1)
                 acc = xor_sum(acc, m);
-            if(live && sub == 0) {
-                const float v = acc / (float)cnt;
-                float tt = b.ceiling - v;                     // reference src/source.cpp:1550
-                tt = (tt < 0.0f) ? 0.0f : (b.dbrange < tt) ? b.dbrange : tt;
-                const float y = lerp_std(b.border_top, b.border_bottom, tt / b.dbrange);
-                const int half = b.num_bars / 2;
-                const int img = 2 * half - bar;                // reference :1559-1564: bars above the middle mirror the lower ones
-                const bool own = !b.mirror || bar <= half;
-                const bool image = b.mirror && bar < half && img > half && img < b.num_bars;
-                if(own) {
-                    out_row[bar] = y;
-                    if(dup_row) dup_row[bar] = y;
-                }
-                if(image) {
-                    out_row[img] = y;
-                    if(dup_row) dup_row[img] = y;
-                }
-            }
+            if(live && sub == 0)
+                emit(bar, acc, cnt);
         }
         if(c + 1 < b.num_chunks)
             sync(); // prod is reused by the next chunk
