@@ -210,6 +210,7 @@ int wfemu_tick(const wf_config *cfg, uint32_t n_streams, uint32_t ring_cap, cons
 
 // host tables of the product (waveform_amd/csrc/wf_host_tables.cpp) without a device.
 // which: 0 window, 1 slope, 2 rolloff, 3 interp_indices, 4 interp_weights, 5 band_widths (as float),
+//        7 bar_coef, 8 bar_bin, 9 bar_off (device form of the bar reduction, flat),
 //        6 scalars {window_sum, gravity(seconds), db_min, num_bars, radius, taps, border_top, border_bottom, out_ch}
 // returns the element count (copies at most cap elements), or a negative error
 long wfemu_host_table(const wf_config *cfg, int which, float seconds, float *out, long cap)
@@ -226,10 +227,38 @@ long wfemu_host_table(const wf_config *cfg, int which, float seconds, float *out
     case 3: v = tab.interp_indices; break;
     case 4: v = tab.interp_weights; break;
     case 5: v.assign(tab.band_widths.begin(), tab.band_widths.end()); break;
+    case 7: v = tab.bar_coef; break;
+    case 8: v.assign(tab.bar_bin.begin(), tab.bar_bin.end()); break;
+    case 9: v.assign(tab.bar_off.begin(), tab.bar_off.end()); break;
     case 6:
         v = {tab.window_sum, wf::gravity_for(*cfg, seconds), wf::db_min(), (float)tab.num_bars, (float)tab.interp_radius,
              (float)tab.interp_taps, tab.border_top, tab.border_bottom, (float)tab.output_channels};
         break;
+    default: return -1;
+    }
+    for(long i = 0; i < (long)v.size() && i < cap; ++i)
+        out[i] = v[(size_t)i];
+    return (long)v.size();
+}
+
+// the per-thread segment form of the bar tables (wf::bar_segments) for `threads` threads per spectrum.
+// which: 0 lane coef [blocks][threads][4], 1 lane bin (as float), 2 bar_seg (as float), 3 scalars {num_segs, blocks}
+// returns the element count, -1000 if the segment form does not exist for this configuration, other negatives on error
+long wfemu_bar_lanes(const wf_config *cfg, int threads, int max_blocks, int which, float *out, long cap)
+{
+    wf::HostTables tab;
+    const int rc = wf::build_host_tables(*cfg, tab);
+    if(rc != 0)
+        return rc;
+    wf::BarLaneTables lanes;
+    if(!wf::bar_segments(tab, threads, max_blocks, lanes))
+        return -1000;
+    std::vector<float> v;
+    switch(which) {
+    case 0: v = lanes.coef; break;
+    case 1: v.assign(lanes.bin.begin(), lanes.bin.end()); break;
+    case 2: v.assign(lanes.bar_seg.begin(), lanes.bar_seg.end()); break;
+    case 3: v = {(float)lanes.num_segs, (float)lanes.blocks}; break;
     default: return -1;
     }
     for(long i = 0; i < (long)v.size() && i < cap; ++i)

@@ -132,6 +132,47 @@ def test_lds_budget_and_conflicts():
     assert rd_actual <= 1.6 * rd_ideal, (rd_ideal, rd_actual)
 
 
+def test_bar_segment_tables_are_a_permutation_of_the_flat_tables():
+    """wf::bar_segments (what the kernel's bars phase reads) must hold exactly the flat table's (coefficient, bin) pairs,
+    bar by bar: evaluate both forms on a random dB row in float64"""
+    rng = np.random.default_rng(7)
+    threads = {1024: 64, 2048: 64, 4096: 128, 8192: 256, 16384: 512}
+    points = {1024: 8, 2048: 16, 4096: 16, 8192: 16, 16384: 16}
+    for n in (1024, 2048, 4096, 8192, 16384):
+        for mode, extra in ((1, {}), (2, dict(log_scale=0)), (0, dict(mirror_freq_axis=1, bar_width=10, bar_gap=2))):
+            cfg = scenarios.make_config(dict(fft_size=n, stereo=1, bars=1, interp_mode=mode, **extra))
+            coef = emu.host_table(cfg, 7).astype(np.float64)
+            bins = emu.host_table(cfg, 8).astype(np.int64)
+            off = emu.host_table(cfg, 9).astype(np.int64)
+            T, mb = threads[n], points[n] // 4 + 1
+            lc = emu.bar_lanes(cfg, T, mb, 0)
+            num_bars = int(emu.host_table(cfg, 6)[3])
+            lens = np.diff(off)
+            seg_len = 4
+            while num_bars <= T and int(np.ceil(lens / seg_len).clip(1).sum()) > T:
+                seg_len += 4
+            if num_bars > T or seg_len // 4 > mb:  # no segment form (too many bars / segments too long for registers):
+                assert lc is None                   # the kernel takes its chunked path
+                continue
+            assert lc is not None, (n, mode)
+            lb = emu.bar_lanes(cfg, T, mb, 1).astype(np.int64)
+            seg = emu.bar_lanes(cfg, T, mb, 2).astype(np.int64)
+            num_segs, blocks = (int(v) for v in emu.bar_lanes(cfg, T, mb, 3))
+            assert num_segs <= T and 1 <= blocks <= mb and len(seg) == len(off)
+            lc = lc.astype(np.float64).reshape(blocks, T, 4)
+            lb = lb.reshape(blocks, T, 4)
+            assert np.all(lc[:, num_segs:, :] == 0) and np.all((lb >= 0) & (lb < n // 2))
+            db = rng.uniform(-120.0, 0.0, n // 2)
+            per_thread = (lc * db[lb]).sum(axis=(0, 2))          # one partial per thread / segment
+            for b in range(len(off) - 1):
+                flat = float((coef[off[b]:off[b + 1]] * db[bins[off[b]:off[b + 1]]]).sum())
+                lanes = float(per_thread[seg[b]:seg[b + 1]].sum())
+                assert abs(flat - lanes) <= 1e-9 * max(1.0, abs(flat)), (n, mode, b, flat, lanes)
+    # more bars than threads per spectrum: no segment form, the kernel takes its chunked path
+    many = scenarios.make_config(dict(fft_size=1024, stereo=1, bars=1, interp_mode=1, width=1920, bar_width=1, bar_gap=0, log_scale=0))
+    assert emu.bar_lanes(many, 64, 3, 0) is None
+
+
 # ---- C ABI -----------------------------------------------------------------------------------------------
 def _declared_functions(header: Path):
     text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)

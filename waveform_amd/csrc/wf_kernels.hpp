@@ -69,11 +69,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
     return (size_t)SPW * G::LDS_CF * sizeof(cf) + (size_t)G::R2 * G::R3 * sizeof(cf) + (size_t)SPW * (G::T / 64) * sizeof(int) + 16;
 }
 
-// register budget: waves per SIMD the kernel is compiled for (launch_bounds' second argument)
-#ifndef WF_WPS_P16
-#define WF_WPS_P16 4
-#endif
-#define WF_WAVES_PER_SIMD(G) ((G::P <= 8) ? 4 : (G::P <= 16) ? ((G::T <= 64) ? 3 : WF_WPS_P16) : 3)
+// register budget: waves per SIMD the kernel is compiled for (launch_bounds' second argument) -- 3 only for the
+// one-wavefront 16-point geometry (N = 2048), whose register prefetch of the smoothing state needs ~140 VGPRs
+#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? 3 : 4)
 
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \
@@ -265,9 +263,9 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     if(have_row) {
         p4_db<G>(a, t, mag, d);
         if(!a.skip_decibels) {
-            store_row_stream<G>(rows + (size_t)ch * M, t, d);
+            store_row<G>(rows + (size_t)ch * M, t, d);
             if(dup_row)
-                store_row_stream<G>(rows + (size_t)M, t, d);
+                store_row<G>(rows + (size_t)M, t, d);
         }
     }
     WF_STAMP(10);

@@ -116,61 +116,9 @@ struct TickArgs {
 WF_DEV f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 WF_DEV f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
 WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
-// Streaming variants for data that is touched once per tick (audio window, smoothing state, dB rows):
-// non-temporal, so the ~60 KB of per-configuration tables (window, twiddles, slope) stay in L2 instead of
-// being evicted by the 335 MB/tick stream.
-// WF_STREAM_AUX >= 0: the audio window and the smoothing state are read through buffer loads with these cache-policy
-// bits (gfx950: 1 = sc0, 2 = nt, 16 = sc1); sc1 reads are served by L2 and bypass the per-CU L1, which then only
-// holds the per-configuration tables.  -1: plain global loads.
-#ifndef WF_STREAM_AUX
-#define WF_STREAM_AUX -1
-#endif
-#if defined(__HIPCC__) && WF_STREAM_AUX >= 0
-struct StreamBuf { __amdgpu_buffer_rsrc_t rsrc; };
-WF_DEV StreamBuf make_stream_buf(const float *base_uniform, uint32_t bytes)
-{
-    return StreamBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base_uniform), 0, (int)bytes, 0x00020000)};
-}
-WF_DEV f4 ld4_buf(const StreamBuf &b, uint32_t elem)
-{
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    const v4 v = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)(elem * 4u), 0, WF_STREAM_AUX));
-    return f4{v.x, v.y, v.z, v.w};
-}
-#else
-struct StreamBuf { const float *base; };
-WF_DEV StreamBuf make_stream_buf(const float *base_uniform, uint32_t) { return StreamBuf{base_uniform}; }
-WF_DEV f4 ld4_buf(const StreamBuf &b, uint32_t elem) { return *reinterpret_cast<const f4 *>(b.base + elem); }
-#endif
-
-#ifndef WF_NT_STREAM
-#define WF_NT_STREAM 0 // measured on MI355X: non-temporal streaming is slower here (consecutive ticks' windows overlap by
-                       // 80 % and the state is re-read every tick; both are served by the 256 MB Infinity Cache)
-#endif
-#if defined(__HIPCC__) && WF_NT_STREAM
-typedef float wf_v4f __attribute__((ext_vector_type(4)));
-typedef float wf_v2f __attribute__((ext_vector_type(2)));
-WF_DEV f4 ld4_stream(const float *p)
-{
-    const wf_v4f v = __builtin_nontemporal_load(reinterpret_cast<const wf_v4f *>(p));
-    return f4{v.x, v.y, v.z, v.w};
-}
-WF_DEV f2 ld2_stream(const float *p)
-{
-    const wf_v2f v = __builtin_nontemporal_load(reinterpret_cast<const wf_v2f *>(p));
-    return f2{v.x, v.y};
-}
-WF_DEV float ld1_stream(const float *p) { return __builtin_nontemporal_load(p); }
-WF_DEV void st4_stream(float *p, f4 v)
-{
-    __builtin_nontemporal_store(wf_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<wf_v4f *>(p));
-}
-#else
-WF_DEV f4 ld4_stream(const float *p) { return ld4(p); }
-WF_DEV f2 ld2_stream(const float *p) { return ld2(p); }
-WF_DEV float ld1_stream(const float *p) { return *p; }
-WF_DEV void st4_stream(float *p, f4 v) { st4(p, v); }
-#endif
+// Stream-sized data (audio window, smoothing state, dB rows) goes through the same plain global loads/stores as the
+// tables.  Measured and dropped: non-temporal loads/stores and sc1/nt buffer loads (slower or no change -- consecutive
+// ticks' windows overlap by 80 % and the state is re-read every tick, both served by the 256 MB Infinity Cache).
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
 // WF_LDS_TRACE is defined only by the g++ wavefront emulator in tests/emu to record
@@ -250,33 +198,29 @@ WF_DEV float mag2(float xr, float xi)
 //   tw1   W_M^(n' k1) for this thread's n' (k1 = 1..R1-1)
 //   wb    W_N^(4t+i), i = 0..3: the real-split twiddles of this thread's first bin group; the other groups
 //         are wb * W_N^(4Tu) = wb * W_32^(u*64/P) (exact multiples of 1/32 turn)
-// Prefetch policy.  Threads that own 32 points (N >= 8192) have no registers to spare: they load the window and
-// twiddles where they are used.  Threads with <= 16 points hold them from the start (EARLY_TABLES) and prefetch the
-// smoothing state (and, optionally, the slope table) while passes 2-3 run.
-#ifndef WF_PREFETCH_SLOPE
-#define WF_PREFETCH_SLOPE 1
-#endif
-// WF_PREFETCH_STATE: 1 = smoothing state prefetched into registers behind passes 2-3 (16 VGPRs at P = 16);
-//                    2 = "touch": one dword per 64-byte line of the state row (and of the slope table) is requested right
-//                        after pass 1 so that P4's real loads are served from L2; costs 2 VGPRs instead of 32, which
-//                        keeps the kernel under 128 VGPRs = 4 workgroups per CU;  0 = load in P4.
-//                    -1 (default) = measured choice per geometry on MI355X (interleaved A/B, same box): registers for the
-//                        one-wavefront geometries (N = 1024: 68 vs 75 us, N = 2048: 72.3 vs 75 us), touch for N = 4096
-//                        (77.1-79.1 vs 79.3-80.4 us; 122 instead of 156 VGPRs -> 4 workgroups per CU).
+// Prefetch policy.  Every thread owns <= 16 points, holds the window / twiddle operands from the start and prefetches the
+// smoothing state while passes 2-3 run, in one of two ways (WF_PREFETCH_STATE):
+//   1 = into registers (16 VGPRs at P = 16), together with the slope table;
+//   2 = "touch": one dword per 64-byte line of the state row (and of the slope table) is requested right after pass 1 so
+//       that P4's real loads are served from L2; costs 2 VGPRs instead of 32, which keeps the multi-wavefront
+//       geometries at 4 waves per SIMD;  0 = load in P4.
+//  -1 (default) = the measured choice per geometry on MI355X (interleaved A/B, same box): registers for the one-wavefront
+//       geometries (N = 1024: 68 vs 75 us, N = 2048: 72.3 vs 75 us), touch for N >= 4096 (77.1-79.1 vs 79.3-80.4 us then;
+//       122 instead of 156 VGPRs).
 #ifndef WF_PREFETCH_STATE
 #define WF_PREFETCH_STATE -1
 #endif
 template<class G> struct Policy {
+    static_assert(G::P <= 16, "the phase functions keep a thread's operands in registers: at most 16 points per thread");
     static constexpr int MODE = (WF_PREFETCH_STATE >= 0) ? WF_PREFETCH_STATE : (G::T <= 64 ? 1 : 2);
-    static constexpr bool EARLY_TABLES = (G::P <= 16);
-    static constexpr bool PREFETCH_STATE = (G::P <= 16) && (MODE == 1);
-    static constexpr bool PREFETCH_SLOPE = (G::P <= 16) && WF_PREFETCH_SLOPE && (MODE == 1);
-    static constexpr bool TOUCH_STATE = (G::P <= 16) && (MODE == 2);
+    static constexpr bool PREFETCH_STATE = (MODE == 1);
+    static constexpr bool PREFETCH_SLOPE = (MODE == 1);
+    static constexpr bool TOUCH_STATE = (MODE == 2);
 };
 template<class G> struct P1Regs {
     float smp[G::R1][2 * G::B1];
-    float win[Policy<G>::EARLY_TABLES ? G::R1 : 1][2 * G::B1];
-    float tw1[Policy<G>::EARLY_TABLES ? G::R1 : 1][2 * G::B1];
+    float win[G::R1][2 * G::B1];
+    float tw1[G::R1][2 * G::B1];
     cf wb[4];
 };
 
@@ -311,37 +255,32 @@ template<class G, bool ALIGNED>
 WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
 {
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
-    const StreamBuf xb = make_stream_buf(x, a.ring_cap * 4u);
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
         const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
         if(ALIGNED) {
             if(B1 == 2) {
-                const f4 q = ld4_buf(xb, (start + s0) & a.ring_mask);
+                const f4 q = ld4(x + ((start + s0) & a.ring_mask));
                 r.smp[j][0] = q.x; r.smp[j][1] = q.y; r.smp[j][2 * B1 - 2] = q.z; r.smp[j][2 * B1 - 1] = q.w;
             } else {
-                const f2 q = ld2_stream(x + ((start + s0) & a.ring_mask));
+                const f2 q = ld2(x + ((start + s0) & a.ring_mask));
                 r.smp[j][0] = q.x; r.smp[j][1] = q.y;
             }
         } else {
             WF_UNROLL
             for(int e = 0; e < 2 * B1; ++e)
-                r.smp[j][e] = ld1_stream(x + ((start + s0 + (uint32_t)e) & a.ring_mask));
+                r.smp[j][e] = *(x + ((start + s0 + (uint32_t)e) & a.ring_mask));
         }
     }
-    if(Policy<G>::EARLY_TABLES) {
-        WF_UNROLL
-        for(int j = 0; j < R1; ++j) {
-            p1_load_window<G>(a, t, j, r.win[Policy<G>::EARLY_TABLES ? j : 0]);
-            if(j >= 1)
-                p1_load_tw1<G>(a, t, j, r.tw1[Policy<G>::EARLY_TABLES ? j : 0]);
-        }
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        p1_load_window<G>(a, t, j, r.win[j]);
+        if(j >= 1)
+            p1_load_tw1<G>(a, t, j, r.tw1[j]);
     }
-    if(Policy<G>::EARLY_TABLES) {
-        const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + 4 * t));
-        const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + 4 * t + 2));
-        r.wb[0] = cf{wa.x, wa.y}; r.wb[1] = cf{wa.z, wa.w}; r.wb[2] = cf{wc.x, wc.y}; r.wb[3] = cf{wc.z, wc.w};
-    }
+    const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + 4 * t));
+    const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + 4 * t + 2));
+    r.wb[0] = cf{wa.x, wa.y}; r.wb[1] = cf{wa.z, wa.w}; r.wb[2] = cf{wc.x, wc.y}; r.wb[3] = cf{wc.z, wc.w};
     // x != 0.0f for any sample: OR the bit patterns, drop the sign bit (-0.0f == 0.0f); NaNs have non-zero bits
     uint32_t acc = 0;
     WF_UNROLL
@@ -357,17 +296,14 @@ template<class G>
 WF_DEV void p1_window_pass1(const TickArgs &a, int t, P1Regs<G> &r, cf *lds)
 {
     constexpr int R1 = G::R1, B1 = G::B1;
-    constexpr bool EARLY = Policy<G>::EARLY_TABLES;
+    (void)a;
     cf u[B1][R1];
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
-        float win_late[2 * B1];
-        if(!EARLY)
-            p1_load_window<G>(a, t, j, win_late);
         // in[i] *= window[i] (reference :97-103); the table is all ones for FFTWindow::NONE (x * 1.0f == x)
         WF_UNROLL
         for(int e = 0; e < 2 * B1; ++e)
-            r.smp[j][e] *= EARLY ? r.win[EARLY ? j : 0][e] : win_late[e];
+            r.smp[j][e] *= r.win[j][e];
         WF_UNROLL
         for(int b = 0; b < B1; ++b)
             u[b][j] = cf{r.smp[j][2 * b], r.smp[j][2 * b + 1]};
@@ -381,14 +317,9 @@ WF_DEV void p1_window_pass1(const TickArgs &a, int t, P1Regs<G> &r, cf *lds)
     for(int k1 = 0; k1 < R1; ++k1) {
         const int np = B1 * t;
         cf o[B1];
-        float tw_late[2 * B1];
-        if(!EARLY && k1 >= 1)
-            p1_load_tw1<G>(a, t, k1, tw_late);
         WF_UNROLL
         for(int b = 0; b < B1; ++b)
-            o[b] = (k1 == 0) ? u[b][0]
-                             : cmul(u[b][brev(k1, LB)], EARLY ? cf{r.tw1[EARLY ? k1 : 0][2 * b], r.tw1[EARLY ? k1 : 0][2 * b + 1]}
-                                                            : cf{tw_late[2 * b], tw_late[2 * b + 1]});
+            o[b] = (k1 == 0) ? u[b][0] : cmul(u[b][brev(k1, LB)], cf{r.tw1[k1][2 * b], r.tw1[k1][2 * b + 1]});
         if(B1 == 2)
             lds_st4(lds, ex1_addr<G>(k1, np), o[0], o[B1 - 1]);
         else
@@ -414,12 +345,11 @@ template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float 
         q.touch[1] = a.slope[16 * line];
         return;
     }
-    const StreamBuf tb = make_stream_buf(ts, (uint32_t)G::M * 4u);
     if(Policy<G>::PREFETCH_STATE && (a.mode & WF_MODE_TSMOOTH)) { // one scalar branch around all of the state loads
         constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
         WF_UNROLL
         for(int u = 0; u < P / 4; ++u) {
-            const f4 o = ld4_buf(tb, (uint32_t)(4 * (t + T * u)));
+            const f4 o = ld4(ts + 4 * (t + T * u));
             q.st[S * (4 * u)] = o.x; q.st[S * (4 * u + 1)] = o.y; q.st[S * (4 * u + 2)] = o.z; q.st[S * (4 * u + 3)] = o.w;
         }
     }
@@ -601,7 +531,7 @@ WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, co
             // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
             mag[4 * u + i] = fmaf(a.g, old, a.g2 * mag[4 * u + i]);
         }
-        st4_stream(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+        st4(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
     }
 }
 
@@ -610,17 +540,16 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
                                  float (&mag)[G::P])
 {
     constexpr int M = G::M, T = G::T, P = G::P;
-    // Threads with register headroom (P <= 16) that did not prefetch state/slope earlier issue ALL of those loads now and
-    // consume them only after the whole real split (two loops), so the split math covers their latency.  Threads with
-    // 32 points load group by group.
-    constexpr bool LOAD_ALL_FIRST = Policy<G>::EARLY_TABLES && !Policy<G>::PREFETCH_STATE;
+    // Threads that did not prefetch state/slope into registers earlier issue ALL of those loads now and consume them only
+    // after the whole real split (two loops), so the split math covers their (L2) latency.
+    constexpr bool LOAD_ALL_FIRST = !Policy<G>::PREFETCH_STATE;
     float st_all[LOAD_ALL_FIRST ? P : 4], sl_all[LOAD_ALL_FIRST ? P : 4];
     if(LOAD_ALL_FIRST) {
         WF_UNROLL
         for(int u = 0; u < P / 4; ++u) {
             const int k0 = 4 * (t + T * u);
             if(TS) {
-                const f4 o = ld4_stream(ts + k0);
+                const f4 o = ld4(ts + k0);
                 st_all[4 * u] = o.x; st_all[4 * u + 1] = o.y; st_all[4 * u + 2] = o.z; st_all[4 * u + 3] = o.w;
             }
             const f4 sv = ld4(a.slope + k0);
@@ -653,7 +582,7 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
                 for(int i = 0; i < 4; ++i)
                     st4v[i] = st_all[(LOAD_ALL_FIRST ? 1 : 0) * (4 * u + i)];
             } else {
-                const f4 o = ld4_stream(ts + k0);
+                const f4 o = ld4(ts + k0);
                 st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
             }
         }
@@ -676,15 +605,9 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
         const f4 za = lds_ld4(lds, aA + u * ex3_step<G>(4 * T));
         const f4 zb = lds_ld4(lds, aA + u * ex3_step<G>(4 * T) + 2);
         const cf A[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
-        cf Wl[4];
-        if(!Policy<G>::EARLY_TABLES) { // threads short of registers read the split twiddles where they are used
-            const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + k0));
-            const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + k0 + 2));
-            Wl[0] = cf{wa.x, wa.y}; Wl[1] = cf{wa.z, wa.w}; Wl[2] = cf{wc.x, wc.y}; Wl[3] = cf{wc.z, wc.w};
-        }
         WF_UNROLL
         for(int i = 0; i < 4; ++i) {
-            const cf W = Policy<G>::EARLY_TABLES ? mul_w32(wb[i], u * (64 / P)) : Wl[i]; // W_N^(k0 + i)
+            const cf W = mul_w32(wb[i], u * (64 / P)); // W_N^(k0 + i) = wb[i] * W_N^(4Tu)
             const cf B = lds_ld2(lds, (u == 0 && i == 0) ? aB00 : aB[i] + (P / 4 - 1 - u) * ex3_step<G>(4 * T));
             // 2X[k] = (A + conj B) - i W (A - conj B)
             const float er = A[i].x + B.x, ei = A[i].y - B.y;
@@ -752,15 +675,6 @@ template<class G> WF_DEV void store_row(float *row, int t, const float (&d)[G::P
     for(int u = 0; u < P / 4; ++u)
         st4(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
 }
-// the same to an m_decibels row in HBM (streaming store)
-template<class G> WF_DEV void store_row_stream(float *row, int t, const float (&d)[G::P])
-{
-    constexpr int T = G::T, P = G::P;
-    WF_UNROLL
-    for(int u = 0; u < P / 4; ++u)
-        st4_stream(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
-}
-
 // ---- silence state machine helpers (reference :63-95, :138-139) ------------------------------------
 // "outsilent": every value of the previously displayed row is <= floor - 10.  Each thread looks at the
 // bins it owns in the P4 layout; the caller and-reduces over the spectrum's threads.
