@@ -52,6 +52,10 @@ HipApi &api()
         WF_SYM(read_last_silent)
         WF_SYM(last_error)
 #undef WF_SYM
+        // struct wf_config and the entry points above must be the ones this file was compiled against
+        auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
+        if(abi == nullptr || abi() != WF_HIP_ABI_VERSION)
+            return;
         a.ok = true;
     });
     return a;

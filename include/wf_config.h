@@ -24,6 +24,8 @@ typedef enum wf_window {
 typedef enum wf_tsmoothing { WF_TSMOOTH_NONE = 0, WF_TSMOOTH_EXPONENTIAL, WF_TSMOOTH_TVEXPONENTIAL } wf_tsmoothing;
 /* enum InterpMode, src/source.hpp:43-48 */
 typedef enum wf_interp { WF_INTERP_POINT = 0, WF_INTERP_LANCZOS, WF_INTERP_CATROM } wf_interp;
+/* enum FilterMode, src/source.hpp */
+typedef enum wf_filter { WF_FILTER_NONE = 0, WF_FILTER_GAUSS } wf_filter;
 
 typedef struct wf_config {
     uint32_t fft_size;          /* m_fft_size: power of two, 1024..16384 (the reference accepts any multiple of 16 >= 128) */
@@ -57,6 +59,12 @@ typedef struct wf_config {
     int32_t channel_spacing;    /* m_channel_spacing */
     int32_t min_bar_height;     /* m_min_bar_height */
     uint32_t rounded_caps;      /* m_rounded_caps (changes border_top / border_bottom) */
+    /* curve display (render_curve, src/source.cpp:1360-1425): `width` interpolated points per displayed channel instead
+     * of bars; produced only when bars == 0 && curve != 0 */
+    uint32_t curve;             /* display_mode is CURVE */
+    /* smoothing filter across the bars / curve points before the dB -> pixel mapping (src/source.cpp:1396-1405, 1535-1545) */
+    int32_t filter_mode;        /* m_filter_mode (wf_filter) */
+    float filter_radius;        /* m_filter_radius: sigma of the Gaussian (src/source.cpp:527, 1279-1280) */
 } wf_config;
 
 /* get_defaults (src/source.cpp:119-174) + what update() derives for 48 kHz stereo OBS audio,

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 1
+#define WF_HIP_ABI_VERSION 2
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,

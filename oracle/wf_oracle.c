@@ -40,6 +40,7 @@ struct wfo_source {
     float *weights; int radius, taps;
     float *bars[2];
     float border_top, border_bottom, cpos;
+    float *gauss; int gauss_radius; float gauss_sum; float *filter_tmp; /* m_kernel (Gaussian), apply_filter's output buffer */
     /* FFT work */
     double *wr, *wi;            /* work arrays, n each */
     double *twr, *twi;          /* exp(-2 pi i k / n), k < n/2 */
@@ -236,14 +237,22 @@ static void build_bars(wfo_source *s) /* update() :1267-1276, init_interp :837-8
 {
     const wf_config *c = &s->cfg;
     s->num_bars = 0;
-    if(!c->bars)
+    const int curve = !c->bars && c->curve; /* render_curve: init_interp(m_width), one point per pixel column */
+    if(!c->bars && !curve)
         return;
-    const int bar_stride = c->bar_width + c->bar_gap;
-    int num_bars = (int)(c->width / (unsigned int)bar_stride);
-    if(((int)c->width - (num_bars * bar_stride)) >= c->bar_width)
-        ++num_bars;
+    int num_bars;
+    unsigned int sz;
+    if(curve) {
+        num_bars = (int)c->width;
+        sz = c->width;
+    } else {
+        const int bar_stride = c->bar_width + c->bar_gap;
+        num_bars = (int)(c->width / (unsigned int)bar_stride);
+        if(((int)c->width - (num_bars * bar_stride)) >= c->bar_width)
+            ++num_bars;
+        sz = (unsigned int)(num_bars + 1);
+    }
     s->num_bars = num_bars;
-    const unsigned int sz = (unsigned int)(num_bars + 1);
     const size_t maxbin = (size_t)s->m - 1;
     const float sr = (float)c->sample_rate;
     const float lowbin = clamp_f((float)c->cutoff_low * (float)s->n / sr, 1.0f, (float)maxbin);
@@ -257,18 +266,23 @@ static void build_bars(wfo_source *s) /* update() :1267-1276, init_interp :837-8
     s->band_widths = (int *)malloc(sizeof(int) * (size_t)num_bars);
     size_t total = 0;
     for(int i = 0; i < num_bars; ++i) {
-        const int w = (int)(idx[i + 1] - idx[i]);
+        const int w = curve ? 1 : (int)(idx[i + 1] - idx[i]);
         s->band_widths[i] = (w > 1) ? w : 1;
         total += (size_t)s->band_widths[i];
     }
     if(c->interp_mode != WF_INTERP_POINT) {
-        s->interp_indices = (float *)malloc(sizeof(float) * total);
-        s->n_indices = total;
-        size_t k = 0;
-        for(int i = 0; i < num_bars; ++i)
-            for(int j = 0; j < s->band_widths[i]; ++j)
-                s->interp_indices[k++] = idx[i] + j;
-        free(idx);
+        if(curve) { /* the curve interpolates at the indices themselves (:874-876) */
+            s->interp_indices = idx;
+            s->n_indices = total = sz;
+        } else {    /* bars: one position per band sample (:878-889) */
+            s->interp_indices = (float *)malloc(sizeof(float) * total);
+            s->n_indices = total;
+            size_t k = 0;
+            for(int i = 0; i < num_bars; ++i)
+                for(int j = 0; j < s->band_widths[i]; ++j)
+                    s->interp_indices[k++] = idx[i] + j;
+            free(idx);
+        }
         if(c->interp_mode == WF_INTERP_LANCZOS) { /* make_lanczos_kernel, src/filter.hpp:106-131 */
             const intmax_t radius = 4;
             s->radius = 4;
@@ -317,9 +331,38 @@ static void build_bars(wfo_source *s) /* update() :1267-1276, init_interp :837-8
     if(c->min_bar_height > 0)
         border_bottom -= c->min_bar_height;
     border_bottom = clamp_f(border_bottom, border_top, cpos);
+    if(curve) { /* render_curve maps onto lerp(0, cpos - channel_offset, .), src/source.cpp:1411 */
+        border_top = 0.0f;
+        border_bottom = cpos - channel_offset;
+    }
     s->border_top = border_top;
     s->border_bottom = border_bottom;
     s->cpos = cpos;
+    /* m_kernel = make_gauss_kernel(m_filter_radius), src/source.cpp:1279-1280, src/filter.hpp:40-65 */
+    s->gauss = NULL;
+    s->gauss_radius = 0;
+    s->gauss_sum = 0.0f;
+    if(c->filter_mode == WF_FILTER_GAUSS) {
+        float sigma = fabsf(c->filter_radius);
+        if(sigma < 0.01f)
+            sigma = 0.01f;
+        const int w = (int)ceilf(3.0f * sigma);
+        const int size = (2 * w) - 1;
+        s->gauss = (float *)malloc(sizeof(float) * (size_t)size);
+        s->gauss_radius = w;
+        const float pi2 = 3.14159265358979323846f * 2.0f;
+        const float sigsqr = sigma * sigma;
+        const float expdenom = 2.0f * sigsqr;
+        const float coeff = (1.0f / (sqrtf(pi2) * sigma));
+        int j = 0;
+        for(int i = -w + 1; i < w; ++i) {
+            const float exponent = -((float)(i * i) / expdenom);
+            const float weight = coeff * expf(exponent);
+            s->gauss[j++] = weight;
+            s->gauss_sum += weight;
+        }
+        s->filter_tmp = (float *)calloc((size_t)num_bars, sizeof(float));
+    }
 }
 
 /* ---- CircularBuffer (src/circular_buffer.hpp), in samples ------------------------------------------ */
@@ -384,7 +427,7 @@ void wfo_destroy(wfo_source *s)
         free(s->ring[i]); free(s->tsmooth[i]); free(s->decibels[i]); free(s->bars[i]);
     }
     free(s->window); free(s->slope); free(s->rolloff); free(s->fft_in); free(s->fft_out);
-    free(s->interp_indices); free(s->band_widths); free(s->weights);
+    free(s->interp_indices); free(s->band_widths); free(s->weights); free(s->gauss); free(s->filter_tmp);
     free(s->wr); free(s->wi); free(s->twr); free(s->twi);
     free(s);
 }
@@ -527,16 +570,50 @@ static float kernel_convolve(const float *samples, size_t sz, const float *weigh
     return sum;
 }
 
-/* render_bars: interpolation :1500-1533 and the dB -> pixel mapping :1548-1557 */
+/* weighted_avg, src/filter.hpp:133-157 */
+static float weighted_avg(const float *samples, intmax_t n, const float *weights, int radius, float ksum, intmax_t index)
+{
+    const intmax_t start = (index - radius) + 1;
+    const intmax_t stop = index + radius;
+    float sum = 0;
+    if((start < 0) || (stop > n)) {
+        const intmax_t loopstart = start > 0 ? start : 0;
+        const intmax_t loopstop = stop < n ? stop : n;
+        float wsum = 0;
+        for(intmax_t i = loopstart; i < loopstop; ++i) {
+            const float weight = weights[i - start];
+            wsum += weight;
+            sum += samples[i] * weight;
+        }
+        return sum / wsum;
+    }
+    for(intmax_t i = start; i < stop; ++i)
+        sum += samples[i] * weights[i - start];
+    return sum / ksum;
+}
+
+/* render_bars / render_curve up to the vertex fill: interpolation (src/source.cpp:1500-1533 bars, :1380-1394 curve), the
+ * optional filter across the outputs (:1396-1405, :1535-1545), the dB -> pixel mapping (:1548-1557, :1407-1417) and the
+ * mirror (:1559-1564, :1419-1424) */
 void wfo_render_bars(wfo_source *s)
 {
     if(s->num_bars <= 0)
         return;
+    const int curve = !s->cfg.bars && s->cfg.curve;
     const int dbrange = s->cfg.ceiling_db - s->cfg.floor_db;
     for(int channel = 0; channel < (s->cfg.stereo ? 2 : 1); ++channel) {
         const float *db = s->decibels[channel];
         float *out = s->bars[channel];
-        if(s->cfg.interp_mode != WF_INTERP_POINT) { /* apply_interp_filter (bars), src/filter.hpp:194-211 */
+        if(curve) {
+            if(s->cfg.interp_mode != WF_INTERP_POINT) { /* apply_interp_filter (curve), src/filter.hpp:182-192 */
+                const intmax_t d = (intmax_t)s->radius * 2;
+                for(intmax_t i = 0, j = 0; i < s->num_bars; ++i, j += d)
+                    out[i] = kernel_convolve(db, s->m, s->weights, s->radius, (intmax_t)s->interp_indices[i], j);
+            } else { /* :1391-1393 */
+                for(int i = 0; i < s->num_bars; ++i)
+                    out[i] = db[(int)s->interp_indices[i]];
+            }
+        } else if(s->cfg.interp_mode != WF_INTERP_POINT) { /* apply_interp_filter (bars), src/filter.hpp:194-211 */
             const intmax_t d = (intmax_t)s->radius * 2;
             intmax_t k = 0, l = 0;
             for(int i = 0; i < s->num_bars; ++i) {
@@ -555,9 +632,14 @@ void wfo_render_bars(wfo_source *s)
                 out[i] = sum / (float)count;
             }
         }
-        for(int i = 0; i < s->num_bars; ++i) /* :1548-1557 */
+        if(s->gauss_radius > 0) { /* apply_filter, src/filter.hpp:171-180 */
+            for(int i = 0; i < s->num_bars; ++i)
+                s->filter_tmp[i] = weighted_avg(out, s->num_bars, s->gauss, s->gauss_radius, s->gauss_sum, i);
+            memcpy(out, s->filter_tmp, sizeof(float) * (size_t)s->num_bars);
+        }
+        for(int i = 0; i < s->num_bars; ++i) /* :1548-1557 / :1407-1417 */
             out[i] = lerp_f(s->border_top, s->border_bottom, clamp_f(s->cfg.ceiling_db - out[i], 0.0f, (float)dbrange) / dbrange);
-        if(s->cfg.mirror_freq_axis) { /* :1559-1564 */
+        if(s->cfg.mirror_freq_axis) { /* :1559-1564 / :1419-1424 */
             const unsigned half = (unsigned)s->num_bars / 2u;
             for(unsigned i = half + 1; i < (unsigned)s->num_bars; ++i)
                 out[i] = out[half - (i - half)];

@@ -27,7 +27,7 @@ def ref_settings(cfg, **extra) -> dict:
         log_scale=bool(cfg.log_scale), mirror_freq_axis=bool(cfg.mirror_freq_axis),
         width=cfg.width, height=cfg.height, bar_width=cfg.bar_width, bar_gap=cfg.bar_gap,
         channel_spacing=cfg.channel_spacing, min_bar_height=cfg.min_bar_height, rounded_caps=bool(cfg.rounded_caps),
-        filter_mode="none",
+        filter_mode="gauss" if cfg.filter_mode == 1 else "none", filter_radius=repr(float(np.float32(cfg.filter_radius))),
     )
     s.update(extra)
     return s

@@ -7,7 +7,8 @@ the plugin (audio packets in, video ticks, show/hide).  The same script can be p
   * HipBackend     libwaveform_hip.so through its C ABI               -> GPU tests
 and every backend records the same observables after each tick:
   db    float32 [display_channels, fft_size/2]   m_decibels
-  bars  float32 [display_channels, num_bars]     m_interp_bufs after render_bars (if cfg.bars)
+  bars  float32 [display_channels, num_bars]     m_interp_bufs after render_bars / render_curve (if cfg.bars or cfg.curve;
+                                                  num_bars = m_width for the curve)
   silent bool                                    m_last_silent
 Audio is the counter-hash noise of include/wf_synth.h (tools/synth.py), so fixtures only store
 outputs.
@@ -61,6 +62,14 @@ SCENARIOS = {
                            steps=_steps(3), record=1),
     "many_bars_4096_catrom": dict(cfg=dict(fft_size=4096, stereo=0, bars=1, interp_mode=2, width=600, bar_width=2, bar_gap=1),
                                   steps=_steps(3), record=1),
+    # curve display (render_curve): one interpolated point per pixel column; Gaussian filter across the points / bars
+    "curve_4096_lanczos_gauss": dict(cfg=dict(fft_size=4096, stereo=1, slope=1.0, curve=1, interp_mode=1, filter_mode=1, filter_radius=1.5),
+                                     steps=_steps(4), record=1),
+    "curve_2048_catrom_mirror": dict(cfg=dict(fft_size=2048, stereo=0, curve=1, interp_mode=2, mirror_freq_axis=1, width=600),
+                                     steps=_steps(3), record=1),
+    "curve_1024_point_linear_gauss": dict(cfg=dict(fft_size=1024, stereo=1, capture_channels=1, curve=1, interp_mode=0, log_scale=0,
+                                                   filter_mode=1, filter_radius=4.0, channel_spacing=8), steps=_steps(3), record=1),
+    "bars_gauss_4096": dict(cfg=dict(fft_size=4096, stereo=1, bars=1, interp_mode=1, filter_mode=1, filter_radius=0.8), steps=_steps(4), record=1),
     # ragged packets: 441-frame hops (window start not 16-byte aligned), then a 1024 packet
     "ragged_hops": dict(cfg=dict(fft_size=2048, stereo=1),
                         steps=[("noise", 441), ("tick",), ("noise", 441), ("tick",), ("noise", 1024), ("tick",), ("noise", 3), ("tick",),
@@ -171,7 +180,7 @@ class RefBackend:
     def observe(self):
         db = np.stack([self.src.decibels(c) for c in range(self.disp)])
         bars = None
-        if self.cfg.bars:
+        if self.cfg.bars or self.cfg.curve:
             self.src.render()
             bars = np.stack([self.src.bars(c) for c in range(self.disp)])
         return dict(db=db, bars=bars, silent=self.src.last_silent)
@@ -195,7 +204,7 @@ class OracleBackend:
 
     def observe(self):
         bars = None
-        if self.cfg.bars:
+        if self.cfg.bars or self.cfg.curve:
             self.src.render_bars()
             bars = self.src.bars()
         return dict(db=self.src.decibels(), bars=bars, silent=self.src.last_silent)
@@ -228,7 +237,7 @@ class HipBackend:
 
     def observe(self):
         db = self.batch.decibels()
-        bars = self.batch.bars() if self.cfg.bars else None
+        bars = self.batch.bars() if (self.cfg.bars or self.cfg.curve) else None
         silent = self.batch.last_silent()
         # every copy of the scenario must produce the same bits
         assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"

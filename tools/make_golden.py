@@ -7,6 +7,7 @@ tests/scenarios.py; inputs are regenerated from the counter hash, so fixtures st
 can travel to the GPU box, where /root/reference does not exist.
 
     python tools/make_golden.py            # (re)write all fixtures
+    python tools/make_golden.py NAME ...   # only the named scenarios
 """
 from __future__ import annotations
 
@@ -27,7 +28,13 @@ def main():
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
     total = 0
+    only = set(sys.argv[1:])
+    unknown = only - set(scenarios.SCENARIOS)
+    if unknown:
+        raise SystemExit(f"unknown scenarios: {sorted(unknown)}")
     for name, sc in scenarios.SCENARIOS.items():
+        if only and name not in only:
+            continue
         cfg = scenarios.make_config(sc["cfg"])
         be = scenarios.RefBackend(cfg, isa="generic")
         recs = scenarios.play(be, sc)

@@ -23,6 +23,10 @@ if __name__ == "__main__":
     extra = {}
     if os.environ.get("WF_BENCH_BARS"):
         extra = dict(bars=1, interp_mode=int(os.environ["WF_BENCH_BARS"]))
+    if os.environ.get("WF_BENCH_CURVE"):  # curve display, interp mode as given; WF_BENCH_GAUSS=<sigma> adds the filter
+        extra = dict(curve=1, interp_mode=int(os.environ["WF_BENCH_CURVE"]))
+    if os.environ.get("WF_BENCH_GAUSS"):
+        extra.update(filter_mode=1, filter_radius=float(os.environ["WF_BENCH_GAUSS"]))
     jobs = [a.split(":") for a in sys.argv[1:]] or [("1024", "16384"), ("2048", "8192"), ("4096", "4096"), ("8192", "2048"), ("16384", "1024")]
     for n, s in jobs:
         run(int(n), int(s), **extra)

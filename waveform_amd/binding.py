@@ -32,6 +32,7 @@ class Config(C.Structure):
         ("bars", C.c_uint32), ("interp_mode", C.c_int32), ("log_scale", C.c_uint32), ("mirror_freq_axis", C.c_uint32),
         ("width", C.c_uint32), ("height", C.c_uint32), ("bar_width", C.c_int32), ("bar_gap", C.c_int32),
         ("channel_spacing", C.c_int32), ("min_bar_height", C.c_int32), ("rounded_caps", C.c_uint32),
+        ("curve", C.c_uint32), ("filter_mode", C.c_int32), ("filter_radius", C.c_float),
     ]
 
     @classmethod

@@ -45,6 +45,10 @@ struct wf_hip {
     int *d_bar_bin = nullptr, *d_bar_off = nullptr, *d_band_widths = nullptr, *d_bar_chunk = nullptr;
     int bar_chunks = 0, bar_lpb = 1, bar_segs = 0;
     int bar_blocks = 0;
+    bool curve = false;              // the outputs are curve points (render_curve), not bars
+    int out_steps = 0;               // outputs finished per thread (curve: ceil(width / T); bars in segment form: 1)
+    float *d_cur_coef = nullptr, *d_gauss = nullptr, *d_gauss_wsum = nullptr;
+    int *d_cur_base = nullptr;
     float *d_lane_coef = nullptr;
     int *d_lane_bin = nullptr, *d_bar_seg = nullptr;
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
@@ -170,6 +174,13 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.bar_seg = h->d_bar_seg;
         a.bar.num_segs = h->bar_segs;
         a.bar.lane_blocks = h->bar_blocks;
+        a.bar.cur_coef = h->d_cur_coef;
+        a.bar.cur_base = h->d_cur_base;
+        a.bar.curve = h->curve ? 1 : 0;
+        a.bar.out_steps = h->out_steps;
+        a.bar.gauss = h->d_gauss;
+        a.bar.gauss_wsum = h->d_gauss_wsum;
+        a.bar.gauss_radius = h->tab.gauss_radius;
         a.bar.entries = (int)h->tab.bar_coef.size();
         a.bar.lanes_per_bar = h->bar_lpb;
         a.bar.out = h->d_bars;
@@ -374,16 +385,45 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         while(lpb < 64 && (uint32_t)(threads / (lpb * 2)) >= h->num_bars)
             lpb *= 2;
         h->bar_lpb = lpb;
-        wf::BarLaneTables lanes;
         int points = 16;
         wf::dispatch_geometry(h->N, [&](auto g) { points = decltype(g)::P; });
-        if(wf::bar_segments(h->tab, threads, points / 4 + 1, lanes)) {
-            h->bar_segs = lanes.num_segs;
-            h->bar_blocks = lanes.blocks;
-            WF_CREATE_TRY(upload(h, &h->d_lane_coef, lanes.coef));
-            WF_CREATE_TRY(upload(h, &h->d_lane_bin, lanes.bin));
-            WF_CREATE_TRY(upload(h, &h->d_bar_seg, lanes.bar_seg));
+        const int kmax = threads <= 64 ? 16 : 8; // wf::OutVals<G>::KMAX
+        h->curve = !cfg->bars && cfg->curve;
+        if(h->curve) {
+            // one curve point per thread and step; the filter stages the row's points in the spectrum's LDS
+            wf::CurveLaneTables cl;
+            if(!wf::curve_lanes(h->tab, *cfg, threads, kmax, cl)) {
+                return bail(fail(h, WF_HIP_ERR_UNSUPPORTED,
+                                 "curve display: width %u needs more than %d points per thread at fft_size %u (limit: width <= %d)",
+                                 cfg->width, kmax, h->N, kmax * threads));
+            }
+            h->out_steps = cl.steps;
+            WF_CREATE_TRY(upload(h, &h->d_cur_coef, cl.coef));
+            WF_CREATE_TRY(upload(h, &h->d_cur_base, cl.base));
             WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
+        } else {
+            wf::BarLaneTables lanes;
+            if(wf::bar_segments(h->tab, threads, points / 4 + 1, lanes)) {
+                h->bar_segs = lanes.num_segs;
+                h->bar_blocks = lanes.blocks;
+                h->out_steps = 1;
+                WF_CREATE_TRY(upload(h, &h->d_lane_coef, lanes.coef));
+                WF_CREATE_TRY(upload(h, &h->d_lane_bin, lanes.bin));
+                WF_CREATE_TRY(upload(h, &h->d_bar_seg, lanes.bar_seg));
+                WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
+            }
+        }
+        if(h->tab.gauss_radius > 0) {
+            // staged in the spectrum's LDS: the row with radius-1 zeros on either side, then the weights
+            const size_t staged = (size_t)h->num_bars + 2 * (size_t)(h->tab.gauss_radius - 1) + h->tab.gauss.size();
+            if(h->out_steps == 0 || staged > lds_floats) {
+                return bail(fail(h, WF_HIP_ERR_UNSUPPORTED,
+                                 "filter_mode gauss: %u outputs per row do not fit this configuration's on-chip staging (%zu floats%s)",
+                                 h->num_bars, lds_floats, h->out_steps == 0 ? "; bars outnumber the threads of a spectrum" : ""));
+            }
+            WF_CREATE_TRY(upload(h, &h->d_gauss, h->tab.gauss));
+            WF_CREATE_TRY(upload(h, &h->d_gauss_wsum, h->tab.gauss_wsum));
+            WF_CREATE_HIP(hipStreamSynchronize(h->stream));
         }
     }
 

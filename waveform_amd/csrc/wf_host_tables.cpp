@@ -165,14 +165,25 @@ void build_bars(const wf_config &cfg, HostTables &t)
     t.band_widths.clear();
     t.interp_weights.clear();
     t.interp_radius = t.interp_taps = 0;
-    if(!cfg.bars)
+    t.bar_coef.clear();
+    t.bar_bin.clear();
+    t.bar_off.clear();
+    const bool curve = !cfg.bars && cfg.curve;
+    if(!cfg.bars && !curve)
         return;
-    const int bar_stride = cfg.bar_width + cfg.bar_gap;
-    int num_bars = (int)(cfg.width / (unsigned int)bar_stride);
-    if(((int)cfg.width - (num_bars * bar_stride)) >= cfg.bar_width)
-        ++num_bars;
+    int num_bars;
+    unsigned int sz;
+    if(curve) { // render_curve: init_interp(m_width), one point per pixel column
+        num_bars = (int)cfg.width;
+        sz = cfg.width;
+    } else {
+        const int bar_stride = cfg.bar_width + cfg.bar_gap;
+        num_bars = (int)(cfg.width / (unsigned int)bar_stride);
+        if(((int)cfg.width - (num_bars * bar_stride)) >= cfg.bar_width)
+            ++num_bars;
+        sz = (unsigned int)(num_bars + 1);
+    }
     t.num_bars = num_bars;
-    const unsigned int sz = (unsigned int)(num_bars + 1);
 
     const size_t fft_size = cfg.fft_size;
     const size_t maxbin = (fft_size / 2) - 1;
@@ -190,16 +201,20 @@ void build_bars(const wf_config &cfg, HostTables &t)
     }
     t.band_widths.resize((size_t)num_bars);
     for(int i = 0; i < num_bars; ++i)
-        t.band_widths[(size_t)i] = std::max((int)(idx[(size_t)i + 1] - idx[(size_t)i]), 1);
+        t.band_widths[(size_t)i] = curve ? 1 : std::max((int)(idx[(size_t)i + 1] - idx[(size_t)i]), 1);
 
     if(cfg.interp_mode != WF_INTERP_POINT) {
-        std::vector<float> samples;
-        for(int i = 0; i < num_bars; ++i) {
-            const int count = t.band_widths[(size_t)i];
-            for(int j = 0; j < count; ++j)
-                samples.push_back(idx[(size_t)i] + j);
+        if(!curve) { // bars: the indices so far are band starts; expand to one position per band sample (:878-889)
+            std::vector<float> samples;
+            for(int i = 0; i < num_bars; ++i) {
+                const int count = t.band_widths[(size_t)i];
+                for(int j = 0; j < count; ++j)
+                    samples.push_back(idx[(size_t)i] + j);
+            }
+            t.interp_indices = std::move(samples);
+        } else {
+            t.interp_indices = std::move(idx);
         }
-        t.interp_indices = std::move(samples);
         if(cfg.interp_mode == WF_INTERP_LANCZOS)
             build_lanczos(t.interp_indices, t);
         else
@@ -208,7 +223,7 @@ void build_bars(const wf_config &cfg, HostTables &t)
         t.interp_indices = std::move(idx);
     }
 
-    // render_bars geometry
+    // render_bars geometry (:1476-1494); render_curve maps onto [0, cpos - channel_offset] (:1411)
     const float center = (float)cfg.height / 2;
     const float bottom = (float)cfg.height;
     const float cpos = cfg.stereo ? center : bottom;
@@ -221,14 +236,51 @@ void build_bars(const wf_config &cfg, HostTables &t)
     if(cfg.min_bar_height > 0)
         border_bottom -= cfg.min_bar_height;
     border_bottom = std::clamp(border_bottom, border_top, cpos);
+    if(curve) {
+        border_top = 0.0f;
+        border_bottom = cpos - channel_offset;
+    }
     t.border_top = border_top;
     t.border_bottom = border_bottom;
     t.cpos = cpos;
 
+    // Gaussian filter across the outputs: make_gauss_kernel(m_filter_radius), src/filter.hpp:40-65 (float throughout)
+    t.gauss.clear();
+    t.gauss_wsum.clear();
+    t.gauss_radius = 0;
+    t.gauss_sum = 0.0f;
+    if(cfg.filter_mode == WF_FILTER_GAUSS) {
+        const float sigma = std::max(std::abs(cfg.filter_radius), 0.01f);
+        const int w = (int)std::ceil(3.0f * sigma);
+        const int size = (2 * w) - 1;
+        t.gauss.resize((size_t)size);
+        t.gauss_radius = w;
+        constexpr float pi2 = std::numbers::pi_v<float> * 2.0f;
+        const float sigsqr = sigma * sigma;
+        const float expdenom = 2.0f * sigsqr;
+        const float coeff = (1.0f / (std::sqrt(pi2) * sigma));
+        int j = 0;
+        for(int i = -w + 1; i < w; ++i) {
+            const float exponent = -((float)(i * i) / expdenom);
+            const float weight = coeff * std::exp(exponent);
+            t.gauss[(size_t)j++] = weight;
+            t.gauss_sum += weight;
+        }
+        // weighted_avg (src/filter.hpp:133-157): at the edges the divisor is the running sum of the weights that are used
+        t.gauss_wsum.assign((size_t)num_bars, t.gauss_sum);
+        for(intmax_t o = 0; o < num_bars; ++o) {
+            const intmax_t start = (o - w) + 1, stop = o + w;
+            if((start < 0) || (stop > num_bars)) {
+                float wsum = 0.0f;
+                for(intmax_t i = std::max<intmax_t>(start, 0); i < std::min<intmax_t>(stop, num_bars); ++i)
+                    wsum += t.gauss[(size_t)(i - start)];
+                t.gauss_wsum[(size_t)o] = wsum;
+            }
+        }
+    }
+
     // ---- composite per-bar kernels for the device (see BarArgs in wf_tick_phases.hpp) ---------------------------------
     const intmax_t M = (intmax_t)(cfg.fft_size / 2);
-    t.bar_coef.clear();
-    t.bar_bin.clear();
     t.bar_off.assign((size_t)num_bars + 1, 0);
     size_t k = 0; // running sample index (interpolating modes)
     for(int i = 0; i < num_bars; ++i) {
@@ -330,6 +382,34 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
     return true;
 }
 
+bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max_steps, CurveLaneTables &out)
+{
+    out = CurveLaneTables{};
+    const int n = t.num_bars;
+    const int M = (int)(cfg.fft_size / 2);
+    if(n <= 0 || M < 8)
+        return false;
+    const int steps = (n + threads - 1) / threads;
+    if(steps > max_steps)
+        return false;
+    out.steps = steps;
+    const int padded = (steps + 3) / 4 * 4; // the kernel takes the steps four at a time
+    out.coef.assign((size_t)padded * threads * 8, 0.0f);
+    out.base.assign((size_t)padded * threads, 0);
+    for(int o = 0; o < n; ++o) {
+        const int e0 = t.bar_off[(size_t)o], len = t.bar_off[(size_t)o + 1] - e0;
+        if(len > 8)
+            return false; // not a one-sample output (never for curve tables: <= 2 * radius taps)
+        int base = len > 0 ? t.bar_bin[(size_t)e0] : 0;
+        if(base > M - 8)
+            base = M - 8; // keep all eight reads inside the row; the coefficients move with it
+        out.base[(size_t)o] = base;
+        for(int j = 0; j < len; ++j)
+            out.coef[(size_t)o * 8 + (size_t)(t.bar_bin[(size_t)e0 + j] - base)] = t.bar_coef[(size_t)e0 + j];
+    }
+    return true;
+}
+
 float db_min()
 {
     // const float WAVSource::DB_MIN = 20.0f * std::log10(std::numeric_limits<float>::min()); (src/source.cpp:43)
@@ -424,4 +504,7 @@ extern "C" void wf_config_defaults(wf_config *cfg)
     cfg->channel_spacing = 0;
     cfg->min_bar_height = 0;
     cfg->rounded_caps = 0;
+    cfg->curve = 0;                // no render-time outputs unless asked for
+    cfg->filter_mode = WF_FILTER_NONE;
+    cfg->filter_radius = 1.5f;
 }

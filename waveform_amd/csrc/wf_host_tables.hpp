@@ -21,8 +21,8 @@ struct HostTables {
     std::vector<float> rolloff;  // [M], empty unless rolloff_q > 0 && rolloff_rate > 0
     uint32_t output_channels = 1; // m_output_channels
     uint32_t display_channels = 1; // m_stereo ? 2 : 1
-    // bars
-    int num_bars = 0;                    // m_num_bars
+    // bars, or the points of the curve (cfg.curve): "outputs" of the render-time reduction
+    int num_bars = 0;                    // m_num_bars, or m_width in curve mode
     std::vector<float> interp_indices;   // m_interp_indices after init_interp()
     std::vector<int> band_widths;        // m_band_widths
     std::vector<float> interp_weights;   // m_interp_kernel.weights (Lanczos: 8/sample, Catmull-Rom: 4/sample)
@@ -33,6 +33,12 @@ struct HostTables {
     std::vector<float> bar_coef;   // [entries]
     std::vector<int> bar_bin;      // [entries] the bin each coefficient multiplies
     std::vector<int> bar_off;      // [num_bars + 1]
+    // Gaussian filter across the outputs (make_gauss_kernel, src/filter.hpp:40-65); empty when filter_mode is NONE
+    std::vector<float> gauss;      // [2 * gauss_radius - 1]
+    std::vector<float> gauss_wsum; // [num_bars] weighted_avg's divisor per output: the weights of the taps inside the row,
+                                   // accumulated in tap order (== gauss_sum away from the edges)
+    int gauss_radius = 0;
+    float gauss_sum = 0.0f;
 };
 
 // returns 0 on success, a negative wf_hip error code otherwise
@@ -51,6 +57,16 @@ struct BarLaneTables {
     int num_segs = 0, blocks = 0;
 };
 bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out);
+
+// Curve mode (one output per thread and step): output o = k * threads + s reads the 8 consecutive dB bins starting at
+// base[o] with coefficients coef[o][0..8) (its composite kernel shifted/zero-padded to 8 taps inside [0, M)); tables are
+// padded to whole steps with zero coefficients.
+struct CurveLaneTables {
+    std::vector<float> coef; // [steps rounded up to 4][threads][8]
+    std::vector<int> base;   // [steps rounded up to 4][threads]
+    int steps = 0;
+};
+bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max_steps, CurveLaneTables &out);
 
 // get_gravity(seconds), src/source.hpp:301-312
 float gravity_for(const wf_config &cfg, float seconds);

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             store_row<G>(dbl, t, d);
         spectrum_sync<G>();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+        float *out1 = dup_row ? out0 + a.bar.num_bars : nullptr;
 #ifdef WF_PHASE_TIMING
         BarArgs bar_args = a.bar;
         bar_args.clk = (a.phase_clock && threadIdx.x == 0) ? a.phase_clock + (size_t)blockIdx.x * 16 : nullptr;
@@ -287,9 +288,16 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 #else
         const BarArgs &bar_args = a.bar;
 #endif
-        bars_reduce_row<G>(
-            bar_args, bar_pre, bar_entries, have_row, dbl, dbl + M, t, out0, dup_row ? out0 + a.bar.num_bars : nullptr,
-            [] { spectrum_sync<G>(); }, [](float v, int m) { return v + __shfl_xor(v, m, 64); });
+        OutVals<G> ov;
+        bool pending = true;
+        if(a.bar.curve)
+            curve_row<G>(bar_args, have_row, dbl, t, ov);
+        else
+            pending = bars_reduce_row<G>(
+                bar_args, bar_pre, bar_entries, have_row, dbl, dbl + M, t, out0, out1, ov, [] { spectrum_sync<G>(); },
+                [](float v, int m) { return v + __shfl_xor(v, m, 64); });
+        if(pending)
+            outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
     }
     WF_STAMP(13);
 }

@@ -59,6 +59,18 @@ struct BarArgs {
     const int *bar_seg;        // [num_bars + 1]
     int num_segs;
     int lane_blocks;
+    // Curve display (render_curve, reference src/source.cpp:1360-1425): num_bars = m_width points per row, point
+    // o = k*T + s is the dot product of 8 consecutive dB bins starting at cur_base[o] with cur_coef[o][0..8) (the
+    // Lanczos / Catmull-Rom taps of that point, clipped to [0, M) as kernel_convolve does; POINT mode: one tap).
+    const float *cur_coef;     // [out_steps][T][8]
+    const int *cur_base;       // [out_steps][T]
+    int curve;                 // 1: curve tables above; 0: bar tables
+    int out_steps;             // ceil(num_bars / T) when the outputs are finished one per thread and step, else 0
+    // Gaussian filter across the outputs before the dB -> pixel mapping (apply_filter / weighted_avg,
+    // reference src/filter.hpp:133-157,171-180; kernel make_gauss_kernel :40-65); gauss_radius == 0: off
+    const float *gauss;        // [2 * gauss_radius - 1]
+    const float *gauss_wsum;   // [num_bars] the sum of the weights whose taps fall inside the row (weighted_avg's divisor)
+    int gauss_radius;
 #ifdef WF_PHASE_TIMING
     unsigned long long *clk;   // development aid: this workgroup's stamp slots
 #endif
@@ -601,7 +613,6 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
     const int aB00 = ex3_addr<G>((M - 4 * t) & (M - 1));
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
-        const int k0 = 4 * (t + T * u);
         const f4 za = lds_ld4(lds, aA + u * ex3_step<G>(4 * T));
         const f4 zb = lds_ld4(lds, aA + u * ex3_step<G>(4 * T) + 2);
         const cf A[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
@@ -820,31 +831,146 @@ template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEnt
     }
 }
 
+// mean dB of output o -> pixel row (reference src/source.cpp:1548-1557 bars, :1411 curve), incl. the mirrored image
+// (:1559-1564, :1419-1424): outputs above the middle repeat the lower ones
+WF_DEV void emit_output(const BarArgs &b, int o, float v, float *out_row, float *dup_row)
+{
+    float tt = b.ceiling - v; // reference src/source.cpp:1550
+    tt = (tt < 0.0f) ? 0.0f : (b.dbrange < tt) ? b.dbrange : tt;
+    const float y = lerp_std(b.border_top, b.border_bottom, tt / b.dbrange);
+    const int half = b.num_bars / 2;
+    const int img = 2 * half - o;
+    const bool own = !b.mirror || o <= half;
+    const bool image = b.mirror && o < half && img > half && img < b.num_bars;
+    if(own) {
+        out_row[o] = y;
+        if(dup_row) dup_row[o] = y;
+    }
+    if(image) {
+        out_row[img] = y;
+        if(dup_row) dup_row[img] = y;
+    }
+}
+
+// the outputs (bars or curve points) thread t finishes: o = t + T*k, k < out_steps <= KMAX
+template<class G> struct OutVals {
+    static constexpr int KMAX = (G::T <= 64) ? 16 : 8; // 1024 outputs per row on one wavefront, 8 per thread otherwise
+    float v[KMAX];
+};
+
+// curve points of this thread from the dB row parked in LDS.  Steps are taken four at a time: the (L2) table loads of a
+// group are issued together; the tables are padded to whole groups with zero coefficients.
+template<class G> WF_DEV void curve_row(const BarArgs &b, bool has_row, const float *db, int t, OutVals<G> &ov)
+{
+    constexpr int T = G::T, K = OutVals<G>::KMAX;
+    static_assert(K % 4 == 0, "curve steps are processed in groups of four");
+    WF_UNROLL
+    for(int k = 0; k < K; ++k)
+        ov.v[k] = 0.0f;
+    WF_UNROLL
+    for(int g = 0; g < K / 4; ++g) {
+        if(4 * g < b.out_steps && has_row) { // the first condition is uniform
+            f4 c0[4], c1[4];
+            int base[4];
+            WF_UNROLL
+            for(int j = 0; j < 4; ++j) {
+                const int o = (4 * g + j) * T + t;
+                c0[j] = ld4(b.cur_coef + 8 * o);
+                c1[j] = ld4(b.cur_coef + 8 * o + 4);
+                base[j] = b.cur_base[o];
+            }
+            WF_UNROLL
+            for(int j = 0; j < 4; ++j) {
+                const float *p = db + base[j];
+                // kernel_convolve (reference src/filter.hpp:160-169): sum += samples[i] * weight, ascending taps
+                float sum = p[0] * c0[j].x;
+                sum = fmaf(p[1], c0[j].y, sum);
+                sum = fmaf(p[2], c0[j].z, sum);
+                sum = fmaf(p[3], c0[j].w, sum);
+                sum = fmaf(p[4], c1[j].x, sum);
+                sum = fmaf(p[5], c1[j].y, sum);
+                sum = fmaf(p[6], c1[j].z, sum);
+                sum = fmaf(p[7], c1[j].w, sum);
+                ov.v[4 * g + j] = sum;
+            }
+        }
+    }
+}
+
+// optional Gaussian filter across the row's outputs, then mapping + stores.  `lds` is the spectrum's LDS as floats; it may
+// alias everything the row used before (the dB row, the partials) and is written only after a barrier.
+// weighted_avg (reference src/filter.hpp:133-157) divides the tap sum by the sum of the weights whose taps fall inside the
+// row.  Here the row is staged with radius-1 zeros on either side (a dropped tap adds an exact 0), the weights sit next
+// to it, and the divisor of every output comes from a table the host accumulated in the reference's order -- so the
+// inner loop is one LDS read and one FMA per tap, no bounds logic.
+template<class G, class Sync>
+WF_DEV void outputs_finish(const BarArgs &b, bool has_row, OutVals<G> &ov, float *lds, int t, float *out_row, float *dup_row, Sync sync)
+{
+    constexpr int T = G::T, K = OutVals<G>::KMAX;
+    static_assert(K % 4 == 0, "outputs are filtered in groups of four");
+    const int n = b.num_bars;
+    if(b.gauss_radius > 0) {
+        const int pad = b.gauss_radius - 1, size = 2 * b.gauss_radius - 1;
+        float *vp = lds;               // [pad | n | pad]
+        float *wl = lds + n + 2 * pad; // [size]
+        sync();
+        for(int i = t; i < pad; i += T) {
+            vp[i] = 0.0f;
+            vp[pad + n + i] = 0.0f;
+        }
+        for(int i = t; i < size; i += T)
+            wl[i] = b.gauss[i];
+        if(has_row) {
+            WF_UNROLL
+            for(int k = 0; k < K; ++k)
+                if(k < b.out_steps && k * T + t < n)
+                    vp[pad + k * T + t] = ov.v[k];
+        }
+        sync();
+        if(has_row) {
+            WF_UNROLL
+            for(int g = 0; g < K / 4; ++g) {
+                if(4 * g < b.out_steps) { // uniform
+                    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    int o[4];
+                    float div[4];
+                    WF_UNROLL
+                    for(int j = 0; j < 4; ++j) {
+                        o[j] = (4 * g + j) * T + t;
+                        if(o[j] >= n)
+                            o[j] = n - 1; // lanes past the end redo the last output; their result is not stored
+                        div[j] = b.gauss_wsum[o[j]];
+                    }
+                    for(int tap = 0; tap < size; ++tap) {
+                        const float w = wl[tap];
+                        WF_UNROLL
+                        for(int j = 0; j < 4; ++j)
+                            sum[j] = fmaf(vp[o[j] + tap], w, sum[j]);
+                    }
+                    WF_UNROLL
+                    for(int j = 0; j < 4; ++j)
+                        ov.v[4 * g + j] = sum[j] / div[j];
+                }
+            }
+        }
+    }
+    if(has_row) {
+        WF_UNROLL
+        for(int k = 0; k < K; ++k)
+            if(k < b.out_steps && k * T + t < n)
+                emit_output(b, k * T + t, ov.v[k], out_row, dup_row);
+    }
+}
+
 // Called by every thread of the workgroup (sync may be a block barrier); `has_row` says whether this spectrum produced one.
+// Returns true when the bars were left in `ov` for outputs_finish (one bar per thread, k = 0), false when they have already
+// been mapped and stored (chunked path; no filter there).
 template<class G, class Sync, class XorSum>
-WF_DEV void bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntries<G> &be, bool has_row, float *db, float *prod, int t,
-                            float *out_row, float *dup_row, Sync sync, XorSum xor_sum)
+WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntries<G> &be, bool has_row, float *db, float *prod, int t,
+                            float *out_row, float *dup_row, OutVals<G> &ov, Sync sync, XorSum xor_sum)
 {
     constexpr int T = G::T;
-    // band mean -> pixel row of bar `bar` (reference src/source.cpp:1548-1564), incl. the mirrored image
-    auto emit = [&](int bar, float sum, int cnt) {
-        const float v = sum / (float)cnt;
-        float tt = b.ceiling - v;                     // reference src/source.cpp:1550
-        tt = (tt < 0.0f) ? 0.0f : (b.dbrange < tt) ? b.dbrange : tt;
-        const float y = lerp_std(b.border_top, b.border_bottom, tt / b.dbrange);
-        const int half = b.num_bars / 2;
-        const int img = 2 * half - bar;                // reference :1559-1564: bars above the middle mirror the lower ones
-        const bool own = !b.mirror || bar <= half;
-        const bool image = b.mirror && bar < half && img > half && img < b.num_bars;
-        if(own) {
-            out_row[bar] = y;
-            if(dup_row) dup_row[bar] = y;
-        }
-        if(image) {
-            out_row[img] = y;
-            if(dup_row) dup_row[img] = y;
-        }
-    };
+    auto emit = [&](int bar, float sum, int cnt) { emit_output(b, bar, sum / (float)cnt, out_row, dup_row); };
     if(b.num_segs > 0) {
         // A: every thread forms the dot product of its own segment (padded pairs have coefficient 0 and bin 0) -- four
         // independent partial sums in entry order -- and parks it behind the dB row
@@ -866,23 +992,21 @@ WF_DEV void bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
         WF_BAR_STAMP(14);
         WF_BAR_STAMP(15);
         // B: one thread per bar adds the bar's partials in segment order
-        if(has_row) {
-            for(int bar = t; bar < b.num_bars; bar += T) {
-                const bool first = bar == t;
-                const int s0 = first ? pre.s0 : b.bar_seg[bar], s1 = first ? pre.s1 : b.bar_seg[bar + 1];
-                const int cnt = first ? pre.count : b.count[bar];
-                float a0 = 0.0f, a1 = 0.0f;
-                int k = s0;
-                for(; k + 1 < s1; k += 2) {
-                    a0 += prod[k];
-                    a1 += prod[k + 1];
-                }
-                if(k < s1)
-                    a0 += prod[k];
-                emit(bar, a0 + a1, cnt);
+        WF_UNROLL
+        for(int k = 0; k < OutVals<G>::KMAX; ++k)
+            ov.v[k] = 0.0f;
+        if(has_row && t < b.num_bars) {
+            float a0 = 0.0f, a1 = 0.0f;
+            int k = pre.s0;
+            for(; k + 1 < pre.s1; k += 2) {
+                a0 += prod[k];
+                a1 += prod[k + 1];
             }
+            if(k < pre.s1)
+                a0 += prod[k];
+            ov.v[0] = (a0 + a1) / (float)pre.count;
         }
-        return;
+        return true;
     }
     // ---- tables larger than the scratch (very many bars): chunk by chunk, lanes_per_bar threads per bar ---------------
     const int lpb = b.lanes_per_bar;
@@ -928,6 +1052,7 @@ WF_DEV void bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
         if(c + 1 < b.num_chunks)
             sync(); // prod is reused by the next chunk
     }
+    return false;
 }
 
 } // namespace wf
