@@ -82,7 +82,8 @@ uint32_t wf_hip_num_streams(const wf_hip *h);
 uint32_t wf_hip_capture_channels(const wf_hip *h);
 uint32_t wf_hip_output_channels(const wf_hip *h);  /* m_output_channels */
 uint32_t wf_hip_display_channels(const wf_hip *h); /* m_stereo ? 2 : 1 */
-uint32_t wf_hip_num_bars(const wf_hip *h);         /* m_num_bars (0 when cfg.bars == 0) */
+uint32_t wf_hip_num_bars(const wf_hip *h);         /* outputs per displayed row: m_num_bars with cfg.bars, m_width with cfg.curve
+                                                      (render_curve, src/source.cpp:1360-1425), 0 with neither */
 uint32_t wf_hip_ring_frames(const wf_hip *h);
 
 /* ---- audio ingest ------------------------------------------------------------------- */
@@ -108,7 +109,7 @@ typedef struct wf_hip_tick_params {
     float input_rms;        /* m_input_rms, only read when cfg.normalize_volume */
     uint32_t flags;         /* WF_HIP_TICK_* */
 } wf_hip_tick_params;
-#define WF_HIP_TICK_NO_DECIBELS 1u /* bars-only batch mode: skip the m_decibels store (cfg.bars must be set) */
+#define WF_HIP_TICK_NO_DECIBELS 1u /* bars/curve-only batch mode: skip the m_decibels store (cfg.bars or cfg.curve must be set) */
 
 /* Asynchronous: enqueues the fused kernel for all streams on the handle's stream. */
 int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
@@ -120,8 +121,8 @@ int wf_hip_sync(wf_hip *h);
 /* ---- results ----------------------------------------------------------------------------- */
 /* m_decibels of streams [first, first+count): [count][output_channels][fft_size/2] */
 int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out);
-/* bar tops in pixels (m_interp_bufs after the dB->y mapping of render_bars,
- * src/source.cpp:1548-1557): [count][display_channels][num_bars] */
+/* bar tops / curve points in pixels (m_interp_bufs after the optional Gaussian filter, the dB->y mapping and the mirror of
+ * render_bars, src/source.cpp:1535-1564, or render_curve, :1396-1424): [count][display_channels][num_bars] */
 int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
