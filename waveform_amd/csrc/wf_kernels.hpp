@@ -71,7 +71,13 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 
 // register budget: waves per SIMD the kernel is compiled for (launch_bounds' second argument) -- 3 only for the
 // one-wavefront 16-point geometry (N = 2048), whose register prefetch of the smoothing state needs ~140 VGPRs
-#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? 3 : 4)
+#ifndef WF_WPS_SMALL
+#define WF_WPS_SMALL 5 // 8-point geometry (N = 1024): 5 waves per SIMD measured +4 % over 4; 6 spills
+#endif
+#ifndef WF_WPS_2048
+#define WF_WPS_2048 3
+#endif
+#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 8) ? WF_WPS_SMALL : 4)
 
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \
