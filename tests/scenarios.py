@@ -187,10 +187,11 @@ class RefBackend:
 
 
 class OracleBackend:
-    def __init__(self, cfg):
+    def __init__(self, cfg, input_rms=0.0):
         from oracle import restate
         self.cfg = cfg
         self.src = restate.OracleSource(cfg)
+        self.src.set_input_rms(input_rms)
         self.capture_channels = self.src.capture_channels
 
     def push(self, audio, muted):
@@ -214,9 +215,10 @@ class HipBackend:
     """`streams` identical copies of the scenario run in one batch (they must all agree);
     observe() returns stream `probe`."""
 
-    def __init__(self, cfg, streams=3, probe=1):
+    def __init__(self, cfg, streams=3, probe=1, input_rms=0.0):
         import waveform_amd as wf
         self.cfg = cfg
+        self.input_rms = input_rms  # m_input_rms (the host's update_input_rms), for normalize_volume configurations
         self.batch = wf.SpectrumBatch(cfg, streams)
         self.capture_channels = self.batch.capture_channels
         self.streams = streams
@@ -230,7 +232,7 @@ class HipBackend:
             self.batch.push_audio(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
 
     def tick(self, seconds):
-        self.batch.tick(seconds=seconds)
+        self.batch.tick(seconds=seconds, input_rms=self.input_rms)
 
     def set_hidden(self, hidden):
         self.batch.set_hidden(np.full(self.streams, 1 if hidden else 0, np.uint8))

@@ -1,0 +1,89 @@
+"""Randomised parity: libwaveform_hip.so against the CPU restatement (oracle/wf_oracle.c, itself pinned to the
+reference by tests/test_golden.py) over configurations and event sequences nobody wrote by hand.
+
+Every case is a seeded draw of
+  * a configuration: FFT size, channel layout (mono, mono mixdown, stereo, one channel shown twice), window, smoothing
+    mode / gravity / fast peaks, slope, roll-off, volume normalisation, display (none, bars, curve), interpolation,
+    log/linear axis, mirror, geometry, Gaussian filter;
+  * a script: noise packets of ragged sizes, digital silence long enough to reach m_last_silent, a half-silent
+    stretch, muted packets, hide/show, ticks with varying frame times.
+Same tolerances as the golden tests.  The draws are deterministic (seeded), so a failure names its case.
+"""
+import numpy as np
+import pytest
+
+import scenarios
+from helpers import assert_db_close
+
+CASES = list(range(28))
+
+
+def draw(seed: int):
+    r = np.random.default_rng(1000 + seed)
+    n = int(r.choice([1024, 2048, 4096, 8192, 16384], p=[0.3, 0.25, 0.25, 0.1, 0.1]))
+    layout = int(r.integers(0, 4))  # 0 mono capture, 1 mono mixdown of 2, 2 stereo, 3 one captured channel shown twice
+    cfg = dict(fft_size=n,
+               capture_channels=1 if layout in (0, 3) else 2,
+               stereo=1 if layout in (2, 3) else 0,
+               window=int(r.integers(0, 6)), sine_exponent=int(r.integers(1, 5)),
+               tsmoothing=int(r.integers(0, 3)), gravity=float(np.float32(r.uniform(0.05, 0.95))),
+               fast_peaks=int(r.integers(0, 2)),
+               slope=float(np.float32(r.choice([0.0, 0.5, 1.0, 2.5]))),
+               floor_db=int(r.choice([-65, -80, -50])), ceiling_db=int(r.choice([0, -6])))
+    if r.random() < 0.35:
+        cfg.update(rolloff_q=float(np.float32(r.uniform(0.5, 3.0))), rolloff_rate=float(np.float32(r.uniform(3.0, 24.0))))
+    if r.random() < 0.3:
+        cfg.update(normalize_volume=1, volume_target=float(np.float32(r.uniform(-20.0, -3.0))), max_gain=float(np.float32(r.uniform(6.0, 30.0))))
+    display = int(r.integers(0, 3))  # 0 spectrum only, 1 bars, 2 curve
+    if display:
+        cfg.update(interp_mode=int(r.integers(0, 3)), log_scale=int(r.integers(0, 2)), mirror_freq_axis=int(r.random() < 0.3),
+                   height=int(r.choice([225, 300, 101])), channel_spacing=int(r.choice([0, 0, 6])))
+        if display == 1:
+            cfg.update(bars=1, width=int(r.choice([800, 640, 1000])), bar_width=int(r.choice([24, 12, 5])), bar_gap=int(r.choice([6, 2, 0])),
+                       min_bar_height=int(r.choice([0, 3])), rounded_caps=int(r.random() < 0.3))
+        else:
+            cfg.update(curve=1, width=int(r.choice([800, 500, 333, 1024])))
+        if r.random() < 0.5:
+            cfg.update(filter_mode=1, filter_radius=float(np.float32(r.choice([0.4, 1.5, 3.0, 7.5]))))
+    steps = []
+    for _ in range(int(r.integers(3, 6))):
+        steps += [("noise", int(r.choice([800, 441, 1024, 37, 1600]))), ("tick", float(np.float32(r.choice([1 / 60, 1 / 30, 1 / 144]))))]
+    kind = int(r.integers(0, 5))
+    if kind == 0:    # digital silence until the display decays and the source goes silent, then noise again
+        steps += [("silence", n + 400), ("tick",)] + [("silence", 800), ("tick",)] * 12 + [("noise", 800), ("tick",)] * 2
+    elif kind == 1 and cfg["capture_channels"] == 2:
+        steps += [("noise_ch0_only", n + 400), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 8
+    elif kind == 2:
+        steps += [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",), ("noise", 800), ("tick",), ("noise", 800), ("tick",)]
+    elif kind == 3:
+        steps += [("mute", 800), ("tick",), ("noise", 800), ("tick",), ("mute", n), ("tick",)]
+    return cfg, steps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", CASES)
+def test_hip_matches_oracle_on_random_case(seed):
+    cfg_dict, steps = draw(seed)
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all")
+    import waveform_amd as wf
+    rms = 0.0316 if cfg.normalize_volume else 0.0  # what the host's update_input_rms would hand over (-30 dBFS)
+    try:
+        hip = scenarios.HipBackend(cfg, streams=2, probe=1, input_rms=rms)
+    except wf.WfHipError as e:
+        # a documented limit of the device path (e.g. more curve points per row than a spectrum's threads can finish)
+        assert e.code == -2, e  # WF_HIP_ERR_UNSUPPORTED
+        pytest.skip(f"configuration outside the device path's documented limits: {e}")
+    ora = scenarios.OracleBackend(cfg, input_rms=rms)
+    try:
+        got = scenarios.play(hip, sc)
+        want = scenarios.play(ora, sc)
+    finally:
+        hip.close()
+    assert len(got) == len(want)
+    for t, (g, w) in enumerate(zip(got, want)):
+        assert g["silent"] == w["silent"], f"case {seed} tick {t}: m_last_silent {g['silent']} != {w['silent']} ({cfg_dict})"
+        assert_db_close(g["db"], w["db"], f"case {seed} tick {t} decibels ({cfg_dict})")
+        if w["bars"] is not None:
+            err = np.abs(g["bars"].astype(np.float64) - w["bars"])
+            assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"case {seed} tick {t} bars/curve: max err {err.max():.3e} px ({cfg_dict})"
