@@ -106,7 +106,8 @@ typedef struct wf_hip_tick_params {
     uint32_t delay_frames;  /* audio already captured beyond the tick time: the window is the fft_size
                                samples ending delay_frames before the newest one
                                (dtaudio > 0 in src/source_generic.cpp:50-51) */
-    float input_rms;        /* m_input_rms, only read when cfg.normalize_volume */
+    float input_rms;        /* m_input_rms, only read when cfg.normalize_volume; the same value for every stream unless
+                               wf_hip_set_input_rms has given the streams their own */
     uint32_t flags;         /* WF_HIP_TICK_* */
 } wf_hip_tick_params;
 #define WF_HIP_TICK_NO_DECIBELS 1u /* bars/curve-only batch mode: skip the m_decibels store (cfg.bars or cfg.curve must be set) */
@@ -116,6 +117,12 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
 /* show()/hide()/capture-timeout per stream: hidden streams take the reset branch of
  * tick_spectrum (src/source_generic.cpp:34-48).  mask[i] != 0 -> hidden. */
 int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *mask);
+/* m_input_rms per stream (what update_input_rms leaves, src/source_generic.cpp:392-403), for batches whose streams are
+ * normalised independently (cfg.normalize_volume): rms[i] belongs to stream first+i and stays in force until the next
+ * call for that stream.  Once any stream has been given a value, wf_hip_tick_params::input_rms is ignored (streams never
+ * set read 0, i.e. the full max_gain, as a source that has not seen audio yet does).  The volume compensation
+ * min(volume_target - dbfs(rms), max_gain) (src/source_generic.cpp:163) is evaluated here, on the host, in float. */
+int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float *rms);
 int wf_hip_sync(wf_hip *h);
 
 /* ---- results ----------------------------------------------------------------------------- */

@@ -175,7 +175,7 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
         phase(c, [&](int t) { p3_pass3_write<G>(t, lds.data(), regs[(size_t)t].v); });
         phase(c, [&](int t) { p4_split_smooth<G>(a, t, lds.data(), ts, regs[(size_t)t].r1.wb, regs[(size_t)t].r4, regs[(size_t)t].mag); });
         phase(false, [&](int t) {
-            p4_db<G>(a, t, regs[(size_t)t].mag, regs[(size_t)t].d);
+            p4_db<G>(a, t, regs[(size_t)t].mag, regs[(size_t)t].d, a.vol_comp);
             store_row<G>(out, t, regs[(size_t)t].d);
         });
     }

@@ -87,3 +87,29 @@ def test_hip_matches_oracle_on_random_case(seed):
         if w["bars"] is not None:
             err = np.abs(g["bars"].astype(np.float64) - w["bars"])
             assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"case {seed} tick {t} bars/curve: max err {err.max():.3e} px ({cfg_dict})"
+
+
+@pytest.mark.gpu
+def test_per_stream_input_rms():
+    """wf_hip_set_input_rms: every stream of a batch is normalised with its own m_input_rms
+    (volume_compensation, reference src/source_generic.cpp:161-167)"""
+    import waveform_amd as wf
+    from tools import synth
+    cfg_dict = dict(fft_size=2048, stereo=1, normalize_volume=1, volume_target=-8.0, max_gain=30.0, slope=1.0)
+    cfg = scenarios.make_config(cfg_dict)
+    rms = np.array([0.5, 0.0316, 0.0, 1e-4], np.float32)  # 0.0: "no audio seen yet" -> the full max_gain
+    audio = synth.block(scenarios.SEED, 0, 1, 2, 0, 800 * 4)[0]
+    with wf.SpectrumBatch(cfg, len(rms)) as b:
+        b.set_input_rms(rms[:2])
+        b.set_input_rms(rms[2:], first=2)
+        for t in range(4):
+            b.push_audio(np.broadcast_to(audio[None, :, t * 800:(t + 1) * 800], (len(rms), 2, 800)))
+            b.tick(input_rms=0.123)  # ignored once per-stream values exist
+        got = b.decibels()
+    for i, r in enumerate(rms):
+        ora = scenarios.OracleBackend(cfg, input_rms=float(r))
+        for t in range(4):
+            ora.push(audio[:, t * 800:(t + 1) * 800], muted=False)
+            ora.tick(1.0 / 60.0)
+        assert_db_close(got[i], ora.observe()["db"], f"stream {i} (input_rms {r})")
+    assert not np.allclose(got[0], got[1])

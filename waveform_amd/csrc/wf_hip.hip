@@ -45,6 +45,7 @@ struct wf_hip {
     int *d_bar_bin = nullptr, *d_bar_off = nullptr, *d_band_widths = nullptr, *d_bar_chunk = nullptr;
     int bar_chunks = 0, bar_lpb = 1, bar_segs = 0;
     int bar_blocks = 0;
+    float *d_vol_comp = nullptr;     // [n_streams] volume compensation per stream (wf_hip_set_input_rms), or nullptr
     bool curve = false;              // the outputs are curve points (render_curve), not bars
     int out_steps = 0;               // outputs finished per thread (curve: ceil(width / T); bars in segment form: 1)
     float *d_cur_coef = nullptr, *d_gauss = nullptr, *d_gauss_wsum = nullptr;
@@ -215,6 +216,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         // volume_compensation, reference src/source_generic.cpp:163
         const float rms_db = (p->input_rms > 0.0f) ? 20.0f * std::log10(p->input_rms) : wf::db_min();
         a.vol_comp = std::min(h->cfg.volume_target - rms_db, h->cfg.max_gain);
+        a.vol_comp_stream = h->d_vol_comp; // per-stream values once wf_hip_set_input_rms has been used
     }
     a.mode = mode;
     a.phase_clock = h->d_phase_clock;
@@ -609,6 +611,35 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
                        h->d_mask);
     WF_HIP_TRY(h, hipGetLastError());
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `mask` is borrowed for the call only
+    return WF_HIP_OK;
+}
+
+int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float *rms)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(rms == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "rms is NULL");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    // volume_compensation of every stream, reference src/source_generic.cpp:163 with dbfs() of src/source.hpp:293-299
+    auto comp = [&](float r) {
+        const float rms_db = (r > 0.0f) ? 20.0f * std::log10(r) : wf::db_min();
+        return std::min(h->cfg.volume_target - rms_db, h->cfg.max_gain);
+    };
+    if(h->d_vol_comp == nullptr) {
+        rc = dev_alloc(h, &h->d_vol_comp, (size_t)h->n_streams);
+        if(rc)
+            return rc;
+        const std::vector<float> init(h->n_streams, comp(0.0f));
+        WF_HIP_TRY(h, hipMemcpyAsync(h->d_vol_comp, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    std::vector<float> v(count);
+    for(uint32_t i = 0; i < count; ++i)
+        v[i] = comp(rms[i]);
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_vol_comp + first, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // the staging vector dies here
     return WF_HIP_OK;
 }
 

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
     float d[P];
     if(have_row) {
-        p4_db<G>(a, t, mag, d);
+        p4_db<G>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp);
         if(!a.skip_decibels) {
             store_row<G>(rows + (size_t)ch * M, t, d);
             if(dup_row)

@@ -113,6 +113,7 @@ struct TickArgs {
     float half_coef;           // 0.5f * (2.0f / m_window_sum)
     float g, g2;               // get_gravity(seconds), 1 - g
     float vol_comp;            // min(m_volume_target - dbfs(m_input_rms), m_max_gain)
+    const float *vol_comp_stream; // [n_streams] the same per stream (wf_hip_set_input_rms), or nullptr: vol_comp for all
     float db_min;              // DB_MIN
     float silent_floor;        // (float)(m_floor - 10)
     uint32_t n_streams;
@@ -653,7 +654,7 @@ WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, 
 
 // dB conversion + volume normalisation + roll-off of this thread's bins (reference :144-179); d[] is the
 // final m_decibels content, stored by store_row()
-template<class G> WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P])
+template<class G> WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P], float vol_comp)
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
@@ -666,7 +667,7 @@ template<class G> WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)
             WF_UNROLL
             for(int i = 0; i < 4; ++i)
                 if(k0 + i >= 1) // the generic path starts at i = 1 (reference :165)
-                    d[4 * u + i] += a.vol_comp;
+                    d[4 * u + i] += vol_comp;
         }
         if(a.mode & WF_MODE_ROLLOFF) {
             const f4 r = ld4(a.rolloff + k0);
