@@ -8,6 +8,7 @@
 // product: libwaveform_hip.so never links this file and has no CPU path.
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <map>
@@ -136,6 +137,7 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
     struct Regs { cf v[P]; float mag[P]; float d[P]; P1Regs<G> r1; P4Regs<G> r4; };
     std::vector<Regs> regs((size_t)T);
 
+    int phase_no = 0; // development aid: WF_EMU_VERBOSE prints the census per phase
     auto census_waves = [&](bool enable) {
         if(!enable) return;
         for(int w = 0; w < T / 64; ++w) {
@@ -150,7 +152,14 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
             fn(t);
         }
         emu::g_trace = nullptr;
+        const ConflictStats before[2] = {st[0], st[1]};
         census_waves(do_census);
+        if(do_census && getenv("WF_EMU_VERBOSE"))
+            fprintf(stderr, "[emu N=%d] phase %d: reads %llu instr ideal %llu actual %llu | writes %llu instr ideal %llu actual %llu\n", G::N, phase_no,
+                    (unsigned long long)(st[0].instr - before[0].instr), (unsigned long long)(st[0].ideal_cycles - before[0].ideal_cycles),
+                    (unsigned long long)(st[0].actual_cycles - before[0].actual_cycles), (unsigned long long)(st[1].instr - before[1].instr),
+                    (unsigned long long)(st[1].ideal_cycles - before[1].ideal_cycles), (unsigned long long)(st[1].actual_cycles - before[1].actual_cycles));
+        ++phase_no;
     };
 
     const uint32_t n_spec = n_streams * cfg.capture_channels;

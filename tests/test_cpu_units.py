@@ -118,18 +118,19 @@ def test_emulated_kernel_window_delay():
 
 
 def test_lds_budget_and_conflicts():
-    """LDS per spectrum stays within the occupancy plan and writes stay conflict-free"""
+    """LDS per spectrum stays within the occupancy plan and every exchange access is bank-conflict free under the
+    lane-group model of MI355X_MICROARCH.md (reads and writes, all geometries)"""
     budget = {1024: 5 * 1024, 2048: 9 * 1024, 4096: 17408, 8192: 34 * 1024, 16384: 68 * 1024}
     for n, b in budget.items():
         assert 0 < emu.lib().wfemu_lds_bytes(n) <= b
-    cfg = scenarios.make_config(dict(fft_size=4096, stereo=1))
-    ring = np.zeros((2, 8192), np.float32)
-    ring[:, :] = synth.block(1, 0, 1, 2, 0, 8192)[0]
-    ts = np.zeros((2, 2048), np.float32)
-    _, st = emu.tick(cfg, ring, 8192, ts)
-    rd_instr, rd_ideal, rd_actual, wr_instr, wr_ideal, wr_actual = st
-    assert wr_actual == wr_ideal, "LDS writes must be bank-conflict free"
-    assert rd_actual <= 1.6 * rd_ideal, (rd_ideal, rd_actual)
+        cfg = scenarios.make_config(dict(fft_size=n, stereo=1))
+        ring = np.ascontiguousarray(synth.block(1, 0, 1, 2, 0, 2 * n)[0], np.float32)
+        ts = np.zeros((2, n // 2), np.float32)
+        _, st = emu.tick(cfg, ring, 2 * n, ts)
+        rd_instr, rd_ideal, rd_actual, wr_instr, wr_ideal, wr_actual = st
+        assert rd_instr > 0 and wr_instr > 0
+        assert wr_actual == wr_ideal, (n, "LDS writes must be bank-conflict free", wr_ideal, wr_actual)
+        assert rd_actual == rd_ideal, (n, "LDS reads must be bank-conflict free", rd_ideal, rd_actual)
 
 
 def test_bar_segment_tables_are_a_permutation_of_the_flat_tables():

@@ -123,11 +123,15 @@ template<int N_, int T_, int R1_, int R2_, int R3_> struct Geom {
     static constexpr int M1 = M / R1_;      // = R2*R3 = T*B1
     // LDS exchange layouts (complex units).  ex1: [k1][n'] with padded row stride S1;
     // ex2: [q' = k1 + R1*k2][n3] rows of R3 with an XOR swizzle on 16-byte chunks;
-    // ex3: natural order Z[k] with one 16-byte pad every 64 bins.
-    static constexpr int S1 = M1 + 8;
+    // ex3: four planes by k mod 4 -- Z[k] at (k & 3) * S3 + (k >> 2) -- so that the real split, whose threads own four
+    // consecutive bins and need Z[k] and Z[M-k], reads consecutive 8-byte words across a wavefront in both directions.
+    // ex1 row stride: pass 2 reads, per half wavefront, 32/R3 rows of R3 consecutive points (8 bytes each); the rows must
+    // start 2*R3 banks apart, i.e. S1 % 32 == R3 % 32 (any padding does for R3 = 32: one row fills all 64 banks)
+    static constexpr int S1 = M1 + ((R3_ < 32) ? R3_ : 8);
     static constexpr int EX1_SIZE = R1_ * S1;
     static constexpr int EX2_SIZE = M;
-    static constexpr int EX3_SIZE = M + (M / 64) * 2;
+    static constexpr int S3 = M / 4 + 4;    // ex3 plane stride (see ex3_addr)
+    static constexpr int EX3_SIZE = 4 * S3;
     static constexpr int LDS_CF = (EX1_SIZE > EX3_SIZE) ? EX1_SIZE : EX3_SIZE; // per spectrum, in cf
     static_assert(R1_ * R2_ * R3_ == N_ / 2, "radices must multiply to M");
     static_assert(B1 == 1 || B1 == 2, "pass 1 loads 8 or 16 bytes per thread");
@@ -153,16 +157,16 @@ template<class G> WF_DEV int ex2_addr(int q, int n3)
     const int chunk = (n3 >> 1) ^ ex2_swz<G>(q);
     return q * G::R3 + chunk * 2 + (n3 & 1);
 }
-template<class G> WF_DEV int ex3_addr(int k) { return k + (k >> 6) * 2; }
+template<class G> WF_DEV int ex3_addr(int k) { return (k & 3) * G::S3 + (k >> 2); }
 
 // Address algebra the compiler does not find by itself (every helper below is checked against the plain formulas by
 // tests/emu, which replays the kernel's phase functions lane by lane):
-//  * ex3 is affine in steps that are multiples of 64 bins:  ex3_addr(k + 64*m) == ex3_addr(k) + 66*m
+//  * ex3 is affine in steps that are multiples of 4 bins:  ex3_addr(k + 4*m) == ex3_addr(k) + m
 //  * ex2: for q = k1 + R1*k2 the swizzle term of a thread's store is its k2 = 0 address XOR a compile-time constant:
 //        ex2_addr(k1 + R1*k2, n3) == (ex2_addr(k1, n3) ^ ex2_xor<G>(k2)) + k2*R1*R3
 //    (R1 is a multiple of the rows per bank row, so swz(q) = (k1/RPB + (R1/RPB)*k2) mod CH, and k1/RPB < R1/RPB has no
 //    bit in common with (R1/RPB)*k2.)
-template<class G> constexpr int ex3_step(int bins) { return bins + (bins / 64) * 2; } // bins % 64 == 0
+template<class G> constexpr int ex3_step(int bins) { return bins / 4; } // bins % 4 == 0
 template<class G> constexpr int ex2_xor(int k2)
 {
     constexpr int CH = G::R3 / 2;

@@ -451,13 +451,13 @@ template<class G> WF_DEV void p3_read(int t, const cf *lds, cf (&v)[G::P])
 {
     constexpr int R3 = G::R3, B3 = G::B3, T = G::T;
     if constexpr(G::H3 == 2) {
-        // radix 32 with 16 points per thread: threads 2q and 2q+1 share row q.  Both read the whole row; thread h
+        // radix 32 with 16 points per thread: threads q and q + R1*R2 share row q.  Both read the whole row; thread h
         // keeps the first radix-2 stage's half that feeds the outputs k3 = 2k' + h:
         //   h = 0: s[j] = v[j] + v[j+16]        h = 1: d[j] = (v[j] - v[j+16]) * W_32^j
         // written select-free: u[j] = (v[j] + sg * v[j+16]) * (h ? W_32^j : 1).
         constexpr int HALF = R3 / 2;
-        const int q = t >> 1;
-        const float hf = (float)(t & 1);
+        const int q = t & (G::R1 * G::R2 - 1), h = t / (G::R1 * G::R2); // the two threads of row q sit in different wavefronts
+        const float hf = (float)h;
         const float sg = 1.0f - 2.0f * hf;
         WF_UNROLL
         for(int j = 0; j < HALF; j += 2) {
@@ -487,8 +487,8 @@ template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
     constexpr int R1 = G::R1, R2 = G::R2, R3 = G::R3, B3 = G::B3, T = G::T;
     if constexpr(G::H3 == 2) {
         constexpr int HALF = R3 / 2, LBH = ilog2(HALF);
-        static_assert((R1 * R2) % 64 == 0, "ex3 stride algebra");
-        const int q = t >> 1, h = t & 1;
+        static_assert((R1 * R2) % 4 == 0, "ex3 stride algebra");
+        const int q = t & (R1 * R2 - 1), h = t / (R1 * R2);
         cf u[HALF];
         WF_UNROLL
         for(int j = 0; j < HALF; ++j)
@@ -508,7 +508,7 @@ template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
         for(int n3 = 0; n3 < R3; ++n3)
             u[n3] = v[b * R3 + n3];
         dft_dif<R3>(u);
-        static_assert((R1 * R2) % 64 == 0, "ex3 stride algebra");
+        static_assert((R1 * R2) % 4 == 0, "ex3 stride algebra");
         const int q = t + T * b;
         const int a3 = ex3_addr<G>(q); // == ex3_addr<G>(q + R1*R2*k3) - k3 * ex3_step(R1*R2)
         WF_UNROLL
@@ -602,21 +602,22 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
         p4_slope_smooth_group<G, TS, FPK>(a, t, u, ts, st4v, sl4, mag);
     };
     // ---- loop 1: real split -> |2X| * coef/2 -------------------------------------------------------------------------
-    // LDS addresses: bins advance by 4T (a multiple of 64) per group, so every group is the first one's address plus a
-    // compile-time step.  Z[k0 + i] sits at aA (+2 for the second pair); the mirrored bins M - k0 - i at aB[i] - u*step,
+    // LDS addresses: bins advance by 4T per group, i.e. by T words inside every ex3 plane, so every group is the first
+    // one's address plus a compile-time step.  Z[k0 + i] sits at aA[i]; the mirrored bins M - k0 - i at aB[i] - u*step,
     // except bin M - 0 = 0 for the very first bin of thread 0.
-    static_assert((4 * T) % 64 == 0, "ex3 stride algebra");
-    const int aA = ex3_addr<G>(4 * t);
-    int aB[4];
+    int aA[4], aB[4];
     WF_UNROLL
-    for(int i = 0; i < 4; ++i)
+    for(int i = 0; i < 4; ++i) {
+        aA[i] = ex3_addr<G>(4 * t + i);
         aB[i] = ex3_addr<G>(M - 4 * t - i - 4 * T * (P / 4 - 1)); // the LAST group's address: offsets below stay non-negative
+    }
     const int aB00 = ex3_addr<G>((M - 4 * t) & (M - 1));
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
-        const f4 za = lds_ld4(lds, aA + u * ex3_step<G>(4 * T));
-        const f4 zb = lds_ld4(lds, aA + u * ex3_step<G>(4 * T) + 2);
-        const cf A[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
+        cf A[4];
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i)
+            A[i] = lds_ld2(lds, aA[i] + u * ex3_step<G>(4 * T));
         WF_UNROLL
         for(int i = 0; i < 4; ++i) {
             const cf W = mul_w32(wb[i], u * (64 / P)); // W_N^(k0 + i) = wb[i] * W_N^(4Tu)
