@@ -2,16 +2,16 @@
 //
 //   spectrum_tick_kernel<G, SPW, ALIGNED>   the fused per-tick pass: ring fetch -> window -> r2c FFT
 //                                           in LDS -> |X| -> slope -> temporal smoothing -> dBFS
-//                                           (-> volume normalisation -> roll-off), one HBM pass.
-//                                           Replaces WAVSource*::tick_spectrum (reference
+//                                           (-> volume normalisation -> roll-off -> bars / curve), one HBM
+//                                           pass.  Replaces WAVSource*::tick_spectrum (reference
 //                                           src/source_generic.cpp:26-180) for a whole batch of sources.
 //   ring_push_kernel / ring_synth_kernel    CircularBuffer::push_back for every (stream, channel)
 //                                           (reference src/source.cpp:1873-1886).
 //   fill_kernel                             state initialisation (reference src/source.cpp:1170-1182).
 //
 // Work decomposition: a spectrum (one channel of one stream) is owned by T = G::T threads
-// (one wavefront for N <= 4096); a workgroup holds SPW spectra, laid out so that the
-// channels of a stream share a workgroup (needed by the mono mixdown, reference :150-154).
+// (1..8 wavefronts, wf_geometry.hpp); a workgroup holds SPW spectra, laid out so that the
+// channels of a stream share a workgroup (silence state machine, mono mixdown, reference :63-95, :150-154).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "wf_geometry.hpp"
@@ -28,14 +28,6 @@ template<class G> __device__ __forceinline__ void spectrum_sync()
         __syncthreads();
     else
         __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for(int off = 32; off >= 1; off >>= 1)
-        v += __shfl_xor(v, off, 64);
-    return v;
 }
 
 // global -> LDS copy of a BYTES-sized table by the LDS-DMA path (global_load_lds: destination = wave-uniform base +

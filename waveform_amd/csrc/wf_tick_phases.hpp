@@ -7,10 +7,12 @@
 //   P1  fetch the latest N samples of the channel ring (reference :55-59), multiply by
 //       the window (:97-103), radix-R1 butterflies, twiddle            -> write ex1
 //   P2  read ex1, radix-R2 butterflies, twiddle                         -> write ex2
-//   P3  read ex2, radix-R3 butterflies                                  -> write ex3 (Z, natural order)
+//   P3  read ex2, radix-R3 butterflies                                  -> write ex3 (Z, four planes by k mod 4)
 //   P4  read Z[k], Z[M-k]; real split; |X|*2/sum(w) (:110-119); slope (:121-122);
 //       temporal smoothing incl. fast peaks (:124-132); dBFS (:144-159, src/source.hpp:293-299);
 //       volume normalisation (:161-167); roll-off (:169-179)            -> HBM
+//   then, for configurations that display bars or a curve, the render-time reduction of the row just produced
+//   (render_bars / render_curve, src/source.cpp:1360-1425, 1500-1564): bars_reduce_row / curve_row, outputs_finish.
 //
 // Each P*_read / P*_write split below marks where a block barrier is needed when
 // T > 64 (several wavefronts share the spectrum); with T == 64 program order inside
@@ -37,7 +39,7 @@ enum : uint32_t {
     WF_STREAM_HIDDEN = 1u << 1,      // !m_show or capture timed out (host sets it)
 };
 
-// bars (render_bars interpolation + dB -> pixel mapping); out == nullptr: the configuration shows no bars
+// bars or curve (render_bars / render_curve interpolation, filter, dB -> pixel mapping); out == nullptr: neither
 struct BarArgs {
     // Per bar b the reference computes (1/count_b) * sum over the band's samples k of sum_t dB[ix_k - r + 1 + t] * W[k][t]
     // (src/filter.hpp:194-211; POINT mode: plain band mean, src/source.cpp:1525-1532).  The samples of a band sit on
