@@ -77,6 +77,16 @@ def test_unsupported_fft_sizes_are_rejected():
             emu.host_table(cfg, 0)
 
 
+def test_degenerate_display_configurations_are_rejected():
+    """configurations whose setup would divide by zero (the reference would produce NaNs) come back as errors"""
+    for bad in (dict(bars=1, bar_width=0, bar_gap=0), dict(bars=1, width=0), dict(curve=1, width=1),
+                dict(bars=1, floor_db=0, ceiling_db=0), dict(curve=1, filter_mode=1, filter_radius=float("nan")),
+                dict(bars=1, filter_mode=7)):
+        cfg = scenarios.make_config(dict(fft_size=1024, **bad))
+        with pytest.raises(ValueError):
+            emu.host_table(cfg, 0)
+
+
 # ---- kernel phases in the wavefront emulator vs the oracle --------------------------------------------
 @pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
 @pytest.mark.parametrize("hop", [800, 441])

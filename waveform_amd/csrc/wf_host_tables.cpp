@@ -435,6 +435,12 @@ int build_host_tables(const wf_config &cfg, HostTables &out)
         return WF_HIP_ERR_INVALID;
     if(cfg.bars && ((cfg.bar_width + cfg.bar_gap) <= 0 || cfg.width == 0))
         return WF_HIP_ERR_INVALID;
+    if(!cfg.bars && cfg.curve && cfg.width < 2) // init_interp divides by (width - 1)
+        return WF_HIP_ERR_INVALID;
+    if((cfg.bars || cfg.curve) && cfg.ceiling_db <= cfg.floor_db) // the dB -> pixel mapping divides by (ceiling - floor)
+        return WF_HIP_ERR_INVALID;
+    if(cfg.filter_mode != WF_FILTER_NONE && (cfg.filter_mode != WF_FILTER_GAUSS || !std::isfinite(cfg.filter_radius)))
+        return WF_HIP_ERR_INVALID;
     build_window(cfg, out);
     build_slope(cfg, out);
     build_rolloff(cfg, out);
