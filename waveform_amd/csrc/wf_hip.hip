@@ -584,6 +584,8 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
     if((uint64_t)p->delay_frames + h->N > h->ring_cap)
         return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u + fft_size %u exceeds the ring capacity %u", p->delay_frames, h->N,
                     h->ring_cap);
+    if((p->flags & WF_HIP_TICK_NO_DECIBELS) && h->num_bars == 0)
+        return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS on a configuration without bars or curve: the tick would produce nothing");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const wf::TickArgs a = make_args(h, p);
     const bool aligned = h->all_aligned && (p->delay_frames % 4u) == 0;
