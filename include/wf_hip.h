@@ -117,6 +117,11 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
 /* show()/hide()/capture-timeout per stream: hidden streams take the reset branch of
  * tick_spectrum (src/source_generic.cpp:34-48).  mask[i] != 0 -> hidden. */
 int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *mask);
+/* A/V-sync delay per stream, in frames (dtaudio > 0 of each source, src/source_generic.cpp:50-51), for batches whose
+ * sources run on their own audio timestamps: stream first+i analyses the window ending delay[i] + the tick's common
+ * delay_frames before its newest sample; stays in force until the next call for that stream.  Each delay[i] + fft_size
+ * must fit the ring (and so must their sum with any wf_hip_tick_params::delay_frames used later). */
+int wf_hip_set_stream_delay(wf_hip *h, uint32_t first, uint32_t count, const uint32_t *delay_frames);
 /* m_input_rms per stream (what update_input_rms leaves, src/source_generic.cpp:392-403), for batches whose streams are
  * normalised independently (cfg.normalize_volume): rms[i] belongs to stream first+i and stays in force until the next
  * call for that stream.  Once any stream has been given a value, wf_hip_tick_params::input_rms is ignored (streams never

@@ -113,3 +113,28 @@ def test_per_stream_input_rms():
             ora.tick(1.0 / 60.0)
         assert_db_close(got[i], ora.observe()["db"], f"stream {i} (input_rms {r})")
     assert not np.allclose(got[0], got[1])
+
+
+@pytest.mark.gpu
+def test_per_stream_av_sync_delay():
+    """wf_hip_set_stream_delay: every stream analyses the window ending its own number of frames before its newest sample
+    (dtaudio > 0 of each source, reference src/source_generic.cpp:50-59), aligned and unaligned delays"""
+    import waveform_amd as wf
+    from tools import synth
+    cfg_dict = dict(fft_size=1024, stereo=1, tsmoothing=0)
+    cfg = scenarios.make_config(cfg_dict)
+    for delays in ([0, 400, 800, 1200], [0, 37, 441, 1023]):
+        d = np.array(delays, np.uint32)
+        total = 1024 + 1600
+        audio = synth.block(scenarios.SEED, 0, 1, 2, 0, total)[0]
+        with wf.SpectrumBatch(cfg, len(d), ring_frames=4096) as b:
+            b.set_stream_delay(d)
+            b.push_audio(np.broadcast_to(audio[None], (len(d), 2, total)))
+            b.tick(delay_frames=100 if delays[1] == 37 else 0)
+            got = b.decibels()
+        common = 100 if delays[1] == 37 else 0
+        for i, di in enumerate(delays):
+            ora = scenarios.OracleBackend(cfg)
+            ora.push(audio[:, : total - di - common], muted=False)  # the oracle sees the audio up to the window's end
+            ora.tick(1.0 / 60.0)
+            assert_db_close(got[i], ora.observe()["db"], f"delays {delays}: stream {i}")

@@ -90,6 +90,7 @@ def lib():
     L.wf_hip_tick.argtypes = [vp, C.POINTER(TickParams)]
     L.wf_hip_set_hidden.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
     L.wf_hip_set_input_rms.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_set_stream_delay.argtypes = [vp, u32, u32, C.POINTER(C.c_uint32)]
     L.wf_hip_sync.argtypes = [vp]
     L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
@@ -210,6 +211,11 @@ class SpectrumBatch:
         """mask: uint8[count]; non-zero = hidden / capture timed out (reset branch of tick_spectrum)"""
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         self._ck(self.L.wf_hip_set_hidden(self.h, first, len(m), m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def set_stream_delay(self, delay_frames, first: int = 0):
+        """delay_frames: uint32[count], A/V-sync delay of streams first.. in frames (added to the tick's delay_frames)"""
+        d = np.ascontiguousarray(delay_frames, dtype=np.uint32)
+        self._ck(self.L.wf_hip_set_stream_delay(self.h, first, len(d), d.ctypes.data_as(C.POINTER(C.c_uint32))))
 
     def set_input_rms(self, rms, first: int = 0):
         """rms: float32[count], m_input_rms of streams first.. (per-stream volume normalisation)"""

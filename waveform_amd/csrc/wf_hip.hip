@@ -45,6 +45,9 @@ struct wf_hip {
     int *d_bar_bin = nullptr, *d_bar_off = nullptr, *d_band_widths = nullptr, *d_bar_chunk = nullptr;
     int bar_chunks = 0, bar_lpb = 1, bar_segs = 0;
     int bar_blocks = 0;
+    uint32_t *d_delay = nullptr;     // [n_streams] A/V-sync delay per stream (wf_hip_set_stream_delay), or nullptr
+    uint32_t max_stream_delay = 0;   // largest value ever set (ring-capacity check of the tick)
+    bool stream_delays_aligned = true; // all of them multiples of 4 frames (vector fetch without straddling)
     float *d_vol_comp = nullptr;     // [n_streams] volume compensation per stream (wf_hip_set_input_rms), or nullptr
     bool curve = false;              // the outputs are curve points (render_curve), not bars
     int out_steps = 0;               // outputs finished per thread (curve: ceil(width / T); bars in segment form: 1)
@@ -152,6 +155,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     a.ring_cap = h->ring_cap;
     a.ring_mask = h->ring_cap - 1;
     a.delay = p->delay_frames;
+    a.delay_stream = h->d_delay;
     a.window = h->d_window;
     a.tw1 = h->d_tw1;
     a.tw2 = h->d_tw2;
@@ -581,14 +585,14 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
 {
     if(h == nullptr || p == nullptr)
         return WF_HIP_ERR_INVALID;
-    if((uint64_t)p->delay_frames + h->N > h->ring_cap)
-        return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u + fft_size %u exceeds the ring capacity %u", p->delay_frames, h->N,
-                    h->ring_cap);
+    if((uint64_t)p->delay_frames + h->max_stream_delay + h->N > h->ring_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u (+ per-stream %u) + fft_size %u exceeds the ring capacity %u", p->delay_frames,
+                    h->max_stream_delay, h->N, h->ring_cap);
     if((p->flags & WF_HIP_TICK_NO_DECIBELS) && h->num_bars == 0)
         return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS on a configuration without bars or curve: the tick would produce nothing");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const wf::TickArgs a = make_args(h, p);
-    const bool aligned = h->all_aligned && (p->delay_frames % 4u) == 0;
+    const bool aligned = h->all_aligned && h->stream_delays_aligned && (p->delay_frames % 4u) == 0;
     h->launch(h, a, aligned);
     WF_HIP_TRY(h, hipGetLastError());
     return WF_HIP_OK;
@@ -613,6 +617,35 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
                        h->d_mask);
     WF_HIP_TRY(h, hipGetLastError());
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `mask` is borrowed for the call only
+    return WF_HIP_OK;
+}
+
+int wf_hip_set_stream_delay(wf_hip *h, uint32_t first, uint32_t count, const uint32_t *delay_frames)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(delay_frames == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "delay_frames is NULL");
+    uint32_t mx = 0;
+    bool al = true;
+    for(uint32_t i = 0; i < count; ++i) {
+        mx = std::max(mx, delay_frames[i]);
+        al = al && (delay_frames[i] % 4u) == 0;
+    }
+    if((uint64_t)mx + h->N > h->ring_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "stream delay %u + fft_size %u exceeds the ring capacity %u", mx, h->N, h->ring_cap);
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->d_delay == nullptr) {
+        rc = dev_alloc(h, &h->d_delay, (size_t)h->n_streams);
+        if(rc)
+            return rc;
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_delay, 0, (size_t)h->n_streams * sizeof(uint32_t), h->stream));
+    }
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_delay + first, delay_frames, (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `delay_frames` is borrowed for the call only
+    h->max_stream_delay = std::max(h->max_stream_delay, mx);
+    h->stream_delays_aligned = h->stream_delays_aligned && al; // conservative: never switches back to the vector fetch
     return WF_HIP_OK;
 }
 

@@ -119,7 +119,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF;
     int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
     const float *x = a.ring + (size_t)spec * a.ring_cap;
-    const uint32_t start = (wpos - a.delay - (uint32_t)G::N) & a.ring_mask;
+    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const uint32_t start = (wpos - delay - (uint32_t)G::N) & a.ring_mask;
     float *ts = a.tsmooth + (size_t)spec * M;
     float *rows = a.decibels + (size_t)stream * a.out_ch * M; // m_decibels[0..out_ch) of this stream
 
