@@ -65,6 +65,14 @@ typedef struct wf_config {
     /* smoothing filter across the bars / curve points before the dB -> pixel mapping (src/source.cpp:1396-1405, 1535-1545) */
     int32_t filter_mode;        /* m_filter_mode (wf_filter) */
     float filter_radius;        /* m_filter_radius: sigma of the Gaussian (src/source.cpp:527, 1279-1280) */
+    /* level meter (display_mode METER / STEPPED_METER -> m_meter_mode, src/source.cpp:651-656; tick_meter,
+     * src/source_generic.cpp:182-269).  With meter != 0 the handle is a meter batch: update()'s overrides apply
+     * (window NONE, stereo off, slope 0, no normalisation / mirror / filter, interp POINT, src/source.cpp:1106-1128),
+     * fft_size is ignored on input and becomes the meter buffer length sample_rate * (meter_ms / 1000.0) & -16 (:1121),
+     * and the outputs are one level per captured channel (m_meter_val) plus its bar (render_bars, :1505-1509). */
+    uint32_t meter;             /* m_meter_mode */
+    uint32_t meter_rms;         /* m_meter_rms: RMS (1) or peak (0) */
+    int32_t meter_ms;           /* m_meter_ms: milliseconds of audio the level is taken over */
 } wf_config;
 
 /* get_defaults (src/source.cpp:119-174) + what update() derives for 48 kHz stereo OBS audio,

@@ -25,6 +25,13 @@
  *                        (src/source.cpp:1500-1557; src/filter.hpp:160-211)
  *   wf_hip_read_*        reading m_decibels / m_interp_bufs / m_tsmooth_buf
  *
+ * Level meter.  A handle created from a configuration with cfg.meter != 0 is a *meter batch*: wf_hip_tick runs
+ * WAVSource*::tick_meter (src/source_generic.cpp:182-269; AVX src/source_avx.cpp:202-322) for every stream -- the
+ * meter buffer is the last wf_hip_fft_size() samples consumed from the device ring, RMS or peak over it, temporal
+ * smoothing, dBFS, m_last_silent -- and wf_hip_read_meter / wf_hip_read_bars return m_meter_val and the bars
+ * render_bars draws from it (src/source.cpp:1505-1509, :1548-1557).  Spectrum-only entry points
+ * (read_decibels, read/write_tsmooth, the table getters) fail with WF_HIP_ERR_INVALID on a meter batch.
+ *
  * Conventions: plain C types only; every function returns WF_HIP_OK (0) or a negative
  * wf_hip_status, never throws, never aborts; wf_hip_last_error() gives the text.  A handle
  * is used by one thread at a time (the reference holds m_mtx around tick/update,
@@ -47,7 +54,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 2
+#define WF_HIP_ABI_VERSION 3
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -115,7 +122,12 @@ typedef struct wf_hip_tick_params {
 /* Asynchronous: enqueues the fused kernel for all streams on the handle's stream. */
 int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
 /* show()/hide()/capture-timeout per stream: hidden streams take the reset branch of
- * tick_spectrum (src/source_generic.cpp:34-48).  mask[i] != 0 -> hidden. */
+ * tick_spectrum (src/source_generic.cpp:34-48).  mask[i] != 0 -> hidden.  tick_meter tells the two causes apart
+ * (capture timeout: the meter buffer is cleared and nothing is consumed, src/source_generic.cpp:184-199; !m_show: the
+ * audio is consumed, then the state is reset, :222-230), so a host passes WF_HIP_HIDDEN_TIMEOUT for the former. */
+#define WF_HIP_SHOWN 0
+#define WF_HIP_HIDDEN 1          /* !m_show */
+#define WF_HIP_HIDDEN_TIMEOUT 2  /* m_tick_ts - m_capture_ts > CAPTURE_TIMEOUT */
 int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *mask);
 /* A/V-sync delay per stream, in frames (dtaudio > 0 of each source, src/source_generic.cpp:50-51), for batches whose
  * sources run on their own audio timestamps: stream first+i analyses the window ending delay[i] + the tick's common
@@ -139,6 +151,8 @@ int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);
+/* meter batches: m_meter_val (dBFS) of streams [first, first+count): [count][capture_channels] */
+int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* m_tsmooth_buf: [count][capture_channels][fft_size/2] */
 int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out);
 int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in);

@@ -217,6 +217,16 @@ size_t wfref_bars(wfref_t *h, int ch, const float **out)
     return v.size();
 }
 
+int wfref_meter_mode(wfref_t *h) { return h->obj->m_meter_mode ? 1 : 0; }
+float wfref_meter_val(wfref_t *h, int ch) { return h->obj->m_meter_val[ch & 1]; }
+float wfref_meter_buf(wfref_t *h, int ch) { return h->obj->m_meter_buf[ch & 1]; }
+float wfref_input_rms(wfref_t *h) { return h->obj->m_input_rms; }
+size_t wfref_decibels_size(wfref_t *h)
+{
+    const bool spectrum = !h->obj->m_meter_mode && (h->obj->m_display_mode != DisplayMode::WAVEFORM);
+    return spectrum ? h->obj->m_fft_size / 2 : h->obj->m_fft_size;
+}
+
 int wfref_using_hip(wfref_t *h)
 {
     auto p = dynamic_cast<WAVSourceHIP *>(h->obj);

@@ -75,6 +75,13 @@ size_t wfref_band_widths(wfref_t *h, const int **out);      /* m_band_widths */
 size_t wfref_interp_kernel(wfref_t *h, const float **out, int *radius, int *size); /* m_interp_kernel.weights */
 size_t wfref_bars(wfref_t *h, int ch, const float **out);   /* m_interp_bufs[ch] after render(): pixel y */
 
+/* level meter / volume normalisation / waveform state */
+int wfref_meter_mode(wfref_t *h);                  /* m_meter_mode */
+float wfref_meter_val(wfref_t *h, int ch);         /* m_meter_val[ch] (dBFS) */
+float wfref_meter_buf(wfref_t *h, int ch);         /* m_meter_buf[ch] (EMA state) */
+float wfref_input_rms(wfref_t *h);                 /* m_input_rms after tick()'s update_input_rms() */
+size_t wfref_decibels_size(wfref_t *h);            /* floats in m_decibels[ch]: fft_size/2 (spectrum), fft_size (meter, waveform) */
+
 /* ---- CPU baseline ----
  * n_streams WAVSource objects split statically over n_threads std::threads; each tick
  * every stream receives `hop` new frames/channel of counter-hash white noise through

@@ -62,6 +62,21 @@ def lib():
     L.wfo_interp_weights.restype = C.c_size_t
     L.wfo_interp_weights.argtypes = [vp, C.POINTER(fp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.wfo_r2c.argtypes = [fp, C.c_uint32, fp]
+    L.wfo_meter_create.restype = vp
+    L.wfo_meter_create.argtypes = [vp]
+    L.wfo_meter_destroy.argtypes = [vp]
+    L.wfo_meter_push_audio.argtypes = [vp, fp, fp, C.c_uint32, C.c_int]
+    L.wfo_meter_set_sync_delay.argtypes = [vp, C.c_uint32]
+    L.wfo_meter_set_state.argtypes = [vp, C.c_int]
+    L.wfo_meter_tick.argtypes = [vp, C.c_float]
+    L.wfo_meter_render.argtypes = [vp]
+    L.wfo_meter_size.restype = C.c_uint32
+    L.wfo_meter_size.argtypes = [vp]
+    L.wfo_meter_last_silent.restype = C.c_int
+    L.wfo_meter_last_silent.argtypes = [vp]
+    for n in ("wfo_meter_val", "wfo_meter_ema", "wfo_meter_bar"):
+        getattr(L, n).restype = C.c_float
+        getattr(L, n).argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -188,3 +203,58 @@ class OracleSource:
         if ch is not None:
             return _arr(self.L.wfo_bars(self.h, ch), self.num_bars)
         return np.stack([_arr(self.L.wfo_bars(self.h, c), self.num_bars) for c in range(self.display_channels)])
+
+
+class OracleMeter:
+    """One restated WAVSource in level-meter display mode (oracle/wf_oracle_meter.c)."""
+
+    def __init__(self, cfg):
+        self.L = lib()
+        self._cfg = cfg
+        self.h = self.L.wfo_meter_create(C.cast(C.byref(cfg), C.c_void_p))
+        if not self.h:
+            raise ValueError("wfo_meter_create rejected the configuration")
+        self.size = self.L.wfo_meter_size(self.h)
+        self.capture_channels = int(cfg.capture_channels)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.wfo_meter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push_audio(self, audio, muted=False):
+        a = np.ascontiguousarray(audio, np.float32)
+        fp = C.POINTER(C.c_float)
+        p0 = a[0].ctypes.data_as(fp)
+        p1 = a[1].ctypes.data_as(fp) if self.capture_channels > 1 else fp()
+        self.L.wfo_meter_push_audio(self.h, p0, p1, a.shape[1], 1 if muted else 0)
+
+    def set_sync_delay(self, frames):
+        self.L.wfo_meter_set_sync_delay(self.h, frames)
+
+    def set_state(self, state):
+        """0 shown, 1 hidden (!m_show), 2 capture timed out"""
+        self.L.wfo_meter_set_state(self.h, state)
+
+    def tick(self, seconds=1.0 / 60.0):
+        self.L.wfo_meter_tick(self.h, seconds)
+
+    @property
+    def last_silent(self):
+        return bool(self.L.wfo_meter_last_silent(self.h))
+
+    def levels(self):
+        return np.array([self.L.wfo_meter_val(self.h, c) for c in range(self.capture_channels)], np.float32)
+
+    def ema(self):
+        return np.array([self.L.wfo_meter_ema(self.h, c) for c in range(self.capture_channels)], np.float32)
+
+    def bars(self):
+        self.L.wfo_meter_render(self.h)
+        return np.array([self.L.wfo_meter_bar(self.h, c) for c in range(self.capture_channels)], np.float32)

@@ -68,6 +68,21 @@ size_t wfo_band_widths(const wfo_source *s, const int **out);
 size_t wfo_interp_weights(const wfo_source *s, const float **out, int *radius, int *taps);
 const float *wfo_bars(const wfo_source *s, int ch); /* pixel y per bar after wfo_render_bars */
 
+/* ---- level meter (wf_oracle_meter.c): WAVSourceGeneric::tick_meter, src/source_generic.cpp:182-269 ------------- */
+typedef struct wfo_meter wfo_meter;
+wfo_meter *wfo_meter_create(const wf_config *cfg); /* cfg->meter must be set */
+void wfo_meter_destroy(wfo_meter *m);
+void wfo_meter_push_audio(wfo_meter *m, const float *ch0, const float *ch1, uint32_t frames, int muted);
+void wfo_meter_set_sync_delay(wfo_meter *m, uint32_t frames);
+void wfo_meter_set_state(wfo_meter *m, int state); /* 0 shown, 1 !m_show, 2 capture timed out */
+void wfo_meter_tick(wfo_meter *m, float seconds);
+void wfo_meter_render(wfo_meter *m);                /* render_bars' mapping of the levels */
+uint32_t wfo_meter_size(const wfo_meter *m);        /* m_fft_size (meter buffer length) */
+int wfo_meter_last_silent(const wfo_meter *m);
+float wfo_meter_val(const wfo_meter *m, int ch);    /* m_meter_val */
+float wfo_meter_ema(const wfo_meter *m, int ch);    /* m_meter_buf */
+float wfo_meter_bar(const wfo_meter *m, int ch);    /* m_interp_bufs[0][ch] after wfo_meter_render */
+
 /* the bare DFT stage, for FFT-only tests: out[k] = (re, im) of bin k, k < n/2 */
 void wfo_r2c(const float *in, uint32_t n, float *out_interleaved);
 

@@ -51,6 +51,15 @@ def lib():
     for name in ("wfref_stereo", "wfref_last_silent", "wfref_num_bars", "wfref_using_hip"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp]
+    L.wfref_meter_mode.restype = C.c_int
+    L.wfref_meter_mode.argtypes = [vp]
+    for name in ("wfref_meter_val", "wfref_meter_buf"):
+        getattr(L, name).restype = C.c_float
+        getattr(L, name).argtypes = [vp, C.c_int]
+    L.wfref_input_rms.restype = C.c_float
+    L.wfref_input_rms.argtypes = [vp]
+    L.wfref_decibels_size.restype = C.c_size_t
+    L.wfref_decibels_size.argtypes = [vp]
     L.wfref_ring_bytes.restype = C.c_size_t
     L.wfref_ring_bytes.argtypes = [vp, C.c_int]
     L.wfref_gravity.restype = C.c_float
@@ -179,6 +188,20 @@ class RefSource:
     @property
     def num_bars(self):
         return self.L.wfref_num_bars(self.h)
+
+    @property
+    def meter_mode(self):
+        return bool(self.L.wfref_meter_mode(self.h))
+
+    def meter_val(self, ch):
+        return float(self.L.wfref_meter_val(self.h, ch))
+
+    def meter_buf(self, ch):
+        return float(self.L.wfref_meter_buf(self.h, ch))
+
+    @property
+    def input_rms(self):
+        return float(self.L.wfref_input_rms(self.h))
 
     def ring_bytes(self, ch):
         return self.L.wfref_ring_bytes(self.h, ch)

@@ -10,6 +10,9 @@ and every backend records the same observables after each tick:
   bars  float32 [display_channels, num_bars]     m_interp_bufs after render_bars / render_curve (if cfg.bars or cfg.curve;
                                                   num_bars = m_width for the curve)
   silent bool                                    m_last_silent
+Level-meter configurations (cfg.meter) record instead
+  db    float32 [1, capture_channels]            m_meter_val (dBFS), one level per captured channel
+  bars  float32 [1, capture_channels]            m_interp_bufs[0] after render_bars (src/source.cpp:1505-1509, :1548-1557)
 Audio is the counter-hash noise of include/wf_synth.h (tools/synth.py), so fixtures only store
 outputs.
 """
@@ -89,6 +92,29 @@ SCENARIOS = {
     # muted packets are pushed as zeros (src/source.cpp:1879-1880)
     "muted_packets": dict(cfg=dict(fft_size=1024, stereo=1, tsmoothing=0), steps=_steps(2) + [("mute", 800), ("tick",), ("noise", 800), ("tick",)],
                           record="all"),
+    # ---- level meter (tick_meter, src/source_generic.cpp:182-269) -------------------------------------------------------
+    # defaults: RMS over 150 ms (7200 samples), EMA g = 0.65, two captured channels; m_meter_buf starts at DB_MIN (quirk)
+    "meter_rms_stereo": dict(cfg=dict(meter=1), steps=_steps(30), record="all"),
+    # peak mode, one captured channel, TV-EMA + fast peaks, 100 ms buffer, quieter audio in the middle (decay)
+    "meter_peak_mono_tv_fastpeaks": dict(cfg=dict(meter=1, meter_rms=0, capture_channels=1, tsmoothing=2, fast_peaks=1, meter_ms=100),
+                                         steps=_steps(6) + [("noise_amp", 800, 0.05), ("tick",)] * 8 + _steps(3), record="all"),
+    # no smoothing, ragged 441-frame packets (window start not 16-byte aligned), a packet longer than the meter buffer
+    "meter_nosmooth_ragged": dict(cfg=dict(meter=1, tsmoothing=0, meter_ms=50),
+                                  steps=[("noise", 441), ("tick",)] * 5 + [("noise", 5000), ("tick",), ("noise", 3), ("tick",), ("tick",)],
+                                  record="all"),
+    # noise, then digital silence until both levels fall below floor-10 (m_last_silent), then noise again
+    "meter_silence_cycle": dict(cfg=dict(meter=1, gravity=0.2, meter_ms=50),
+                                steps=_steps(4) + [("silence", 800), ("tick",)] * 16 + _steps(3), record="all"),
+    # one channel live, the other silent: never m_last_silent
+    "meter_half_silent": dict(cfg=dict(meter=1, gravity=0.2, meter_ms=50),
+                              steps=_steps(3) + [("noise_ch0_only", 800), ("tick",)] * 12, record="all"),
+    # hide (audio still consumed, state reset) / show; capture timeout (meter buffer cleared) / resume; rounded caps geometry
+    # (channel_mode stereo keeps m_channel_spacing through get_settings, src/source.cpp:579; update() then clears m_stereo)
+    "meter_hide_show_timeout": dict(cfg=dict(meter=1, stereo=1, rounded_caps=1, channel_spacing=6, min_bar_height=3),
+                                    steps=_steps(4) + [("hide",), ("noise", 800), ("tick",), ("noise", 800), ("tick",), ("show",)] + _steps(3)
+                                    + [("timeout",), ("tick",), ("tick",)] + _steps(4), record="all"),
+    # spectrum: capture timeout takes the same reset branch as hide (src/source_generic.cpp:34)
+    "timeout_spectrum": dict(cfg=dict(fft_size=1024, stereo=1), steps=_steps(3) + [("timeout",), ("tick",), ("tick",)] + _steps(3), record="all"),
 }
 
 
@@ -105,13 +131,15 @@ class _Feeder:
         self.channels = channels
         self.pos = 0
 
-    def block(self, kind, frames):
+    def block(self, kind, frames, amp=1.0):
         a = synth.block(SEED, 0, 1, 2, self.pos, frames)[0]
         self.pos += frames
         if kind == "silence" or kind == "mute":
             a[:] = 0.0
         elif kind == "noise_ch0_only":
             a[1] = 0.0
+        elif kind == "noise_amp":
+            a *= np.float32(amp)
         return a[: self.channels]
 
 
@@ -123,6 +151,10 @@ def play(backend, scenario: dict):
         op = step[0]
         if op in ("noise", "silence", "noise_ch0_only"):
             backend.push(feeder.block(op, step[1]), muted=False)
+        elif op == "noise_amp":
+            backend.push(feeder.block(op, step[1], step[2]), muted=False)
+        elif op == "timeout":
+            backend.timeout()  # no packet for more than CAPTURE_TIMEOUT (500 ms); the next packet ends it
         elif op == "mute":
             backend.push(feeder.block(op, step[1]), muted=True)
         elif op == "tick":
@@ -155,6 +187,7 @@ class RefBackend:
         self.capture_channels = int(cfg.capture_channels)
         self.disp = 2 if cfg.stereo else 1
         self.now = 1_000_000_000
+        assert self.src.meter_mode == bool(cfg.meter)
 
     def push(self, audio, muted):
         import ctypes as C
@@ -174,10 +207,17 @@ class RefBackend:
         self.src.L.wfref_set_clock_ns(self.now)
         self.src.L.wfref_tick(self.src.h, seconds)
 
+    def timeout(self):
+        self.now += 600_000_000  # > CAPTURE_TIMEOUT (500 ms) since the last packet
+
     def set_hidden(self, hidden):
         self.src.show(not hidden)
 
     def observe(self):
+        if self.cfg.meter:
+            levels = np.array([[self.src.meter_val(c) for c in range(self.capture_channels)]], np.float32)
+            self.src.render()
+            return dict(db=levels, bars=self.src.bars(0)[None, : self.capture_channels], silent=self.src.last_silent)
         db = np.stack([self.src.decibels(c) for c in range(self.disp)])
         bars = None
         if self.cfg.bars or self.cfg.curve:
@@ -190,20 +230,38 @@ class OracleBackend:
     def __init__(self, cfg, input_rms=0.0):
         from oracle import restate
         self.cfg = cfg
-        self.src = restate.OracleSource(cfg)
-        self.src.set_input_rms(input_rms)
+        self.hidden = False
+        if cfg.meter:
+            self.src = restate.OracleMeter(cfg)
+        else:
+            self.src = restate.OracleSource(cfg)
+            self.src.set_input_rms(input_rms)
         self.capture_channels = self.src.capture_channels
 
+    def _state(self, timed_out=False):
+        # the restatement takes the tick's gate as given: 0 shown, 1 !m_show, 2 capture timed out
+        if self.cfg.meter:
+            self.src.set_state(2 if timed_out else (1 if self.hidden else 0))
+        else:
+            self.src.set_hidden(self.hidden or timed_out)
+
     def push(self, audio, muted):
+        self._state()  # a packet ends a capture timeout
         self.src.push_audio(audio, muted=muted)
 
     def tick(self, seconds):
         self.src.tick(seconds)
 
+    def timeout(self):
+        self._state(timed_out=True)
+
     def set_hidden(self, hidden):
-        self.src.set_hidden(hidden)
+        self.hidden = hidden
+        self._state()
 
     def observe(self):
+        if self.cfg.meter:
+            return dict(db=self.src.levels()[None], bars=self.src.bars()[None], silent=self.src.last_silent)
         bars = None
         if self.cfg.bars or self.cfg.curve:
             self.src.render_bars()
@@ -224,8 +282,19 @@ class HipBackend:
         self.streams = streams
         self.probe = probe
         self.disp = self.batch.display_channels
+        self.hidden = False
+
+    def _state(self, timed_out=False):
+        self.batch.set_hidden(np.full(self.streams, 2 if timed_out else (1 if self.hidden else 0), np.uint8))
+
+    def timeout(self):
+        self._state(timed_out=True)
+        self.timed_out = True
 
     def push(self, audio, muted):
+        if getattr(self, "timed_out", False):
+            self.timed_out = False
+            self._state()  # a packet ends a capture timeout
         if muted:
             self.batch.push_silence(audio.shape[1])
         else:
@@ -235,9 +304,14 @@ class HipBackend:
         self.batch.tick(seconds=seconds, input_rms=self.input_rms)
 
     def set_hidden(self, hidden):
-        self.batch.set_hidden(np.full(self.streams, 1 if hidden else 0, np.uint8))
+        self.hidden = hidden
+        self._state()
 
     def observe(self):
+        if self.cfg.meter:
+            lv, bars, silent = self.batch.meter(), self.batch.bars(), self.batch.last_silent()
+            assert all(np.array_equal(lv[0], lv[i]) for i in range(1, self.streams)), "streams of one batch disagree"
+            return dict(db=lv[self.probe][None], bars=bars[self.probe], silent=bool(silent[self.probe]))
         db = self.batch.decibels()
         bars = self.batch.bars() if (self.cfg.bars or self.cfg.curve) else None
         silent = self.batch.last_silent()

@@ -33,6 +33,7 @@ class Config(C.Structure):
         ("width", C.c_uint32), ("height", C.c_uint32), ("bar_width", C.c_int32), ("bar_gap", C.c_int32),
         ("channel_spacing", C.c_int32), ("min_bar_height", C.c_int32), ("rounded_caps", C.c_uint32),
         ("curve", C.c_uint32), ("filter_mode", C.c_int32), ("filter_radius", C.c_float),
+        ("meter", C.c_uint32), ("meter_rms", C.c_uint32), ("meter_ms", C.c_int32),
     ]
 
     @classmethod
@@ -95,6 +96,7 @@ def lib():
     L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
     L.wf_hip_copy_bars_device.argtypes = [vp, u32, u32, vp]
+    L.wf_hip_read_meter.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_write_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
@@ -208,7 +210,8 @@ class SpectrumBatch:
         self._ck(self.L.wf_hip_tick(self.h, C.byref(p)))
 
     def set_hidden(self, mask, first: int = 0):
-        """mask: uint8[count]; non-zero = hidden / capture timed out (reset branch of tick_spectrum)"""
+        """mask: uint8[count]; non-zero = hidden (1) / capture timed out (2) (reset branch of tick_spectrum; tick_meter
+        tells the two apart)"""
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         self._ck(self.L.wf_hip_set_hidden(self.h, first, len(m), m.ctypes.data_as(C.POINTER(C.c_uint8))))
 
@@ -249,6 +252,13 @@ class SpectrumBatch:
         """device-to-device copy of the bar tops into a caller-owned buffer (e.g. a torch tensor's data_ptr())"""
         count = self.streams - first if count is None else count
         self._ck(self.L.wf_hip_copy_bars_device(self.h, first, count, C.c_void_p(dev_ptr)))
+
+    def meter(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """meter batches: m_meter_val in dBFS, [count, capture_channels]"""
+        count = self.streams - first if count is None else count
+        out = np.empty((count, self.capture_channels), np.float32)
+        self._ck(self.L.wf_hip_read_meter(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def tsmooth(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.streams - first if count is None else count

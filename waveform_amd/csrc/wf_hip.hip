@@ -13,6 +13,7 @@
 #include "wf_hip.h"
 #include "wf_host_tables.hpp"
 #include "wf_kernels.hpp"
+#include "wf_meter.hpp"
 
 namespace {
 
@@ -49,6 +50,11 @@ struct wf_hip {
     uint32_t max_stream_delay = 0;   // largest value ever set (ring-capacity check of the tick)
     bool stream_delays_aligned = true; // all of them multiples of 4 frames (vector fetch without straddling)
     float *d_vol_comp = nullptr;     // [n_streams] volume compensation per stream (wf_hip_set_input_rms), or nullptr
+    // level-meter batches (cfg.meter): N is the meter buffer length, there is no FFT state
+    bool meter = false;
+    uint32_t *d_mend = nullptr;      // [n_streams] consumption point of tick_meter
+    float *d_meter_buf = nullptr;    // [n_streams * cap_ch] m_meter_buf
+    float *d_meter_val = nullptr;    // [n_streams * cap_ch] m_meter_val
     bool curve = false;              // the outputs are curve points (render_curve), not bars
     int out_steps = 0;               // outputs finished per thread (curve: ceil(width / T); bars in segment form: 1)
     float *d_cur_coef = nullptr, *d_gauss = nullptr, *d_gauss_wsum = nullptr;
@@ -227,6 +233,37 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     return a;
 }
 
+wf::MeterArgs make_meter_args(wf_hip *h, const wf_hip_tick_params *p)
+{
+    wf::MeterArgs m{};
+    m.ring = h->d_ring;
+    m.wpos = h->d_wpos;
+    m.mend = h->d_mend;
+    m.ring_cap = h->ring_cap;
+    m.ring_mask = h->ring_cap - 1;
+    m.delay = p->delay_frames;
+    m.delay_stream = h->d_delay;
+    m.size = h->N;
+    m.meter_buf = h->d_meter_buf;
+    m.meter_val = h->d_meter_val;
+    m.stream_flags = h->d_flags;
+    m.bars = h->d_bars;
+    m.g = wf::gravity_for(h->cfg, p->seconds);
+    m.g2 = 1.0f - m.g;
+    m.db_min = wf::db_min();
+    m.silent_floor = (float)(h->cfg.floor_db - 10);
+    m.border_top = h->tab.border_top;
+    m.border_bottom = h->tab.border_bottom;
+    m.ceiling = (float)h->cfg.ceiling_db;
+    m.dbrange = (float)(h->cfg.ceiling_db - h->cfg.floor_db);
+    m.n_streams = h->n_streams;
+    m.cap_ch = h->cap_ch;
+    m.rms = h->cfg.meter_rms ? 1u : 0u;
+    m.tsmooth = (h->cfg.tsmoothing != WF_TSMOOTH_NONE) ? 1u : 0u;
+    m.fast_peaks = h->cfg.fast_peaks ? 1u : 0u;
+    return m;
+}
+
 int check_range(wf_hip *h, uint32_t first, uint32_t count)
 {
     if(h == nullptr)
@@ -293,6 +330,10 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(cfg == nullptr || max_streams == 0)
         return fail(nullptr, WF_HIP_ERR_INVALID, "cfg is NULL or max_streams is 0");
     wf::HostTables tab;
+    wf_config cfg_eff = *cfg;
+    if(cfg_eff.meter)
+        wf::meter_config(cfg_eff); // update()'s overrides for the mode; fft_size becomes the meter buffer length
+    cfg = &cfg_eff;
     int rc = wf::build_host_tables(*cfg, tab);
     if(rc == WF_HIP_ERR_UNSUPPORTED)
         return fail(nullptr, rc, "fft_size %u: only powers of two in 1024..16384 are implemented", cfg->fft_size);
@@ -318,6 +359,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     h->disp_ch = h->tab.display_channels;
     h->num_bars = (uint32_t)h->tab.num_bars;
     h->ring_cap = next_pow2(ring_frames ? std::max(ring_frames, h->N) : 2 * h->N);
+    h->meter = cfg->meter != 0;
 
     auto bail = [&](int code) {
         g_create_error = h->last_error;
@@ -353,6 +395,19 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     const size_t n_spec = (size_t)h->n_streams * h->cap_ch;
     WF_CREATE_TRY(dev_alloc(h, &h->d_ring, n_spec * h->ring_cap));
     WF_CREATE_TRY(dev_alloc(h, &h->d_wpos, (size_t)h->n_streams));
+    if(h->meter) {
+        // level meter: rings, consumption points, two floats of state per channel, one bar per channel
+        WF_CREATE_TRY(dev_alloc(h, &h->d_mend, (size_t)h->n_streams));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_meter_buf, n_spec));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_meter_val, n_spec));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->n_streams));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_bars, n_spec));
+        h->kernel_name = "meter_tick_kernel";
+        WF_CREATE_TRY(wf_hip_reset(h, 0, h->n_streams));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+        *out = h;
+        return WF_HIP_OK;
+    }
     WF_CREATE_TRY(dev_alloc(h, &h->d_tsmooth, n_spec * h->M));
     WF_CREATE_TRY(dev_alloc(h, &h->d_decibels, (size_t)h->n_streams * h->out_ch * h->M));
     WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->n_streams));
@@ -487,6 +542,22 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
         return rc;
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const size_t spec0 = (size_t)first * h->cap_ch, nspec = (size_t)count * h->cap_ch;
+    if(h->meter) {
+        // update() in meter mode (src/source.cpp:1123-1127, :1181, :1243): empty rings (no zero pre-fill), meter buffer 0,
+        // m_meter_buf = m_meter_val = DB_MIN, m_last_silent = false
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_cap, 0, nspec * h->ring_cap * sizeof(float), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_wpos + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_mend + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+        const dim3 g((unsigned)((nspec + 255) / 256)), b(256);
+        hipLaunchKernelGGL(wf::fill_f32_kernel, g, b, 0, h->stream, h->d_meter_buf + spec0, nspec, wf::db_min());
+        hipLaunchKernelGGL(wf::fill_f32_kernel, g, b, 0, h->stream, h->d_meter_val + spec0, nspec, wf::db_min());
+        hipLaunchKernelGGL(wf::fill_f32_kernel, g, b, 0, h->stream, h->d_bars + spec0, nspec, h->tab.border_bottom);
+        WF_HIP_TRY(h, hipGetLastError());
+        if(first == 0 && count == h->n_streams)
+            h->all_aligned = true;
+        return WF_HIP_OK;
+    }
     // m_tsmooth_buf = 0, rings = zeros with N samples "written", m_decibels = DB_MIN, m_last_silent = false
     WF_HIP_TRY(h, hipMemsetAsync(h->d_tsmooth + spec0 * h->M, 0, nspec * h->M * sizeof(float), h->stream));
     WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_cap, 0, nspec * h->ring_cap * sizeof(float), h->stream));
@@ -591,6 +662,12 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
     if((p->flags & WF_HIP_TICK_NO_DECIBELS) && h->num_bars == 0)
         return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS on a configuration without bars or curve: the tick would produce nothing");
     WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->meter) {
+        const wf::MeterArgs m = make_meter_args(h, p);
+        hipLaunchKernelGGL(wf::meter_tick_kernel, dim3(h->n_streams), dim3(wf::METER_THREADS), 0, h->stream, m);
+        WF_HIP_TRY(h, hipGetLastError());
+        return WF_HIP_OK;
+    }
     const wf::TickArgs a = make_args(h, p);
     const bool aligned = h->all_aligned && h->stream_delays_aligned && (p->delay_frames % 4u) == 0;
     h->launch(h, a, aligned);
@@ -702,6 +779,8 @@ int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out)
     int rc = check_range(h, first, count);
     if(rc)
         return rc;
+    if(h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "meter batch: there is no m_decibels; read the levels with wf_hip_read_meter");
     const size_t per = (size_t)h->out_ch * h->M;
     return read_back(h, h->d_decibels + first * per, out, count * per * sizeof(float));
 }
@@ -733,11 +812,23 @@ int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_o
     return WF_HIP_OK;
 }
 
+int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(!h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "not a meter batch (cfg.meter == 0)");
+    return read_back(h, h->d_meter_val + (size_t)first * h->cap_ch, out, (size_t)count * h->cap_ch * sizeof(float));
+}
+
 int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out)
 {
     int rc = check_range(h, first, count);
     if(rc)
         return rc;
+    if(h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "meter batch: there is no m_tsmooth_buf");
     const size_t per = (size_t)h->cap_ch * h->M;
     return read_back(h, h->d_tsmooth + first * per, out, count * per * sizeof(float));
 }
@@ -749,6 +840,8 @@ int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float 
         return rc;
     if(in == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "input pointer is NULL");
+    if(h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "meter batch: there is no m_tsmooth_buf");
     const size_t per = (size_t)h->cap_ch * h->M;
     WF_HIP_TRY(h, hipSetDevice(h->device));
     WF_HIP_TRY(h, hipMemcpyAsync(h->d_tsmooth + first * per, in, count * per * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -850,6 +943,8 @@ uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags)
 {
     if(h == nullptr)
         return 0;
+    if(h->meter) // read the meter buffer of every captured channel; state, level and bar are a few floats per channel
+        return (uint64_t)h->n_streams * h->cap_ch * (4ull * h->N + 20ull);
     // read the N-sample window of every captured channel, read + write the smoothing
     // state (M floats each way) when temporal smoothing is on, write M dB values per displayed/output channel
     // (stereo: both channels; mono mixdown: one), plus the bar heights when the configuration has bars.

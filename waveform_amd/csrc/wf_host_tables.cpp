@@ -157,6 +157,30 @@ void build_catrom(const std::vector<float> &indices, HostTables &t)
     }
 }
 
+// render_bars geometry (src/source.cpp:1476-1494); render_curve maps onto [0, cpos - channel_offset] (:1411)
+void render_geometry(const wf_config &cfg, bool curve, HostTables &t)
+{
+    const float center = (float)cfg.height / 2;
+    const float bottom = (float)cfg.height;
+    const float cpos = cfg.stereo ? center : bottom;
+    const float cap_radius = (float)cfg.bar_width / 2.0f;
+    const float channel_offset = cfg.channel_spacing * 0.5f;
+    float border_top = cfg.rounded_caps ? cap_radius : 0.0f;
+    float border_bottom = (cfg.rounded_caps && (!cfg.stereo || (cfg.channel_spacing > 0))) ? cpos - cap_radius : cpos;
+    if(cfg.channel_spacing > 0)
+        border_bottom -= channel_offset;
+    if(cfg.min_bar_height > 0)
+        border_bottom -= cfg.min_bar_height;
+    border_bottom = std::clamp(border_bottom, border_top, cpos);
+    if(curve) {
+        border_top = 0.0f;
+        border_bottom = cpos - channel_offset;
+    }
+    t.border_top = border_top;
+    t.border_bottom = border_bottom;
+    t.cpos = cpos;
+}
+
 // bar layout: update() :1267-1276, init_interp :837-896, render_bars geometry :1476-1494
 void build_bars(const wf_config &cfg, HostTables &t)
 {
@@ -223,26 +247,7 @@ void build_bars(const wf_config &cfg, HostTables &t)
         t.interp_indices = std::move(idx);
     }
 
-    // render_bars geometry (:1476-1494); render_curve maps onto [0, cpos - channel_offset] (:1411)
-    const float center = (float)cfg.height / 2;
-    const float bottom = (float)cfg.height;
-    const float cpos = cfg.stereo ? center : bottom;
-    const float cap_radius = (float)cfg.bar_width / 2.0f;
-    const float channel_offset = cfg.channel_spacing * 0.5f;
-    float border_top = cfg.rounded_caps ? cap_radius : 0.0f;
-    float border_bottom = (cfg.rounded_caps && (!cfg.stereo || (cfg.channel_spacing > 0))) ? cpos - cap_radius : cpos;
-    if(cfg.channel_spacing > 0)
-        border_bottom -= channel_offset;
-    if(cfg.min_bar_height > 0)
-        border_bottom -= cfg.min_bar_height;
-    border_bottom = std::clamp(border_bottom, border_top, cpos);
-    if(curve) {
-        border_top = 0.0f;
-        border_bottom = cpos - channel_offset;
-    }
-    t.border_top = border_top;
-    t.border_bottom = border_bottom;
-    t.cpos = cpos;
+    render_geometry(cfg, curve, t);
 
     // Gaussian filter across the outputs: make_gauss_kernel(m_filter_radius), src/filter.hpp:40-65 (float throughout)
     t.gauss.clear();
@@ -427,8 +432,39 @@ float gravity_for(const wf_config &cfg, float seconds)
     return (cfg.tsmoothing == WF_TSMOOTH_TVEXPONENTIAL) ? std::exp(-seconds / std::lerp(lo, hi, cfg.gravity)) : cfg.gravity;
 }
 
+uint32_t meter_config(wf_config &cfg)
+{
+    // "turn off stuff we don't need in this mode", src/source.cpp:1108-1118
+    cfg.window = WF_WINDOW_NONE;
+    cfg.interp_mode = WF_INTERP_POINT;
+    cfg.filter_mode = WF_FILTER_NONE;
+    cfg.slope = 0.0f;
+    cfg.stereo = 0;
+    cfg.normalize_volume = 0;
+    cfg.mirror_freq_axis = 0;
+    cfg.bars = 0;
+    cfg.curve = 0;
+    // "repurpose m_fft_size for meter buffer size", :1121
+    cfg.fft_size = (uint32_t)(size_t((double)cfg.sample_rate * ((double)cfg.meter_ms / 1000.0)) & (size_t)-16);
+    return cfg.fft_size;
+}
+
 int build_host_tables(const wf_config &cfg, HostTables &out)
 {
+    if(cfg.meter) {
+        // level meter: no FFT, no tables; one "bar" per captured channel through render_bars' mapping (:1257-1266, :1505-1509)
+        if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0 || cfg.meter_ms <= 0 || cfg.fft_size < 16)
+            return WF_HIP_ERR_INVALID;
+        if(cfg.ceiling_db <= cfg.floor_db)
+            return WF_HIP_ERR_INVALID;
+        out = HostTables{};
+        out.window_sum = (float)cfg.fft_size;
+        out.output_channels = ((cfg.capture_channels > 1) || cfg.stereo) ? 2u : 1u;
+        out.display_channels = 1u;
+        out.num_bars = (int)cfg.capture_channels;
+        render_geometry(cfg, false, out);
+        return WF_HIP_OK;
+    }
     if(!is_pow2(cfg.fft_size) || cfg.fft_size < 1024 || cfg.fft_size > 16384)
         return WF_HIP_ERR_UNSUPPORTED;
     if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0)
@@ -513,4 +549,7 @@ extern "C" void wf_config_defaults(wf_config *cfg)
     cfg->curve = 0;                // no render-time outputs unless asked for
     cfg->filter_mode = WF_FILTER_NONE;
     cfg->filter_radius = 1.5f;
+    cfg->meter = 0;
+    cfg->meter_rms = 1;            // P_RMS_MODE default true
+    cfg->meter_ms = 150;           // P_METER_BUF default
 }

@@ -17,6 +17,7 @@
 #include "wf_geometry.hpp"
 #include "wf_tick_phases.hpp"
 #include "wf_synth.h"
+#include "wf_hip.h"
 
 namespace wf {
 
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     }
     WF_STAMP(10);
     if(active && ch == 0 && t == 0)
-        a.stream_flags[stream] = (sflags & WF_STREAM_HIDDEN) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
+        a.stream_flags[stream] = (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
 
     // ---- bars: what render_bars derives from the rows just written (reference src/source.cpp:1500-1557) ---------------
     if(a.bar.out != nullptr) {
@@ -334,13 +335,14 @@ __global__ void wpos_advance_kernel(uint32_t *wpos, uint32_t first, uint32_t cou
         wpos[first + i] += frames;
 }
 
-// show()/hide()/capture timeout: set or clear WF_STREAM_HIDDEN, keep m_last_silent
+// show()/hide()/capture timeout: set or clear WF_STREAM_HIDDEN (mask 1: hidden, 2: capture timed out), keep m_last_silent
 __global__ void set_hidden_kernel(uint32_t *flags, uint32_t first, uint32_t count, const uint8_t *mask)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < count) {
-        const uint32_t f = flags[first + i];
-        flags[first + i] = mask[i] ? (f | WF_STREAM_HIDDEN) : (f & ~WF_STREAM_HIDDEN);
+        const uint32_t f = flags[first + i] & ~(WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT);
+        const uint32_t m = mask[i];
+        flags[first + i] = f | (m ? WF_STREAM_HIDDEN : 0u) | (m == WF_HIP_HIDDEN_TIMEOUT ? WF_STREAM_TIMEOUT : 0u);
     }
 }
 

@@ -37,6 +37,7 @@ enum : uint32_t {
 enum : uint32_t {
     WF_STREAM_LAST_SILENT = 1u << 0, // m_last_silent
     WF_STREAM_HIDDEN = 1u << 1,      // !m_show or capture timed out (host sets it)
+    WF_STREAM_TIMEOUT = 1u << 2,     // set with HIDDEN when the cause is the capture timeout: tick_meter treats the two differently
 };
 
 // bars or curve (render_bars / render_curve interpolation, filter, dB -> pixel mapping); out == nullptr: neither
