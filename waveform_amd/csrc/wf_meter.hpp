@@ -43,7 +43,7 @@ struct MeterArgs {
 };
 
 constexpr int METER_THREADS = 256;
-constexpr int METER_UNROLL = 4; // 16-byte loads in flight per thread and channel
+constexpr int METER_UNROLL = 8; // 16-byte loads in flight per thread and channel
 
 // sum of squares / max |x| of the four samples of one aligned chunk, masked to the window [head, head + size)
 WF_DEV void meter_accumulate(const f4 v, uint32_t e0, uint32_t head, uint32_t stop, bool rms, float &acc)
