@@ -106,6 +106,10 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
                       uint64_t index0, uint32_t frames);
 /* muted / silent packet: CircularBuffer::push_back_zero (src/source.cpp:1879-1880) */
 int wf_hip_push_silence(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames);
+/* muted packet that still carries samples (muted && !m_ignore_mute): the rings receive zeros, but capture_audio takes the
+ * volume-normalisation RMS from the packet itself (src/source.cpp:1842-1871), so the device RMS producer receives
+ * `samples`.  Without wf_hip_enable_input_rms this is wf_hip_push_silence. */
+int wf_hip_push_audio_muted(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames);
 
 /* ---- the tick ------------------------------------------------------------------------- */
 typedef struct wf_hip_tick_params {
@@ -140,6 +144,15 @@ int wf_hip_set_stream_delay(wf_hip *h, uint32_t first, uint32_t count, const uin
  * set read 0, i.e. the full max_gain, as a source that has not seen audio yet does).  The volume compensation
  * min(volume_target - dbfs(rms), max_gain) (src/source_generic.cpp:163) is evaluated here, on the host, in float. */
 int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float *rms);
+/* Volume normalisation produced on the device: update_input_rms for every stream (src/source_generic.cpp:392-403 with
+ * sync_rms_buffer, src/source.cpp:810-835, fed by the RMS part of capture_audio, :1842-1871).  After this call every
+ * wf_hip_push_* also appends the squared per-frame peak of the captured channels to a per-stream RMS ring, and every
+ * wf_hip_tick first recomputes m_input_rms over the m_input_rms_size (= sample_rate & -16) frames that end at the
+ * A/V-sync point, as WAVSource::tick does (src/source.cpp:1330-1331); wf_hip_tick_params::input_rms is then ignored and
+ * wf_hip_set_input_rms fails.  Needs cfg.normalize_volume.  Audio pushed before the call counts as silence. */
+int wf_hip_enable_input_rms(wf_hip *h);
+/* m_input_rms of streams [first, first+count) as of the last tick */
+int wf_hip_read_input_rms(wf_hip *h, uint32_t first, uint32_t count, float *out);
 int wf_hip_sync(wf_hip *h);
 
 /* ---- results ----------------------------------------------------------------------------- */

@@ -33,6 +33,9 @@ def lib():
     L.wfo_set_hidden.argtypes = [vp, C.c_int]
     L.wfo_set_input_rms.argtypes = [vp, C.c_float]
     L.wfo_tick.argtypes = [vp, C.c_float]
+    L.wfo_update_input_rms.argtypes = [vp]
+    L.wfo_input_rms.restype = C.c_float
+    L.wfo_input_rms.argtypes = [vp]
     L.wfo_render_bars.argtypes = [vp]
     L.wfo_fft_size.restype = C.c_uint32
     L.wfo_fft_size.argtypes = [vp]
@@ -143,6 +146,11 @@ class OracleSource:
 
     def set_input_rms(self, rms):
         self.L.wfo_set_input_rms(self.h, rms)
+
+    def update_input_rms(self):
+        """update_input_rms() from the captured audio (cfg.normalize_volume); returns m_input_rms"""
+        self.L.wfo_update_input_rms(self.h)
+        return float(self.L.wfo_input_rms(self.h))
 
     def tick(self, seconds=1.0 / 60.0):
         self.L.wfo_tick(self.h, seconds)

@@ -23,6 +23,9 @@ struct wfo_source {
     int hidden;
     int last_silent;            /* m_last_silent */
     float input_rms;
+    /* volume normalisation producer (capture_audio's RMS part + update_input_rms), only with cfg.normalize_volume */
+    float *rms_sync; size_t rms_sync_len, rms_sync_cap; /* m_rms_sync_buf (CircularBuffer of squared peaks), in samples */
+    float *rms_buf; size_t rms_size, rms_pos;           /* m_input_rms_buf (circular), m_input_rms_size, m_input_rms_pos */
     /* tables */
     float *window;              /* NULL when FFTWindow::NONE */
     float window_sum;
@@ -416,6 +419,12 @@ wfo_source *wfo_create(const wf_config *cfg)
     build_bars(s);
     build_slope(s);
     build_rolloff(s);
+    if(cfg->normalize_volume) { /* src/source.cpp:1144-1152 */
+        s->input_rms = 0.0f;
+        s->rms_size = (size_t)cfg->sample_rate & (size_t)-16;
+        s->rms_pos = 0;
+        s->rms_buf = (float *)calloc(s->rms_size, sizeof(float));
+    }
     return s;
 }
 
@@ -429,6 +438,7 @@ void wfo_destroy(wfo_source *s)
     free(s->window); free(s->slope); free(s->rolloff); free(s->fft_in); free(s->fft_out);
     free(s->interp_indices); free(s->band_widths); free(s->weights); free(s->gauss); free(s->filter_tmp);
     free(s->wr); free(s->wi); free(s->twr); free(s->twi);
+    free(s->rms_sync); free(s->rms_buf);
     free(s);
 }
 
@@ -440,6 +450,29 @@ void wfo_set_input_rms(wfo_source *s, float rms) { s->input_rms = rms; }
 void wfo_push_audio(wfo_source *s, const float *ch0, const float *ch1, uint32_t frames, int muted)
 {
     const float *data[2] = {ch0, ch1};
+    if(s->cfg.normalize_volume) { /* :1842-1871: the largest |sample| of all channels per frame, squared -- muted or not */
+        if(s->rms_sync_len + frames > s->rms_sync_cap) {
+            size_t cap = s->rms_sync_cap ? s->rms_sync_cap : 4096;
+            while(cap < s->rms_sync_len + frames)
+                cap *= 2;
+            s->rms_sync = (float *)realloc(s->rms_sync, cap * sizeof(float));
+            s->rms_sync_cap = cap;
+        }
+        for(uint32_t i = 0; i < frames; ++i) {
+            float val = 0.0f;
+            for(uint32_t ch = 0; ch < s->cap_ch; ++ch)
+                if(data[ch] != NULL)
+                    val = fmaxf(fabsf(data[ch][i]), val);
+            s->rms_sync[s->rms_sync_len + i] = val * val;
+        }
+        s->rms_sync_len += frames;
+        const size_t max_rms_size = (size_t)s->sync_delay + s->rms_size;
+        if(s->rms_sync_len > max_rms_size) {
+            const size_t drop = s->rms_sync_len - max_rms_size;
+            memmove(s->rms_sync, s->rms_sync + drop, max_rms_size * sizeof(float));
+            s->rms_sync_len = max_rms_size;
+        }
+    }
     for(uint32_t j = 0; j < s->cap_ch; ++j) {
         if(muted || data[j] == NULL)
             ring_push(s, (int)j, NULL, frames);
@@ -450,6 +483,33 @@ void wfo_push_audio(wfo_source *s, const float *ch0, const float *ch1, uint32_t 
             ring_pop_front(s, (int)j, s->ring_len[j] - max_size);
     }
 }
+
+/* WAVSourceGeneric::update_input_rms (src/source_generic.cpp:392-403) with sync_rms_buffer (src/source.cpp:810-835); the
+ * reference calls it at the top of every tick() when m_normalize_volume (src/source.cpp:1330-1331) */
+void wfo_update_input_rms(wfo_source *s)
+{
+    if(!s->cfg.normalize_volume)
+        return;
+    const size_t dtsize = s->sync_delay;
+    if(s->rms_sync_len <= dtsize)
+        return;
+    size_t head = 0;
+    while(s->rms_sync_len - head > dtsize) {
+        const size_t consume = s->rms_sync_len - head - dtsize;
+        const size_t max = s->rms_size - s->rms_pos;
+        const size_t n = (consume >= max) ? max : consume;
+        memcpy(s->rms_buf + s->rms_pos, s->rms_sync + head, n * sizeof(float));
+        head += n;
+        s->rms_pos = (consume >= max) ? 0 : s->rms_pos + n;
+    }
+    memmove(s->rms_sync, s->rms_sync + head, (s->rms_sync_len - head) * sizeof(float));
+    s->rms_sync_len -= head;
+    float sum = 0.0f;
+    for(size_t i = 0; i < s->rms_size; ++i)
+        sum += s->rms_buf[i];
+    s->input_rms = sqrtf(sum / s->rms_size);
+}
+float wfo_input_rms(const wfo_source *s) { return s->input_rms; }
 
 /* WAVSourceGeneric::tick_spectrum, src/source_generic.cpp:26-180 */
 void wfo_tick(wfo_source *s, float seconds)

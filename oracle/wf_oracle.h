@@ -47,6 +47,10 @@ void wfo_set_sync_delay(wfo_source *s, uint32_t frames);
 /* m_show / capture timeout: hidden != 0 takes the reset branch (src/source_generic.cpp:34-48) */
 void wfo_set_hidden(wfo_source *s, int hidden);
 void wfo_set_input_rms(wfo_source *s, float rms);
+/* update_input_rms() from what wfo_push_audio collected (cfg.normalize_volume): what WAVSource::tick does first,
+ * src/source.cpp:1330-1331; overwrites the value of wfo_set_input_rms */
+void wfo_update_input_rms(wfo_source *s);
+float wfo_input_rms(const wfo_source *s);
 void wfo_tick(wfo_source *s, float seconds);
 void wfo_render_bars(wfo_source *s);
 

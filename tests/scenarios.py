@@ -92,6 +92,21 @@ SCENARIOS = {
     # muted packets are pushed as zeros (src/source.cpp:1879-1880)
     "muted_packets": dict(cfg=dict(fft_size=1024, stereo=1, tsmoothing=0), steps=_steps(2) + [("mute", 800), ("tick",), ("noise", 800), ("tick",)],
                           record="all"),
+    # ---- volume normalisation with its producer (capture_audio's RMS part + update_input_rms, src/source.cpp:1842-1871,
+    # :810-835, src/source_generic.cpp:392-403): every backend derives m_input_rms from the audio itself; records add
+    #   rms  float32 scalar  m_input_rms after the tick
+    "normalize_4096_stereo": dict(cfg=dict(fft_size=4096, stereo=1, normalize_volume=1),
+                                  steps=[("noise_amp", 800, 0.05), ("tick",)] * 10, record=2),
+    # muted packets still feed the RMS (not the rings); ragged hops; mono mixdown; gain limited by max_gain at first
+    "normalize_mono_muted_ragged": dict(cfg=dict(fft_size=1024, stereo=0, normalize_volume=1, volume_target=-12.0, max_gain=20.0),
+                                        steps=[("noise_amp", 441, 0.02), ("tick",)] * 4 + [("mute_noise", 441), ("tick",)] * 3
+                                        + [("noise", 1024), ("tick",), ("noise", 3), ("tick",), ("tick",)], record="all"),
+    # more than one second of audio: the one-second RMS window slides (m_input_rms_buf wraps), loud then quiet.  Packets stay
+    # <= AUDIO_OUTPUT_FRAMES (1024) as OBS delivers them: capture_audio's RMS loop re-reads the start of a longer packet
+    # for its second chunk (src/source.cpp:1848-1861 never advances `data`), which no OBS packet can trigger.
+    "normalize_long_1024": dict(cfg=dict(fft_size=1024, stereo=1, normalize_volume=1, tsmoothing=0),
+                                steps=[("noise", 1000), ("noise", 600), ("tick",)] * 25
+                                + [("noise_amp", 1000, 0.1), ("noise_amp", 600, 0.1), ("tick",)] * 20, record=2),
     # ---- level meter (tick_meter, src/source_generic.cpp:182-269) -------------------------------------------------------
     # defaults: RMS over 150 ms (7200 samples), EMA g = 0.65, two captured channels; m_meter_buf starts at DB_MIN (quirk)
     "meter_rms_stereo": dict(cfg=dict(meter=1), steps=_steps(30), record="all"),
@@ -140,6 +155,7 @@ class _Feeder:
             a[1] = 0.0
         elif kind == "noise_amp":
             a *= np.float32(amp)
+        # "mute_noise": a muted packet that carries samples
         return a[: self.channels]
 
 
@@ -155,7 +171,7 @@ def play(backend, scenario: dict):
             backend.push(feeder.block(op, step[1], step[2]), muted=False)
         elif op == "timeout":
             backend.timeout()  # no packet for more than CAPTURE_TIMEOUT (500 ms); the next packet ends it
-        elif op == "mute":
+        elif op in ("mute", "mute_noise"):
             backend.push(feeder.block(op, step[1]), muted=True)
         elif op == "tick":
             seconds = step[1] if len(step) > 1 else 1.0 / 60.0
@@ -223,19 +239,26 @@ class RefBackend:
         if self.cfg.bars or self.cfg.curve:
             self.src.render()
             bars = np.stack([self.src.bars(c) for c in range(self.disp)])
-        return dict(db=db, bars=bars, silent=self.src.last_silent)
+        rec = dict(db=db, bars=bars, silent=self.src.last_silent)
+        if self.cfg.normalize_volume:
+            rec["rms"] = np.float32(self.src.input_rms)
+        return rec
 
 
 class OracleBackend:
-    def __init__(self, cfg, input_rms=0.0):
+    """input_rms=None: m_input_rms comes from the restated producer (update_input_rms before every tick, as
+    WAVSource::tick does); a number: the host's value, fixed"""
+
+    def __init__(self, cfg, input_rms=None):
         from oracle import restate
         self.cfg = cfg
         self.hidden = False
+        self.auto_rms = bool(cfg.normalize_volume) and input_rms is None
         if cfg.meter:
             self.src = restate.OracleMeter(cfg)
         else:
             self.src = restate.OracleSource(cfg)
-            self.src.set_input_rms(input_rms)
+            self.src.set_input_rms(input_rms or 0.0)
         self.capture_channels = self.src.capture_channels
 
     def _state(self, timed_out=False):
@@ -250,6 +273,8 @@ class OracleBackend:
         self.src.push_audio(audio, muted=muted)
 
     def tick(self, seconds):
+        if self.auto_rms:
+            self.rms = self.src.update_input_rms()
         self.src.tick(seconds)
 
     def timeout(self):
@@ -266,18 +291,25 @@ class OracleBackend:
         if self.cfg.bars or self.cfg.curve:
             self.src.render_bars()
             bars = self.src.bars()
-        return dict(db=self.src.decibels(), bars=bars, silent=self.src.last_silent)
+        rec = dict(db=self.src.decibels(), bars=bars, silent=self.src.last_silent)
+        if self.auto_rms:
+            rec["rms"] = np.float32(self.rms)
+        return rec
 
 
 class HipBackend:
     """`streams` identical copies of the scenario run in one batch (they must all agree);
-    observe() returns stream `probe`."""
+    observe() returns stream `probe`.  input_rms=None: the device producer (wf_hip_enable_input_rms) for
+    normalize_volume configurations; a number: the host's m_input_rms, fixed."""
 
-    def __init__(self, cfg, streams=3, probe=1, input_rms=0.0):
+    def __init__(self, cfg, streams=3, probe=1, input_rms=None):
         import waveform_amd as wf
         self.cfg = cfg
-        self.input_rms = input_rms  # m_input_rms (the host's update_input_rms), for normalize_volume configurations
+        self.auto_rms = bool(cfg.normalize_volume) and not cfg.meter and input_rms is None
+        self.input_rms = input_rms or 0.0  # m_input_rms (the host's update_input_rms), for normalize_volume configurations
         self.batch = wf.SpectrumBatch(cfg, streams)
+        if self.auto_rms:
+            self.batch.enable_input_rms()
         self.capture_channels = self.batch.capture_channels
         self.streams = streams
         self.probe = probe
@@ -295,7 +327,9 @@ class HipBackend:
         if getattr(self, "timed_out", False):
             self.timed_out = False
             self._state()  # a packet ends a capture timeout
-        if muted:
+        if muted and self.auto_rms:
+            self.batch.push_audio_muted(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
+        elif muted:
             self.batch.push_silence(audio.shape[1])
         else:
             self.batch.push_audio(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
@@ -317,7 +351,10 @@ class HipBackend:
         silent = self.batch.last_silent()
         # every copy of the scenario must produce the same bits
         assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"
-        return dict(db=db[self.probe][: self.disp], bars=None if bars is None else bars[self.probe], silent=bool(silent[self.probe]))
+        rec = dict(db=db[self.probe][: self.disp], bars=None if bars is None else bars[self.probe], silent=bool(silent[self.probe]))
+        if self.auto_rms:
+            rec["rms"] = self.batch.input_rms()[self.probe]
+        return rec
 
     def close(self):
         self.batch.close()

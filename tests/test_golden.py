@@ -38,6 +38,10 @@ def _check(name, backend):
     assert len(recs) == meta["n_ticks"]
     silent = np.array([r["silent"] for r in recs], np.uint8)
     assert np.array_equal(silent, z["silent"]), f"{name}: m_last_silent sequence {silent} != reference {z['silent']}"
+    if "rms" in z.files:
+        # m_input_rms: the reference adds its 48000 squares one by one in float; 1e-5 relative is the north star's tolerance
+        got = np.array([r["rms"] for r in recs], np.float64)
+        assert np.all(np.abs(got - z["rms"]) <= 1e-5 * np.abs(z["rms"]) + 1e-9), f"{name}: m_input_rms {got} vs reference {z['rms']}"
     for t, r in scenarios.recorded(recs, sc["record"]):
         assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels")
         if f"bars_{t}" in z.files:

@@ -40,6 +40,8 @@ def main():
         recs = scenarios.play(be, sc)
         arrays = {}
         silent = np.array([r["silent"] for r in recs], np.uint8)
+        if recs and "rms" in recs[0]:
+            arrays["rms"] = np.array([r["rms"] for r in recs], np.float32)  # m_input_rms after every tick
         for t, r in scenarios.recorded(recs, sc["record"]):
             arrays[f"db_{t}"] = r["db"].astype(np.float32)
             if r["bars"] is not None:

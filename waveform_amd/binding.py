@@ -88,6 +88,9 @@ def lib():
     L.wf_hip_push_audio_device.argtypes = [vp, u32, u32, vp, u32]
     L.wf_hip_push_synth.argtypes = [vp, u32, u32, u64, u32, u64, u32]
     L.wf_hip_push_silence.argtypes = [vp, u32, u32, u32]
+    L.wf_hip_push_audio_muted.argtypes = [vp, u32, u32, fp, u32]
+    L.wf_hip_enable_input_rms.argtypes = [vp]
+    L.wf_hip_read_input_rms.argtypes = [vp, u32, u32, fp]
     L.wf_hip_tick.argtypes = [vp, C.POINTER(TickParams)]
     L.wf_hip_set_hidden.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
     L.wf_hip_set_input_rms.argtypes = [vp, u32, u32, fp]
@@ -188,6 +191,22 @@ class SpectrumBatch:
         s = np.ascontiguousarray(samples, dtype=np.float32)
         assert s.ndim == 3 and s.shape[1] == self.capture_channels, s.shape
         self._ck(self.L.wf_hip_push_audio(self.h, first, s.shape[0], s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[2]))
+
+    def push_audio_muted(self, samples: np.ndarray, first: int = 0):
+        """muted packet: zeros into the rings, `samples` into the device RMS producer"""
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        assert s.ndim == 3 and s.shape[1] == self.capture_channels, s.shape
+        self._ck(self.L.wf_hip_push_audio_muted(self.h, first, s.shape[0], s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[2]))
+
+    def enable_input_rms(self):
+        """update_input_rms on the device from now on (cfg.normalize_volume)"""
+        self._ck(self.L.wf_hip_enable_input_rms(self.h))
+
+    def input_rms(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty(count, np.float32)
+        self._ck(self.L.wf_hip_read_input_rms(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def push_audio_device(self, dev_ptr: int, count: int, frames: int, first: int = 0):
         self._ck(self.L.wf_hip_push_audio_device(self.h, first, count, C.c_void_p(dev_ptr), frames))

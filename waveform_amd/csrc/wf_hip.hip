@@ -14,6 +14,7 @@
 #include "wf_host_tables.hpp"
 #include "wf_kernels.hpp"
 #include "wf_meter.hpp"
+#include "wf_rms.hpp"
 
 namespace {
 
@@ -50,6 +51,12 @@ struct wf_hip {
     uint32_t max_stream_delay = 0;   // largest value ever set (ring-capacity check of the tick)
     bool stream_delays_aligned = true; // all of them multiples of 4 frames (vector fetch without straddling)
     float *d_vol_comp = nullptr;     // [n_streams] volume compensation per stream (wf_hip_set_input_rms), or nullptr
+    // volume-normalisation producer on the device (wf_hip_enable_input_rms): update_input_rms per stream and tick
+    float *d_rms_ring = nullptr;     // [n_streams][rms_cap] squared peaks (capture_audio's m_rms_sync_buf)
+    float *d_rms_bsum = nullptr;     // [n_streams][rms_cap / RMS_BLOCK]
+    uint32_t *d_rend = nullptr;      // [n_streams] consumption point of sync_rms_buffer
+    float *d_input_rms = nullptr;    // [n_streams] m_input_rms
+    uint32_t rms_cap = 0, rms_size = 0;
     // level-meter batches (cfg.meter): N is the meter buffer length, there is no FFT state
     bool meter = false;
     uint32_t *d_mend = nullptr;      // [n_streams] consumption point of tick_meter
@@ -287,7 +294,16 @@ int ensure_stage(wf_hip *h, size_t floats)
     return WF_HIP_OK;
 }
 
-int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, uint32_t frames)
+// the RMS ring follows every push (before wpos advances): squared peaks, then the sums of the blocks the push completed
+void rms_after_push(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
+{
+    hipLaunchKernelGGL(wf::rms_block_kernel, dim3(frames / wf::RMS_BLOCK + 1, count), dim3(64), 0, h->stream, h->d_rms_ring,
+                       h->d_rms_bsum, h->d_wpos, h->rms_cap, first, frames);
+}
+
+// d_src feeds the audio rings (nullptr: zeros); d_rms_src feeds the squared-peak ring when the producer is enabled
+// (capture_audio takes the RMS from the packet even when it is muted, src/source.cpp:1842-1871 vs :1879-1880)
+int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, const float *d_rms_src, uint32_t frames)
 {
     if(frames == 0)
         return WF_HIP_OK;
@@ -296,6 +312,11 @@ int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, u
     const dim3 grid((frames + 255) / 256 > 64 ? 64 : (frames + 255) / 256, count * h->cap_ch), block(256);
     hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->cap_ch, first,
                        d_src, frames);
+    if(h->d_rms_ring) {
+        hipLaunchKernelGGL(wf::rms_push_kernel, dim3(grid.x, count), block, 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
+                           h->cap_ch, first, d_rms_src, frames);
+        rms_after_push(h, first, count, frames);
+    }
     hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
                        frames);
     WF_HIP_TRY(h, hipGetLastError());
@@ -574,6 +595,14 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
                            h->d_bars + (size_t)first * h->disp_ch * h->num_bars, nb, h->tab.border_bottom);
     }
     WF_HIP_TRY(h, hipGetLastError());
+    if(h->d_rms_ring) {
+        // update(): m_rms_sync_buf empty, m_input_rms_buf = 0, m_input_rms = 0 (src/source.cpp:1144-1152)
+        const size_t nblk = h->rms_cap / wf::RMS_BLOCK;
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_rms_ring + (size_t)first * h->rms_cap, 0, (size_t)count * h->rms_cap * sizeof(float), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_rms_bsum + (size_t)first * nblk, 0, (size_t)count * nblk * sizeof(float), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_rend + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_input_rms + first, 0, (size_t)count * sizeof(float), h->stream));
+    }
     if(first == 0 && count == h->n_streams)
         h->all_aligned = true; // every write position is back at fft_size
     return WF_HIP_OK;
@@ -587,7 +616,7 @@ uint32_t wf_hip_display_channels(const wf_hip *h) { return h ? h->disp_ch : 0; }
 uint32_t wf_hip_num_bars(const wf_hip *h) { return h ? h->num_bars : 0; }
 uint32_t wf_hip_ring_frames(const wf_hip *h) { return h ? h->ring_cap : 0; }
 
-int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames)
+static int push_host(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames, bool muted)
 {
     int rc = check_range(h, first, count);
     if(rc)
@@ -601,13 +630,23 @@ int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *sa
     if(rc)
         return rc;
     WF_HIP_TRY(h, hipMemcpyAsync(h->d_stage, samples, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    rc = push_common(h, first, count, h->d_stage, frames);
+    rc = push_common(h, first, count, muted ? nullptr : h->d_stage, h->d_stage, frames);
     if(rc)
         return rc;
     // `samples` is borrowed only for the duration of the call (pageable memory: the copy has been staged by the
     // runtime when hipMemcpyAsync returns; pinned memory: wait for it)
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
     return WF_HIP_OK;
+}
+
+int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames)
+{
+    return push_host(h, first, count, samples, frames, false);
+}
+
+int wf_hip_push_audio_muted(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames)
+{
+    return push_host(h, first, count, samples, frames, true);
 }
 
 int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const float *d_samples, uint32_t frames)
@@ -618,7 +657,7 @@ int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const fl
     if(d_samples == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "d_samples is NULL");
     WF_HIP_TRY(h, hipSetDevice(h->device));
-    return push_common(h, first, count, d_samples, frames);
+    return push_common(h, first, count, d_samples, d_samples, frames);
 }
 
 int wf_hip_push_silence(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
@@ -627,7 +666,7 @@ int wf_hip_push_silence(wf_hip *h, uint32_t first, uint32_t count, uint32_t fram
     if(rc)
         return rc;
     WF_HIP_TRY(h, hipSetDevice(h->device));
-    return push_common(h, first, count, nullptr, frames);
+    return push_common(h, first, count, nullptr, nullptr, frames);
 }
 
 int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, uint32_t stream_id0, uint64_t index0,
@@ -644,6 +683,11 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
     const uint32_t gx = std::min<uint32_t>((frames + 255) / 256, 256);
     hipLaunchKernelGGL(wf::ring_synth_kernel, dim3(gx, count * h->cap_ch), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,
                        h->ring_cap, h->cap_ch, first, seed, stream_id0, index0, frames);
+    if(h->d_rms_ring) {
+        hipLaunchKernelGGL(wf::rms_synth_kernel, dim3(gx, count), dim3(256), 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
+                           h->cap_ch, first, seed, stream_id0, index0, frames);
+        rms_after_push(h, first, count, frames);
+    }
     hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
                        frames);
     WF_HIP_TRY(h, hipGetLastError());
@@ -667,6 +711,26 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         hipLaunchKernelGGL(wf::meter_tick_kernel, dim3(h->n_streams), dim3(wf::METER_THREADS), 0, h->stream, m);
         WF_HIP_TRY(h, hipGetLastError());
         return WF_HIP_OK;
+    }
+    if(h->d_rms_ring) {
+        // update_input_rms of every stream (what WAVSource::tick does first, src/source.cpp:1330-1331); leaves the
+        // per-stream volume compensation where the spectrum kernel reads it
+        wf::RmsArgs r{};
+        r.rms_ring = h->d_rms_ring;
+        r.bsum = h->d_rms_bsum;
+        r.wpos = h->d_wpos;
+        r.rend = h->d_rend;
+        r.rms_cap = h->rms_cap;
+        r.size = h->rms_size;
+        r.delay = p->delay_frames;
+        r.delay_stream = h->d_delay;
+        r.input_rms = h->d_input_rms;
+        r.vol_comp = h->d_vol_comp;
+        r.volume_target = h->cfg.volume_target;
+        r.max_gain = h->cfg.max_gain;
+        r.db_min = wf::db_min();
+        r.n_streams = h->n_streams;
+        hipLaunchKernelGGL(wf::input_rms_kernel, dim3(h->n_streams), dim3(64), 0, h->stream, r);
     }
     const wf::TickArgs a = make_args(h, p);
     const bool aligned = h->all_aligned && h->stream_delays_aligned && (p->delay_frames % 4u) == 0;
@@ -733,6 +797,8 @@ int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float 
         return rc;
     if(rms == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "rms is NULL");
+    if(h->d_rms_ring)
+        return fail(h, WF_HIP_ERR_INVALID, "m_input_rms is produced on the device (wf_hip_enable_input_rms); it cannot be set");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     // volume_compensation of every stream, reference src/source_generic.cpp:163 with dbfs() of src/source.hpp:293-299
     auto comp = [&](float r) {
@@ -753,6 +819,52 @@ int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float 
     WF_HIP_TRY(h, hipMemcpyAsync(h->d_vol_comp + first, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // the staging vector dies here
     return WF_HIP_OK;
+}
+
+static int read_back(wf_hip *h, const void *d, void *out, size_t bytes);
+
+int wf_hip_enable_input_rms(wf_hip *h)
+{
+    if(h == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if(!h->cfg.normalize_volume || h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_enable_input_rms needs a spectrum batch with cfg.normalize_volume");
+    if(h->d_rms_ring)
+        return WF_HIP_OK;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    h->rms_size = h->cfg.sample_rate & ~15u; // m_input_rms_size, src/source.cpp:1147
+    if(h->rms_size == 0)
+        return fail(h, WF_HIP_ERR_INVALID, "sample_rate %u is too small for the RMS window", h->cfg.sample_rate);
+    // the window + every A/V-sync delay the audio rings admit + the two ragged blocks at its ends
+    h->rms_cap = next_pow2(h->rms_size + (h->ring_cap - h->N) + 2 * wf::RMS_BLOCK);
+    const size_t nblk = h->rms_cap / wf::RMS_BLOCK;
+    float *ring = nullptr, *bsum = nullptr;
+    int rc = dev_alloc(h, &ring, (size_t)h->n_streams * h->rms_cap);
+    if(rc == WF_HIP_OK) rc = dev_alloc(h, &bsum, (size_t)h->n_streams * nblk);
+    if(rc == WF_HIP_OK) rc = dev_alloc(h, &h->d_rend, (size_t)h->n_streams);
+    if(rc == WF_HIP_OK) rc = dev_alloc(h, &h->d_input_rms, (size_t)h->n_streams);
+    if(rc == WF_HIP_OK && h->d_vol_comp == nullptr) rc = dev_alloc(h, &h->d_vol_comp, (size_t)h->n_streams);
+    if(rc)
+        return rc;
+    // audio captured before this call counts as silence (m_input_rms_buf starts as zeros); the first tick's kernel
+    // fills d_vol_comp before the spectrum kernel reads it
+    WF_HIP_TRY(h, hipMemsetAsync(ring, 0, (size_t)h->n_streams * h->rms_cap * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(bsum, 0, (size_t)h->n_streams * nblk * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_rend, 0, (size_t)h->n_streams * sizeof(uint32_t), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_input_rms, 0, (size_t)h->n_streams * sizeof(float), h->stream));
+    h->d_rms_bsum = bsum;
+    h->d_rms_ring = ring; // from here on every push feeds it
+    return WF_HIP_OK;
+}
+
+int wf_hip_read_input_rms(wf_hip *h, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_input_rms == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "the device RMS producer is not enabled (wf_hip_enable_input_rms)");
+    return read_back(h, h->d_input_rms + first, out, (size_t)count * sizeof(float));
 }
 
 int wf_hip_sync(wf_hip *h)
