@@ -25,6 +25,7 @@ struct HipApi {
     decltype(&wf_hip_set_hidden) set_hidden = nullptr;
     decltype(&wf_hip_read_decibels) read_decibels = nullptr;
     decltype(&wf_hip_read_last_silent) read_last_silent = nullptr;
+    decltype(&wf_hip_read_meter) read_meter = nullptr;
     decltype(&wf_hip_last_error) last_error = nullptr;
     bool ok = false;
 };
@@ -50,6 +51,7 @@ HipApi &api()
         WF_SYM(set_hidden)
         WF_SYM(read_decibels)
         WF_SYM(read_last_silent)
+        WF_SYM(read_meter)
         WF_SYM(last_error)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
@@ -87,9 +89,12 @@ void WAVSourceHIP::hip_release()
 bool WAVSourceHIP::hip_configure()
 {
     hip_release();
-    if(!available() || m_meter_mode || (m_display_mode == DisplayMode::WAVEFORM) || (m_capture_channels == 0))
+    if(!available() || (m_display_mode == DisplayMode::WAVEFORM) || (m_capture_channels == 0))
         return false;
     wf_config c{};
+    c.meter = m_meter_mode ? 1u : 0u;   // update() has already applied the mode's overrides to the members below
+    c.meter_rms = m_meter_rms ? 1u : 0u;
+    c.meter_ms = m_meter_ms;
     c.fft_size = (uint32_t)m_fft_size;
     c.sample_rate = m_audio_info.samples_per_sec;
     c.capture_channels = m_capture_channels;
@@ -130,6 +135,7 @@ bool WAVSourceHIP::hip_configure()
     m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
     m_hip_out.assign((size_t)m_output_channels * (m_fft_size / 2), 0.0f);
     m_hip_hidden = false;
+    m_hip_state = WF_HIP_SHOWN;
     return true;
 }
 
@@ -195,5 +201,59 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     }
     for(auto channel = 0u; channel < m_output_channels; ++channel)
         std::memcpy(m_decibels[channel].get(), m_hip_out.data() + (size_t)channel * outsz, outsz * sizeof(float));
+    m_last_silent = silent != 0;
+}
+
+// Same observable behaviour as WAVSourceGeneric::tick_meter (src/source_generic.cpp:182-269): the audio that tick_meter
+// would pop into its meter buffer this tick (everything older than the A/V-sync point, :201-220) goes to the device ring
+// instead; the device takes the level over the last m_fft_size consumed samples, smooths it, converts to dBFS and
+// decides m_last_silent; m_meter_val / m_last_silent come back for render_bars (src/source.cpp:1505-1509).
+void WAVSourceHIP::tick_meter(float seconds)
+{
+    if(m_hip == nullptr) {
+        WAVSourceGeneric::tick_meter(seconds);
+        return;
+    }
+    auto &a = api();
+    const auto dtcapture = m_tick_ts - m_capture_ts;
+    const bool timed_out = dtcapture > CAPTURE_TIMEOUT; // :184
+    const int state = timed_out ? WF_HIP_HIDDEN_TIMEOUT : (m_show ? WF_HIP_SHOWN : WF_HIP_HIDDEN);
+    bool ok = true;
+    if(state != m_hip_state) {
+        const uint8_t mask = (uint8_t)state;
+        ok = a.set_hidden(m_hip, 0, 1, &mask) == WF_HIP_OK;
+        m_hip_state = state;
+    }
+    if(ok && !timed_out) {
+        // :201-220: everything beyond dtsize bytes is consumed -- here: moved to the device ring, oldest first
+        const int64_t dtaudio = get_audio_sync(m_tick_ts);
+        const size_t dtsize = (dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) * sizeof(float) : 0;
+        size_t frames = 0;
+        for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+            const auto sz = m_capturebufs[channel].size();
+            const size_t n = (sz > dtsize) ? (sz - dtsize) / sizeof(float) : 0;
+            frames = (channel == 0) ? n : std::min(frames, n); // the channels of a source are pushed together by capture_audio
+        }
+        if(frames > 0) {
+            m_hip_window.resize((size_t)m_capture_channels * frames);
+            for(auto channel = 0u; channel < m_capture_channels; ++channel)
+                m_capturebufs[channel].pop_front(m_hip_window.data() + (size_t)channel * frames, frames * sizeof(float));
+            // capture_audio keeps at most dtsamples + m_fft_size samples, so this is never more than the ring holds
+            ok = a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)frames) == WF_HIP_OK;
+        }
+    }
+    wf_hip_tick_params p{};
+    p.seconds = seconds;
+    float levels[2] = {DB_MIN, DB_MIN};
+    uint8_t silent = 0;
+    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read_meter(m_hip, 0, 1, levels) != WF_HIP_OK ||
+       a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
+        LogWarn << "HIP meter tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
+        hip_release();
+        WAVSourceGeneric::tick_meter(seconds);
+        return;
+    }
+    for(auto channel = 0u; channel < m_capture_channels; ++channel)
+        m_meter_val[channel] = levels[channel];
     m_last_silent = silent != 0;
 }
