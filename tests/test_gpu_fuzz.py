@@ -138,3 +138,72 @@ def test_per_stream_av_sync_delay():
             ora.push(audio[:, : total - di - common], muted=False)  # the oracle sees the audio up to the window's end
             ora.tick(1.0 / 60.0)
             assert_db_close(got[i], ora.observe()["db"], f"delays {delays}: stream {i}")
+
+
+# ---- level meter --------------------------------------------------------------------------------------------------------
+METER_CASES = list(range(16))
+
+
+def draw_meter(seed: int):
+    r = np.random.default_rng(5000 + seed)
+    cfg = dict(meter=1, meter_rms=int(r.integers(0, 2)), meter_ms=int(r.choice([20, 50, 100, 150, 333, 500])),
+               capture_channels=int(r.integers(1, 3)), tsmoothing=int(r.integers(0, 3)),
+               gravity=float(np.float32(r.uniform(0.05, 0.95))), fast_peaks=int(r.integers(0, 2)),
+               floor_db=int(r.choice([-65, -80, -50])), ceiling_db=int(r.choice([0, -6])), height=int(r.choice([225, 300, 101])),
+               rounded_caps=int(r.random() < 0.3), min_bar_height=int(r.choice([0, 3])), bar_width=int(r.choice([24, 12])))
+    steps = []
+    for _ in range(int(r.integers(18, 30))):  # long enough for the EMA to climb out of its DB_MIN start
+        steps += [("noise_amp", int(r.choice([800, 441, 1024, 37, 1600])), float(np.float32(r.choice([1.0, 0.3, 0.01])))),
+                  ("tick", float(np.float32(r.choice([1 / 60, 1 / 30, 1 / 144]))))]
+    kind = int(r.integers(0, 4))
+    if kind == 0:
+        steps += [("silence", 800), ("tick",)] * 14 + [("noise", 800), ("tick",)] * 3
+    elif kind == 1:
+        steps += [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",), ("noise", 800), ("tick",), ("noise", 800), ("tick",)]
+    elif kind == 2:
+        steps += [("timeout",), ("tick",), ("tick",), ("noise", 800), ("tick",), ("noise", 800), ("tick",)]
+    elif cfg["capture_channels"] == 2:
+        steps += [("noise_ch0_only", 800), ("tick",)] * 10
+    return cfg, steps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", METER_CASES)
+def test_hip_meter_matches_oracle_on_random_case(seed):
+    cfg_dict, steps = draw_meter(seed)
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all")
+    hip = scenarios.HipBackend(cfg, streams=3, probe=2)
+    ora = scenarios.OracleBackend(cfg)
+    try:
+        got = scenarios.play(hip, sc)
+        want = scenarios.play(ora, sc)
+    finally:
+        hip.close()
+    assert len(got) == len(want)
+    for t, (g, w) in enumerate(zip(got, want)):
+        assert g["silent"] == w["silent"], f"meter case {seed} tick {t}: m_last_silent {g['silent']} != {w['silent']} ({cfg_dict})"
+        assert_db_close(g["db"], w["db"], f"meter case {seed} tick {t} levels ({cfg_dict})")
+        err = np.abs(g["bars"].astype(np.float64) - w["bars"])
+        assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"meter case {seed} tick {t} bars: max err {err.max():.3e} px ({cfg_dict})"
+
+
+@pytest.mark.gpu
+def test_meter_sync_delay_never_unconsumes():
+    """tick_meter pops everything older than the A/V-sync point; a later tick with a larger delay leaves the meter buffer
+    as it was (src/source_generic.cpp:204-220: the while loop simply does not run)."""
+    import waveform_amd as wf
+    from oracle import restate
+    from tools import synth
+    cfg = wf.Config.defaults(meter=1, meter_ms=50, tsmoothing=0)
+    ora = restate.OracleMeter(cfg)
+    delays = [0, 400, 1300, 100, 0, 2000, 5, 0]
+    with wf.SpectrumBatch(cfg, 2, ring_frames=16384) as b:
+        for t, d in enumerate(delays):
+            audio = synth.block(synth.DEFAULT_SEED, 0, 1, 2, t * 800, 800)
+            b.push_audio(np.broadcast_to(audio, (2, 2, 800)))
+            ora.set_sync_delay(d)
+            ora.push_audio(audio[0])
+            b.tick(delay_frames=d)
+            ora.tick()
+            assert_db_close(b.meter()[1], ora.levels(), f"tick {t} delay {d}")
