@@ -1,6 +1,6 @@
 """device timing of the level-meter tick (development aid).  usage: python tools/meter_bench.py [streams[:meter_ms[:rms]] ...]"""
 import sys, json
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import waveform_amd as wf
 from tools import synth
 

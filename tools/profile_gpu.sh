@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline $EXTRA"
+CMD=${WF_PROFILE_CMD:-"python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline $EXTRA"}   # WF_PROFILE_CMD: profile another driver (e.g. tools/meter_bench.py)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \

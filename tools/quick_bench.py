@@ -1,7 +1,7 @@
 """quick device timing of the fused tick kernel (development aid; bench.py is the contract).
 usage: python tools/quick_bench.py [N:streams ...]   (env WF_HIP_LIB selects a library build)"""
 import sys, json, os
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import waveform_amd as wf
 from tools import synth
 

@@ -9,7 +9,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def main(tag, name, streams=4096, fft=4096):
+def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None, kernel=None):
     src = ROOT / "gpurun_out" / "prof" / tag
     dst = ROOT / "profiles"
     dst.mkdir(exist_ok=True)
@@ -18,7 +18,7 @@ def main(tag, name, streams=4096, fft=4096):
     for f in sorted(glob.glob(str(src / "pmc_*" / "pmc_counter_collection.csv"))):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "spectrum_tick" in r["Kernel_Name"]:
+            if match in r["Kernel_Name"]:
                 kname = r["Kernel_Name"]
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 res = {k: r[k] for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
@@ -26,15 +26,15 @@ def main(tag, name, streams=4096, fft=4096):
             tot[k] = sum(v) / len(v)
     stats = {}
     for r in csv.DictReader(open(src / "stats" / "stats_kernel_stats.csv")):
-        if "spectrum_tick" in r["Name"]:
+        if match in r["Name"]:
             stats = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
     fetch_b = tot.get("FETCH_SIZE", 0) * 1024 * 2
     write_b = tot.get("WRITE_SIZE", 0) * 1024
     cyc = tot.get("GRBM_GUI_ACTIVE", 0) / 8
     out = {
-        "tag": tag, "command": "python bench.py --steps 30 --warmup 3 --no-cpu-baseline (tools/profile_gpu.sh)",
+        "tag": tag, "command": command or "python bench.py --steps 30 --warmup 3 --no-cpu-baseline (tools/profile_gpu.sh)",
         "kernel_rocprof_name": kname, "streams": streams, "fft_size": fft,
-        "kernel": f"spectrum_tick_kernel<N={fft},T=128,R=8x16x16,SPW=2>" if fft == 4096 else None,
+        "kernel": kernel or (f"spectrum_tick_kernel<N={fft},T=128,R=8x16x16,SPW=2>" if fft == 4096 else None),
         "kernel_stats": stats, "dispatch": res,
         "hbm_bytes_per_launch": fetch_b + write_b,
         "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
@@ -54,4 +54,8 @@ def main(tag, name, streams=4096, fft=4096):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    # usage: summarize_profile.py TAG NAME [kernel-name-substring [streams [fft [command]]]]
+    a = sys.argv
+    main(a[1], a[2], streams=int(a[4]) if len(a) > 4 else 4096, fft=int(a[5]) if len(a) > 5 else 4096,
+         match=a[3] if len(a) > 3 else "spectrum_tick", command=a[6] if len(a) > 6 else None,
+         kernel=a[3] if len(a) > 3 and a[3] != "spectrum_tick" else None)
