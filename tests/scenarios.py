@@ -92,6 +92,17 @@ SCENARIOS = {
     # muted packets are pushed as zeros (src/source.cpp:1879-1880)
     "muted_packets": dict(cfg=dict(fft_size=1024, stereo=1, tsmoothing=0), steps=_steps(2) + [("mute", 800), ("tick",), ("noise", 800), ("tick",)],
                           record="all"),
+    # ---- the largest geometry runs the channels of a stereo stream in different workgroups (split mode): everything that
+    # couples the channels, at N = 16384
+    "split_16384_silence_cycle": dict(cfg=dict(fft_size=16384, stereo=1, gravity=0.2),
+                                      steps=_steps(2) + [("silence", 17000), ("tick",)] + [("silence", 800), ("tick",)] * 14 + _steps(2), record=2),
+    "split_16384_half_silent": dict(cfg=dict(fft_size=16384, stereo=1, gravity=0.2, bars=1, interp_mode=1),
+                                    steps=_steps(2) + [("noise_ch0_only", 17000), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 12
+                                    + [("silence", 17000), ("tick",)] + [("silence", 800), ("tick",)] * 13 + [("noise_ch1_only", 800), ("tick",)] * 2,
+                                    record=3),
+    "split_16384_hide_timeout": dict(cfg=dict(fft_size=16384, stereo=1, slope=1.0),
+                                     steps=_steps(2) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(2)
+                                     + [("timeout",), ("tick",), ("tick",)] + _steps(2), record=2),
     # ---- volume normalisation with its producer (capture_audio's RMS part + update_input_rms, src/source.cpp:1842-1871,
     # :810-835, src/source_generic.cpp:392-403): every backend derives m_input_rms from the audio itself; records add
     #   rms  float32 scalar  m_input_rms after the tick
@@ -153,6 +164,8 @@ class _Feeder:
             a[:] = 0.0
         elif kind == "noise_ch0_only":
             a[1] = 0.0
+        elif kind == "noise_ch1_only":
+            a[0] = 0.0
         elif kind == "noise_amp":
             a *= np.float32(amp)
         # "mute_noise": a muted packet that carries samples
@@ -165,7 +178,7 @@ def play(backend, scenario: dict):
     records = []
     for step in scenario["steps"]:
         op = step[0]
-        if op in ("noise", "silence", "noise_ch0_only"):
+        if op in ("noise", "silence", "noise_ch0_only", "noise_ch1_only"):
             backend.push(feeder.block(op, step[1]), muted=False)
         elif op == "noise_amp":
             backend.push(feeder.block(op, step[1], step[2]), muted=False)

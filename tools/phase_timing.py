@@ -1,7 +1,7 @@
 """development aid: per-phase s_memtime stamps of the tick kernel (needs the -DWF_PHASE_TIMING build)."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("WF_HIP_LIB", os.path.abspath("build/variants/lib_timing.so"))
 import waveform_amd as wf
 from tools import synth

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -39,7 +40,10 @@ struct wf_hip {
     uint32_t *d_wpos = nullptr;
     float *d_tsmooth = nullptr;
     float *d_decibels = nullptr;
-    uint32_t *d_flags = nullptr;
+    uint32_t *d_flags = nullptr;     // [flag_bufs][n_streams]; the buffer flag_cur holds the current m_last_silent / hidden bits
+    uint32_t *d_verdict = nullptr;   // split mode: [3][n_streams * cap_ch] "row has a value > floor - 10" (TickArgs::verdict_*)
+    uint32_t flag_bufs = 1, flag_cur = 0;
+    bool split = false;              // the channels of a stream run in different workgroups (spectrum_tick_kernel<.., SPLIT>)
     float *d_bars = nullptr;
     float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
@@ -127,6 +131,32 @@ template<class T> int upload(wf_hip *h, T **out, const std::vector<T> &v)
     return WF_HIP_OK;
 }
 
+template<class G> void launch_tick_split(wf_hip *h, const wf::TickArgs &a, bool aligned)
+{
+    const dim3 grid(a.n_streams * a.cap_ch), block(G::T);
+    const size_t lds = wf::tick_lds_bytes<G, 1>();
+    if(aligned)
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, true, true>), grid, block, lds, h->stream, a);
+    else
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, false, true>), grid, block, lds, h->stream, a);
+}
+
+template<class G> int setup_launch_split(wf_hip *h)
+{
+    const int lds = (int)wf::tick_lds_bytes<G, 1>();
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 1, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 1, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick_split<G>;
+    h->split = true;
+    h->flag_bufs = 3;
+    char name[96];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=1,split>", G::N, G::T, G::R1, G::R2, G::R3);
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
 template<class G, int SPW> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     const uint32_t n_spec = a.n_streams * a.cap_ch;
@@ -177,7 +207,15 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     a.rolloff = h->d_rolloff;
     a.tsmooth = h->d_tsmooth;
     a.decibels = h->d_decibels;
-    a.stream_flags = h->d_flags;
+    a.stream_flags = h->d_flags + (size_t)h->flag_cur * h->n_streams;
+    if(h->split) {
+        const uint32_t nxt = (h->flag_cur + 1) % 3, clr = (h->flag_cur + 2) % 3;
+        const size_t n_spec = (size_t)h->n_streams * h->cap_ch;
+        a.flags_out = h->d_flags + (size_t)nxt * h->n_streams;
+        a.verdict_in = h->d_verdict + (size_t)h->flag_cur * n_spec;
+        a.verdict_out = h->d_verdict + (size_t)nxt * n_spec;
+        a.verdict_clear = h->d_verdict + (size_t)clr * n_spec;
+    }
     a.skip_decibels = (p->flags & WF_HIP_TICK_NO_DECIBELS) ? 1u : 0u;
     a.bar = wf::BarArgs{};
     if(h->d_bars) {
@@ -431,7 +469,17 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     }
     WF_CREATE_TRY(dev_alloc(h, &h->d_tsmooth, n_spec * h->M));
     WF_CREATE_TRY(dev_alloc(h, &h->d_decibels, (size_t)h->n_streams * h->out_ch * h->M));
-    WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->n_streams));
+    // Split mode: a stereo pair of the largest geometry in two workgroups (two per CU instead of one).  Measured on MI355X:
+    // N = 16384 45 -> 54 % of the HBM peak, N = 8192 no change (its pair already fits twice).  WF_HIP_SPLIT=0/1 overrides
+    // (development aid; mono mixdown and single-channel captures never split).
+    bool want_split = cfg->fft_size >= 16384;
+    if(const char *e = std::getenv("WF_HIP_SPLIT"))
+        want_split = (e[0] == '1') && cfg->fft_size >= 8192;
+    want_split = want_split && cfg->capture_channels == 2 && cfg->stereo;
+    h->flag_bufs = want_split ? 3 : 1;
+    WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->flag_bufs * h->n_streams));
+    if(want_split)
+        WF_CREATE_TRY(dev_alloc(h, &h->d_verdict, 3 * n_spec));
     if(h->num_bars)
         WF_CREATE_TRY(dev_alloc(h, &h->d_bars, (size_t)h->n_streams * h->disp_ch * h->num_bars));
 
@@ -517,7 +565,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
         // the channels of a stream share a workgroup (silence state machine, mono mixdown)
         if constexpr(G::T >= 256)
-            setup_rc = (cfg->capture_channels > 1) ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
+            setup_rc = want_split ? setup_launch_split<G>(h) : (cfg->capture_channels > 1) ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
         else
             setup_rc = setup_launch<G, 2>(h);
     });
@@ -582,7 +630,11 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
     // m_tsmooth_buf = 0, rings = zeros with N samples "written", m_decibels = DB_MIN, m_last_silent = false
     WF_HIP_TRY(h, hipMemsetAsync(h->d_tsmooth + spec0 * h->M, 0, nspec * h->M * sizeof(float), h->stream));
     WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_cap, 0, nspec * h->ring_cap * sizeof(float), h->stream));
-    WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+    for(uint32_t b = 0; b < h->flag_bufs; ++b)
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + (size_t)b * h->n_streams + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+    if(h->d_verdict) // rows of DB_MIN: nothing above floor - 10
+        for(uint32_t b = 0; b < 3; ++b)
+            WF_HIP_TRY(h, hipMemsetAsync(h->d_verdict + (size_t)b * h->n_streams * h->cap_ch + spec0, 0, nspec * sizeof(uint32_t), h->stream));
     const size_t ndb = (size_t)count * h->out_ch * h->M;
     hipLaunchKernelGGL(wf::fill_f32_kernel, dim3((unsigned)std::min<size_t>((ndb + 255) / 256, 4096)), dim3(256), 0, h->stream,
                        h->d_decibels + (size_t)first * h->out_ch * h->M, ndb, wf::db_min());
@@ -736,6 +788,8 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
     const bool aligned = h->all_aligned && h->stream_delays_aligned && (p->delay_frames % 4u) == 0;
     h->launch(h, a, aligned);
     WF_HIP_TRY(h, hipGetLastError());
+    if(h->split)
+        h->flag_cur = (h->flag_cur + 1) % 3; // what the kernel wrote is what the next tick (and the readers) see
     return WF_HIP_OK;
 }
 
@@ -754,8 +808,8 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
         h->mask_bytes = count;
     }
     WF_HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, count, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(wf::set_hidden_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_flags, first, count,
-                       h->d_mask);
+    hipLaunchKernelGGL(wf::set_hidden_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream,
+                       h->d_flags + (size_t)h->flag_cur * h->n_streams, first, count, h->d_mask);
     WF_HIP_TRY(h, hipGetLastError());
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `mask` is borrowed for the call only
     return WF_HIP_OK;
@@ -967,7 +1021,7 @@ int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *
     if(rc)
         return rc;
     std::vector<uint32_t> tmp(count);
-    rc = read_back(h, h->d_flags + first, tmp.data(), count * sizeof(uint32_t));
+    rc = read_back(h, h->d_flags + (size_t)h->flag_cur * h->n_streams + first, tmp.data(), count * sizeof(uint32_t));
     if(rc)
         return rc;
     for(uint32_t i = 0; i < count; ++i)

@@ -59,7 +59,7 @@ template<int BYTES> __device__ __forceinline__ void lds_dma_copy(const void *src
 // per-wavefront facts per wave.
 template<class G, int SPW> constexpr size_t tick_lds_bytes()
 {
-    return (size_t)SPW * G::LDS_CF * sizeof(cf) + (size_t)G::R2 * G::R3 * sizeof(cf) + (size_t)SPW * (G::T / 64) * sizeof(int) + 16;
+    return (size_t)SPW * G::LDS_CF * sizeof(cf) + (size_t)G::R2 * G::R3 * sizeof(cf) + 2 * (size_t)SPW * (G::T / 64) * sizeof(int) + 16;
 }
 
 // register budget: waves per SIMD the kernel is compiled for (launch_bounds' second argument) -- 3 only for the
@@ -91,9 +91,17 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #define WF_STAMP_HWID()
 #endif
 
-template<class G, int SPW, bool ALIGNED>
+// SPLIT (SPW == 1, two captured channels, stereo display): the channels of a stream run in different workgroups, so that
+// the largest geometry (139 KB of LDS for a stereo pair) fits two workgroups per CU and one loads while the other computes
+// (N = 16384: 45 -> 54 % of the HBM peak).  What couples the channels is the silence state machine; a channel whose window
+// has a non-zero sample needs nothing from its partner (plan_stream: it is processed and the stream is not silent), and the
+// rare all-zero channel gets the partner's facts without racing it: "has a non-zero sample" by scanning the partner's
+// window itself, "previous row entirely <= floor - 10" and m_last_silent from words the *previous* tick left (verdict_in,
+// stream_flags) while this tick writes the next tick's copies (verdict_out, flags_out).
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false>
 __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
+    static_assert(!SPLIT || SPW == 1, "split mode: one spectrum per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int T = G::T, M = G::M, P = G::P, WPS = G::T / 64;
     const int tid = (int)threadIdx.x;
@@ -115,6 +123,12 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool mono_mix = (a.mode & WF_MODE_MONO_MIX) != 0;
     const uint32_t wpos = a.wpos[stream];
     const uint32_t sflags = a.stream_flags[stream];
+    // split mode: the previous tick's verdicts on both rows of the stream, requested with the other per-stream words
+    uint32_t vin0 = 0, vin1 = 0;
+    if constexpr(SPLIT) {
+        vin0 = a.verdict_in[2u * stream];
+        vin1 = a.verdict_in[2u * stream + 1u];
+    }
 
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * G::LDS_CF;
     cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF;
@@ -150,7 +164,33 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     if(lane == 0)
         facts[wave_in_block] = (wave_nz ? 1 : 0) | (wave_below ? 2 : 0);
     __syncthreads(); // facts + the LDS twiddle table are visible to the whole workgroup
-    if(T > 64 || a.cap_ch > 1) {
+    if constexpr(SPLIT) {
+        int orf = 0;
+#pragma unroll
+        for(int w = 0; w < WPS; ++w)
+            orf |= facts[w];
+        const bool nz_own = (orf & 1) != 0;
+        bool nz_other = false;
+        if(!nz_own && !hidden) { // workgroup-uniform and rare: this channel's window is digital silence
+            const float *xo = a.ring + (size_t)(spec ^ 1u) * a.ring_cap;
+            uint32_t acc = 0;
+            for(uint32_t i = (uint32_t)tid; i < (uint32_t)G::N; i += (uint32_t)T)
+                acc |= f32_bits(xo[(start + i) & a.ring_mask]);
+            const bool w_nz = __any((acc & 0x7fffffffu) != 0) != 0;
+            if(lane == 0)
+                facts[WPS + wave_in_block] = w_nz ? 1 : 0;
+            __syncthreads();
+            int o2 = 0;
+#pragma unroll
+            for(int w = 0; w < WPS; ++w)
+                o2 |= facts[WPS + w];
+            nz_other = o2 != 0;
+        }
+        nz0 = ch == 0 ? nz_own : nz_other;
+        nz1 = ch == 0 ? nz_other : nz_own;
+        below0 = vin0 == 0u;
+        below1 = vin1 == 0u;
+    } else if(T > 64 || a.cap_ch > 1) {
         const int sb0 = (sub - (int)ch) * WPS; // first wavefront of the subgroup that owns channel 0 of this stream
         int or0 = 0, and0 = 3, or1 = 0, and1 = 3;
 #pragma unroll
@@ -270,7 +310,22 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     }
     WF_STAMP(10);
     if(active && ch == 0 && t == 0)
-        a.stream_flags[stream] = (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
+        (SPLIT ? a.flags_out : a.stream_flags)[stream] =
+            (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
+    if constexpr(SPLIT) {
+        // what the next tick's silence test will find in this channel's row (reference :78-86: any value > floor - 10?)
+        bool exceeds = false;
+        if(have_row) {
+#pragma unroll
+            for(int i = 0; i < P; ++i)
+                exceeds = exceeds || (d[i] > a.silent_floor);
+        } else if(!(hidden && !was_silent)) // row untouched this tick (the reset branch leaves DB_MIN everywhere: below)
+            exceeds = (ch == 0 ? vin0 : vin1) != 0u;
+        if(__any(exceeds) && lane == 0)
+            atomicOr(a.verdict_out + spec, 1u);
+        if(tid == 0)
+            a.verdict_clear[spec] = 0u;
+    }
 
     // ---- bars: what render_bars derives from the rows just written (reference src/source.cpp:1500-1557) ---------------
     if(a.bar.out != nullptr) {

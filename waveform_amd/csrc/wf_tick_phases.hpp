@@ -112,7 +112,13 @@ struct TickArgs {
     // per-spectrum state and outputs
     float *tsmooth;            // [n_streams * cap_ch][M]   m_tsmooth_buf
     float *decibels;           // [n_streams][out_ch][M]    m_decibels
-    uint32_t *stream_flags;    // [n_streams]
+    uint32_t *stream_flags;    // [n_streams] read at the start of the tick; written at its end unless flags_out is set
+    // split mode (the channels of a stereo stream in different workgroups, see spectrum_tick_kernel<.., SPLIT>): the words a
+    // workgroup writes must not be the ones its partner reads in the same tick, so they rotate through three buffers
+    uint32_t *flags_out;       // [n_streams] the flags the next tick reads
+    const uint32_t *verdict_in; // [n_streams * cap_ch] != 0: the row left by the previous tick has a value > floor - 10
+    uint32_t *verdict_out;     // the same for the rows as this tick leaves them (zero on entry; waves OR into it)
+    uint32_t *verdict_clear;   // the buffer the next tick ORs into
     // scalars
     float half_coef;           // 0.5f * (2.0f / m_window_sum)
     float g, g2;               // get_gravity(seconds), 1 - g
