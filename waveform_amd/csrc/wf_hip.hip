@@ -31,6 +31,7 @@ struct wf_hip {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t n_streams = 0;
     uint32_t ring_cap = 0;
+    uint32_t ring_stride = 0;        // floats between consecutive rings: ring_cap + padding (see wf_hip_create)
     uint32_t N = 0, M = 0;
     uint32_t cap_ch = 1, out_ch = 1, disp_ch = 1;
     uint32_t num_bars = 0;
@@ -196,6 +197,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     a.ring = h->d_ring;
     a.wpos = h->d_wpos;
     a.ring_cap = h->ring_cap;
+    a.ring_stride = h->ring_stride;
     a.ring_mask = h->ring_cap - 1;
     a.delay = p->delay_frames;
     a.delay_stream = h->d_delay;
@@ -285,6 +287,7 @@ wf::MeterArgs make_meter_args(wf_hip *h, const wf_hip_tick_params *p)
     m.wpos = h->d_wpos;
     m.mend = h->d_mend;
     m.ring_cap = h->ring_cap;
+    m.ring_stride = h->ring_stride;
     m.ring_mask = h->ring_cap - 1;
     m.delay = p->delay_frames;
     m.delay_stream = h->d_delay;
@@ -348,7 +351,7 @@ int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, c
     if(frames > h->ring_cap)
         return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the ring capacity %u", frames, h->ring_cap);
     const dim3 grid((frames + 255) / 256 > 64 ? 64 : (frames + 255) / 256, count * h->cap_ch), block(256);
-    hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->cap_ch, first,
+    hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->ring_stride, h->cap_ch, first,
                        d_src, frames);
     if(h->d_rms_ring) {
         hipLaunchKernelGGL(wf::rms_push_kernel, dim3(grid.x, count), block, 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
@@ -418,6 +421,16 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     h->disp_ch = h->tab.display_channels;
     h->num_bars = (uint32_t)h->tab.num_bars;
     h->ring_cap = next_pow2(ring_frames ? std::max(ring_frames, h->N) : 2 * h->N);
+    {
+        // Deep rings (a window of fft_size samples somewhere in a row of >= 256 KB) with a power-of-two row stride put every
+        // stream's window at the same offset modulo the stride; 64 KB + 256 B of padding per row spreads them over the memory
+        // channels: +2.5-4 % on the 1 MB rows of bench.py (60.0-60.3 -> 61.7-63.2 % of peak, three interleaved runs), nothing
+        // to gain on shallow rings.  WF_HIP_RING_PAD=<floats> overrides (development aid).
+        uint32_t pad = h->ring_cap >= 65536u ? 16448u : 0u;
+        if(const char *e = std::getenv("WF_HIP_RING_PAD"))
+            pad = (uint32_t)std::strtoul(e, nullptr, 10) & ~3u;
+        h->ring_stride = h->ring_cap + pad;
+    }
     h->meter = cfg->meter != 0;
 
     auto bail = [&](int code) {
@@ -452,7 +465,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     WF_CREATE_HIP(hipEventCreate(&h->ev1));
 
     const size_t n_spec = (size_t)h->n_streams * h->cap_ch;
-    WF_CREATE_TRY(dev_alloc(h, &h->d_ring, n_spec * h->ring_cap));
+    WF_CREATE_TRY(dev_alloc(h, &h->d_ring, n_spec * h->ring_stride));
     WF_CREATE_TRY(dev_alloc(h, &h->d_wpos, (size_t)h->n_streams));
     if(h->meter) {
         // level meter: rings, consumption points, two floats of state per channel, one bar per channel
@@ -614,7 +627,7 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
     if(h->meter) {
         // update() in meter mode (src/source.cpp:1123-1127, :1181, :1243): empty rings (no zero pre-fill), meter buffer 0,
         // m_meter_buf = m_meter_val = DB_MIN, m_last_silent = false
-        WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_cap, 0, nspec * h->ring_cap * sizeof(float), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_stride, 0, nspec * h->ring_stride * sizeof(float), h->stream));
         WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
         WF_HIP_TRY(h, hipMemsetAsync(h->d_wpos + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
         WF_HIP_TRY(h, hipMemsetAsync(h->d_mend + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
@@ -629,7 +642,7 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
     }
     // m_tsmooth_buf = 0, rings = zeros with N samples "written", m_decibels = DB_MIN, m_last_silent = false
     WF_HIP_TRY(h, hipMemsetAsync(h->d_tsmooth + spec0 * h->M, 0, nspec * h->M * sizeof(float), h->stream));
-    WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_cap, 0, nspec * h->ring_cap * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_stride, 0, nspec * h->ring_stride * sizeof(float), h->stream));
     for(uint32_t b = 0; b < h->flag_bufs; ++b)
         WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + (size_t)b * h->n_streams + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
     if(h->d_verdict) // rows of DB_MIN: nothing above floor - 10
@@ -734,7 +747,7 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t gx = std::min<uint32_t>((frames + 255) / 256, 256);
     hipLaunchKernelGGL(wf::ring_synth_kernel, dim3(gx, count * h->cap_ch), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,
-                       h->ring_cap, h->cap_ch, first, seed, stream_id0, index0, frames);
+                       h->ring_cap, h->ring_stride, h->cap_ch, first, seed, stream_id0, index0, frames);
     if(h->d_rms_ring) {
         hipLaunchKernelGGL(wf::rms_synth_kernel, dim3(gx, count), dim3(256), 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
                            h->cap_ch, first, seed, stream_id0, index0, frames);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * G::LDS_CF;
     cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF;
     int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
-    const float *x = a.ring + (size_t)spec * a.ring_cap;
+    const float *x = a.ring + (size_t)spec * a.ring_stride;
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
     const uint32_t start = (wpos - delay - (uint32_t)G::N) & a.ring_mask;
     float *ts = a.tsmooth + (size_t)spec * M;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         const bool nz_own = (orf & 1) != 0;
         bool nz_other = false;
         if(!nz_own && !hidden) { // workgroup-uniform and rare: this channel's window is digital silence
-            const float *xo = a.ring + (size_t)(spec ^ 1u) * a.ring_cap;
+            const float *xo = a.ring + (size_t)(spec ^ 1u) * a.ring_stride;
             uint32_t acc = 0;
             for(uint32_t i = (uint32_t)tid; i < (uint32_t)G::N; i += (uint32_t)T)
                 acc |= f32_bits(xo[(start + i) & a.ring_mask]);
@@ -359,25 +359,25 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 
 // ---- ring maintenance ---------------------------------------------------------------------------
 // src: [count*cap_ch][frames]; appends to the rings of streams [first, first+count)
-__global__ void ring_push_kernel(float *ring, const uint32_t *wpos, uint32_t ring_cap, uint32_t cap_ch, uint32_t first,
+__global__ void ring_push_kernel(float *ring, const uint32_t *wpos, uint32_t ring_cap, uint32_t ring_stride, uint32_t cap_ch, uint32_t first,
                                  const float *src, uint32_t frames)
 {
     const uint32_t row = blockIdx.y; // (stream - first) * cap_ch + ch
     const uint32_t stream = first + row / cap_ch;
     const uint32_t w = wpos[stream];
-    float *dst = ring + ((size_t)stream * cap_ch + row % cap_ch) * ring_cap;
+    float *dst = ring + ((size_t)stream * cap_ch + row % cap_ch) * ring_stride;
     for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frames; i += gridDim.x * blockDim.x)
         dst[(w + i) & (ring_cap - 1)] = src ? src[(size_t)row * frames + i] : 0.0f;
 }
 
-__global__ void ring_synth_kernel(float *ring, const uint32_t *wpos, uint32_t ring_cap, uint32_t cap_ch, uint32_t first,
+__global__ void ring_synth_kernel(float *ring, const uint32_t *wpos, uint32_t ring_cap, uint32_t ring_stride, uint32_t cap_ch, uint32_t first,
                                   uint64_t seed, uint32_t stream_id0, uint64_t index0, uint32_t frames)
 {
     const uint32_t row = blockIdx.y;
     const uint32_t s = row / cap_ch, c = row % cap_ch;
     const uint32_t stream = first + s;
     const uint32_t w = wpos[stream];
-    float *dst = ring + ((size_t)stream * cap_ch + c) * ring_cap;
+    float *dst = ring + ((size_t)stream * cap_ch + c) * ring_stride;
     const uint64_t key = wf_synth_key(seed, stream_id0 + s, c);
     for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frames; i += gridDim.x * blockDim.x)
         dst[(w + i) & (ring_cap - 1)] = wf_synth_sample(key, index0 + i);

@@ -24,6 +24,7 @@ struct MeterArgs {
     uint32_t *mend;            // [n_streams] consumption point: samples popped into the meter buffer so far, modulo 2^32
     uint32_t ring_mask;
     uint32_t ring_cap;
+    uint32_t ring_stride;      // floats between the rings of consecutive channels (>= ring_cap)
     uint32_t delay;            // frames of captured audio that lie after the tick time (dtsize, :201-202)
     const uint32_t *delay_stream;
     uint32_t size;             // m_fft_size = meter buffer length (multiple of 16)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(METER_THREADS) void meter_tick_kernel(const MeterAr
     uint32_t mend = a.mend[stream];
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
     const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
-    float *rows = a.ring + (size_t)stream * a.cap_ch * a.ring_cap;
+    float *rows = a.ring + (size_t)stream * a.cap_ch * a.ring_stride;
     float *buf = a.meter_buf + (size_t)stream * a.cap_ch;
     float *val = a.meter_val + (size_t)stream * a.cap_ch;
     float *bar = a.bars ? a.bars + (size_t)stream * a.cap_ch : nullptr;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(METER_THREADS) void meter_tick_kernel(const MeterAr
             return;
         for(uint32_t c = 0; c < a.cap_ch; ++c)
             for(uint32_t i = (uint32_t)tid; i < a.size; i += METER_THREADS)
-                rows[(size_t)c * a.ring_cap + ((start + i) & a.ring_mask)] = 0.0f;
+                rows[(size_t)c * a.ring_stride + ((start + i) & a.ring_mask)] = 0.0f;
         if(tid < (int)a.cap_ch) {
             buf[tid] = 0.0f;
             val[tid] = a.db_min;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(METER_THREADS) void meter_tick_kernel(const MeterAr
     const uint32_t n_chunks = (stop + 3u) >> 2;
     const bool rms = a.rms != 0;
     const bool two = a.cap_ch > 1;
-    const float *row0 = rows, *row1 = rows + a.ring_cap;
+    const float *row0 = rows, *row1 = rows + a.ring_stride;
 
     float acc0 = 0.0f, acc1 = 0.0f;
     for(uint32_t j0 = (uint32_t)tid; j0 < n_chunks; j0 += METER_THREADS * METER_UNROLL) {

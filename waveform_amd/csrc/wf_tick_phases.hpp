@@ -100,6 +100,7 @@ struct TickArgs {
     const uint32_t *wpos;      // [n_streams] samples written so far, modulo 2^32
     uint32_t ring_mask;        // ring_cap - 1
     uint32_t ring_cap;
+    uint32_t ring_stride;      // floats between the rings of consecutive (stream, channel) rows (>= ring_cap)
     uint32_t delay;            // frames between the end of the window and wpos (A/V sync, reference :50-51)
     const uint32_t *delay_stream; // [n_streams] added to `delay` per stream (wf_hip_set_stream_delay), or nullptr
     // per-configuration tables (read-only, shared by every stream)
