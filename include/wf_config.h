@@ -72,7 +72,13 @@ typedef struct wf_config {
      * and the outputs are one level per captured channel (m_meter_val) plus its bar (render_bars, :1505-1509). */
     uint32_t meter;             /* m_meter_mode */
     uint32_t meter_rms;         /* m_meter_rms: RMS (1) or peak (0) */
-    int32_t meter_ms;           /* m_meter_ms: milliseconds of audio the level is taken over */
+    int32_t meter_ms;           /* m_meter_ms: milliseconds of audio the level is taken over (meter) / shown (waveform) */
+    /* waveform display (display_mode WAVEFORM; tick_waveform, src/source_generic.cpp:271-390): a history of `width` points
+     * per channel, one every meter_ms / width, each the dBFS of |sample| at that time.  With waveform != 0 the handle is a
+     * waveform batch: fft_size is ignored on input and becomes `width` (m_fft_size = m_width, src/source.cpp:1140), the rings
+     * hold m_waveform_samples = sample_rate * (meter_ms / 1000.0) samples (+ the A/V-sync reserve), window / slope / mirror /
+     * log scale are off (:1133-1137). */
+    uint32_t waveform;          /* m_display_mode == DisplayMode::WAVEFORM */
 } wf_config;
 
 /* get_defaults (src/source.cpp:119-174) + what update() derives for 48 kHz stereo OBS audio,

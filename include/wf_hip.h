@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 3
+#define WF_HIP_ABI_VERSION 4
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,

@@ -65,6 +65,23 @@ def lib():
     L.wfo_interp_weights.restype = C.c_size_t
     L.wfo_interp_weights.argtypes = [vp, C.POINTER(fp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.wfo_r2c.argtypes = [fp, C.c_uint32, fp]
+    L.wfo_wave_create.restype = vp
+    L.wfo_wave_create.argtypes = [vp]
+    L.wfo_wave_destroy.argtypes = [vp]
+    L.wfo_wave_push_audio.argtypes = [vp, fp, fp, C.c_uint32, C.c_int]
+    L.wfo_wave_set_time.argtypes = [vp, C.c_uint64, C.c_uint32]
+    L.wfo_wave_set_hidden.argtypes = [vp, C.c_int]
+    L.wfo_wave_set_input_rms.argtypes = [vp, C.c_float]
+    L.wfo_wave_tick.argtypes = [vp]
+    for n in ("wfo_wave_points", "wfo_wave_output_channels"):
+        getattr(L, n).restype = C.c_uint32
+        getattr(L, n).argtypes = [vp]
+    L.wfo_wave_last_silent.restype = C.c_int
+    L.wfo_wave_last_silent.argtypes = [vp]
+    L.wfo_wave_row.restype = fp
+    L.wfo_wave_row.argtypes = [vp, C.c_int]
+    L.wfo_wave_ts.restype = C.c_uint64
+    L.wfo_wave_ts.argtypes = [vp]
     L.wfo_meter_create.restype = vp
     L.wfo_meter_create.argtypes = [vp]
     L.wfo_meter_destroy.argtypes = [vp]
@@ -266,3 +283,60 @@ class OracleMeter:
     def bars(self):
         self.L.wfo_meter_render(self.h)
         return np.array([self.L.wfo_meter_bar(self.h, c) for c in range(self.capture_channels)], np.float32)
+
+
+class OracleWave:
+    """One restated WAVSource in waveform display mode (oracle/wf_oracle_wave.c)."""
+
+    def __init__(self, cfg):
+        self.L = lib()
+        self._cfg = cfg
+        self.h = self.L.wfo_wave_create(C.cast(C.byref(cfg), C.c_void_p))
+        if not self.h:
+            raise ValueError("wfo_wave_create rejected the configuration")
+        self.points = self.L.wfo_wave_points(self.h)
+        self.capture_channels = int(cfg.capture_channels)
+        self.output_channels = self.L.wfo_wave_output_channels(self.h)
+        self.display_channels = 2 if cfg.stereo else 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.wfo_wave_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_time(self, audio_ts_ns, reserve_frames=0):
+        self.L.wfo_wave_set_time(self.h, audio_ts_ns, reserve_frames)
+
+    def push_audio(self, audio, muted=False):
+        a = np.ascontiguousarray(audio, np.float32)
+        fp = C.POINTER(C.c_float)
+        p0 = a[0].ctypes.data_as(fp)
+        p1 = a[1].ctypes.data_as(fp) if self.capture_channels > 1 else fp()
+        self.L.wfo_wave_push_audio(self.h, p0, p1, a.shape[1], 1 if muted else 0)
+
+    def set_hidden(self, hidden):
+        self.L.wfo_wave_set_hidden(self.h, 1 if hidden else 0)
+
+    def set_input_rms(self, rms):
+        self.L.wfo_wave_set_input_rms(self.h, rms)
+
+    def tick(self):
+        self.L.wfo_wave_tick(self.h)
+
+    @property
+    def last_silent(self):
+        return bool(self.L.wfo_wave_last_silent(self.h))
+
+    @property
+    def waveform_ts(self):
+        return int(self.L.wfo_wave_ts(self.h))
+
+    def rows(self):
+        """[display_channels, points]"""
+        return np.stack([_arr(self.L.wfo_wave_row(self.h, c), self.points) for c in range(self.display_channels)])

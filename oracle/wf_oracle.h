@@ -87,6 +87,23 @@ float wfo_meter_val(const wfo_meter *m, int ch);    /* m_meter_val */
 float wfo_meter_ema(const wfo_meter *m, int ch);    /* m_meter_buf */
 float wfo_meter_bar(const wfo_meter *m, int ch);    /* m_interp_bufs[0][ch] after wfo_meter_render */
 
+/* ---- waveform display (wf_oracle_wave.c): WAVSourceGeneric::tick_waveform, src/source_generic.cpp:271-390 -------- */
+typedef struct wfo_wave wfo_wave;
+wfo_wave *wfo_wave_create(const wf_config *cfg); /* cfg->waveform must be set */
+void wfo_wave_destroy(wfo_wave *w);
+void wfo_wave_push_audio(wfo_wave *w, const float *ch0, const float *ch1, uint32_t frames, int muted);
+/* m_audio_ts (end-of-audio timestamp of the newest captured sample) and the A/V-sync reserve in frames, as of the next
+ * push / tick */
+void wfo_wave_set_time(wfo_wave *w, uint64_t audio_ts_ns, uint32_t reserve_frames);
+void wfo_wave_set_hidden(wfo_wave *w, int hidden); /* !m_show || capture timed out */
+void wfo_wave_set_input_rms(wfo_wave *w, float rms);
+void wfo_wave_tick(wfo_wave *w);
+uint32_t wfo_wave_points(const wfo_wave *w);        /* m_fft_size = m_width */
+uint32_t wfo_wave_output_channels(const wfo_wave *w);
+int wfo_wave_last_silent(const wfo_wave *w);
+const float *wfo_wave_row(const wfo_wave *w, int ch); /* m_decibels[ch], wfo_wave_points() floats */
+uint64_t wfo_wave_ts(const wfo_wave *w);            /* m_waveform_ts */
+
 /* the bare DFT stage, for FFT-only tests: out[k] = (re, im) of bin k, k < n/2 */
 void wfo_r2c(const float *in, uint32_t n, float *out_interleaved);
 

@@ -210,7 +210,7 @@ class RefSource:
         return float(self.L.wfref_gravity(self.h, seconds))
 
     def decibels(self, ch):
-        return _arr(self.L.wfref_decibels(self.h, ch), self.fft_size // 2)
+        return _arr(self.L.wfref_decibels(self.h, ch), self.L.wfref_decibels_size(self.h))
 
     def tsmooth(self, ch):
         return _arr(self.L.wfref_tsmooth(self.h, ch), self.fft_size // 2)

@@ -13,6 +13,10 @@ and every backend records the same observables after each tick:
 Level-meter configurations (cfg.meter) record instead
   db    float32 [1, capture_channels]            m_meter_val (dBFS), one level per captured channel
   bars  float32 [1, capture_channels]            m_interp_bufs[0] after render_bars (src/source.cpp:1505-1509, :1548-1557)
+Waveform configurations (cfg.waveform) record
+  db    float32 [display_channels, width]        m_decibels: the history of dBFS points (tick_waveform)
+A scenario may carry sync_ms: the source's audio sync offset (P_AUDIO_SYNC_OFFSET), i.e. a constant A/V-sync reserve of
+sync_ms * 48 frames that every backend applies.
 Audio is the counter-hash noise of include/wf_synth.h (tools/synth.py), so fixtures only store
 outputs.
 """
@@ -118,6 +122,19 @@ SCENARIOS = {
     "normalize_long_1024": dict(cfg=dict(fft_size=1024, stereo=1, normalize_volume=1, tsmoothing=0),
                                 steps=[("noise", 1000), ("noise", 600), ("tick",)] * 25
                                 + [("noise_amp", 1000, 0.1), ("noise_amp", 600, 0.1), ("tick",)] * 20, record=2),
+    # ---- waveform display (tick_waveform, src/source_generic.cpp:271-390) ------------------------------------------------
+    "wave_stereo_800": dict(cfg=dict(waveform=1, stereo=1), steps=_steps(10), record=3),
+    # mono mixdown (row 1 keeps raw samples), ragged packets, shorter history
+    "wave_mono_mix_ragged": dict(cfg=dict(waveform=1, stereo=0, width=500, meter_ms=100),
+                                 steps=[("noise", 441), ("tick",)] * 5 + [("noise", 1024), ("tick",), ("noise", 37), ("tick",), ("tick",)]
+                                 + [("noise_amp", 800, 0.05), ("tick",)] * 3, record=4),
+    # one captured channel shown as two rows; ticks without new audio, then a burst longer than the history
+    "wave_single_dup_stall": dict(cfg=dict(waveform=1, stereo=1, capture_channels=1, width=640),
+                                  steps=_steps(3) + [("tick",)] * 3 + [("noise", 1024)] * 9 + [("tick",)] + _steps(2), record=3),
+    # hide / show / capture timeout, with a 10 ms audio sync offset (A/V-sync reserve of 480 frames)
+    "wave_hide_timeout_sync": dict(cfg=dict(waveform=1, stereo=1, width=333), sync_ms=10,
+                                   steps=_steps(4) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(3)
+                                   + [("timeout",), ("tick",), ("tick",)] + _steps(3), record="all"),
     # ---- level meter (tick_meter, src/source_generic.cpp:182-269) -------------------------------------------------------
     # defaults: RMS over 150 ms (7200 samples), EMA g = 0.65, two captured channels; m_meter_buf starts at DB_MIN (quirk)
     "meter_rms_stereo": dict(cfg=dict(meter=1), steps=_steps(30), record="all"),
@@ -176,6 +193,8 @@ def play(backend, scenario: dict):
     """returns list of per-tick records: dict(db=..., bars=... | None, silent=bool)"""
     feeder = _Feeder(backend.capture_channels)
     records = []
+    if scenario.get("sync_ms"):
+        backend.set_sync_ms(int(scenario["sync_ms"]))
     for step in scenario["steps"]:
         op = step[0]
         if op in ("noise", "silence", "noise_ch0_only", "noise_ch1_only"):
@@ -239,6 +258,10 @@ class RefBackend:
     def timeout(self):
         self.now += 600_000_000  # > CAPTURE_TIMEOUT (500 ms) since the last packet
 
+    def set_sync_ms(self, ms):
+        self.src.L.wfref_set_clock_ns(self.now)
+        self.src.update(dict(audio_sync_offset=ms))  # re-runs update(): only valid before the first packet
+
     def set_hidden(self, hidden):
         self.src.show(not hidden)
 
@@ -249,7 +272,7 @@ class RefBackend:
             return dict(db=levels, bars=self.src.bars(0)[None, : self.capture_channels], silent=self.src.last_silent)
         db = np.stack([self.src.decibels(c) for c in range(self.disp)])
         bars = None
-        if self.cfg.bars or self.cfg.curve:
+        if (self.cfg.bars or self.cfg.curve) and not self.cfg.waveform:
             self.src.render()
             bars = np.stack([self.src.bars(c) for c in range(self.disp)])
         rec = dict(db=db, bars=bars, silent=self.src.last_silent)
@@ -267,12 +290,24 @@ class OracleBackend:
         self.cfg = cfg
         self.hidden = False
         self.auto_rms = bool(cfg.normalize_volume) and input_rms is None
+        self.now = 1_000_000_000  # the same clock model as RefBackend: packets end "now", ticks happen "now"
+        self.reserve = 0
         if cfg.meter:
             self.src = restate.OracleMeter(cfg)
+        elif cfg.waveform:
+            self.src = restate.OracleWave(cfg)
+            self.src.set_input_rms(input_rms or 0.0)
         else:
             self.src = restate.OracleSource(cfg)
             self.src.set_input_rms(input_rms or 0.0)
         self.capture_channels = self.src.capture_channels
+
+    def set_sync_ms(self, ms):
+        self.reserve = ms * 48
+        if self.cfg.waveform:
+            self.src.set_time(self.now, self.reserve)
+        else:
+            self.src.set_sync_delay(self.reserve)
 
     def _state(self, timed_out=False):
         # the restatement takes the tick's gate as given: 0 shown, 1 !m_show, 2 capture timed out
@@ -283,14 +318,21 @@ class OracleBackend:
 
     def push(self, audio, muted):
         self._state()  # a packet ends a capture timeout
+        self.now += audio.shape[1] * 1_000_000_000 // 48000 + 1
+        if self.cfg.waveform:
+            self.src.set_time(self.now, self.reserve)  # m_audio_ts = end of this packet
         self.src.push_audio(audio, muted=muted)
 
     def tick(self, seconds):
+        if self.cfg.waveform:
+            self.src.tick()
+            return
         if self.auto_rms:
             self.rms = self.src.update_input_rms()
         self.src.tick(seconds)
 
     def timeout(self):
+        self.now += 600_000_000  # as RefBackend: no packet for 600 ms
         self._state(timed_out=True)
 
     def set_hidden(self, hidden):
@@ -300,6 +342,8 @@ class OracleBackend:
     def observe(self):
         if self.cfg.meter:
             return dict(db=self.src.levels()[None], bars=self.src.bars()[None], silent=self.src.last_silent)
+        if self.cfg.waveform:
+            return dict(db=self.src.rows(), bars=None, silent=self.src.last_silent)
         bars = None
         if self.cfg.bars or self.cfg.curve:
             self.src.render_bars()

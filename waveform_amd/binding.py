@@ -34,6 +34,7 @@ class Config(C.Structure):
         ("channel_spacing", C.c_int32), ("min_bar_height", C.c_int32), ("rounded_caps", C.c_uint32),
         ("curve", C.c_uint32), ("filter_mode", C.c_int32), ("filter_radius", C.c_float),
         ("meter", C.c_uint32), ("meter_rms", C.c_uint32), ("meter_ms", C.c_int32),
+        ("waveform", C.c_uint32),
     ]
 
     @classmethod

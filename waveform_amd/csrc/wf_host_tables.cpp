@@ -552,4 +552,5 @@ extern "C" void wf_config_defaults(wf_config *cfg)
     cfg->meter = 0;
     cfg->meter_rms = 1;            // P_RMS_MODE default true
     cfg->meter_ms = 150;           // P_METER_BUF default
+    cfg->waveform = 0;
 }
