@@ -89,9 +89,10 @@ void WAVSourceHIP::hip_release()
 bool WAVSourceHIP::hip_configure()
 {
     hip_release();
-    if(!available() || (m_display_mode == DisplayMode::WAVEFORM) || (m_capture_channels == 0))
+    if(!available() || (m_capture_channels == 0))
         return false;
     wf_config c{};
+    c.waveform = (m_display_mode == DisplayMode::WAVEFORM) ? 1u : 0u; // m_fft_size is m_width in this mode
     c.meter = m_meter_mode ? 1u : 0u;   // update() has already applied the mode's overrides to the members below
     c.meter_rms = m_meter_rms ? 1u : 0u;
     c.meter_ms = m_meter_ms;
@@ -136,6 +137,7 @@ bool WAVSourceHIP::hip_configure()
     m_hip_out.assign((size_t)m_output_channels * (m_fft_size / 2), 0.0f);
     m_hip_hidden = false;
     m_hip_state = WF_HIP_SHOWN;
+    m_hip_pushed = (m_display_mode == DisplayMode::WAVEFORM) ? m_fft_size : 0; // update() pre-fills m_fft_size zeros; so does the device
     return true;
 }
 
@@ -255,5 +257,75 @@ void WAVSourceHIP::tick_meter(float seconds)
     }
     for(auto channel = 0u; channel < m_capture_channels; ++channel)
         m_meter_val[channel] = levels[channel];
+    m_last_silent = silent != 0;
+}
+
+// Same observable behaviour as WAVSourceGeneric::tick_waveform (src/source_generic.cpp:271-390).  The device ring mirrors
+// m_capturebufs: every tick the frames captured since the last one are appended to it, the device picks the new points
+// from its ring exactly where the reference picks them from its scratch copy (both count back from the newest sample),
+// and m_capturebufs is popped down to the A/V-sync reserve as the reference does (:321).  m_waveform_ts lives on the device.
+void WAVSourceHIP::tick_waveform(float seconds)
+{
+    if(m_hip == nullptr) {
+        WAVSourceGeneric::tick_waveform(seconds);
+        return;
+    }
+    auto &a = api();
+    const auto outsz = m_fft_size;
+    const auto dtcapture = m_tick_ts - m_capture_ts;
+    const bool hidden = !m_show || (dtcapture > CAPTURE_TIMEOUT); // :279
+    bool ok = true;
+    if(hidden != m_hip_hidden) {
+        const uint8_t mask = hidden ? 1 : 0;
+        ok = a.set_hidden(m_hip, 0, 1, &mask) == WF_HIP_OK;
+        m_hip_hidden = hidden;
+    }
+    wf_hip_tick_params p{};
+    p.seconds = seconds;
+    p.input_rms = m_input_rms;
+    p.audio_ts_ns = m_audio_ts;
+    if(ok && !hidden) {
+        const int64_t dtaudio = get_audio_sync(m_tick_ts);
+        const size_t reserve = (dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) : 0; // frames
+        const size_t max_frames = m_waveform_samples + reserve;
+        for(auto i = 0u; i < m_capture_channels; ++i)
+            if(m_capturebufs[i].size() <= reserve * sizeof(float)) // :293-295
+                return;
+        size_t frames = 0, fresh = 0;
+        for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+            auto &buf = m_capturebufs[channel];
+            if(buf.size() > max_frames * sizeof(float)) // :303-304
+                buf.pop_front(nullptr, buf.size() - max_frames * sizeof(float));
+            const size_t s = buf.size() / sizeof(float);
+            // capture_audio drops from the front only once the ring exceeds dtsamples + m_waveform_samples; below that
+            // nothing was dropped and the first m_hip_pushed frames are on the device already.  Above it the whole buffer
+            // is re-sent: the device only looks at the newest m_waveform_samples + reserve frames, which are then contiguous.
+            const size_t n = (s < m_waveform_samples && s >= m_hip_pushed) ? s - m_hip_pushed : s;
+            if(channel == 0) {
+                frames = s;
+                fresh = n;
+                m_hip_window.resize((size_t)m_capture_channels * fresh);
+            }
+            std::vector<float> all(s);
+            buf.peek_front(all.data(), s * sizeof(float));
+            std::memcpy(m_hip_window.data() + (size_t)channel * fresh, all.data() + (s - fresh), fresh * sizeof(float));
+            buf.pop_front(nullptr, (s - reserve) * sizeof(float)); // :321: only the reserve stays
+        }
+        (void)frames;
+        if(fresh > 0)
+            ok = a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)fresh) == WF_HIP_OK;
+        m_hip_pushed = reserve;
+        p.delay_frames = (uint32_t)reserve;
+    }
+    m_hip_out.resize((size_t)m_output_channels * outsz);
+    uint8_t silent = 0;
+    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read_decibels(m_hip, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
+       a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
+        LogWarn << "HIP waveform tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
+        hip_release();
+        return; // the audio of this tick has been consumed; the CPU path takes over at the next one
+    }
+    for(auto channel = 0u; channel < m_output_channels; ++channel)
+        std::memcpy(m_decibels[channel].get(), m_hip_out.data() + (size_t)channel * outsz, outsz * sizeof(float));
     m_last_silent = silent != 0;
 }

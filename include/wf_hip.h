@@ -25,6 +25,12 @@
  *                        (src/source.cpp:1500-1557; src/filter.hpp:160-211)
  *   wf_hip_read_*        reading m_decibels / m_interp_bufs / m_tsmooth_buf
  *
+ * Waveform display.  A handle created from a configuration with cfg.waveform != 0 is a *waveform batch*: wf_hip_tick runs
+ * WAVSource*::tick_waveform (src/source_generic.cpp:271-390) for every stream -- a history of cfg.width dBFS points per
+ * channel, extended by one point per meter_ms / width of newly consumed audio -- and wf_hip_read_decibels returns the rows
+ * ([count][output_channels][width]; wf_hip_fft_size() == width as m_fft_size does in this mode).  The tick needs
+ * wf_hip_tick_params::audio_ts_ns.  Widths up to 8192 points.
+ *
  * Level meter.  A handle created from a configuration with cfg.meter != 0 is a *meter batch*: wf_hip_tick runs
  * WAVSource*::tick_meter (src/source_generic.cpp:182-269; AVX src/source_avx.cpp:202-322) for every stream -- the
  * meter buffer is the last wf_hip_fft_size() samples consumed from the device ring, RMS or peak over it, temporal
@@ -120,6 +126,8 @@ typedef struct wf_hip_tick_params {
     float input_rms;        /* m_input_rms, only read when cfg.normalize_volume; the same value for every stream unless
                                wf_hip_set_input_rms has given the streams their own */
     uint32_t flags;         /* WF_HIP_TICK_* */
+    uint64_t audio_ts_ns;   /* m_audio_ts: end-of-audio timestamp of the newest pushed sample (src/source.cpp:1829-1832), in ns;
+                               only waveform batches read it (tick_waveform places its points in time with it) */
 } wf_hip_tick_params;
 #define WF_HIP_TICK_NO_DECIBELS 1u /* bars/curve-only batch mode: skip the m_decibels store (cfg.bars or cfg.curve must be set) */
 

@@ -372,15 +372,22 @@ class HipBackend:
         self.probe = probe
         self.disp = self.batch.display_channels
         self.hidden = False
+        self.now = 1_000_000_000  # the same clock model as RefBackend: packets end "now", ticks happen "now"
+        self.reserve = 0
+
+    def set_sync_ms(self, ms):
+        self.reserve = ms * 48
 
     def _state(self, timed_out=False):
         self.batch.set_hidden(np.full(self.streams, 2 if timed_out else (1 if self.hidden else 0), np.uint8))
 
     def timeout(self):
+        self.now += 600_000_000
         self._state(timed_out=True)
         self.timed_out = True
 
     def push(self, audio, muted):
+        self.now += audio.shape[1] * 1_000_000_000 // 48000 + 1
         if getattr(self, "timed_out", False):
             self.timed_out = False
             self._state()  # a packet ends a capture timeout
@@ -392,7 +399,7 @@ class HipBackend:
             self.batch.push_audio(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
 
     def tick(self, seconds):
-        self.batch.tick(seconds=seconds, input_rms=self.input_rms)
+        self.batch.tick(seconds=seconds, input_rms=self.input_rms, delay_frames=self.reserve, audio_ts_ns=self.now)
 
     def set_hidden(self, hidden):
         self.hidden = hidden
@@ -404,6 +411,9 @@ class HipBackend:
             assert all(np.array_equal(lv[0], lv[i]) for i in range(1, self.streams)), "streams of one batch disagree"
             return dict(db=lv[self.probe][None], bars=bars[self.probe], silent=bool(silent[self.probe]))
         db = self.batch.decibels()
+        if self.cfg.waveform:
+            assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"
+            return dict(db=db[self.probe][: self.disp], bars=None, silent=bool(self.batch.last_silent()[self.probe]))
         bars = self.batch.bars() if (self.cfg.bars or self.cfg.curve) else None
         silent = self.batch.last_silent()
         # every copy of the scenario must produce the same bits

@@ -74,7 +74,9 @@ DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4096_ema_s
           "hide_show", "muted_packets", "timeout_spectrum",
           # WAVSourceHIP::tick_meter
           "meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",
-          "meter_hide_show_timeout"]
+          "meter_hide_show_timeout",
+          # WAVSourceHIP::tick_waveform
+          "wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync"]
 
 
 @pytest.mark.gpu

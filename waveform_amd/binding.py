@@ -49,7 +49,8 @@ class Config(C.Structure):
 
 
 class TickParams(C.Structure):
-    _fields_ = [("seconds", C.c_float), ("delay_frames", C.c_uint32), ("input_rms", C.c_float), ("flags", C.c_uint32)]
+    _fields_ = [("seconds", C.c_float), ("delay_frames", C.c_uint32), ("input_rms", C.c_float), ("flags", C.c_uint32),
+                ("audio_ts_ns", C.c_uint64)]
 
 
 TICK_NO_DECIBELS = 1
@@ -157,7 +158,7 @@ class SpectrumBatch:
         self.h = h
         self.streams = streams
         self.fft_size = self.L.wf_hip_fft_size(h)
-        self.bins = self.fft_size // 2
+        self.bins = self.fft_size if cfg.waveform else self.fft_size // 2  # floats per m_decibels row
         self.capture_channels = self.L.wf_hip_capture_channels(h)
         self.output_channels = self.L.wf_hip_output_channels(h)
         self.display_channels = self.L.wf_hip_display_channels(h)
@@ -225,8 +226,8 @@ class SpectrumBatch:
         self._ck(self.L.wf_hip_reset(self.h, first, count))
 
     # -- tick -------------------------------------------------------------------------
-    def tick(self, seconds: float = 1.0 / 60.0, delay_frames: int = 0, input_rms: float = 0.0, flags: int = 0):
-        p = TickParams(seconds, delay_frames, input_rms, flags)
+    def tick(self, seconds: float = 1.0 / 60.0, delay_frames: int = 0, input_rms: float = 0.0, flags: int = 0, audio_ts_ns: int = 0):
+        p = TickParams(seconds, delay_frames, input_rms, flags, audio_ts_ns)
         self._ck(self.L.wf_hip_tick(self.h, C.byref(p)))
 
     def set_hidden(self, mask, first: int = 0):
@@ -250,7 +251,7 @@ class SpectrumBatch:
 
     def time_ticks(self, ticks: int, hop: int, first_delay: int, seconds: float = 1.0 / 60.0, flags: int = 0) -> float:
         """average fused-kernel duration in ms over `ticks` back-to-back ticks (hipEvents on the handle's stream)"""
-        p = TickParams(seconds, first_delay, 0.0, flags)
+        p = TickParams(seconds, first_delay, 0.0, flags, 0)
         ms = C.c_float(0.0)
         self._ck(self.L.wf_hip_time_ticks(self.h, C.byref(p), ticks, hop, C.byref(ms)))
         return float(ms.value)

@@ -16,6 +16,7 @@
 #include "wf_kernels.hpp"
 #include "wf_meter.hpp"
 #include "wf_rms.hpp"
+#include "wf_wave.hpp"
 
 namespace {
 
@@ -62,6 +63,11 @@ struct wf_hip {
     uint32_t *d_rend = nullptr;      // [n_streams] consumption point of sync_rms_buffer
     float *d_input_rms = nullptr;    // [n_streams] m_input_rms
     uint32_t rms_cap = 0, rms_size = 0;
+    // waveform batches (cfg.waveform): N = M = width (points per row), there is no FFT state
+    bool wave = false;
+    uint32_t wave_samples = 0;       // m_waveform_samples
+    uint32_t *d_cend = nullptr;      // [n_streams] samples consumed so far
+    unsigned long long *d_wts = nullptr; // [n_streams] m_waveform_ts
     // level-meter batches (cfg.meter): N is the meter buffer length, there is no FFT state
     bool meter = false;
     uint32_t *d_mend = nullptr;      // [n_streams] consumption point of tick_meter
@@ -393,7 +399,10 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         return fail(nullptr, WF_HIP_ERR_INVALID, "cfg is NULL or max_streams is 0");
     wf::HostTables tab;
     wf_config cfg_eff = *cfg;
-    if(cfg_eff.meter)
+    uint32_t wave_samples = 0;
+    if(cfg_eff.waveform)
+        wave_samples = wf::waveform_config(cfg_eff); // update()'s overrides; fft_size becomes the row length (width)
+    else if(cfg_eff.meter)
         wf::meter_config(cfg_eff); // update()'s overrides for the mode; fft_size becomes the meter buffer length
     cfg = &cfg_eff;
     int rc = wf::build_host_tables(*cfg, tab);
@@ -421,6 +430,18 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     h->disp_ch = h->tab.display_channels;
     h->num_bars = (uint32_t)h->tab.num_bars;
     h->ring_cap = next_pow2(ring_frames ? std::max(ring_frames, h->N) : 2 * h->N);
+    if(cfg->waveform) {
+        // rows of `width` points; the ring holds the history the points are picked from (+ the width zeros of update())
+        h->wave = true;
+        h->wave_samples = wave_samples;
+        h->M = h->N;
+        if(h->N > 8192u) {
+            g_create_error = "waveform display: width above 8192 points is not implemented";
+            delete h;
+            return fail(nullptr, WF_HIP_ERR_UNSUPPORTED, "waveform display: width %u above 8192 points is not implemented", cfg->width);
+        }
+        h->ring_cap = next_pow2(std::max(ring_frames, 2 * (wave_samples + h->N)));
+    }
     {
         // Deep rings (a window of fft_size samples somewhere in a row of >= 256 KB) with a power-of-two row stride put every
         // stream's window at the same offset modulo the stride; 64 KB + 256 B of padding per row spreads them over the memory
@@ -467,6 +488,20 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     const size_t n_spec = (size_t)h->n_streams * h->cap_ch;
     WF_CREATE_TRY(dev_alloc(h, &h->d_ring, n_spec * h->ring_stride));
     WF_CREATE_TRY(dev_alloc(h, &h->d_wpos, (size_t)h->n_streams));
+    if(h->wave) {
+        WF_CREATE_TRY(dev_alloc(h, &h->d_cend, (size_t)h->n_streams));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_wts, (size_t)h->n_streams));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_decibels, (size_t)h->n_streams * h->out_ch * h->M));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->n_streams));
+        const int lds = (int)(2u * h->cap_ch * h->N * sizeof(float));
+        WF_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::waveform_tick_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        h->kernel_name = "waveform_tick_kernel";
+        WF_CREATE_TRY(wf_hip_reset(h, 0, h->n_streams));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+        *out = h;
+        return WF_HIP_OK;
+    }
     if(h->meter) {
         // level meter: rings, consumption points, two floats of state per channel, one bar per channel
         WF_CREATE_TRY(dev_alloc(h, &h->d_mend, (size_t)h->n_streams));
@@ -624,6 +659,22 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
         return rc;
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const size_t spec0 = (size_t)first * h->cap_ch, nspec = (size_t)count * h->cap_ch;
+    if(h->wave) {
+        // update() in waveform mode (src/source.cpp:1142, :1172-1182, :1243-1248): rows = DB_MIN, rings = width zeros, m_waveform_ts = 0
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_stride, 0, nspec * h->ring_stride * sizeof(float), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_cend + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_wts + first, 0, (size_t)count * sizeof(unsigned long long), h->stream));
+        const size_t ndb = (size_t)count * h->out_ch * h->M;
+        hipLaunchKernelGGL(wf::fill_f32_kernel, dim3((unsigned)std::min<size_t>((ndb + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           h->d_decibels + (size_t)first * h->out_ch * h->M, ndb, wf::db_min());
+        hipLaunchKernelGGL(wf::fill_u32_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos + first, (size_t)count,
+                           h->N);
+        WF_HIP_TRY(h, hipGetLastError());
+        if(first == 0 && count == h->n_streams)
+            h->all_aligned = true;
+        return WF_HIP_OK;
+    }
     if(h->meter) {
         // update() in meter mode (src/source.cpp:1123-1127, :1181, :1243): empty rings (no zero pre-fill), meter buffer 0,
         // m_meter_buf = m_meter_val = DB_MIN, m_last_silent = false
@@ -765,12 +816,45 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
 {
     if(h == nullptr || p == nullptr)
         return WF_HIP_ERR_INVALID;
-    if((uint64_t)p->delay_frames + h->max_stream_delay + h->N > h->ring_cap)
+    if((uint64_t)p->delay_frames + h->max_stream_delay + (h->wave ? h->wave_samples : h->N) > h->ring_cap)
         return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u (+ per-stream %u) + fft_size %u exceeds the ring capacity %u", p->delay_frames,
                     h->max_stream_delay, h->N, h->ring_cap);
     if((p->flags & WF_HIP_TICK_NO_DECIBELS) && h->num_bars == 0)
         return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS on a configuration without bars or curve: the tick would produce nothing");
     WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->wave) {
+        wf::WaveArgs w{};
+        w.ring = h->d_ring;
+        w.wpos = h->d_wpos;
+        w.cend = h->d_cend;
+        w.wts = h->d_wts;
+        w.ring_mask = h->ring_cap - 1;
+        w.ring_stride = h->ring_stride;
+        w.delay = p->delay_frames;
+        w.delay_stream = h->d_delay;
+        w.rows = h->d_decibels;
+        w.stream_flags = h->d_flags;
+        w.audio_ts = p->audio_ts_ns;
+        w.step_ns = ((unsigned long long)h->cfg.meter_ms * 1000000ull) / h->N; // src/source_generic.cpp:299
+        w.waveform_samples = h->wave_samples;
+        w.width = h->N;
+        w.sample_rate = h->cfg.sample_rate;
+        w.n_streams = h->n_streams;
+        w.cap_ch = h->cap_ch;
+        w.out_ch = h->out_ch;
+        w.stereo = h->cfg.stereo ? 1u : 0u;
+        w.normalize = h->cfg.normalize_volume ? 1u : 0u;
+        if(w.normalize) {
+            const float rms_db = (p->input_rms > 0.0f) ? 20.0f * std::log10(p->input_rms) : wf::db_min();
+            w.vol_comp = std::min(h->cfg.volume_target - rms_db, h->cfg.max_gain); // src/source_generic.cpp:381
+            w.vol_comp_stream = h->d_vol_comp;
+        }
+        w.db_min = wf::db_min();
+        const size_t lds = 2u * (size_t)h->cap_ch * h->N * sizeof(float);
+        hipLaunchKernelGGL(wf::waveform_tick_kernel, dim3(h->n_streams), dim3(wf::WAVE_THREADS), lds, h->stream, w);
+        WF_HIP_TRY(h, hipGetLastError());
+        return WF_HIP_OK;
+    }
     if(h->meter) {
         const wf::MeterArgs m = make_meter_args(h, p);
         hipLaunchKernelGGL(wf::meter_tick_kernel, dim3(h->n_streams), dim3(wf::METER_THREADS), 0, h->stream, m);
@@ -894,7 +978,7 @@ int wf_hip_enable_input_rms(wf_hip *h)
 {
     if(h == nullptr)
         return WF_HIP_ERR_INVALID;
-    if(!h->cfg.normalize_volume || h->meter)
+    if(!h->cfg.normalize_volume || h->meter || h->wave)
         return fail(h, WF_HIP_ERR_INVALID, "wf_hip_enable_input_rms needs a spectrum batch with cfg.normalize_volume");
     if(h->d_rms_ring)
         return WF_HIP_OK;
@@ -1006,8 +1090,8 @@ int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out)
     int rc = check_range(h, first, count);
     if(rc)
         return rc;
-    if(h->meter)
-        return fail(h, WF_HIP_ERR_INVALID, "meter batch: there is no m_tsmooth_buf");
+    if(h->meter || h->wave)
+        return fail(h, WF_HIP_ERR_INVALID, "meter / waveform batch: there is no m_tsmooth_buf");
     const size_t per = (size_t)h->cap_ch * h->M;
     return read_back(h, h->d_tsmooth + first * per, out, count * per * sizeof(float));
 }
@@ -1019,8 +1103,8 @@ int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float 
         return rc;
     if(in == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "input pointer is NULL");
-    if(h->meter)
-        return fail(h, WF_HIP_ERR_INVALID, "meter batch: there is no m_tsmooth_buf");
+    if(h->meter || h->wave)
+        return fail(h, WF_HIP_ERR_INVALID, "meter / waveform batch: there is no m_tsmooth_buf");
     const size_t per = (size_t)h->cap_ch * h->M;
     WF_HIP_TRY(h, hipSetDevice(h->device));
     WF_HIP_TRY(h, hipMemcpyAsync(h->d_tsmooth + first * per, in, count * per * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -1122,6 +1206,8 @@ uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags)
 {
     if(h == nullptr)
         return 0;
+    if(h->wave) // read + write every row (the shift), plus the samples picked from the rings (not counted: <= width per row)
+        return (uint64_t)h->n_streams * h->out_ch * h->N * 8ull;
     if(h->meter) // read the meter buffer of every captured channel; state, level and bar are a few floats per channel
         return (uint64_t)h->n_streams * h->cap_ch * (4ull * h->N + 20ull);
     // read the N-sample window of every captured channel, read + write the smoothing

@@ -449,8 +449,33 @@ uint32_t meter_config(wf_config &cfg)
     return cfg.fft_size;
 }
 
+uint32_t waveform_config(wf_config &cfg)
+{
+    // "turn off stuff we don't need in this mode", src/source.cpp:1132-1137
+    cfg.window = WF_WINDOW_NONE;
+    cfg.slope = 0.0f;
+    cfg.mirror_freq_axis = 0;
+    cfg.log_scale = 0;
+    cfg.meter = 0;
+    cfg.bars = 0;  // the curve through the points (render_curve) stays with the host's renderer
+    cfg.curve = 0;
+    cfg.fft_size = cfg.width; // "repurpose m_fft_size for buffer size", :1140
+    return (uint32_t)(size_t)((double)cfg.sample_rate * ((double)cfg.meter_ms / 1000.0)); // m_waveform_samples, :1141
+}
+
 int build_host_tables(const wf_config &cfg, HostTables &out)
 {
+    if(cfg.waveform) {
+        if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0 || cfg.meter_ms <= 0 || cfg.width == 0)
+            return WF_HIP_ERR_INVALID;
+        if(((uint64_t)cfg.meter_ms * 1000000ull) / cfg.width == 0) // step_ns, src/source_generic.cpp:299
+            return WF_HIP_ERR_INVALID;
+        out = HostTables{};
+        out.window_sum = (float)cfg.fft_size;
+        out.output_channels = ((cfg.capture_channels > 1) || cfg.stereo) ? 2u : 1u;
+        out.display_channels = cfg.stereo ? 2u : 1u;
+        return WF_HIP_OK;
+    }
     if(cfg.meter) {
         // level meter: no FFT, no tables; one "bar" per captured channel through render_bars' mapping (:1257-1266, :1505-1509)
         if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0 || cfg.meter_ms <= 0 || cfg.fft_size < 16)

@@ -44,6 +44,9 @@ struct HostTables {
 // Level-meter mode (cfg.meter): applies update()'s overrides for the mode to `cfg` (src/source.cpp:1106-1128) and
 // returns the meter buffer length, which replaces cfg.fft_size.  Call before build_host_tables.
 uint32_t meter_config(wf_config &cfg);
+// Waveform display mode (cfg.waveform): update()'s overrides (src/source.cpp:1130-1142) applied to `cfg`; fft_size becomes
+// the row length (m_width); returns m_waveform_samples.  Call before build_host_tables.
+uint32_t waveform_config(wf_config &cfg);
 // returns 0 on success, a negative wf_hip error code otherwise
 int build_host_tables(const wf_config &cfg, HostTables &out);
 // bar ranges whose entries fit `cap_floats` of LDS scratch together (every single bar fits: len <= M + 7 <= cap)

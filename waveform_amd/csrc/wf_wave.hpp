@@ -1,0 +1,173 @@
+// wf_wave.hpp -- gfx950 kernel of the waveform-display tick (device code only; hipcc).
+//
+//   waveform_tick_kernel   WAVSource*::tick_waveform for a whole batch of sources (reference src/source_generic.cpp:271-390,
+//                          AVX variant src/source_avx.cpp:347-470): a history of `width` points per channel; each tick appends
+//                          one point per step_ns = meter_ms / width of newly consumed audio -- the sample nearest to that
+//                          time -- shifts the history left by as many, and converts the new points to dBFS (|x|, or the mean
+//                          of |L| and |R| in mono display), plus volume normalisation.
+//
+// The reference pops the ring into a scratch buffer and indexes it backwards from the newest sample
+// (temp[total - index]); on the device that is ring[wpos - index], so nothing is copied.  All time arithmetic is the
+// reference's 64-bit integer arithmetic (libobs util_mul_div64 behind ns_to_audio_frames / audio_frames_to_ns).
+// One workgroup per stream: the old rows are staged in LDS (the shift is in place in memory), the new rows assembled in a
+// second LDS area because what is finally stored depends on whether *every* channel's row is all zeros (m_last_silent).
+// HBM traffic: read + write of out_ch * width floats per stream and tick plus the few samples picked from the ring.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wf_tick_phases.hpp"
+
+namespace wf {
+
+struct WaveArgs {
+    const float *ring;         // [n_streams * cap_ch] rows of ring_stride floats
+    const uint32_t *wpos;      // [n_streams] samples written so far, modulo 2^32
+    uint32_t *cend;            // [n_streams] samples consumed so far (the reference's ring holds wpos - cend samples)
+    unsigned long long *wts;   // [n_streams] m_waveform_ts
+    uint32_t ring_mask, ring_stride;
+    uint32_t delay;            // A/V-sync reserve in frames (dtaudio > 0, :291-292)
+    const uint32_t *delay_stream;
+    float *rows;               // [n_streams][out_ch][width] m_decibels
+    uint32_t *stream_flags;
+    unsigned long long audio_ts; // m_audio_ts: end-of-audio timestamp of the newest captured sample (ns)
+    unsigned long long step_ns;  // (m_meter_ms * 1000000) / width, :299
+    uint32_t waveform_samples; // m_waveform_samples
+    uint32_t width;            // m_fft_size = m_width
+    uint32_t sample_rate;
+    uint32_t n_streams, cap_ch, out_ch;
+    uint32_t stereo, normalize;
+    float vol_comp;
+    const float *vol_comp_stream;
+    float db_min;
+};
+
+constexpr int WAVE_THREADS = 256;
+
+// libobs util_mul_div64 (media-io/audio-io.h helpers are built on it)
+WF_DEV unsigned long long mul_div64(unsigned long long num, unsigned long long mul, unsigned long long div)
+{
+    const unsigned long long rem = num % div;
+    return (num / div) * mul + (rem * mul) / div;
+}
+
+// exact dbfs of the reference (20 * log10f) -- a few hundred points per stream and tick, so the library log is affordable
+WF_DEV float wave_dbfs(float mag, float db_min) { return (mag > 0.0f) ? __fmul_rn(20.0f, log10f(mag)) : db_min; }
+
+__global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wave_lds[]; // old rows [cap_ch][W], then new rows [cap_ch][W]
+    const uint32_t stream = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = a.width;
+    const uint32_t sflags = a.stream_flags[stream];
+    const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
+    float *rows = a.rows + (size_t)stream * a.out_ch * W;
+    const uint32_t disp = a.stereo ? 2u : 1u;
+
+    if(sflags & WF_STREAM_HIDDEN) { // !m_show || capture timed out, :279-288
+        if(was_silent)
+            return;
+        for(uint32_t i = tid; i < disp * W; i += WAVE_THREADS)
+            rows[i] = a.db_min;
+        if(tid == 0)
+            a.stream_flags[stream] = sflags | WF_STREAM_LAST_SILENT;
+        return;
+    }
+    const uint32_t wpos = a.wpos[stream];
+    const uint32_t cend = a.cend[stream];
+    const uint32_t R = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const uint32_t avail = wpos - cend;
+    if(avail <= R) // not enough audio in advance, :293-295
+        return;
+    const uint32_t max_size = a.waveform_samples + R;
+    const uint32_t total = avail < max_size ? avail : max_size; // :303-304
+    const unsigned long long sr = a.sample_rate;
+    const unsigned long long start_ts = a.audio_ts - mul_div64(total, 1000000000ull, sr);
+    const unsigned long long stop_ts = a.audio_ts - mul_div64(R, 1000000000ull, sr);
+    if(start_ts >= a.audio_ts || stop_ts > a.audio_ts)
+        return; // timestamp rollover, :316-317
+    unsigned long long wts = a.wts[stream];
+    if(wts < start_ts)
+        wts = start_ts; // catch up
+    if(wts > stop_ts && (wts - stop_ts) > a.step_ns)
+        wts = start_ts; // fix desync
+    // points this tick adds: ts = wts + i * step_ns while ts < stop_ts, at most W (:322-331)
+    uint32_t counts = 0;
+    if(wts < stop_ts) {
+        const unsigned long long c = (stop_ts - wts + a.step_ns - 1ull) / a.step_ns;
+        counts = c < (unsigned long long)W ? (uint32_t)c : W;
+    }
+    float *old_rows = wave_lds, *new_rows = wave_lds + (size_t)a.cap_ch * W;
+    for(uint32_t c = 0; c < a.cap_ch; ++c)
+        for(uint32_t i = tid; i < W; i += WAVE_THREADS)
+            old_rows[c * W + i] = rows[c * W + i];
+    __syncthreads();
+    // assemble the rotated rows (:332) and look for a non-zero value (:334-343)
+    int nz0 = 0, nz1 = 0;
+    const uint32_t keep = W - counts;
+    for(uint32_t c = 0; c < a.cap_ch; ++c) {
+        const float *x = a.ring + ((size_t)stream * a.cap_ch + c) * a.ring_stride;
+        int nz = 0;
+        for(uint32_t i = tid; i < W; i += WAVE_THREADS) {
+            float v;
+            if(i < keep)
+                v = old_rows[c * W + i + counts];
+            else {
+                const unsigned long long ts = wts + (unsigned long long)(i - keep) * a.step_ns;
+                unsigned long long index = mul_div64(a.audio_ts - ts, sr, 1000000000ull);
+                const unsigned long long lo = (unsigned long long)R + 1ull, hi = total;
+                index = index < lo ? lo : (hi < index ? hi : index);
+                v = x[(wpos - (uint32_t)index) & a.ring_mask]; // temp[total - index]
+            }
+            new_rows[c * W + i] = v;
+            nz |= (v != 0.0f) ? 1 : 0;
+        }
+        if(c == 0) nz0 = nz; else nz1 = nz;
+    }
+    const int any0 = __syncthreads_or(nz0);
+    const int any1 = a.cap_ch > 1 ? __syncthreads_or(nz1) : 0;
+    const bool all_silent = !any0 && (a.cap_ch == 1 || !any1); // every channel's row is zeros -> m_last_silent (:345-349)
+    if(tid == 0) {
+        a.cend[stream] = wpos - R;                               // everything but the reserve has been popped, :321
+        a.wts[stream] = wts + (unsigned long long)counts * a.step_ns; // :351
+        a.stream_flags[stream] = (sflags & ~WF_STREAM_LAST_SILENT) | (all_silent ? WF_STREAM_LAST_SILENT : 0u);
+    }
+    if(all_silent) { // :353-359
+        for(uint32_t i = tid; i < disp * W; i += WAVE_THREADS)
+            rows[i] = a.db_min;
+        // a captured channel that is not displayed keeps its (rotated) raw history
+        for(uint32_t c = disp; c < a.cap_ch; ++c)
+            for(uint32_t i = tid; i < W; i += WAVE_THREADS)
+                rows[c * W + i] = new_rows[c * W + i];
+        return;
+    }
+    const float comp = a.normalize ? (a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp) : 0.0f;
+    const bool mono_mix = !a.stereo && a.cap_ch > 1;
+    for(uint32_t i = tid; i < W; i += WAVE_THREADS) {
+        const bool fresh = i >= keep;
+        float r0 = new_rows[i];
+        const float r1 = a.cap_ch > 1 ? new_rows[W + i] : r0;
+        if(a.out_ch > a.cap_ch) // one captured channel shown twice: row 1 is row 0 *before* its new points are converted,
+            rows[W + i] = r0;   // and its own count is 0, so they stay raw (:361-362, :364-368 with counts[1] == 0)
+        if(fresh) {
+            if(a.stereo || a.cap_ch == 1)
+                r0 = wave_dbfs(__builtin_fabsf(r0), a.db_min);
+            else
+                r0 = wave_dbfs(__fmul_rn(__fadd_rn(__builtin_fabsf(r0), __builtin_fabsf(r1)), 0.5f), a.db_min);
+            if(a.normalize)
+                r0 = __fadd_rn(r0, comp);
+        }
+        rows[i] = r0;
+        if(a.cap_ch > 1) {
+            float o1 = r1;
+            if(fresh && a.stereo) {
+                o1 = wave_dbfs(__builtin_fabsf(r1), a.db_min);
+                if(a.normalize)
+                    o1 = __fadd_rn(o1, comp);
+            }
+            rows[W + i] = o1; // mono display: the raw history of channel 1
+        }
+    }
+    (void)mono_mix;
+}
+
+} // namespace wf
