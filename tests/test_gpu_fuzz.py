@@ -207,3 +207,49 @@ def test_meter_sync_delay_never_unconsumes():
             b.tick(delay_frames=d)
             ora.tick()
             assert_db_close(b.meter()[1], ora.levels(), f"tick {t} delay {d}")
+
+
+# ---- waveform display -----------------------------------------------------------------------------------------------------
+WAVE_CASES = list(range(12))
+
+
+def draw_wave(seed: int):
+    r = np.random.default_rng(9000 + seed)
+    layout = int(r.integers(0, 4))
+    cfg = dict(waveform=1, capture_channels=1 if layout in (0, 3) else 2, stereo=1 if layout in (2, 3) else 0,
+               width=int(r.choice([800, 333, 1024, 64, 2000])), meter_ms=int(r.choice([150, 50, 400, 20])))
+    if r.random() < 0.4:
+        cfg.update(normalize_volume=1, volume_target=float(np.float32(r.uniform(-20.0, -3.0))), max_gain=float(np.float32(r.uniform(6.0, 30.0))))
+    steps = []
+    for _ in range(int(r.integers(6, 14))):
+        for _ in range(int(r.integers(0, 3))):
+            steps.append(("noise_amp", int(r.choice([800, 441, 1024, 37])), float(np.float32(r.choice([1.0, 0.2])))))
+        steps.append(("tick",))
+    kind = int(r.integers(0, 3))
+    if kind == 0:
+        steps += [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",), ("noise", 800), ("tick",)]
+    elif kind == 1:
+        steps += [("timeout",), ("tick",), ("noise", 800), ("tick",), ("noise", 800), ("tick",)]
+    else:
+        steps += [("silence", 1024)] * 8 + [("tick",), ("noise", 800), ("tick",)]
+    return cfg, steps, int(r.choice([0, 0, 5, 20]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", WAVE_CASES)
+def test_hip_waveform_matches_oracle_on_random_case(seed):
+    cfg_dict, steps, sync_ms = draw_wave(seed)
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
+    rms = 0.0316 if cfg.normalize_volume else 0.0
+    hip = scenarios.HipBackend(cfg, streams=3, probe=0, input_rms=rms)
+    ora = scenarios.OracleBackend(cfg, input_rms=rms)
+    try:
+        got = scenarios.play(hip, sc)
+        want = scenarios.play(ora, sc)
+    finally:
+        hip.close()
+    assert len(got) == len(want)
+    for t, (g, w) in enumerate(zip(got, want)):
+        assert g["silent"] == w["silent"], f"wave case {seed} tick {t}: m_last_silent {g['silent']} != {w['silent']} ({cfg_dict})"
+        assert_db_close(g["db"], w["db"], f"wave case {seed} tick {t} rows ({cfg_dict}, sync {sync_ms} ms)")
