@@ -83,7 +83,8 @@ const char *wf_hip_last_error(const wf_hip *h);
 /* ---- lifetime ----------------------------------------------------------------------- */
 /* max_streams: batch size (independent WAVSource instances sharing cfg).
  * ring_frames: capacity of each per-channel device ring in samples; 0 = default
- *              (smallest power of two >= 2 * fft_size). Rounded up to a power of two. */
+ *              (smallest power of two >= max(2 * fft_size, 4096)). Rounded up to a power of two.  A packet longer than
+ *              the ring keeps its newest ring_frames samples. */
 int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32_t ring_frames, wf_hip **out);
 void wf_hip_destroy(wf_hip *h);
 /* re-initialise streams [first, first+count): smoothing state 0, decibels DB_MIN, rings = N zeros */

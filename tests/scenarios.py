@@ -96,6 +96,15 @@ SCENARIOS = {
     # muted packets are pushed as zeros (src/source.cpp:1879-1880)
     "muted_packets": dict(cfg=dict(fft_size=1024, stereo=1, tsmoothing=0), steps=_steps(2) + [("mute", 800), ("tick",), ("noise", 800), ("tick",)],
                           record="all"),
+    # ---- FFT sizes below the smallest geometry run zero-padded on the 1024-point one (512, 256, 128 = the slider's minimum)
+    "small_512_stereo_bars": dict(cfg=dict(fft_size=512, stereo=1, slope=1.0, bars=1, interp_mode=1), steps=_steps(6), record=2),
+    "small_256_mono_mix_tv": dict(cfg=dict(fft_size=256, stereo=0, tsmoothing=2, fast_peaks=1, window=3, rolloff_q=1.5, rolloff_rate=12.0),
+                                  steps=[("noise", 441), ("tick",)] * 4 + [("noise", 1024), ("tick",), ("noise", 3), ("tick",)], record=3),
+    "small_128_single_dup_curve": dict(cfg=dict(fft_size=128, stereo=1, capture_channels=1, curve=1, interp_mode=2, width=300, tsmoothing=0),
+                                       steps=_steps(4), record=2),
+    "small_512_silence_cycle": dict(cfg=dict(fft_size=512, stereo=1, gravity=0.2),
+                                    steps=_steps(3) + [("silence", 800), ("tick",)] * 15 + _steps(2) + [("hide",), ("noise", 800), ("tick",), ("show",)]
+                                    + _steps(2), record="all"),
     # ---- the largest geometry runs the channels of a stereo stream in different workgroups (split mode): everything that
     # couples the channels, at N = 16384
     "split_16384_silence_cycle": dict(cfg=dict(fft_size=16384, stereo=1, gravity=0.2),

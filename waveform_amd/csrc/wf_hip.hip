@@ -164,6 +164,32 @@ template<class G> int setup_launch_split(wf_hip *h)
     return WF_HIP_OK;
 }
 
+// FFT sizes 512 / 256 / 128 on the 1024-point geometry, zero-padded (spectrum_tick_kernel<.., DEC>)
+template<class G, int DEC> void launch_tick_dec(wf_hip *h, const wf::TickArgs &a, bool aligned)
+{
+    const uint32_t n_spec = a.n_streams * a.cap_ch;
+    const dim3 grid((n_spec + 1) / 2), block(G::T * 2);
+    const size_t lds = wf::tick_lds_bytes<G, 2>();
+    if(aligned)
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, true, false, DEC>), grid, block, lds, h->stream, a);
+    else
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, false, false, DEC>), grid, block, lds, h->stream, a);
+}
+
+template<class G, int DEC> int setup_launch_dec(wf_hip *h)
+{
+    const int lds = (int)wf::tick_lds_bytes<G, 2>();
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 2, true, false, DEC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 2, false, false, DEC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick_dec<G, DEC>;
+    char name[96];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d zero-padded to %d,T=%d,R=%dx%dx%d,SPW=2>", G::N >> DEC, G::N, G::T, G::R1, G::R2, G::R3);
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
 template<class G, int SPW> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     const uint32_t n_spec = a.n_streams * a.cap_ch;
@@ -354,8 +380,9 @@ int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, c
 {
     if(frames == 0)
         return WF_HIP_OK;
-    if(frames > h->ring_cap)
-        return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the ring capacity %u", frames, h->ring_cap);
+    // a packet longer than the ring keeps its newest ring_cap frames, as CircularBuffer + capture_audio's trimming would
+    if(h->d_rms_ring && frames > h->rms_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the RMS ring capacity %u", frames, h->rms_cap);
     const dim3 grid((frames + 255) / 256 > 64 ? 64 : (frames + 255) / 256, count * h->cap_ch), block(256);
     hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->ring_stride, h->cap_ch, first,
                        d_src, frames);
@@ -407,7 +434,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     cfg = &cfg_eff;
     int rc = wf::build_host_tables(*cfg, tab);
     if(rc == WF_HIP_ERR_UNSUPPORTED)
-        return fail(nullptr, rc, "fft_size %u: only powers of two in 1024..16384 are implemented", cfg->fft_size);
+        return fail(nullptr, rc, "fft_size %u: only powers of two in 128..16384 are implemented", cfg->fft_size);
     if(rc)
         return fail(nullptr, rc, "invalid configuration");
     const int ndev = wf_hip_device_count();
@@ -429,7 +456,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     h->out_ch = h->tab.output_channels;
     h->disp_ch = h->tab.display_channels;
     h->num_bars = (uint32_t)h->tab.num_bars;
-    h->ring_cap = next_pow2(ring_frames ? std::max(ring_frames, h->N) : 2 * h->N);
+    h->ring_cap = next_pow2(ring_frames ? std::max(ring_frames, h->N) : std::max(2 * h->N, 4096u));
     if(cfg->waveform) {
         // rows of `width` points; the ring holds the history the points are picked from (+ the width zeros of update())
         h->wave = true;
@@ -551,7 +578,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         // LDS scratch for the products: what is left of a spectrum's exchange buffer behind the M dB values
         size_t lds_floats = 0;
         int threads = 64;
-        wf::dispatch_geometry(h->N, [&](auto g) {
+        wf::dispatch_geometry(std::max(h->N, 1024u), [&](auto g) {
             using G = decltype(g);
             lds_floats = (size_t)G::LDS_CF * 2;
             threads = G::T;
@@ -564,7 +591,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             lpb *= 2;
         h->bar_lpb = lpb;
         int points = 16;
-        wf::dispatch_geometry(h->N, [&](auto g) { points = decltype(g)::P; });
+        wf::dispatch_geometry(std::max(h->N, 1024u), [&](auto g) { points = decltype(g)::P; });
         const int kmax = threads <= 64 ? 16 : 8; // wf::OutVals<G>::KMAX
         h->curve = !cfg->bars && cfg->curve;
         if(h->curve) {
@@ -608,11 +635,18 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     // FFT plan: twiddle tables for the geometry of this fft_size + the kernel instantiation
     int setup_rc = WF_HIP_ERR_UNSUPPORTED;
     std::vector<wf::cfloat> tw1, tw2, tws;
-    wf::dispatch_geometry(h->N, [&](auto g) {
+    wf::dispatch_geometry(std::max(h->N, 1024u), [&](auto g) {
         using G = decltype(g);
         wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
         // the channels of a stream share a workgroup (silence state machine, mono mixdown)
-        if constexpr(G::T >= 256)
+        if constexpr(G::N == 1024) {
+            switch(h->N) {
+            case 512: setup_rc = setup_launch_dec<G, 1>(h); break;
+            case 256: setup_rc = setup_launch_dec<G, 2>(h); break;
+            case 128: setup_rc = setup_launch_dec<G, 3>(h); break;
+            default: setup_rc = setup_launch<G, 2>(h); break;
+            }
+        } else if constexpr(G::T >= 256)
             setup_rc = want_split ? setup_launch_split<G>(h) : (cfg->capture_channels > 1) ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
         else
             setup_rc = setup_launch<G, 2>(h);
@@ -793,8 +827,8 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
         return rc;
     if(frames == 0)
         return WF_HIP_OK;
-    if(frames > h->ring_cap)
-        return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the ring capacity %u", frames, h->ring_cap);
+    if(h->d_rms_ring && frames > h->rms_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the RMS ring capacity %u", frames, h->rms_cap);
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t gx = std::min<uint32_t>((frames + 255) / 256, 256);
     hipLaunchKernelGGL(wf::ring_synth_kernel, dim3(gx, count * h->cap_ch), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,

@@ -72,6 +72,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #endif
 #define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 8) ? WF_WPS_SMALL : 4)
 
+#ifndef WF_EARLY_TOUCH
+#define WF_EARLY_TOUCH 0
+#endif
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \
     do {                                                                                 \
@@ -98,12 +101,21 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // rare all-zero channel gets the partner's facts without racing it: "has a non-zero sample" by scanning the partner's
 // window itself, "previous row entirely <= floor - 10" and m_last_silent from words the *previous* tick left (verdict_in,
 // stream_flags) while this tick writes the next tick's copies (verdict_out, flags_out).
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false>
+//
+// DEC > 0: FFT sizes below the smallest geometry (N >> DEC = 512, 256, 128 on the 1024-point one).  The N >> DEC samples are
+// transformed zero-padded to N points -- bin o of the small transform is bin o << DEC of the padded one, exactly -- so
+// passes 1-3 run unchanged on the rows that hold samples and the epilogue keeps every (1 << DEC)-th bin: the first
+// (M >> DEC) / 4 threads of the spectrum own four consecutive output bins each; rows, state and tables have M >> DEC entries.
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0>
 __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
     static_assert(!SPLIT || SPW == 1, "split mode: one spectrum per workgroup");
+    static_assert(DEC == 0 || (!SPLIT && G::T == 64 && (G::R1 >> DEC) >= 1 && (G::M >> DEC) >= 64), "decimated path: one-wavefront geometry");
+    constexpr int MO = G::M >> DEC;                        // bins per output row
+    using RG = RowG<DEC ? MO / 4 : G::T, DEC ? 4 : G::P>;  // threads x bins per thread that own the output rows
+    constexpr int RP = RG::P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int T = G::T, M = G::M, P = G::P, WPS = G::T / 64;
+    constexpr int T = G::T, P = G::P, WPS = G::T / 64;
     const int tid = (int)threadIdx.x;
     const int sub = __builtin_amdgcn_readfirstlane(tid / T); // which spectrum of the workgroup (wave-uniform: T % 64 == 0)
     const int t = tid % T;            // thread within the spectrum
@@ -135,9 +147,10 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
     const float *x = a.ring + (size_t)spec * a.ring_stride;
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
-    const uint32_t start = (wpos - delay - (uint32_t)G::N) & a.ring_mask;
-    float *ts = a.tsmooth + (size_t)spec * M;
-    float *rows = a.decibels + (size_t)stream * a.out_ch * M; // m_decibels[0..out_ch) of this stream
+    const uint32_t start = (wpos - delay - (uint32_t)(G::N >> DEC)) & a.ring_mask;
+    float *ts = a.tsmooth + (size_t)spec * MO;
+    float *rows = a.decibels + (size_t)stream * a.out_ch * MO; // m_decibels[0..out_ch) of this stream
+    const bool row_thread = DEC == 0 || t < RG::T;             // this thread owns bins of the output row
 
     const bool hidden = (sflags & WF_STREAM_HIDDEN) != 0;
     const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
@@ -149,7 +162,12 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     P1Regs<G> r1;
     bool nz = false;
     if(active)
-        nz = p1_fetch<G, ALIGNED>(a, t, x, start, r1) && !hidden;
+        nz = p1_fetch<G, ALIGNED, DEC>(a, t, x, start, r1) && !hidden;
+#if WF_EARLY_TOUCH
+    P4Regs<G> r4;
+    if(Policy<G>::TOUCH_STATE)
+        p4_prefetch<G>(a, t, ts, r4); // the state row's lines requested right behind the window
+#endif
     // the workgroup's copy of the pass-2 twiddles: LDS-DMA (no staging registers), requested behind the window so that it
     // costs no round trip of its own; complete at the barrier below
     lds_dma_copy<G::R2 * G::R3 * (int)sizeof(cf)>(a.tw2, tw2_lds, wave_in_block, T * SPW / 64, lane);
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(1);
     bool wave_below = true;
     if(active && !hidden && !wave_nz) // wave-uniform and rare: the whole slice of this wave is digital silence
-        wave_below = __all(row_all_below<G>(rows + (size_t)(stereo ? ch : 0u) * M, t, a.silent_floor)) != 0;
+        wave_below = __all(!row_thread || row_all_below<RG>(rows + (size_t)(stereo ? ch : 0u) * MO, t, a.silent_floor)) != 0;
 
     bool nz0 = wave_nz, nz1 = false, below0 = wave_below, below1 = true;
     if(lane == 0)
@@ -215,12 +233,17 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 
     // ---- the FFT path --------------------------------------------------------------------------------------
     cf v[P];
-    float mag[P];
+    float mag[RP];
     WF_STAMP(2);
+#if !WF_EARLY_TOUCH
     P4Regs<G> r4;
+#endif
     if(process) {
         p1_window_pass1<G>(a, t, r1, lds);
-        p4_prefetch<G>(a, t, ts, r4);
+        if constexpr(DEC > 0)
+            p4_prefetch_dec<G, DEC>(a, t, ts, r4);
+        else if(!WF_EARLY_TOUCH || !Policy<G>::TOUCH_STATE)
+            p4_prefetch<G>(a, t, ts, r4);
     }
     __builtin_amdgcn_sched_barrier(0); // keep the prefetch up here: do not sink it to its first use in P4
     WF_STAMP(3);
@@ -243,22 +266,27 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     spectrum_sync<G>();
     WF_STAMP(8);
     if(process) {
-        p4_split_smooth<G>(a, t, lds, ts, r1.wb, r4, mag);
-        if(Policy<G>::TOUCH_STATE)
-            asm volatile("" ::"v"(r4.touch[0]), "v"(r4.touch[1])); // the touched dwords are only ever waited for
-    } else if(do_db && !(mono_mix && ch == 1))
-        load_row<G>(rows + (size_t)ch * M, t, mag); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
+        if constexpr(DEC > 0) {
+            if(row_thread)
+                p4_split_smooth_dec<G, DEC>(a, t, lds, ts, r1.wb, r4, mag);
+        } else {
+            p4_split_smooth<G>(a, t, lds, ts, r1.wb, r4, mag);
+            if(Policy<G>::TOUCH_STATE)
+                asm volatile("" ::"v"(r4.touch[0]), "v"(r4.touch[1])); // the touched dwords are only ever waited for
+        }
+    } else if(do_db && !(mono_mix && ch == 1) && row_thread)
+        load_row<RG>(rows + (size_t)ch * MO, t, mag); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
 
     // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------
     if(active && hidden && !was_silent) {
-        if(a.mode & WF_MODE_TSMOOTH)
-            fill_row<G>(ts, t, 0.0f);
+        if((a.mode & WF_MODE_TSMOOTH) && row_thread)
+            fill_row<RG>(ts, t, 0.0f);
         if(ch < (stereo ? 2u : 1u)) {
             const bool dup = a.out_ch > a.cap_ch; // one captured channel shown as two rows
-            if(!a.skip_decibels) {
-                fill_row<G>(rows + (size_t)ch * M, t, a.db_min);
+            if(!a.skip_decibels && row_thread) {
+                fill_row<RG>(rows + (size_t)ch * MO, t, a.db_min);
                 if(dup)
-                    fill_row<G>(rows + (size_t)M, t, a.db_min);
+                    fill_row<RG>(rows + (size_t)MO, t, a.db_min);
             }
             if(a.bar.out != nullptr) {
                 // what render_bars makes of rows of DB_MIN: every bar at border_bottom
@@ -274,17 +302,17 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         // dB[0][i] = dbfs((dB[0][i] + dB[1][i]) * 0.5f): channel 1 hands its magnitudes to channel 0 through LDS
         float *xch = reinterpret_cast<float *>(lds);
         __syncthreads();
-        if(do_db && ch == 1) {
+        if(do_db && ch == 1 && row_thread) {
 #pragma unroll
-            for(int u = 0; u < P / 4; ++u)
-                *reinterpret_cast<f4 *>(xch + 4 * (t + T * u)) = f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]};
+            for(int u = 0; u < RP / 4; ++u)
+                *reinterpret_cast<f4 *>(xch + 4 * (t + RG::T * u)) = f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]};
         }
         __syncthreads();
-        if(do_db && ch == 0) {
+        if(do_db && ch == 0 && row_thread) {
             const float *other = reinterpret_cast<const float *>(lds + G::LDS_CF);
 #pragma unroll
-            for(int u = 0; u < P / 4; ++u) {
-                const f4 o = *reinterpret_cast<const f4 *>(other + 4 * (t + T * u));
+            for(int u = 0; u < RP / 4; ++u) {
+                const f4 o = *reinterpret_cast<const f4 *>(other + 4 * (t + RG::T * u));
                 mag[4 * u] = (mag[4 * u] + o.x) * 0.5f;
                 mag[4 * u + 1] = (mag[4 * u + 1] + o.y) * 0.5f;
                 mag[4 * u + 2] = (mag[4 * u + 2] + o.z) * 0.5f;
@@ -299,13 +327,13 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
-    float d[P];
-    if(have_row) {
-        p4_db<G>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp);
+    float d[RP];
+    if(have_row && row_thread) {
+        p4_db<RG>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp);
         if(!a.skip_decibels) {
-            store_row<G>(rows + (size_t)ch * M, t, d);
+            store_row<RG>(rows + (size_t)ch * MO, t, d);
             if(dup_row)
-                store_row<G>(rows + (size_t)M, t, d);
+                store_row<RG>(rows + (size_t)MO, t, d);
         }
     }
     WF_STAMP(10);
@@ -317,7 +345,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         bool exceeds = false;
         if(have_row) {
 #pragma unroll
-            for(int i = 0; i < P; ++i)
+            for(int i = 0; i < RP; ++i)
                 exceeds = exceeds || (d[i] > a.silent_floor);
         } else if(!(hidden && !was_silent)) // row untouched this tick (the reset branch leaves DB_MIN everywhere: below)
             exceeds = (ch == 0 ? vin0 : vin1) != 0u;
@@ -331,8 +359,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     if(a.bar.out != nullptr) {
         float *dbl = reinterpret_cast<float *>(lds);
         spectrum_sync<G>(); // every thread of the spectrum is done reading its exchange buffer
-        if(have_row)
-            store_row<G>(dbl, t, d);
+        if(have_row && row_thread)
+            store_row<RG>(dbl, t, d);
         spectrum_sync<G>();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
         float *out1 = dup_row ? out0 + a.bar.num_bars : nullptr;
@@ -349,7 +377,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             curve_row<G>(bar_args, have_row, dbl, t, ov);
         else
             pending = bars_reduce_row<G>(
-                bar_args, bar_pre, bar_entries, have_row, dbl, dbl + M, t, out0, out1, ov, [] { spectrum_sync<G>(); },
+                bar_args, bar_pre, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
                 [](float v, int m) { return v + __shfl_xor(v, m, 64); });
         if(pending)
             outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
@@ -366,7 +394,8 @@ __global__ void ring_push_kernel(float *ring, const uint32_t *wpos, uint32_t rin
     const uint32_t stream = first + row / cap_ch;
     const uint32_t w = wpos[stream];
     float *dst = ring + ((size_t)stream * cap_ch + row % cap_ch) * ring_stride;
-    for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frames; i += gridDim.x * blockDim.x)
+    const uint32_t skip = frames > ring_cap ? frames - ring_cap : 0u; // a packet longer than the ring: only its tail survives
+    for(uint32_t i = skip + blockIdx.x * blockDim.x + threadIdx.x; i < frames; i += gridDim.x * blockDim.x)
         dst[(w + i) & (ring_cap - 1)] = src ? src[(size_t)row * frames + i] : 0.0f;
 }
 
@@ -379,7 +408,8 @@ __global__ void ring_synth_kernel(float *ring, const uint32_t *wpos, uint32_t ri
     const uint32_t w = wpos[stream];
     float *dst = ring + ((size_t)stream * cap_ch + c) * ring_stride;
     const uint64_t key = wf_synth_key(seed, stream_id0 + s, c);
-    for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frames; i += gridDim.x * blockDim.x)
+    const uint32_t skip = frames > ring_cap ? frames - ring_cap : 0u;
+    for(uint32_t i = skip + blockIdx.x * blockDim.x + threadIdx.x; i < frames; i += gridDim.x * blockDim.x)
         dst[(w + i) & (ring_cap - 1)] = wf_synth_sample(key, index0 + i);
 }
 

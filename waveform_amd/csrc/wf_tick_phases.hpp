@@ -284,14 +284,25 @@ template<class G> WF_DEV void p1_load_tw1(const TickArgs &a, int t, int k1, floa
 }
 
 // returns whether any sample of this thread is non-zero (the reference's silence scan, :63-72)
-template<class G, bool ALIGNED>
+// DEC > 0 (FFT sizes below the smallest geometry): the window is the first N >> DEC samples of a zero-padded N-point
+// transform -- rows j >= R1 >> DEC of every thread are zeros and are not loaded -- and the real-split twiddles are those of
+// the bins the small transform keeps, k = (4t + i) << DEC.
+template<class G, bool ALIGNED, int DEC = 0>
 WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
 {
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    constexpr int RV = R1 >> DEC; // rows that hold samples
+    static_assert(RV >= 1, "zero-padding leaves at least one row of samples per thread");
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
         const uint32_t s0 = 2u * (uint32_t)(j * M1 + B1 * t);
-        if(ALIGNED) {
+        if(j >= RV) {
+            WF_UNROLL
+            for(int e = 0; e < 2 * B1; ++e) {
+                r.smp[j][e] = 0.0f;
+                r.win[j][e] = 0.0f;
+            }
+        } else if(ALIGNED) {
             if(B1 == 2) {
                 const f4 q = ld4(x + ((start + s0) & a.ring_mask));
                 r.smp[j][0] = q.x; r.smp[j][1] = q.y; r.smp[j][2 * B1 - 2] = q.z; r.smp[j][2 * B1 - 1] = q.w;
@@ -307,13 +318,23 @@ WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P
     }
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
-        p1_load_window<G>(a, t, j, r.win[j]);
+        if(j < RV)
+            p1_load_window<G>(a, t, j, r.win[j]);
         if(j >= 1 && (!WF_TW1_POWERS || j == 1))
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
     }
-    const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + 4 * t));
-    const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + 4 * t + 2));
-    r.wb[0] = cf{wa.x, wa.y}; r.wb[1] = cf{wa.z, wa.w}; r.wb[2] = cf{wc.x, wc.y}; r.wb[3] = cf{wc.z, wc.w};
+    if(DEC == 0) {
+        const f4 wa = ld4(reinterpret_cast<const float *>(a.tws + 4 * t));
+        const f4 wc = ld4(reinterpret_cast<const float *>(a.tws + 4 * t + 2));
+        r.wb[0] = cf{wa.x, wa.y}; r.wb[1] = cf{wa.z, wa.w}; r.wb[2] = cf{wc.x, wc.y}; r.wb[3] = cf{wc.z, wc.w};
+    } else {
+        WF_UNROLL
+        for(int i = 0; i < 4; ++i) {
+            const int k = ((4 * t + i) << DEC) & (G::M - 1); // threads beyond the kept bins read a valid entry they never use
+            const f2 w = ld2(reinterpret_cast<const float *>(a.tws + k));
+            r.wb[i] = cf{w.x, w.y};
+        }
+    }
     // x != 0.0f for any sample: OR the bit patterns, drop the sign bit (-0.0f == 0.0f); NaNs have non-zero bits
     uint32_t acc = 0;
     WF_UNROLL
@@ -689,6 +710,63 @@ WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, 
             p4_split_smooth_impl<G, true, false>(a, t, lds, ts, wb, q, mag);
     } else
         p4_split_smooth_impl<G, false, false>(a, t, lds, ts, wb, q, mag);
+}
+
+// ---- decimated epilogue (DEC > 0): the N >> DEC point transform's bin o is bin o << DEC of the zero-padded one --------------
+// Row geometry of the outputs: MO = M >> DEC bins, the first MO / 4 threads own four consecutive ones each.
+template<int TT, int PP> struct RowG { static constexpr int T = TT, P = PP; };
+
+template<class G, int DEC> WF_DEV void p4_prefetch_dec(const TickArgs &a, int t, const float *ts, P4Regs<G> &q)
+{
+    static_assert(Policy<G>::PREFETCH_STATE && Policy<G>::PREFETCH_SLOPE, "the decimated path runs on a one-wavefront geometry");
+    constexpr int TO = (G::M >> DEC) / 4;
+    const int tt = t < TO ? t : 0;
+    if(a.mode & WF_MODE_TSMOOTH) {
+        const f4 o = ld4(ts + 4 * tt);
+        q.st[0] = o.x; q.st[1] = o.y; q.st[2] = o.z; q.st[3] = o.w;
+    }
+    const f4 sv = ld4(a.slope + 4 * tt);
+    q.sl[0] = sv.x; q.sl[1] = sv.y; q.sl[2] = sv.z; q.sl[3] = sv.w;
+}
+
+template<class G, int DEC, bool TS, bool FPK>
+WF_DEV void p4_split_smooth_dec_impl(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[4])
+{
+    constexpr int M = G::M;
+    WF_UNROLL
+    for(int i = 0; i < 4; ++i) {
+        const int k = (4 * t + i) << DEC;
+        const cf A = lds_ld2(lds, ex3_addr<G>(k));
+        const cf B = lds_ld2(lds, ex3_addr<G>((M - k) & (M - 1)));
+        const cf W = wb[i];
+        const float er = A.x + B.x, ei = A.y - B.y;
+        const float dr = A.x - B.x, di = A.y + B.y;
+        const float pr = fmaf(W.x, dr, -(W.y * di));
+        const float pi = fmaf(W.x, di, W.y * dr);
+        const float xr = er + pi, xi = ei - pr;
+        float m = mag2(xr, xi) * a.half_coef;
+        m *= q.sl[i];
+        if(TS) {
+            float old = q.st[i];
+            if(FPK)
+                old = fmaxf(m, old);
+            m = fmaf(a.g, old, a.g2 * m);
+        }
+        mag[i] = m;
+    }
+    if(TS)
+        st4(ts + 4 * t, f4{mag[0], mag[1], mag[2], mag[3]});
+}
+template<class G, int DEC>
+WF_DEV void p4_split_smooth_dec(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[4])
+{
+    if(a.mode & WF_MODE_TSMOOTH) {
+        if(a.mode & WF_MODE_FAST_PEAKS)
+            p4_split_smooth_dec_impl<G, DEC, true, true>(a, t, lds, ts, wb, q, mag);
+        else
+            p4_split_smooth_dec_impl<G, DEC, true, false>(a, t, lds, ts, wb, q, mag);
+    } else
+        p4_split_smooth_dec_impl<G, DEC, false, false>(a, t, lds, ts, wb, q, mag);
 }
 
 // dB conversion + volume normalisation + roll-off of this thread's bins (reference :144-179); d[] is the
