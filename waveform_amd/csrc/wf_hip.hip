@@ -190,29 +190,46 @@ template<class G, int DEC> int setup_launch_dec(wf_hip *h)
     return WF_HIP_OK;
 }
 
-template<class G, int SPW> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
+template<class G, int SPW, bool TLDS> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     const uint32_t n_spec = a.n_streams * a.cap_ch;
     const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
     const size_t lds = wf::tick_lds_bytes<G, SPW>();
     if(aligned)
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true>), grid, block, lds, h->stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS>), grid, block, lds, h->stream, a);
     else
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false>), grid, block, lds, h->stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS>), grid, block, lds, h->stream, a);
 }
 
-template<class G, int SPW> int setup_launch(wf_hip *h)
+template<class G, int SPW, bool TLDS> int setup_launch_impl(wf_hip *h)
 {
     const int lds = (int)wf::tick_lds_bytes<G, SPW>();
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true>),
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false>),
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    h->launch = &launch_tick<G, SPW>;
+    h->launch = &launch_tick<G, SPW, TLDS>;
     char name[96];
-    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=%d>", G::N, G::T, G::R1, G::R2, G::R3, SPW);
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=%d%s>", G::N, G::T, G::R1, G::R2, G::R3, SPW,
+             TLDS ? ",tables via LDS" : "");
     h->kernel_name = name;
     return WF_HIP_OK;
+}
+
+// Workgroups of two spectra can stage the window / pass-1 twiddle tables in LDS once (spectrum_tick_kernel<.., TLDS>).
+// Measured on MI355X (interleaved A/B): N = 1024 63.4 -> 68.7 % of the HBM peak (8-byte table loads, 23 per thread, become
+// 8 DMA requests per wavefront), N = 2048 +-1 %, N = 4096 -1.5 % (the extra barrier costs what the halved table traffic
+// saves), N = 8192 +1 %: on for the 8-point geometry only.  WF_HIP_TLDS=0/1 overrides (development aid).
+template<class G, int SPW> int setup_launch(wf_hip *h)
+{
+    if constexpr(SPW == 2) {
+        bool tlds = G::P <= 8;
+        if(const char *e = std::getenv("WF_HIP_TLDS"))
+            tlds = e[0] == '1';
+        if(tlds)
+            return setup_launch_impl<G, 2, true>(h);
+    }
+    return setup_launch_impl<G, SPW, false>(h);
 }
 
 uint32_t next_pow2(uint32_t v)

@@ -106,9 +106,17 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // transformed zero-padded to N points -- bin o of the small transform is bin o << DEC of the padded one, exactly -- so
 // passes 1-3 run unchanged on the rows that hold samples and the epilogue keeps every (1 << DEC)-th bin: the first
 // (M >> DEC) / 4 threads of the spectrum own four consecutive output bins each; rows, state and tables have M >> DEC entries.
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0>
+//
+// TLDS (SPW == 2): the two spectra of a workgroup use the same window and pass-1 twiddle operands, thread for thread.
+// Instead of every thread loading its 2 * R1 - 1 table vectors (two thirds of the fetch burst's bytes through the
+// vector-memory path, twice per workgroup), the workgroup copies both tables once by LDS-DMA into the exchange buffers --
+// free until pass 1 stores into them -- and the threads take their operands from LDS; one more barrier separates those
+// reads from pass 1's stores.
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false>
 __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
+    static_assert(!TLDS || (SPW == 2 && !SPLIT && DEC == 0 && (size_t)SPW * G::LDS_CF * sizeof(cf) >= 2u * G::N * sizeof(float)),
+                  "staged tables: window + pass-1 twiddles must fit the workgroup's exchange buffers");
     static_assert(!SPLIT || SPW == 1, "split mode: one spectrum per workgroup");
     static_assert(DEC == 0 || (!SPLIT && G::T == 64 && (G::R1 >> DEC) >= 1 && (G::M >> DEC) >= 64), "decimated path: one-wavefront geometry");
     constexpr int MO = G::M >> DEC;                        // bins per output row
@@ -162,7 +170,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     P1Regs<G> r1;
     bool nz = false;
     if(active)
-        nz = p1_fetch<G, ALIGNED, DEC>(a, t, x, start, r1) && !hidden;
+        nz = p1_fetch<G, ALIGNED, DEC, TLDS>(a, t, x, start, r1) && !hidden;
+    if constexpr(TLDS) {
+        lds_dma_copy<G::N * (int)sizeof(float)>(a.window, smem_raw, wave_in_block, T * SPW / 64, lane);
+        lds_dma_copy<G::M * (int)sizeof(cf)>(a.tw1, smem_raw + G::N * sizeof(float), wave_in_block, T * SPW / 64, lane);
+    }
 #if WF_EARLY_TOUCH
     P4Regs<G> r4;
     if(Policy<G>::TOUCH_STATE)
@@ -238,8 +250,19 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 #if !WF_EARLY_TOUCH
     P4Regs<G> r4;
 #endif
+    if constexpr(TLDS) {
+        cf o1[G::R1][G::B1];
+        if(process) {
+            p1_tables_from_lds<G>(t, reinterpret_cast<const cf *>(smem_raw), r1);
+            p1_window_dft<G>(r1, o1);
+        }
+        __syncthreads(); // every thread has taken its operands: pass 1 may overwrite the staged tables
+        if(process)
+            p1_store<G>(t, lds, o1);
+    }
     if(process) {
-        p1_window_pass1<G>(a, t, r1, lds);
+        if constexpr(!TLDS)
+            p1_window_pass1<G>(a, t, r1, lds);
         if constexpr(DEC > 0)
             p4_prefetch_dec<G, DEC>(a, t, ts, r4);
         else if(!WF_EARLY_TOUCH || !Policy<G>::TOUCH_STATE)

@@ -241,19 +241,10 @@ template<class G> struct Policy {
     static constexpr bool PREFETCH_SLOPE = (MODE == 1);
     static constexpr bool TOUCH_STATE = (MODE == 2);
 };
-// WF_TW1_POWERS (experiment, off): the pass-1 twiddles W_M^(n' k1), k1 = 2..R1-1, as powers of the k1 = 1 row (<= log2(R1)
-// complex multiplications deep) instead of R1-2 more table rows per thread: a third fewer vector loads in the fetch burst
-// and 3-9 % faster at every size (N = 1024: 60 -> 65.5 % of peak, 4096: 63-66 -> 65-68 %, 16384: 53 -> 56.5 %) -- but the
-// k-th power carries ~k/2 ulp of the table entry's rounding error (4.5e-7 at k = 15), and a bin 60 dB below its neighbours
-// (they occur: white noise has Rayleigh-distributed magnitudes) then misses the 1e-5 relative tolerance (2.7e-5 seen).
-// Parity first: the table rows stay.
-#ifndef WF_TW1_POWERS
-#define WF_TW1_POWERS 0
-#endif
 template<class G> struct P1Regs {
     float smp[G::R1][2 * G::B1];
     float win[G::R1][2 * G::B1];
-    float tw1[WF_TW1_POWERS ? 2 : G::R1][2 * G::B1]; // row k1 (all rows), or only row 1
+    float tw1[G::R1][2 * G::B1];
     cf wb[4];
 };
 
@@ -287,7 +278,8 @@ template<class G> WF_DEV void p1_load_tw1(const TickArgs &a, int t, int k1, floa
 // DEC > 0 (FFT sizes below the smallest geometry): the window is the first N >> DEC samples of a zero-padded N-point
 // transform -- rows j >= R1 >> DEC of every thread are zeros and are not loaded -- and the real-split twiddles are those of
 // the bins the small transform keeps, k = (4t + i) << DEC.
-template<class G, bool ALIGNED, int DEC = 0>
+// TLDS: the window and pass-1 twiddle tables are not loaded here -- the workgroup stages them in LDS (p1_tables_to_lds).
+template<class G, bool ALIGNED, int DEC = 0, bool TLDS = false>
 WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
 {
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
@@ -318,9 +310,9 @@ WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P
     }
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
-        if(j < RV)
+        if(j < RV && !TLDS)
             p1_load_window<G>(a, t, j, r.win[j]);
-        if(j >= 1 && (!WF_TW1_POWERS || j == 1))
+        if(j >= 1 && !TLDS)
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
     }
     if(DEC == 0) {
@@ -346,15 +338,15 @@ WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P
     return (acc & 0x7fffffffu) != 0;
 }
 
+// window multiply (reference :97-103; the table is all ones for FFTWindow::NONE: x * 1.0f == x), butterflies over n1 (= j),
+// twiddle by W_M^(n' k1): o[k1][b] = A'[k1][n' + b]
 template<class G>
-WF_DEV void p1_window_pass1(const TickArgs &a, int t, P1Regs<G> &r, cf *lds)
+WF_DEV void p1_window_dft(P1Regs<G> &r, cf (&o)[G::R1][G::B1])
 {
     constexpr int R1 = G::R1, B1 = G::B1;
-    (void)a;
     cf u[B1][R1];
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
-        // in[i] *= window[i] (reference :97-103); the table is all ones for FFTWindow::NONE (x * 1.0f == x)
         WF_UNROLL
         for(int e = 0; e < 2 * B1; ++e)
             r.smp[j][e] *= r.win[j][e];
@@ -362,40 +354,60 @@ WF_DEV void p1_window_pass1(const TickArgs &a, int t, P1Regs<G> &r, cf *lds)
         for(int b = 0; b < B1; ++b)
             u[b][j] = cf{r.smp[j][2 * b], r.smp[j][2 * b + 1]};
     }
-    // butterflies over n1 (= j), twiddle by W_M^(n' k1), store A'[k1][n']
     WF_UNROLL
     for(int b = 0; b < B1; ++b)
         dft_dif<R1>(u[b]);
     constexpr int LB = ilog2(R1);
-    cf pw[B1][WF_TW1_POWERS ? R1 : 1]; // pw[b][k] = W_M^(n' k) of point b, built from pw[b][1] as the loop needs them
-    if(WF_TW1_POWERS) {
-        WF_UNROLL
-        for(int b = 0; b < B1; ++b)
-            pw[b][WF_TW1_POWERS ? 1 : 0] = cf{r.tw1[1][2 * b], r.tw1[1][2 * b + 1]};
-    }
     WF_UNROLL
     for(int k1 = 0; k1 < R1; ++k1) {
-        const int np = B1 * t;
-        cf o[B1];
         WF_UNROLL
-        for(int b = 0; b < B1; ++b) {
-            cf w;
-            if(WF_TW1_POWERS) {
-                if(k1 >= 2) { // highest power of two below k1 times the rest: depth <= log2(R1)
-                    int hp = 1;
-                    while(hp * 2 <= k1) hp *= 2;
-                    pw[b][WF_TW1_POWERS ? k1 : 0] = (k1 == hp) ? cmul(pw[b][WF_TW1_POWERS ? hp / 2 : 0], pw[b][WF_TW1_POWERS ? hp / 2 : 0])
-                                                               : cmul(pw[b][WF_TW1_POWERS ? hp : 0], pw[b][WF_TW1_POWERS ? k1 - hp : 0]);
-                }
-                w = pw[b][WF_TW1_POWERS ? k1 : 0];
-            } else
-                w = cf{r.tw1[WF_TW1_POWERS ? 1 : k1][2 * b], r.tw1[WF_TW1_POWERS ? 1 : k1][2 * b + 1]};
-            o[b] = (k1 == 0) ? u[b][0] : cmul(u[b][brev(k1, LB)], w);
-        }
+        for(int b = 0; b < B1; ++b)
+            o[k1][b] = (k1 == 0) ? u[b][0] : cmul(u[b][brev(k1, LB)], cf{r.tw1[k1][2 * b], r.tw1[k1][2 * b + 1]});
+    }
+}
+// store A'[k1][n'] into the exchange buffer
+template<class G> WF_DEV void p1_store(int t, cf *lds, const cf (&o)[G::R1][G::B1])
+{
+    constexpr int R1 = G::R1, B1 = G::B1;
+    const int np = B1 * t;
+    WF_UNROLL
+    for(int k1 = 0; k1 < R1; ++k1) {
         if(B1 == 2)
-            lds_st4(lds, ex1_addr<G>(k1, np), o[0], o[B1 - 1]);
+            lds_st4(lds, ex1_addr<G>(k1, np), o[k1][0], o[k1][B1 - 1]);
         else
-            lds_st2(lds, ex1_addr<G>(k1, np), o[0]);
+            lds_st2(lds, ex1_addr<G>(k1, np), o[k1][0]);
+    }
+}
+template<class G>
+WF_DEV void p1_window_pass1(const TickArgs &a, int t, P1Regs<G> &r, cf *lds)
+{
+    (void)a;
+    cf o[G::R1][G::B1];
+    p1_window_dft<G>(r, o);
+    p1_store<G>(t, lds, o);
+}
+// TLDS: the window (N floats) and the pass-1 twiddles (M complex) staged by the workgroup in LDS, in memory order:
+// tab[0 .. M) = window as float pairs, tab[M .. 2M) = tw1.  This thread's operands, as p1_fetch would have loaded them.
+template<class G> WF_DEV void p1_tables_from_lds(int t, const cf *tab, P1Regs<G> &r)
+{
+    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1, M = G::M;
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        if(B1 == 2) {
+            const f4 w = lds_ld4(tab, j * M1 + B1 * t);
+            r.win[j][0] = w.x; r.win[j][1] = w.y; r.win[j][2 * B1 - 2] = w.z; r.win[j][2 * B1 - 1] = w.w;
+            if(j >= 1) {
+                const f4 q = lds_ld4(tab, M + j * M1 + B1 * t);
+                r.tw1[j][0] = q.x; r.tw1[j][1] = q.y; r.tw1[j][2 * B1 - 2] = q.z; r.tw1[j][2 * B1 - 1] = q.w;
+            }
+        } else {
+            const cf w = lds_ld2(tab, j * M1 + t);
+            r.win[j][0] = w.x; r.win[j][1] = w.y;
+            if(j >= 1) {
+                const cf q = lds_ld2(tab, M + j * M1 + t);
+                r.tw1[j][0] = q.x; r.tw1[j][1] = q.y;
+            }
+        }
     }
 }
 
