@@ -230,3 +230,33 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
     ldd = subprocess.run(["ldd", str(ROOT / "waveform_amd" / "libwaveform_hip.so")], capture_output=True, text=True).stdout
     assert "wforacle" not in ldd and "wfref" not in ldd and "fftw" not in ldd
+
+
+# ---- configuration checks that run before any device is touched ---------------------------------------------------------
+def _create_code(**overrides):
+    """status of wf_hip_create for defaults + overrides on a machine without a GPU: -3 (NO_DEVICE) means the configuration
+    itself was accepted, -1 / -2 that it was rejected as invalid / unsupported"""
+    import waveform_amd as wf
+    if wf.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(wf.WfHipError) as e:
+        wf.SpectrumBatch(wf.Config.defaults(**overrides), 2)
+    return e.value.code
+
+
+def test_fft_sizes_accepted_and_rejected():
+    for n in (128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+        assert _create_code(fft_size=n) == -3, n
+    for n in (64, 800, 4160, 32768, 65536):  # legal for the reference (multiples of 16 >= 128 up to 65536) or below its minimum
+        assert _create_code(fft_size=n) == -2, n
+
+
+def test_meter_and_waveform_configurations():
+    assert _create_code(meter=1) == -3
+    assert _create_code(meter=1, meter_ms=0) == -1
+    assert _create_code(meter=1, ceiling_db=-70) == -1       # ceiling <= floor: the bar mapping would divide by zero
+    assert _create_code(meter=1, fft_size=12345) == -3       # fft_size is ignored in meter mode (it becomes the buffer length)
+    assert _create_code(waveform=1) == -3
+    assert _create_code(waveform=1, width=0) == -1
+    assert _create_code(waveform=1, meter_ms=0) == -1
+    assert _create_code(waveform=1, width=9000) == -2        # more points per row than the kernel stages in LDS

@@ -450,6 +450,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         wf::meter_config(cfg_eff); // update()'s overrides for the mode; fft_size becomes the meter buffer length
     cfg = &cfg_eff;
     int rc = wf::build_host_tables(*cfg, tab);
+    if(rc == WF_HIP_ERR_UNSUPPORTED && cfg->waveform)
+        return fail(nullptr, rc, "waveform display: width %u above 8192 points is not implemented", cfg->width);
     if(rc == WF_HIP_ERR_UNSUPPORTED)
         return fail(nullptr, rc, "fft_size %u: only powers of two in 128..16384 are implemented", cfg->fft_size);
     if(rc)
@@ -479,11 +481,6 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         h->wave = true;
         h->wave_samples = wave_samples;
         h->M = h->N;
-        if(h->N > 8192u) {
-            g_create_error = "waveform display: width above 8192 points is not implemented";
-            delete h;
-            return fail(nullptr, WF_HIP_ERR_UNSUPPORTED, "waveform display: width %u above 8192 points is not implemented", cfg->width);
-        }
         h->ring_cap = next_pow2(std::max(ring_frames, 2 * (wave_samples + h->N)));
     }
     {

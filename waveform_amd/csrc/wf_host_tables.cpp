@@ -470,6 +470,8 @@ int build_host_tables(const wf_config &cfg, HostTables &out)
             return WF_HIP_ERR_INVALID;
         if(((uint64_t)cfg.meter_ms * 1000000ull) / cfg.width == 0) // step_ns, src/source_generic.cpp:299
             return WF_HIP_ERR_INVALID;
+        if(cfg.width > 8192u) // the kernel stages 2 * capture_channels rows of `width` floats in LDS
+            return WF_HIP_ERR_UNSUPPORTED;
         out = HostTables{};
         out.window_sum = (float)cfg.fft_size;
         out.output_channels = ((cfg.capture_channels > 1) || cfg.stereo) ? 2u : 1u;

@@ -72,9 +72,6 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #endif
 #define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 8) ? WF_WPS_SMALL : 4)
 
-#ifndef WF_EARLY_TOUCH
-#define WF_EARLY_TOUCH 0
-#endif
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \
     do {                                                                                 \
@@ -175,11 +172,6 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         lds_dma_copy<G::N * (int)sizeof(float)>(a.window, smem_raw, wave_in_block, T * SPW / 64, lane);
         lds_dma_copy<G::M * (int)sizeof(cf)>(a.tw1, smem_raw + G::N * sizeof(float), wave_in_block, T * SPW / 64, lane);
     }
-#if WF_EARLY_TOUCH
-    P4Regs<G> r4;
-    if(Policy<G>::TOUCH_STATE)
-        p4_prefetch<G>(a, t, ts, r4); // the state row's lines requested right behind the window
-#endif
     // the workgroup's copy of the pass-2 twiddles: LDS-DMA (no staging registers), requested behind the window so that it
     // costs no round trip of its own; complete at the barrier below
     lds_dma_copy<G::R2 * G::R3 * (int)sizeof(cf)>(a.tw2, tw2_lds, wave_in_block, T * SPW / 64, lane);
@@ -247,9 +239,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     cf v[P];
     float mag[RP];
     WF_STAMP(2);
-#if !WF_EARLY_TOUCH
     P4Regs<G> r4;
-#endif
     if constexpr(TLDS) {
         cf o1[G::R1][G::B1];
         if(process) {
@@ -265,7 +255,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             p1_window_pass1<G>(a, t, r1, lds);
         if constexpr(DEC > 0)
             p4_prefetch_dec<G, DEC>(a, t, ts, r4);
-        else if(!WF_EARLY_TOUCH || !Policy<G>::TOUCH_STATE)
+        else
             p4_prefetch<G>(a, t, ts, r4);
     }
     __builtin_amdgcn_sched_barrier(0); // keep the prefetch up here: do not sink it to its first use in P4
