@@ -71,7 +71,7 @@ def test_host_tables_bit_identical_to_oracle(ov):
 
 
 def test_unsupported_fft_sizes_are_rejected():
-    for n in (800, 512, 32768, 3000):
+    for n in (800, 64, 32768, 3000):
         cfg = scenarios.make_config(dict(fft_size=n))
         with pytest.raises(ValueError):
             emu.host_table(cfg, 0)
