@@ -314,7 +314,7 @@ class OracleBackend:
     def set_sync_ms(self, ms):
         self.reserve = ms * 48
         if self.cfg.waveform:
-            self.src.set_time(self.now, self.reserve)
+            self.src.set_time(0, self.reserve)  # m_audio_ts stays 0 until the first packet
         else:
             self.src.set_sync_delay(self.reserve)
 
@@ -382,6 +382,7 @@ class HipBackend:
         self.disp = self.batch.display_channels
         self.hidden = False
         self.now = 1_000_000_000  # the same clock model as RefBackend: packets end "now", ticks happen "now"
+        self.audio_ts = 0         # m_audio_ts: 0 until the first packet (release_audio_capture, src/source.cpp:747)
         self.reserve = 0
 
     def set_sync_ms(self, ms):
@@ -397,6 +398,7 @@ class HipBackend:
 
     def push(self, audio, muted):
         self.now += audio.shape[1] * 1_000_000_000 // 48000 + 1
+        self.audio_ts = self.now
         if getattr(self, "timed_out", False):
             self.timed_out = False
             self._state()  # a packet ends a capture timeout
@@ -408,7 +410,7 @@ class HipBackend:
             self.batch.push_audio(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
 
     def tick(self, seconds):
-        self.batch.tick(seconds=seconds, input_rms=self.input_rms, delay_frames=self.reserve, audio_ts_ns=self.now)
+        self.batch.tick(seconds=seconds, input_rms=self.input_rms, delay_frames=self.reserve, audio_ts_ns=self.audio_ts)
 
     def set_hidden(self, hidden):
         self.hidden = hidden
