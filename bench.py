@@ -52,7 +52,7 @@ def parse_args():
                     help="BASELINE configs[4] shape: bars (26 Lanczos bars per channel) computed in the tick and all-gathered "
                          "across ranks (RCCL over xGMI) after every step; changes the workload, so it is off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget (core-seconds) of the baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="CPU work budget (core-seconds) of the baseline leg")
     return ap.parse_args()
 
 

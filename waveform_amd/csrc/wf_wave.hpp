@@ -42,11 +42,24 @@ struct WaveArgs {
 
 constexpr int WAVE_THREADS = 256;
 
-// libobs util_mul_div64 (media-io/audio-io.h helpers are built on it)
-WF_DEV unsigned long long mul_div64(unsigned long long num, unsigned long long mul, unsigned long long div)
+// libobs util_mul_div64 (media-io/audio-io.h helpers are built on it): (num / div) * mul + ((num % div) * mul) / div
+// audio_frames_to_ns(sr, frames) = util_mul_div64(frames, 10^9, sr) for frames, sr < 2^32: the quotient and remainder are
+// 32-bit divisions; the last term, floor(r * 10^9 / sr) with r < sr, is below 10^9 -- a double-precision estimate corrected
+// by one exact 64-bit comparison in each direction (no 64-bit division by a run-time divisor on the device).
+WF_DEV unsigned long long frames_to_ns(uint32_t frames, uint32_t sr)
 {
-    const unsigned long long rem = num % div;
-    return (num / div) * mul + (rem * mul) / div;
+    const uint32_t q = frames / sr, r = frames - q * sr;
+    const unsigned long long num = (unsigned long long)r * 1000000000ull; // < 2^62
+    unsigned long long e = (unsigned long long)((double)r * 1.0e9 / (double)sr);
+    while(e * sr > num) --e;          // at most one step each: the estimate is within 1 of the floor
+    while((e + 1ull) * sr <= num) ++e;
+    return (unsigned long long)q * 1000000000ull + e;
+}
+// ns_to_audio_frames(sr, ns) = util_mul_div64(ns, sr, 10^9): the divisor is a compile-time constant (multiply-high)
+WF_DEV unsigned long long ns_to_frames(unsigned long long ns, uint32_t sr)
+{
+    const unsigned long long q = ns / 1000000000ull, r = ns - q * 1000000000ull;
+    return q * sr + (r * sr) / 1000000000ull;
 }
 
 // exact dbfs of the reference (20 * log10f) -- a few hundred points per stream and tick, so the library log is affordable
@@ -80,9 +93,9 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
         return;
     const uint32_t max_size = a.waveform_samples + R;
     const uint32_t total = avail < max_size ? avail : max_size; // :303-304
-    const unsigned long long sr = a.sample_rate;
-    const unsigned long long start_ts = a.audio_ts - mul_div64(total, 1000000000ull, sr);
-    const unsigned long long stop_ts = a.audio_ts - mul_div64(R, 1000000000ull, sr);
+    const uint32_t sr = a.sample_rate;
+    const unsigned long long start_ts = a.audio_ts - frames_to_ns(total, sr);
+    const unsigned long long stop_ts = a.audio_ts - frames_to_ns(R, sr);
     if(start_ts >= a.audio_ts || stop_ts > a.audio_ts)
         return; // timestamp rollover, :316-317
     unsigned long long wts = a.wts[stream];
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
                 v = old_rows[c * W + i + counts];
             else {
                 const unsigned long long ts = wts + (unsigned long long)(i - keep) * a.step_ns;
-                unsigned long long index = mul_div64(a.audio_ts - ts, sr, 1000000000ull);
+                unsigned long long index = ns_to_frames(a.audio_ts - ts, sr);
                 const unsigned long long lo = (unsigned long long)R + 1ull, hi = total;
                 index = index < lo ? lo : (hi < index ? hi : index);
                 v = x[(wpos - (uint32_t)index) & a.ring_mask]; // temp[total - index]
