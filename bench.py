@@ -52,7 +52,7 @@ def parse_args():
                     help="BASELINE configs[4] shape: bars (26 Lanczos bars per channel) computed in the tick and all-gathered "
                          "across ranks (RCCL over xGMI) after every step; changes the workload, so it is off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="CPU work budget (core-seconds) of the baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU work budget (core-seconds) of the baseline leg")
     return ap.parse_args()
 
 
@@ -69,7 +69,7 @@ def cpu_baseline(fft: int, cores: int, budget_core_s: float):
         return None
     per_core = max(budget_core_s / max(cores, 1), 0.25)          # seconds of work per thread
     streams_per_thread = 8
-    ticks = int(max(64, min(4096, per_core * v1 / (2 * streams_per_thread))))
+    ticks = int(max(64, min(16384, per_core * v1 / (2 * streams_per_thread))))
     n_streams = streams_per_thread * cores
     v, el = wfref.bench("avx2", settings, n_streams, cores, 16, ticks, hop=HOP, seed=SEED)
     return {
