@@ -15,13 +15,13 @@ import pytest
 import scenarios
 from helpers import assert_db_close
 
-CASES = list(range(40))
+CASES = list(range(40)) + [527]  # 527: mono mixdown + Gaussian filter on a one-wavefront geometry (LDS staging race, fixed)
 
 
 def draw(seed: int):
     r = np.random.default_rng(1000 + seed)
     n = int(r.choice([1024, 2048, 4096, 8192, 16384], p=[0.3, 0.25, 0.25, 0.1, 0.1]))
-    if seed >= 28:  # cases added with the zero-padded small sizes: the earlier draws stay what they were
+    if 28 <= seed < 1000:  # cases added with the zero-padded small sizes: the earlier draws stay what they were
         n = int(r.choice([128, 256, 512]))
     layout = int(r.integers(0, 4))  # 0 mono capture, 1 mono mixdown of 2, 2 stereo, 3 one captured channel shown twice
     cfg = dict(fft_size=n,

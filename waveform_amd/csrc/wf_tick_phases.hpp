@@ -1044,12 +1044,16 @@ WF_DEV void outputs_finish(const BarArgs &b, bool has_row, OutVals<G> &ov, float
         float *vp = lds;               // [pad | n | pad]
         float *wl = lds + n + 2 * pad; // [size]
         sync();
-        for(int i = t; i < pad; i += T) {
-            vp[i] = 0.0f;
-            vp[pad + n + i] = 0.0f;
+        // only the spectrum that has a row stages anything: in mono display channel 1's buffer is what channel 0 reads the
+        // partner's magnitudes from, and on the one-wavefront geometries nothing orders that read before this point
+        if(has_row) {
+            for(int i = t; i < pad; i += T) {
+                vp[i] = 0.0f;
+                vp[pad + n + i] = 0.0f;
+            }
+            for(int i = t; i < size; i += T)
+                wl[i] = b.gauss[i];
         }
-        for(int i = t; i < size; i += T)
-            wl[i] = b.gauss[i];
         if(has_row) {
             WF_UNROLL
             for(int k = 0; k < K; ++k)
