@@ -1,11 +1,13 @@
 /*
  * wf_hip.h -- C ABI of libwaveform_hip.so, the MI355X (gfx950) implementation of
- * phandasm/waveform's per-tick spectrum path.
+ * phandasm/waveform's per-tick DSP: the spectrum path and, behind the same interface, the
+ * level meter, the waveform display and the volume-normalisation RMS.
  *
  * Boundary.  The reference selects its DSP kernels through four virtuals on
- * WAVSource (src/source.hpp:273-277); callbacks::create (src/source.cpp:87-102)
- * instantiates WAVSourceAVX2 / WAVSourceAVX / WAVSourceGeneric.  This library is
- * what a fourth subclass, WAVSourceHIP, calls from its tick_spectrum() override
+ * WAVSource (src/source.hpp:273-277: update_input_rms, tick_spectrum, tick_meter,
+ * tick_waveform); callbacks::create (src/source.cpp:87-102) instantiates WAVSourceAVX2 /
+ * WAVSourceAVX / WAVSourceGeneric.  This library is what a fourth subclass, WAVSourceHIP,
+ * calls from its tick_spectrum() / tick_meter() / tick_waveform() overrides
  * (host/wav_source_hip.hpp; the binding a maintainer adds is in INTEGRATION.md).
  * One wf_hip handle serves a *batch* of independent sources ("streams") that share
  * one configuration, because a GPU only pays off batched.
@@ -24,6 +26,11 @@
  *                        the configuration displays bars, the bar reduction of render_bars
  *                        (src/source.cpp:1500-1557; src/filter.hpp:160-211)
  *   wf_hip_read_*        reading m_decibels / m_interp_bufs / m_tsmooth_buf
+ *   wf_hip_enable_input_rms / wf_hip_read_input_rms
+ *                        capture_audio's RMS part + sync_rms_buffer + update_input_rms
+ *                        (src/source.cpp:1842-1871, :810-835; src/source_generic.cpp:392-403)
+ * FFT sizes: powers of two 128..16384 (the reference: any multiple of 16 >= 128, up to 65536); others ->
+ * WF_HIP_ERR_UNSUPPORTED and the host keeps its CPU class.
  *
  * Waveform display.  A handle created from a configuration with cfg.waveform != 0 is a *waveform batch*: wf_hip_tick runs
  * WAVSource*::tick_waveform (src/source_generic.cpp:271-390) for every stream -- a history of cfg.width dBFS points per
