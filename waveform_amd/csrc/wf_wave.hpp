@@ -65,6 +65,25 @@ WF_DEV unsigned long long ns_to_frames(unsigned long long ns, uint32_t sr)
 // exact dbfs of the reference (20 * log10f) -- a few hundred points per stream and tick, so the library log is affordable
 WF_DEV float wave_dbfs(float mag, float db_min) { return (mag > 0.0f) ? __fmul_rn(20.0f, log10f(mag)) : db_min; }
 
+// V = 4: rows whose length is a multiple of 4 floats are 16-byte aligned; every row access is a 16-byte vector and a thread
+// handles four consecutive points per step.  V = 1: any width, dword accesses.
+template<int V> WF_DEV void wave_ld(const float *p, float (&v)[V])
+{
+    if constexpr(V == 4) {
+        const f4 q = ld4(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else
+        v[0] = *p;
+}
+template<int V> WF_DEV void wave_st(float *p, const float (&v)[V])
+{
+    if constexpr(V == 4)
+        st4(p, f4{v[0], v[1], v[2], v[3]});
+    else
+        *p = v[0];
+}
+
+template<int V>
 __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float wave_lds[]; // old rows [cap_ch][W], then new rows [cap_ch][W]
@@ -75,12 +94,16 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
     float *rows = a.rows + (size_t)stream * a.out_ch * W;
     const uint32_t disp = a.stereo ? 2u : 1u;
+    float dbm[V];
+#pragma unroll
+    for(int e = 0; e < V; ++e)
+        dbm[e] = a.db_min;
 
     if(sflags & WF_STREAM_HIDDEN) { // !m_show || capture timed out, :279-288
         if(was_silent)
             return;
-        for(uint32_t i = tid; i < disp * W; i += WAVE_THREADS)
-            rows[i] = a.db_min;
+        for(uint32_t i = V * tid; i < disp * W; i += V * WAVE_THREADS)
+            wave_st<V>(rows + i, dbm);
         if(tid == 0)
             a.stream_flags[stream] = sflags | WF_STREAM_LAST_SILENT;
         return;
@@ -91,13 +114,20 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     const uint32_t avail = wpos - cend;
     if(avail <= R) // not enough audio in advance, :293-295
         return;
+    // the old rows are on their way while the time arithmetic runs
+    float *old_rows = wave_lds, *new_rows = wave_lds + (size_t)a.cap_ch * W;
+    for(uint32_t i = V * tid; i < a.cap_ch * W; i += V * WAVE_THREADS) {
+        float v[V];
+        wave_ld<V>(rows + i, v);
+        wave_st<V>(old_rows + i, v);
+    }
     const uint32_t max_size = a.waveform_samples + R;
     const uint32_t total = avail < max_size ? avail : max_size; // :303-304
     const uint32_t sr = a.sample_rate;
     const unsigned long long start_ts = a.audio_ts - frames_to_ns(total, sr);
     const unsigned long long stop_ts = a.audio_ts - frames_to_ns(R, sr);
     if(start_ts >= a.audio_ts || stop_ts > a.audio_ts)
-        return; // timestamp rollover, :316-317
+        return; // timestamp rollover, :316-317 (nothing has been written)
     unsigned long long wts = a.wts[stream];
     if(wts < start_ts)
         wts = start_ts; // catch up
@@ -109,10 +139,6 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
         const unsigned long long c = (stop_ts - wts + a.step_ns - 1ull) / a.step_ns;
         counts = c < (unsigned long long)W ? (uint32_t)c : W;
     }
-    float *old_rows = wave_lds, *new_rows = wave_lds + (size_t)a.cap_ch * W;
-    for(uint32_t c = 0; c < a.cap_ch; ++c)
-        for(uint32_t i = tid; i < W; i += WAVE_THREADS)
-            old_rows[c * W + i] = rows[c * W + i];
     __syncthreads();
     // assemble the rotated rows (:332) and look for a non-zero value (:334-343)
     int nz0 = 0, nz1 = 0;
@@ -120,19 +146,23 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     for(uint32_t c = 0; c < a.cap_ch; ++c) {
         const float *x = a.ring + ((size_t)stream * a.cap_ch + c) * a.ring_stride;
         int nz = 0;
-        for(uint32_t i = tid; i < W; i += WAVE_THREADS) {
-            float v;
-            if(i < keep)
-                v = old_rows[c * W + i + counts];
-            else {
-                const unsigned long long ts = wts + (unsigned long long)(i - keep) * a.step_ns;
-                unsigned long long index = ns_to_frames(a.audio_ts - ts, sr);
-                const unsigned long long lo = (unsigned long long)R + 1ull, hi = total;
-                index = index < lo ? lo : (hi < index ? hi : index);
-                v = x[(wpos - (uint32_t)index) & a.ring_mask]; // temp[total - index]
+        for(uint32_t i0 = V * tid; i0 < W; i0 += V * WAVE_THREADS) {
+            float v[V];
+#pragma unroll
+            for(int e = 0; e < V; ++e) {
+                const uint32_t i = i0 + (uint32_t)e;
+                if(i < keep)
+                    v[e] = old_rows[c * W + i + counts];
+                else {
+                    const unsigned long long ts = wts + (unsigned long long)(i - keep) * a.step_ns;
+                    unsigned long long index = ns_to_frames(a.audio_ts - ts, sr);
+                    const unsigned long long lo = (unsigned long long)R + 1ull, hi = total;
+                    index = index < lo ? lo : (hi < index ? hi : index);
+                    v[e] = x[(wpos - (uint32_t)index) & a.ring_mask]; // temp[total - index]
+                }
+                nz |= (v[e] != 0.0f) ? 1 : 0;
             }
-            new_rows[c * W + i] = v;
-            nz |= (v != 0.0f) ? 1 : 0;
+            wave_st<V>(new_rows + c * W + i0, v);
         }
         if(c == 0) nz0 = nz; else nz1 = nz;
     }
@@ -145,42 +175,48 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
         a.stream_flags[stream] = (sflags & ~WF_STREAM_LAST_SILENT) | (all_silent ? WF_STREAM_LAST_SILENT : 0u);
     }
     if(all_silent) { // :353-359
-        for(uint32_t i = tid; i < disp * W; i += WAVE_THREADS)
-            rows[i] = a.db_min;
+        for(uint32_t i = V * tid; i < disp * W; i += V * WAVE_THREADS)
+            wave_st<V>(rows + i, dbm);
         // a captured channel that is not displayed keeps its (rotated) raw history
         for(uint32_t c = disp; c < a.cap_ch; ++c)
-            for(uint32_t i = tid; i < W; i += WAVE_THREADS)
-                rows[c * W + i] = new_rows[c * W + i];
+            for(uint32_t i = V * tid; i < W; i += V * WAVE_THREADS) {
+                float v[V];
+                wave_ld<V>(new_rows + c * W + i, v);
+                wave_st<V>(rows + c * W + i, v);
+            }
         return;
     }
     const float comp = a.normalize ? (a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp) : 0.0f;
-    const bool mono_mix = !a.stereo && a.cap_ch > 1;
-    for(uint32_t i = tid; i < W; i += WAVE_THREADS) {
-        const bool fresh = i >= keep;
-        float r0 = new_rows[i];
-        const float r1 = a.cap_ch > 1 ? new_rows[W + i] : r0;
-        if(a.out_ch > a.cap_ch) // one captured channel shown twice: row 1 is row 0 *before* its new points are converted,
-            rows[W + i] = r0;   // and its own count is 0, so they stay raw (:361-362, :364-368 with counts[1] == 0)
-        if(fresh) {
-            if(a.stereo || a.cap_ch == 1)
-                r0 = wave_dbfs(__builtin_fabsf(r0), a.db_min);
-            else
-                r0 = wave_dbfs(__fmul_rn(__fadd_rn(__builtin_fabsf(r0), __builtin_fabsf(r1)), 0.5f), a.db_min);
-            if(a.normalize)
-                r0 = __fadd_rn(r0, comp);
-        }
-        rows[i] = r0;
-        if(a.cap_ch > 1) {
-            float o1 = r1;
-            if(fresh && a.stereo) {
-                o1 = wave_dbfs(__builtin_fabsf(r1), a.db_min);
+    for(uint32_t i0 = V * tid; i0 < W; i0 += V * WAVE_THREADS) {
+        float r0[V], r1[V], o1[V];
+        wave_ld<V>(new_rows + i0, r0);
+        if(a.cap_ch > 1)
+            wave_ld<V>(new_rows + W + i0, r1);
+        if(a.out_ch > a.cap_ch)             // one captured channel shown twice: row 1 is row 0 *before* its new points are
+            wave_st<V>(rows + W + i0, r0);  // converted, and its own count is 0, so they stay raw (:361-362, :364-368)
+#pragma unroll
+        for(int e = 0; e < V; ++e) {
+            const bool fresh = i0 + (uint32_t)e >= keep;
+            const float s1 = a.cap_ch > 1 ? r1[e] : r0[e];
+            o1[e] = s1;
+            if(fresh) {
+                if(a.stereo || a.cap_ch == 1)
+                    r0[e] = wave_dbfs(__builtin_fabsf(r0[e]), a.db_min);
+                else
+                    r0[e] = wave_dbfs(__fmul_rn(__fadd_rn(__builtin_fabsf(r0[e]), __builtin_fabsf(s1)), 0.5f), a.db_min);
                 if(a.normalize)
-                    o1 = __fadd_rn(o1, comp);
+                    r0[e] = __fadd_rn(r0[e], comp);
+                if(a.stereo && a.cap_ch > 1) {
+                    o1[e] = wave_dbfs(__builtin_fabsf(s1), a.db_min);
+                    if(a.normalize)
+                        o1[e] = __fadd_rn(o1[e], comp);
+                }
             }
-            rows[W + i] = o1; // mono display: the raw history of channel 1
         }
+        wave_st<V>(rows + i0, r0);
+        if(a.cap_ch > 1)
+            wave_st<V>(rows + W + i0, o1); // mono display: the raw history of channel 1
     }
-    (void)mono_mix;
 }
 
 } // namespace wf
