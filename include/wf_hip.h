@@ -165,7 +165,8 @@ int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float 
  * wf_hip_push_* also appends the squared per-frame peak of the captured channels to a per-stream RMS ring, and every
  * wf_hip_tick first recomputes m_input_rms over the m_input_rms_size (= sample_rate & -16) frames that end at the
  * A/V-sync point, as WAVSource::tick does (src/source.cpp:1330-1331); wf_hip_tick_params::input_rms is then ignored and
- * wf_hip_set_input_rms fails.  Needs cfg.normalize_volume.  Audio pushed before the call counts as silence. */
+ * wf_hip_set_input_rms fails.  Needs cfg.normalize_volume (spectrum or waveform batches).  Audio pushed before the call
+ * counts as silence. */
 int wf_hip_enable_input_rms(wf_hip *h);
 /* m_input_rms of streams [first, first+count) as of the last tick */
 int wf_hip_read_input_rms(wf_hip *h, uint32_t first, uint32_t count, float *out);

@@ -73,6 +73,8 @@ def lib():
     L.wfo_wave_set_hidden.argtypes = [vp, C.c_int]
     L.wfo_wave_set_input_rms.argtypes = [vp, C.c_float]
     L.wfo_wave_tick.argtypes = [vp]
+    L.wfo_wave_update_input_rms.restype = C.c_float
+    L.wfo_wave_update_input_rms.argtypes = [vp]
     for n in ("wfo_wave_points", "wfo_wave_output_channels"):
         getattr(L, n).restype = C.c_uint32
         getattr(L, n).argtypes = [vp]
@@ -325,6 +327,9 @@ class OracleWave:
 
     def set_input_rms(self, rms):
         self.L.wfo_wave_set_input_rms(self.h, rms)
+
+    def update_input_rms(self):
+        return float(self.L.wfo_wave_update_input_rms(self.h))
 
     def tick(self):
         self.L.wfo_wave_tick(self.h)

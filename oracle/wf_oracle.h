@@ -97,6 +97,7 @@ void wfo_wave_push_audio(wfo_wave *w, const float *ch0, const float *ch1, uint32
 void wfo_wave_set_time(wfo_wave *w, uint64_t audio_ts_ns, uint32_t reserve_frames);
 void wfo_wave_set_hidden(wfo_wave *w, int hidden); /* !m_show || capture timed out */
 void wfo_wave_set_input_rms(wfo_wave *w, float rms);
+float wfo_wave_update_input_rms(wfo_wave *w);  /* update_input_rms() from the pushed audio (cfg.normalize_volume); returns m_input_rms */
 void wfo_wave_tick(wfo_wave *w);
 uint32_t wfo_wave_points(const wfo_wave *w);        /* m_fft_size = m_width */
 uint32_t wfo_wave_output_channels(const wfo_wave *w);

@@ -33,6 +33,9 @@ struct wfo_wave {
     int hidden;                 /* !m_show || capture timed out */
     int last_silent;
     float input_rms;
+    /* volume-normalisation producer, as in wf_oracle.c (capture_audio's RMS part, sync_rms_buffer, update_input_rms) */
+    float *rms_sync; size_t rms_sync_len, rms_sync_cap;
+    float *rms_buf; size_t rms_size, rms_pos;
     float *rows[2];             /* m_decibels */
     float *temp; size_t temp_cap; /* m_interp_bufs[2] */
 };
@@ -90,6 +93,10 @@ wfo_wave *wfo_wave_create(const wf_config *cfg)
     }
     for(uint32_t c = 0; c < w->cap_ch; ++c) /* :1243-1248 */
         ring_push(w, (int)c, NULL, w->n);
+    if(cfg->normalize_volume) { /* src/source.cpp:1144-1152 */
+        w->rms_size = (size_t)cfg->sample_rate & (size_t)-16;
+        w->rms_buf = (float *)calloc(w->rms_size, sizeof(float));
+    }
     return w;
 }
 
@@ -102,6 +109,8 @@ void wfo_wave_destroy(wfo_wave *w)
         free(w->rows[c]);
     }
     free(w->temp);
+    free(w->rms_sync);
+    free(w->rms_buf);
     free(w);
 }
 
@@ -117,12 +126,61 @@ void wfo_wave_set_input_rms(wfo_wave *w, float rms) { w->input_rms = rms; }
 void wfo_wave_push_audio(wfo_wave *w, const float *ch0, const float *ch1, uint32_t frames, int muted)
 {
     const float *data[2] = {ch0, ch1};
+    if(w->cfg.normalize_volume) { /* src/source.cpp:1842-1871 */
+        if(w->rms_sync_len + frames > w->rms_sync_cap) {
+            size_t cap = w->rms_sync_cap ? w->rms_sync_cap : 4096;
+            while(cap < w->rms_sync_len + frames)
+                cap *= 2;
+            w->rms_sync = (float *)realloc(w->rms_sync, cap * sizeof(float));
+            w->rms_sync_cap = cap;
+        }
+        for(uint32_t i = 0; i < frames; ++i) {
+            float val = 0.0f;
+            for(uint32_t ch = 0; ch < w->cap_ch; ++ch)
+                if(data[ch] != NULL)
+                    val = fmaxf(fabsf(data[ch][i]), val);
+            w->rms_sync[w->rms_sync_len + i] = val * val;
+        }
+        w->rms_sync_len += frames;
+        const size_t max_rms_size = (size_t)w->reserve + w->rms_size;
+        if(w->rms_sync_len > max_rms_size) {
+            const size_t drop = w->rms_sync_len - max_rms_size;
+            memmove(w->rms_sync, w->rms_sync + drop, max_rms_size * sizeof(float));
+            w->rms_sync_len = max_rms_size;
+        }
+    }
     for(uint32_t j = 0; j < w->cap_ch; ++j) {
         ring_push(w, (int)j, (muted || data[j] == NULL) ? NULL : data[j], frames);
         const size_t max_size = (size_t)w->reserve + w->waveform_samples;
         if(w->ring_len[j] > max_size)
             ring_pop(w, (int)j, NULL, w->ring_len[j] - max_size);
     }
+}
+
+/* update_input_rms + sync_rms_buffer (src/source_generic.cpp:392-403, src/source.cpp:810-835): what WAVSource::tick runs first */
+float wfo_wave_update_input_rms(wfo_wave *w)
+{
+    if(!w->cfg.normalize_volume)
+        return w->input_rms;
+    const size_t dtsize = w->reserve;
+    if(w->rms_sync_len <= dtsize)
+        return w->input_rms;
+    size_t head = 0;
+    while(w->rms_sync_len - head > dtsize) {
+        const size_t consume = w->rms_sync_len - head - dtsize;
+        const size_t max = w->rms_size - w->rms_pos;
+        const size_t n = (consume >= max) ? max : consume;
+        memcpy(w->rms_buf + w->rms_pos, w->rms_sync + head, n * sizeof(float));
+        head += n;
+        w->rms_pos = (consume >= max) ? 0 : w->rms_pos + n;
+    }
+    memmove(w->rms_sync, w->rms_sync + head, (w->rms_sync_len - head) * sizeof(float));
+    w->rms_sync_len -= head;
+    float sum = 0.0f;
+    for(size_t i = 0; i < w->rms_size; ++i)
+        sum += w->rms_buf[i];
+    w->input_rms = sqrtf(sum / w->rms_size);
+    return w->input_rms;
 }
 
 /* WAVSourceGeneric::tick_waveform, src/source_generic.cpp:271-390 */

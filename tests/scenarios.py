@@ -141,6 +141,10 @@ SCENARIOS = {
     "wave_single_dup_stall": dict(cfg=dict(waveform=1, stereo=1, capture_channels=1, width=640),
                                   steps=_steps(3) + [("tick",)] * 3 + [("noise", 1024)] * 9 + [("tick",)] + _steps(2), record=3),
     # hide / show / capture timeout, with a 10 ms audio sync offset (A/V-sync reserve of 480 frames)
+    # volume normalisation in waveform mode, m_input_rms from its producer (quiet audio: the gain is not clipped by max_gain)
+    "wave_normalize": dict(cfg=dict(waveform=1, stereo=1, width=400, normalize_volume=1),
+                           steps=[("noise_amp", 800, 0.05), ("tick",)] * 6 + [("mute_noise", 800), ("tick",)] * 2 + [("noise_amp", 800, 0.5), ("tick",)] * 3,
+                           record=3),
     "wave_hide_timeout_sync": dict(cfg=dict(waveform=1, stereo=1, width=333), sync_ms=10,
                                    steps=_steps(4) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(3)
                                    + [("timeout",), ("tick",), ("tick",)] + _steps(3), record="all"),
@@ -334,6 +338,8 @@ class OracleBackend:
 
     def tick(self, seconds):
         if self.cfg.waveform:
+            if self.auto_rms:
+                self.rms = self.src.update_input_rms()
             self.src.tick()
             return
         if self.auto_rms:
@@ -352,7 +358,10 @@ class OracleBackend:
         if self.cfg.meter:
             return dict(db=self.src.levels()[None], bars=self.src.bars()[None], silent=self.src.last_silent)
         if self.cfg.waveform:
-            return dict(db=self.src.rows(), bars=None, silent=self.src.last_silent)
+            rec = dict(db=self.src.rows(), bars=None, silent=self.src.last_silent)
+            if self.auto_rms:
+                rec["rms"] = np.float32(self.rms)
+            return rec
         bars = None
         if self.cfg.bars or self.cfg.curve:
             self.src.render_bars()
@@ -424,7 +433,10 @@ class HipBackend:
         db = self.batch.decibels()
         if self.cfg.waveform:
             assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"
-            return dict(db=db[self.probe][: self.disp], bars=None, silent=bool(self.batch.last_silent()[self.probe]))
+            rec = dict(db=db[self.probe][: self.disp], bars=None, silent=bool(self.batch.last_silent()[self.probe]))
+            if self.auto_rms:
+                rec["rms"] = self.batch.input_rms()[self.probe]
+            return rec
         bars = self.batch.bars() if (self.cfg.bars or self.cfg.curve) else None
         silent = self.batch.last_silent()
         # every copy of the scenario must produce the same bits

@@ -76,7 +76,7 @@ DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4096_ema_s
           "meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",
           "meter_hide_show_timeout",
           # WAVSourceHIP::tick_waveform
-          "wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync"]
+          "wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync", "wave_normalize"]
 
 
 @pytest.mark.gpu

@@ -361,6 +361,30 @@ wf::MeterArgs make_meter_args(wf_hip *h, const wf_hip_tick_params *p)
     return m;
 }
 
+// update_input_rms of every stream (what WAVSource::tick does first, src/source.cpp:1330-1331); leaves the per-stream volume
+// compensation where the tick kernels read it.  No-op unless wf_hip_enable_input_rms has been called.
+void launch_input_rms(wf_hip *h, const wf_hip_tick_params *p)
+{
+    if(h->d_rms_ring == nullptr)
+        return;
+    wf::RmsArgs r{};
+    r.rms_ring = h->d_rms_ring;
+    r.bsum = h->d_rms_bsum;
+    r.wpos = h->d_wpos;
+    r.rend = h->d_rend;
+    r.rms_cap = h->rms_cap;
+    r.size = h->rms_size;
+    r.delay = p->delay_frames;
+    r.delay_stream = h->d_delay;
+    r.input_rms = h->d_input_rms;
+    r.vol_comp = h->d_vol_comp;
+    r.volume_target = h->cfg.volume_target;
+    r.max_gain = h->cfg.max_gain;
+    r.db_min = wf::db_min();
+    r.n_streams = h->n_streams;
+    hipLaunchKernelGGL(wf::input_rms_kernel, dim3(h->n_streams), dim3(64), 0, h->stream, r);
+}
+
 int check_range(wf_hip *h, uint32_t first, uint32_t count)
 {
     if(h == nullptr)
@@ -873,6 +897,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS on a configuration without bars or curve: the tick would produce nothing");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     if(h->wave) {
+        launch_input_rms(h, p);
         wf::WaveArgs w{};
         w.ring = h->d_ring;
         w.wpos = h->d_wpos;
@@ -914,26 +939,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         WF_HIP_TRY(h, hipGetLastError());
         return WF_HIP_OK;
     }
-    if(h->d_rms_ring) {
-        // update_input_rms of every stream (what WAVSource::tick does first, src/source.cpp:1330-1331); leaves the
-        // per-stream volume compensation where the spectrum kernel reads it
-        wf::RmsArgs r{};
-        r.rms_ring = h->d_rms_ring;
-        r.bsum = h->d_rms_bsum;
-        r.wpos = h->d_wpos;
-        r.rend = h->d_rend;
-        r.rms_cap = h->rms_cap;
-        r.size = h->rms_size;
-        r.delay = p->delay_frames;
-        r.delay_stream = h->d_delay;
-        r.input_rms = h->d_input_rms;
-        r.vol_comp = h->d_vol_comp;
-        r.volume_target = h->cfg.volume_target;
-        r.max_gain = h->cfg.max_gain;
-        r.db_min = wf::db_min();
-        r.n_streams = h->n_streams;
-        hipLaunchKernelGGL(wf::input_rms_kernel, dim3(h->n_streams), dim3(64), 0, h->stream, r);
-    }
+    launch_input_rms(h, p);
     const wf::TickArgs a = make_args(h, p);
     const bool aligned = h->all_aligned && h->stream_delays_aligned && (p->delay_frames % 4u) == 0;
     h->launch(h, a, aligned);
@@ -1031,8 +1037,8 @@ int wf_hip_enable_input_rms(wf_hip *h)
 {
     if(h == nullptr)
         return WF_HIP_ERR_INVALID;
-    if(!h->cfg.normalize_volume || h->meter || h->wave)
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_enable_input_rms needs a spectrum batch with cfg.normalize_volume");
+    if(!h->cfg.normalize_volume || h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_enable_input_rms needs a spectrum or waveform batch with cfg.normalize_volume");
     if(h->d_rms_ring)
         return WF_HIP_OK;
     WF_HIP_TRY(h, hipSetDevice(h->device));
@@ -1040,7 +1046,7 @@ int wf_hip_enable_input_rms(wf_hip *h)
     if(h->rms_size == 0)
         return fail(h, WF_HIP_ERR_INVALID, "sample_rate %u is too small for the RMS window", h->cfg.sample_rate);
     // the window + every A/V-sync delay the audio rings admit + the two ragged blocks at its ends
-    h->rms_cap = next_pow2(h->rms_size + (h->ring_cap - h->N) + 2 * wf::RMS_BLOCK);
+    h->rms_cap = next_pow2(h->rms_size + (h->wave ? h->ring_cap : h->ring_cap - h->N) + 2 * wf::RMS_BLOCK);
     const size_t nblk = h->rms_cap / wf::RMS_BLOCK;
     float *ring = nullptr, *bsum = nullptr;
     int rc = dev_alloc(h, &ring, (size_t)h->n_streams * h->rms_cap);
