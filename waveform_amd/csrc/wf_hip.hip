@@ -78,7 +78,7 @@ struct wf_hip {
     float *d_cur_coef = nullptr, *d_gauss = nullptr, *d_gauss_wsum = nullptr;
     int *d_cur_base = nullptr;
     float *d_lane_coef = nullptr;
-    int *d_lane_bin = nullptr, *d_bar_seg = nullptr;
+    int *d_lane_bin = nullptr, *d_bar_seg = nullptr, *d_seg_group = nullptr;
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;
@@ -279,6 +279,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.lane_coef = h->d_lane_coef;
         a.bar.lane_bin = h->d_lane_bin;
         a.bar.bar_seg = h->d_bar_seg;
+        a.bar.seg_group = h->d_seg_group;
         a.bar.num_segs = h->bar_segs;
         a.bar.lane_blocks = h->bar_blocks;
         a.bar.cur_coef = h->d_cur_coef;
@@ -655,6 +656,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 WF_CREATE_TRY(upload(h, &h->d_lane_coef, lanes.coef));
                 WF_CREATE_TRY(upload(h, &h->d_lane_bin, lanes.bin));
                 WF_CREATE_TRY(upload(h, &h->d_bar_seg, lanes.bar_seg));
+                WF_CREATE_TRY(upload(h, &h->d_seg_group, lanes.seg_group));
                 WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
             }
         }

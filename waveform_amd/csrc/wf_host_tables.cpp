@@ -374,6 +374,10 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
     }
     out.bar_seg.push_back((int)seg_start.size());
     out.num_segs = (int)seg_start.size();
+    out.seg_group.assign((size_t)threads, 0);
+    for(int b = 0; b < t.num_bars; ++b)
+        for(int k = out.bar_seg[(size_t)b]; k < out.bar_seg[(size_t)b + 1]; k += 8)
+            out.seg_group[(size_t)k] = std::min(8, out.bar_seg[(size_t)b + 1] - k);
     out.blocks = L / 4;
     // lane-major: block c of lane s at [(c * threads + s) * 4, +4)  ->  one coalesced 16-byte load per lane and block
     out.coef.assign((size_t)out.blocks * threads * 4, 0.0f);

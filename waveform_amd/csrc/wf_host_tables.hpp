@@ -60,6 +60,7 @@ struct BarLaneTables {
     std::vector<float> coef;  // [blocks][threads][4]
     std::vector<int> bin;     // [blocks][threads][4]
     std::vector<int> bar_seg; // [num_bars + 1]
+    std::vector<int> seg_group; // [threads] > 0 where a group of that many (<= 8) consecutive segments of one bar starts
     int num_segs = 0, blocks = 0;
 };
 bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out);

@@ -60,6 +60,7 @@ struct BarArgs {
     const float *lane_coef;    // [lane_blocks][T][4]
     const int *lane_bin;       // [lane_blocks][T][4]
     const int *bar_seg;        // [num_bars + 1]
+    const int *seg_group;      // [T] > 0: this segment starts a group of that many (<= 8) consecutive segments of one bar
     int num_segs;
     int lane_blocks;
     // Curve display (render_curve, reference src/source.cpp:1360-1425): num_bars = m_width points per row, point
@@ -914,12 +915,13 @@ WF_DEV float lerp_std(float a, float b, float t)
 // What a thread needs to know about "its" bar in the first pass of the first chunk (bar = t / lanes_per_bar).  Fetched at
 // the very start of the kernel with the audio window, so that the bars phase at the end does not begin with a chain of
 // dependent table loads.
-struct BarPre { int off, len, count; int s0, s1; };
+struct BarPre { int off, len, count; int s0, s1; int glen; };
 template<class G> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 {
-    BarPre p{0, 0, 1, 0, 0};
+    BarPre p{0, 0, 1, 0, 0, 0};
     if(b.out != nullptr) {
         if(b.num_segs > 0) { // bar t's segment range
+            p.glen = b.seg_group[t];
             if(t < b.num_bars) {
                 p.s0 = b.bar_seg[t];
                 p.s1 = b.bar_seg[t + 1];
@@ -1125,19 +1127,37 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
         sync();
         WF_BAR_STAMP(14);
         WF_BAR_STAMP(15);
-        // B: one thread per bar adds the bar's partials in segment order
+        // B1: the partials of a bar are added in two levels -- groups of up to eight consecutive segments first (their
+        // leaders read the eight values in one go), then one thread per bar adds its group sums in order.  A log-axis display
+        // has bars of a few hundred bins = dozens of segments; one thread walking them alone was the longest chain of the phase.
+        float *gsum = prod + T + 8; // behind the partials and the eight floats a leader may read past them
+        if(has_row && pre.glen > 0) {
+            float q[8];
+            WF_UNROLL
+            for(int j = 0; j < 8; ++j)
+                q[j] = prod[t + j]; // inside the scratch for every t; entries past the group are not used
+            float a0 = q[0], a1 = 0.0f;
+            WF_UNROLL
+            for(int j = 1; j < 8; ++j) {
+                const float v = (j < pre.glen) ? q[j] : 0.0f;
+                if(j & 1) a1 += v; else a0 += v;
+            }
+            gsum[t] = a0 + a1;
+        }
+        sync();
+        // B2: one thread per bar
         WF_UNROLL
         for(int k = 0; k < OutVals<G>::KMAX; ++k)
             ov.v[k] = 0.0f;
         if(has_row && t < b.num_bars) {
             float a0 = 0.0f, a1 = 0.0f;
             int k = pre.s0;
-            for(; k + 1 < pre.s1; k += 2) {
-                a0 += prod[k];
-                a1 += prod[k + 1];
+            for(; k + 8 < pre.s1; k += 16) {
+                a0 += gsum[k];
+                a1 += gsum[k + 8];
             }
             if(k < pre.s1)
-                a0 += prod[k];
+                a0 += gsum[k];
             ov.v[0] = (a0 + a1) / (float)pre.count;
         }
         return true;
