@@ -116,6 +116,14 @@ SCENARIOS = {
     "split_16384_hide_timeout": dict(cfg=dict(fft_size=16384, stereo=1, slope=1.0),
                                      steps=_steps(2) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(2)
                                      + [("timeout",), ("tick",), ("tick",)] + _steps(2), record=2),
+    # ---- 32768 points ("large FFT"): one spectrum per workgroup, both radix-32 passes shared by thread pairs; stereo runs split
+    "large_32768_stereo_bars": dict(cfg=dict(fft_size=32768, stereo=1, slope=1.0, bars=1, interp_mode=1), steps=_steps(4), record=1),
+    "large_32768_single_tv": dict(cfg=dict(fft_size=32768, stereo=0, capture_channels=1, tsmoothing=2, fast_peaks=1, window=4),
+                                  steps=[("noise", 441), ("tick",)] * 3 + [("noise", 1024), ("tick",)], record=1),
+    "large_32768_half_silent": dict(cfg=dict(fft_size=32768, stereo=1, gravity=0.2),
+                                    steps=_steps(2) + [("noise_ch0_only", 33000), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 6
+                                    + [("silence", 33000), ("tick",)] + [("silence", 800), ("tick",)] * 10 + [("noise_ch1_only", 800), ("tick",)] * 2,
+                                    record=2),
     # ---- volume normalisation with its producer (capture_audio's RMS part + update_input_rms, src/source.cpp:1842-1871,
     # :810-835, src/source_generic.cpp:392-403): every backend derives m_input_rms from the audio itself; records add
     #   rms  float32 scalar  m_input_rms after the tick

@@ -117,7 +117,8 @@ template<int N_, int T_, int R1_, int R2_, int R3_> struct Geom {
     static constexpr int P = M / T_;        // points per thread
     static constexpr int R1 = R1_, R2 = R2_, R3 = R3_;
     static constexpr int B1 = P / R1_;      // pass-1 butterflies per thread (1 or 2)
-    static constexpr int B2 = P / R2_;
+    static constexpr int H2 = (R2_ > P) ? R2_ / P : 1; // threads sharing one pass-2 butterfly (N = 32768 only)
+    static constexpr int B2 = (R2_ > P) ? 1 : P / R2_;
     static constexpr int H3 = (R3_ > P) ? R3_ / P : 1; // threads sharing one pass-3 butterfly (radix 32 with 16 points per thread)
     static constexpr int B3 = (R3_ > P) ? 1 : P / R3_;
     static constexpr int M1 = M / R1_;      // = R2*R3 = T*B1
@@ -137,6 +138,7 @@ template<int N_, int T_, int R1_, int R2_, int R3_> struct Geom {
     static_assert(B1 == 1 || B1 == 2, "pass 1 loads 8 or 16 bytes per thread");
     static_assert(T_ * B1 == M1, "pass-1 butterflies must tile the threads");
     static_assert(B2 >= 1 && (R3_ % B2) == 0, "pass-2 butterflies of a thread share k1");
+    static_assert(H2 == 1 || (H2 == 2 && T_ == R1_ * R3_ * 2), "a pass-2 butterfly is split over at most two threads");
     static_assert(H3 == 1 || H3 == 2, "a pass-3 butterfly is split over at most two threads");
     static_assert(B3 >= 1 && T_ * B3 == R1_ * R2_ * H3, "pass-3 butterflies must tile the threads");
     static_assert((P % 4) == 0, "epilogue handles 4 bins per step");

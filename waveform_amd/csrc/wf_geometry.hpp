@@ -13,6 +13,8 @@ using G8192 = Geom<8192, 256, 8, 16, 32>;     // four wavefronts; radix 8 first 
                                               // per thread instead of the 47 eight-byte ones of 16x16x16: 53 -> 57 % of the HBM peak),
                                               // radix-32 last pass shared by thread pairs
 using G16384 = Geom<16384, 512, 16, 16, 32>;  // eight wavefronts; the radix-32 pass is shared by thread pairs
+using G32768 = Geom<32768, 1024, 16, 32, 32>; // sixteen wavefronts = one workgroup per spectrum (132 KB of LDS); both radix-32
+                                              // passes are shared by thread pairs.  The reference's "large FFT" range.
 
 // calls f(G{}) for the geometry of fft_size n; returns false for unsupported sizes
 template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)
@@ -23,6 +25,7 @@ template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)
     case 4096: f(G4096{}); return true;
     case 8192: f(G8192{}); return true;
     case 16384: f(G16384{}); return true;
+    case 32768: f(G32768{}); return true;
     default: return false;
     }
 }

@@ -478,7 +478,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(rc == WF_HIP_ERR_UNSUPPORTED && cfg->waveform)
         return fail(nullptr, rc, "waveform display: width %u above 8192 points is not implemented", cfg->width);
     if(rc == WF_HIP_ERR_UNSUPPORTED)
-        return fail(nullptr, rc, "fft_size %u: only powers of two in 128..16384 are implemented", cfg->fft_size);
+        return fail(nullptr, rc, "fft_size %u: only powers of two in 128..32768 are implemented", cfg->fft_size);
     if(rc)
         return fail(nullptr, rc, "invalid configuration");
     const int ndev = wf_hip_device_count();
@@ -688,6 +688,15 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             case 128: setup_rc = setup_launch_dec<G, 3>(h); break;
             default: setup_rc = setup_launch<G, 2>(h); break;
             }
+        } else if constexpr(G::N >= 32768) {
+            // one spectrum fills a CU's LDS: a stereo pair runs split, a single captured channel alone; mono mixdown of two
+            // channels (which needs both in one workgroup) is not available at this size
+            if(want_split)
+                setup_rc = setup_launch_split<G>(h);
+            else if(cfg->capture_channels == 1)
+                setup_rc = setup_launch<G, 1>(h);
+            else
+                setup_rc = fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: mono mixdown of two captured channels is not implemented above 16384", cfg->fft_size);
         } else if constexpr(G::T >= 256)
             setup_rc = want_split ? setup_launch_split<G>(h) : (cfg->capture_channels > 1) ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
         else

@@ -496,7 +496,7 @@ int build_host_tables(const wf_config &cfg, HostTables &out)
         render_geometry(cfg, false, out);
         return WF_HIP_OK;
     }
-    if(!is_pow2(cfg.fft_size) || cfg.fft_size < 128 || cfg.fft_size > 16384)
+    if(!is_pow2(cfg.fft_size) || cfg.fft_size < 128 || cfg.fft_size > 32768)
         return WF_HIP_ERR_UNSUPPORTED;
     if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0)
         return WF_HIP_ERR_INVALID;

@@ -453,6 +453,25 @@ template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float 
 template<class G> WF_DEV void p2_read(int t, const cf *lds, cf (&v)[G::P])
 {
     constexpr int R2 = G::R2, R3 = G::R3, B2 = G::B2;
+    if constexpr(G::H2 == 2) {
+        // radix 32 with 16 points per thread (N = 32768): threads c and c + R1*R3 share column c = k1*R3 + n3.  Both read
+        // the whole column; thread h keeps the half of the first radix-2 stage that feeds the outputs k2 = 2k' + h, as
+        // pass 3 does: u[j] = (v[j] + sg * v[j+16]) * (h ? W_32^j : 1).
+        constexpr int HALF = R2 / 2;
+        static_assert(R2 == 32, "the shared second pass is written for radix 32");
+        const int c = t & (G::R1 * R3 - 1), h = t / (G::R1 * R3);
+        const int k1 = c / R3, n3 = c % R3;
+        const float hf = (float)h;
+        const float sg = 1.0f - 2.0f * hf;
+        WF_UNROLL
+        for(int j = 0; j < HALF; ++j) {
+            const cf lo = lds_ld2(lds, ex1_addr<G>(k1, j * R3 + n3));
+            const cf hi = lds_ld2(lds, ex1_addr<G>(k1, (j + HALF) * R3 + n3));
+            const cf e = cf{fmaf(sg, hi.x, lo.x), fmaf(sg, hi.y, lo.y)};
+            v[j] = cmul(e, half_twiddle32(j, hf));
+        }
+        return;
+    }
     const int q0 = B2 * t;
     const int k1 = q0 / R3, n30 = q0 % R3;
     WF_UNROLL
@@ -476,6 +495,23 @@ template<class G> WF_DEV void p2_read(int t, const cf *lds, cf (&v)[G::P])
 template<class G> WF_DEV void p2_pass2_write(const cf *tw2, int t, cf *lds, cf (&v)[G::P])
 {
     constexpr int R1 = G::R1, R2 = G::R2, R3 = G::R3, B2 = G::B2;
+    if constexpr(G::H2 == 2) {
+        constexpr int HALF = R2 / 2, LBH = ilog2(HALF);
+        const int c = t & (R1 * R3 - 1), h = t / (R1 * R3);
+        const int k1 = c / R3, n3 = c % R3;
+        cf u[HALF];
+        WF_UNROLL
+        for(int j = 0; j < HALF; ++j)
+            u[j] = v[j];
+        dft_dif<HALF>(u);
+        WF_UNROLL
+        for(int kk = 0; kk < HALF; ++kk) {
+            const int k2 = 2 * kk + h;                 // this thread's outputs
+            const cf w = lds_ld2(tw2, k2 * R3 + n3);   // W_(R2 R3)^(n3 k2); row 0 is all ones
+            lds_st2(lds, ex2_addr<G>(k1 + R1 * k2, n3), cmul(u[brev(kk, LBH)], w));
+        }
+        return;
+    }
     constexpr int LB = ilog2(R2);
     const int q0 = B2 * t;
     const int k1 = q0 / R3, n30 = q0 % R3;
