@@ -1,6 +1,6 @@
 // wf_geometry.hpp -- the FFT decompositions the library ships, one per supported FFT size.
 // T threads per spectrum (1, 1, 2, 4, 8 wavefronts for N = 1024 ... 16384); every thread owns
-// P = N/(2T) complex points (8 or 16); pass 1 fetches 16-byte vectors where the radices allow (8-byte ones at 1024 and 16384).  Measured alternatives with 32 points per
+// P = N/(2T) complex points (8 or 16); pass 1 fetches 16-byte vectors where the radices allow (8-byte ones at 1024 and 32768).  Measured alternatives with 32 points per
 // thread (N = 4096 on one wavefront, 8192 on two, 16384 on four) held 156-168 VGPRs and ran 15-20 % slower.
 #pragma once
 #include "wf_fft_core.hpp"
@@ -12,7 +12,8 @@ using G4096 = Geom<4096, 128, 8, 16, 16>;     // two wavefronts
 using G8192 = Geom<8192, 256, 8, 16, 32>;     // four wavefronts; radix 8 first so that pass 1 fetches 16-byte vectors (23 requests
                                               // per thread instead of the 47 eight-byte ones of 16x16x16: 53 -> 57 % of the HBM peak),
                                               // radix-32 last pass shared by thread pairs
-using G16384 = Geom<16384, 512, 16, 16, 32>;  // eight wavefronts; the radix-32 pass is shared by thread pairs
+using G16384 = Geom<16384, 512, 8, 32, 32>;   // eight wavefronts; radix 8 first (16-byte pass-1 vectors: 51.7 -> 53.5 % over
+                                              // 16x16x32), both radix-32 passes shared by thread pairs
 using G32768 = Geom<32768, 1024, 16, 32, 32>; // sixteen wavefronts = one workgroup per spectrum (132 KB of LDS); both radix-32
                                               // passes are shared by thread pairs.  The reference's "large FFT" range.
 
