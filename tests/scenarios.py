@@ -113,6 +113,10 @@ SCENARIOS = {
                                     steps=_steps(2) + [("noise_ch0_only", 17000), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 12
                                     + [("silence", 17000), ("tick",)] + [("silence", 800), ("tick",)] * 13 + [("noise_ch1_only", 800), ("tick",)] * 2,
                                     record=3),
+    "split_8192_half_silent": dict(cfg=dict(fft_size=8192, stereo=1, gravity=0.2, curve=1, interp_mode=1, filter_mode=1, filter_radius=2.0),
+                                   steps=_steps(2) + [("noise_ch1_only", 9000), ("tick",)] + [("noise_ch1_only", 800), ("tick",)] * 10
+                                   + [("silence", 9000), ("tick",)] + [("silence", 800), ("tick",)] * 12 + [("noise_ch0_only", 800), ("tick",)] * 2
+                                   + [("hide",), ("noise", 800), ("tick",), ("show",)] + _steps(2), record=3),
     "split_16384_hide_timeout": dict(cfg=dict(fft_size=16384, stereo=1, slope=1.0),
                                      steps=_steps(2) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(2)
                                      + [("timeout",), ("tick",), ("tick",)] + _steps(2), record=2),

@@ -585,10 +585,10 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     }
     WF_CREATE_TRY(dev_alloc(h, &h->d_tsmooth, n_spec * h->M));
     WF_CREATE_TRY(dev_alloc(h, &h->d_decibels, (size_t)h->n_streams * h->out_ch * h->M));
-    // Split mode: a stereo pair of the largest geometry in two workgroups (two per CU instead of one).  Measured on MI355X:
-    // N = 16384 45 -> 54 % of the HBM peak, N = 8192 no change (its pair already fits twice).  WF_HIP_SPLIT=0/1 overrides
-    // (development aid; mono mixdown and single-channel captures never split).
-    bool want_split = cfg->fft_size >= 16384;
+    // Split mode: the channels of a stereo pair in different workgroups.  Measured on MI355X: N = 16384 45 -> 52 % of the HBM
+    // peak (two workgroups per CU instead of one), N = 8192 57.2 -> 58.5 % (four instead of two), N = 32768 cannot run a
+    // pair any other way.  WF_HIP_SPLIT=0/1 overrides (development aid; mono mixdown and single-channel captures never split).
+    bool want_split = cfg->fft_size >= 8192;
     if(const char *e = std::getenv("WF_HIP_SPLIT"))
         want_split = (e[0] == '1') && cfg->fft_size >= 8192;
     want_split = want_split && cfg->capture_channels == 2 && cfg->stereo;
