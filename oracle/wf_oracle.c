@@ -136,6 +136,27 @@ static void fft_double(double *re, double *im, const double *twr, const double *
 static void r2c(wfo_source *s)
 {
     const uint32_t n = s->n;
+    if(n & (n - 1)) {
+        /* any other length (the reference takes every multiple of 16 >= 128): the DFT sum itself, in double; the table
+         * holds exp(-2 pi i k / n) for k < n / 2 and the second half of the circle is its negation */
+        const uint32_t h = n / 2;
+        for(uint32_t k = 0; k < s->m; ++k) {
+            double re = 0.0, im = 0.0;
+            uint32_t idx = 0; /* (j * k) mod n */
+            for(uint32_t j = 0; j < n; ++j) {
+                const double x = (double)s->fft_in[j];
+                const double cr = idx < h ? s->twr[idx] : -s->twr[idx - h], ci = idx < h ? s->twi[idx] : -s->twi[idx - h];
+                re += x * cr;
+                im += x * ci;
+                idx += k;
+                if(idx >= n)
+                    idx -= n;
+            }
+            s->fft_out[2 * k] = (float)re;
+            s->fft_out[2 * k + 1] = (float)im;
+        }
+        return;
+    }
     for(uint32_t i = 0; i < n; ++i) {
         s->wr[i] = (double)s->fft_in[i];
         s->wi[i] = 0.0;
@@ -394,8 +415,8 @@ static void ring_pop_front(wfo_source *s, int ch, size_t frames)
 
 wfo_source *wfo_create(const wf_config *cfg)
 {
-    if(cfg == NULL || cfg->fft_size < 128 || (cfg->fft_size & 15) || (cfg->fft_size & (cfg->fft_size - 1)))
-        return NULL; /* the restated DFT needs a power of two */
+    if(cfg == NULL || cfg->fft_size < 128 || (cfg->fft_size & 15))
+        return NULL; /* src/source.cpp:562-565: at least 128, a multiple of 16 */
     wfo_source *s = (wfo_source *)calloc(1, sizeof(*s));
     s->cfg = *cfg;
     s->n = cfg->fft_size;

@@ -120,6 +120,17 @@ SCENARIOS = {
     "split_16384_hide_timeout": dict(cfg=dict(fft_size=16384, stereo=1, slope=1.0),
                                      steps=_steps(2) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(2)
                                      + [("timeout",), ("tick",), ("tick",)] + _steps(2), record=2),
+    # ---- FFT sizes that are not powers of two (every other position of the reference's slider, and its "auto" size 800):
+    # Bluestein over the complex FFT core
+    "any_800_mono_mix_bars": dict(cfg=dict(fft_size=800, stereo=0, slope=1.0, bars=1, interp_mode=1), steps=_steps(6), record=2),
+    "any_1536_stereo_curve": dict(cfg=dict(fft_size=1536, stereo=1, tsmoothing=2, fast_peaks=1, curve=1, interp_mode=2, width=600, window=3),
+                                  steps=[("noise", 441), ("tick",)] * 4 + [("noise", 1024), ("tick",), ("noise", 3), ("tick",)], record=2),
+    "any_4160_stereo_silence": dict(cfg=dict(fft_size=4160, stereo=1, gravity=0.2, rolloff_q=1.5, rolloff_rate=12.0),
+                                    steps=_steps(3) + [("noise_ch0_only", 4400), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 5
+                                    + [("silence", 4400), ("tick",)] + [("silence", 800), ("tick",)] * 12 + _steps(2)
+                                    + [("hide",), ("noise", 800), ("tick",), ("show",)] + _steps(2), record=3),
+    "any_8000_single_nosmooth": dict(cfg=dict(fft_size=8000, stereo=0, capture_channels=1, tsmoothing=0, window=1),
+                                     steps=_steps(3), record=1),
     # ---- 32768 points ("large FFT"): one spectrum per workgroup, both radix-32 passes shared by thread pairs; stereo runs split
     "large_32768_stereo_bars": dict(cfg=dict(fft_size=32768, stereo=1, slope=1.0, bars=1, interp_mode=1), steps=_steps(4), record=1),
     "large_32768_single_tv": dict(cfg=dict(fft_size=32768, stereo=0, capture_channels=1, tsmoothing=2, fast_peaks=1, window=4),
