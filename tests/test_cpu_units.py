@@ -71,7 +71,7 @@ def test_host_tables_bit_identical_to_oracle(ov):
 
 
 def test_unsupported_fft_sizes_are_rejected():
-    for n in (800, 64, 65536, 3000):
+    for n in (64, 65536, 3000, 12000):  # below the minimum, too long, not a multiple of 16, too long for Bluestein
         cfg = scenarios.make_config(dict(fft_size=n))
         with pytest.raises(ValueError):
             emu.host_table(cfg, 0)
@@ -245,9 +245,9 @@ def _create_code(**overrides):
 
 
 def test_fft_sizes_accepted_and_rejected():
-    for n in (128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768):
+    for n in (128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 144, 800, 4160, 8000, 10912):
         assert _create_code(fft_size=n) == -3, n
-    for n in (64, 800, 4160, 65536):  # legal for the reference (multiples of 16 >= 128 up to 65536) or below its minimum
+    for n in (64, 808, 10928, 65536):  # legal for the reference (multiples of 16 >= 128 up to 65536) or below its minimum
         assert _create_code(fft_size=n) == -2, n
 
 

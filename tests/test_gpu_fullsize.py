@@ -130,8 +130,8 @@ def test_delay_frames_is_the_av_sync_window():
 
 def test_errors_are_reported_not_thrown():
     with pytest.raises(wf.WfHipError) as e:
-        wf.SpectrumBatch(wf.Config.defaults(fft_size=800), 1)
-    assert e.value.code == -2  # WF_HIP_ERR_UNSUPPORTED: legal for the reference (multiple of 16), not implemented here
+        wf.SpectrumBatch(wf.Config.defaults(fft_size=12000), 1)
+    assert e.value.code == -2  # WF_HIP_ERR_UNSUPPORTED: legal for the reference with "large FFT", too long for the Bluestein path
     cfg = wf.Config.defaults(fft_size=1024)
     with wf.SpectrumBatch(cfg, 2) as b:
         with pytest.raises(wf.WfHipError):

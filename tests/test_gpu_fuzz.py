@@ -15,7 +15,7 @@ import pytest
 import scenarios
 from helpers import assert_db_close
 
-CASES = list(range(40)) + [527]  # 527: mono mixdown + Gaussian filter on a one-wavefront geometry (LDS staging race, fixed)
+CASES = list(range(40)) + [527] + list(range(2000, 2016))  # 527: mono mixdown + Gaussian filter on a one-wavefront geometry (LDS staging race, fixed)
 
 
 def draw(seed: int):
@@ -23,6 +23,8 @@ def draw(seed: int):
     n = int(r.choice([1024, 2048, 4096, 8192, 16384], p=[0.3, 0.25, 0.25, 0.1, 0.1]))
     if 28 <= seed < 1000:  # cases added with the zero-padded small sizes: the earlier draws stay what they were
         n = int(r.choice([128, 256, 512]))
+    if 2000 <= seed < 3000:  # FFT sizes that are not powers of two (Bluestein path)
+        n = int(r.choice([144, 800, 1008, 1536, 2640, 4160, 5456, 6000]))
     layout = int(r.integers(0, 4))  # 0 mono capture, 1 mono mixdown of 2, 2 stereo, 3 one captured channel shown twice
     cfg = dict(fft_size=n,
                capture_channels=1 if layout in (0, 3) else 2,

@@ -46,6 +46,10 @@ struct wf_hip {
     uint32_t *d_verdict = nullptr;   // split mode: [3][n_streams * cap_ch] "row has a value > floor - 10" (TickArgs::verdict_*)
     uint32_t flag_bufs = 1, flag_cur = 0;
     bool split = false;              // the channels of a stream run in different workgroups (spectrum_tick_kernel<.., SPLIT>)
+    // FFT sizes that are not powers of two: Bluestein over the geometry of geom_n = 2 * L points (spectrum_tick_kernel<.., BLU>)
+    bool blu = false;
+    uint32_t geom_n = 0;             // the fft size whose geometry runs the batch (N itself for the power-of-two sizes >= 1024)
+    wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr;
     float *d_bars = nullptr;
     float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
@@ -190,6 +194,29 @@ template<class G, int DEC> int setup_launch_dec(wf_hip *h)
     return WF_HIP_OK;
 }
 
+// Bluestein path (FFT sizes that are not powers of two): always the scalar fetch
+template<class G, int SPW, bool SPLIT> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a, bool)
+{
+    const uint32_t n_spec = a.n_streams * a.cap_ch;
+    const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
+    const size_t lds = wf::tick_lds_bytes<G, SPW>();
+    hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>), grid, block, lds, h->stream, a);
+}
+
+template<class G, int SPW, bool SPLIT> int setup_launch_blu(wf_hip *h)
+{
+    const int lds = (int)wf::tick_lds_bytes<G, SPW>();
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick_blu<G, SPW, SPLIT>;
+    h->split = SPLIT;
+    char name[128];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%u by Bluestein over %d complex points,T=%d,R=%dx%dx%d,SPW=%d%s>", h->N, G::M, G::T,
+             G::R1, G::R2, G::R3, SPW, SPLIT ? ",split" : "");
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
 template<class G, int SPW, bool TLDS> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     const uint32_t n_spec = a.n_streams * a.cap_ch;
@@ -302,6 +329,13 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     }
     a.half_coef = 0.5f * (2.0f / h->tab.window_sum); // mag_coefficient (reference src/source_generic.cpp:110), halved: the
                                                      // kernel produces 2X[k] from the real split
+    a.row_bins = h->M;
+    if(h->blu) {
+        a.blu_a = h->d_blu_a;
+        a.blu_b = h->d_blu_b;
+        a.blu_n = h->N;
+        a.half_coef = (2.0f / h->tab.window_sum) / (float)(h->geom_n / 2); // |c_k| / L, times mag_coefficient
+    }
     a.g = wf::gravity_for(h->cfg, p->seconds);
     a.g2 = 1.0f - a.g;
     a.db_min = wf::db_min();
@@ -478,7 +512,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(rc == WF_HIP_ERR_UNSUPPORTED && cfg->waveform)
         return fail(nullptr, rc, "waveform display: width %u above 8192 points is not implemented", cfg->width);
     if(rc == WF_HIP_ERR_UNSUPPORTED)
-        return fail(nullptr, rc, "fft_size %u: only powers of two in 128..32768 are implemented", cfg->fft_size);
+        return fail(nullptr, rc, "fft_size %u: implemented are the powers of two 128..32768 and every other multiple of 16 from 128 to 10912", cfg->fft_size);
     if(rc)
         return fail(nullptr, rc, "invalid configuration");
     const int ndev = wf_hip_device_count();
@@ -501,6 +535,11 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     h->disp_ch = h->tab.display_channels;
     h->num_bars = (uint32_t)h->tab.num_bars;
     h->ring_cap = next_pow2(ring_frames ? std::max(ring_frames, h->N) : std::max(2 * h->N, 4096u));
+    {
+        const uint32_t L = (cfg->meter || cfg->waveform) ? 0u : wf::bluestein_length(cfg->fft_size);
+        h->blu = L != 0;
+        h->geom_n = L ? 2 * L : std::max(h->N, 1024u);
+    }
     if(cfg->waveform) {
         // rows of `width` points; the ring holds the history the points are picked from (+ the width zeros of update())
         h->wave = true;
@@ -588,9 +627,9 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     // Split mode: the channels of a stereo pair in different workgroups.  Measured on MI355X: N = 16384 45 -> 52 % of the HBM
     // peak (two workgroups per CU instead of one), N = 8192 57.2 -> 58.5 % (four instead of two), N = 32768 cannot run a
     // pair any other way.  WF_HIP_SPLIT=0/1 overrides (development aid; mono mixdown and single-channel captures never split).
-    bool want_split = cfg->fft_size >= 8192;
+    bool want_split = h->geom_n >= 8192;
     if(const char *e = std::getenv("WF_HIP_SPLIT"))
-        want_split = (e[0] == '1') && cfg->fft_size >= 8192;
+        want_split = (e[0] == '1') && h->geom_n >= 8192;
     want_split = want_split && cfg->capture_channels == 2 && cfg->stereo;
     h->flag_bufs = want_split ? 3 : 1;
     WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->flag_bufs * h->n_streams));
@@ -619,7 +658,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         // LDS scratch for the products: what is left of a spectrum's exchange buffer behind the M dB values
         size_t lds_floats = 0;
         int threads = 64;
-        wf::dispatch_geometry(std::max(h->N, 1024u), [&](auto g) {
+        wf::dispatch_geometry(h->geom_n, [&](auto g) {
             using G = decltype(g);
             lds_floats = (size_t)G::LDS_CF * 2;
             threads = G::T;
@@ -632,7 +671,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             lpb *= 2;
         h->bar_lpb = lpb;
         int points = 16;
-        wf::dispatch_geometry(std::max(h->N, 1024u), [&](auto g) { points = decltype(g)::P; });
+        wf::dispatch_geometry(h->geom_n, [&](auto g) { points = decltype(g)::P; });
         const int kmax = threads <= 64 ? 16 : 8; // wf::OutVals<G>::KMAX
         h->curve = !cfg->bars && cfg->curve;
         if(h->curve) {
@@ -677,11 +716,25 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     // FFT plan: twiddle tables for the geometry of this fft_size + the kernel instantiation
     int setup_rc = WF_HIP_ERR_UNSUPPORTED;
     std::vector<wf::cfloat> tw1, tw2, tws;
-    wf::dispatch_geometry(std::max(h->N, 1024u), [&](auto g) {
+    wf::dispatch_geometry(h->geom_n, [&](auto g) {
         using G = decltype(g);
         wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
         // the channels of a stream share a workgroup (silence state machine, mono mixdown)
-        if constexpr(G::N == 1024) {
+        if(h->blu) {
+            if constexpr(G::N >= 32768) {
+                if(want_split)
+                    setup_rc = setup_launch_blu<G, 1, true>(h);
+                else if(cfg->capture_channels == 1)
+                    setup_rc = setup_launch_blu<G, 1, false>(h);
+                else
+                    setup_rc = fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: mono mixdown of two captured channels is not implemented above 5456",
+                                    cfg->fft_size);
+            } else if constexpr(G::T >= 256)
+                setup_rc = want_split ? setup_launch_blu<G, 1, true>(h)
+                                      : (cfg->capture_channels > 1) ? setup_launch_blu<G, 2, false>(h) : setup_launch_blu<G, 1, false>(h);
+            else
+                setup_rc = setup_launch_blu<G, 2, false>(h);
+        } else if constexpr(G::N == 1024) {
             switch(h->N) {
             case 512: setup_rc = setup_launch_dec<G, 1>(h); break;
             case 256: setup_rc = setup_launch_dec<G, 2>(h); break;
@@ -713,6 +766,16 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_tw2, t2));
         WF_CREATE_TRY(upload(h, &h->d_tws, t3));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
+    }
+    if(h->blu) {
+        wf::BluesteinTables bt;
+        wf::build_bluestein(h->cfg, h->tab, bt);
+        std::vector<wf::cf> ta(bt.a.size()), tb(bt.b.size());
+        std::memcpy(ta.data(), bt.a.data(), ta.size() * sizeof(wf::cf));
+        std::memcpy(tb.data(), bt.b.data(), tb.size() * sizeof(wf::cf));
+        WF_CREATE_TRY(upload(h, &h->d_blu_a, ta));
+        WF_CREATE_TRY(upload(h, &h->d_blu_b, tb));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
     WF_CREATE_TRY(wf_hip_reset(h, 0, h->n_streams));
     WF_CREATE_HIP(hipStreamSynchronize(h->stream));

@@ -496,7 +496,9 @@ int build_host_tables(const wf_config &cfg, HostTables &out)
         render_geometry(cfg, false, out);
         return WF_HIP_OK;
     }
-    if(!is_pow2(cfg.fft_size) || cfg.fft_size < 128 || cfg.fft_size > 32768)
+    if(cfg.fft_size < 128 || (cfg.fft_size & 15u)) // the reference raises / aligns such values itself (src/source.cpp:562-565)
+        return WF_HIP_ERR_UNSUPPORTED;
+    if(is_pow2(cfg.fft_size) ? cfg.fft_size > 32768 : bluestein_length(cfg.fft_size) == 0)
         return WF_HIP_ERR_UNSUPPORTED;
     if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0)
         return WF_HIP_ERR_INVALID;
@@ -515,6 +517,83 @@ int build_host_tables(const wf_config &cfg, HostTables &out)
     out.display_channels = cfg.stereo ? 2u : 1u;
     build_bars(cfg, out);
     return WF_HIP_OK;
+}
+
+uint32_t bluestein_length(uint32_t n)
+{
+    if(is_pow2(n))
+        return 0;
+    uint32_t L = 512;
+    while((uint64_t)L * 2 < (uint64_t)n * 3) // L >= 3n/2
+        L <<= 1;
+    return L <= 16384u ? L : 0u; // 16384 complex points = the 32768 geometry
+}
+
+namespace {
+// iterative radix-2 complex FFT in double (host, tables only)
+void fft_double(std::vector<double> &re, std::vector<double> &im)
+{
+    const size_t n = re.size();
+    for(size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for(; j & bit; bit >>= 1)
+            j ^= bit;
+        j ^= bit;
+        if(i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    const double two_pi = 6.283185307179586476925286766559;
+    for(size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len >> 1;
+        for(size_t k = 0; k < half; ++k) {
+            const double a = -two_pi * (double)k / (double)len;
+            const double cr = std::cos(a), ci = std::sin(a);
+            for(size_t i = k; i < n; i += len) {
+                const double xr = re[i + half] * cr - im[i + half] * ci;
+                const double xi = re[i + half] * ci + im[i + half] * cr;
+                re[i + half] = re[i] - xr;
+                im[i + half] = im[i] - xi;
+                re[i] += xr;
+                im[i] += xi;
+            }
+        }
+    }
+}
+} // namespace
+
+void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out)
+{
+    const uint32_t n = cfg.fft_size;
+    out = BluesteinTables{};
+    out.L = bluestein_length(n);
+    if(out.L == 0)
+        return;
+    const uint32_t L = out.L;
+    const double pi = 3.14159265358979323846264338327950288;
+    auto chirp = [&](uint64_t m, double &cr, double &ci) { // w_m = exp(i pi m^2 / n), the phase reduced exactly
+        const uint64_t ph = (m * m) % (2ull * n);
+        const double a = pi * (double)ph / (double)n;
+        cr = std::cos(a);
+        ci = std::sin(a);
+    };
+    out.a.assign(L, cfloat{0.0f, 0.0f});
+    for(uint32_t j = 0; j < n; ++j) {
+        double cr, ci;
+        chirp(j, cr, ci);
+        const double w = t.window.empty() ? 1.0 : (double)t.window[j];
+        out.a[j] = cfloat{(float)(w * cr), (float)(-w * ci)};
+    }
+    std::vector<double> br(L, 0.0), bi(L, 0.0);
+    for(uint32_t m = 0; m < n && m <= L - n; ++m) // non-negative lags; only m < n/2 is ever needed and L - n >= n/2
+        chirp(m, br[m], bi[m]);
+    for(uint32_t m = 1; m < n; ++m) // negative lags, wrapped
+        chirp(m, br[L - m], bi[L - m]);
+    fft_double(br, bi);
+    out.b.resize(L);
+    for(uint32_t k = 0; k < L; ++k)
+        out.b[k] = cfloat{(float)br[k], (float)bi[k]};
 }
 
 void build_twiddles(int M, int R1, int R2, int R3, std::vector<cfloat> &tw1, std::vector<cfloat> &tw2, std::vector<cfloat> &tws)

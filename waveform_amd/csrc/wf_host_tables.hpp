@@ -13,6 +13,8 @@
 
 namespace wf {
 
+struct cfloat { float re, im; };
+
 struct HostTables {
     // spectrum
     std::vector<float> window;   // [N], empty when FFTWindow::NONE
@@ -75,13 +77,26 @@ struct CurveLaneTables {
 };
 bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max_steps, CurveLaneTables &out);
 
+// FFT sizes that are not powers of two: Bluestein's algorithm over the complex FFT core.
+//   X_k = conj(w_k) * sum_j (x_j conj(w_j)) w_(k-j),  w_m = exp(i pi m^2 / n)   (jk = (j^2 + k^2 - (k-j)^2) / 2)
+// i.e. |X_k| = |(a * b)_k| with a_j = window_j x_j conj(w_j), b_m = w_m: a circular convolution of length L >= 3n/2 (only
+// k < n/2 is wanted), computed as IFFT_L(FFT_L(a) . FFT_L(b)).  The tables: a's constant factor and FFT_L(b), in double,
+// rounded once.
+struct BluesteinTables {
+    uint32_t L = 0;            // complex transform length: smallest power of two >= 3n/2 (and >= 512)
+    std::vector<cfloat> a;     // [L] window_j * conj(w_j), zero for j >= n
+    std::vector<cfloat> b;     // [L] FFT_L of the chirp, b_m = w_m for -(n-1) <= m <= L-n (negative m wrapped)
+};
+// 0 when n is a power of two (no Bluestein needed) or too long for the largest geometry
+uint32_t bluestein_length(uint32_t n);
+void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out);
+
 // get_gravity(seconds), src/source.hpp:301-312
 float gravity_for(const wf_config &cfg, float seconds);
 // DB_MIN, src/source.cpp:43
 float db_min();
 
 // FFT twiddle tables for the (R1, R2, R3) decomposition of the M-point complex FFT
-struct cfloat { float re, im; };
 void build_twiddles(int M, int R1, int R2, int R3, std::vector<cfloat> &tw1, std::vector<cfloat> &tw2,
                     std::vector<cfloat> &tws);
 

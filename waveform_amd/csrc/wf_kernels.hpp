@@ -109,16 +109,24 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // vector-memory path, twice per workgroup), the workgroup copies both tables once by LDS-DMA into the exchange buffers --
 // free until pass 1 stores into them -- and the threads take their operands from LDS; one more barrier separates those
 // reads from pass 1's stores.
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false>
+//
+// BLU: FFT sizes that are not powers of two (Bluestein, see p1_fetch_blu): the geometry's M-point complex transform runs
+// twice -- on the chirped window, then (conjugated) on its product with the chirp's transform -- and the epilogue takes
+// |c_k| of the first a.row_bins bins directly, no real split.  Rows and state have a.row_bins (a run-time number) entries;
+// the threads whose groups of four bins lie beyond it sit the epilogue out.
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false>
 __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
+    static_assert(!BLU || (DEC == 0 && !TLDS && !ALIGNED), "Bluestein path: scalar fetch, no decimation, no staged tables");
     static_assert(!TLDS || (SPW == 2 && !SPLIT && DEC == 0 && (size_t)SPW * G::LDS_CF * sizeof(cf) >= 2u * G::N * sizeof(float)),
                   "staged tables: window + pass-1 twiddles must fit the workgroup's exchange buffers");
     static_assert(!SPLIT || SPW == 1, "split mode: one spectrum per workgroup");
     static_assert(DEC == 0 || (!SPLIT && G::T == 64 && (G::R1 >> DEC) >= 1 && (G::M >> DEC) >= 64), "decimated path: one-wavefront geometry");
-    constexpr int MO = G::M >> DEC;                        // bins per output row
-    using RG = RowG<DEC ? MO / 4 : G::T, DEC ? 4 : G::P>;  // threads x bins per thread that own the output rows
+    constexpr int MO_C = G::M >> DEC;                       // bins per output row (power-of-two paths)
+    using RG = RowG<DEC ? MO_C / 4 : G::T, DEC ? 4 : G::P>; // threads x bins per thread that own the output rows
     constexpr int RP = RG::P;
+    const int MO = BLU ? (int)a.row_bins : MO_C;            // run-time only for the Bluestein path
+    const int NB = MO;                                      // row bound of the guarded row helpers (BLU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int T = G::T, P = G::P, WPS = G::T / 64;
     const int tid = (int)threadIdx.x;
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
     const float *x = a.ring + (size_t)spec * a.ring_stride;
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
-    const uint32_t start = (wpos - delay - (uint32_t)(G::N >> DEC)) & a.ring_mask;
+    const uint32_t start = (wpos - delay - (BLU ? a.blu_n : (uint32_t)(G::N >> DEC))) & a.ring_mask;
     float *ts = a.tsmooth + (size_t)spec * MO;
     float *rows = a.decibels + (size_t)stream * a.out_ch * MO; // m_decibels[0..out_ch) of this stream
     const bool row_thread = DEC == 0 || t < RG::T;             // this thread owns bins of the output row
@@ -166,7 +174,10 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     // (hidden streams are fetched too: the flags word is not waited for before the loads are issued)
     P1Regs<G> r1;
     bool nz = false;
-    if(active)
+    if constexpr(BLU) {
+        if(active)
+            nz = p1_fetch_blu<G>(a, t, x, start, r1) && !hidden;
+    } else if(active)
         nz = p1_fetch<G, ALIGNED, DEC, TLDS>(a, t, x, start, r1) && !hidden;
     if constexpr(TLDS) {
         lds_dma_copy<G::N * (int)sizeof(float)>(a.window, smem_raw, wave_in_block, T * SPW / 64, lane);
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(1);
     bool wave_below = true;
     if(active && !hidden && !wave_nz) // wave-uniform and rare: the whole slice of this wave is digital silence
-        wave_below = __all(!row_thread || row_all_below<RG>(rows + (size_t)(stereo ? ch : 0u) * MO, t, a.silent_floor)) != 0;
+        wave_below = __all(!row_thread || row_all_below<RG, BLU>(rows + (size_t)(stereo ? ch : 0u) * MO, t, a.silent_floor, NB)) != 0;
 
     bool nz0 = wave_nz, nz1 = false, below0 = wave_below, below1 = true;
     if(lane == 0)
@@ -196,7 +207,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         if(!nz_own && !hidden) { // workgroup-uniform and rare: this channel's window is digital silence
             const float *xo = a.ring + (size_t)(spec ^ 1u) * a.ring_stride;
             uint32_t acc = 0;
-            for(uint32_t i = (uint32_t)tid; i < (uint32_t)G::N; i += (uint32_t)T)
+            const uint32_t wlen = BLU ? a.blu_n : (uint32_t)G::N; // the partner's window is as long as this one
+            for(uint32_t i = (uint32_t)tid; i < wlen; i += (uint32_t)T)
                 acc |= f32_bits(xo[(start + i) & a.ring_mask]);
             const bool w_nz = __any((acc & 0x7fffffffu) != 0) != 0;
             if(lane == 0)
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             p1_window_pass1<G>(a, t, r1, lds);
         if constexpr(DEC > 0)
             p4_prefetch_dec<G, DEC>(a, t, ts, r4);
-        else
+        else if constexpr(!BLU) // the Bluestein epilogue loads its (shorter) rows itself
             p4_prefetch<G>(a, t, ts, r4);
     }
     __builtin_amdgcn_sched_barrier(0); // keep the prefetch up here: do not sink it to its first use in P4
@@ -277,9 +289,32 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         p3_pass3_write<G>(t, lds, v);
     WF_STAMP(7);
     spectrum_sync<G>();
+    if constexpr(BLU) {
+        // second transform: conj(FFT(a) . FFT(b)) read from the natural-order buffer, then passes 1-3 again
+        if(process)
+            blu_mid<G>(a, t, lds, r1);
+        spectrum_sync<G>(); // every thread has read its points: pass 1 may overwrite the buffer
+        if(process)
+            p1_window_pass1<G>(a, t, r1, lds);
+        spectrum_sync<G>();
+        if(process)
+            p2_read<G>(t, lds, v);
+        spectrum_sync<G>();
+        if(process)
+            p2_pass2_write<G>(tw2_lds, t, lds, v);
+        spectrum_sync<G>();
+        if(process)
+            p3_read<G>(t, lds, v);
+        spectrum_sync<G>();
+        if(process)
+            p3_pass3_write<G>(t, lds, v);
+        spectrum_sync<G>();
+    }
     WF_STAMP(8);
     if(process) {
-        if constexpr(DEC > 0) {
+        if constexpr(BLU) {
+            p4_direct<G>(a, t, lds, ts, mag);
+        } else if constexpr(DEC > 0) {
             if(row_thread)
                 p4_split_smooth_dec<G, DEC>(a, t, lds, ts, r1.wb, r4, mag);
         } else {
@@ -288,18 +323,18 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
                 asm volatile("" ::"v"(r4.touch[0]), "v"(r4.touch[1])); // the touched dwords are only ever waited for
         }
     } else if(do_db && !(mono_mix && ch == 1) && row_thread)
-        load_row<RG>(rows + (size_t)ch * MO, t, mag); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
+        load_row<RG, BLU>(rows + (size_t)ch * MO, t, mag, NB); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
 
     // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------
     if(active && hidden && !was_silent) {
         if((a.mode & WF_MODE_TSMOOTH) && row_thread)
-            fill_row<RG>(ts, t, 0.0f);
+            fill_row<RG, BLU>(ts, t, 0.0f, NB);
         if(ch < (stereo ? 2u : 1u)) {
             const bool dup = a.out_ch > a.cap_ch; // one captured channel shown as two rows
             if(!a.skip_decibels && row_thread) {
-                fill_row<RG>(rows + (size_t)ch * MO, t, a.db_min);
+                fill_row<RG, BLU>(rows + (size_t)ch * MO, t, a.db_min, NB);
                 if(dup)
-                    fill_row<RG>(rows + (size_t)MO, t, a.db_min);
+                    fill_row<RG, BLU>(rows + (size_t)MO, t, a.db_min, NB);
             }
             if(a.bar.out != nullptr) {
                 // what render_bars makes of rows of DB_MIN: every bar at border_bottom
@@ -342,11 +377,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
     float d[RP];
     if(have_row && row_thread) {
-        p4_db<RG>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp);
+        p4_db<RG, BLU>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp, NB);
         if(!a.skip_decibels) {
-            store_row<RG>(rows + (size_t)ch * MO, t, d);
+            store_row<RG, BLU>(rows + (size_t)ch * MO, t, d, NB);
             if(dup_row)
-                store_row<RG>(rows + (size_t)MO, t, d);
+                store_row<RG, BLU>(rows + (size_t)MO, t, d, NB);
         }
     }
     WF_STAMP(10);
@@ -359,7 +394,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         if(have_row) {
 #pragma unroll
             for(int i = 0; i < RP; ++i)
-                exceeds = exceeds || (d[i] > a.silent_floor);
+                exceeds = exceeds || ((!BLU || 4 * (t + T * (i / 4)) < NB) && d[i] > a.silent_floor);
         } else if(!(hidden && !was_silent)) // row untouched this tick (the reset branch leaves DB_MIN everywhere: below)
             exceeds = (ch == 0 ? vin0 : vin1) != 0u;
         if(__any(exceeds) && lane == 0)
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         float *dbl = reinterpret_cast<float *>(lds);
         spectrum_sync<G>(); // every thread of the spectrum is done reading its exchange buffer
         if(have_row && row_thread)
-            store_row<RG>(dbl, t, d);
+            store_row<RG, BLU>(dbl, t, d, NB);
         spectrum_sync<G>();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
         float *out1 = dup_row ? out0 + a.bar.num_bars : nullptr;

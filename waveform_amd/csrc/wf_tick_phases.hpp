@@ -133,6 +133,12 @@ struct TickArgs {
     uint32_t out_ch;           // m_output_channels
     uint32_t mode;
     uint32_t skip_decibels;    // WF_HIP_TICK_NO_DECIBELS: bars-only batch mode
+    // FFT sizes that are not powers of two (Bluestein, spectrum_tick_kernel<.., BLU>): the geometry's M is the padded
+    // convolution length L, the transform the host asked for has blu_n points and row_bins = blu_n / 2 output bins
+    const cf *blu_a;           // [M] window_j * conj(w_j), zero for j >= blu_n
+    const cf *blu_b;           // [M] FFT_M of the chirp
+    uint32_t blu_n;
+    uint32_t row_bins;         // bins per output / state row (M >> DEC for the power-of-two paths)
     BarArgs bar;
     unsigned long long *phase_clock; // development aid (builds with -DWF_PHASE_TIMING): s_memtime stamps per workgroup
 };
@@ -447,6 +453,117 @@ template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float 
             q.sl[S * (4 * u)] = o.x; q.sl[S * (4 * u + 1)] = o.y; q.sl[S * (4 * u + 2)] = o.z; q.sl[S * (4 * u + 3)] = o.w;
         }
     }
+}
+
+// ---- Bluestein (FFT sizes that are not powers of two) ---------------------------------------------------------------------
+// X_k = conj(w_k) sum_j (x_j conj(w_j)) w_(k-j), w_m = exp(i pi m^2 / n): a circular convolution of length M >= 3n/2 done
+// with two M-point complex transforms of the same core.  The product a_j = x_j * (window_j conj(w_j)) is the first
+// transform's input, already complex: it goes through p1_window_dft with a window of ones.
+template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
+{
+    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    uint32_t acc = 0;
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        float xs[B1];
+        WF_UNROLL
+        for(int b = 0; b < B1; ++b) {
+            const uint32_t idx = (uint32_t)(j * M1 + B1 * t + b);
+            const bool in = idx < a.blu_n;
+            const float v = x[(start + (in ? idx : 0u)) & a.ring_mask];
+            xs[b] = in ? v : 0.0f;
+            acc |= f32_bits(xs[b]);
+        }
+        const float *tab = reinterpret_cast<const float *>(a.blu_a + j * M1 + B1 * t);
+        if(B1 == 2) {
+            const f4 q = ld4(tab);
+            r.smp[j][0] = xs[0] * q.x; r.smp[j][1] = xs[0] * q.y;
+            r.smp[j][2 * B1 - 2] = xs[B1 - 1] * q.z; r.smp[j][2 * B1 - 1] = xs[B1 - 1] * q.w;
+        } else {
+            const f2 q = ld2(tab);
+            r.smp[j][0] = xs[0] * q.x; r.smp[j][1] = xs[0] * q.y;
+        }
+        WF_UNROLL
+        for(int e = 0; e < 2 * B1; ++e)
+            r.win[j][e] = 1.0f;
+        if(j >= 1)
+            p1_load_tw1<G>(a, t, j, r.tw1[j]);
+    }
+    return (acc & 0x7fffffffu) != 0;
+}
+
+// between the transforms: conj(FFT(a) . FFT(b)) for this thread's pass-1 points, read from the natural-order buffer
+// (IFFT(C) = conj(FFT(conj(C))) / M; the conjugation and the 1/M on the way out do not change a magnitude)
+template<class G> WF_DEV void blu_mid(const TickArgs &a, int t, const cf *lds, P1Regs<G> &r)
+{
+    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        const int idx = j * M1 + B1 * t;
+        cf bv[B1];
+        const float *tab = reinterpret_cast<const float *>(a.blu_b + idx);
+        if(B1 == 2) {
+            const f4 q = ld4(tab);
+            bv[0] = cf{q.x, q.y}; bv[B1 - 1] = cf{q.z, q.w};
+        } else {
+            const f2 q = ld2(tab);
+            bv[0] = cf{q.x, q.y};
+        }
+        WF_UNROLL
+        for(int b = 0; b < B1; ++b) {
+            const cf c = cmul(lds_ld2(lds, ex3_addr<G>(idx + b)), bv[b]);
+            r.smp[j][2 * b] = c.x;
+            r.smp[j][2 * b + 1] = -c.y;
+        }
+        WF_UNROLL
+        for(int e = 0; e < 2 * B1; ++e)
+            r.win[j][e] = 1.0f;
+        if(j >= 1)
+            p1_load_tw1<G>(a, t, j, r.tw1[j]);
+    }
+}
+
+// epilogue without a real split: |X_k| = |c_k| for the first row_bins outputs; slope, smoothing and the state store as in
+// p4_slope_smooth_group, on the groups of four bins that lie inside the row
+template<class G, bool TS, bool FPK>
+WF_DEV void p4_direct_impl(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
+{
+    constexpr int T = G::T, P = G::P;
+    WF_UNROLL
+    for(int u = 0; u < P / 4; ++u) {
+        const int k0 = 4 * (t + T * u);
+        if(k0 < (int)a.row_bins) {
+            const f4 sv = ld4(a.slope + k0);
+            f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            if(TS)
+                st = ld4(ts + k0);
+            const float sl4[4] = {sv.x, sv.y, sv.z, sv.w}, st4v[4] = {st.x, st.y, st.z, st.w};
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i) {
+                const cf z = lds_ld2(lds, ex3_addr<G>(k0 + i));
+                float m = mag2(z.x, z.y) * a.half_coef * sl4[i];
+                if(TS) {
+                    float old = st4v[i];
+                    if(FPK)
+                        old = fmaxf(m, old);
+                    m = fmaf(a.g, old, a.g2 * m);
+                }
+                mag[4 * u + i] = m;
+            }
+            if(TS)
+                st4(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+        }
+    }
+}
+template<class G> WF_DEV void p4_direct(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
+{
+    if(a.mode & WF_MODE_TSMOOTH) {
+        if(a.mode & WF_MODE_FAST_PEAKS)
+            p4_direct_impl<G, true, true>(a, t, lds, ts, mag);
+        else
+            p4_direct_impl<G, true, false>(a, t, lds, ts, mag);
+    } else
+        p4_direct_impl<G, false, false>(a, t, lds, ts, mag);
 }
 
 // ---- P2: pass 2 ---------------------------------------------------------------------------------
@@ -820,12 +937,16 @@ WF_DEV void p4_split_smooth_dec(const TickArgs &a, int t, const cf *lds, float *
 
 // dB conversion + volume normalisation + roll-off of this thread's bins (reference :144-179); d[] is the
 // final m_decibels content, stored by store_row()
-template<class G> WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P], float vol_comp)
+// GUARD (rows shorter than T * P bins: the Bluestein path): groups of four bins at or beyond `nb` are skipped
+template<class G, bool GUARD = false>
+WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P], float vol_comp, int nb = 0)
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         const int k0 = 4 * (t + T * u);
+        if(GUARD && k0 >= nb)
+            continue;
         WF_UNROLL
         for(int i = 0; i < 4; ++i)
             d[4 * u + i] = dbfs(mag[4 * u + i], a.db_min);
@@ -846,22 +967,25 @@ template<class G> WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)
     }
 }
 
-template<class G> WF_DEV void store_row(float *row, int t, const float (&d)[G::P])
+template<class G, bool GUARD = false> WF_DEV void store_row(float *row, int t, const float (&d)[G::P], int nb = 0)
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u)
-        st4(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
+        if(!GUARD || 4 * (t + T * u) < nb)
+            st4(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
 }
 // ---- silence state machine helpers (reference :63-95, :138-139) ------------------------------------
 // "outsilent": every value of the previously displayed row is <= floor - 10.  Each thread looks at the
 // bins it owns in the P4 layout; the caller and-reduces over the spectrum's threads.
-template<class G> WF_DEV bool row_all_below(const float *row, int t, float limit)
+template<class G, bool GUARD = false> WF_DEV bool row_all_below(const float *row, int t, float limit, int nb = 0)
 {
     constexpr int T = G::T, P = G::P;
     bool below = true;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
+        if(GUARD && 4 * (t + T * u) >= nb)
+            continue;
         const f4 d = ld4(row + 4 * (t + T * u));
         below = below && !(d.x > limit) && !(d.y > limit) && !(d.z > limit) && !(d.w > limit);
     }
@@ -870,22 +994,25 @@ template<class G> WF_DEV bool row_all_below(const float *row, int t, float limit
 
 // a skipped channel of a stream that is not silent: the reference's end-of-tick dB pass runs over its
 // *stale* m_decibels row again; load that row as the "magnitudes"
-template<class G> WF_DEV void load_row(const float *row, int t, float (&mag)[G::P])
+template<class G, bool GUARD = false> WF_DEV void load_row(const float *row, int t, float (&mag)[G::P], int nb = 0)
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
+        if(GUARD && 4 * (t + T * u) >= nb)
+            continue;
         const f4 d = ld4(row + 4 * (t + T * u));
         mag[4 * u] = d.x; mag[4 * u + 1] = d.y; mag[4 * u + 2] = d.z; mag[4 * u + 3] = d.w;
     }
 }
 
-template<class G> WF_DEV void fill_row(float *row, int t, float v)
+template<class G, bool GUARD = false> WF_DEV void fill_row(float *row, int t, float v, int nb = 0)
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u)
-        st4(row + 4 * (t + T * u), f4{v, v, v, v});
+        if(!GUARD || 4 * (t + T * u) < nb)
+            st4(row + 4 * (t + T * u), f4{v, v, v, v});
 }
 
 // The per-stream decision of the channel loop, replayed from the per-channel facts.
