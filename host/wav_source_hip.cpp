@@ -128,7 +128,7 @@ bool WAVSourceHIP::hip_configure()
     c.rounded_caps = m_rounded_caps ? 1u : 0u;
     const int rc = api().create(&c, 0, 1, 0, &m_hip);
     if(rc != WF_HIP_OK) {
-        // e.g. WF_HIP_ERR_UNSUPPORTED for an FFT size that is not a power of two in 128..32768
+        // e.g. WF_HIP_ERR_UNSUPPORTED for an FFT size outside the implemented set (powers of two 128..32768, other multiples of 16 up to 10912)
         LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
         m_hip = nullptr;
         return false;

@@ -29,7 +29,8 @@
  *   wf_hip_enable_input_rms / wf_hip_read_input_rms
  *                        capture_audio's RMS part + sync_rms_buffer + update_input_rms
  *                        (src/source.cpp:1842-1871, :810-835; src/source_generic.cpp:392-403)
- * FFT sizes: powers of two 128..32768 (the reference: any multiple of 16 >= 128, up to 65536); others ->
+ * FFT sizes: powers of two 128..32768 and every other multiple of 16 from 128 to 10912 (Bluestein); the reference: any
+ * multiple of 16 >= 128, up to 65536; others ->
  * WF_HIP_ERR_UNSUPPORTED and the host keeps its CPU class.
  *
  * Waveform display.  A handle created from a configuration with cfg.waveform != 0 is a *waveform batch*: wf_hip_tick runs
