@@ -113,6 +113,17 @@ uint32_t wf_hip_ring_frames(const wf_hip *h);
  * Layout of `samples` (host memory): [count][capture_channels][frames], planar float32 --
  * what capture_audio receives per source in audio_data::data[] (src/source.cpp:1873-1882). */
 int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames);
+/* Pipelined ingest: page-locked host buffers (wf_hip_host_alloc) are copied by DMA without the runtime's bounce buffer, on a
+ * second HIP stream of the handle, so that the copy of the next packet runs under the tick of the previous one; the ring
+ * append is ordered behind the copy, the next tick behind the append.  The call does not wait: `samples` must stay
+ * untouched until wf_hip_ingest_done(slot) -- two buffers used alternately (slot 0 / 1) keep a 60 fps loop from ever waiting.
+ * Layout as wf_hip_push_audio.  Measured (4096 stereo streams, one 800-frame hop each per step). */
+int wf_hip_push_audio_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_samples, uint32_t frames, uint32_t slot);
+/* blocks until the copy issued with `slot` (0 or 1) has left the host buffer */
+int wf_hip_ingest_done(wf_hip *h, uint32_t slot);
+/* page-locked host memory for wf_hip_push_audio_async (hipHostMalloc); NULL on failure */
+void *wf_hip_host_alloc(size_t bytes);
+void wf_hip_host_free(void *p);
 /* Same, from a device pointer on the handle's device (no PCIe crossing). */
 int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const float *d_samples, uint32_t frames);
 /* Same, but the samples are generated on the device by the counter hash of wf_synth.h:

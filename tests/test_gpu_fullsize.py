@@ -140,3 +140,27 @@ def test_errors_are_reported_not_thrown():
             b.bars()
         with pytest.raises(wf.WfHipError):
             b.decibels(first=2, count=1)
+
+
+def test_pipelined_ingest_matches_the_blocking_one():
+    """wf_hip_push_audio_async (page-locked buffers, copy stream, two slots) feeds the rings exactly as wf_hip_push_audio does"""
+    cfg = wf.Config.defaults(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    streams, ticks, hop = 96, 7, 800
+    audio = [synth.block(SEED, 0, streams, 2, t * hop, hop) for t in range(ticks)]
+    with wf.SpectrumBatch(cfg, streams) as ref:
+        for t in range(ticks):
+            ref.push_audio(audio[t])
+            ref.tick()
+        want_db, want_bars = ref.decibels(), ref.bars()
+    pin = [wf.PinnedBuffer((streams, 2, hop)), wf.PinnedBuffer((streams, 2, hop))]
+    with wf.SpectrumBatch(cfg, streams) as b:
+        for t in range(ticks):
+            slot = t & 1
+            b.ingest_done(slot)
+            pin[slot].array[...] = audio[t]
+            b.push_audio_async(pin[slot], streams, hop, slot)
+            b.tick()
+        got_db, got_bars = b.decibels(), b.bars()
+    for p in pin:
+        p.close()
+    assert np.array_equal(got_db, want_db) and np.array_equal(got_bars, want_bars)

@@ -3,7 +3,8 @@ every step hands one 60 fps hop of host audio per stream through the C ABI (wf_h
 runs the tick and, optionally, reads the bars back.
 usage: python tools/ingest_bench.py [streams] [fft]"""
 import json, sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import waveform_amd as wf
 from tools import synth
@@ -21,6 +22,27 @@ with wf.SpectrumBatch(cfg, streams) as b:
                 b.sync()
                 t0 = time.perf_counter()
             b.push_audio(packet)
+            b.tick()
+            if mode.endswith("read_bars"):
+                b.bars()
+        b.sync()
+        dt = (time.perf_counter() - t0) / steps
+        print(json.dumps(dict(mode=mode, streams=streams, fft=n, ms_per_step=round(dt * 1e3, 3),
+                              Mspectra_s=round(2 * streams / dt / 1e6, 2),
+                              host_GBps=round(packet.nbytes / dt / 1e9, 2))), flush=True)
+
+    # pipelined: page-locked buffers, the copy of packet i+1 under the tick of packet i (wf_hip_push_audio_async)
+    pin = [wf.PinnedBuffer(packet.shape), wf.PinnedBuffer(packet.shape)]
+    for p in pin:
+        p.array[...] = packet
+    for mode in ("push_audio_async + tick", "push_audio_async + tick + read_bars"):
+        for i in range(warm + steps):
+            if i == warm:
+                b.sync()
+                t0 = time.perf_counter()
+            slot = i & 1
+            b.ingest_done(slot)            # the buffer is free again (a real host would refill it here)
+            b.push_audio_async(pin[slot], streams, hop, slot)
             b.tick()
             if mode.endswith("read_bars"):
                 b.bars()

@@ -88,6 +88,11 @@ def lib():
         f.argtypes = [vp]
     L.wf_hip_push_audio.argtypes = [vp, u32, u32, fp, u32]
     L.wf_hip_push_audio_device.argtypes = [vp, u32, u32, vp, u32]
+    L.wf_hip_push_audio_async.argtypes = [vp, u32, u32, vp, u32, u32]
+    L.wf_hip_ingest_done.argtypes = [vp, u32]
+    L.wf_hip_host_alloc.restype = vp
+    L.wf_hip_host_alloc.argtypes = [C.c_size_t]
+    L.wf_hip_host_free.argtypes = [vp]
     L.wf_hip_push_synth.argtypes = [vp, u32, u32, u64, u32, u64, u32]
     L.wf_hip_push_silence.argtypes = [vp, u32, u32, u32]
     L.wf_hip_push_audio_muted.argtypes = [vp, u32, u32, fp, u32]
@@ -209,6 +214,13 @@ class SpectrumBatch:
         out = np.empty(count, np.float32)
         self._ck(self.L.wf_hip_read_input_rms(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def push_audio_async(self, pinned: "PinnedBuffer", count: int, frames: int, slot: int, first: int = 0):
+        """pipelined ingest from page-locked memory (see wf_hip_push_audio_async); does not wait"""
+        self._ck(self.L.wf_hip_push_audio_async(self.h, first, count, C.c_void_p(pinned.ptr), frames, slot))
+
+    def ingest_done(self, slot: int):
+        self._ck(self.L.wf_hip_ingest_done(self.h, slot))
 
     def push_audio_device(self, dev_ptr: int, count: int, frames: int, first: int = 0):
         self._ck(self.L.wf_hip_push_audio_device(self.h, first, count, C.c_void_p(dev_ptr), frames))
@@ -333,3 +345,27 @@ class SpectrumBatch:
 
     def algorithmic_bytes_per_tick(self, flags: int = 0) -> int:
         return int(self.L.wf_hip_algorithmic_bytes_per_tick(self.h, flags))
+
+
+class PinnedBuffer:
+    """page-locked host memory (wf_hip_host_alloc) viewed as a float32 numpy array"""
+
+    def __init__(self, shape):
+        self.L = lib()
+        n = int(np.prod(shape))
+        self.ptr = self.L.wf_hip_host_alloc(n * 4)
+        if not self.ptr:
+            raise MemoryError("wf_hip_host_alloc failed")
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_float)), shape=(n,)).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.L.wf_hip_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -30,6 +30,13 @@ struct wf_hip {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // pipelined ingest (wf_hip_push_audio_async): a copy stream, per-slot staging blocks and events
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};   // the H2D copy of the slot has finished (host buffer free, staging full)
+    hipEvent_t ev_consumed[2] = {nullptr, nullptr}; // the ring append that read the slot's staging block has finished
+    float *d_stage_async[2] = {nullptr, nullptr};
+    size_t stage_async_floats[2] = {0, 0};
+    bool slot_used[2] = {false, false};
     uint32_t n_streams = 0;
     uint32_t ring_cap = 0;
     uint32_t ring_stride = 0;        // floats between consecutive rings: ring_cap + padding (see wf_hip_create)
@@ -794,6 +801,13 @@ void wf_hip_destroy(wf_hip *h)
         (void)hipStreamSynchronize(h->stream);
     for(void *p : h->allocs)
         (void)hipFree(p);
+    if(h->copy_stream)
+        (void)hipStreamSynchronize(h->copy_stream);
+    for(int i = 0; i < 2; ++i) {
+        if(h->ev_copied[i]) (void)hipEventDestroy(h->ev_copied[i]);
+        if(h->ev_consumed[i]) (void)hipEventDestroy(h->ev_consumed[i]);
+    }
+    if(h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if(h->ev0) (void)hipEventDestroy(h->ev0);
     if(h->ev1) (void)hipEventDestroy(h->ev1);
     if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -911,6 +925,74 @@ int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *sa
 int wf_hip_push_audio_muted(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames)
 {
     return push_host(h, first, count, samples, frames, true);
+}
+
+int wf_hip_push_audio_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_samples, uint32_t frames, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(pinned_samples == nullptr || slot > 1)
+        return fail(h, WF_HIP_ERR_INVALID, "samples is NULL or slot is not 0 / 1");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->copy_stream == nullptr) {
+        WF_HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for(int i = 0; i < 2; ++i) {
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_consumed[i], hipEventDisableTiming));
+        }
+    }
+    const size_t n = (size_t)count * h->cap_ch * frames;
+    if(h->stage_async_floats[slot] < n) {
+        if(h->slot_used[slot])
+            WF_HIP_TRY(h, hipEventSynchronize(h->ev_consumed[slot])); // the old block may still feed an append
+        float *p = nullptr;
+        rc = dev_alloc(h, &p, n);
+        if(rc)
+            return rc;
+        h->d_stage_async[slot] = p;
+        h->stage_async_floats[slot] = n;
+    }
+    // copy stream: wait until the previous append from this slot's staging block is done, then copy
+    if(h->slot_used[slot])
+        WF_HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->ev_consumed[slot], 0));
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_stage_async[slot], pinned_samples, n * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_copied[slot], h->copy_stream));
+    // compute stream: the append waits for the copy; whatever is enqueued behind it (the tick) is ordered by the stream
+    WF_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
+    rc = push_common(h, first, count, h->d_stage_async[slot], h->d_stage_async[slot], frames);
+    if(rc)
+        return rc;
+    WF_HIP_TRY(h, hipEventRecord(h->ev_consumed[slot], h->stream));
+    h->slot_used[slot] = true;
+    return WF_HIP_OK;
+}
+
+int wf_hip_ingest_done(wf_hip *h, uint32_t slot)
+{
+    if(h == nullptr || slot > 1)
+        return WF_HIP_ERR_INVALID;
+    if(!h->slot_used[slot])
+        return WF_HIP_OK;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipEventSynchronize(h->ev_copied[slot]));
+    return WF_HIP_OK;
+}
+
+void *wf_hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if(hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void wf_hip_host_free(void *p)
+{
+    if(p)
+        (void)hipHostFree(p);
 }
 
 int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const float *d_samples, uint32_t frames)
