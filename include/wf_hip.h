@@ -190,6 +190,12 @@ int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* bar tops / curve points in pixels (m_interp_bufs after the optional Gaussian filter, the dB->y mapping and the mirror of
  * render_bars, src/source.cpp:1535-1564, or render_curve, :1396-1424): [count][display_channels][num_bars] */
 int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out);
+/* Pipelined readback: the bars of the tick(s) enqueued so far are copied into page-locked memory (wf_hip_host_alloc) on the
+ * handle's readback stream, without waiting; the following ticks run meanwhile.  `slot` (0 or 1) names the copy for
+ * wf_hip_readback_done, which blocks until it has landed.  The device keeps one snapshot per slot, so a later tick does not
+ * disturb a copy in flight. */
+int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
+int wf_hip_readback_done(wf_hip *h, uint32_t slot);
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);

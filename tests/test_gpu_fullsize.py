@@ -153,6 +153,13 @@ def test_pipelined_ingest_matches_the_blocking_one():
             ref.tick()
         want_db, want_bars = ref.decibels(), ref.bars()
     pin = [wf.PinnedBuffer((streams, 2, hop)), wf.PinnedBuffer((streams, 2, hop))]
+    out = [wf.PinnedBuffer((streams, 2, 26)), wf.PinnedBuffer((streams, 2, 26))]
+    per_tick = []
+    with wf.SpectrumBatch(cfg, streams) as ref2:
+        for t in range(ticks):
+            ref2.push_audio(audio[t])
+            ref2.tick()
+            per_tick.append(ref2.bars())
     with wf.SpectrumBatch(cfg, streams) as b:
         for t in range(ticks):
             slot = t & 1
@@ -160,7 +167,11 @@ def test_pipelined_ingest_matches_the_blocking_one():
             pin[slot].array[...] = audio[t]
             b.push_audio_async(pin[slot], streams, hop, slot)
             b.tick()
+            b.readback_done(slot)
+            if t >= 2:  # what the slot received two ticks ago: the bars of tick t - 2
+                assert np.array_equal(out[slot].array, per_tick[t - 2]), f"pipelined readback of tick {t - 2}"
+            b.read_bars_async(out[slot], slot)
         got_db, got_bars = b.decibels(), b.bars()
-    for p in pin:
+    for p in pin + out:
         p.close()
     assert np.array_equal(got_db, want_db) and np.array_equal(got_bars, want_bars)

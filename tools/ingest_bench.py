@@ -35,7 +35,8 @@ with wf.SpectrumBatch(cfg, streams) as b:
     pin = [wf.PinnedBuffer(packet.shape), wf.PinnedBuffer(packet.shape)]
     for p in pin:
         p.array[...] = packet
-    for mode in ("push_audio_async + tick", "push_audio_async + tick + read_bars"):
+    out = [wf.PinnedBuffer((streams, b.display_channels, b.num_bars)), wf.PinnedBuffer((streams, b.display_channels, b.num_bars))]
+    for mode in ("push_audio_async + tick", "push_audio_async + tick + read_bars", "push_audio_async + tick + read_bars_async"):
         for i in range(warm + steps):
             if i == warm:
                 b.sync()
@@ -46,6 +47,9 @@ with wf.SpectrumBatch(cfg, streams) as b:
             b.tick()
             if mode.endswith("read_bars"):
                 b.bars()
+            elif mode.endswith("read_bars_async"):
+                b.readback_done(slot)      # the bars of two ticks ago have landed (a renderer would draw them now)
+                b.read_bars_async(out[slot], slot)
         b.sync()
         dt = (time.perf_counter() - t0) / steps
         print(json.dumps(dict(mode=mode, streams=streams, fft=n, ms_per_step=round(dt * 1e3, 3),

@@ -90,6 +90,8 @@ def lib():
     L.wf_hip_push_audio_device.argtypes = [vp, u32, u32, vp, u32]
     L.wf_hip_push_audio_async.argtypes = [vp, u32, u32, vp, u32, u32]
     L.wf_hip_ingest_done.argtypes = [vp, u32]
+    L.wf_hip_read_bars_async.argtypes = [vp, u32, u32, vp, u32]
+    L.wf_hip_readback_done.argtypes = [vp, u32]
     L.wf_hip_host_alloc.restype = vp
     L.wf_hip_host_alloc.argtypes = [C.c_size_t]
     L.wf_hip_host_free.argtypes = [vp]
@@ -218,6 +220,14 @@ class SpectrumBatch:
     def push_audio_async(self, pinned: "PinnedBuffer", count: int, frames: int, slot: int, first: int = 0):
         """pipelined ingest from page-locked memory (see wf_hip_push_audio_async); does not wait"""
         self._ck(self.L.wf_hip_push_audio_async(self.h, first, count, C.c_void_p(pinned.ptr), frames, slot))
+
+    def read_bars_async(self, pinned: "PinnedBuffer", slot: int, first: int = 0, count: int | None = None):
+        """bars of the ticks enqueued so far -> page-locked memory, without waiting (wf_hip_read_bars_async)"""
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_read_bars_async(self.h, first, count, C.c_void_p(pinned.ptr), slot))
+
+    def readback_done(self, slot: int):
+        self._ck(self.L.wf_hip_readback_done(self.h, slot))
 
     def ingest_done(self, slot: int):
         self._ck(self.L.wf_hip_ingest_done(self.h, slot))

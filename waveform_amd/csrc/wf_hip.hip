@@ -37,6 +37,12 @@ struct wf_hip {
     float *d_stage_async[2] = {nullptr, nullptr};
     size_t stage_async_floats[2] = {0, 0};
     bool slot_used[2] = {false, false};
+    // pipelined readback (wf_hip_read_bars_async): a stream for the D2H copies, a device snapshot and two events per slot
+    hipStream_t read_stream = nullptr;
+    hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr};
+    float *d_snap[2] = {nullptr, nullptr};
+    size_t snap_floats[2] = {0, 0};
+    bool read_used[2] = {false, false};
     uint32_t n_streams = 0;
     uint32_t ring_cap = 0;
     uint32_t ring_stride = 0;        // floats between consecutive rings: ring_cap + padding (see wf_hip_create)
@@ -808,6 +814,13 @@ void wf_hip_destroy(wf_hip *h)
         if(h->ev_consumed[i]) (void)hipEventDestroy(h->ev_consumed[i]);
     }
     if(h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if(h->read_stream)
+        (void)hipStreamSynchronize(h->read_stream);
+    for(int i = 0; i < 2; ++i) {
+        if(h->ev_snap[i]) (void)hipEventDestroy(h->ev_snap[i]);
+        if(h->ev_read[i]) (void)hipEventDestroy(h->ev_read[i]);
+    }
+    if(h->read_stream) (void)hipStreamDestroy(h->read_stream);
     if(h->ev0) (void)hipEventDestroy(h->ev0);
     if(h->ev1) (void)hipEventDestroy(h->ev1);
     if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -1272,6 +1285,56 @@ int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out)
         return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
     const size_t per = (size_t)h->disp_ch * h->num_bars;
     return read_back(h, h->d_bars + first * per, out, count * per * sizeof(float));
+}
+
+int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_bars == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
+    if(pinned_out == nullptr || slot > 1)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL or slot is not 0 / 1");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->read_stream == nullptr) {
+        WF_HIP_TRY(h, hipStreamCreateWithFlags(&h->read_stream, hipStreamNonBlocking));
+        for(int i = 0; i < 2; ++i) {
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_snap[i], hipEventDisableTiming));
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_read[i], hipEventDisableTiming));
+        }
+    }
+    const size_t per = (size_t)h->disp_ch * h->num_bars, n = count * per;
+    if(h->read_used[slot])
+        WF_HIP_TRY(h, hipEventSynchronize(h->ev_read[slot])); // the slot's previous copy must have left its snapshot
+    if(h->snap_floats[slot] < n) {
+        float *p = nullptr;
+        rc = dev_alloc(h, &p, n);
+        if(rc)
+            return rc;
+        h->d_snap[slot] = p;
+        h->snap_floats[slot] = n;
+    }
+    // compute stream: snapshot behind the ticks enqueued so far (device to device, a few MB at most)
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_snap[slot], h->d_bars + first * per, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_snap[slot], h->stream));
+    // readback stream: the D2H copy of the snapshot; later ticks do not wait for it
+    WF_HIP_TRY(h, hipStreamWaitEvent(h->read_stream, h->ev_snap[slot], 0));
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_out, h->d_snap[slot], n * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
+    h->read_used[slot] = true;
+    return WF_HIP_OK;
+}
+
+int wf_hip_readback_done(wf_hip *h, uint32_t slot)
+{
+    if(h == nullptr || slot > 1)
+        return WF_HIP_ERR_INVALID;
+    if(!h->read_used[slot])
+        return WF_HIP_OK;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipEventSynchronize(h->ev_read[slot]));
+    return WF_HIP_OK;
 }
 
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out)
