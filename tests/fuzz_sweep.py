@@ -1,6 +1,6 @@
-"""one-off extended fuzz sweep (development aid): python tools/fuzz_sweep.py LO HI [spec,meter,wave]"""
+"""one-off extended fuzz sweep (development aid): python tests/fuzz_sweep.py LO HI [spec,meter,wave]"""
 import sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, traceback
 import scenarios, test_gpu_fuzz as f
 import waveform_amd as wf
