@@ -149,7 +149,11 @@ typedef struct wf_hip_tick_params {
     uint64_t audio_ts_ns;   /* m_audio_ts: end-of-audio timestamp of the newest pushed sample (src/source.cpp:1829-1832), in ns;
                                only waveform batches read it (tick_waveform places its points in time with it) */
 } wf_hip_tick_params;
-#define WF_HIP_TICK_NO_DECIBELS 1u /* bars/curve-only batch mode: skip the m_decibels store (cfg.bars or cfg.curve must be set) */
+/* bars/curve-only batch mode: skip the m_decibels store (cfg.bars or cfg.curve must be set).  The silence state machine
+ * (src/source_generic.cpp:74-95) keeps working: the kernel leaves a one-word verdict per row ("a value > floor - 10") for the
+ * next tick's test instead.  After the first such tick, wf_hip_read_decibels returns rows only as fresh as the last tick
+ * without the flag that rewrote them.  Mono mixdown of two captured channels stores its (single) row regardless. */
+#define WF_HIP_TICK_NO_DECIBELS 1u
 
 /* Asynchronous: enqueues the fused kernel for all streams on the handle's stream. */
 int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);

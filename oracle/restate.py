@@ -90,6 +90,7 @@ def lib():
     L.wfo_meter_push_audio.argtypes = [vp, fp, fp, C.c_uint32, C.c_int]
     L.wfo_meter_set_sync_delay.argtypes = [vp, C.c_uint32]
     L.wfo_meter_set_state.argtypes = [vp, C.c_int]
+    L.wfo_meter_set_exact.argtypes = [vp, C.c_int]
     L.wfo_meter_tick.argtypes = [vp, C.c_float]
     L.wfo_meter_render.argtypes = [vp]
     L.wfo_meter_size.restype = C.c_uint32
@@ -268,6 +269,10 @@ class OracleMeter:
     def set_state(self, state):
         """0 shown, 1 hidden (!m_show), 2 capture timed out"""
         self.L.wfo_meter_set_state(self.h, state)
+
+    def set_exact(self, exact=True):
+        """RMS sums accumulated in double: the value the reference's sequential float sum approximates"""
+        self.L.wfo_meter_set_exact(self.h, 1 if exact else 0)
 
     def tick(self, seconds=1.0 / 60.0):
         self.L.wfo_meter_tick(self.h, seconds)

@@ -96,9 +96,10 @@ static void fft_prepare(wfo_source *s)
     const uint32_t n = s->n;
     s->wr = (double *)malloc(sizeof(double) * n);
     s->wi = (double *)malloc(sizeof(double) * n);
-    s->twr = (double *)malloc(sizeof(double) * (n / 2));
-    s->twi = (double *)malloc(sizeof(double) * (n / 2));
-    for(uint32_t k = 0; k < n / 2; ++k) {
+    /* the full circle exp(-2 pi i k / n); the power-of-two path uses its first half */
+    s->twr = (double *)malloc(sizeof(double) * n);
+    s->twi = (double *)malloc(sizeof(double) * n);
+    for(uint32_t k = 0; k < n; ++k) {
         const double a = -2.0 * 3.14159265358979323846264338327950288 * (double)k / (double)n;
         s->twr[k] = cos(a);
         s->twi[k] = sin(a);
@@ -133,28 +134,84 @@ static void fft_double(double *re, double *im, const double *twr, const double *
     }
 }
 
-static void r2c(wfo_source *s)
+/* Any other length (the reference takes every multiple of 16 in [128, 65536]): the same DFT sum, evaluated in double by
+ * recursive decimation in time over the prime factors of n (smallest first); a prime length is the plain sum.  tw holds
+ * the full circle exp(-2 pi i j / root), the sub-transform of length n uses every (root / n)-th entry.  In place on
+ * (re, im)[0 .. n) read with `stride`; the result is contiguous in (yr, yi). */
+static void dft_any(const double *xr, const double *xi, size_t stride, uint32_t n, double *yr, double *yi, const double *twr,
+                    const double *twi, uint32_t root)
 {
-    const uint32_t n = s->n;
-    if(n & (n - 1)) {
-        /* any other length (the reference takes every multiple of 16 >= 128): the DFT sum itself, in double; the table
-         * holds exp(-2 pi i k / n) for k < n / 2 and the second half of the circle is its negation */
-        const uint32_t h = n / 2;
-        for(uint32_t k = 0; k < s->m; ++k) {
-            double re = 0.0, im = 0.0;
+    uint32_t p = n;
+    for(uint32_t f = 2; (uint64_t)f * f <= n; ++f)
+        if(n % f == 0) {
+            p = f;
+            break;
+        }
+    const uint32_t m = n / p, step = root / n;
+    if(m == 1) { /* prime (or 1): X[k] = sum_j x[j] W_n^(jk) */
+        for(uint32_t k = 0; k < n; ++k) {
+            double ar = 0.0, ai = 0.0;
             uint32_t idx = 0; /* (j * k) mod n */
             for(uint32_t j = 0; j < n; ++j) {
-                const double x = (double)s->fft_in[j];
-                const double cr = idx < h ? s->twr[idx] : -s->twr[idx - h], ci = idx < h ? s->twi[idx] : -s->twi[idx - h];
-                re += x * cr;
-                im += x * ci;
+                const double cr = twr[(size_t)idx * step], ci = twi[(size_t)idx * step];
+                const double vr = xr[j * stride], vi = xi[j * stride];
+                ar += vr * cr - vi * ci;
+                ai += vr * ci + vi * cr;
                 idx += k;
                 if(idx >= n)
                     idx -= n;
             }
-            s->fft_out[2 * k] = (float)re;
-            s->fft_out[2 * k + 1] = (float)im;
+            yr[k] = ar;
+            yi[k] = ai;
         }
+        return;
+    }
+    /* Y_r = DFT_m(x[r], x[r + p], ...) into block r; then X[k + m q] = sum_r (W_n^(r k) Y_r[k]) W_p^(r q) */
+    for(uint32_t r = 0; r < p; ++r)
+        dft_any(xr + r * stride, xi + r * stride, stride * p, m, yr + (size_t)r * m, yi + (size_t)r * m, twr, twi, root);
+    double tr[64], ti[64], *hr = tr, *hi = ti;
+    if(p > 64) {
+        hr = (double *)malloc(sizeof(double) * 2 * p);
+        hi = hr + p;
+    }
+    for(uint32_t k = 0; k < m; ++k) {
+        for(uint32_t r = 0; r < p; ++r) {
+            const size_t w = (size_t)(((uint64_t)r * k) % n) * step;
+            const double vr = yr[(size_t)r * m + k], vi = yi[(size_t)r * m + k];
+            hr[r] = vr * twr[w] - vi * twi[w];
+            hi[r] = vr * twi[w] + vi * twr[w];
+        }
+        for(uint32_t q = 0; q < p; ++q) {
+            double ar = 0.0, ai = 0.0;
+            for(uint32_t r = 0; r < p; ++r) {
+                const size_t w = (size_t)(((uint64_t)r * q) % p) * m * step; /* W_p^(r q) = W_n^(m r q) */
+                ar += hr[r] * twr[w] - hi[r] * twi[w];
+                ai += hr[r] * twi[w] + hi[r] * twr[w];
+            }
+            yr[(size_t)q * m + k] = ar;
+            yi[(size_t)q * m + k] = ai;
+        }
+    }
+    if(p > 64)
+        free(hr);
+}
+
+static void r2c(wfo_source *s)
+{
+    const uint32_t n = s->n;
+    if(n & (n - 1)) {
+        double *xr = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+        double *xi = xr + n, *yr = xi + n, *yi = yr + n;
+        for(uint32_t i = 0; i < n; ++i) {
+            xr[i] = (double)s->fft_in[i];
+            xi[i] = 0.0;
+        }
+        dft_any(xr, xi, 1, n, yr, yi, s->twr, s->twi, n);
+        for(uint32_t k = 0; k < s->m; ++k) {
+            s->fft_out[2 * k] = (float)yr[k];
+            s->fft_out[2 * k + 1] = (float)yi[k];
+        }
+        free(xr);
         return;
     }
     for(uint32_t i = 0; i < n; ++i) {
@@ -419,6 +476,17 @@ wfo_source *wfo_create(const wf_config *cfg)
         return NULL; /* src/source.cpp:562-565: at least 128, a multiple of 16 */
     wfo_source *s = (wfo_source *)calloc(1, sizeof(*s));
     s->cfg = *cfg;
+    /* get_settings()' repairs, src/source.cpp:567-579 */
+    if((s->cfg.cutoff_high - s->cfg.cutoff_low) < 0) {
+        s->cfg.cutoff_high = 17500;
+        s->cfg.cutoff_low = 120;
+    }
+    if((s->cfg.ceiling_db - s->cfg.floor_db) < 1) {
+        s->cfg.ceiling_db = 0;
+        s->cfg.floor_db = -120;
+    }
+    if(!s->cfg.stereo || (((int)s->cfg.height - s->cfg.channel_spacing) < 1))
+        s->cfg.channel_spacing = 0;
     s->n = cfg->fft_size;
     s->m = cfg->fft_size / 2;
     s->cap_ch = cfg->capture_channels;

@@ -79,6 +79,9 @@ void wfo_meter_destroy(wfo_meter *m);
 void wfo_meter_push_audio(wfo_meter *m, const float *ch0, const float *ch1, uint32_t frames, int muted);
 void wfo_meter_set_sync_delay(wfo_meter *m, uint32_t frames);
 void wfo_meter_set_state(wfo_meter *m, int state); /* 0 shown, 1 !m_show, 2 capture timed out */
+/* exact != 0: the RMS sum of squares is accumulated in double instead of the reference's sequential float sum (:236-241) --
+ * the value that sum approximates; used by the tests to tell "differs from the reference" from "is less accurate than it" */
+void wfo_meter_set_exact(wfo_meter *m, int exact);
 void wfo_meter_tick(wfo_meter *m, float seconds);
 void wfo_meter_render(wfo_meter *m);                /* render_bars' mapping of the levels */
 uint32_t wfo_meter_size(const wfo_meter *m);        /* m_fft_size (meter buffer length) */

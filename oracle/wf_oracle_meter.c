@@ -36,6 +36,7 @@ struct wfo_meter {
     float ema[2];               /* m_meter_buf */
     float bars[2];              /* m_interp_bufs[0] after render_bars */
     float border_top, border_bottom;
+    int exact;                  /* wfo_meter_set_exact: the RMS sum in double (what the float sum approximates) */
 };
 
 static float db_min_f(void) { return 20.0f * log10f(FLT_MIN); }
@@ -94,6 +95,17 @@ wfo_meter *wfo_meter_create(const wf_config *cfg)
         return NULL;
     wfo_meter *m = (wfo_meter *)calloc(1, sizeof(*m));
     m->cfg = *cfg;
+    /* get_settings()' repairs, src/source.cpp:567-579 */
+    if((m->cfg.cutoff_high - m->cfg.cutoff_low) < 0) {
+        m->cfg.cutoff_high = 17500;
+        m->cfg.cutoff_low = 120;
+    }
+    if((m->cfg.ceiling_db - m->cfg.floor_db) < 1) {
+        m->cfg.ceiling_db = 0;
+        m->cfg.floor_db = -120;
+    }
+    if(!m->cfg.stereo || (((int)m->cfg.height - m->cfg.channel_spacing) < 1))
+        m->cfg.channel_spacing = 0;
     /* src/source.cpp:1108-1121 */
     m->cfg.stereo = 0;
     m->cfg.slope = 0.0f;
@@ -107,16 +119,16 @@ wfo_meter *wfo_meter_create(const wf_config *cfg)
         m->val[c] = db_min_f();
     }
     /* render_bars geometry, src/source.cpp:1476-1494 (m_stereo is false in meter mode) */
-    const float bottom = (float)cfg->height;
+    const float bottom = (float)m->cfg.height;
     const float cpos = bottom;
-    const float cap_radius = (float)cfg->bar_width / 2.0f;
-    const float channel_offset = cfg->channel_spacing * 0.5f;
-    float border_top = cfg->rounded_caps ? cap_radius : 0.0f;
-    float border_bottom = cfg->rounded_caps ? cpos - cap_radius : cpos;
-    if(cfg->channel_spacing > 0)
+    const float cap_radius = (float)m->cfg.bar_width / 2.0f;
+    const float channel_offset = m->cfg.channel_spacing * 0.5f;
+    float border_top = m->cfg.rounded_caps ? cap_radius : 0.0f;
+    float border_bottom = m->cfg.rounded_caps ? cpos - cap_radius : cpos;
+    if(m->cfg.channel_spacing > 0)
         border_bottom -= channel_offset;
-    if(cfg->min_bar_height > 0)
-        border_bottom -= cfg->min_bar_height;
+    if(m->cfg.min_bar_height > 0)
+        border_bottom -= m->cfg.min_bar_height;
     m->border_top = border_top;
     m->border_bottom = clampf(border_bottom, border_top, cpos);
     m->bars[0] = m->bars[1] = m->border_bottom;
@@ -136,6 +148,7 @@ void wfo_meter_destroy(wfo_meter *m)
 
 void wfo_meter_set_sync_delay(wfo_meter *m, uint32_t frames) { m->sync_delay = frames; }
 void wfo_meter_set_state(wfo_meter *m, int state) { m->state = state; }
+void wfo_meter_set_exact(wfo_meter *m, int exact) { m->exact = exact; }
 
 /* capture_audio, src/source.cpp:1873-1886 */
 void wfo_meter_push_audio(wfo_meter *m, const float *ch0, const float *ch1, uint32_t frames, int muted)
@@ -191,7 +204,13 @@ void wfo_meter_tick(wfo_meter *m, float seconds)
     }
     for(uint32_t ch = 0; ch < m->cap_ch; ++ch) { /* :232-260 */
         float out = 0.0f;
-        if(m->cfg.meter_rms) {
+        if(m->cfg.meter_rms && m->exact) {
+            /* the value the reference's sequential float sum approximates: every term and the sum in double, rounded once */
+            double acc = 0.0;
+            for(size_t i = 0; i < outsz; ++i)
+                acc += (double)m->buffer[ch][i] * (double)m->buffer[ch][i];
+            out = (float)sqrt(acc / (double)m->n);
+        } else if(m->cfg.meter_rms) {
             for(size_t i = 0; i < outsz; ++i) {
                 const float v = m->buffer[ch][i];
                 out += v * v;

@@ -82,6 +82,17 @@ wfo_wave *wfo_wave_create(const wf_config *cfg)
         return NULL;
     wfo_wave *w = (wfo_wave *)calloc(1, sizeof(*w));
     w->cfg = *cfg;
+    /* get_settings()' repairs, src/source.cpp:567-579 */
+    if((w->cfg.cutoff_high - w->cfg.cutoff_low) < 0) {
+        w->cfg.cutoff_high = 17500;
+        w->cfg.cutoff_low = 120;
+    }
+    if((w->cfg.ceiling_db - w->cfg.floor_db) < 1) {
+        w->cfg.ceiling_db = 0;
+        w->cfg.floor_db = -120;
+    }
+    if(!w->cfg.stereo || (((int)w->cfg.height - w->cfg.channel_spacing) < 1))
+        w->cfg.channel_spacing = 0;
     w->n = cfg->width;                                                            /* :1140 */
     w->waveform_samples = (size_t)((double)cfg->sample_rate * ((double)cfg->meter_ms / 1000.0)); /* :1141 */
     w->cap_ch = cfg->capture_channels;

@@ -225,6 +225,15 @@ class _Feeder:
         return a[: self.channels]
 
 
+def sync_reserve_frames(audio_ts_ns: int, sync_ns: int, tick_ts_ns: int, sample_rate: int = 48000) -> int:
+    """What a host hands over as the A/V-sync delay of a tick or packet: get_audio_sync(ts) = m_audio_ts + m_ts_offset - ts
+    (src/source.hpp:279-285) in frames, ns_to_audio_frames' integer arithmetic; 0 when the audio is not ahead of the video."""
+    if audio_ts_ns == 0:
+        return 0  # no packet yet (get_audio_sync: m_audio_ts == 0 -> 0)
+    dt = audio_ts_ns + sync_ns - tick_ts_ns
+    return (dt * sample_rate) // 1_000_000_000 if dt > 0 else 0
+
+
 def play(backend, scenario: dict):
     """returns list of per-tick records: dict(db=..., bars=... | None, silent=bool)"""
     feeder = _Feeder(backend.capture_channels)
@@ -266,6 +275,9 @@ class RefBackend:
         from helpers import ref_settings
         from oracle import wfref
         self.cfg = cfg
+        # update() stamps m_capture_ts with the clock (src/source.cpp:1242): the source is created "now", so that a tick
+        # before the first packet is not a capture timeout of the harness's making
+        wfref.lib().wfref_set_clock_ns(1_000_000_000)
         self.src = wfref.RefSource(ref_settings(cfg), isa=isa, channels=int(cfg.capture_channels))
         assert self.src.capture_channels == cfg.capture_channels
         self.capture_channels = int(cfg.capture_channels)
@@ -274,6 +286,13 @@ class RefBackend:
         assert self.src.meter_mode == bool(cfg.meter)
 
     def push(self, audio, muted):
+        # OBS delivers packets of at most AUDIO_OUTPUT_FRAMES (1024) frames; capture_audio's RMS loop re-reads the start of a
+        # longer packet for its second chunk (src/source.cpp:1848-1861 never advances `data`), which no OBS packet can
+        # trigger -- a longer script packet reaches the reference as OBS would have cut it
+        if audio.shape[1] > 1024:
+            for i in range(0, audio.shape[1], 1024):
+                self.push(audio[:, i:i + 1024], muted)
+            return
         import ctypes as C
         n = audio.shape[1]
         self.now += n * 1_000_000_000 // 48000 + 1
@@ -321,15 +340,18 @@ class OracleBackend:
     """input_rms=None: m_input_rms comes from the restated producer (update_input_rms before every tick, as
     WAVSource::tick does); a number: the host's value, fixed"""
 
-    def __init__(self, cfg, input_rms=None):
+    def __init__(self, cfg, input_rms=None, exact=False):
         from oracle import restate
         self.cfg = cfg
         self.hidden = False
         self.auto_rms = bool(cfg.normalize_volume) and input_rms is None
         self.now = 1_000_000_000  # the same clock model as RefBackend: packets end "now", ticks happen "now"
-        self.reserve = 0
+        self.sync_ns = 0
+        self.audio_ts = 0
         if cfg.meter:
             self.src = restate.OracleMeter(cfg)
+            if exact:  # level meter only: sums of squares in double (tests/helpers.py::assert_levels_close)
+                self.src.set_exact(True)
         elif cfg.waveform:
             self.src = restate.OracleWave(cfg)
             self.src.set_input_rms(input_rms or 0.0)
@@ -339,11 +361,15 @@ class OracleBackend:
         self.capture_channels = self.src.capture_channels
 
     def set_sync_ms(self, ms):
-        self.reserve = ms * 48
+        self.sync_ns = ms * 1_000_000
+
+    def _sync(self):
+        """the A/V-sync reserve as of `now`, handed to the restatement the way a host computes it"""
+        reserve = sync_reserve_frames(self.audio_ts, self.sync_ns, self.now)
         if self.cfg.waveform:
-            self.src.set_time(0, self.reserve)  # m_audio_ts stays 0 until the first packet
+            self.src.set_time(self.audio_ts, reserve)
         else:
-            self.src.set_sync_delay(self.reserve)
+            self.src.set_sync_delay(reserve)
 
     def _state(self, timed_out=False):
         # the restatement takes the tick's gate as given: 0 shown, 1 !m_show, 2 capture timed out
@@ -355,11 +381,12 @@ class OracleBackend:
     def push(self, audio, muted):
         self._state()  # a packet ends a capture timeout
         self.now += audio.shape[1] * 1_000_000_000 // 48000 + 1
-        if self.cfg.waveform:
-            self.src.set_time(self.now, self.reserve)  # m_audio_ts = end of this packet
+        self.audio_ts = self.now  # m_audio_ts = end of this packet
+        self._sync()
         self.src.push_audio(audio, muted=muted)
 
     def tick(self, seconds):
+        self._sync()
         if self.cfg.waveform:
             if self.auto_rms:
                 self.rms = self.src.update_input_rms()
@@ -415,10 +442,10 @@ class HipBackend:
         self.hidden = False
         self.now = 1_000_000_000  # the same clock model as RefBackend: packets end "now", ticks happen "now"
         self.audio_ts = 0         # m_audio_ts: 0 until the first packet (release_audio_capture, src/source.cpp:747)
-        self.reserve = 0
+        self.sync_ns = 0
 
     def set_sync_ms(self, ms):
-        self.reserve = ms * 48
+        self.sync_ns = ms * 1_000_000
 
     def _state(self, timed_out=False):
         self.batch.set_hidden(np.full(self.streams, 2 if timed_out else (1 if self.hidden else 0), np.uint8))
@@ -442,7 +469,8 @@ class HipBackend:
             self.batch.push_audio(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
 
     def tick(self, seconds):
-        self.batch.tick(seconds=seconds, input_rms=self.input_rms, delay_frames=self.reserve, audio_ts_ns=self.audio_ts)
+        reserve = sync_reserve_frames(self.audio_ts, self.sync_ns, self.now)  # what WAVSourceHIP derives from get_audio_sync
+        self.batch.tick(seconds=seconds, input_rms=self.input_rms, delay_frames=reserve, audio_ts_ns=self.audio_ts)
 
     def set_hidden(self, hidden):
         self.hidden = hidden

@@ -254,7 +254,7 @@ def test_fft_sizes_accepted_and_rejected():
 def test_meter_and_waveform_configurations():
     assert _create_code(meter=1) == -3
     assert _create_code(meter=1, meter_ms=0) == -1
-    assert _create_code(meter=1, ceiling_db=-70) == -1       # ceiling <= floor: the bar mapping would divide by zero
+    assert _create_code(meter=1, ceiling_db=-70) == -3       # ceiling <= floor is repaired as get_settings does (src/source.cpp:572-576): 0 / -120
     assert _create_code(meter=1, fft_size=12345) == -3       # fft_size is ignored in meter mode (it becomes the buffer length)
     assert _create_code(waveform=1) == -3
     assert _create_code(waveform=1, width=0) == -1

@@ -110,6 +110,50 @@ def test_bars_only_mode_matches_full_mode():
     assert np.all(res[1][1] == np.float32(wf.db_min()))
 
 
+@pytest.mark.parametrize("layout", [
+    dict(fft_size=1024, stereo=1), dict(fft_size=4096, stereo=1), dict(fft_size=2048, stereo=1, capture_channels=1),
+    dict(fft_size=4096, stereo=0, capture_channels=1), dict(fft_size=2048, stereo=0), dict(fft_size=512, stereo=1),
+    dict(fft_size=8192, stereo=1), dict(fft_size=800, stereo=1), dict(fft_size=8192, stereo=0, capture_channels=1)])
+def test_bars_only_mode_keeps_the_silence_state_machine(layout):
+    """WF_HIP_TICK_NO_DECIBELS through noise -> digital silence (the display decays below floor - 10, m_last_silent latches,
+    reference src/source_generic.cpp:74-95) -> one live channel (the skipped one is re-dBFS'ed) -> hide/show -> noise:
+    bars and m_last_silent of a bars-only batch equal the full mode's on every tick, on the geometries that keep a stereo
+    pair in one workgroup, on the split ones, zero-padded, Bluestein and mono mixdown (which stores its row regardless)."""
+    cfg = wf.Config.defaults(slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"], gravity=0.2, **layout)
+    n, streams, hop = cfg.fft_size, 5, 800
+    cc = int(cfg.capture_channels)
+    script = [("noise", hop)] * 3 + [("silence", n + 400)] + [("silence", hop)] * 14 + [("ch0", n + 400)] + [("ch0", hop)] * 3 \
+        + [("noise", hop)] * 2 + [("hide", hop)] * 2 + [("show", hop)] + [("silence", n + 400)] + [("silence", hop)] * 14 + [("noise", hop)] * 2
+    res = []
+    for flags in (0, 1):
+        out = []
+        pos = 0
+        with wf.SpectrumBatch(cfg, streams) as b:
+            for op, frames in script:
+                a = synth.block(SEED, 0, streams, cc, pos, frames)
+                pos += frames
+                if op == "silence":
+                    a[:] = 0.0
+                elif op == "ch0" and cc > 1:
+                    a[:, 1] = 0.0
+                if op == "hide":
+                    b.set_hidden(np.ones(streams, np.uint8))
+                elif op == "show":
+                    b.set_hidden(np.zeros(streams, np.uint8))
+                # stream 3 stays live throughout: a batch with streams in different states
+                a[3] = synth.block(SEED, 7, 1, cc, pos, frames)[0]
+                b.push_audio(a)
+                b.tick(flags=flags)
+                out.append((b.bars(), b.last_silent()))
+        res.append(out)
+    went_silent = False
+    for t, ((b0, s0), (b1, s1)) in enumerate(zip(*res)):
+        assert np.array_equal(s0, s1), f"tick {t} ({script[t][0]}): m_last_silent {s0} vs bars-only {s1}"
+        assert np.array_equal(b0, b1), f"tick {t} ({script[t][0]}): bars differ in bars-only mode"
+        went_silent = went_silent or bool(s0[0])
+    assert went_silent, "the script must drive stream 0 into m_last_silent"
+
+
 def test_delay_frames_is_the_av_sync_window():
     """tick(delay_frames=d) analyses the window that ends d frames before the newest sample (reference :50-59)"""
     cfg = wf.Config.defaults(fft_size=2048, stereo=1, tsmoothing=wf.TSMOOTH["none"])

@@ -13,18 +13,28 @@ import numpy as np
 import pytest
 
 import scenarios
-from helpers import assert_db_close
+from helpers import assert_db_close, assert_levels_close
 
-CASES = list(range(40)) + [527] + list(range(2000, 2016))  # 527: mono mixdown + Gaussian filter on a one-wavefront geometry (LDS staging race, fixed)
+# Consecutive seeds, nothing picked: every family runs range(N) of its own draw function.
+SPEC_SEEDS = range(600)    # power-of-two FFT sizes 128 .. MAX_POW2
+BLU_SEEDS = range(500)     # every other multiple of 16 (Bluestein)
+REF_EVERY = 8              # every 8th spectrum / Bluestein seed is also played against libwfref.so (the reference, float FFTW)
+MAX_POW2 = 32768
+MAX_ANY = 10912
 
 
-def draw(seed: int):
-    r = np.random.default_rng(1000 + seed)
-    n = int(r.choice([1024, 2048, 4096, 8192, 16384], p=[0.3, 0.25, 0.25, 0.1, 0.1]))
-    if 28 <= seed < 1000:  # cases added with the zero-padded small sizes: the earlier draws stay what they were
-        n = int(r.choice([128, 256, 512]))
-    if 2000 <= seed < 3000:  # FFT sizes that are not powers of two (Bluestein path)
-        n = int(r.choice([144, 800, 1008, 1536, 2640, 4160, 5456, 6000]))
+def draw(seed: int, family: str = "pow2"):
+    r = np.random.default_rng((1000 if family == "pow2" else 77000) + seed)
+    if family == "pow2":
+        sizes = [128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
+        p = np.array([0.07, 0.07, 0.08, 0.2, 0.17, 0.17, 0.09, 0.07, 0.04, 0.04])
+        keep = [i for i, v in enumerate(sizes) if v <= MAX_POW2]
+        n = int(r.choice([sizes[i] for i in keep], p=p[keep] / p[keep].sum()))
+    else:  # any multiple of 16 in [128, MAX_ANY] that is not a power of two; small sizes as likely as large ones
+        hi = float(r.choice([1024, 4096, MAX_ANY]))
+        n = 16 * int(r.integers(8, int(hi) // 16 + 1))
+        if n & (n - 1) == 0:
+            n += 16
     layout = int(r.integers(0, 4))  # 0 mono capture, 1 mono mixdown of 2, 2 stereo, 3 one captured channel shown twice
     cfg = dict(fft_size=n,
                capture_channels=1 if layout in (0, 3) else 2,
@@ -37,7 +47,7 @@ def draw(seed: int):
     if r.random() < 0.35:
         cfg.update(rolloff_q=float(np.float32(r.uniform(0.5, 3.0))), rolloff_rate=float(np.float32(r.uniform(3.0, 24.0))))
     if r.random() < 0.3:
-        cfg.update(normalize_volume=1, volume_target=float(np.float32(r.uniform(-20.0, -3.0))), max_gain=float(np.float32(r.uniform(6.0, 30.0))))
+        cfg.update(normalize_volume=1, volume_target=float(r.integers(-20, -2)), max_gain=float(r.integers(6, 31)))  # integer sliders in the reference
     display = int(r.integers(0, 3))  # 0 spectrum only, 1 bars, 2 curve
     if display:
         cfg.update(interp_mode=int(r.integers(0, 3)), log_scale=int(r.integers(0, 2)), mirror_freq_axis=int(r.random() < 0.3),
@@ -61,22 +71,53 @@ def draw(seed: int):
         steps += [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",), ("noise", 800), ("tick",), ("noise", 800), ("tick",)]
     elif kind == 3:
         steps += [("mute", 800), ("tick",), ("noise", 800), ("tick",), ("mute", n), ("tick",)]
-    return cfg, steps
+    # a quarter of the cases run with an audio sync offset: a constant A/V-sync reserve of sync_ms * 48 frames behind the
+    # window (dtaudio > 0, src/source_generic.cpp:50-59; sync_rms_buffer holds the RMS values back as well)
+    sync_ms = int(r.choice([0, 0, 0, 5, 20]))
+    return cfg, steps, sync_ms
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", CASES)
-def test_hip_matches_oracle_on_random_case(seed):
-    cfg_dict, steps = draw(seed)
-    cfg = scenarios.make_config(cfg_dict)
-    sc = dict(cfg=cfg_dict, steps=steps, record="all")
+def _undo_db(cfg):
+    """per-bin dB offsets applied after the FFT (the roll-off table), added back before the linear-domain comparison"""
+    if not (cfg.rolloff_q > 0 and cfg.rolloff_rate > 0):
+        return None
+    from oracle import restate
+    o = restate.OracleSource(cfg)
+    try:
+        ro = o.rolloff()
+    finally:
+        o.close()
+    if ro is None:
+        return None
+    ro = ro.astype(np.float64)
+    ro[0] = 0.0  # the roll-off loop starts at bin 1 (src/source_generic.cpp:173)
+    return ro
+
+
+def _compare(got, want, undo, what):
+    assert len(got) == len(want)
+    for t, (g, w) in enumerate(zip(got, want)):
+        assert g["silent"] == w["silent"], f"{what} tick {t}: m_last_silent {g['silent']} != {w['silent']}"
+        assert_db_close(g["db"], w["db"], f"{what} tick {t} decibels", undo_db=undo)
+        if w["bars"] is not None:
+            err = np.abs(g["bars"].astype(np.float64) - w["bars"])
+            assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"{what} tick {t} bars/curve: max err {err.max():.3e} px"
+        if "rms" in w:
+            assert abs(float(g["rms"]) - float(w["rms"])) <= 1e-5 * abs(float(w["rms"])) + 1e-9, f"{what} tick {t} m_input_rms"
+
+
+def run_spectrum_case(seed, family):
     import waveform_amd as wf
+    cfg_dict, steps, sync_ms = draw(seed, family)
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
+    what = f"{family} case {seed} ({cfg_dict}, sync {sync_ms} ms)"
+    undo = _undo_db(cfg)
     rms = 0.0316 if cfg.normalize_volume else 0.0  # what the host's update_input_rms would hand over (-30 dBFS)
     try:
         hip = scenarios.HipBackend(cfg, streams=2, probe=1, input_rms=rms)
     except wf.WfHipError as e:
-        # a documented limit of the device path (e.g. more curve points per row than a spectrum's threads can finish)
-        assert e.code == -2, e  # WF_HIP_ERR_UNSUPPORTED
+        assert e.code == -2, e  # WF_HIP_ERR_UNSUPPORTED: a documented limit of the device path; shows up as a skip, never silently
         pytest.skip(f"configuration outside the device path's documented limits: {e}")
     ora = scenarios.OracleBackend(cfg, input_rms=rms)
     try:
@@ -84,13 +125,32 @@ def test_hip_matches_oracle_on_random_case(seed):
         want = scenarios.play(ora, sc)
     finally:
         hip.close()
-    assert len(got) == len(want)
-    for t, (g, w) in enumerate(zip(got, want)):
-        assert g["silent"] == w["silent"], f"case {seed} tick {t}: m_last_silent {g['silent']} != {w['silent']} ({cfg_dict})"
-        assert_db_close(g["db"], w["db"], f"case {seed} tick {t} decibels ({cfg_dict})")
-        if w["bars"] is not None:
-            err = np.abs(g["bars"].astype(np.float64) - w["bars"])
-            assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"case {seed} tick {t} bars/curve: max err {err.max():.3e} px ({cfg_dict})"
+    _compare(got, want, undo, what + " vs the restatement")
+    if seed % REF_EVERY == 0:
+        # the same script against the reference itself (its own float FFTW, its own update_input_rms); the device derives
+        # m_input_rms from the audio too
+        from oracle import wfref
+        if wfref.available():
+            hip = scenarios.HipBackend(cfg, streams=2, probe=0)
+            ref = scenarios.RefBackend(cfg)
+            try:
+                got = scenarios.play(hip, sc)
+                want = scenarios.play(ref, sc)
+            finally:
+                hip.close()
+            _compare(got, want, undo, what + " vs libwfref")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SPEC_SEEDS)
+def test_hip_matches_oracle_on_random_case(seed):
+    run_spectrum_case(seed, "pow2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", BLU_SEEDS)
+def test_hip_matches_oracle_on_random_size(seed):
+    run_spectrum_case(seed, "any")
 
 
 @pytest.mark.gpu
@@ -145,7 +205,7 @@ def test_per_stream_av_sync_delay():
 
 
 # ---- level meter --------------------------------------------------------------------------------------------------------
-METER_CASES = list(range(16))
+METER_SEEDS = range(500)
 
 
 def draw_meter(seed: int):
@@ -171,25 +231,36 @@ def draw_meter(seed: int):
     return cfg, steps
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", METER_CASES)
-def test_hip_meter_matches_oracle_on_random_case(seed):
+def run_meter_case(seed):
     cfg_dict, steps = draw_meter(seed)
     cfg = scenarios.make_config(cfg_dict)
     sc = dict(cfg=cfg_dict, steps=steps, record="all")
     hip = scenarios.HipBackend(cfg, streams=3, probe=2)
     ora = scenarios.OracleBackend(cfg)
+    exact = scenarios.OracleBackend(cfg, exact=True)  # the same restatement with the sum of squares in double
     try:
         got = scenarios.play(hip, sc)
         want = scenarios.play(ora, sc)
+        truth = scenarios.play(exact, sc)
     finally:
         hip.close()
-    assert len(got) == len(want)
-    for t, (g, w) in enumerate(zip(got, want)):
-        assert g["silent"] == w["silent"], f"meter case {seed} tick {t}: m_last_silent {g['silent']} != {w['silent']} ({cfg_dict})"
-        assert_db_close(g["db"], w["db"], f"meter case {seed} tick {t} levels ({cfg_dict})")
-        err = np.abs(g["bars"].astype(np.float64) - w["bars"])
-        assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"meter case {seed} tick {t} bars: max err {err.max():.3e} px ({cfg_dict})"
+    assert len(got) == len(want) == len(truth)
+    dbrange = float(cfg.ceiling_db - cfg.floor_db)
+    for t, (g, w, x) in enumerate(zip(got, want, truth)):
+        what = f"meter case {seed} tick {t} ({cfg_dict})"
+        # m_last_silent is a threshold on the level: it may only differ where the reference and the exact sum differ too
+        assert g["silent"] == w["silent"] or g["silent"] == x["silent"], f"{what}: m_last_silent {g['silent']} != {w['silent']}"
+        assert_levels_close(g["db"], w["db"], x["db"], what + " levels")
+        tol = 1e-5 * np.abs(w["bars"]) + 2e-3
+        gb, wb, xb = (np.asarray(v["bars"], np.float64) for v in (g, w, x))
+        ok = (np.abs(gb - wb) <= tol) | (np.abs(gb - xb) <= np.abs(wb - xb) + tol)
+        assert ok.all(), f"{what} bars: got {gb}, reference {wb}, exact sum {xb} (range {dbrange} dB)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", METER_SEEDS)
+def test_hip_meter_matches_oracle_on_random_case(seed):
+    run_meter_case(seed)
 
 
 @pytest.mark.gpu
@@ -214,7 +285,7 @@ def test_meter_sync_delay_never_unconsumes():
 
 
 # ---- waveform display -----------------------------------------------------------------------------------------------------
-WAVE_CASES = list(range(12))
+WAVE_SEEDS = range(100)
 
 
 def draw_wave(seed: int):
@@ -223,7 +294,7 @@ def draw_wave(seed: int):
     cfg = dict(waveform=1, capture_channels=1 if layout in (0, 3) else 2, stereo=1 if layout in (2, 3) else 0,
                width=int(r.choice([800, 333, 1024, 64, 2000])), meter_ms=int(r.choice([150, 50, 400, 20])))
     if r.random() < 0.4:
-        cfg.update(normalize_volume=1, volume_target=float(np.float32(r.uniform(-20.0, -3.0))), max_gain=float(np.float32(r.uniform(6.0, 30.0))))
+        cfg.update(normalize_volume=1, volume_target=float(r.integers(-20, -2)), max_gain=float(r.integers(6, 31)))  # integer sliders in the reference
     steps = []
     for _ in range(int(r.integers(6, 14))):
         for _ in range(int(r.integers(0, 3))):
@@ -240,7 +311,7 @@ def draw_wave(seed: int):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", WAVE_CASES)
+@pytest.mark.parametrize("seed", WAVE_SEEDS)
 def test_hip_waveform_matches_oracle_on_random_case(seed):
     cfg_dict, steps, sync_ms = draw_wave(seed)
     cfg = scenarios.make_config(cfg_dict)
@@ -256,4 +327,4 @@ def test_hip_waveform_matches_oracle_on_random_case(seed):
     assert len(got) == len(want)
     for t, (g, w) in enumerate(zip(got, want)):
         assert g["silent"] == w["silent"], f"wave case {seed} tick {t}: m_last_silent {g['silent']} != {w['silent']} ({cfg_dict})"
-        assert_db_close(g["db"], w["db"], f"wave case {seed} tick {t} rows ({cfg_dict}, sync {sync_ms} ms)")
+        assert_db_close(g["db"], w["db"], f"wave case {seed} tick {t} rows ({cfg_dict}, sync {sync_ms} ms)", lin_eps=None)

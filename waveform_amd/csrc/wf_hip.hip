@@ -58,6 +58,12 @@ struct wf_hip {
     uint32_t *d_flags = nullptr;     // [flag_bufs][n_streams]; the buffer flag_cur holds the current m_last_silent / hidden bits
     uint32_t *d_verdict = nullptr;   // split mode: [3][n_streams * cap_ch] "row has a value > floor - 10" (TickArgs::verdict_*)
     uint32_t flag_bufs = 1, flag_cur = 0;
+    // bars-only ticks on a batch that does not run split: per-wavefront row verdicts (TickArgs::row_verdict), allocated by the
+    // first tick that carries WF_HIP_TICK_NO_DECIBELS; from the tick after it the silence test reads them instead of the rows
+    uint32_t *d_row_verdict = nullptr;
+    float *d_stale_row = nullptr;    // [M] of DB_MIN (TickArgs::stale_row), allocated with the first bars-only tick
+    uint32_t waves_per_spectrum = 1;
+    bool verdict_tracking = false;
     bool split = false;              // the channels of a stream run in different workgroups (spectrum_tick_kernel<.., SPLIT>)
     // FFT sizes that are not powers of two: Bluestein over the geometry of geom_n = 2 * L points (spectrum_tick_kernel<.., BLU>)
     bool blu = false;
@@ -307,7 +313,12 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.verdict_out = h->d_verdict + (size_t)nxt * n_spec;
         a.verdict_clear = h->d_verdict + (size_t)clr * n_spec;
     }
-    a.skip_decibels = (p->flags & WF_HIP_TICK_NO_DECIBELS) ? 1u : 0u;
+    // mono mixdown keeps storing its row: the silence quirk adds the stale row to the partner's magnitudes (wf_kernels.hpp)
+    const bool mono_mix_rows = !h->cfg.stereo && h->cap_ch > 1;
+    a.skip_decibels = ((p->flags & WF_HIP_TICK_NO_DECIBELS) && !mono_mix_rows) ? 1u : 0u;
+    a.row_verdict = h->d_row_verdict;
+    a.use_verdict = h->verdict_tracking ? 1u : 0u;
+    a.stale_row = h->d_stale_row;
     a.bar = wf::BarArgs{};
     if(h->d_bars) {
         a.bar.coef = h->d_bar_coef;
@@ -442,19 +453,42 @@ int check_range(wf_hip *h, uint32_t first, uint32_t count)
     return WF_HIP_OK;
 }
 
+// frees a block handed out by dev_alloc (the caller has made sure nothing enqueued still uses it)
+void dev_release(wf_hip *h, void *p)
+{
+    if(p == nullptr)
+        return;
+    for(size_t i = 0; i < h->allocs.size(); ++i)
+        if(h->allocs[i] == p) {
+            h->allocs[i] = h->allocs.back();
+            h->allocs.pop_back();
+            break;
+        }
+    (void)hipFree(p);
+}
+
+// staging blocks grow geometrically and the outgrown block is released once the stream has drained it
+size_t grown(size_t have, size_t need) { return std::max(need, have + have / 2); }
+
 int ensure_stage(wf_hip *h, size_t floats)
 {
     if(h->stage_floats >= floats)
         return WF_HIP_OK;
-    // grow: the old block stays in allocs and is released at destroy
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // the old block may still feed a ring append
+    dev_release(h, h->d_stage);
+    h->d_stage = nullptr;
+    const size_t want = grown(h->stage_floats, floats);
+    h->stage_floats = 0;
     float *p = nullptr;
-    int rc = dev_alloc(h, &p, floats);
+    int rc = dev_alloc(h, &p, want);
     if(rc)
         return rc;
     h->d_stage = p;
-    h->stage_floats = floats;
+    h->stage_floats = want;
     return WF_HIP_OK;
 }
+
+constexpr uint32_t PUSH_SLICE = 16384; // streams per launch of the ingest kernels (rows = streams * cap_ch <= 65535)
 
 // the RMS ring follows every push (before wpos advances): squared peaks, then the sums of the blocks the push completed
 void rms_after_push(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
@@ -472,13 +506,18 @@ int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, c
     // a packet longer than the ring keeps its newest ring_cap frames, as CircularBuffer + capture_audio's trimming would
     if(h->d_rms_ring && frames > h->rms_cap)
         return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the RMS ring capacity %u", frames, h->rms_cap);
-    const dim3 grid((frames + 255) / 256 > 64 ? 64 : (frames + 255) / 256, count * h->cap_ch), block(256);
-    hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->ring_stride, h->cap_ch, first,
-                       d_src, frames);
-    if(h->d_rms_ring) {
-        hipLaunchKernelGGL(wf::rms_push_kernel, dim3(grid.x, count), block, 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
-                           h->cap_ch, first, d_rms_src, frames);
-        rms_after_push(h, first, count, frames);
+    // the kernels index (stream, channel) rows by blockIdx.y (at most 65535): larger batches go in slices
+    for(uint32_t off = 0; off < count; off += PUSH_SLICE) {
+        const uint32_t cnt = std::min(PUSH_SLICE, count - off);
+        const size_t skip = (size_t)off * h->cap_ch * frames;
+        const dim3 grid((frames + 255) / 256 > 64 ? 64 : (frames + 255) / 256, cnt * h->cap_ch), block(256);
+        hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->ring_stride, h->cap_ch,
+                           first + off, d_src ? d_src + skip : nullptr, frames);
+        if(h->d_rms_ring) {
+            hipLaunchKernelGGL(wf::rms_push_kernel, dim3(grid.x, cnt), block, 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
+                               h->cap_ch, first + off, d_rms_src ? d_rms_src + skip : nullptr, frames);
+            rms_after_push(h, first + off, cnt, frames);
+        }
     }
     hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
                        frames);
@@ -516,6 +555,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     wf::HostTables tab;
     wf_config cfg_eff = *cfg;
     uint32_t wave_samples = 0;
+    wf::normalize_config(cfg_eff);
     if(cfg_eff.waveform)
         wave_samples = wf::waveform_config(cfg_eff); // update()'s overrides; fft_size becomes the row length (width)
     else if(cfg_eff.meter)
@@ -732,6 +772,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     wf::dispatch_geometry(h->geom_n, [&](auto g) {
         using G = decltype(g);
         wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
+        h->waves_per_spectrum = G::T / 64;
         // the channels of a stream share a workgroup (silence state machine, mono mixdown)
         if(h->blu) {
             if constexpr(G::N >= 32768) {
@@ -827,6 +868,20 @@ void wf_hip_destroy(wf_hip *h)
     delete h;
 }
 
+// update(): m_rms_sync_buf empty, m_input_rms_buf = 0, m_input_rms = 0 (src/source.cpp:1144-1152); no-op unless the device
+// producer is enabled
+static int reset_rms_producer(wf_hip *h, uint32_t first, uint32_t count)
+{
+    if(h->d_rms_ring == nullptr)
+        return WF_HIP_OK;
+    const size_t nblk = h->rms_cap / wf::RMS_BLOCK;
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_rms_ring + (size_t)first * h->rms_cap, 0, (size_t)count * h->rms_cap * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_rms_bsum + (size_t)first * nblk, 0, (size_t)count * nblk * sizeof(float), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_rend + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_input_rms + first, 0, (size_t)count * sizeof(float), h->stream));
+    return WF_HIP_OK;
+}
+
 int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
 {
     int rc = check_range(h, first, count);
@@ -848,7 +903,7 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
         WF_HIP_TRY(h, hipGetLastError());
         if(first == 0 && count == h->n_streams)
             h->all_aligned = true;
-        return WF_HIP_OK;
+        return reset_rms_producer(h, first, count); // waveform batches normalise too (src/source_generic.cpp:376-388)
     }
     if(h->meter) {
         // update() in meter mode (src/source.cpp:1123-1127, :1181, :1243): empty rings (no zero pre-fill), meter buffer 0,
@@ -871,6 +926,8 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
     WF_HIP_TRY(h, hipMemsetAsync(h->d_ring + spec0 * h->ring_stride, 0, nspec * h->ring_stride * sizeof(float), h->stream));
     for(uint32_t b = 0; b < h->flag_bufs; ++b)
         WF_HIP_TRY(h, hipMemsetAsync(h->d_flags + (size_t)b * h->n_streams + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
+    if(h->d_row_verdict)
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_row_verdict + spec0 * h->waves_per_spectrum, 0, nspec * h->waves_per_spectrum * sizeof(uint32_t), h->stream));
     if(h->d_verdict) // rows of DB_MIN: nothing above floor - 10
         for(uint32_t b = 0; b < 3; ++b)
             WF_HIP_TRY(h, hipMemsetAsync(h->d_verdict + (size_t)b * h->n_streams * h->cap_ch + spec0, 0, nspec * sizeof(uint32_t), h->stream));
@@ -886,14 +943,9 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
                            h->d_bars + (size_t)first * h->disp_ch * h->num_bars, nb, h->tab.border_bottom);
     }
     WF_HIP_TRY(h, hipGetLastError());
-    if(h->d_rms_ring) {
-        // update(): m_rms_sync_buf empty, m_input_rms_buf = 0, m_input_rms = 0 (src/source.cpp:1144-1152)
-        const size_t nblk = h->rms_cap / wf::RMS_BLOCK;
-        WF_HIP_TRY(h, hipMemsetAsync(h->d_rms_ring + (size_t)first * h->rms_cap, 0, (size_t)count * h->rms_cap * sizeof(float), h->stream));
-        WF_HIP_TRY(h, hipMemsetAsync(h->d_rms_bsum + (size_t)first * nblk, 0, (size_t)count * nblk * sizeof(float), h->stream));
-        WF_HIP_TRY(h, hipMemsetAsync(h->d_rend + first, 0, (size_t)count * sizeof(uint32_t), h->stream));
-        WF_HIP_TRY(h, hipMemsetAsync(h->d_input_rms + first, 0, (size_t)count * sizeof(float), h->stream));
-    }
+    int rrc = reset_rms_producer(h, first, count);
+    if(rrc)
+        return rrc;
     if(first == 0 && count == h->n_streams)
         h->all_aligned = true; // every write position is back at fft_size
     return WF_HIP_OK;
@@ -959,12 +1011,16 @@ int wf_hip_push_audio_async(wf_hip *h, uint32_t first, uint32_t count, const flo
     if(h->stage_async_floats[slot] < n) {
         if(h->slot_used[slot])
             WF_HIP_TRY(h, hipEventSynchronize(h->ev_consumed[slot])); // the old block may still feed an append
+        dev_release(h, h->d_stage_async[slot]);
+        h->d_stage_async[slot] = nullptr;
+        const size_t want = grown(h->stage_async_floats[slot], n);
+        h->stage_async_floats[slot] = 0;
         float *p = nullptr;
-        rc = dev_alloc(h, &p, n);
+        rc = dev_alloc(h, &p, want);
         if(rc)
             return rc;
         h->d_stage_async[slot] = p;
-        h->stage_async_floats[slot] = n;
+        h->stage_async_floats[slot] = want;
     }
     // copy stream: wait until the previous append from this slot's staging block is done, then copy
     if(h->slot_used[slot])
@@ -1040,12 +1096,15 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
         return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the RMS ring capacity %u", frames, h->rms_cap);
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t gx = std::min<uint32_t>((frames + 255) / 256, 256);
-    hipLaunchKernelGGL(wf::ring_synth_kernel, dim3(gx, count * h->cap_ch), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,
-                       h->ring_cap, h->ring_stride, h->cap_ch, first, seed, stream_id0, index0, frames);
-    if(h->d_rms_ring) {
-        hipLaunchKernelGGL(wf::rms_synth_kernel, dim3(gx, count), dim3(256), 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
-                           h->cap_ch, first, seed, stream_id0, index0, frames);
-        rms_after_push(h, first, count, frames);
+    for(uint32_t off = 0; off < count; off += PUSH_SLICE) {
+        const uint32_t cnt = std::min(PUSH_SLICE, count - off);
+        hipLaunchKernelGGL(wf::ring_synth_kernel, dim3(gx, cnt * h->cap_ch), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,
+                           h->ring_cap, h->ring_stride, h->cap_ch, first + off, seed, stream_id0 + off, index0, frames);
+        if(h->d_rms_ring) {
+            hipLaunchKernelGGL(wf::rms_synth_kernel, dim3(gx, cnt), dim3(256), 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
+                               h->cap_ch, first + off, seed, stream_id0 + off, index0, frames);
+            rms_after_push(h, first + off, cnt, frames);
+        }
     }
     hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
                        frames);
@@ -1108,11 +1167,27 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         WF_HIP_TRY(h, hipGetLastError());
         return WF_HIP_OK;
     }
+    const bool mono_mix_rows = !h->cfg.stereo && h->cap_ch > 1;
+    if((p->flags & WF_HIP_TICK_NO_DECIBELS) && !mono_mix_rows && h->d_stale_row == nullptr) {
+        if(h->cfg.floor_db - 10 >= 0)
+            return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS needs floor_db < 10 (a skipped channel's row must be negative)");
+        int rc = dev_alloc(h, &h->d_stale_row, (size_t)h->M);
+        if(rc)
+            return rc;
+        hipLaunchKernelGGL(wf::fill_f32_kernel, dim3((h->M + 255) / 256), dim3(256), 0, h->stream, h->d_stale_row, (size_t)h->M, wf::db_min());
+        if(!h->split) {
+            rc = dev_alloc(h, &h->d_row_verdict, (size_t)h->n_streams * h->cap_ch * h->waves_per_spectrum);
+            if(rc)
+                return rc;
+        }
+    }
     launch_input_rms(h, p);
     const wf::TickArgs a = make_args(h, p);
     const bool aligned = h->all_aligned && h->stream_delays_aligned && (p->delay_frames % 4u) == 0;
     h->launch(h, a, aligned);
     WF_HIP_TRY(h, hipGetLastError());
+    if(h->d_row_verdict)
+        h->verdict_tracking = true; // this tick left a verdict for every row; later ticks read those
     if(h->split)
         h->flag_cur = (h->flag_cur + 1) % 3; // what the kernel wrote is what the next tick (and the readers) see
     return WF_HIP_OK;
@@ -1153,8 +1228,9 @@ int wf_hip_set_stream_delay(wf_hip *h, uint32_t first, uint32_t count, const uin
         mx = std::max(mx, delay_frames[i]);
         al = al && (delay_frames[i] % 4u) == 0;
     }
-    if((uint64_t)mx + h->N > h->ring_cap)
-        return fail(h, WF_HIP_ERR_INVALID, "stream delay %u + fft_size %u exceeds the ring capacity %u", mx, h->N, h->ring_cap);
+    const uint32_t window = h->wave ? h->wave_samples : h->N; // the same capacity term as wf_hip_tick
+    if((uint64_t)mx + window > h->ring_cap)
+        return fail(h, WF_HIP_ERR_INVALID, "stream delay %u + window %u exceeds the ring capacity %u", mx, window, h->ring_cap);
     WF_HIP_TRY(h, hipSetDevice(h->device));
     if(h->d_delay == nullptr) {
         rc = dev_alloc(h, &h->d_delay, (size_t)h->n_streams);
@@ -1307,13 +1383,17 @@ int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pin
     const size_t per = (size_t)h->disp_ch * h->num_bars, n = count * per;
     if(h->read_used[slot])
         WF_HIP_TRY(h, hipEventSynchronize(h->ev_read[slot])); // the slot's previous copy must have left its snapshot
-    if(h->snap_floats[slot] < n) {
+    if(h->snap_floats[slot] < n) { // (the slot's previous copy has left its snapshot: waited for above)
+        dev_release(h, h->d_snap[slot]);
+        h->d_snap[slot] = nullptr;
+        const size_t want = grown(h->snap_floats[slot], n);
+        h->snap_floats[slot] = 0;
         float *p = nullptr;
-        rc = dev_alloc(h, &p, n);
+        rc = dev_alloc(h, &p, want);
         if(rc)
             return rc;
         h->d_snap[slot] = p;
-        h->snap_floats[slot] = n;
+        h->snap_floats[slot] = want;
     }
     // compute stream: snapshot behind the ticks enqueued so far (device to device, a few MB at most)
     WF_HIP_TRY(h, hipMemcpyAsync(h->d_snap[slot], h->d_bars + first * per, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
@@ -1497,7 +1577,7 @@ uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags)
         bytes += n_spec * 8ull * h->M;
     const bool mono_mix = !h->cfg.stereo && h->cap_ch > 1;
     const uint64_t out_rows = (uint64_t)h->n_streams * (mono_mix ? 1u : h->out_ch);
-    if(!(flags & WF_HIP_TICK_NO_DECIBELS))
+    if(!(flags & WF_HIP_TICK_NO_DECIBELS) || mono_mix) // the mono-mixdown row is stored in either mode
         bytes += out_rows * 4ull * h->M;
     bytes += (uint64_t)h->n_streams * h->disp_ch * h->num_bars * 4ull;
     return bytes;

@@ -436,6 +436,21 @@ float gravity_for(const wf_config &cfg, float seconds)
     return (cfg.tsmoothing == WF_TSMOOTH_TVEXPONENTIAL) ? std::exp(-seconds / std::lerp(lo, hi, cfg.gravity)) : cfg.gravity;
 }
 
+void normalize_config(wf_config &cfg)
+{
+    // what get_settings() makes of out-of-range combinations before update() sees them (src/source.cpp:567-579)
+    if((cfg.cutoff_high - cfg.cutoff_low) < 0) {
+        cfg.cutoff_high = 17500;
+        cfg.cutoff_low = 120;
+    }
+    if((cfg.ceiling_db - cfg.floor_db) < 1) {
+        cfg.ceiling_db = 0;
+        cfg.floor_db = -120;
+    }
+    if(!cfg.stereo || (((int)cfg.height - cfg.channel_spacing) < 1))
+        cfg.channel_spacing = 0;
+}
+
 uint32_t meter_config(wf_config &cfg)
 {
     // "turn off stuff we don't need in this mode", src/source.cpp:1108-1118

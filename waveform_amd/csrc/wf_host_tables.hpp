@@ -43,6 +43,9 @@ struct HostTables {
     float gauss_sum = 0.0f;
 };
 
+// get_settings()' repairs of out-of-range combinations (src/source.cpp:567-579): cutoffs swapped, ceiling <= floor, channel
+// spacing in mono display or larger than the height.  Call first.
+void normalize_config(wf_config &cfg);
 // Level-meter mode (cfg.meter): applies update()'s overrides for the mode to `cfg` (src/source.cpp:1106-1128) and
 // returns the meter buffer length, which replaces cfg.fft_size.  Call before build_host_tables.
 uint32_t meter_config(wf_config &cfg);

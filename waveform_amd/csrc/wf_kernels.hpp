@@ -190,8 +190,12 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
     bool wave_below = true;
-    if(active && !hidden && !wave_nz) // wave-uniform and rare: the whole slice of this wave is digital silence
-        wave_below = __all(!row_thread || row_all_below<RG, BLU>(rows + (size_t)(stereo ? ch : 0u) * MO, t, a.silent_floor, NB)) != 0;
+    if(active && !hidden && !wave_nz) { // wave-uniform and rare: the whole slice of this wave is digital silence
+        if(!SPLIT && a.use_verdict)     // rows in HBM are stale (a tick skipped their store): the word this wave left instead
+            wave_below = a.row_verdict[(size_t)(spec - (stereo ? 0u : ch)) * WPS + (wave_in_block - sub * WPS)] == 0u;
+        else
+            wave_below = __all(!row_thread || row_all_below<RG, BLU>(rows + (size_t)(stereo ? ch : 0u) * MO, t, a.silent_floor, NB)) != 0;
+    }
 
     bool nz0 = wave_nz, nz1 = false, below0 = wave_below, below1 = true;
     if(lane == 0)
@@ -322,8 +326,15 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             if(Policy<G>::TOUCH_STATE)
                 asm volatile("" ::"v"(r4.touch[0]), "v"(r4.touch[1])); // the touched dwords are only ever waited for
         }
-    } else if(do_db && !(mono_mix && ch == 1) && row_thread)
-        load_row<RG, BLU>(rows + (size_t)ch * MO, t, mag, NB); // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3)
+    } else if(do_db && !(mono_mix && ch == 1) && row_thread) {
+        // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3).  A channel is only skipped when that
+        // row is entirely <= floor - 10 < 0, and dbfs() of a negative number is DB_MIN: when the row in HBM is not current
+        // (bars-only ticks) any negative stand-in gives the reference's result.  Mono mixdown adds the stale row to the
+        // partner's magnitudes first, so its rows are always stored and loaded.
+        // (read from a.stale_row, a row of DB_MIN in HBM: filling mag[] in place here made ROCm 7.2's clang sink the
+        // store into a pointer phi over scratch and global memory, which its backend cannot select)
+        load_row<RG, BLU>((a.stale_row != nullptr && !mono_mix) ? a.stale_row : rows + (size_t)ch * MO, t, mag, NB);
+    }
 
     // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------
     if(active && hidden && !was_silent) {
@@ -376,8 +387,17 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
     float d[RP];
+    bool row_exceeds = false; // bars-only handles: this thread's part of the row has a value > floor - 10
     if(have_row && row_thread) {
         p4_db<RG, BLU>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp, NB);
+        if(!SPLIT && a.row_verdict != nullptr) {
+            // taken here, where d[] is produced: reading the array again under a later branch makes ROCm 7.2's clang merge
+            // that read with a global load through a pointer phi, i.e. a flat pointer into scratch, and its backend aborts
+            // ("Illegal instruction detected: Operand has incorrect register class", V_CMP_NE_U32 0, src_private_base)
+#pragma unroll
+            for(int i = 0; i < RP; ++i)
+                row_exceeds = row_exceeds || ((!BLU || 4 * (t + RG::T * (i / 4)) < NB) && d[i] > a.silent_floor);
+        }
         if(!a.skip_decibels) {
             store_row<RG, BLU>(rows + (size_t)ch * MO, t, d, NB);
             if(dup_row)
@@ -388,6 +408,22 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     if(active && ch == 0 && t == 0)
         (SPLIT ? a.flags_out : a.stream_flags)[stream] =
             (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
+    if(!SPLIT && a.row_verdict != nullptr && active) {
+        // bars-only handles: what the next tick's silence test would find in the row this spectrum owns (see TickArgs)
+        bool exceeds = false, write = true;
+        if(have_row) {
+            exceeds = row_exceeds;
+        } else if(hidden && !was_silent) {
+            exceeds = false; // the reset branch: rows of DB_MIN
+        } else if(!a.use_verdict && !(mono_mix && ch == 1)) {
+            // first tracked tick, row untouched by it: the row in HBM is still current
+            exceeds = row_thread && !row_all_below<RG, BLU>(rows + (size_t)ch * MO, t, a.silent_floor, NB);
+        } else
+            write = false; // untouched: the word stays
+        const bool any_exceeds = __any(exceeds) != 0;
+        if(write && lane == 0)
+            a.row_verdict[(size_t)spec * WPS + (wave_in_block - sub * WPS)] = any_exceeds ? 1u : 0u;
+    }
     if constexpr(SPLIT) {
         // what the next tick's silence test will find in this channel's row (reference :78-86: any value > floor - 10?)
         bool exceeds = false;

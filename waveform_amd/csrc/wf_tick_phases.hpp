@@ -133,6 +133,14 @@ struct TickArgs {
     uint32_t out_ch;           // m_output_channels
     uint32_t mode;
     uint32_t skip_decibels;    // WF_HIP_TICK_NO_DECIBELS: bars-only batch mode
+    // Once a tick of a handle has skipped the row store, m_decibels in HBM is no longer what the silence state machine must
+    // inspect (reference :78-86).  From that tick on every wavefront leaves "my slice of the row I produced has a value
+    // > floor - 10" in row_verdict[spec * (T/64) + wave] and the test reads those words instead of the rows (use_verdict;
+    // 0 on the first such tick, whose rows are still current).  nullptr: not tracked.  Split mode has its own rotating
+    // verdict words (above).
+    uint32_t *row_verdict;
+    uint32_t use_verdict;
+    const float *stale_row;    // [M] of DB_MIN, non-null once a tick has skipped the row store: stands in for a skipped channel's stale row
     // FFT sizes that are not powers of two (Bluestein, spectrum_tick_kernel<.., BLU>): the geometry's M is the padded
     // convolution length L, the transform the host asked for has blu_n points and row_bins = blu_n / 2 output bins
     const cf *blu_a;           // [M] window_j * conj(w_j), zero for j >= blu_n
@@ -895,10 +903,14 @@ template<class G, int DEC> WF_DEV void p4_prefetch_dec(const TickArgs &a, int t,
     q.sl[0] = sv.x; q.sl[1] = sv.y; q.sl[2] = sv.z; q.sl[3] = sv.w;
 }
 
+// Returns the four magnitudes by value (not through the caller's array): with the array written inside each of the three
+// mode arms, ROCm 7.2's clang sinks the arms' last stores -- one into scratch, two into the state row -- into a single store
+// through a pointer phi, a flat pointer its backend then fails to select ("Operand has incorrect register class").
 template<class G, int DEC, bool TS, bool FPK>
-WF_DEV void p4_split_smooth_dec_impl(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[4])
+WF_DEV f4 p4_split_smooth_dec_impl(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q)
 {
     constexpr int M = G::M;
+    float mag[4];
     WF_UNROLL
     for(int i = 0; i < 4; ++i) {
         const int k = (4 * t + i) << DEC;
@@ -920,19 +932,23 @@ WF_DEV void p4_split_smooth_dec_impl(const TickArgs &a, int t, const cf *lds, fl
         }
         mag[i] = m;
     }
+    const f4 r = f4{mag[0], mag[1], mag[2], mag[3]};
     if(TS)
-        st4(ts + 4 * t, f4{mag[0], mag[1], mag[2], mag[3]});
+        st4(ts + 4 * t, r);
+    return r;
 }
 template<class G, int DEC>
 WF_DEV void p4_split_smooth_dec(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[4])
 {
+    f4 r;
     if(a.mode & WF_MODE_TSMOOTH) {
         if(a.mode & WF_MODE_FAST_PEAKS)
-            p4_split_smooth_dec_impl<G, DEC, true, true>(a, t, lds, ts, wb, q, mag);
+            r = p4_split_smooth_dec_impl<G, DEC, true, true>(a, t, lds, ts, wb, q);
         else
-            p4_split_smooth_dec_impl<G, DEC, true, false>(a, t, lds, ts, wb, q, mag);
+            r = p4_split_smooth_dec_impl<G, DEC, true, false>(a, t, lds, ts, wb, q);
     } else
-        p4_split_smooth_dec_impl<G, DEC, false, false>(a, t, lds, ts, wb, q, mag);
+        r = p4_split_smooth_dec_impl<G, DEC, false, false>(a, t, lds, ts, wb, q);
+    mag[0] = r.x; mag[1] = r.y; mag[2] = r.z; mag[3] = r.w;
 }
 
 // dB conversion + volume normalisation + roll-off of this thread's bins (reference :144-179); d[] is the
