@@ -23,5 +23,8 @@ for k in kinds:
             print("SKIP", k, s, str(e)[:200], flush=True)
         except Exception as e:
             bad += 1
-            print("FAIL", k, s, str(e)[:400].replace("\n", " "), flush=True)
+            m = str(e).replace("\n", " ")
+            print("FAIL", k, s, m[-260:] if len(m) > 260 else m, flush=True)
+            if os.environ.get("WF_FUZZ_VERBOSE"):
+                print("     ", m[:700], flush=True)
 print("done", lo, hi, kinds, "failures", bad, "skips", skipped)

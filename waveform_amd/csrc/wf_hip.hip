@@ -519,8 +519,8 @@ int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, c
             rms_after_push(h, first + off, cnt, frames);
         }
     }
-    hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
-                       frames);
+    hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos,
+                       h->d_flags + (size_t)h->flag_cur * h->n_streams, first, count, frames);
     WF_HIP_TRY(h, hipGetLastError());
     if(frames % 4u)
         h->all_aligned = false;
@@ -1106,8 +1106,8 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
             rms_after_push(h, first + off, cnt, frames);
         }
     }
-    hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, first, count,
-                       frames);
+    hipLaunchKernelGGL(wf::wpos_advance_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos,
+                       h->d_flags + (size_t)h->flag_cur * h->n_streams, first, count, frames);
     WF_HIP_TRY(h, hipGetLastError());
     if(frames % 4u)
         h->all_aligned = false;

@@ -247,7 +247,16 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         nz1 = (or1 & 1) != 0;
         below1 = (and1 & 2) != 0;
     }
-    const StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nz0, nz1, below0, below1);
+    StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nz0, nz1, below0, below1);
+    // Fewer samples captured than window + A/V-sync delay (reference :55-61: `continue`, the channel is left alone and
+    // m_last_silent stays).  The ring is zero history before the first sample, so without this the window would be analysed
+    // as digital silence.  Only ever true in the first `delay` samples after a reset (wpos starts at fft_size).
+    const uint32_t fft_n = BLU ? a.blu_n : (uint32_t)(G::N >> DEC);
+    const bool underflow = !(sflags & WF_STREAM_WRAPPED) && (wpos - fft_n) < delay;
+    if(underflow) {
+        plan.process0 = plan.process1 = false;
+        plan.last_silent = was_silent;
+    }
     const bool process = active && !hidden && (ch == 0 ? plan.process0 : plan.process1);
     const bool do_db = active && !hidden && !plan.last_silent; // reference :138-139
 
@@ -326,14 +335,16 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             if(Policy<G>::TOUCH_STATE)
                 asm volatile("" ::"v"(r4.touch[0]), "v"(r4.touch[1])); // the touched dwords are only ever waited for
         }
-    } else if(do_db && !(mono_mix && ch == 1) && row_thread) {
+    } else if(do_db && (!(mono_mix && ch == 1) || underflow) && row_thread) {
         // skipped channel of a live stream: its stale row is re-dBFS'ed (Appendix C.3).  A channel is only skipped when that
         // row is entirely <= floor - 10 < 0, and dbfs() of a negative number is DB_MIN: when the row in HBM is not current
         // (bars-only ticks) any negative stand-in gives the reference's result.  Mono mixdown adds the stale row to the
         // partner's magnitudes first, so its rows are always stored and loaded.
         // (read from a.stale_row, a row of DB_MIN in HBM: filling mag[] in place here made ROCm 7.2's clang sink the
         // store into a pointer phi over scratch and global memory, which its backend cannot select)
-        load_row<RG, BLU>((a.stale_row != nullptr && !mono_mix) ? a.stale_row : rows + (size_t)ch * MO, t, mag, NB);
+        // (underflow in mono mixdown: both channels take row 0, which no tick has filled yet -- DB_MIN, as m_decibels[1] is
+        // in the reference at that point; the mean of two negative rows is negative: DB_MIN again)
+        load_row<RG, BLU>((a.stale_row != nullptr && !mono_mix) ? a.stale_row : rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
     }
 
     // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(10);
     if(active && ch == 0 && t == 0)
         (SPLIT ? a.flags_out : a.stream_flags)[stream] =
-            (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
+            (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
     if(!SPLIT && a.row_verdict != nullptr && active) {
         // bars-only handles: what the next tick's silence test would find in the row this spectrum owns (see TickArgs)
         bool exceeds = false, write = true;
@@ -497,11 +508,15 @@ __global__ void ring_synth_kernel(float *ring, const uint32_t *wpos, uint32_t ri
         dst[(w + i) & (ring_cap - 1)] = wf_synth_sample(key, index0 + i);
 }
 
-__global__ void wpos_advance_kernel(uint32_t *wpos, uint32_t first, uint32_t count, uint32_t frames)
+__global__ void wpos_advance_kernel(uint32_t *wpos, uint32_t *flags, uint32_t first, uint32_t count, uint32_t frames)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i < count)
-        wpos[first + i] += frames;
+    if(i < count) {
+        const uint32_t w = wpos[first + i], n = w + frames;
+        wpos[first + i] = n;
+        if(n < w) // 2^32 samples (a day at 48 kHz): the position wraps, the stream has long had all the audio any delay asks for
+            flags[first + i] |= WF_STREAM_WRAPPED;
+    }
 }
 
 // show()/hide()/capture timeout: set or clear WF_STREAM_HIDDEN (mask 1: hidden, 2: capture timed out), keep m_last_silent
