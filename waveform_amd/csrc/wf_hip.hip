@@ -65,6 +65,7 @@ struct wf_hip {
     uint32_t waves_per_spectrum = 1;
     bool verdict_tracking = false;
     bool split = false;              // the channels of a stream run in different workgroups (spectrum_tick_kernel<.., SPLIT>)
+    bool split_mono = false;         // ... and, for mono mixdown, in different launches (TickArgs::split_ch)
     // FFT sizes that are not powers of two: Bluestein over the geometry of geom_n = 2 * L points (spectrum_tick_kernel<.., BLU>)
     bool blu = false;
     uint32_t geom_n = 0;             // the fft size whose geometry runs the batch (N itself for the power-of-two sizes >= 1024)
@@ -76,6 +77,7 @@ struct wf_hip {
     int *d_bar_bin = nullptr, *d_bar_off = nullptr, *d_band_widths = nullptr, *d_bar_chunk = nullptr;
     int bar_chunks = 0, bar_lpb = 1, bar_segs = 0;
     int bar_blocks = 0;
+    int bar_stage_off = 0;           // BarArgs::stage_off
     uint32_t *d_delay = nullptr;     // [n_streams] A/V-sync delay per stream (wf_hip_set_stream_delay), or nullptr
     uint32_t max_stream_delay = 0;   // largest value ever set (ring-capacity check of the tick)
     bool stream_delays_aligned = true; // all of them multiples of 4 frames (vector fetch without straddling)
@@ -161,14 +163,20 @@ template<class T> int upload(wf_hip *h, T **out, const std::vector<T> &v)
     return WF_HIP_OK;
 }
 
-template<class G> void launch_tick_split(wf_hip *h, const wf::TickArgs &a, bool aligned)
+template<class G> void launch_tick_split(wf_hip *h, const wf::TickArgs &a0, bool aligned)
 {
-    const dim3 grid(a.n_streams * a.cap_ch), block(G::T);
+    const dim3 block(G::T);
     const size_t lds = wf::tick_lds_bytes<G, 1>();
-    if(aligned)
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, true, true>), grid, block, lds, h->stream, a);
-    else
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, false, true>), grid, block, lds, h->stream, a);
+    // mono mixdown: channel 1 of every stream, then channel 0 (TickArgs::split_ch); stereo pairs: everything at once
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
+        wf::TickArgs a = a0;
+        a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(h->split_mono ? a.n_streams : a.n_streams * a.cap_ch);
+        if(aligned)
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, true, true>), grid, block, lds, h->stream, a);
+        else
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, false, true>), grid, block, lds, h->stream, a);
+    }
 }
 
 template<class G> int setup_launch_split(wf_hip *h)
@@ -214,12 +222,18 @@ template<class G, int DEC> int setup_launch_dec(wf_hip *h)
 }
 
 // Bluestein path (FFT sizes that are not powers of two): always the scalar fetch
-template<class G, int SPW, bool SPLIT> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a, bool)
+template<class G, int SPW, bool SPLIT> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a0, bool)
 {
-    const uint32_t n_spec = a.n_streams * a.cap_ch;
-    const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
+    const uint32_t n_spec = a0.n_streams * a0.cap_ch;
+    const dim3 block(G::T * SPW);
     const size_t lds = wf::tick_lds_bytes<G, SPW>();
-    hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>), grid, block, lds, h->stream, a);
+    const bool two = SPLIT && h->split_mono; // mono mixdown in two launches (TickArgs::split_ch)
+    for(int pass = 0; pass < (two ? 2 : 1); ++pass) {
+        wf::TickArgs a = a0;
+        a.split_ch = two ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(two ? a.n_streams : (n_spec + SPW - 1) / SPW);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>), grid, block, lds, h->stream, a);
+    }
 }
 
 template<class G, int SPW, bool SPLIT> int setup_launch_blu(wf_hip *h)
@@ -316,6 +330,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     // mono mixdown keeps storing its row: the silence quirk adds the stale row to the partner's magnitudes (wf_kernels.hpp)
     const bool mono_mix_rows = !h->cfg.stereo && h->cap_ch > 1;
     a.skip_decibels = ((p->flags & WF_HIP_TICK_NO_DECIBELS) && !mono_mix_rows) ? 1u : 0u;
+    a.split_ch = 0xffffffffu;
     a.row_verdict = h->d_row_verdict;
     a.use_verdict = h->verdict_tracking ? 1u : 0u;
     a.stale_row = h->d_stale_row;
@@ -340,6 +355,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.gauss = h->d_gauss;
         a.bar.gauss_wsum = h->d_gauss_wsum;
         a.bar.gauss_radius = h->tab.gauss_radius;
+        a.bar.stage_off = h->bar_stage_off;
         a.bar.entries = (int)h->tab.bar_coef.size();
         a.bar.lanes_per_bar = h->bar_lpb;
         a.bar.out = h->d_bars;
@@ -684,6 +700,10 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(const char *e = std::getenv("WF_HIP_SPLIT"))
         want_split = (e[0] == '1') && h->geom_n >= 8192;
     want_split = want_split && cfg->capture_channels == 2 && cfg->stereo;
+    // mono mixdown needs both channels' magnitudes; where a workgroup holds one spectrum (132 KB of LDS) the pair runs split
+    // as well, channel 1 a launch ahead of channel 0
+    h->split_mono = h->geom_n >= 32768 && cfg->capture_channels == 2 && !cfg->stereo;
+    want_split = want_split || h->split_mono;
     h->flag_bufs = want_split ? 3 : 1;
     WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->flag_bufs * h->n_streams));
     if(want_split)
@@ -716,9 +736,6 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             lds_floats = (size_t)G::LDS_CF * 2;
             threads = G::T;
         });
-        chunks = wf::bar_chunks(h->tab, lds_floats - h->M);
-        WF_CREATE_TRY(upload(h, &h->d_bar_chunk, chunks));
-        h->bar_chunks = (int)chunks.size() - 1;
         int lpb = 1;
         while(lpb < 64 && (uint32_t)(threads / (lpb * 2)) >= h->num_bars)
             lpb *= 2;
@@ -752,18 +769,44 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
             }
         }
+        size_t chunk_cap = lds_floats - h->M; // LDS scratch for the products: what is left behind the dB row
         if(h->tab.gauss_radius > 0) {
             // staged in the spectrum's LDS: the row with radius-1 zeros on either side, then the weights
             const size_t staged = (size_t)h->num_bars + 2 * (size_t)(h->tab.gauss_radius - 1) + h->tab.gauss.size();
-            if(h->out_steps == 0 || staged > lds_floats) {
+            if(h->out_steps == 0) {
+                // bars in chunked form (more bars than threads): the staging area sits at the end of the buffer, the product
+                // scratch shrinks by it and must still hold the longest bar
+                int longest = 0;
+                for(uint32_t b = 0; b < h->num_bars; ++b)
+                    longest = std::max(longest, h->tab.bar_off[(size_t)b + 1] - h->tab.bar_off[(size_t)b]);
+                if(staged + (size_t)longest + h->M > lds_floats) {
+                    return bail(fail(h, WF_HIP_ERR_UNSUPPORTED,
+                                     "filter_mode gauss: %u bars + the filter's staging do not fit this configuration's on-chip buffer (%zu floats)",
+                                     h->num_bars, lds_floats));
+                }
+                chunk_cap -= staged;
+                h->bar_stage_off = (int)(lds_floats - staged);
+            } else if(staged > lds_floats) {
                 return bail(fail(h, WF_HIP_ERR_UNSUPPORTED,
-                                 "filter_mode gauss: %u outputs per row do not fit this configuration's on-chip staging (%zu floats%s)",
-                                 h->num_bars, lds_floats, h->out_steps == 0 ? "; bars outnumber the threads of a spectrum" : ""));
+                                 "filter_mode gauss: %u outputs per row do not fit this configuration's on-chip staging (%zu floats)",
+                                 h->num_bars, lds_floats));
             }
             WF_CREATE_TRY(upload(h, &h->d_gauss, h->tab.gauss));
             WF_CREATE_TRY(upload(h, &h->d_gauss_wsum, h->tab.gauss_wsum));
             WF_CREATE_HIP(hipStreamSynchronize(h->stream));
         }
+        if(h->bar_segs == 0 && !h->curve) { // chunked form: a chunk holds at least one whole bar
+            int longest = 0;
+            for(uint32_t b = 0; b < h->num_bars; ++b)
+                longest = std::max(longest, h->tab.bar_off[(size_t)b + 1] - h->tab.bar_off[(size_t)b]);
+            if((size_t)longest > chunk_cap)
+                return bail(fail(h, WF_HIP_ERR_UNSUPPORTED, "bars: the widest band (%d bins and taps) does not fit the on-chip scratch (%zu floats)",
+                                 longest, chunk_cap));
+        }
+        chunks = wf::bar_chunks(h->tab, chunk_cap);
+        WF_CREATE_TRY(upload(h, &h->d_bar_chunk, chunks));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+        h->bar_chunks = (int)chunks.size() - 1;
     }
 
     // FFT plan: twiddle tables for the geometry of this fft_size + the kernel instantiation
@@ -781,8 +824,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 else if(cfg->capture_channels == 1)
                     setup_rc = setup_launch_blu<G, 1, false>(h);
                 else
-                    setup_rc = fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: mono mixdown of two captured channels is not implemented above 5456",
-                                    cfg->fft_size);
+                    setup_rc = fail(h, WF_HIP_ERR_RUNTIME, "fft_size %u: no launch plan", cfg->fft_size);
             } else if constexpr(G::T >= 256)
                 setup_rc = want_split ? setup_launch_blu<G, 1, true>(h)
                                       : (cfg->capture_channels > 1) ? setup_launch_blu<G, 2, false>(h) : setup_launch_blu<G, 1, false>(h);
@@ -803,7 +845,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             else if(cfg->capture_channels == 1)
                 setup_rc = setup_launch<G, 1>(h);
             else
-                setup_rc = fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: mono mixdown of two captured channels is not implemented above 16384", cfg->fft_size);
+                setup_rc = fail(h, WF_HIP_ERR_RUNTIME, "fft_size %u: no launch plan", cfg->fft_size);
         } else if constexpr(G::T >= 256)
             setup_rc = want_split ? setup_launch_split<G>(h) : (cfg->capture_channels > 1) ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
         else

@@ -138,7 +138,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     // (no branch), stream/channel come from a shift (cap_ch is 1 or 2), and the two per-stream words (write position,
     // flags) are scalar loads issued together.
     const uint32_t n_spec = a.n_streams * a.cap_ch;
-    const uint32_t spec_raw = blockIdx.x * SPW + (uint32_t)sub;
+    uint32_t spec_raw = blockIdx.x * SPW + (uint32_t)sub;
+    if constexpr(SPLIT) {
+        if(a.split_ch != 0xffffffffu) // one channel of every stream per launch (mono mixdown in two launches, see TickArgs)
+            spec_raw = 2u * blockIdx.x + a.split_ch;
+    }
     const bool active = spec_raw < n_spec;
     const uint32_t spec = active ? spec_raw : n_spec - 1;
     const uint32_t cap_shift = a.cap_ch - 1;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         nz0 = ch == 0 ? nz_own : nz_other;
         nz1 = ch == 0 ? nz_other : nz_own;
         below0 = vin0 == 0u;
-        below1 = vin1 == 0u;
+        below1 = stereo ? (vin1 == 0u) : (vin0 == 0u); // mono display: channel 1 inspects row 0 too (reference :81)
     } else if(T > 64 || a.cap_ch > 1) {
         const int sb0 = (sub - (int)ch) * WPS; // first wavefront of the subgroup that owns channel 0 of this stream
         int or0 = 0, and0 = 3, or1 = 0, and1 = 3;
@@ -368,7 +372,19 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     }
 
     // ---- end-of-tick dB pass (reference :141-179) ------------------------------------------------------------------
-    if(mono_mix) {
+    if(mono_mix && SPLIT) {
+        // the channels run in different launches, channel 1 first: its magnitudes wait in m_decibels[1]
+        if(ch == 1) {
+            if(process && row_thread)
+                store_row<RG, BLU>(rows + (size_t)MO, t, mag, NB);
+        } else if(do_db && row_thread) {
+            float o[RP];
+            load_row<RG, BLU>(rows + (size_t)MO, t, o, NB);
+#pragma unroll
+            for(int i = 0; i < RP; ++i)
+                mag[i] = (mag[i] + o[i]) * 0.5f;
+        }
+    } else if(mono_mix) {
         // dB[0][i] = dbfs((dB[0][i] + dB[1][i]) * 0.5f): channel 1 hands its magnitudes to channel 0 through LDS
         float *xch = reinterpret_cast<float *>(lds);
         __syncthreads();

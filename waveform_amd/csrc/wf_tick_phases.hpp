@@ -76,6 +76,7 @@ struct BarArgs {
     const float *gauss;        // [2 * gauss_radius - 1]
     const float *gauss_wsum;   // [num_bars] the sum of the weights whose taps fall inside the row (weighted_avg's divisor)
     int gauss_radius;
+    int stage_off;             // chunked bars + filter: float offset (from the dB row in LDS) of the staging area [pad | bars | pad | weights]
 #ifdef WF_PHASE_TIMING
     unsigned long long *clk;   // development aid: this workgroup's stamp slots
 #endif
@@ -134,6 +135,11 @@ struct TickArgs {
     uint32_t out_ch;           // m_output_channels
     uint32_t mode;
     uint32_t skip_decibels;    // WF_HIP_TICK_NO_DECIBELS: bars-only batch mode
+    // Mono mixdown on a geometry that holds one spectrum per workgroup (N = 32768 and its Bluestein sizes): the tick is two
+    // launches of the split kernel -- channel 1 of every stream first (its smoothed magnitudes go to m_decibels[1], where
+    // the reference keeps them too, src/source_generic.cpp:134), then channel 0, which mixes them in.  split_ch = the
+    // channel this launch runs; 0xffffffff: all channels in one launch.
+    uint32_t split_ch;
     // Once a tick of a handle has skipped the row store, m_decibels in HBM is no longer what the silence state machine must
     // inspect (reference :78-86).  From that tick on every wavefront leaves "my slice of the row I produced has a value
     // > floor - 10" in row_verdict[spec * (T/64) + wave] and the test reads those words instead of the rows (use_verdict;
@@ -1345,6 +1351,20 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
     // ---- tables larger than the scratch (very many bars): chunk by chunk, lanes_per_bar threads per bar ---------------
     const int lpb = b.lanes_per_bar;
     const int bars_per_pass = T / lpb;
+    // With the Gaussian filter the bar means are parked in a staging area behind the product scratch (the host sized the
+    // chunks around it) instead of being mapped at once; the filter runs when the last chunk is done.
+    const bool filtered = b.gauss_radius > 0;
+    const int gpad = b.gauss_radius - 1, gsize = 2 * b.gauss_radius - 1;
+    float *vp = db + b.stage_off;                   // [gpad | num_bars | gpad]
+    float *wl = vp + b.num_bars + 2 * gpad;         // [gsize]
+    if(filtered && has_row) {
+        for(int i = t; i < gpad; i += T) {
+            vp[i] = 0.0f;
+            vp[gpad + b.num_bars + i] = 0.0f;
+        }
+        for(int i = t; i < gsize; i += T)
+            wl[i] = b.gauss[i];
+    }
     for(int c = 0; c < b.num_chunks; ++c) {
         const bool single = (b.num_chunks == 1);
         const int bar_lo = single ? 0 : b.chunk[c], bar_hi = single ? b.num_bars : b.chunk[c + 1];
@@ -1380,11 +1400,28 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
             }
             for(int m = lpb >> 1; m >= 1; m >>= 1)
                 acc = xor_sum(acc, m);
-            if(live && sub == 0)
-                emit(bar, acc, cnt);
+            if(live && sub == 0) {
+                if(filtered)
+                    vp[gpad + bar] = acc / (float)cnt;
+                else
+                    emit(bar, acc, cnt);
+            }
         }
         if(c + 1 < b.num_chunks)
             sync(); // prod is reused by the next chunk
+    }
+    if(filtered) {
+        // apply_filter / weighted_avg (reference src/filter.hpp:133-157, :171-180) as in outputs_finish, one output per
+        // thread and round
+        sync();
+        if(has_row) {
+            for(int o = t; o < b.num_bars; o += T) {
+                float sum = 0.0f;
+                for(int tap = 0; tap < gsize; ++tap)
+                    sum = fmaf(vp[o + tap], wl[tap], sum);
+                emit_output(b, o, sum / b.gauss_wsum[o], out_row, dup_row);
+            }
+        }
     }
     return false;
 }
