@@ -30,6 +30,17 @@ struct wf_hip {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Lanes: a large batch is ticked as n_lanes slices of streams, slice 0 on `stream`, the others on their own HIP streams.
+    // Consecutive ticks of a slice are ordered by its stream; slices share nothing, so while no other call intervenes the
+    // tail of one slice's launch overlaps the head of another's (a lone launch leaves the chip draining for a workgroup's
+    // lifetime at both ends).  Every other entry point first makes `stream` wait for the lanes (join_lanes) and the next
+    // tick makes the lanes wait for `stream`: outside wf_hip_tick the handle behaves as if it had the one stream.
+    static constexpr int MAX_LANES = 4;
+    int n_lanes = 1;
+    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_lane[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_fork = nullptr;
+    bool lanes_pending = false; // a lane holds work `stream` has not waited for
+    bool main_dirty = true;     // `stream` holds work the lanes have not waited for
     // pipelined ingest (wf_hip_push_audio_async): a copy stream, per-slot staging blocks and events
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr};   // the H2D copy of the slot has finished (host buffer free, staging full)
@@ -61,7 +72,8 @@ struct wf_hip {
     // bars-only ticks on a batch that does not run split: per-wavefront row verdicts (TickArgs::row_verdict), allocated by the
     // first tick that carries WF_HIP_TICK_NO_DECIBELS; from the tick after it the silence test reads them instead of the rows
     uint32_t *d_row_verdict = nullptr;
-    float *d_stale_row = nullptr;    // [M] of DB_MIN (TickArgs::stale_row), allocated with the first bars-only tick
+    float *d_stale_row = nullptr;    // [M] of DB_MIN (BarsOnlyState::stale_row), allocated with the first bars-only tick
+    wf::BarsOnlyState *d_bars_only = nullptr; // the kernel's view of the three fields above
     uint32_t waves_per_spectrum = 1;
     bool verdict_tracking = false;
     bool split = false;              // the channels of a stream run in different workgroups (spectrum_tick_kernel<.., SPLIT>)
@@ -114,6 +126,7 @@ struct wf_hip {
     std::string kernel_name;
     // launch description, fixed at create
     void (*launch)(wf_hip *, const wf::TickArgs &, bool aligned) = nullptr;
+    hipStream_t launch_stream = nullptr; // where `launch` enqueues (the lane's stream, set by wf_hip_tick)
 };
 
 namespace {
@@ -131,6 +144,13 @@ int fail(wf_hip *h, int code, const char *fmt, ...)
         g_create_error = buf;
     return code;
 }
+
+#define WF_TRY_RC(expr)                 \
+    do {                                \
+        const int rc_ = (expr);         \
+        if(rc_ != WF_HIP_OK)            \
+            return rc_;                 \
+    } while(0)
 
 #define WF_HIP_TRY(h, expr)                                                                                       \
     do {                                                                                                          \
@@ -171,11 +191,11 @@ template<class G> void launch_tick_split(wf_hip *h, const wf::TickArgs &a0, bool
     for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
         wf::TickArgs a = a0;
         a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
-        const dim3 grid(h->split_mono ? a.n_streams : a.n_streams * a.cap_ch);
+        const dim3 grid(h->split_mono ? a.stream_count : a.stream_count * a.cap_ch);
         if(aligned)
-            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, true, true>), grid, block, lds, h->stream, a);
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, true, true>), grid, block, lds, h->launch_stream, a);
         else
-            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, false, true>), grid, block, lds, h->stream, a);
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, false, true>), grid, block, lds, h->launch_stream, a);
     }
 }
 
@@ -198,13 +218,13 @@ template<class G> int setup_launch_split(wf_hip *h)
 // FFT sizes 512 / 256 / 128 on the 1024-point geometry, zero-padded (spectrum_tick_kernel<.., DEC>)
 template<class G, int DEC> void launch_tick_dec(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
-    const uint32_t n_spec = a.n_streams * a.cap_ch;
+    const uint32_t n_spec = a.stream_count * a.cap_ch;
     const dim3 grid((n_spec + 1) / 2), block(G::T * 2);
     const size_t lds = wf::tick_lds_bytes<G, 2>();
     if(aligned)
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, true, false, DEC>), grid, block, lds, h->stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, true, false, DEC>), grid, block, lds, h->launch_stream, a);
     else
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, false, false, DEC>), grid, block, lds, h->stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, false, false, DEC>), grid, block, lds, h->launch_stream, a);
 }
 
 template<class G, int DEC> int setup_launch_dec(wf_hip *h)
@@ -224,15 +244,15 @@ template<class G, int DEC> int setup_launch_dec(wf_hip *h)
 // Bluestein path (FFT sizes that are not powers of two): always the scalar fetch
 template<class G, int SPW, bool SPLIT> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a0, bool)
 {
-    const uint32_t n_spec = a0.n_streams * a0.cap_ch;
+    const uint32_t n_spec = a0.stream_count * a0.cap_ch;
     const dim3 block(G::T * SPW);
     const size_t lds = wf::tick_lds_bytes<G, SPW>();
     const bool two = SPLIT && h->split_mono; // mono mixdown in two launches (TickArgs::split_ch)
     for(int pass = 0; pass < (two ? 2 : 1); ++pass) {
         wf::TickArgs a = a0;
         a.split_ch = two ? (uint32_t)(1 - pass) : 0xffffffffu;
-        const dim3 grid(two ? a.n_streams : (n_spec + SPW - 1) / SPW);
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>), grid, block, lds, h->stream, a);
+        const dim3 grid(two ? a.stream_count : (n_spec + SPW - 1) / SPW);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>), grid, block, lds, h->launch_stream, a);
     }
 }
 
@@ -252,13 +272,13 @@ template<class G, int SPW, bool SPLIT> int setup_launch_blu(wf_hip *h)
 
 template<class G, int SPW, bool TLDS> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
-    const uint32_t n_spec = a.n_streams * a.cap_ch;
+    const uint32_t n_spec = a.stream_count * a.cap_ch;
     const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
     const size_t lds = wf::tick_lds_bytes<G, SPW>();
     if(aligned)
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS>), grid, block, lds, h->stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS>), grid, block, lds, h->launch_stream, a);
     else
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS>), grid, block, lds, h->stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS>), grid, block, lds, h->launch_stream, a);
 }
 
 template<class G, int SPW, bool TLDS> int setup_launch_impl(wf_hip *h)
@@ -331,9 +351,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     const bool mono_mix_rows = !h->cfg.stereo && h->cap_ch > 1;
     a.skip_decibels = ((p->flags & WF_HIP_TICK_NO_DECIBELS) && !mono_mix_rows) ? 1u : 0u;
     a.split_ch = 0xffffffffu;
-    a.row_verdict = h->d_row_verdict;
-    a.use_verdict = h->verdict_tracking ? 1u : 0u;
-    a.stale_row = h->d_stale_row;
+    a.bars_only = h->d_bars_only;
     a.bar = wf::BarArgs{};
     if(h->d_bars) {
         a.bar.coef = h->d_bar_coef;
@@ -382,6 +400,8 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     a.silent_floor = (float)(h->cfg.floor_db - 10);
     a.vol_comp = 0.0f;
     a.n_streams = h->n_streams;
+    a.stream_base = 0;
+    a.stream_count = h->n_streams;
     a.cap_ch = h->cap_ch;
     a.out_ch = h->out_ch;
     uint32_t mode = 0;
@@ -460,13 +480,27 @@ void launch_input_rms(wf_hip *h, const wf_hip_tick_params *p)
     hipLaunchKernelGGL(wf::input_rms_kernel, dim3(h->n_streams), dim3(64), 0, h->stream, r);
 }
 
+// Every entry point other than wf_hip_tick: `stream` waits for what the lanes hold, and the next tick's lanes will wait for
+// what this call enqueues on `stream`.
+int join_lanes(wf_hip *h)
+{
+    if(h->lanes_pending) {
+        WF_HIP_TRY(h, hipSetDevice(h->device));
+        for(int l = 1; l < h->n_lanes; ++l)
+            WF_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_lane[l], 0));
+        h->lanes_pending = false;
+    }
+    h->main_dirty = true;
+    return WF_HIP_OK;
+}
+
 int check_range(wf_hip *h, uint32_t first, uint32_t count)
 {
     if(h == nullptr)
         return WF_HIP_ERR_INVALID;
     if(count == 0 || first >= h->n_streams || count > h->n_streams - first)
         return fail(h, WF_HIP_ERR_INVALID, "stream range [%u, %u+%u) outside 0..%u", first, first, count, h->n_streams);
-    return WF_HIP_OK;
+    return join_lanes(h);
 }
 
 // frees a block handed out by dev_alloc (the caller has made sure nothing enqueued still uses it)
@@ -873,6 +907,25 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_blu_b, tb));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
+    {
+        // lanes (see struct wf_hip): two slices once each still fills the chip a couple of times over.  Measured on MI355X
+        // (cfg3, 8192 spectra per tick, back-to-back ticks): 1 lane 66 us per tick, 2 lanes 58 us.  WF_HIP_LANES overrides.
+        const uint32_t wgs = (uint32_t)(n_spec / (h->split ? 1u : 2u));
+        int lanes = wgs >= 2048u ? 2 : 1;
+        if(const char *e = std::getenv("WF_HIP_LANES"))
+            lanes = std::atoi(e);
+        lanes = std::max(1, std::min({lanes, (int)wf_hip::MAX_LANES, (int)h->n_streams}));
+#ifdef WF_PHASE_TIMING
+        lanes = 1;
+#endif
+        for(int l = 1; l < lanes; ++l) {
+            WF_CREATE_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+            WF_CREATE_HIP(hipEventCreateWithFlags(&h->ev_lane[l], hipEventDisableTiming));
+        }
+        if(lanes > 1)
+            WF_CREATE_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        h->n_lanes = lanes;
+    }
     WF_CREATE_TRY(wf_hip_reset(h, 0, h->n_streams));
     WF_CREATE_HIP(hipStreamSynchronize(h->stream));
 #undef WF_CREATE_TRY
@@ -886,8 +939,16 @@ void wf_hip_destroy(wf_hip *h)
     if(h == nullptr)
         return;
     (void)hipSetDevice(h->device);
+    for(int l = 1; l < wf_hip::MAX_LANES; ++l)
+        if(h->lane_stream[l])
+            (void)hipStreamSynchronize(h->lane_stream[l]);
     if(h->stream)
         (void)hipStreamSynchronize(h->stream);
+    for(int l = 1; l < wf_hip::MAX_LANES; ++l) {
+        if(h->ev_lane[l]) (void)hipEventDestroy(h->ev_lane[l]);
+        if(h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]);
+    }
+    if(h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for(void *p : h->allocs)
         (void)hipFree(p);
     if(h->copy_stream)
@@ -1222,14 +1283,46 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
             if(rc)
                 return rc;
         }
+        rc = dev_alloc(h, &h->d_bars_only, 1);
+        if(rc)
+            return rc;
+        const wf::BarsOnlyState st{h->d_row_verdict, h->d_stale_row, 0u}; // this tick's rows are still current
+        WF_HIP_TRY(h, hipMemcpyAsync(h->d_bars_only, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+        WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `st` dies here
+        h->main_dirty = true;
     }
+    if(h->d_rms_ring)
+        WF_TRY_RC(join_lanes(h)); // (never pending: the RMS producer keeps the batch on one lane)
     launch_input_rms(h, p);
-    const wf::TickArgs a = make_args(h, p);
+    wf::TickArgs a = make_args(h, p);
     const bool aligned = h->all_aligned && h->stream_delays_aligned && (p->delay_frames % 4u) == 0;
-    h->launch(h, a, aligned);
+    const int lanes = h->d_rms_ring ? 1 : h->n_lanes; // update_input_rms runs on `stream` ahead of every tick: one lane
+    if(lanes > 1 && h->main_dirty) {
+        WF_HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+        for(int l = 1; l < lanes; ++l)
+            WF_HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_fork, 0));
+    }
+    h->main_dirty = false;
+    for(int l = 0; l < lanes; ++l) {
+        const uint32_t lo = (uint32_t)((uint64_t)h->n_streams * l / lanes), hi = (uint32_t)((uint64_t)h->n_streams * (l + 1) / lanes);
+        a.stream_base = lo;
+        a.stream_count = hi - lo;
+        h->launch_stream = l == 0 ? h->stream : h->lane_stream[l];
+        h->launch(h, a, aligned);
+        if(l > 0)
+            WF_HIP_TRY(h, hipEventRecord(h->ev_lane[l], h->lane_stream[l]));
+    }
+    if(lanes > 1)
+        h->lanes_pending = true;
     WF_HIP_TRY(h, hipGetLastError());
-    if(h->d_row_verdict)
-        h->verdict_tracking = true; // this tick left a verdict for every row; later ticks read those
+    if(h->d_row_verdict && !h->verdict_tracking) {
+        // this tick left a verdict for every row; later ticks read those (the flag flips behind this tick's kernels, on every lane)
+        h->verdict_tracking = true;
+        WF_TRY_RC(join_lanes(h));
+        const wf::BarsOnlyState st{h->d_row_verdict, h->d_stale_row, 1u};
+        WF_HIP_TRY(h, hipMemcpyAsync(h->d_bars_only, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+        WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     if(h->split)
         h->flag_cur = (h->flag_cur + 1) % 3; // what the kernel wrote is what the next tick (and the readers) see
     return WF_HIP_OK;
@@ -1329,6 +1422,7 @@ int wf_hip_enable_input_rms(wf_hip *h)
     if(h->d_rms_ring)
         return WF_HIP_OK;
     WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_TRY_RC(join_lanes(h));
     h->rms_size = h->cfg.sample_rate & ~15u; // m_input_rms_size, src/source.cpp:1147
     if(h->rms_size == 0)
         return fail(h, WF_HIP_ERR_INVALID, "sample_rate %u is too small for the RMS window", h->cfg.sample_rate);
@@ -1369,6 +1463,7 @@ int wf_hip_sync(wf_hip *h)
     if(h == nullptr)
         return WF_HIP_ERR_INVALID;
     WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_TRY_RC(join_lanes(h));
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
     return WF_HIP_OK;
 }
@@ -1528,7 +1623,13 @@ int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *
 
 float *wf_hip_decibels_device(wf_hip *h) { return h ? h->d_decibels : nullptr; }
 float *wf_hip_bars_device(wf_hip *h) { return h ? h->d_bars : nullptr; }
-void *wf_hip_stream(wf_hip *h) { return h ? (void *)h->stream : nullptr; }
+void *wf_hip_stream(wf_hip *h)
+{
+    if(h == nullptr)
+        return nullptr;
+    (void)join_lanes(h); // whatever the caller orders behind this stream is ordered behind every tick enqueued so far
+    return (void *)h->stream;
+}
 
 size_t wf_hip_table_window(const wf_hip *h, const float **out, float *window_sum)
 {
@@ -1573,7 +1674,9 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
     if((uint64_t)hop * (ticks - 1) > p->delay_frames)
         return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u too small for %u ticks of hop %u", p->delay_frames, ticks, hop);
     WF_HIP_TRY(h, hipSetDevice(h->device));
-    // events recorded on the handle's own stream, around the fused kernels only
+    WF_TRY_RC(join_lanes(h));
+    // events recorded on the handle's own stream, around the fused kernels only (the lanes fork behind ev0 and are joined
+    // in front of ev1)
     WF_HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     wf_hip_tick_params q = *p;
     for(uint32_t i = 0; i < ticks; ++i) {
@@ -1582,6 +1685,7 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
         if(rc)
             return rc;
     }
+    WF_TRY_RC(join_lanes(h));
     WF_HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     WF_HIP_TRY(h, hipEventSynchronize(h->ev1));
     float ms = 0.0f;

@@ -64,6 +64,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 
 // register budget: waves per SIMD the kernel is compiled for (launch_bounds' second argument) -- 3 only for the
 // one-wavefront 16-point geometry (N = 2048), whose register prefetch of the smoothing state needs ~140 VGPRs
+#ifndef WF_TRACK
+#define WF_TRACK 1
+#endif
 #ifndef WF_WPS_SMALL
 #define WF_WPS_SMALL 5 // 8-point geometry (N = 1024): 5 waves per SIMD measured +4 % over 4; 6 spills
 #endif
@@ -137,11 +140,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     // Prologue: nothing here may wait for memory before the window fetch is in flight.  The spectrum index is clamped
     // (no branch), stream/channel come from a shift (cap_ch is 1 or 2), and the two per-stream words (write position,
     // flags) are scalar loads issued together.
-    const uint32_t n_spec = a.n_streams * a.cap_ch;
-    uint32_t spec_raw = blockIdx.x * SPW + (uint32_t)sub;
+    const uint32_t n_spec = (a.stream_base + a.stream_count) * a.cap_ch; // end of this launch's slice
+    uint32_t spec_raw = a.stream_base * a.cap_ch + blockIdx.x * SPW + (uint32_t)sub;
     if constexpr(SPLIT) {
         if(a.split_ch != 0xffffffffu) // one channel of every stream per launch (mono mixdown in two launches, see TickArgs)
-            spec_raw = 2u * blockIdx.x + a.split_ch;
+            spec_raw = 2u * (a.stream_base + blockIdx.x) + a.split_ch;
     }
     const bool active = spec_raw < n_spec;
     const uint32_t spec = active ? spec_raw : n_spec - 1;
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(1);
     bool wave_below = true;
     if(active && !hidden && !wave_nz) { // wave-uniform and rare: the whole slice of this wave is digital silence
-        if(!SPLIT && a.use_verdict)     // rows in HBM are stale (a tick skipped their store): the word this wave left instead
-            wave_below = a.row_verdict[(size_t)(spec - (stereo ? 0u : ch)) * WPS + (wave_in_block - sub * WPS)] == 0u;
+        if(!SPLIT && (WF_TRACK && a.bars_only != nullptr) && a.bars_only->use_verdict) // rows in HBM are stale: the word this wave left instead
+            wave_below = a.bars_only->row_verdict[(size_t)(spec - (stereo ? 0u : ch)) * WPS + (wave_in_block - sub * WPS)] == 0u;
         else
             wave_below = __all(!row_thread || row_all_below<RG, BLU>(rows + (size_t)(stereo ? ch : 0u) * MO, t, a.silent_floor, NB)) != 0;
     }
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         // store into a pointer phi over scratch and global memory, which its backend cannot select)
         // (underflow in mono mixdown: both channels take row 0, which no tick has filled yet -- DB_MIN, as m_decibels[1] is
         // in the reference at that point; the mean of two negative rows is negative: DB_MIN again)
-        load_row<RG, BLU>((a.stale_row != nullptr && !mono_mix) ? a.stale_row : rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
+        load_row<RG, BLU>(((WF_TRACK && a.bars_only != nullptr) && !mono_mix) ? a.bars_only->stale_row : rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
     }
 
     // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     bool row_exceeds = false; // bars-only handles: this thread's part of the row has a value > floor - 10
     if(have_row && row_thread) {
         p4_db<RG, BLU>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp, NB);
-        if(!SPLIT && a.row_verdict != nullptr) {
+        if(!SPLIT && (WF_TRACK && a.bars_only != nullptr)) {
             // taken here, where d[] is produced: reading the array again under a later branch makes ROCm 7.2's clang merge
             // that read with a global load through a pointer phi, i.e. a flat pointer into scratch, and its backend aborts
             // ("Illegal instruction detected: Operand has incorrect register class", V_CMP_NE_U32 0, src_private_base)
@@ -435,21 +438,21 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     if(active && ch == 0 && t == 0)
         (SPLIT ? a.flags_out : a.stream_flags)[stream] =
             (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
-    if(!SPLIT && a.row_verdict != nullptr && active) {
+    if(!SPLIT && (WF_TRACK && a.bars_only != nullptr) && active) {
         // bars-only handles: what the next tick's silence test would find in the row this spectrum owns (see TickArgs)
         bool exceeds = false, write = true;
         if(have_row) {
             exceeds = row_exceeds;
         } else if(hidden && !was_silent) {
             exceeds = false; // the reset branch: rows of DB_MIN
-        } else if(!a.use_verdict && !(mono_mix && ch == 1)) {
+        } else if(!a.bars_only->use_verdict && !(mono_mix && ch == 1)) {
             // first tracked tick, row untouched by it: the row in HBM is still current
             exceeds = row_thread && !row_all_below<RG, BLU>(rows + (size_t)ch * MO, t, a.silent_floor, NB);
         } else
             write = false; // untouched: the word stays
         const bool any_exceeds = __any(exceeds) != 0;
         if(write && lane == 0)
-            a.row_verdict[(size_t)spec * WPS + (wave_in_block - sub * WPS)] = any_exceeds ? 1u : 0u;
+            a.bars_only->row_verdict[(size_t)spec * WPS + (wave_in_block - sub * WPS)] = any_exceeds ? 1u : 0u;
     }
     if constexpr(SPLIT) {
         // what the next tick's silence test will find in this channel's row (reference :78-86: any value > floor - 10?)

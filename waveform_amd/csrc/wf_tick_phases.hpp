@@ -97,6 +97,17 @@ struct BarArgs {
 #define WF_BAR_STAMP(i)
 #endif
 
+// State of a handle that runs bars-only ticks, in device memory.  From the first such tick on every wavefront leaves "my
+// slice of the row I produced has a value > floor - 10" in row_verdict[spec * (T/64) + wave] and the silence test reads those
+// words instead of the rows (use_verdict; 0 on the first such tick, whose rows are still current).  Split mode has its own
+// rotating verdict words (TickArgs::verdict_*) and leaves row_verdict null.  stale_row: M values of DB_MIN that stand in for
+// the stale row of a skipped channel (wf_kernels.hpp).
+struct BarsOnlyState {
+    uint32_t *row_verdict;
+    const float *stale_row;
+    uint32_t use_verdict;
+};
+
 struct TickArgs {
     // audio rings: one per (stream, captured channel), ring_cap samples each (power of two)
     const float *ring;
@@ -131,6 +142,7 @@ struct TickArgs {
     float db_min;              // DB_MIN
     float silent_floor;        // (float)(m_floor - 10)
     uint32_t n_streams;
+    uint32_t stream_base, stream_count; // the slice of the batch this launch runs (wf_hip_tick issues the batch as lanes)
     uint32_t cap_ch;           // m_capture_channels (1 or 2)
     uint32_t out_ch;           // m_output_channels
     uint32_t mode;
@@ -140,14 +152,10 @@ struct TickArgs {
     // the reference keeps them too, src/source_generic.cpp:134), then channel 0, which mixes them in.  split_ch = the
     // channel this launch runs; 0xffffffff: all channels in one launch.
     uint32_t split_ch;
-    // Once a tick of a handle has skipped the row store, m_decibels in HBM is no longer what the silence state machine must
-    // inspect (reference :78-86).  From that tick on every wavefront leaves "my slice of the row I produced has a value
-    // > floor - 10" in row_verdict[spec * (T/64) + wave] and the test reads those words instead of the rows (use_verdict;
-    // 0 on the first such tick, whose rows are still current).  nullptr: not tracked.  Split mode has its own rotating
-    // verdict words (above).
-    uint32_t *row_verdict;
-    uint32_t use_verdict;
-    const float *stale_row;    // [M] of DB_MIN, non-null once a tick has skipped the row store: stands in for a skipped channel's stale row
+    // Once a tick of a handle has skipped the row store (WF_HIP_TICK_NO_DECIBELS), m_decibels in HBM is no longer what the
+    // silence state machine must inspect (reference :78-86): see BarsOnlyState.  nullptr: rows are always stored (the usual
+    // case; one pointer here instead of its fields keeps the kernel's scalar registers free).
+    const BarsOnlyState *bars_only;
     // FFT sizes that are not powers of two (Bluestein, spectrum_tick_kernel<.., BLU>): the geometry's M is the padded
     // convolution length L, the transform the host asked for has blu_n points and row_bins = blu_n / 2 output bins
     const cf *blu_a;           // [M] window_j * conj(w_j), zero for j >= blu_n
@@ -263,6 +271,18 @@ template<class G> struct Policy {
     static constexpr bool PREFETCH_SLOPE = (MODE == 1);
     static constexpr bool TOUCH_STATE = (MODE == 2);
 };
+// Pass-1 twiddle rows W_M^(n' k1), k1 = 1..R1-1: only the rows whose k1 is a power of two come from the table; the others
+// are products of two of those (or of one and an earlier product): k1 = hi + lo with lo the lowest set bit.  At R1 = 8 that
+// is 3 loaded rows and 4 complex multiplications per point instead of 7 loaded rows: 16 fewer VGPRs held through the fetch
+// burst and 4 of its 23 sixteen-byte requests gone.  Accuracy: inputs are correctly rounded table entries (1/2 ulp each), a
+// product adds one rounding: the worst row (k1 = 7 = (4 + 2) + 1) carries ~3.5 rounding units (2e-7 relative) instead of 1/2
+// -- the size of the FFT's own round-off, an order of magnitude under the parity tolerance.  (Round 1 tried powers of the
+// single row k1 = 1: up to 8e-7, rejected then.)  WF_TW1_POW2=0 loads every row.
+#ifndef WF_TW1_POW2
+#define WF_TW1_POW2 1
+#endif
+constexpr bool tw1_row_loaded(int k1) { return !WF_TW1_POW2 || (k1 & (k1 - 1)) == 0; }
+
 template<class G> struct P1Regs {
     float smp[G::R1][2 * G::B1];
     float win[G::R1][2 * G::B1];
@@ -334,7 +354,7 @@ WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P
     for(int j = 0; j < R1; ++j) {
         if(j < RV && !TLDS)
             p1_load_window<G>(a, t, j, r.win[j]);
-        if(j >= 1 && !TLDS)
+        if(j >= 1 && !TLDS && tw1_row_loaded(j))
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
     }
     if(DEC == 0) {
@@ -382,6 +402,15 @@ WF_DEV void p1_window_dft(P1Regs<G> &r, cf (&o)[G::R1][G::B1])
     constexpr int LB = ilog2(R1);
     WF_UNROLL
     for(int k1 = 0; k1 < R1; ++k1) {
+        if(k1 >= 1 && !tw1_row_loaded(k1)) { // row k1 = row (k1 minus its lowest set bit) times row (lowest set bit)
+            const int lo = k1 & -k1, hi = k1 - lo;
+            WF_UNROLL
+            for(int b = 0; b < B1; ++b) {
+                const cf w = cmul(cf{r.tw1[hi][2 * b], r.tw1[hi][2 * b + 1]}, cf{r.tw1[lo][2 * b], r.tw1[lo][2 * b + 1]});
+                r.tw1[k1][2 * b] = w.x;
+                r.tw1[k1][2 * b + 1] = w.y;
+            }
+        }
         WF_UNROLL
         for(int b = 0; b < B1; ++b)
             o[k1][b] = (k1 == 0) ? u[b][0] : cmul(u[b][brev(k1, LB)], cf{r.tw1[k1][2 * b], r.tw1[k1][2 * b + 1]});
@@ -501,7 +530,7 @@ template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float
         WF_UNROLL
         for(int e = 0; e < 2 * B1; ++e)
             r.win[j][e] = 1.0f;
-        if(j >= 1)
+        if(j >= 1 && tw1_row_loaded(j))
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
     }
     return (acc & 0x7fffffffu) != 0;
@@ -533,7 +562,7 @@ template<class G> WF_DEV void blu_mid(const TickArgs &a, int t, const cf *lds, P
         WF_UNROLL
         for(int e = 0; e < 2 * B1; ++e)
             r.win[j][e] = 1.0f;
-        if(j >= 1)
+        if(j >= 1 && tw1_row_loaded(j))
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
     }
 }
