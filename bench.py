@@ -8,25 +8,37 @@ Workload at every N: BASELINE.json configs[2] per GPU -- 4096 independent stereo
 (8192 spectra per tick), FFT 4096, Hann window, EXPONENTIAL smoothing g=0.65, slope 1.0,
 48 kHz synthetic white noise (include/wf_synth.h), hop 800 samples (60 fps).  Weak scaling:
 every rank owns its own 4096 streams, no data-path collective (the streams share nothing,
-SURVEY.md §8(e)).
+SURVEY.md section 8(e)).
 
-A "step" is one tick_spectrum over the whole batch = one launch of the fused kernel.  All
-audio for warm-up + timed ticks is generated into the device rings before the timed region
-(inputs resident in HBM); tick i analyses the window that ends (steps-1-i)*hop frames before
-the newest sample, i.e. exactly the ring contents the reference would see at that video
-frame (its own A/V-sync path, src/source_generic.cpp:50-59).
+A "step" is one tick_spectrum over the whole batch.  All audio for warm-up + timed ticks is
+generated into the device rings before the timed region (inputs resident in HBM); tick i
+analyses the window that ends (steps-1-i)*hop frames before the newest sample, i.e. exactly
+the ring contents the reference would see at that video frame (its own A/V-sync path,
+src/source_generic.cpp:50-59).
+
+`python bench.py --gpus N` launches itself: with WORLD_SIZE unset and N > 1 it re-executes under
+torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous), capped at the devices the box
+has -- the line says how many were measured.
 
 One JSON line on rank 0.  Extra objects:
-  roofline     algorithmic bytes per launch / average kernel duration (HIP events on the
-               library's stream, same timed region) vs 8 TB/s HBM peak
-  cpu_baseline the reference's own AVX2 path (oracle/_ref/libwfref.so: verbatim TUs + vendored
-               FFTW) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  roofline       algorithmic bytes per tick / average device time per tick (HIP events on the
+                 library's stream over the same timed region) vs 8 TB/s HBM peak
+  cpu_baseline   the reference's own AVX2 path (oracle/_ref/libwfref.so: verbatim TUs + vendored
+                 FFTW) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  other_configs  (N=1) the same measurement on the other shapes the north star names: working sets
+                 past the 256 MB Infinity Cache (8192 / 16384 streams), BASELINE configs[3]
+                 (N=16384 x 1024 streams, TV-EMA + Lanczos bars), configs[1], the configs[4] per-GPU
+                 shape (8192 streams, bars only), each with its own roofline object
+  pcie_inclusive (N=1) the headline shape fed through the host boundary every step (page-locked
+                 buffers, wf_hip_push_audio_async under the previous tick) -- never `value`
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -39,6 +51,7 @@ FFT_SIZE = 4096
 STREAMS_PER_GPU = 4096
 HOP = 800
 SEED = 0x5741564546524D31
+MAX_DEPTH = 512  # ticks of audio resident per stream; longer runs walk the same windows again (same work per step)
 
 
 def parse_args():
@@ -49,9 +62,10 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
     ap.add_argument("--fft", type=int, default=FFT_SIZE)
     ap.add_argument("--bars-allgather", action="store_true",
-                    help="BASELINE configs[4] shape: bars (26 Lanczos bars per channel) computed in the tick and all-gathered "
-                         "across ranks (RCCL over xGMI) after every step; changes the workload, so it is off by default")
+                    help="BASELINE configs[4] shape: bars (26 Lanczos bars per channel) computed in the tick (bars-only mode) and "
+                         "all-gathered across ranks (RCCL over xGMI) under the next tick; changes the workload, so it is off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs / pcie_inclusive legs (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU work budget (core-seconds) of the baseline leg")
     return ap.parse_args()
 
@@ -92,7 +106,7 @@ def host_cores() -> int:
 
 
 def pmc_traffic(kernel: str, streams: int):
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
+    """HBM bytes per tick from committed rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
     best = None
     for p in sorted((ROOT / "profiles").glob("*_pmc.json")):
         try:
@@ -104,16 +118,129 @@ def pmc_traffic(kernel: str, streams: int):
     return best
 
 
+def roofline(batch, streams, kernel_ms, flags=0):
+    algo = batch.algorithmic_bytes_per_tick(flags)
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": pmc_traffic(batch.kernel_name(), streams), "kernel": batch.kernel_name(), "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": algo}
+
+
+def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0):
+    """One of the other shapes: `steps` back-to-back ticks over resident audio; wall clock and device events."""
+    depth = min(steps + warmup, 64)
+    with wf.SpectrumBatch(cfg, streams, device=device, ring_frames=cfg.fft_size + HOP * (depth + 1)) as b:
+        b.push_synth(SEED, 0, HOP * depth)
+        b.sync()
+        if warmup:
+            b.time_ticks(min(warmup, depth), HOP, HOP * (min(warmup, depth) - 1), flags=flags)
+        t0 = time.perf_counter()
+        ms, done = 0.0, 0
+        while done < steps:
+            n = min(depth, steps - done)
+            ms += b.time_ticks(n, HOP, HOP * (n - 1), flags=flags) * n
+            done += n
+        wall = time.perf_counter() - t0
+        spectra = streams * b.capture_channels
+        return {"name": name, "streams": streams, "fft_size": int(cfg.fft_size), "spectra_per_tick": spectra, "steps": steps,
+                "value": spectra * steps / wall, "unit": "spectra/s", "ms_per_step": wall * 1e3 / steps,
+                "roofline": roofline(b, streams, ms / steps, flags)}
+
+
+def other_configs(wf, device):
+    out = []
+    ema = dict(stereo=1, slope=1.0, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)
+    shapes = [
+        ("configs[2] x2: 8192 stereo streams, FFT 4096, EMA + slope (536 MB working set, past the 256 MB Infinity Cache)",
+         wf.Config.defaults(fft_size=4096, **ema), 8192, 60, 0),
+        ("configs[2] x4: 16384 stereo streams, FFT 4096, EMA + slope (1.07 GB working set)",
+         wf.Config.defaults(fft_size=4096, **ema), 16384, 40, 0),
+        ("configs[3]: 1024 stereo streams, FFT 16384, TV-EMA (gravity) + 26 Lanczos bars per channel",
+         wf.Config.defaults(fft_size=16384, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["tvexponential"], gravity=0.65,
+                            bars=1, interp_mode=wf.INTERP["lanczos"]), 1024, 60, 0),
+        ("configs[1] as a batch: 256 stereo streams, FFT 2048, Hann + magnitude + dB, no smoothing",
+         wf.Config.defaults(fft_size=2048, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["none"]), 256, 60, 0),
+        ("configs[4] per-GPU shape: 8192 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars only (no m_decibels store)",
+         wf.Config.defaults(fft_size=4096, bars=1, interp_mode=wf.INTERP["lanczos"], **ema), 8192, 60, wf.TICK_NO_DECIBELS),
+    ]
+    for name, cfg, streams, steps, flags in shapes:
+        try:
+            out.append(measure_shape(wf, name, cfg, streams, steps, 8, device, flags))
+        except Exception as e:  # reported, never required
+            out.append({"name": name, "error": str(e)})
+    return out
+
+
+def pcie_inclusive(wf, cfg, streams, device, steps=40, warm=8):
+    """The headline shape with every step's audio crossing the host boundary: one 60 fps hop per stream in page-locked
+    memory -> wf_hip_push_audio_async (H2D on the copy stream under the previous tick) -> ring append -> tick."""
+    import numpy as np
+    from tools import synth
+    packet = np.ascontiguousarray(np.broadcast_to(synth.block(SEED, 0, 1, 2, 0, HOP), (streams, 2, HOP)), np.float32)
+    with wf.SpectrumBatch(cfg, streams, device=device) as b:
+        pin = [wf.PinnedBuffer(packet.shape), wf.PinnedBuffer(packet.shape)]
+        for p in pin:
+            p.array[...] = packet
+        for i in range(warm + steps):
+            if i == warm:
+                b.sync()
+                t0 = time.perf_counter()
+            slot = i & 1
+            b.ingest_done(slot)  # the buffer is free again (a live host refills it here)
+            b.push_audio_async(pin[slot], streams, HOP, slot)
+            b.tick()
+        b.sync()
+        dt = (time.perf_counter() - t0) / steps
+        for p in pin:
+            p.close()
+    return {"value": streams * 2 / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3, "host_GBps": packet.nbytes / dt / 1e9,
+            "path": "page-locked host buffer -> wf_hip_push_audio_async (H2D under the previous tick) -> ring append -> tick",
+            "bytes_per_step": int(packet.nbytes), "steps": steps}
+
+
+def self_launch(args):
+    """--gpus N without a launcher: re-execute under torch.distributed.run, one rank per GPU this box has."""
+    import torch
+    have = torch.cuda.device_count()
+    n = min(args.gpus, have)
+    if n < 1:
+        print("bench.py: no GPU visible (torch.cuda.device_count() is 0)", file=sys.stderr)
+        sys.exit(3)
+    if n < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested, {have} device(s) present: measuring {n}", file=sys.stderr)
+    if n == 1:
+        return 1  # run in this process
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    # replace the --gpus value with what is measured
+    out = []
+    skip = False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == "--gpus":
+            skip = True
+            continue
+        if a.startswith("--gpus="):
+            continue
+        out.append(a)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), "--gpus", str(n)] + out
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        args.gpus = self_launch(args)  # returns only when a single device is measured in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
-            sys.exit(2)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import waveform_amd as wf
@@ -130,12 +257,12 @@ def main():
 
     cfg = wf.Config.defaults(fft_size=args.fft, stereo=1, slope=1.0, window=wf.WINDOW["hann"],
                              tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)
+    flags = 0
     if args.bars_allgather:
         cfg.bars = 1
         cfg.interp_mode = wf.INTERP["lanczos"]
+        flags = wf.TICK_NO_DECIBELS
     total_ticks = args.warmup + args.steps
-    # audio of up to MAX_DEPTH consecutive ticks is resident; longer runs walk the same windows again (same work per step)
-    MAX_DEPTH = 512
     depth = min(total_ticks, MAX_DEPTH)
     ring_frames = args.fft + HOP * (depth + 1)
     batch = wf.SpectrumBatch(cfg, args.streams, device=local_rank, ring_frames=ring_frames)
@@ -153,26 +280,27 @@ def main():
 
     gather = None
     if args.bars_allgather:
-        from waveform_amd.dist import shard_streams, allgather_bars
-        shard = shard_streams(args.streams * world, rank, world)
-        local_bars = torch.empty((args.streams, batch.display_channels, batch.num_bars), dtype=torch.float32, device="cuda")
-
-        def gather():
-            batch.copy_bars_to_device(local_bars.data_ptr())       # D2D on the library's stream (synchronised)
-            return allgather_bars(local_bars, shard)               # one all_gather_into_tensor
+        from waveform_amd.dist import shard_streams, BarsGather
+        gather = BarsGather(batch, shard_streams(args.streams * world, rank, world))
 
     def run(n_ticks):
-        """n_ticks steps over the resident audio, oldest window first; returns the average fused-kernel duration in ms"""
+        """n_ticks steps over the resident audio, oldest window first; returns the average device time per tick in ms"""
         ms, done = 0.0, 0
         while done < n_ticks:
             n = min(depth, n_ticks - done)
             if gather is None:
                 ms += batch.time_ticks(n, HOP, HOP * (n - 1)) * n
             else:
+                # tick i, its bars handed to the gather stream (wf_hip_copy_bars_device_async), the all-gather of tick i
+                # under tick i+1; nothing here waits on the host
+                batch.time_begin()
                 for i in range(n):
-                    ms += batch.time_ticks(1, HOP, HOP * (n - 1 - i))
-                    gather()
+                    batch.tick(delay_frames=HOP * (n - 1 - i), flags=flags)
+                    gather.launch()
+                ms += batch.time_end()
             done += n
+        if gather is not None:
+            gather.wait()
         return ms / n_ticks
 
     # warm-up: W untimed steps
@@ -180,7 +308,7 @@ def main():
         run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    # K timed steps: K launches of the fused kernel, HIP events around them on the library's stream
+    # K timed steps, HIP events around them on the library's stream
     kernel_ms = run(args.steps)
     barrier()
     t1 = time.perf_counter()
@@ -196,8 +324,6 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = spectra_per_step * world * args.steps / elapsed
-        algo_bytes = batch.algorithmic_bytes_per_tick()
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "spectra/sec at FFT=4096, batch=4096 streams; achieved HBM GB/s vs peak",
             "value": value,
@@ -215,17 +341,13 @@ def main():
                 "workload": (f"BASELINE configs[{4 if args.bars_allgather else 2}]{' shape (per GPU)' if args.bars_allgather else ''}: "
                              f"{args.streams} independent stereo streams per GPU ({spectra_per_step} spectra/tick), "
                              f"FFT={args.fft}, Hann, EMA g=0.65 + slope 1.0"
-                             f"{', 26 Lanczos bars per channel all-gathered' if args.bars_allgather else ''}, "
+                             f"{', 26 Lanczos bars per channel (bars-only ticks) all-gathered under the next tick' if args.bars_allgather else ''}, "
                              f"48 kHz counter-hash white noise, hop {HOP}"),
                 "streams_per_gpu": args.streams, "fft_size": args.fft, "hop": HOP,
                 "parallelism": (f"streams sharded over {world} GPU(s); bar heights all-gathered after every step" if args.bars_allgather
                                 else f"streams sharded over {world} GPU(s), no data-path collective"),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(batch.kernel_name(), args.streams),
-                "kernel": batch.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
-            },
+            "roofline": roofline(batch, args.streams, kernel_ms, flags),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -233,9 +355,16 @@ def main():
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = None
                 print(f"bench.py: cpu_baseline failed: {e}", file=sys.stderr)
-        print(json.dumps(out), flush=True)
 
     batch.close()
+    if rank == 0 and world == 1 and not args.no_other_configs and not args.bars_allgather:
+        try:
+            out["other_configs"] = other_configs(wf, local_rank)
+            out["pcie_inclusive"] = pcie_inclusive(wf, cfg, args.streams, local_rank)
+        except Exception as e:
+            print(f"bench.py: other_configs failed: {e}", file=sys.stderr)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -203,6 +203,10 @@ int wf_hip_readback_done(wf_hip *h, uint32_t slot);
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);
+/* the same without waiting: the copy is enqueued behind the ticks issued so far and `consumer_stream` (a hipStream_t of
+ * the caller, e.g. the stream its RCCL all-gather runs on) is made to wait for it; the handle's own stream goes on with the
+ * next tick meanwhile.  The caller keeps `d_out` untouched by anything else until its consumer has run. */
+int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, void *d_out, void *consumer_stream);
 /* meter batches: m_meter_val (dBFS) of streams [first, first+count): [count][capture_channels] */
 int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* m_tsmooth_buf: [count][capture_channels][fft_size/2] */
@@ -231,6 +235,11 @@ float wf_hip_db_min(void);                            /* DB_MIN, src/source.cpp:
  * the rings: delay_frames = first_delay - i*hop) and returns the average duration of the fused
  * kernel in milliseconds, measured with hipEvents on the handle's stream. */
 int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, uint32_t hop, float *avg_kernel_ms);
+/* The same measurement around calls of the host's choosing: wf_hip_time_begin records a hipEvent on the handle's stream,
+ * wf_hip_time_end joins everything issued since (ticks on every lane, copies), records the second event, waits for it and
+ * returns the elapsed device time in milliseconds. */
+int wf_hip_time_begin(wf_hip *h);
+int wf_hip_time_end(wf_hip *h, float *elapsed_ms);
 const char *wf_hip_kernel_name(const wf_hip *h);
 /* algorithmic HBM bytes one tick moves: per spectrum 4N in + state r/w + dB out */
 uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags);

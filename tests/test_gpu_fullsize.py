@@ -25,23 +25,118 @@ def _oracle_rows(cfg, stream_ids, ticks, hop, bars=False):
     return np.stack(out), (np.stack(outb) if bars else None)
 
 
+def _oracle_ticks(cfg, stream_ids, ticks, hop, keep, bars=False):
+    """per stream the rows (and bars) after each of the last `keep` ticks: [stream][tick][...]"""
+    rows, bar_rows = [], []
+    for s in stream_ids:
+        o = restate.OracleSource(cfg)
+        r, br = [], []
+        for t in range(ticks):
+            o.feed_and_tick(synth.block(SEED, s, 1, cfg.capture_channels, t * hop, hop)[0])
+            if t >= ticks - keep:
+                r.append(o.decibels())
+                if bars:
+                    o.render_bars()
+                    br.append(o.bars())
+        rows.append(np.stack(r))
+        if bars:
+            bar_rows.append(np.stack(br))
+    return np.stack(rows), (np.stack(bar_rows) if bars else None)
+
+
 def test_cfg3_full_batch_spot_checks_and_determinism():
-    """configs[2]: 4096 stereo streams, FFT 4096, EMA + slope.  Device-generated audio (wf_synth) for every stream;
-    first/last 16 streams against the oracle; two identical batches must agree bit for bit."""
+    """configs[2]: 4096 stereo streams, FFT 4096, EMA + slope.  Device-generated audio (wf_synth) for every stream; 16 warm-up
+    ticks (the EMA settles) + 8 checked ticks, the first and last 32 streams of the batch against the oracle on every
+    checked tick; two identical batches must agree bit for bit."""
     cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0)
-    streams, ticks, hop = 4096, 5, 800
+    streams, warm, checked, hop = 4096, 16, 8, 800
+    ticks = warm + checked
+    ids = list(range(32)) + list(range(streams - 32, streams))
     res = []
     for rep in range(2):
+        got = []
         with wf.SpectrumBatch(cfg, streams, ring_frames=4096 + hop * (ticks + 1)) as b:
             b.push_synth(SEED, 0, hop * ticks)
             for t in range(ticks):
                 b.tick(delay_frames=hop * (ticks - 1 - t))
-            res.append(b.decibels())
-    assert np.array_equal(res[0], res[1]), "two identical runs differ: the kernel is not deterministic"
-    ids = list(range(16)) + list(range(streams - 16, streams))
-    want, _ = _oracle_rows(cfg, ids, ticks, hop)
-    assert_db_close(res[0][ids], want, "cfg3 full batch vs oracle (first/last 16 streams)")
-    assert np.all(np.isfinite(res[0]))
+                if t >= warm:
+                    got.append(np.concatenate([b.decibels(0, 32), b.decibels(streams - 32, 32)]))
+            full = b.decibels()
+        res.append((np.stack(got, axis=1), full))
+    assert np.array_equal(res[0][1], res[1][1]), "two identical runs differ: the kernel is not deterministic"
+    assert np.array_equal(res[0][0], res[1][0])
+    want, _ = _oracle_ticks(cfg, ids, ticks, hop, checked)
+    for k in range(checked):
+        assert_db_close(res[0][0][:, k], want[:, k], f"cfg3 full batch vs oracle, tick {warm + k} (first/last 32 streams)")
+    assert np.all(np.isfinite(res[0][1]))
+
+
+def test_cfg2_256_consecutive_frames():
+    """configs[1]: stereo, FFT 2048, Hann + magnitude + dB, no smoothing, "batch = 256 frames": 256 consecutive 60 fps frames
+    of one stereo stream.  Every frame against the oracle; and the same 256 frames as ONE batch -- stream i analyses the
+    window i hops back (per-stream A/V-sync delay) -- must give the same bits as the frame-by-frame run."""
+    cfg = wf.Config.defaults(fft_size=2048, stereo=1, tsmoothing=wf.TSMOOTH["none"])
+    frames, hop = 256, 800
+    audio = synth.block(SEED, 0, 1, 2, 0, hop * frames)[0]
+    o = restate.OracleSource(cfg)
+    seq = []
+    with wf.SpectrumBatch(cfg, 1) as b:
+        for t in range(frames):
+            blk = audio[:, t * hop:(t + 1) * hop]
+            b.push_audio(blk[None])
+            b.tick()
+            o.feed_and_tick(blk)
+            got = b.decibels()[0]
+            assert_db_close(got, o.decibels(), f"cfg2 frame {t}")
+            seq.append(got)
+    seq = np.stack(seq)
+    with wf.SpectrumBatch(cfg, frames, ring_frames=2048 + hop * (frames + 1)) as b:
+        b.push_audio(np.broadcast_to(audio[None], (frames, 2, hop * frames)))
+        b.set_stream_delay(np.array([hop * (frames - 1 - i) for i in range(frames)], np.uint32))
+        b.tick()
+        batch = b.decibels()
+    assert np.array_equal(batch, seq), "256 frames as one batch differ from the frame-by-frame run"
+
+
+def test_cfg5_per_gpu_shape_bars_only():
+    """configs[4] per GPU: 8192 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars-only ticks
+    (WF_HIP_TICK_NO_DECIBELS); 16 warm-up + 8 checked ticks, first / last 32 streams' bars against the oracle."""
+    cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    streams, warm, checked, hop = 8192, 16, 8, 800
+    ticks = warm + checked
+    ids = list(range(32)) + list(range(streams - 32, streams))
+    got = []
+    with wf.SpectrumBatch(cfg, streams, ring_frames=4096 + hop * (ticks + 1)) as b:
+        b.push_synth(SEED, 0, hop * ticks)
+        for t in range(ticks):
+            b.tick(delay_frames=hop * (ticks - 1 - t), flags=wf.TICK_NO_DECIBELS)
+            if t >= warm:
+                got.append(np.concatenate([b.bars(0, 32), b.bars(streams - 32, 32)]))
+        assert b.bars().shape == (streams, 2, 26)
+    got = np.stack(got, axis=1)
+    _, want = _oracle_ticks(cfg, ids, ticks, hop, checked, bars=True)
+    err = np.abs(got.astype(np.float64) - want)
+    assert np.all(err <= 1e-5 * np.abs(want) + 2e-3), f"cfg5 per-GPU shape bars: max err {err.max():.3e} px"
+
+
+def test_bars_gather_world1_and_self_launching_bench():
+    """The configs[4] exchange at world 1 runs the whole device path -- wf_hip_copy_bars_device_async onto a side stream, the
+    double-buffered BarsGather under the following tick -- and must hand back the bars of the tick it was launched after;
+    bench.py --gpus 8 launches itself (no torch.distributed.run wrapper) and reports the devices it measured.  Both in
+    child processes: torch brings its own HIP runtime and has to be imported before libwaveform_hip.so is loaded."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tests" / "gather_world1.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "gather ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--streams", "256",
+                        "--no-cpu-baseline", "--no-other-configs", "--bars-allgather"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert 1 <= line["n_gpus"] <= 8
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
 
 
 def test_cfg3_gain_invariance_full_batch():

@@ -6,5 +6,5 @@ implementation in here: if the library (or a gfx950 device) is missing, calls fa
 """
 from .binding import (  # noqa: F401
     Config, SpectrumBatch, PinnedBuffer, WfHipError, lib, library_path, device_count, db_min,
-    WINDOW, TSMOOTH, INTERP,
+    WINDOW, TSMOOTH, INTERP, TICK_NO_DECIBELS,
 )

@@ -108,6 +108,9 @@ def lib():
     L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
     L.wf_hip_copy_bars_device.argtypes = [vp, u32, u32, vp]
+    L.wf_hip_copy_bars_device_async.argtypes = [vp, u32, u32, vp, vp]
+    L.wf_hip_time_begin.argtypes = [vp]
+    L.wf_hip_time_end.argtypes = [vp, fp]
     L.wf_hip_read_meter.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_write_tsmooth.argtypes = [vp, u32, u32, fp]
@@ -295,6 +298,21 @@ class SpectrumBatch:
         """device-to-device copy of the bar tops into a caller-owned buffer (e.g. a torch tensor's data_ptr())"""
         count = self.streams - first if count is None else count
         self._ck(self.L.wf_hip_copy_bars_device(self.h, first, count, C.c_void_p(dev_ptr)))
+
+    def copy_bars_to_device_async(self, dev_ptr: int, consumer_stream: int, first: int = 0, count: int | None = None):
+        """the same without waiting: `consumer_stream` (a hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream) is made
+        to wait for the copy; the handle goes on with its next tick"""
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_copy_bars_device_async(self.h, first, count, C.c_void_p(dev_ptr), C.c_void_p(consumer_stream)))
+
+    def time_begin(self):
+        self._ck(self.L.wf_hip_time_begin(self.h))
+
+    def time_end(self) -> float:
+        """device milliseconds since time_begin (everything the handle issued in between, on every lane)"""
+        ms = C.c_float(0.0)
+        self._ck(self.L.wf_hip_time_end(self.h, C.byref(ms)))
+        return float(ms.value)
 
     def meter(self, first: int = 0, count: int | None = None) -> np.ndarray:
         """meter batches: m_meter_val in dBFS, [count, capture_channels]"""

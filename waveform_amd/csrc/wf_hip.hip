@@ -30,6 +30,7 @@ struct wf_hip {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_bars = nullptr;   // wf_hip_copy_bars_device_async: the copy has been made
     // Lanes: a large batch is ticked as n_lanes slices of streams, slice 0 on `stream`, the others on their own HIP streams.
     // Consecutive ticks of a slice are ordered by its stream; slices share nothing, so while no other call intervenes the
     // tail of one slice's launch overlaps the head of another's (a lone launch leaves the chip draining for a workgroup's
@@ -965,6 +966,7 @@ void wf_hip_destroy(wf_hip *h)
         if(h->ev_read[i]) (void)hipEventDestroy(h->ev_read[i]);
     }
     if(h->read_stream) (void)hipStreamDestroy(h->read_stream);
+    if(h->ev_bars) (void)hipEventDestroy(h->ev_bars);
     if(h->ev0) (void)hipEventDestroy(h->ev0);
     if(h->ev1) (void)hipEventDestroy(h->ev1);
     if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -1570,6 +1572,25 @@ int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_o
     return WF_HIP_OK;
 }
 
+int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, void *d_out, void *consumer_stream)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_bars == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
+    if(d_out == nullptr || consumer_stream == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer or consumer stream is NULL");
+    const size_t per = (size_t)h->disp_ch * h->num_bars;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->ev_bars == nullptr)
+        WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_bars, hipEventDisableTiming));
+    WF_HIP_TRY(h, hipMemcpyAsync(d_out, h->d_bars + first * per, count * per * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_bars, h->stream));
+    WF_HIP_TRY(h, hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->ev_bars, 0));
+    return WF_HIP_OK;
+}
+
 int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out)
 {
     int rc = check_range(h, first, count);
@@ -1666,6 +1687,28 @@ size_t wf_hip_table_interp_weights(const wf_hip *h, const float **out, int *radi
 }
 float wf_hip_gravity(const wf_hip *h, float seconds) { return wf::gravity_for(h->cfg, seconds); }
 float wf_hip_db_min(void) { return wf::db_min(); }
+
+int wf_hip_time_begin(wf_hip *h)
+{
+    if(h == nullptr)
+        return WF_HIP_ERR_INVALID;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_TRY_RC(join_lanes(h));
+    WF_HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    return WF_HIP_OK;
+}
+
+int wf_hip_time_end(wf_hip *h, float *elapsed_ms)
+{
+    if(h == nullptr || elapsed_ms == nullptr)
+        return WF_HIP_ERR_INVALID;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_TRY_RC(join_lanes(h));
+    WF_HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    WF_HIP_TRY(h, hipEventSynchronize(h->ev1));
+    WF_HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return WF_HIP_OK;
+}
 
 int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, uint32_t hop, float *avg_kernel_ms)
 {

@@ -57,3 +57,40 @@ def allgather_bars(local, shard: Shard, group=None):
         c = base + (1 if r < extra else 0)
         parts.append(out[r * largest:r * largest + c])
     return torch.cat(parts, dim=0)
+
+
+class BarsGather:
+    """The per-tick exchange of BASELINE configs[4], overlapped: after tick i the handle copies its bars into one of two
+    send buffers on its own stream (wf_hip_copy_bars_device_async) and goes on with tick i+1; the all-gather of tick i runs
+    on a side stream that waits only for that copy (11 us of xGMI wire time per peer against ~140 us of compute per tick,
+    SURVEY.md section 8(e)).  Nothing blocks the host: a send buffer is reused two ticks later, after an event says its gather
+    has run.  world 1: the "gather" is the local copy -- the same device path, no collective."""
+
+    def __init__(self, batch, shard: Shard, group=None):
+        import torch
+        self.batch, self.shard, self.group = batch, shard, group
+        shape = (shard.count, batch.display_channels, batch.num_bars)
+        self.send = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(2)]
+        self.result = [None, None]
+        self.done = [None, None]
+        self.side = torch.cuda.Stream()
+        self.i = 0
+
+    def launch(self):
+        import torch
+        k = self.i & 1
+        self.i += 1
+        if self.done[k] is not None:
+            self.done[k].synchronize()  # the gather that read this send buffer two ticks ago (long finished)
+        self.batch.copy_bars_to_device_async(self.send[k].data_ptr(), self.side.cuda_stream)
+        with torch.cuda.stream(self.side):
+            self.result[k] = allgather_bars(self.send[k], self.shard, self.group)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.done[k] = ev
+        return k
+
+    def wait(self):
+        """blocks until every launched gather has run; returns the newest combined bars [total, display_channels, num_bars]"""
+        self.side.synchronize()
+        return self.result[(self.i - 1) & 1] if self.i else None
