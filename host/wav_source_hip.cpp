@@ -10,7 +10,10 @@
 
 #include <dlfcn.h>
 #include <cstdlib>
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <memory>
 #include <mutex>
 
 namespace {
@@ -27,6 +30,14 @@ struct HipApi {
     decltype(&wf_hip_read_last_silent) read_last_silent = nullptr;
     decltype(&wf_hip_read_meter) read_meter = nullptr;
     decltype(&wf_hip_last_error) last_error = nullptr;
+    decltype(&wf_hip_reset) reset = nullptr;
+    decltype(&wf_hip_push_audio_ragged_async) push_audio_ragged_async = nullptr;
+    decltype(&wf_hip_ingest_done) ingest_done = nullptr;
+    decltype(&wf_hip_read_rows_async) read_rows_async = nullptr;
+    decltype(&wf_hip_readback_done) readback_done = nullptr;
+    decltype(&wf_hip_set_input_rms) set_input_rms = nullptr;
+    decltype(&wf_hip_host_alloc) host_alloc = nullptr;
+    decltype(&wf_hip_host_free) host_free = nullptr;
     bool ok = false;
 };
 
@@ -53,6 +64,14 @@ HipApi &api()
         WF_SYM(read_last_silent)
         WF_SYM(read_meter)
         WF_SYM(last_error)
+        WF_SYM(reset)
+        WF_SYM(push_audio_ragged_async)
+        WF_SYM(ingest_done)
+        WF_SYM(read_rows_async)
+        WF_SYM(readback_done)
+        WF_SYM(set_input_rms)
+        WF_SYM(host_alloc)
+        WF_SYM(host_free)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
         auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
@@ -63,7 +82,147 @@ HipApi &api()
     return a;
 }
 
+std::atomic<uint64_t> g_fallback_ticks{0};
+
+bool batched_mode()
+{
+    const char *e = std::getenv("WF_HIP_BATCHED"); // 0: every source its own handle, results inside the call
+    return e == nullptr || e[0] != '0';
+}
+
+uint32_t group_capacity()
+{
+    const char *e = std::getenv("WF_HIP_BATCH_CAPACITY");
+    const long v = e ? std::atol(e) : 64;
+    return (uint32_t)std::min<long>(std::max<long>(v, 1), 16384);
+}
+
 } // namespace
+
+// One handle shared by the sources of one configuration: sources are streams of its batch.
+//
+// A video frame, seen from the group: OBS ticks its active sources one after the other on the video thread
+// (reference callbacks::tick, src/source.cpp:481-484).  Every member's tick_spectrum
+//   1. collects: copies its row of the PREVIOUS frame's tick out of the page-locked readback buffer (one frame of latency:
+//      the copy was enqueued 16 ms ago and has long landed), and
+//   2. submits: writes the samples its window gained since its last tick into the page-locked staging block of the batch
+//      being assembled, with its show / hide / timeout state and its m_input_rms.
+// The member that completes the frame -- or one that comes round again while an incomplete batch is waiting -- flushes:
+// state masks and RMS values that changed, ONE ragged ingest (wf_hip_push_audio_ragged_async), ONE wf_hip_tick, ONE
+// readback (wf_hip_read_rows_async); members that did not show up are paused for that tick.  Nothing in a flush waits for
+// the device.
+struct WFHipGroup {
+    wf_config cfg{};
+    wf_hip *h = nullptr;
+    uint32_t capacity = 0, cap_ch = 0, out_ch = 0, N = 0, M = 0;
+    std::vector<WAVSourceHIP *> member;   // [capacity] or nullptr
+    uint32_t members = 0;
+    uint64_t batch = 1;                   // the batch being assembled (batch - 1: the last one flushed)
+    std::vector<uint64_t> submitted;      // [capacity] the batch a member last submitted to
+    uint32_t n_submitted = 0;
+    float *stage[2] = {nullptr, nullptr}; // page-locked [capacity][cap_ch][N]
+    float *rows[2] = {nullptr, nullptr};  // page-locked [capacity][out_ch][M]
+    uint8_t *silent[2] = {nullptr, nullptr};
+    bool rows_valid[2] = {false, false};
+    std::vector<uint32_t> frames;         // [capacity] frames each member staged for this batch
+    std::vector<uint8_t> state, state_dev;
+    std::vector<float> rms, rms_dev;
+    float seconds = 1.0f / 60.0f;
+    bool failed = false;
+
+    bool create(const wf_config &c)
+    {
+        auto &a = api();
+        cfg = c;
+        capacity = group_capacity();
+        if(a.create(&c, 0, capacity, 0, &h) != WF_HIP_OK) {
+            h = nullptr;
+            return false;
+        }
+        cap_ch = c.capture_channels;
+        N = c.fft_size;
+        M = c.fft_size / 2;
+        out_ch = ((cap_ch > 1) || c.stereo) ? 2u : 1u; // src/source.cpp:1171
+        member.assign(capacity, nullptr);
+        submitted.assign(capacity, 0);
+        frames.assign(capacity, 0);
+        state.assign(capacity, WF_HIP_PAUSED);
+        state_dev.assign(capacity, WF_HIP_SHOWN);
+        rms.assign(capacity, 0.0f);
+        rms_dev.assign(capacity, -1.0f);
+        for(int i = 0; i < 2; ++i) {
+            stage[i] = static_cast<float *>(a.host_alloc((size_t)capacity * cap_ch * N * sizeof(float)));
+            rows[i] = static_cast<float *>(a.host_alloc((size_t)capacity * out_ch * M * sizeof(float)));
+            silent[i] = static_cast<uint8_t *>(a.host_alloc(capacity));
+            if(stage[i] == nullptr || rows[i] == nullptr || silent[i] == nullptr)
+                return false;
+        }
+        return true;
+    }
+
+    ~WFHipGroup()
+    {
+        auto &a = api();
+        if(h)
+            a.destroy(h); // synchronises its streams first
+        for(int i = 0; i < 2; ++i) {
+            if(stage[i]) a.host_free(stage[i]);
+            if(rows[i]) a.host_free(rows[i]);
+            if(silent[i]) a.host_free(silent[i]);
+        }
+    }
+
+    // everything the frame's members staged goes to the device as one batch; returns false when the device path failed
+    bool flush()
+    {
+        auto &a = api();
+        const uint32_t b = (uint32_t)(batch & 1);
+        for(uint32_t i = 0; i < capacity; ++i)
+            if(submitted[i] != batch) { // not ticked in this frame (inactive source, free slot): left exactly as it is
+                state[i] = WF_HIP_PAUSED;
+                frames[i] = 0;
+            }
+        bool ok = true;
+        if(state != state_dev) {
+            ok = a.set_hidden(h, 0, capacity, state.data()) == WF_HIP_OK;
+            state_dev = state;
+        }
+        if(ok && cfg.normalize_volume && rms != rms_dev) {
+            ok = a.set_input_rms(h, 0, capacity, rms.data()) == WF_HIP_OK;
+            rms_dev = rms;
+        }
+        ok = ok && a.push_audio_ragged_async(h, 0, capacity, stage[b], frames.data(), N, b) == WF_HIP_OK;
+        wf_hip_tick_params p{};
+        p.seconds = seconds;
+        ok = ok && a.tick(h, &p) == WF_HIP_OK;
+        ok = ok && a.read_rows_async(h, 0, capacity, rows[b], silent[b], b) == WF_HIP_OK;
+        rows_valid[b] = ok;
+        ++batch;
+        n_submitted = 0;
+        std::fill(frames.begin(), frames.end(), 0u);
+        if(!ok) {
+            LogWarn << "HIP batch tick failed (" << a.last_error(h) << "); its sources fall back to the CPU path";
+            failed = true;
+        }
+        return ok;
+    }
+};
+
+namespace {
+
+struct Registry {
+    std::mutex mtx;
+    std::vector<std::unique_ptr<WFHipGroup>> groups;
+};
+Registry &registry()
+{
+    static Registry *r = new Registry; // never destroyed: sources an exiting host leaks must not call into an unloaded runtime
+    return *r;
+}
+
+} // namespace
+
+uint64_t WAVSourceHIP::fallback_ticks() { return g_fallback_ticks.load(); }
 
 bool WAVSourceHIP::available()
 {
@@ -82,6 +241,20 @@ void WAVSourceHIP::hip_release()
     if(m_hip != nullptr) {
         api().destroy(m_hip);
         m_hip = nullptr;
+    }
+    if(m_group != nullptr) {
+        auto &r = registry();
+        std::lock_guard lock(r.mtx);
+        auto g = m_group;
+        m_group = nullptr;
+        g->member[m_slot] = nullptr;
+        if(g->submitted[m_slot] == g->batch && g->n_submitted > 0)
+            --g->n_submitted; // what it staged for the batch in assembly is dropped with it
+        g->submitted[m_slot] = 0;
+        g->frames[m_slot] = 0;
+        g->state[m_slot] = WF_HIP_PAUSED;
+        if(--g->members == 0)
+            r.groups.erase(std::remove_if(r.groups.begin(), r.groups.end(), [g](const auto &p) { return p.get() == g; }), r.groups.end());
     }
 }
 
@@ -126,6 +299,42 @@ bool WAVSourceHIP::hip_configure()
     c.channel_spacing = m_channel_spacing;
     c.min_bar_height = m_min_bar_height;
     c.rounded_caps = m_rounded_caps ? 1u : 0u;
+    m_hip_have_prev = false;
+    if(!c.waveform && !c.meter && batched_mode()) {
+        // spectrum display: join (or open) the batch of this configuration
+        auto &r = registry();
+        std::lock_guard lock(r.mtx);
+        WFHipGroup *g = nullptr;
+        for(auto &p : r.groups)
+            if(!p->failed && p->members < p->capacity && std::memcmp(&p->cfg, &c, sizeof(c)) == 0) {
+                g = p.get();
+                break;
+            }
+        if(g == nullptr) {
+            auto fresh = std::make_unique<WFHipGroup>();
+            if(!fresh->create(c)) {
+                LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
+                return false;
+            }
+            g = fresh.get();
+            r.groups.push_back(std::move(fresh));
+        }
+        uint32_t slot = 0;
+        while(g->member[slot] != nullptr)
+            ++slot;
+        if(api().reset(g->h, slot, 1) != WF_HIP_OK) // the stream starts as update() leaves a source
+            return false;
+        g->member[slot] = this;
+        m_hip_joined = g->batch; // rows read back for earlier batches belong to whoever held the slot then
+        g->submitted[slot] = 0;
+        g->state[slot] = WF_HIP_PAUSED;
+        ++g->members;
+        m_group = g;
+        m_slot = slot;
+        m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
+        m_hip_prev.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
+        return true;
+    }
     const int rc = api().create(&c, 0, 1, 0, &m_hip);
     if(rc != WF_HIP_OK) {
         // e.g. WF_HIP_ERR_UNSUPPORTED for an FFT size outside the implemented set (powers of two 128..32768, other multiples of 16 up to 10912)
@@ -152,41 +361,147 @@ void WAVSourceHIP::update(obs_data_t *settings)
 // window of each channel goes to the device, the device runs the whole per-tick state machine (hidden/timeout reset,
 // silence detection, window, FFT, magnitude, slope, smoothing, dBFS, normalisation, roll-off) and m_decibels /
 // m_last_silent come back.
+// reference :50-59: keep dtsize bytes in every channel's ring, copy the first fft_size samples of what is left -- the
+// A/V-synchronised window -- into m_hip_window.  false: a channel holds less than that (the reference skips it).
+bool WAVSourceHIP::hip_window(size_t &dtframes)
+{
+    const auto bufsz = m_fft_size * sizeof(float);
+    const int64_t dtaudio = get_audio_sync(m_tick_ts);
+    dtframes = (dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) : 0;
+    const size_t dtsize = dtframes * sizeof(float) + bufsz;
+    for(auto channel = 0u; channel < m_capture_channels; ++channel)
+        if(m_capturebufs[channel].size() < dtsize)
+            return false;
+    for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+        m_capturebufs[channel].pop_front(nullptr, m_capturebufs[channel].size() - dtsize);
+        m_capturebufs[channel].peek_front(m_hip_window.data() + (size_t)channel * m_fft_size, bufsz);
+    }
+    return true;
+}
+
+// The batched path (struct WFHipGroup).  m_decibels / m_last_silent are the device's results for the previous video frame.
+void WAVSourceHIP::tick_spectrum_batched(float seconds)
+{
+    auto &a = api();
+    auto &r = registry();
+    std::unique_lock lock(r.mtx);
+    WFHipGroup *g = m_group;
+    const uint32_t slot = m_slot;
+    const size_t N = m_fft_size, outsz = m_fft_size / 2;
+    bool ok = !g->failed;
+    // a member that comes round again while its last hand-over is still waiting for the rest of the frame completes it
+    if(ok && g->submitted[slot] == g->batch)
+        ok = g->flush();
+    // 1. collect the row the last flushed batch left for this source
+    const uint32_t last = (uint32_t)((g->batch - 1) & 1);
+    // (whatever the stream holds after that batch: a source that sat a frame out finds the row of its last tick, unchanged)
+    if(ok && g->batch > 1 && g->rows_valid[last] && g->batch - 1 >= m_hip_joined) {
+        ok = a.readback_done(g->h, last) == WF_HIP_OK;
+        if(ok) {
+            const float *row = g->rows[last] + (size_t)slot * g->out_ch * g->M;
+            for(auto channel = 0u; channel < m_output_channels; ++channel)
+                std::memcpy(m_decibels[channel].get(), row + (size_t)channel * outsz, outsz * sizeof(float));
+            m_last_silent = g->silent[last][slot] != 0;
+        }
+    }
+    if(!ok) {
+        lock.unlock();
+        LogWarn << "HIP batch unavailable; this source continues on the CPU path";
+        hip_release();
+        g_fallback_ticks.fetch_add(1);
+        WAVSourceGeneric::tick_spectrum(seconds);
+        return;
+    }
+    // 2. submit this frame
+    const uint32_t b = (uint32_t)(g->batch & 1);
+    if(g->n_submitted == 0)
+        a.ingest_done(g->h, b); // the staging block of this slot has been copied out (two frames ago)
+    const auto dtcapture = m_tick_ts - m_capture_ts;
+    const bool timed_out = dtcapture > CAPTURE_TIMEOUT;
+    const bool hidden = !m_show || timed_out; // reference :34
+    uint32_t fresh = 0;
+    uint8_t st = hidden ? (timed_out ? WF_HIP_HIDDEN_TIMEOUT : WF_HIP_HIDDEN) : WF_HIP_SHOWN;
+    size_t dtframes = 0;
+    if(!hidden) {
+        if(!hip_window(dtframes)) {
+            st = WF_HIP_PAUSED; // underflow: the reference leaves the source as it is (:55-61)
+        } else {
+            // Which samples are new?  The device ring of this stream ends with the window handed over last time; the new
+            // window overlaps it by fft_size - shift samples.  The shift the timestamps suggest is checked against the
+            // samples themselves (and its neighbours tried: the timestamps round); if no overlap is found the whole window
+            // goes -- always correct, since the device analyses the newest fft_size samples of its ring.
+            long est = (long)N;
+            if(m_hip_have_prev) {
+                const int64_t dts = (int64_t)(m_audio_ts - m_hip_prev_audio_ts);
+                est = (long)std::llround((double)dts * (double)m_audio_info.samples_per_sec / 1e9) - ((long)dtframes - (long)m_hip_prev_sync);
+            }
+            auto overlaps = [&](long s) {
+                if(s < 0 || s > (long)N)
+                    return false;
+                for(auto channel = 0u; channel < m_capture_channels; ++channel)
+                    if(std::memcmp(m_hip_prev.data() + (size_t)channel * N + (size_t)s, m_hip_window.data() + (size_t)channel * N,
+                                   (N - (size_t)s) * sizeof(float)) != 0)
+                        return false;
+                return true;
+            };
+            long shift = (long)N;
+            if(m_hip_have_prev) {
+                for(long d : {0L, 1L, -1L, 2L, -2L})
+                    if(overlaps(est + d)) {
+                        shift = est + d;
+                        break;
+                    }
+            }
+            fresh = (uint32_t)shift;
+            float *dst = g->stage[b] + (size_t)slot * g->cap_ch * N;
+            for(auto channel = 0u; channel < m_capture_channels; ++channel)
+                std::memcpy(dst + (size_t)channel * N, m_hip_window.data() + (size_t)channel * N + (N - fresh), (size_t)fresh * sizeof(float));
+            m_hip_prev.swap(m_hip_window);
+            m_hip_have_prev = true;
+            m_hip_prev_audio_ts = m_audio_ts;
+            m_hip_prev_sync = (int64_t)dtframes;
+        }
+    }
+    g->frames[slot] = fresh;
+    g->state[slot] = st;
+    g->rms[slot] = m_input_rms;
+    g->seconds = seconds;
+    g->submitted[slot] = g->batch;
+    ++g->n_submitted;
+    // 3. the frame's last member sends the batch off
+    if(g->n_submitted >= g->members)
+        g->flush(); // (a failure shows at the members' next tick)
+}
+
 void WAVSourceHIP::tick_spectrum(float seconds)
 {
+    if(m_group != nullptr) {
+        tick_spectrum_batched(seconds);
+        return;
+    }
     if(m_hip == nullptr) {
+        g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_spectrum(seconds);
         return;
     }
     auto &a = api();
-    const auto bufsz = m_fft_size * sizeof(float);
     const auto outsz = m_fft_size / 2;
 
     const auto dtcapture = m_tick_ts - m_capture_ts;
     const bool hidden = !m_show || (dtcapture > CAPTURE_TIMEOUT); // reference :34
+    bool ok = true;
     if(hidden != m_hip_hidden) {
         const uint8_t mask = hidden ? 1 : 0;
-        a.set_hidden(m_hip, 0, 1, &mask);
+        ok = a.set_hidden(m_hip, 0, 1, &mask) == WF_HIP_OK;
         m_hip_hidden = hidden;
     }
-    if(!hidden) {
-        // reference :50-59: keep dtsize bytes, look at the first fft_size samples of what is left
-        const int64_t dtaudio = get_audio_sync(m_tick_ts);
-        const size_t dtsize = ((dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) * sizeof(float) : 0) + bufsz;
-        for(auto channel = 0u; channel < m_capture_channels; ++channel) {
-            if(m_capturebufs[channel].size() < dtsize) {
-                // underflow: the reference leaves this channel untouched; without a full window there is nothing to send
-                WAVSourceGeneric::tick_spectrum(seconds);
-                return;
-            }
-            m_capturebufs[channel].pop_front(nullptr, m_capturebufs[channel].size() - dtsize);
-            m_capturebufs[channel].peek_front(m_hip_window.data() + (size_t)channel * m_fft_size, bufsz);
-        }
+    if(ok && !hidden) {
+        size_t dtframes = 0;
+        if(!hip_window(dtframes))
+            return; // underflow: the reference leaves the source untouched (:55-61); so does this tick -- no CPU tick on
+                    // host state the device path does not maintain
         // the whole window replaces the device ring's newest fft_size samples
-        if(a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)m_fft_size) != WF_HIP_OK) {
-            WAVSourceGeneric::tick_spectrum(seconds);
-            return;
-        }
+        ok = a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)m_fft_size) == WF_HIP_OK;
     }
     wf_hip_tick_params p{};
     p.seconds = seconds;
@@ -194,10 +509,11 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     p.input_rms = m_input_rms;
     p.flags = 0;
     uint8_t silent = 0;
-    if(a.tick(m_hip, &p) != WF_HIP_OK || a.read_decibels(m_hip, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
+    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read_decibels(m_hip, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
        a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
         LogWarn << "HIP tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
         hip_release();
+        g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_spectrum(seconds);
         return;
     }
@@ -213,6 +529,7 @@ void WAVSourceHIP::tick_spectrum(float seconds)
 void WAVSourceHIP::tick_meter(float seconds)
 {
     if(m_hip == nullptr) {
+        g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_meter(seconds);
         return;
     }
@@ -252,6 +569,7 @@ void WAVSourceHIP::tick_meter(float seconds)
        a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
         LogWarn << "HIP meter tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
         hip_release();
+        g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_meter(seconds);
         return;
     }
@@ -267,6 +585,7 @@ void WAVSourceHIP::tick_meter(float seconds)
 void WAVSourceHIP::tick_waveform(float seconds)
 {
     if(m_hip == nullptr) {
+        g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_waveform(seconds);
         return;
     }
@@ -323,6 +642,7 @@ void WAVSourceHIP::tick_waveform(float seconds)
        a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
         LogWarn << "HIP waveform tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
         hip_release();
+        g_fallback_ticks.fetch_add(1);
         return; // the audio of this tick has been consumed; the CPU path takes over at the next one
     }
     for(auto channel = 0u; channel < m_output_channels; ++channel)

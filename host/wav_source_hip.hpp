@@ -25,7 +25,19 @@ protected:
     void tick_meter(float seconds) override;   // level meter: src/source_generic.cpp:182-269 on the device
     void tick_waveform(float seconds) override; // waveform display: src/source_generic.cpp:271-390 on the device
 
-    // one batch of 1 stream: a plugin that hosts several sources would share one handle per configuration
+    // Two ways to the device (see wav_source_hip.cpp):
+    //  * batched (the default for the spectrum display): sources that share a configuration share one handle, as streams of
+    //    one batch; every video frame each source hands over the audio its capture buffers gained, the frame's last source
+    //    enqueues ONE tick for all of them and every source picks up its row one frame later (m_group / m_slot);
+    //  * synchronous (WF_HIP_BATCHED=0; always for the level meter and the waveform display): a handle of one stream per
+    //    source, push -> tick -> read inside the call, zero latency (m_hip).
+    struct WFHipGroup *m_group = nullptr;
+    uint32_t m_slot = 0;
+    uint64_t m_hip_joined = 0;         // the group's batch counter when this source took its slot
+    bool m_hip_have_prev = false;      // m_hip_prev holds the window handed over at the previous tick
+    std::vector<float> m_hip_prev;     // [capture_channels][fft_size]
+    uint64_t m_hip_prev_audio_ts = 0;  // m_audio_ts / A/V-sync frames of that window: where the next one is expected to start
+    int64_t m_hip_prev_sync = 0;
     wf_hip *m_hip = nullptr;
     bool m_hip_hidden = false;
     std::vector<float> m_hip_window;   // [capture_channels][fft_size] staging for the H2D copy
@@ -44,5 +56,12 @@ public:
 
     // true when a gfx950 device and libwaveform_hip.so are available (callbacks::create asks this first)
     static bool available();
-    bool using_hip() const { return m_hip != nullptr; }
+    bool using_hip() const { return m_hip != nullptr || m_group != nullptr; }
+    // ticks a HIP-configured source had to hand to the CPU class (underflow excepted: the reference skips those too)
+    static uint64_t fallback_ticks();
+
+private:
+    void tick_spectrum_batched(float seconds);
+    bool hip_window(size_t &dtframes);  // the A/V-synchronised window of every channel -> m_hip_window; false on underflow
+    friend struct WFHipGroup;
 };

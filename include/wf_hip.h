@@ -121,6 +121,13 @@ int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *sa
 int wf_hip_push_audio_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_samples, uint32_t frames, uint32_t slot);
 /* blocks until the copy issued with `slot` (0 or 1) has left the host buffer */
 int wf_hip_ingest_done(wf_hip *h, uint32_t slot);
+/* Hops of different lengths (a plugin's sources tick with whatever their capture buffers gained): stream first+i appends
+ * frames[i] <= max_frames frames from pinned_samples[i][channel][0 .. max_frames); frames[i] == 0 leaves it alone.
+ * `frames` is copied before the call returns; `pinned_samples` follows the rules of wf_hip_push_audio_async (slot 0 / 1,
+ * wf_hip_ingest_done).  Not available while the device RMS producer is enabled. */
+int wf_hip_push_audio_ragged_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_samples, const uint32_t *frames,
+                                   uint32_t max_frames, uint32_t slot);
+
 /* page-locked host memory for wf_hip_push_audio_async (hipHostMalloc); NULL on failure */
 void *wf_hip_host_alloc(size_t bytes);
 void wf_hip_host_free(void *p);
@@ -164,6 +171,8 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
 #define WF_HIP_SHOWN 0
 #define WF_HIP_HIDDEN 1          /* !m_show */
 #define WF_HIP_HIDDEN_TIMEOUT 2  /* m_tick_ts - m_capture_ts > CAPTURE_TIMEOUT */
+#define WF_HIP_PAUSED 3          /* spectrum batches: the source was not ticked in this video frame (OBS ticks only active sources) --
+                                    the next wf_hip_tick leaves the stream exactly as it is; cleared by any other value */
 int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *mask);
 /* A/V-sync delay per stream, in frames (dtaudio > 0 of each source, src/source_generic.cpp:50-51), for batches whose
  * sources run on their own audio timestamps: stream first+i analyses the window ending delay[i] + the tick's common
@@ -200,6 +209,11 @@ int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out);
  * disturb a copy in flight. */
 int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
 int wf_hip_readback_done(wf_hip *h, uint32_t slot);
+/* Pipelined readback of what the ticks issued so far leave in m_decibels and m_last_silent of streams [first, first+count):
+ * rows [count][output_channels][fft_size/2] and one byte per stream into page-locked memory, on the readback stream;
+ * wf_hip_readback_done(slot) blocks until both have landed.  The next wf_hip_tick waits (on the device, not the host) for a
+ * copy still in flight before it overwrites the rows. */
+int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_rows, uint8_t *pinned_last_silent, uint32_t slot);
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);

@@ -233,6 +233,8 @@ int wfref_using_hip(wfref_t *h)
     return (p != nullptr && p->using_hip()) ? 1 : 0;
 }
 
+uint64_t wfref_hip_fallback_ticks(void) { return WAVSourceHIP::fallback_ticks(); }
+
 float wfref_noise(uint64_t seed, uint32_t stream, uint32_t channel, uint64_t index)
 {
     return wf_synth_noise(seed, stream, channel, index);

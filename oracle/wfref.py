@@ -51,6 +51,8 @@ def lib():
     for name in ("wfref_stereo", "wfref_last_silent", "wfref_num_bars", "wfref_using_hip"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp]
+    L.wfref_hip_fallback_ticks.restype = C.c_uint64
+    L.wfref_hip_fallback_ticks.argtypes = []
     L.wfref_meter_mode.restype = C.c_int
     L.wfref_meter_mode.argtypes = [vp]
     for name in ("wfref_meter_val", "wfref_meter_buf"):
@@ -247,6 +249,11 @@ class RefSource:
         p = C.POINTER(C.c_float)()
         n = self.L.wfref_bars(self.h, ch, C.byref(p))
         return _arr(p, n)
+
+
+def hip_fallback_ticks() -> int:
+    """ticks WAVSourceHIP handed to the reference's CPU class so far (process-wide)"""
+    return int(lib().wfref_hip_fallback_ticks())
 
 
 def db_min() -> float:

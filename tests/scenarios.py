@@ -192,6 +192,13 @@ SCENARIOS = {
     "meter_hide_show_timeout": dict(cfg=dict(meter=1, stereo=1, rounded_caps=1, channel_spacing=6, min_bar_height=3),
                                     steps=_steps(4) + [("hide",), ("noise", 800), ("tick",), ("noise", 800), ("tick",), ("show",)] + _steps(3)
                                     + [("timeout",), ("tick",), ("tick",)] + _steps(4), record="all"),
+    # spectrum with an audio sync offset: the window ends sync_ms before the newest sample (dtaudio > 0,
+    # src/source_generic.cpp:50-59, src/source.hpp:279-285); the first ticks underflow (fewer samples than window + reserve)
+    "sync_spectrum_2048": dict(cfg=dict(fft_size=2048, stereo=1, slope=1.0), sync_ms=25,
+                               steps=[("noise", 441), ("tick",)] * 6 + _steps(4) + [("timeout",), ("tick",)] + _steps(3), record="all"),
+    "sync_spectrum_4096_normalize_mono": dict(cfg=dict(fft_size=4096, stereo=0, normalize_volume=1, volume_target=-12.0, max_gain=20.0), sync_ms=10,
+                                              steps=[("noise_amp", 800, 0.05), ("tick",)] * 8 + [("hide",), ("noise", 800), ("tick",), ("show",)]
+                                              + _steps(3), record=4),
     # spectrum: capture timeout takes the same reset branch as hide (src/source_generic.cpp:34)
     "timeout_spectrum": dict(cfg=dict(fft_size=1024, stereo=1), steps=_steps(3) + [("timeout",), ("tick",), ("tick",)] + _steps(3), record="all"),
 }

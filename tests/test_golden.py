@@ -68,28 +68,147 @@ def test_hip_reproduces_reference(name):
         be.close()
 
 
-# ---- the drop-in: the reference plugin itself, with only tick_spectrum replaced by the HIP binding -----------------
-DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4096_ema_slope", "cfg4_16384_tv_lanczos_bars",
-          "mono_mix_4096_tv_fastpeaks", "rolloff_catrom_linear", "ragged_hops", "silence_cycle", "half_silent_stereo",
-          "hide_show", "muted_packets", "timeout_spectrum", "split_8192_half_silent", "small_512_stereo_bars", "small_128_single_dup_curve", "large_32768_single_tv", "any_800_mono_mix_bars", "any_4160_stereo_silence",
-          # WAVSourceHIP::tick_meter
-          "meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",
-          "meter_hide_show_timeout",
-          # WAVSourceHIP::tick_waveform
-          "wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync", "wave_normalize"]
+# ---- the drop-in: the reference plugin itself, with only the per-tick DSP virtuals replaced by the HIP binding -------------
+SPECTRUM_DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4096_ema_slope", "cfg4_16384_tv_lanczos_bars",
+                   "mono_mix_4096_tv_fastpeaks", "rolloff_catrom_linear", "ragged_hops", "silence_cycle", "half_silent_stereo",
+                   "hide_show", "muted_packets", "timeout_spectrum", "split_8192_half_silent", "small_512_stereo_bars",
+                   "small_128_single_dup_curve", "large_32768_single_tv", "any_800_mono_mix_bars", "any_4160_stereo_silence",
+                   "sync_spectrum_2048", "sync_spectrum_4096_normalize_mono", "normalize_4096_stereo", "curve_4096_lanczos_gauss"]
+DROPIN = SPECTRUM_DROPIN + [
+    # WAVSourceHIP::tick_meter
+    "meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",
+    "meter_hide_show_timeout",
+    # WAVSourceHIP::tick_waveform
+    "wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync", "wave_normalize"]
+
+
+def _hip_env(batched):
+    import os
+    from oracle import wfref
+    if not wfref.available():
+        pytest.skip("oracle/_ref/libwfref.so not built")
+    os.environ["WF_HIP_LIBRARY"] = str(Path(__file__).resolve().parent.parent / "waveform_amd" / "libwaveform_hip.so")
+    os.environ["WF_HIP_BATCHED"] = "1" if batched else "0"
+    return wfref
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", DROPIN)
 def test_reference_plugin_with_hip_tick(name):
     """oracle/_ref's WAVSource (update / capture_audio / tick / render_bars run verbatim) with WAVSourceHIP
-    (host/wav_source_hip.cpp) as the tick_spectrum / tick_meter implementation, against the same golden vectors."""
-    import os
-    from oracle import wfref
-    if not wfref.available():
-        pytest.skip("oracle/_ref/libwfref.so not built")
-    os.environ["WF_HIP_LIBRARY"] = str(Path(__file__).resolve().parent.parent / "waveform_amd" / "libwaveform_hip.so")
+    (host/wav_source_hip.cpp) as the tick_spectrum / tick_meter / tick_waveform implementation, against the same golden
+    vectors; synchronous mode (WF_HIP_BATCHED=0: one handle per source, results inside the call).  The device path must
+    still be the one in use when the scenario ends, and no tick may have been served by the CPU class."""
+    wfref = _hip_env(batched=False)
     cfg = scenarios.make_config(scenarios.SCENARIOS[name]["cfg"])
+    before = wfref.hip_fallback_ticks()
     be = scenarios.RefBackend(cfg, isa="hip")
     assert be.src.using_hip, "WAVSourceHIP fell back to the CPU path: the HIP library did not load or no gfx950 device"
     _check(name, be)
+    assert be.src.using_hip, "WAVSourceHIP released the device path during the scenario"
+    assert wfref.hip_fallback_ticks() == before, "ticks were served by the reference's CPU class"
+
+
+class _OneFrameLate:
+    """plays a scenario on a backend whose outputs lag one video frame (the batched plugin mode): every tick's record is
+    taken at the following tick; one extra tick at the end collects the last frame"""
+
+    def __init__(self, backend):
+        self.be = backend
+        self.capture_channels = backend.capture_channels
+        self.pending = False
+        self.records = []
+
+    def __getattr__(self, name):
+        return getattr(self.be, name)
+
+    def tick(self, seconds):
+        self.be.tick(seconds)
+        if self.pending:
+            self.records.append(self.be.observe())
+        self.pending = True
+
+    def observe(self):
+        return None  # records are taken one tick later, see tick()
+
+    def finish(self):
+        self.be.tick(1.0 / 60.0)
+        self.records.append(self.be.observe())
+        return self.records
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SPECTRUM_DROPIN)
+def test_reference_plugin_with_batched_hip_tick(name):
+    """The plugin mode that can win (SURVEY.md section 7 "Drop-in latency"): sources of one configuration share a batch,
+    one tick per video frame for all of them, every source reads its row ONE FRAME LATER.  The reference plugin with
+    WAVSourceHIP in batched mode reproduces every spectrum golden scenario shifted by exactly one tick."""
+    wfref = _hip_env(batched=True)
+    sc = scenarios.SCENARIOS[name]
+    cfg = scenarios.make_config(sc["cfg"])
+    z, meta = _load(name)
+    before = wfref.hip_fallback_ticks()
+    late = _OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
+    assert late.be.src.using_hip
+    scenarios.play(late, sc)
+    recs = late.finish()
+    assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before
+    assert len(recs) == meta["n_ticks"]
+    silent = np.array([r["silent"] for r in recs], np.uint8)
+    assert np.array_equal(silent, z["silent"]), f"{name}: m_last_silent sequence {silent} != reference {z['silent']} (one frame late)"
+    for t, r in scenarios.recorded(recs, sc["record"]):
+        assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels, read one frame later")
+        if f"bars_{t}" in z.files:
+            err = np.abs(r["bars"].astype(np.float64) - z[f"bars_{t}"])
+            assert np.all(err <= 1e-5 * np.abs(z[f"bars_{t}"]) + 2e-3), f"{name} tick {t} bars: max err {err.max():.3e} px"
+
+
+@pytest.mark.gpu
+def test_sixty_four_sources_share_one_batch():
+    """64 WAVSourceHIP sources of one configuration in one fake-OBS process: one handle, one tick per video frame.  Every
+    source gets its own audio, some hide or stall along the way; each one's m_decibels at frame t+1 is what the restatement
+    (pinned to the reference) has at frame t.  Then the cost: microseconds per source and frame of the batched device path
+    against the reference's own AVX2 class in the same harness, one host thread each."""
+    import os
+    from tools import synth
+    wfref = _hip_env(batched=True)
+    os.environ["WF_HIP_BATCH_CAPACITY"] = "64"
+    cfg_dict = dict(fft_size=4096, stereo=1, slope=1.0)
+    cfg = scenarios.make_config(cfg_dict)
+    n_src, frames, hop = 64, 14, 800
+    before = wfref.hip_fallback_ticks()
+    srcs = [scenarios.RefBackend(cfg, isa="hip") for _ in range(n_src)]
+    oras = [scenarios.OracleBackend(cfg) for _ in range(n_src)]
+    assert all(s.src.using_hip for s in srcs)
+    want_prev = [None] * n_src
+    for f in range(frames):
+        for i, (s, o) in enumerate(zip(srcs, oras)):
+            stalled = (i % 7 == 3) and f in (5, 6)          # no packet and no tick in these frames: the stream is paused
+            hidden = (i % 5 == 1) and 4 <= f < 8
+            if f == 4 and i % 5 == 1:
+                s.set_hidden(True), o.set_hidden(True)
+            if f == 8 and i % 5 == 1:
+                s.set_hidden(False), o.set_hidden(False)
+            if stalled:
+                continue
+            a = synth.block(scenarios.SEED, 100 + i, 1, 2, f * hop, hop)[0]
+            s.push(a, muted=False)
+            o.push(a, muted=False)
+            s.tick(1.0 / 60.0)
+            o.tick(1.0 / 60.0)
+            got = s.observe()
+            if want_prev[i] is not None:
+                assert got["silent"] == want_prev[i]["silent"], f"source {i} frame {f}"
+                assert_db_close(got["db"], want_prev[i]["db"], f"source {i} frame {f}: row of the previous frame{' (hidden)' if hidden else ''}")
+            want_prev[i] = o.observe()
+    assert all(s.src.using_hip for s in srcs) and wfref.hip_fallback_ticks() == before
+    del srcs
+    # cost per source and frame (wfref_bench: one thread ticks every source once per frame, packets through capture_audio)
+    settings = dict(fft_size=4096, enable_large_fft=True, channel_mode="stereo", slope=1.0, window="hann",
+                    temporal_smoothing="exp_moving_avg", gravity=0.65)
+    v_hip, _ = wfref.bench("hip", settings, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED)
+    v_avx, _ = wfref.bench("avx2", settings, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED)
+    us_hip, us_avx = 2e6 / v_hip, 2e6 / v_avx  # a stereo source = 2 spectra per frame
+    print(f"\nplugin mode, 64 sources x FFT 4096 stereo: batched HIP {us_hip:.1f} us per source and frame, reference AVX2 {us_avx:.1f} us")
+    assert wfref.hip_fallback_ticks() == before
+    assert us_hip < us_avx, f"the batched device path ({us_hip:.1f} us per source) does not beat the reference's AVX2 tick ({us_avx:.1f} us)"

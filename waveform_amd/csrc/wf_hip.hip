@@ -55,6 +55,12 @@ struct wf_hip {
     float *d_snap[2] = {nullptr, nullptr};
     size_t snap_floats[2] = {0, 0};
     bool read_used[2] = {false, false};
+    bool rows_in_flight[2] = {false, false}; // wf_hip_read_rows_async copies straight from m_decibels: the next tick waits for them
+    uint32_t *d_frames_async[2] = {nullptr, nullptr}; // ragged ingest: per-stream frame counts of the slot
+    uint32_t *h_frames_async[2] = {nullptr, nullptr}; // (page-locked host copy)
+    size_t frames_async_cap[2] = {0, 0};
+    uint8_t *d_silent_bytes[2] = {nullptr, nullptr};  // rows readback: m_last_silent as bytes
+    size_t silent_bytes_cap[2] = {0, 0};
     uint32_t n_streams = 0;
     uint32_t ring_cap = 0;
     uint32_t ring_stride = 0;        // floats between consecutive rings: ring_cap + padding (see wf_hip_create)
@@ -966,6 +972,8 @@ void wf_hip_destroy(wf_hip *h)
         if(h->ev_read[i]) (void)hipEventDestroy(h->ev_read[i]);
     }
     if(h->read_stream) (void)hipStreamDestroy(h->read_stream);
+    for(int i = 0; i < 2; ++i)
+        if(h->h_frames_async[i]) (void)hipHostFree(h->h_frames_async[i]);
     if(h->ev_bars) (void)hipEventDestroy(h->ev_bars);
     if(h->ev0) (void)hipEventDestroy(h->ev0);
     if(h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1142,6 +1150,76 @@ int wf_hip_push_audio_async(wf_hip *h, uint32_t first, uint32_t count, const flo
     return WF_HIP_OK;
 }
 
+int wf_hip_push_audio_ragged_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_samples, const uint32_t *frames,
+                                   uint32_t max_frames, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(pinned_samples == nullptr || frames == nullptr || slot > 1 || max_frames == 0)
+        return fail(h, WF_HIP_ERR_INVALID, "samples or frames is NULL, max_frames is 0 or slot is not 0 / 1");
+    if(h->d_rms_ring)
+        return fail(h, WF_HIP_ERR_INVALID, "ragged pushes are not available while the device RMS producer is enabled");
+    if(count > 65535u)
+        return fail(h, WF_HIP_ERR_INVALID, "at most 65535 streams per ragged push");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->copy_stream == nullptr) {
+        WF_HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for(int i = 0; i < 2; ++i) {
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_consumed[i], hipEventDisableTiming));
+        }
+    }
+    const size_t n = (size_t)count * h->cap_ch * max_frames;
+    if(h->slot_used[slot])
+        WF_HIP_TRY(h, hipEventSynchronize(h->ev_consumed[slot])); // the slot's staging (samples and counts) is free again
+    if(h->stage_async_floats[slot] < n) {
+        dev_release(h, h->d_stage_async[slot]);
+        h->d_stage_async[slot] = nullptr;
+        const size_t want = grown(h->stage_async_floats[slot], n);
+        h->stage_async_floats[slot] = 0;
+        float *p = nullptr;
+        rc = dev_alloc(h, &p, want);
+        if(rc)
+            return rc;
+        h->d_stage_async[slot] = p;
+        h->stage_async_floats[slot] = want;
+    }
+    if(h->frames_async_cap[slot] < count) {
+        dev_release(h, h->d_frames_async[slot]);
+        h->d_frames_async[slot] = nullptr;
+        if(h->h_frames_async[slot])
+            (void)hipHostFree(h->h_frames_async[slot]);
+        h->h_frames_async[slot] = nullptr;
+        h->frames_async_cap[slot] = 0;
+        const size_t want = std::max<size_t>(count, 64);
+        rc = dev_alloc(h, &h->d_frames_async[slot], want);
+        if(rc)
+            return rc;
+        WF_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_frames_async[slot]), want * sizeof(uint32_t), hipHostMallocDefault));
+        h->frames_async_cap[slot] = want;
+    }
+    bool aligned = true;
+    for(uint32_t i = 0; i < count; ++i) {
+        h->h_frames_async[slot][i] = frames[i];
+        aligned = aligned && (frames[i] % 4u) == 0;
+    }
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_stage_async[slot], pinned_samples, n * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_frames_async[slot], h->h_frames_async[slot], (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 h->copy_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_copied[slot], h->copy_stream));
+    WF_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
+    hipLaunchKernelGGL(wf::ring_push_ragged_kernel, dim3(1, count), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,
+                       h->d_flags + (size_t)h->flag_cur * h->n_streams, h->ring_cap, h->ring_stride, h->cap_ch, first, h->d_stage_async[slot],
+                       h->d_frames_async[slot], max_frames);
+    WF_HIP_TRY(h, hipGetLastError());
+    WF_HIP_TRY(h, hipEventRecord(h->ev_consumed[slot], h->stream));
+    h->slot_used[slot] = true;
+    if(!aligned)
+        h->all_aligned = false;
+    return WF_HIP_OK;
+}
+
 int wf_hip_ingest_done(wf_hip *h, uint32_t slot)
 {
     if(h == nullptr || slot > 1)
@@ -1293,6 +1371,12 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `st` dies here
         h->main_dirty = true;
     }
+    for(int i = 0; i < 2; ++i)
+        if(h->rows_in_flight[i]) { // wf_hip_read_rows_async reads m_decibels itself: this tick's stores wait for it (on the device)
+            WF_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_read[i], 0));
+            h->rows_in_flight[i] = false;
+            h->main_dirty = true;
+        }
     if(h->d_rms_ring)
         WF_TRY_RC(join_lanes(h)); // (never pending: the RMS producer keeps the batch on one lane)
     launch_input_rms(h, p);
@@ -1337,6 +1421,10 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
         return rc;
     if(mask == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "mask is NULL");
+    if(h->meter || h->wave)
+        for(uint32_t i = 0; i < count; ++i)
+            if(mask[i] == WF_HIP_PAUSED)
+                return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_PAUSED applies to spectrum batches only");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     if(h->mask_bytes < count) {
         rc = dev_alloc(h, &h->d_mask, (size_t)count);
@@ -1542,6 +1630,57 @@ int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pin
     WF_HIP_TRY(h, hipMemcpyAsync(pinned_out, h->d_snap[slot], n * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
     WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
     h->read_used[slot] = true;
+    return WF_HIP_OK;
+}
+
+// m_last_silent of streams [first, first+count) as bytes (for the D2H copy of wf_hip_read_rows_async)
+__global__ void silent_bytes_kernel(const uint32_t *flags, uint32_t first, uint32_t count, uint8_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < count)
+        out[i] = (flags[first + i] & wf::WF_STREAM_LAST_SILENT) ? 1 : 0;
+}
+
+int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_rows, uint8_t *pinned_last_silent, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "meter batch: there is no m_decibels");
+    if(pinned_rows == nullptr || pinned_last_silent == nullptr || slot > 1)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL or slot is not 0 / 1");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->read_stream == nullptr) {
+        WF_HIP_TRY(h, hipStreamCreateWithFlags(&h->read_stream, hipStreamNonBlocking));
+        for(int i = 0; i < 2; ++i) {
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_snap[i], hipEventDisableTiming));
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_read[i], hipEventDisableTiming));
+        }
+    }
+    if(h->read_used[slot])
+        WF_HIP_TRY(h, hipEventSynchronize(h->ev_read[slot])); // the slot's previous copy has landed
+    if(h->silent_bytes_cap[slot] < count) {
+        dev_release(h, h->d_silent_bytes[slot]);
+        h->d_silent_bytes[slot] = nullptr;
+        h->silent_bytes_cap[slot] = 0;
+        const size_t want = std::max<size_t>(count, 256);
+        rc = dev_alloc(h, &h->d_silent_bytes[slot], want);
+        if(rc)
+            return rc;
+        h->silent_bytes_cap[slot] = want;
+    }
+    hipLaunchKernelGGL(silent_bytes_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_flags + (size_t)h->flag_cur * h->n_streams,
+                       first, count, h->d_silent_bytes[slot]);
+    WF_HIP_TRY(h, hipGetLastError());
+    WF_HIP_TRY(h, hipEventRecord(h->ev_snap[slot], h->stream));
+    WF_HIP_TRY(h, hipStreamWaitEvent(h->read_stream, h->ev_snap[slot], 0));
+    const size_t per = (size_t)h->out_ch * h->M;
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_rows, h->d_decibels + first * per, count * per * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_last_silent, h->d_silent_bytes[slot], count, hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
+    h->read_used[slot] = true;
+    h->rows_in_flight[slot] = true;
     return WF_HIP_OK;
 }
 

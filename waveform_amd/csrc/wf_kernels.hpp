@@ -172,8 +172,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     float *rows = a.decibels + (size_t)stream * a.out_ch * MO; // m_decibels[0..out_ch) of this stream
     const bool row_thread = DEC == 0 || t < RG::T;             // this thread owns bins of the output row
 
-    const bool hidden = (sflags & WF_STREAM_HIDDEN) != 0;
-    const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
+    // a paused stream (its source was not ticked this frame) walks through like a hidden one that is already silent: the
+    // reference returns at once for those (:36-37) -- nothing is read, reset or written; its flags word is kept as it is
+    const bool paused = (sflags & WF_STREAM_PAUSED) != 0;
+    const bool hidden = (sflags & (WF_STREAM_HIDDEN | WF_STREAM_PAUSED)) != 0;
+    const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0 || paused;
 
     WF_STAMP(0);
     WF_STAMP_HWID();
@@ -437,7 +440,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(10);
     if(active && ch == 0 && t == 0)
         (SPLIT ? a.flags_out : a.stream_flags)[stream] =
-            (sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u);
+            paused ? sflags
+                   : ((sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u));
     if(!SPLIT && (WF_TRACK && a.bars_only != nullptr) && active) {
         // bars-only handles: what the next tick's silence test would find in the row this spectrum owns (see TickArgs)
         bool exceeds = false, write = true;
@@ -513,6 +517,30 @@ __global__ void ring_push_kernel(float *ring, const uint32_t *wpos, uint32_t rin
         dst[(w + i) & (ring_cap - 1)] = src ? src[(size_t)row * frames + i] : 0.0f;
 }
 
+// the same with a frame count per stream (sources of a plugin batch hand over hops of different lengths): src is
+// [count*cap_ch][max_frames], frames[count]; every stream's write position advances by its own count
+__global__ void ring_push_ragged_kernel(float *ring, uint32_t *wpos, uint32_t *flags, uint32_t ring_cap, uint32_t ring_stride, uint32_t cap_ch,
+                                        uint32_t first, const float *src, const uint32_t *frames, uint32_t max_frames)
+{
+    const uint32_t s = blockIdx.y; // stream - first
+    const uint32_t stream = first + s;
+    const uint32_t n = frames[s] < max_frames ? frames[s] : max_frames;
+    const uint32_t w = wpos[stream];
+    const uint32_t skip = n > ring_cap ? n - ring_cap : 0u;
+    for(uint32_t c = 0; c < cap_ch; ++c) {
+        float *dst = ring + ((size_t)stream * cap_ch + c) * ring_stride;
+        const float *from = src + ((size_t)s * cap_ch + c) * max_frames;
+        for(uint32_t i = skip + threadIdx.x; i < n; i += blockDim.x)
+            dst[(w + i) & (ring_cap - 1)] = from[i];
+    }
+    __syncthreads(); // every thread has read the old position
+    if(threadIdx.x == 0 && n > 0) {
+        wpos[stream] = w + n;
+        if(w + n < w)
+            flags[stream] |= WF_STREAM_WRAPPED;
+    }
+}
+
 __global__ void ring_synth_kernel(float *ring, const uint32_t *wpos, uint32_t ring_cap, uint32_t ring_stride, uint32_t cap_ch, uint32_t first,
                                   uint64_t seed, uint32_t stream_id0, uint64_t index0, uint32_t frames)
 {
@@ -543,9 +571,10 @@ __global__ void set_hidden_kernel(uint32_t *flags, uint32_t first, uint32_t coun
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < count) {
-        const uint32_t f = flags[first + i] & ~(WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT);
+        const uint32_t f = flags[first + i] & ~(WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_PAUSED);
         const uint32_t m = mask[i];
-        flags[first + i] = f | (m ? WF_STREAM_HIDDEN : 0u) | (m == WF_HIP_HIDDEN_TIMEOUT ? WF_STREAM_TIMEOUT : 0u);
+        flags[first + i] = m == WF_HIP_PAUSED ? (f | WF_STREAM_PAUSED)
+                                              : (f | (m ? WF_STREAM_HIDDEN : 0u) | (m == WF_HIP_HIDDEN_TIMEOUT ? WF_STREAM_TIMEOUT : 0u));
     }
 }
 

@@ -38,6 +38,7 @@ enum : uint32_t {
     WF_STREAM_LAST_SILENT = 1u << 0, // m_last_silent
     WF_STREAM_HIDDEN = 1u << 1,      // !m_show or capture timed out (host sets it)
     WF_STREAM_TIMEOUT = 1u << 2,     // set with HIDDEN when the cause is the capture timeout: tick_meter treats the two differently
+    WF_STREAM_PAUSED = 1u << 4,      // the host did not tick this source in this video frame (WF_HIP_PAUSED): the stream is left exactly as it is
     WF_STREAM_WRAPPED = 1u << 3,     // wpos has wrapped past 2^32 since the last reset: "fewer samples than the A/V-sync delay yet" is over for good
 };
 
