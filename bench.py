@@ -105,28 +105,32 @@ def host_cores() -> int:
     return n
 
 
-def pmc_traffic(kernel: str, streams: int):
-    """HBM bytes per tick from committed rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
+def pmc_traffic(shape: str):
+    """HBM bytes per tick from the latest committed rocprofv3 PMC pass of this shape (profiles/rNN*_<shape>_pmc.json), or None."""
     best = None
-    for p in sorted((ROOT / "profiles").glob("*_pmc.json")):
+    for p in sorted((ROOT / "profiles").glob(f"r*_{shape}_pmc.json")):
         try:
             d = json.loads(p.read_text())
         except Exception:
             continue
-        if d.get("kernel") == kernel and d.get("streams") == streams and d.get("hbm_bytes_per_launch"):
-            best = d["hbm_bytes_per_launch"]
+        if d.get("hbm_bytes_per_launch"):
+            best = d.get("hbm_bytes_per_tick") or d["hbm_bytes_per_launch"]
     return best
 
 
-def roofline(batch, streams, kernel_ms, flags=0):
+def roofline(batch, shape, kernel_ms, flags=0):
     algo = batch.algorithmic_bytes_per_tick(flags)
     achieved = algo / (kernel_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic(batch.kernel_name(), streams), "kernel": batch.kernel_name(), "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": algo}
+            "traffic": pmc_traffic(shape) if shape else None, "kernel": batch.kernel_name(), "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": algo,
+            # "launch" = one wf_hip_tick: the batch goes out as this many concurrent launches of the kernel (lanes on their
+            # own HIP streams), timed together by the events; rocprofv3's per-launch average covers one slice sharing the
+            # chip with the others -- profiles/*_pmc.json carries the per-tick span taken from the same trace
+            "kernel_launches_per_tick": batch.launches_per_tick()}
 
 
-def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0):
+def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0, shape=None):
     """One of the other shapes: `steps` back-to-back ticks over resident audio; wall clock and device events."""
     depth = min(steps + warmup, 64)
     with wf.SpectrumBatch(cfg, streams, device=device, ring_frames=cfg.fft_size + HOP * (depth + 1)) as b:
@@ -144,28 +148,32 @@ def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0):
         spectra = streams * b.capture_channels
         return {"name": name, "streams": streams, "fft_size": int(cfg.fft_size), "spectra_per_tick": spectra, "steps": steps,
                 "value": spectra * steps / wall, "unit": "spectra/s", "ms_per_step": wall * 1e3 / steps,
-                "roofline": roofline(b, streams, ms / steps, flags)}
+                "roofline": roofline(b, shape, ms / steps, flags)}
+
+
+def shape_list(wf):
+    ema = dict(stereo=1, slope=1.0, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)
+    shapes = [
+        ("configs[2] x2: 8192 stereo streams, FFT 4096, EMA + slope (536 MB working set, past the 256 MB Infinity Cache)",
+         wf.Config.defaults(fft_size=4096, **ema), 8192, 60, 0, "cfg3_8192streams"),
+        ("configs[2] x4: 16384 stereo streams, FFT 4096, EMA + slope (1.07 GB working set)",
+         wf.Config.defaults(fft_size=4096, **ema), 16384, 40, 0, "cfg3_16384streams"),
+        ("configs[3]: 1024 stereo streams, FFT 16384, TV-EMA (gravity) + 26 Lanczos bars per channel",
+         wf.Config.defaults(fft_size=16384, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["tvexponential"], gravity=0.65,
+                            bars=1, interp_mode=wf.INTERP["lanczos"]), 1024, 60, 0, "cfg4_n16384_bars"),
+        ("configs[1] as a batch: 256 stereo streams, FFT 2048, Hann + magnitude + dB, no smoothing",
+         wf.Config.defaults(fft_size=2048, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["none"]), 256, 60, 0, "cfg2_batch"),
+        ("configs[4] per-GPU shape: 8192 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars only (no m_decibels store)",
+         wf.Config.defaults(fft_size=4096, bars=1, interp_mode=wf.INTERP["lanczos"], **ema), 8192, 60, wf.TICK_NO_DECIBELS, "cfg5shape_8192streams_barsonly"),
+    ]
+    return shapes
 
 
 def other_configs(wf, device):
     out = []
-    ema = dict(stereo=1, slope=1.0, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)
-    shapes = [
-        ("configs[2] x2: 8192 stereo streams, FFT 4096, EMA + slope (536 MB working set, past the 256 MB Infinity Cache)",
-         wf.Config.defaults(fft_size=4096, **ema), 8192, 60, 0),
-        ("configs[2] x4: 16384 stereo streams, FFT 4096, EMA + slope (1.07 GB working set)",
-         wf.Config.defaults(fft_size=4096, **ema), 16384, 40, 0),
-        ("configs[3]: 1024 stereo streams, FFT 16384, TV-EMA (gravity) + 26 Lanczos bars per channel",
-         wf.Config.defaults(fft_size=16384, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["tvexponential"], gravity=0.65,
-                            bars=1, interp_mode=wf.INTERP["lanczos"]), 1024, 60, 0),
-        ("configs[1] as a batch: 256 stereo streams, FFT 2048, Hann + magnitude + dB, no smoothing",
-         wf.Config.defaults(fft_size=2048, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["none"]), 256, 60, 0),
-        ("configs[4] per-GPU shape: 8192 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars only (no m_decibels store)",
-         wf.Config.defaults(fft_size=4096, bars=1, interp_mode=wf.INTERP["lanczos"], **ema), 8192, 60, wf.TICK_NO_DECIBELS),
-    ]
-    for name, cfg, streams, steps, flags in shapes:
+    for name, cfg, streams, steps, flags, shape in shape_list(wf):
         try:
-            out.append(measure_shape(wf, name, cfg, streams, steps, 8, device, flags))
+            out.append(measure_shape(wf, name, cfg, streams, steps, 8, device, flags, shape))
         except Exception as e:  # reported, never required
             out.append({"name": name, "error": str(e)})
     return out
@@ -347,7 +355,7 @@ def main():
                 "parallelism": (f"streams sharded over {world} GPU(s); bar heights all-gathered after every step" if args.bars_allgather
                                 else f"streams sharded over {world} GPU(s), no data-path collective"),
             },
-            "roofline": roofline(batch, args.streams, kernel_ms, flags),
+            "roofline": roofline(batch, "cfg3_n4096" if (args.streams, args.fft, flags) == (STREAMS_PER_GPU, FFT_SIZE, 0) else None, kernel_ms, flags),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -255,6 +255,9 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
 int wf_hip_time_begin(wf_hip *h);
 int wf_hip_time_end(wf_hip *h, float *elapsed_ms);
 const char *wf_hip_kernel_name(const wf_hip *h);
+/* launches of the fused kernel one wf_hip_tick issues (lanes: slices of the batch on their own HIP streams, running
+ * concurrently; a profiler's per-launch average is then not the time a tick takes) */
+uint32_t wf_hip_launches_per_tick(const wf_hip *h);
 /* algorithmic HBM bytes one tick moves: per spectrum 4N in + state r/w + dB out */
 uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags);
 

@@ -1,0 +1,21 @@
+#!/bin/bash
+# tools/gpu_round.sh -- one gpurun call that gathers a round's evidence: GPU tests, bench line, rocprofv3 passes.
+#   usage (from the repo root on the GPU box): bash tools/gpu_round.sh TAG [tests|notests]
+set -u
+TAG=${1:-r02a}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+if [ "${2:-tests}" = "tests" ]; then
+  ( time timeout 1800 python -m pytest tests -m gpu -x -q --durations=15 -n ${WF_XDIST:-0} ) > $O/gputests_$TAG.log 2>&1
+  tail -4 $O/gputests_$TAG.log
+fi
+( time python bench.py ) > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+tail -c 600 $O/bench_$TAG.json | head -c 600; echo
+# headline shape: full counter set; the other shapes: durations + HBM bytes
+bash tools/profile_gpu.sh ${TAG}_cfg3 30 > /dev/null 2>&1
+WF_PMC_SET=short bash tools/profile_gpu.sh ${TAG}_cfg3_16384streams 20 "--streams 16384" > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 2 30" bash tools/profile_gpu.sh ${TAG}_cfg4 > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 4 30" bash tools/profile_gpu.sh ${TAG}_cfg5shape > /dev/null 2>&1
+ls $O/prof

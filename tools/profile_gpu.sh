@@ -11,8 +11,15 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-CMD=${WF_PROFILE_CMD:-"python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline $EXTRA"}   # WF_PROFILE_CMD: profile another driver (e.g. tools/meter_bench.py)
+CMD=${WF_PROFILE_CMD:-"python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-other-configs $EXTRA"}   # WF_PROFILE_CMD: profile another driver (e.g. tools/meter_bench.py)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
+if [ "${WF_PMC_SET:-full}" = "short" ]; then   # HBM bytes only
+for PMC in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc_$PMC -o pmc -- $CMD > $OUT/pmc_$PMC.log 2>&1
+done
+find $OUT -name "*.csv" | head -40
+exit 0
+fi
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT"; do

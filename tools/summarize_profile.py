@@ -28,6 +28,22 @@ def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None,
     for r in csv.DictReader(open(src / "stats" / "stats_kernel_stats.csv")):
         if match in r["Name"]:
             stats = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    # launches of one tick may overlap (lanes: wf_hip_tick issues the batch as slices on several HIP streams), so the
+    # per-launch average above is not the time a tick takes: the trace gives that as the steady-state span per tick
+    trace = {}
+    tr = src / "stats" / "stats_kernel_trace.csv"
+    if tr.exists():
+        rows = [r for r in csv.DictReader(open(tr)) if match in r["Kernel_Name"]]
+        lanes = len({r["Stream_Id"] for r in rows}) or 1
+        ticks = len(rows) // lanes
+        skip = min(3, ticks // 4) * lanes            # warm-up launches
+        if ticks > 1:
+            body = rows[skip:]
+            span = max(int(r["End_Timestamp"]) for r in body) - min(int(r["Start_Timestamp"]) for r in body)
+            trace = {"launches": len(rows), "launches_per_tick": lanes, "ticks_in_span": len(body) // lanes,
+                     "tick_span_ns": span / (len(body) // lanes),
+                     "note": "launches of a tick run concurrently on %d HIP stream(s); tick_span_ns = (last end - first start) / ticks "
+                             "over the steady-state launches, profiler attached" % lanes}
     fetch_b = tot.get("FETCH_SIZE", 0) * 1024 * 2
     write_b = tot.get("WRITE_SIZE", 0) * 1024
     cyc = tot.get("GRBM_GUI_ACTIVE", 0) / 8
@@ -35,9 +51,10 @@ def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None,
         "tag": tag, "command": command or "python bench.py --steps 30 --warmup 3 --no-cpu-baseline (tools/profile_gpu.sh)",
         "kernel_rocprof_name": kname, "streams": streams, "fft_size": fft,
         "kernel": kernel or (f"spectrum_tick_kernel<N={fft},T=128,R=8x16x16,SPW=2>" if fft == 4096 else None),
-        "kernel_stats": stats, "dispatch": res,
+        "kernel_stats": stats, "trace": trace, "dispatch": res,
         "hbm_bytes_per_launch": fetch_b + write_b,
         "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
+        "hbm_bytes_per_tick": (fetch_b + write_b) * (trace.get("launches_per_tick", 1) if trace else 1),
         "correction": "FETCH_SIZE (KiB) x2 per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE (KiB) as reported",
         "counters_mean_per_launch": tot,
         "derived": {
@@ -50,7 +67,7 @@ def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None,
         },
     }
     (dst / f"{name}_pmc.json").write_text(json.dumps(out, indent=1))
-    print(json.dumps({k: out[k] for k in ("kernel_stats", "hbm_bytes_per_launch", "derived")}, indent=1))
+    print(json.dumps({k: out[k] for k in ("kernel_stats", "trace", "hbm_bytes_per_launch", "hbm_bytes_per_tick", "derived")}, indent=1))
 
 
 if __name__ == "__main__":

@@ -135,6 +135,8 @@ def lib():
     L.wf_hip_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, fp]
     L.wf_hip_kernel_name.restype = C.c_char_p
     L.wf_hip_kernel_name.argtypes = [vp]
+    L.wf_hip_launches_per_tick.restype = u32
+    L.wf_hip_launches_per_tick.argtypes = [vp]
     L.wf_hip_algorithmic_bytes_per_tick.restype = u64
     L.wf_hip_algorithmic_bytes_per_tick.argtypes = [vp, u32]
     _LIB = L
@@ -370,6 +372,9 @@ class SpectrumBatch:
 
     def kernel_name(self) -> str:
         return self.L.wf_hip_kernel_name(self.h).decode()
+
+    def launches_per_tick(self) -> int:
+        return int(self.L.wf_hip_launches_per_tick(self.h))
 
     def algorithmic_bytes_per_tick(self, flags: int = 0) -> int:
         return int(self.L.wf_hip_algorithmic_bytes_per_tick(self.h, flags))

@@ -1888,6 +1888,15 @@ extern "C" int wf_hip_debug_phase_clock(wf_hip *h, unsigned long long *out, size
 
 const char *wf_hip_kernel_name(const wf_hip *h) { return h ? h->kernel_name.c_str() : ""; }
 
+uint32_t wf_hip_launches_per_tick(const wf_hip *h)
+{
+    if(h == nullptr)
+        return 0;
+    if(h->wave || h->meter)
+        return 1;
+    return (uint32_t)(h->d_rms_ring ? 1 : h->n_lanes) * (h->split_mono ? 2u : 1u);
+}
+
 uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags)
 {
     if(h == nullptr)
