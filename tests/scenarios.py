@@ -76,6 +76,16 @@ SCENARIOS = {
                                      steps=_steps(3), record=1),
     "curve_1024_point_linear_gauss": dict(cfg=dict(fft_size=1024, stereo=1, capture_channels=1, curve=1, interp_mode=0, log_scale=0,
                                                    filter_mode=1, filter_radius=4.0, channel_spacing=8), steps=_steps(3), record=1),
+    # the plugin's default configuration (src/source.cpp:119-174): mono mixdown of two channels, 800-point Catmull-Rom curve
+    "plugin_defaults_4096": dict(cfg=dict(fft_size=4096, stereo=0, curve=1, interp_mode=2), steps=_steps(5), record=2),
+    # curves wider than a thread's registers hold (more than 8 points per thread at two wavefronts): points streamed; with the
+    # Gaussian filter they are staged behind the row
+    "curve_4096_catrom_wide_gauss": dict(cfg=dict(fft_size=4096, stereo=1, slope=1.0, curve=1, interp_mode=2, width=1900, filter_mode=1,
+                                                  filter_radius=1.5), steps=_steps(4), record=1),
+    "curve_2048_lanczos_wide_mirror": dict(cfg=dict(fft_size=2048, stereo=1, curve=1, interp_mode=1, width=2560, mirror_freq_axis=1),
+                                           steps=_steps(3), record=1),
+    "curve_1024_catrom_3840_linear": dict(cfg=dict(fft_size=1024, stereo=0, capture_channels=1, curve=1, interp_mode=2, width=3840, log_scale=0),
+                                          steps=_steps(3), record=1),
     "bars_gauss_4096": dict(cfg=dict(fft_size=4096, stereo=1, bars=1, interp_mode=1, filter_mode=1, filter_radius=0.8), steps=_steps(4), record=1),
     # ragged packets: 441-frame hops (window start not 16-byte aligned), then a 1024 packet
     "ragged_hops": dict(cfg=dict(fft_size=2048, stereo=1),

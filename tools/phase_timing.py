@@ -9,6 +9,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 streams = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 hop, ticks = 800, 6
 extra = dict(bars=1, interp_mode=1) if os.environ.get("WF_BENCH_BARS") else {}
+if os.environ.get("WF_BENCH_CURVE"):
+    extra = dict(curve=1, interp_mode=int(os.environ["WF_BENCH_CURVE"]))
 cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=1.0, **extra)
 b = wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * (ticks + 2))
 b.push_synth(synth.DEFAULT_SEED, 0, hop * (ticks + 1))
@@ -33,6 +35,8 @@ for i, nm in enumerate(names):
     print(f"{nm:18s} mean {d[:, i].mean():9.1f}  ({100 * d[:, i].mean() / tot.mean():5.1f} %)   p90 {np.percentile(d[:, i], 90):9.1f}")
 
 print("after stamp 10 (flags store, bars if any) until the end of the kernel: mean %.0f ticks" % (s[:, 13] - s[:, 10]).mean())
+if os.environ.get("WF_BENCH_CURVE"):
+    print("curve: row->LDS+syncs %.0f | points + mapping + stores %.0f" % ((s[:, 12] - s[:, 10]).mean(), (s[:, 13] - s[:, 12]).mean()))
 if os.environ.get("WF_BENCH_BARS"):
     print("bars: row->LDS+syncs %.0f | A products+sync %.0f | B1 segment sums+sync %.0f | B2 bar sums+stores %.0f" %
           ((s[:, 12] - s[:, 10]).mean(), (s[:, 14] - s[:, 12]).mean(), (s[:, 15] - s[:, 14]).mean(), (s[:, 13] - s[:, 15]).mean()))

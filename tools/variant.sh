@@ -1,0 +1,8 @@
+#!/bin/bash
+# tools/variant.sh NAME "EXTRA FLAGS" -- a development build of the library into variants/lib_NAME.so (travels with gpurun,
+# git-ignored); select it with WF_HIP_LIB=variants/lib_NAME.so.  e.g. tools/variant.sh t4096 "-DWF_GEOM_ONLY=4096 -DWF_PHASE_TIMING"
+set -e
+NAME=$1; shift
+cd "$(dirname "$0")/../waveform_amd/csrc"
+mkdir -p ../../variants
+make -s BUILD=../../build/variant_$NAME OUT=../../variants/lib_$NAME.so EXTRA="$*"

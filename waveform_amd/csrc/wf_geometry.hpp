@@ -20,14 +20,21 @@ using G32768 = Geom<32768, 1024, 16, 32, 32>; // sixteen wavefronts = one workgr
 // calls f(G{}) for the geometry of fft_size n; returns false for unsupported sizes
 template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)
 {
+    // -DWF_GEOM_ONLY=<N>: development builds that instantiate one geometry (a full build compiles ~70 kernels)
+#ifdef WF_GEOM_ONLY
+#define WF_GEOM_CASE(N_, G_) case N_: if constexpr(N_ == WF_GEOM_ONLY) { f(G_{}); return true; } else return false;
+#else
+#define WF_GEOM_CASE(N_, G_) case N_: f(G_{}); return true;
+#endif
     switch(n) {
-    case 1024: f(G1024{}); return true;
-    case 2048: f(G2048{}); return true;
-    case 4096: f(G4096{}); return true;
-    case 8192: f(G8192{}); return true;
-    case 16384: f(G16384{}); return true;
-    case 32768: f(G32768{}); return true;
+    WF_GEOM_CASE(1024, G1024)
+    WF_GEOM_CASE(2048, G2048)
+    WF_GEOM_CASE(4096, G4096)
+    WF_GEOM_CASE(8192, G8192)
+    WF_GEOM_CASE(16384, G16384)
+    WF_GEOM_CASE(32768, G32768)
     default: return false;
     }
+#undef WF_GEOM_CASE
 }
 } // namespace wf

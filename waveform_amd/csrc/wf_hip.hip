@@ -118,6 +118,9 @@ struct wf_hip {
     float *d_meter_buf = nullptr;    // [n_streams * cap_ch] m_meter_buf
     float *d_meter_val = nullptr;    // [n_streams * cap_ch] m_meter_val
     bool curve = false;              // the outputs are curve points (render_curve), not bars
+    bool curve_catrom = false;       // ... Catmull-Rom: positions only, weights on the device (BarArgs::cur_x)
+    bool stream_steps = false;       // ... more points per thread than OutVals holds (BarArgs::stream_steps)
+    float *d_cur_x = nullptr;
     int out_steps = 0;               // outputs finished per thread (curve: ceil(width / T); bars in segment form: 1)
     float *d_cur_coef = nullptr, *d_gauss = nullptr, *d_gauss_wsum = nullptr;
     int *d_cur_base = nullptr;
@@ -375,7 +378,9 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.lane_blocks = h->bar_blocks;
         a.bar.cur_coef = h->d_cur_coef;
         a.bar.cur_base = h->d_cur_base;
-        a.bar.curve = h->curve ? 1 : 0;
+        a.bar.cur_x = h->d_cur_x;
+        a.bar.curve = h->curve ? (h->curve_catrom ? 2 : 1) : 0;
+        a.bar.stream_steps = h->stream_steps ? 1 : 0;
         a.bar.out_steps = h->out_steps;
         a.bar.gauss = h->d_gauss;
         a.bar.gauss_wsum = h->d_gauss_wsum;
@@ -390,6 +395,8 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.border_bottom = h->tab.border_bottom;
         a.bar.ceiling = (float)h->cfg.ceiling_db;
         a.bar.dbrange = (float)(h->cfg.ceiling_db - h->cfg.floor_db);
+        a.bar.inv_dbrange = 1.0f / a.bar.dbrange;
+        a.bar.lerp_mixed = ((a.bar.border_top <= 0 && a.bar.border_bottom >= 0) || (a.bar.border_top >= 0 && a.bar.border_bottom <= 0)) ? 1 : 0;
         a.bar.disp_ch = h->disp_ch;
     }
     a.half_coef = 0.5f * (2.0f / h->tab.window_sum); // mag_coefficient (reference src/source_generic.cpp:110), halved: the
@@ -788,14 +795,14 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         if(h->curve) {
             // one curve point per thread and step; the filter stages the row's points in the spectrum's LDS
             wf::CurveLaneTables cl;
-            if(!wf::curve_lanes(h->tab, *cfg, threads, kmax, cl)) {
-                return bail(fail(h, WF_HIP_ERR_UNSUPPORTED,
-                                 "curve display: width %u needs more than %d points per thread at fft_size %u (limit: width <= %d)",
-                                 cfg->width, kmax, h->N, kmax * threads));
-            }
+            if(!wf::curve_lanes(h->tab, *cfg, threads, kmax, cl))
+                return bail(fail(h, WF_HIP_ERR_INVALID, "curve display: no point table for width %u at fft_size %u", cfg->width, h->N));
             h->out_steps = cl.steps;
+            h->curve_catrom = !cl.x.empty();
+            h->stream_steps = cl.steps > kmax; // wider than a thread's registers hold: points are finished as they are produced
             WF_CREATE_TRY(upload(h, &h->d_cur_coef, cl.coef));
             WF_CREATE_TRY(upload(h, &h->d_cur_base, cl.base));
+            WF_CREATE_TRY(upload(h, &h->d_cur_x, cl.x));
             WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
         } else {
             wf::BarLaneTables lanes;
@@ -814,7 +821,15 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         if(h->tab.gauss_radius > 0) {
             // staged in the spectrum's LDS: the row with radius-1 zeros on either side, then the weights
             const size_t staged = (size_t)h->num_bars + 2 * (size_t)(h->tab.gauss_radius - 1) + h->tab.gauss.size();
-            if(h->out_steps == 0) {
+            if(h->stream_steps) {
+                // wide curve: the points are staged behind the dB row (and the two guard zeros of the Catmull-Rom taps)
+                if(h->M + 2 + staged > lds_floats) {
+                    return bail(fail(h, WF_HIP_ERR_UNSUPPORTED,
+                                     "filter_mode gauss: %u curve points + the filter's staging do not fit behind the row in this configuration's on-chip buffer (%zu floats)",
+                                     h->num_bars, lds_floats));
+                }
+                h->bar_stage_off = (int)h->M + 2;
+            } else if(h->out_steps == 0) {
                 // bars in chunked form (more bars than threads): the staging area sits at the end of the buffer, the product
                 // scratch shrinks by it and must still hold the longest bar
                 int longest = 0;
@@ -858,6 +873,11 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
         h->waves_per_spectrum = G::T / 64;
         // the channels of a stream share a workgroup (silence state machine, mono mixdown)
+#ifdef WF_GEOM_ONLY // development builds: no Bluestein instantiations
+        if(h->blu) {
+            setup_rc = fail(h, WF_HIP_ERR_UNSUPPORTED, "development build without the Bluestein kernels");
+        } else
+#endif
         if(h->blu) {
             if constexpr(G::N >= 32768) {
                 if(want_split)

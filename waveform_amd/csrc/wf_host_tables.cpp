@@ -399,10 +399,20 @@ bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max
     if(n <= 0 || M < 8)
         return false;
     const int steps = (n + threads - 1) / threads;
-    if(steps > max_steps)
-        return false;
+    (void)max_steps; // more steps than a thread's registers hold: the kernel streams the points (BarArgs::stream_steps)
     out.steps = steps;
     const int padded = (steps + 3) / 4 * 4; // the kernel takes the steps four at a time
+    if(cfg.interp_mode == WF_INTERP_CATROM) {
+        // positions only; init_interp clamps them to [lowbin, highbin] within [1, M - 1], which the device relies on
+        out.x.assign((size_t)padded * threads, 1.0f);
+        for(int o = 0; o < n; ++o) {
+            const float x = t.interp_indices[(size_t)o];
+            if(!(x >= 1.0f && x <= (float)(M - 1)))
+                return false;
+            out.x[(size_t)o] = x;
+        }
+        return true;
+    }
     out.coef.assign((size_t)padded * threads * 8, 0.0f);
     out.base.assign((size_t)padded * threads, 0);
     for(int o = 0; o < n; ++o) {

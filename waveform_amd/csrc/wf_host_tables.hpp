@@ -74,8 +74,9 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
 // base[o] with coefficients coef[o][0..8) (its composite kernel shifted/zero-padded to 8 taps inside [0, M)); tables are
 // padded to whole steps with zero coefficients.
 struct CurveLaneTables {
-    std::vector<float> coef; // [steps rounded up to 4][threads][8]
+    std::vector<float> coef; // [steps rounded up to 4][threads][8]  (empty when `x` is used)
     std::vector<int> base;   // [steps rounded up to 4][threads]
+    std::vector<float> x;    // [steps rounded up to 4][threads] Catmull-Rom: the points' positions (weights evaluated on the device)
     int steps = 0;
 };
 bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max_steps, CurveLaneTables &out);

@@ -67,6 +67,12 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_TRACK
 #define WF_TRACK 1
 #endif
+#ifndef WF_DEFER_ROWS
+#define WF_DEFER_ROWS 0 // (curve display: row stores after the points, so that the points' table loads do not queue behind them: measured +-0)
+#endif
+#ifndef WF_NT_ROWS
+#define WF_NT_ROWS true // m_decibels rows stored with the non-temporal hint
+#endif
 #ifndef WF_WPS_SMALL
 #define WF_WPS_SMALL 5 // 8-point geometry (N = 1024): 5 waves per SIMD measured +4 % over 4; 6 spills
 #endif
@@ -419,6 +425,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
+    const bool defer_rows = WF_DEFER_ROWS && a.bar.out != nullptr && a.bar.curve != 0;
     float d[RP];
     bool row_exceeds = false; // bars-only handles: this thread's part of the row has a value > floor - 10
     if(have_row && row_thread) {
@@ -431,10 +438,12 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             for(int i = 0; i < RP; ++i)
                 row_exceeds = row_exceeds || ((!BLU || 4 * (t + RG::T * (i / 4)) < NB) && d[i] > a.silent_floor);
         }
-        if(!a.skip_decibels) {
-            store_row<RG, BLU>(rows + (size_t)ch * MO, t, d, NB);
+        // (curve display: the row goes out after the points -- their table loads would otherwise wait for these stores to be
+        // acknowledged, vector-memory operations complete in order)
+        if(!a.skip_decibels && !defer_rows) {
+            store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
             if(dup_row)
-                store_row<RG, BLU>(rows + (size_t)MO, t, d, NB);
+                store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
         }
     }
     WF_STAMP(10);
@@ -479,6 +488,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         spectrum_sync<G>(); // every thread of the spectrum is done reading its exchange buffer
         if(have_row && row_thread)
             store_row<RG, BLU>(dbl, t, d, NB);
+        if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)
+            dbl[MO] = dbl[MO + 1] = 0.0f;
         spectrum_sync<G>();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
         float *out1 = dup_row ? out0 + a.bar.num_bars : nullptr;
@@ -491,7 +502,12 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 #endif
         OutVals<G> ov;
         bool pending = true;
-        if(a.bar.curve)
+        if(a.bar.stream_steps) {
+            curve_row_stream<G>(bar_args, have_row, dbl, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
+            pending = false;
+        } else if(a.bar.curve == 2)
+            curve_row_catrom<G>(bar_args, have_row, dbl, t, ov);
+        else if(a.bar.curve)
             curve_row<G>(bar_args, have_row, dbl, t, ov);
         else
             pending = bars_reduce_row<G>(
@@ -499,6 +515,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
                 [](float v, int m) { return v + __shfl_xor(v, m, 64); });
         if(pending)
             outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
+        if(defer_rows && have_row && row_thread && !a.skip_decibels) {
+            store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
+            if(dup_row)
+                store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
+        }
     }
     WF_STAMP(13);
 }

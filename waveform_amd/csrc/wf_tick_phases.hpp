@@ -70,8 +70,14 @@ struct BarArgs {
     // Lanczos / Catmull-Rom taps of that point, clipped to [0, M) as kernel_convolve does; POINT mode: one tap).
     const float *cur_coef;     // [out_steps][T][8]
     const int *cur_base;       // [out_steps][T]
-    int curve;                 // 1: curve tables above; 0: bar tables
+    // Catmull-Rom curve (the plugin's default interpolation, reference src/source.cpp:141): the four weights of a point are
+    // a cubic in u = x - floor(x) (make_catrom_kernel, src/filter.hpp:67-104), so the table is the point's position alone --
+    // 4 bytes per point instead of 36 -- and the weights are evaluated on the fly in the reference's own operation order.
+    const float *cur_x;        // [out_steps rounded up to 4][T] m_interp_indices, lane-major; padding entries hold 1.0f
+    int curve;                 // 2: Catmull-Rom curve from cur_x; 1: curve tables above; 0: bar tables
     int out_steps;             // ceil(num_bars / T) when the outputs are finished one per thread and step, else 0
+    int stream_steps;          // != 0: more steps than a thread's registers hold (wide curves): points are finished as they
+                               // are produced -- mapped and stored at once, or staged behind the dB row for the filter
     // Gaussian filter across the outputs before the dB -> pixel mapping (apply_filter / weighted_avg,
     // reference src/filter.hpp:133-157,171-180; kernel make_gauss_kernel :40-65); gauss_radius == 0: off
     const float *gauss;        // [2 * gauss_radius - 1]
@@ -89,6 +95,8 @@ struct BarArgs {
     int mirror;
     float border_top, border_bottom;
     float ceiling, dbrange;    // m_ceiling, m_ceiling - m_floor
+    float inv_dbrange;         // 1 / dbrange
+    int lerp_mixed;            // border_top and border_bottom have opposite signs or one is 0: std::lerp's first form
     uint32_t disp_ch;
 };
 
@@ -171,9 +179,32 @@ struct TickArgs {
 WF_DEV f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 WF_DEV f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
 WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
-// Stream-sized data (audio window, smoothing state, dB rows) goes through the same plain global loads/stores as the
-// tables.  Measured and dropped: non-temporal loads/stores and sc1/nt buffer loads (slower or no change -- consecutive
-// ticks' windows overlap by 80 % and the state is re-read every tick, both served by the 256 MB Infinity Cache).
+// Streaming accesses.  Measured on MI355X (cfg3, interleaved A/B on one box): the m_decibels rows -- output nothing on the
+// device reads again -- stored with the non-temporal hint +1.8 % (they stop displacing rings and state from the 256 MB
+// Infinity Cache); the same hint on the state stores +-0, on the window loads -2 % (consecutive ticks' windows overlap by
+// 80 %: those lines are wanted in the cache).  WF_NT_STATE / WF_NT_SMP keep the two rejected variants buildable.
+#ifndef WF_NT_STATE
+#define WF_NT_STATE 0
+#endif
+#ifndef WF_NT_SMP
+#define WF_NT_SMP 0
+#endif
+#if defined(__HIPCC__)
+WF_DEV f4 ld4_nt(const float *p)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return f4{v.x, v.y, v.z, v.w};
+}
+WF_DEV void st4_nt(float *p, f4 v)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(p));
+}
+#else // the g++ wavefront emulator (tests/emu): plain accesses
+WF_DEV f4 ld4_nt(const float *p) { return ld4(p); }
+WF_DEV void st4_nt(float *p, f4 v) { st4(p, v); }
+#endif
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
 // WF_LDS_TRACE is defined only by the g++ wavefront emulator in tests/emu to record
@@ -339,7 +370,7 @@ WF_DEV bool p1_fetch(const TickArgs &a, int t, const float *x, uint32_t start, P
             }
         } else if(ALIGNED) {
             if(B1 == 2) {
-                const f4 q = ld4(x + ((start + s0) & a.ring_mask));
+                const f4 q = WF_NT_SMP ? ld4_nt(x + ((start + s0) & a.ring_mask)) : ld4(x + ((start + s0) & a.ring_mask));
                 r.smp[j][0] = q.x; r.smp[j][1] = q.y; r.smp[j][2 * B1 - 2] = q.z; r.smp[j][2 * B1 - 1] = q.w;
             } else {
                 const f2 q = ld2(x + ((start + s0) & a.ring_mask));
@@ -814,7 +845,10 @@ WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, co
             // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
             mag[4 * u + i] = fmaf(a.g, old, a.g2 * mag[4 * u + i]);
         }
-        st4(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+        if(WF_NT_STATE)
+            st4_nt(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+        else
+            st4(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
     }
 }
 
@@ -1020,13 +1054,17 @@ WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)
     }
 }
 
-template<class G, bool GUARD = false> WF_DEV void store_row(float *row, int t, const float (&d)[G::P], int nb = 0)
+template<class G, bool GUARD = false, bool NT = false> WF_DEV void store_row(float *row, int t, const float (&d)[G::P], int nb = 0)
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u)
-        if(!GUARD || 4 * (t + T * u) < nb)
-            st4(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
+        if(!GUARD || 4 * (t + T * u) < nb) {
+            if constexpr(NT)
+                st4_nt(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
+            else
+                st4(row + 4 * (t + T * u), f4{d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]});
+        }
 }
 // ---- silence state machine helpers (reference :63-95, :138-139) ------------------------------------
 // "outsilent": every value of the previously displayed row is <= floor - 10.  Each thread looks at the
@@ -1179,17 +1217,33 @@ template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEnt
     }
 }
 
-// mean dB of output o -> pixel row (reference src/source.cpp:1548-1557 bars, :1411 curve), incl. the mirrored image
-// (:1559-1564, :1419-1424): outputs above the middle repeat the lower ones
-WF_DEV void emit_output(const BarArgs &b, int o, float v, float *out_row, float *dup_row)
+// mean dB of output o -> pixel row (reference src/source.cpp:1548-1557 bars, :1411 curve):
+// y = lerp(border_top, border_bottom, clamp(ceiling - v, 0, range) / range).  Straight-line code: the quotient is
+// tt * (1 / range) corrected by one residual step (q + fma(-q, range, tt) * inv: the correctly rounded quotient but for
+// rare last-bit ties), and std::lerp's case distinction on the signs of its end points is a property of the configuration
+// (BarArgs::lerp_mixed) -- testing it per output cost a dozen scalar branches per point.
+WF_DEV float map_output(const BarArgs &b, float v)
 {
     float tt = b.ceiling - v; // reference src/source.cpp:1550
-    tt = (tt < 0.0f) ? 0.0f : (b.dbrange < tt) ? b.dbrange : tt;
-    const float y = lerp_std(b.border_top, b.border_bottom, tt / b.dbrange);
+    tt = fminf(fmaxf(tt, 0.0f), b.dbrange);
+    float q = tt * b.inv_dbrange;
+    q = fmaf(fmaf(-q, b.dbrange, tt), b.inv_dbrange, q);
+    if(b.lerp_mixed) // border_top <= 0 <= border_bottom (or the reverse): t * b + (1 - t) * a
+        return q * b.border_bottom + (1.0f - q) * b.border_top;
+    return lerp_std(b.border_top, b.border_bottom, q);
+}
+// stores incl. the mirrored image (:1559-1564, :1419-1424): outputs above the middle repeat the lower ones
+WF_DEV void store_output(const BarArgs &b, int o, float y, float *out_row, float *dup_row)
+{
+    if(!b.mirror) {
+        out_row[o] = y;
+        if(dup_row) dup_row[o] = y;
+        return;
+    }
     const int half = b.num_bars / 2;
     const int img = 2 * half - o;
-    const bool own = !b.mirror || o <= half;
-    const bool image = b.mirror && o < half && img > half && img < b.num_bars;
+    const bool own = o <= half;
+    const bool image = o < half && img > half && img < b.num_bars;
     if(own) {
         out_row[o] = y;
         if(dup_row) dup_row[o] = y;
@@ -1198,6 +1252,10 @@ WF_DEV void emit_output(const BarArgs &b, int o, float v, float *out_row, float 
         out_row[img] = y;
         if(dup_row) dup_row[img] = y;
     }
+}
+WF_DEV void emit_output(const BarArgs &b, int o, float v, float *out_row, float *dup_row)
+{
+    store_output(b, o, map_output(b, v), out_row, dup_row);
 }
 
 // the outputs (bars or curve points) thread t finishes: o = t + T*k, k < out_steps <= KMAX
@@ -1240,6 +1298,116 @@ template<class G> WF_DEV void curve_row(const BarArgs &b, bool has_row, const fl
                 sum = fmaf(p[6], c1[j].z, sum);
                 sum = fmaf(p[7], c1[j].w, sum);
                 ov.v[4 * g + j] = sum;
+            }
+        }
+    }
+}
+
+// make_catrom_kernel's weights for u = x - floor(x), tension 0.5, evaluated as the reference does: sum += row[k] * matrix[j][k]
+// over row = {1, u, u*u, u*u*u}, separately rounded products and sums (the zero matrix entries add exact zeros)
+struct CatromW { float w0, w1, w2, w3; };
+WF_DEV CatromW catrom_weights(float u)
+{
+#pragma clang fp contract(off) // every product and sum rounded on its own, as the reference's table was computed
+    const float u2 = u * u, u3 = u2 * u;
+    CatromW c;
+    c.w0 = ((u * -0.5f) + u2) + (u3 * -0.5f);          // {0, -t, 2t, -t}
+    c.w1 = (1.0f + (u2 * -2.5f)) + (u3 * 1.5f);        // {1, 0, t-3, 2-t}
+    c.w2 = ((u * 0.5f) + (u2 * 2.0f)) + (u3 * -1.5f);  // {0, t, 3-2t, t-2}
+    c.w3 = (u2 * -0.5f) + (u3 * 0.5f);                 // {0, 0, -t, t}
+    return c;
+}
+// one Catmull-Rom point: kernel_convolve (reference src/filter.hpp:160-169) over taps floor(x) - 1 .. floor(x) + 2.  The
+// positions lie in [1, M - 1] (init_interp clamps them to [lowbin, highbin]), so only the taps at M and M + 1 can fall
+// outside the row: the caller parks two zeros there (a dropped tap adds an exact 0).
+WF_DEV float catrom_point(const float *db, float x)
+{
+#pragma clang fp contract(off)
+    const float fl = __builtin_floorf(x);
+    const CatromW c = catrom_weights(x - fl);
+    const float *p = db + ((int)fl - 1);
+    float sum = p[0] * c.w0;
+    sum = sum + (p[1] * c.w1);
+    sum = sum + (p[2] * c.w2);
+    sum = sum + (p[3] * c.w3);
+    return sum;
+}
+template<class G> WF_DEV void curve_row_catrom(const BarArgs &b, bool has_row, const float *db, int t, OutVals<G> &ov)
+{
+    constexpr int T = G::T, K = OutVals<G>::KMAX;
+    WF_UNROLL
+    for(int k = 0; k < K; ++k)
+        ov.v[k] = 0.0f;
+    // (requesting the positions before the dB math, as the bars' entries are, measured 8 % slower: the loads queue ahead
+    // of the row stores)
+    WF_UNROLL
+    for(int g = 0; g < K / 4; ++g) {
+        if(4 * g < b.out_steps && has_row) { // the first condition is uniform
+            float x[4];
+            WF_UNROLL
+            for(int j = 0; j < 4; ++j)
+                x[j] = b.cur_x[(4 * g + j) * T + t];
+            WF_UNROLL
+            for(int j = 0; j < 4; ++j)
+                ov.v[4 * g + j] = catrom_point(db, x[j]);
+        }
+    }
+}
+
+// Curves wider than KMAX points per thread: a run-time loop over the steps; every point is mapped and stored as soon as it
+// is produced, or -- with the Gaussian filter on -- staged behind the dB row ([pad | points | pad | weights] from
+// db + stage_off, sized on the host) and filtered in a second loop.
+template<class G, class Sync>
+WF_DEV void curve_row_stream(const BarArgs &b, bool has_row, const float *db, float *lds, int t, float *out_row, float *dup_row, Sync sync)
+{
+    constexpr int T = G::T;
+    const int n = b.num_bars;
+    const bool filtered = b.gauss_radius > 0;
+    const int pad = b.gauss_radius - 1, size = 2 * b.gauss_radius - 1;
+    float *vp = lds + b.stage_off;
+    float *wl = vp + n + 2 * pad;
+    if(filtered && has_row) {
+        for(int i = t; i < pad; i += T) {
+            vp[i] = 0.0f;
+            vp[pad + n + i] = 0.0f;
+        }
+        for(int i = t; i < size; i += T)
+            wl[i] = b.gauss[i];
+    }
+    if(has_row) {
+        for(int k = 0; k < b.out_steps; ++k) {
+            const int o = k * T + t;
+            float v;
+            if(b.curve == 2) {
+                v = catrom_point(db, b.cur_x[o]);
+            } else {
+                const f4 c0 = ld4(b.cur_coef + 8 * o), c1 = ld4(b.cur_coef + 8 * o + 4);
+                const float *p = db + b.cur_base[o];
+                v = p[0] * c0.x;
+                v = fmaf(p[1], c0.y, v);
+                v = fmaf(p[2], c0.z, v);
+                v = fmaf(p[3], c0.w, v);
+                v = fmaf(p[4], c1.x, v);
+                v = fmaf(p[5], c1.y, v);
+                v = fmaf(p[6], c1.z, v);
+                v = fmaf(p[7], c1.w, v);
+            }
+            if(o < n) {
+                if(filtered)
+                    vp[pad + o] = v;
+                else
+                    emit_output(b, o, v, out_row, dup_row);
+            }
+        }
+    }
+    if(filtered) {
+        sync();
+        if(has_row) {
+            for(int o = t; o < n; o += T) {
+                float sum = 0.0f;
+                for(int tap = 0; tap < size; ++tap)
+                    sum = fmaf(vp[o + tap], wl[tap], sum);
+                emit_output(b, o, sum / b.gauss_wsum[o], out_row, dup_row);
             }
         }
     }
@@ -1307,10 +1475,14 @@ WF_DEV void outputs_finish(const BarArgs &b, bool has_row, OutVals<G> &ov, float
         }
     }
     if(has_row) {
+        float y[K];
+        WF_UNROLL
+        for(int k = 0; k < K; ++k)
+            y[k] = map_output(b, ov.v[k]); // all of them, branch-free; the ones past the row are not stored
         WF_UNROLL
         for(int k = 0; k < K; ++k)
             if(k < b.out_steps && k * T + t < n)
-                emit_output(b, k * T + t, ov.v[k], out_row, dup_row);
+                store_output(b, k * T + t, y[k], out_row, dup_row);
     }
 }
 
