@@ -38,6 +38,9 @@ struct HipApi {
     decltype(&wf_hip_set_input_rms) set_input_rms = nullptr;
     decltype(&wf_hip_host_alloc) host_alloc = nullptr;
     decltype(&wf_hip_host_free) host_free = nullptr;
+    decltype(&wf_hip_enable_input_rms_feed) enable_input_rms_feed = nullptr;
+    decltype(&wf_hip_push_rms_ragged_async) push_rms_ragged_async = nullptr;
+    decltype(&wf_hip_read_input_rms_async) read_input_rms_async = nullptr;
     bool ok = false;
 };
 
@@ -72,6 +75,9 @@ HipApi &api()
         WF_SYM(set_input_rms)
         WF_SYM(host_alloc)
         WF_SYM(host_free)
+        WF_SYM(enable_input_rms_feed)
+        WF_SYM(push_rms_ragged_async)
+        WF_SYM(read_input_rms_async)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
         auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
@@ -83,6 +89,7 @@ HipApi &api()
 }
 
 std::atomic<uint64_t> g_fallback_ticks{0};
+std::atomic<uint64_t> g_host_rms_updates{0}; // update_input_rms calls that ran the reference's host loop
 
 bool batched_mode()
 {
@@ -127,6 +134,13 @@ struct WFHipGroup {
     std::vector<uint32_t> frames;         // [capacity] frames each member staged for this batch
     std::vector<uint8_t> state, state_dev;
     std::vector<float> rms, rms_dev;
+    // volume normalisation produced on the device (WAVSourceHIP::update_input_rms): the squared peaks every member's
+    // sync_rms_buffer consumed this frame, page-locked [capacity][sq_max] per ingest slot, and m_input_rms coming back
+    bool rms_feed = false;
+    uint32_t sq_max = 0;
+    float *sq_stage[2] = {nullptr, nullptr};
+    float *rms_back[2] = {nullptr, nullptr};
+    std::vector<uint32_t> sq_frames;      // [capacity] values staged for the batch being assembled
     float seconds = 1.0f / 60.0f;
     bool failed = false;
 
@@ -150,6 +164,17 @@ struct WFHipGroup {
         state_dev.assign(capacity, WF_HIP_SHOWN);
         rms.assign(capacity, 0.0f);
         rms_dev.assign(capacity, -1.0f);
+        sq_frames.assign(capacity, 0);
+        if(c.normalize_volume && std::getenv("WF_HIP_HOST_RMS") == nullptr && a.enable_input_rms_feed(h) == WF_HIP_OK) {
+            rms_feed = true;
+            sq_max = c.sample_rate & ~15u; // m_input_rms_size: more than a window's worth per frame is never needed
+            for(int i = 0; i < 2; ++i) {
+                sq_stage[i] = static_cast<float *>(a.host_alloc((size_t)capacity * sq_max * sizeof(float)));
+                rms_back[i] = static_cast<float *>(a.host_alloc((size_t)capacity * sizeof(float)));
+                if(sq_stage[i] == nullptr || rms_back[i] == nullptr)
+                    return false;
+            }
+        }
         for(int i = 0; i < 2; ++i) {
             stage[i] = static_cast<float *>(a.host_alloc((size_t)capacity * cap_ch * N * sizeof(float)));
             rows[i] = static_cast<float *>(a.host_alloc((size_t)capacity * out_ch * M * sizeof(float)));
@@ -169,6 +194,8 @@ struct WFHipGroup {
             if(stage[i]) a.host_free(stage[i]);
             if(rows[i]) a.host_free(rows[i]);
             if(silent[i]) a.host_free(silent[i]);
+            if(sq_stage[i]) a.host_free(sq_stage[i]);
+            if(rms_back[i]) a.host_free(rms_back[i]);
         }
     }
 
@@ -187,7 +214,10 @@ struct WFHipGroup {
             ok = a.set_hidden(h, 0, capacity, state.data()) == WF_HIP_OK;
             state_dev = state;
         }
-        if(ok && cfg.normalize_volume && rms != rms_dev) {
+        if(ok && rms_feed) {
+            ok = a.push_rms_ragged_async(h, 0, capacity, sq_stage[b], sq_frames.data(), sq_max, b) == WF_HIP_OK;
+            std::fill(sq_frames.begin(), sq_frames.end(), 0u);
+        } else if(ok && cfg.normalize_volume && rms != rms_dev) {
             ok = a.set_input_rms(h, 0, capacity, rms.data()) == WF_HIP_OK;
             rms_dev = rms;
         }
@@ -196,6 +226,8 @@ struct WFHipGroup {
         p.seconds = seconds;
         ok = ok && a.tick(h, &p) == WF_HIP_OK;
         ok = ok && a.read_rows_async(h, 0, capacity, rows[b], silent[b], b) == WF_HIP_OK;
+        if(ok && rms_feed)
+            ok = a.read_input_rms_async(h, 0, capacity, rms_back[b], b) == WF_HIP_OK;
         rows_valid[b] = ok;
         ++batch;
         n_submitted = 0;
@@ -223,6 +255,7 @@ Registry &registry()
 } // namespace
 
 uint64_t WAVSourceHIP::fallback_ticks() { return g_fallback_ticks.load(); }
+uint64_t WAVSourceHIP::host_rms_updates() { return g_host_rms_updates.load(); }
 
 bool WAVSourceHIP::available()
 {
@@ -252,6 +285,7 @@ void WAVSourceHIP::hip_release()
             --g->n_submitted; // what it staged for the batch in assembly is dropped with it
         g->submitted[m_slot] = 0;
         g->frames[m_slot] = 0;
+        g->sq_frames[m_slot] = 0;
         g->state[m_slot] = WF_HIP_PAUSED;
         if(--g->members == 0)
             r.groups.erase(std::remove_if(r.groups.begin(), r.groups.end(), [g](const auto &p) { return p.get() == g; }), r.groups.end());
@@ -402,6 +436,8 @@ void WAVSourceHIP::tick_spectrum_batched(float seconds)
             for(auto channel = 0u; channel < m_output_channels; ++channel)
                 std::memcpy(m_decibels[channel].get(), row + (size_t)channel * outsz, outsz * sizeof(float));
             m_last_silent = g->silent[last][slot] != 0;
+            if(g->rms_feed)
+                m_input_rms = g->rms_back[last][slot]; // as of that batch's tick (for observers; the device uses its own)
         }
     }
     if(!ok) {
@@ -471,6 +507,45 @@ void WAVSourceHIP::tick_spectrum_batched(float seconds)
     // 3. the frame's last member sends the batch off
     if(g->n_submitted >= g->members)
         g->flush(); // (a failure shows at the members' next tick)
+}
+
+// WAVSourceGeneric::update_input_rms (src/source_generic.cpp:392-403) = sync_rms_buffer (src/source.cpp:810-835: everything
+// in m_rms_sync_buf older than the A/V-sync point moves into the circular one-second m_input_rms_buf) + the sum of its
+// m_input_rms_size squares.  Batched mode: the values sync_rms_buffer would move are staged for the device instead, which
+// keeps the window and its (two-level) sum per stream; no 48000-float loop per source and frame on the host.  Called by
+// WAVSource::tick (src/source.cpp:1330-1331) ahead of tick_spectrum, under m_mtx.
+void WAVSourceHIP::update_input_rms()
+{
+    WFHipGroup *g = m_group;
+    if(g == nullptr || !g->rms_feed) {
+        g_host_rms_updates.fetch_add(1);
+        WAVSourceGeneric::update_input_rms();
+        return;
+    }
+    auto &r = registry();
+    std::lock_guard lock(r.mtx);
+    if(g->failed)
+        return; // this source leaves the group at its tick_spectrum and continues on the host
+    // a member that comes round again while its last hand-over is still waiting for the rest of the frame completes it
+    if(g->submitted[m_slot] == g->batch)
+        g->flush();
+    const int64_t dtaudio = get_audio_sync(m_tick_ts);
+    const size_t dtsize = (dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) * sizeof(float) : 0;
+    if(m_rms_sync_buf.size() <= dtsize)
+        return; // sync_rms_buffer returns false: m_input_rms stays
+    const uint32_t b = (uint32_t)(g->batch & 1);
+    if(g->n_submitted == 0 && std::all_of(g->sq_frames.begin(), g->sq_frames.end(), [](uint32_t v) { return v == 0; }))
+        api().ingest_done(g->h, b); // first writer of this frame: the slot's staging has been copied out (two frames ago)
+    size_t consume = (m_rms_sync_buf.size() - dtsize) / sizeof(float);
+    const size_t room = g->sq_max - g->sq_frames[m_slot];
+    if(consume > room) {
+        // more than a window's worth since the last hand-over: only the newest values can still be inside the window
+        m_rms_sync_buf.pop_front(nullptr, (consume - room) * sizeof(float));
+        consume = room;
+    }
+    float *dst = g->sq_stage[b] + (size_t)m_slot * g->sq_max + g->sq_frames[m_slot];
+    m_rms_sync_buf.pop_front(dst, consume * sizeof(float));
+    g->sq_frames[m_slot] += (uint32_t)consume;
 }
 
 void WAVSourceHIP::tick_spectrum(float seconds)

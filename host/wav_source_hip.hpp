@@ -8,7 +8,8 @@
  * end to end: the reference's update() / capture_audio() / tick() / render() run verbatim and only the
  * per-tick DSP virtual is replaced.
  *
- * Interfaces replaced: WAVSource::tick_waveform(float) (src/source.hpp:277; WAVSourceGeneric src/source_generic.cpp:271-390),
+ * Interfaces replaced: WAVSource::update_input_rms() (src/source.hpp:273; WAVSourceGeneric src/source_generic.cpp:392-403),
+ * WAVSource::tick_waveform(float) (src/source.hpp:277; WAVSourceGeneric src/source_generic.cpp:271-390),
  * WAVSource::tick_meter(float) (src/source.hpp:276; WAVSourceGeneric src/source_generic.cpp:182-269,
  * WAVSourceAVX src/source_avx.cpp:202-322) and WAVSource::tick_spectrum(float) (pure virtual, src/source.hpp:275), implemented in the
  * reference by WAVSourceGeneric (src/source_generic.cpp:26-180), WAVSourceAVX (src/source_avx.cpp:29-200) and
@@ -21,6 +22,10 @@
 class WAVSourceHIP : public WAVSourceGeneric
 {
 protected:
+    // update_input_rms (src/source.hpp:273; WAVSourceGeneric src/source_generic.cpp:392-403): in batched mode with volume
+    // normalisation the squared peaks sync_rms_buffer would consume go to the device, which keeps the one-second window
+    // and its sum per stream (wf_hip_enable_input_rms_feed); otherwise the reference's host loop runs
+    void update_input_rms() override;
     void tick_spectrum(float seconds) override;
     void tick_meter(float seconds) override;   // level meter: src/source_generic.cpp:182-269 on the device
     void tick_waveform(float seconds) override; // waveform display: src/source_generic.cpp:271-390 on the device
@@ -59,6 +64,8 @@ public:
     bool using_hip() const { return m_hip != nullptr || m_group != nullptr; }
     // ticks a HIP-configured source had to hand to the CPU class (underflow excepted: the reference skips those too)
     static uint64_t fallback_ticks();
+    // update_input_rms calls served by the reference's host loop (0 for batched sources: the device keeps the RMS window)
+    static uint64_t host_rms_updates();
 
 private:
     void tick_spectrum_batched(float seconds);

@@ -193,6 +193,22 @@ int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float 
  * wf_hip_set_input_rms fails.  Needs cfg.normalize_volume (spectrum or waveform batches).  Audio pushed before the call
  * counts as silence. */
 int wf_hip_enable_input_rms(wf_hip *h);
+/* The same producer for hosts that already hold capture_audio's per-frame squared peaks -- the plugin binding: the
+ * reference's own capture_audio fills m_rms_sync_buf (src/source.cpp:1842-1871, from the packet even when it is muted),
+ * and WAVSourceHIP::update_input_rms (the override of src/source.hpp:273, src/source_generic.cpp:392-403) hands what
+ * sync_rms_buffer would move into m_input_rms_buf this tick (src/source.cpp:810-835) to
+ * wf_hip_push_rms_ragged_async instead of adding up 48000 floats per source and frame on the host.  The squared-peak
+ * ring is then independent of the audio rings' positions; wf_hip_tick recomputes every stream's m_input_rms as above.
+ * Mutually exclusive with wf_hip_enable_input_rms. */
+int wf_hip_enable_input_rms_feed(wf_hip *h);
+/* sq: page-locked [count][max_frames] squared peaks, oldest first; frames[count] values are valid per stream (0: that
+ * stream's sync_rms_buffer had nothing to consume).  max_frames <= sample_rate & -16.  Shares the ingest slots of
+ * wf_hip_push_audio*_async: wf_hip_ingest_done(slot) says when `sq` may be written again. */
+int wf_hip_push_rms_ragged_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_sq, const uint32_t *frames,
+                                 uint32_t max_frames, uint32_t slot);
+/* m_input_rms of streams [first, first+count) as of the last tick, copied behind the rows of the slot's
+ * wf_hip_read_rows_async (call that first); lands with wf_hip_readback_done(slot) */
+int wf_hip_read_input_rms_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
 /* m_input_rms of streams [first, first+count) as of the last tick */
 int wf_hip_read_input_rms(wf_hip *h, uint32_t first, uint32_t count, float *out);
 int wf_hip_sync(wf_hip *h);

@@ -64,6 +64,8 @@ int wfref_using_hip(wfref_t *h);
 /* process-wide: ticks a WAVSourceHIP had to hand to the reference's CPU class since the library was loaded (0 for a
  * device path that never fell back; ticks skipped for lack of audio are not fallbacks) */
 uint64_t wfref_hip_fallback_ticks(void);
+/* update_input_rms calls of WAVSourceHIP sources that ran on the host (the batched mode feeds the device instead) */
+uint64_t wfref_hip_host_rms_updates(void);
 float wfref_gravity(wfref_t *h, float seconds);    /* get_gravity(), src/source.hpp:301-312 */
 float wfref_db_min(void);
 const float *wfref_decibels(wfref_t *h, int ch);   /* m_decibels[ch], fft_size/2 floats */

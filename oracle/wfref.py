@@ -53,6 +53,8 @@ def lib():
         getattr(L, name).argtypes = [vp]
     L.wfref_hip_fallback_ticks.restype = C.c_uint64
     L.wfref_hip_fallback_ticks.argtypes = []
+    L.wfref_hip_host_rms_updates.restype = C.c_uint64
+    L.wfref_hip_host_rms_updates.argtypes = []
     L.wfref_meter_mode.restype = C.c_int
     L.wfref_meter_mode.argtypes = [vp]
     for name in ("wfref_meter_val", "wfref_meter_buf"):
@@ -249,6 +251,11 @@ class RefSource:
         p = C.POINTER(C.c_float)()
         n = self.L.wfref_bars(self.h, ch, C.byref(p))
         return _arr(p, n)
+
+
+def hip_host_rms_updates() -> int:
+    """update_input_rms calls of WAVSourceHIP sources that ran the reference's host loop"""
+    return int(lib().wfref_hip_host_rms_updates())
 
 
 def hip_fallback_ticks() -> int:

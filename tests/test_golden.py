@@ -73,7 +73,8 @@ SPECTRUM_DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4
                    "mono_mix_4096_tv_fastpeaks", "rolloff_catrom_linear", "ragged_hops", "silence_cycle", "half_silent_stereo",
                    "hide_show", "muted_packets", "timeout_spectrum", "split_8192_half_silent", "small_512_stereo_bars",
                    "small_128_single_dup_curve", "large_32768_single_tv", "any_800_mono_mix_bars", "any_4160_stereo_silence",
-                   "sync_spectrum_2048", "sync_spectrum_4096_normalize_mono", "normalize_4096_stereo", "curve_4096_lanczos_gauss"]
+                   "sync_spectrum_2048", "sync_spectrum_4096_normalize_mono", "normalize_4096_stereo", "normalize_mono_muted_ragged",
+                   "normalize_long_1024", "curve_4096_lanczos_gauss", "plugin_defaults_4096", "curve_4096_catrom_wide_gauss"]
 DROPIN = SPECTRUM_DROPIN + [
     # WAVSourceHIP::tick_meter
     "meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",
@@ -147,15 +148,21 @@ def test_reference_plugin_with_batched_hip_tick(name):
     sc = scenarios.SCENARIOS[name]
     cfg = scenarios.make_config(sc["cfg"])
     z, meta = _load(name)
-    before = wfref.hip_fallback_ticks()
+    before, rms_before = wfref.hip_fallback_ticks(), wfref.hip_host_rms_updates()
     late = _OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
     assert late.be.src.using_hip
     scenarios.play(late, sc)
     recs = late.finish()
     assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before
+    assert wfref.hip_host_rms_updates() == rms_before, "update_input_rms ran on the host: the device RMS producer was not in use"
     assert len(recs) == meta["n_ticks"]
     silent = np.array([r["silent"] for r in recs], np.uint8)
     assert np.array_equal(silent, z["silent"]), f"{name}: m_last_silent sequence {silent} != reference {z['silent']} (one frame late)"
+    if "rms" in z.files:
+        # m_input_rms as the device's update_input_rms left it at that batch's tick (WAVSourceHIP::update_input_rms feeds the
+        # squared peaks; the sum is a tree, the reference adds its 48000 squares one by one in float)
+        got = np.array([r["rms"] for r in recs], np.float64)
+        assert np.all(np.abs(got - z["rms"]) <= 1e-5 * np.abs(z["rms"]) + 1e-9), f"{name}: m_input_rms {got} vs reference {z['rms']} (one frame late)"
     for t, r in scenarios.recorded(recs, sc["record"]):
         assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels, read one frame later")
         if f"bars_{t}" in z.files:

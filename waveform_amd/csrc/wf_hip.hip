@@ -105,6 +105,14 @@ struct wf_hip {
     float *d_rms_ring = nullptr;     // [n_streams][rms_cap] squared peaks (capture_audio's m_rms_sync_buf)
     float *d_rms_bsum = nullptr;     // [n_streams][rms_cap / RMS_BLOCK]
     uint32_t *d_rend = nullptr;      // [n_streams] consumption point of sync_rms_buffer
+    bool rms_feed = false;           // the squared peaks come from the host (wf_hip_push_rms_ragged_async), not from the pushed audio
+    float *d_sq_stage[2] = {nullptr, nullptr};      // feed staging per ingest slot: [count][max_frames] squared peaks ...
+    size_t sq_stage_floats[2] = {0, 0};
+    uint32_t *d_sq_frames[2] = {nullptr, nullptr};  // ... and their counts
+    uint32_t *h_sq_frames[2] = {nullptr, nullptr};  // page-locked copy the H2D reads from
+    size_t sq_frames_cap[2] = {0, 0};
+    hipEvent_t ev_sq_consumed[2] = {nullptr, nullptr};
+    bool sq_slot_used[2] = {false, false};
     float *d_input_rms = nullptr;    // [n_streams] m_input_rms
     uint32_t rms_cap = 0, rms_size = 0;
     // waveform batches (cfg.waveform): N = M = width (points per row), there is no FFT state
@@ -491,6 +499,7 @@ void launch_input_rms(wf_hip *h, const wf_hip_tick_params *p)
     r.max_gain = h->cfg.max_gain;
     r.db_min = wf::db_min();
     r.n_streams = h->n_streams;
+    r.feed = h->rms_feed ? 1u : 0u;
     hipLaunchKernelGGL(wf::input_rms_kernel, dim3(h->n_streams), dim3(64), 0, h->stream, r);
 }
 
@@ -552,6 +561,9 @@ int ensure_stage(wf_hip *h, size_t floats)
     return WF_HIP_OK;
 }
 
+// the squared-peak ring follows the pushed audio (wf_hip_enable_input_rms) -- as opposed to being fed by the host
+inline bool rms_follows_audio(const wf_hip *h) { return h->d_rms_ring != nullptr && !h->rms_feed; }
+
 constexpr uint32_t PUSH_SLICE = 16384; // streams per launch of the ingest kernels (rows = streams * cap_ch <= 65535)
 
 // the RMS ring follows every push (before wpos advances): squared peaks, then the sums of the blocks the push completed
@@ -568,7 +580,7 @@ int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, c
     if(frames == 0)
         return WF_HIP_OK;
     // a packet longer than the ring keeps its newest ring_cap frames, as CircularBuffer + capture_audio's trimming would
-    if(h->d_rms_ring && frames > h->rms_cap)
+    if(rms_follows_audio(h) && frames > h->rms_cap)
         return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the RMS ring capacity %u", frames, h->rms_cap);
     // the kernels index (stream, channel) rows by blockIdx.y (at most 65535): larger batches go in slices
     for(uint32_t off = 0; off < count; off += PUSH_SLICE) {
@@ -577,7 +589,7 @@ int push_common(wf_hip *h, uint32_t first, uint32_t count, const float *d_src, c
         const dim3 grid((frames + 255) / 256 > 64 ? 64 : (frames + 255) / 256, cnt * h->cap_ch), block(256);
         hipLaunchKernelGGL(wf::ring_push_kernel, grid, block, 0, h->stream, h->d_ring, h->d_wpos, h->ring_cap, h->ring_stride, h->cap_ch,
                            first + off, d_src ? d_src + skip : nullptr, frames);
-        if(h->d_rms_ring) {
+        if(rms_follows_audio(h)) {
             hipLaunchKernelGGL(wf::rms_push_kernel, dim3(grid.x, cnt), block, 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
                                h->cap_ch, first + off, d_rms_src ? d_rms_src + skip : nullptr, frames);
             rms_after_push(h, first + off, cnt, frames);
@@ -992,8 +1004,11 @@ void wf_hip_destroy(wf_hip *h)
         if(h->ev_read[i]) (void)hipEventDestroy(h->ev_read[i]);
     }
     if(h->read_stream) (void)hipStreamDestroy(h->read_stream);
-    for(int i = 0; i < 2; ++i)
+    for(int i = 0; i < 2; ++i) {
         if(h->h_frames_async[i]) (void)hipHostFree(h->h_frames_async[i]);
+        if(h->h_sq_frames[i]) (void)hipHostFree(h->h_sq_frames[i]);
+        if(h->ev_sq_consumed[i]) (void)hipEventDestroy(h->ev_sq_consumed[i]);
+    }
     if(h->ev_bars) (void)hipEventDestroy(h->ev_bars);
     if(h->ev0) (void)hipEventDestroy(h->ev0);
     if(h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1178,8 +1193,8 @@ int wf_hip_push_audio_ragged_async(wf_hip *h, uint32_t first, uint32_t count, co
         return rc;
     if(pinned_samples == nullptr || frames == nullptr || slot > 1 || max_frames == 0)
         return fail(h, WF_HIP_ERR_INVALID, "samples or frames is NULL, max_frames is 0 or slot is not 0 / 1");
-    if(h->d_rms_ring)
-        return fail(h, WF_HIP_ERR_INVALID, "ragged pushes are not available while the device RMS producer is enabled");
+    if(rms_follows_audio(h))
+        return fail(h, WF_HIP_ERR_INVALID, "ragged pushes are not available while the device RMS producer follows the audio (wf_hip_enable_input_rms)");
     if(count > 65535u)
         return fail(h, WF_HIP_ERR_INVALID, "at most 65535 streams per ragged push");
     WF_HIP_TRY(h, hipSetDevice(h->device));
@@ -1244,10 +1259,10 @@ int wf_hip_ingest_done(wf_hip *h, uint32_t slot)
 {
     if(h == nullptr || slot > 1)
         return WF_HIP_ERR_INVALID;
-    if(!h->slot_used[slot])
+    if(!h->slot_used[slot] && !h->sq_slot_used[slot])
         return WF_HIP_OK;
     WF_HIP_TRY(h, hipSetDevice(h->device));
-    WF_HIP_TRY(h, hipEventSynchronize(h->ev_copied[slot]));
+    WF_HIP_TRY(h, hipEventSynchronize(h->ev_copied[slot])); // the slot's last H2D copy (samples or squared peaks)
     return WF_HIP_OK;
 }
 
@@ -1295,7 +1310,7 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
         return rc;
     if(frames == 0)
         return WF_HIP_OK;
-    if(h->d_rms_ring && frames > h->rms_cap)
+    if(rms_follows_audio(h) && frames > h->rms_cap)
         return fail(h, WF_HIP_ERR_INVALID, "push of %u frames exceeds the RMS ring capacity %u", frames, h->rms_cap);
     WF_HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t gx = std::min<uint32_t>((frames + 255) / 256, 256);
@@ -1303,7 +1318,7 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
         const uint32_t cnt = std::min(PUSH_SLICE, count - off);
         hipLaunchKernelGGL(wf::ring_synth_kernel, dim3(gx, cnt * h->cap_ch), dim3(256), 0, h->stream, h->d_ring, h->d_wpos,
                            h->ring_cap, h->ring_stride, h->cap_ch, first + off, seed, stream_id0 + off, index0, frames);
-        if(h->d_rms_ring) {
+        if(rms_follows_audio(h)) {
             hipLaunchKernelGGL(wf::rms_synth_kernel, dim3(gx, cnt), dim3(256), 0, h->stream, h->d_rms_ring, h->d_wpos, h->rms_cap,
                                h->cap_ch, first + off, seed, stream_id0 + off, index0, frames);
             rms_after_push(h, first + off, cnt, frames);
@@ -1523,21 +1538,23 @@ int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float 
 
 static int read_back(wf_hip *h, const void *d, void *out, size_t bytes);
 
-int wf_hip_enable_input_rms(wf_hip *h)
+static int enable_rms_producer(wf_hip *h, bool feed)
 {
     if(h == nullptr)
         return WF_HIP_ERR_INVALID;
     if(!h->cfg.normalize_volume || h->meter)
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_enable_input_rms needs a spectrum or waveform batch with cfg.normalize_volume");
+        return fail(h, WF_HIP_ERR_INVALID, "the device RMS producer needs a spectrum or waveform batch with cfg.normalize_volume");
     if(h->d_rms_ring)
-        return WF_HIP_OK;
+        return h->rms_feed == feed ? WF_HIP_OK : fail(h, WF_HIP_ERR_INVALID, "the device RMS producer is already enabled in the other mode");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     WF_TRY_RC(join_lanes(h));
     h->rms_size = h->cfg.sample_rate & ~15u; // m_input_rms_size, src/source.cpp:1147
     if(h->rms_size == 0)
         return fail(h, WF_HIP_ERR_INVALID, "sample_rate %u is too small for the RMS window", h->cfg.sample_rate);
-    // the window + every A/V-sync delay the audio rings admit + the two ragged blocks at its ends
-    h->rms_cap = next_pow2(h->rms_size + (h->wave ? h->ring_cap : h->ring_cap - h->N) + 2 * wf::RMS_BLOCK);
+    // the window + every A/V-sync delay the audio rings admit + the two ragged blocks at its ends (feed mode: the window,
+    // the ragged blocks and one feed of up to a window's length)
+    h->rms_cap = feed ? next_pow2(2 * h->rms_size + 2 * wf::RMS_BLOCK)
+                      : next_pow2(h->rms_size + (h->wave ? h->ring_cap : h->ring_cap - h->N) + 2 * wf::RMS_BLOCK);
     const size_t nblk = h->rms_cap / wf::RMS_BLOCK;
     float *ring = nullptr, *bsum = nullptr;
     int rc = dev_alloc(h, &ring, (size_t)h->n_streams * h->rms_cap);
@@ -1554,7 +1571,110 @@ int wf_hip_enable_input_rms(wf_hip *h)
     WF_HIP_TRY(h, hipMemsetAsync(h->d_rend, 0, (size_t)h->n_streams * sizeof(uint32_t), h->stream));
     WF_HIP_TRY(h, hipMemsetAsync(h->d_input_rms, 0, (size_t)h->n_streams * sizeof(float), h->stream));
     h->d_rms_bsum = bsum;
-    h->d_rms_ring = ring; // from here on every push feeds it
+    h->rms_feed = feed;
+    h->d_rms_ring = ring; // from here on every push feeds it (or, feed mode, wf_hip_push_rms_ragged_async does)
+    h->main_dirty = true;
+    return WF_HIP_OK;
+}
+
+int wf_hip_enable_input_rms(wf_hip *h) { return enable_rms_producer(h, false); }
+int wf_hip_enable_input_rms_feed(wf_hip *h) { return enable_rms_producer(h, true); }
+
+int wf_hip_push_rms_ragged_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_sq, const uint32_t *frames, uint32_t max_frames,
+                                 uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(pinned_sq == nullptr || frames == nullptr || slot > 1 || max_frames == 0)
+        return fail(h, WF_HIP_ERR_INVALID, "values or frames is NULL, max_frames is 0 or slot is not 0 / 1");
+    if(!h->rms_feed)
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_push_rms_ragged_async needs wf_hip_enable_input_rms_feed");
+    if(max_frames > h->rms_size)
+        return fail(h, WF_HIP_ERR_INVALID, "a feed of %u values per stream exceeds the RMS window (%u)", max_frames, h->rms_size);
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->copy_stream == nullptr) {
+        WF_HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for(int i = 0; i < 2; ++i) {
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_consumed[i], hipEventDisableTiming));
+        }
+    }
+    if(h->ev_sq_consumed[0] == nullptr)
+        for(int i = 0; i < 2; ++i)
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sq_consumed[i], hipEventDisableTiming));
+    if(h->sq_slot_used[slot])
+        WF_HIP_TRY(h, hipEventSynchronize(h->ev_sq_consumed[slot])); // the slot's staging is free again (two feeds ago)
+    const size_t n = (size_t)count * max_frames;
+    if(h->sq_stage_floats[slot] < n) {
+        dev_release(h, h->d_sq_stage[slot]);
+        h->d_sq_stage[slot] = nullptr;
+        const size_t want = grown(h->sq_stage_floats[slot], n);
+        h->sq_stage_floats[slot] = 0;
+        float *p = nullptr;
+        rc = dev_alloc(h, &p, want);
+        if(rc)
+            return rc;
+        h->d_sq_stage[slot] = p;
+        h->sq_stage_floats[slot] = want;
+    }
+    if(h->sq_frames_cap[slot] < count) {
+        dev_release(h, h->d_sq_frames[slot]);
+        h->d_sq_frames[slot] = nullptr;
+        if(h->h_sq_frames[slot])
+            (void)hipHostFree(h->h_sq_frames[slot]);
+        h->h_sq_frames[slot] = nullptr;
+        h->sq_frames_cap[slot] = 0;
+        const size_t want = std::max<size_t>(count, 64);
+        rc = dev_alloc(h, &h->d_sq_frames[slot], want);
+        if(rc)
+            return rc;
+        WF_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_sq_frames[slot]), want * sizeof(uint32_t), hipHostMallocDefault));
+        h->sq_frames_cap[slot] = want;
+    }
+    uint32_t longest = 0;
+    for(uint32_t i = 0; i < count; ++i) {
+        h->h_sq_frames[slot][i] = std::min(frames[i], max_frames);
+        longest = std::max(longest, h->h_sq_frames[slot][i]);
+    }
+    if(longest == 0)
+        return WF_HIP_OK; // nothing to consume this frame (sync_rms_buffer returns false for every stream)
+    // rows are max_frames apart; only the part any stream uses crosses the bus when the rows are short
+    if(longest == max_frames || count == 1)
+        WF_HIP_TRY(h, hipMemcpyAsync(h->d_sq_stage[slot], pinned_sq, (count == 1 ? (size_t)longest : n) * sizeof(float), hipMemcpyHostToDevice,
+                                     h->copy_stream));
+    else
+        WF_HIP_TRY(h, hipMemcpy2DAsync(h->d_sq_stage[slot], (size_t)max_frames * sizeof(float), pinned_sq, (size_t)max_frames * sizeof(float),
+                                       (size_t)longest * sizeof(float), count, hipMemcpyHostToDevice, h->copy_stream));
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_sq_frames[slot], h->h_sq_frames[slot], (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 h->copy_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_copied[slot], h->copy_stream));
+    WF_TRY_RC(join_lanes(h));
+    WF_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
+    hipLaunchKernelGGL(wf::rms_feed_ragged_kernel, dim3(count), dim3(256), 0, h->stream, h->d_rms_ring, h->d_rms_bsum, h->d_rend, h->rms_cap, first,
+                       h->d_sq_stage[slot], h->d_sq_frames[slot], max_frames);
+    WF_HIP_TRY(h, hipGetLastError());
+    WF_HIP_TRY(h, hipEventRecord(h->ev_sq_consumed[slot], h->stream));
+    h->sq_slot_used[slot] = true;
+    h->main_dirty = true;
+    return WF_HIP_OK;
+}
+
+int wf_hip_read_input_rms_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(pinned_out == nullptr || slot > 1)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL or slot is not 0 / 1");
+    if(h->d_input_rms == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "the device RMS producer is not enabled");
+    if(!h->rows_in_flight[slot] || h->read_stream == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_input_rms_async rides on the slot's wf_hip_read_rows_async: call that first");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    // behind the rows' copy on the readback stream (which already waits for the tick); completes with wf_hip_readback_done(slot)
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_out, h->d_input_rms + first, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
     return WF_HIP_OK;
 }
 

@@ -24,6 +24,15 @@ namespace wf {
 constexpr uint32_t RMS_BLOCK = 256;      // frames per stored partial sum
 constexpr uint32_t RMS_BLOCK_SHIFT = 8;
 
+// fixed-order sum over a wavefront
+WF_DEV float wave_sum(float v)
+{
+#pragma unroll
+    for(int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
+}
+
 // src: [count*cap_ch][frames] (nullptr: silence); squared peaks of streams [first, first+count) at wpos.. (before wpos advances)
 __global__ void rms_push_kernel(float *rms_ring, const uint32_t *wpos, uint32_t rms_cap, uint32_t cap_ch, uint32_t first,
                                 const float *src, uint32_t frames)
@@ -58,15 +67,6 @@ __global__ void rms_synth_kernel(float *rms_ring, const uint32_t *wpos, uint32_t
     }
 }
 
-// fixed-order sum over a wavefront
-WF_DEV float wave_sum(float v)
-{
-#pragma unroll
-    for(int m = 32; m >= 1; m >>= 1)
-        v += __shfl_xor(v, m, 64);
-    return v;
-}
-
 // Partial sums of the blocks this push has completed: block k (frames [k*B, (k+1)*B)) is complete once (k+1)*B <= w + frames
 // and was not before if (k+1)*B > w.  One wavefront per candidate block; runs after rms_push_kernel, before wpos advances.
 __global__ __launch_bounds__(64) void rms_block_kernel(const float *rms_ring, float *bsum, const uint32_t *wpos, uint32_t rms_cap,
@@ -87,6 +87,43 @@ __global__ __launch_bounds__(64) void rms_block_kernel(const float *rms_ring, fl
         bsum[(size_t)stream * (rms_cap >> RMS_BLOCK_SHIFT) + (k & ((rms_cap >> RMS_BLOCK_SHIFT) - 1))] = sum;
 }
 
+// Feed mode (wf_hip_enable_input_rms_feed): the host hands over the squared peaks themselves -- what sync_rms_buffer moves
+// from m_rms_sync_buf into m_input_rms_buf this tick (src/source.cpp:810-835) -- a different number of values per stream.
+// sq: [count][max_frames], frames[count].  One workgroup per stream appends them at the stream's consumption point
+// `rend`, stores the sums of the blocks that became complete, and advances rend.
+__global__ __launch_bounds__(256) void rms_feed_ragged_kernel(float *rms_ring, float *bsum, uint32_t *rend, uint32_t rms_cap, uint32_t first,
+                                                              const float *sq, const uint32_t *frames, uint32_t max_frames)
+{
+    const uint32_t s = blockIdx.x, stream = first + s;
+    const uint32_t n = frames[s] < max_frames ? frames[s] : max_frames;
+    if(n == 0)
+        return;
+    const uint32_t w = rend[stream];
+    float *ring = rms_ring + (size_t)stream * rms_cap;
+    const float *src = sq + (size_t)s * max_frames;
+    const uint32_t skip = n > rms_cap ? n - rms_cap : 0u; // longer than the ring: only the tail survives
+    for(uint32_t i = skip + threadIdx.x; i < n; i += blockDim.x)
+        ring[(w + i) & (rms_cap - 1)] = src[i];
+    __syncthreads(); // the workgroup's own stores are visible to it
+    // blocks completed by this feed: block k ends at (k + 1) * B; complete now, not before, if 0 < end - w <= n
+    float *bs = bsum + (size_t)stream * (rms_cap >> RMS_BLOCK_SHIFT);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for(uint32_t j = wave;; j += blockDim.x >> 6) {
+        const uint32_t k = (w >> RMS_BLOCK_SHIFT) + j;
+        const uint32_t end = (k + 1u) << RMS_BLOCK_SHIFT;
+        const uint32_t dist = end - w; // 1..B for j == 0, then + B per step
+        if(dist > n)
+            break;
+        const f4 v = ld4(ring + (((k << RMS_BLOCK_SHIFT) + 4u * lane) & (rms_cap - 1)));
+        const float sum = wave_sum((v.x + v.y) + (v.z + v.w));
+        if(lane == 0)
+            bs[k & ((rms_cap >> RMS_BLOCK_SHIFT) - 1)] = sum;
+    }
+    __syncthreads();
+    if(threadIdx.x == 0)
+        rend[stream] = w + n;
+}
+
 struct RmsArgs {
     const float *rms_ring;     // [n_streams][rms_cap] squared peaks
     const float *bsum;         // [n_streams][rms_cap / RMS_BLOCK] sums of completed blocks
@@ -100,6 +137,7 @@ struct RmsArgs {
     float *vol_comp;           // [n_streams] min(m_volume_target - dbfs(m_input_rms), m_max_gain), read by the tick kernel
     float volume_target, max_gain, db_min;
     uint32_t n_streams;
+    uint32_t feed;             // 1: rend is advanced by rms_feed_ragged_kernel, not derived from the audio position
 };
 
 // update_input_rms for every stream: one wavefront per stream
@@ -111,9 +149,9 @@ __global__ __launch_bounds__(64) void input_rms_kernel(const RmsArgs a)
     uint32_t rend = a.rend[stream];
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
     const uint32_t cand = wpos - delay;
-    if((int32_t)(cand - rend) > 0) // sync_rms_buffer: everything older than the sync point is consumed; never moves back
+    if(!a.feed && (int32_t)(cand - rend) > 0) // sync_rms_buffer: everything older than the sync point is consumed; never moves back
         rend = cand;
-    if(lane == 0)
+    if(!a.feed && lane == 0)
         a.rend[stream] = rend;
 
     const uint32_t mask = a.rms_cap - 1, nblk_mask = (a.rms_cap >> RMS_BLOCK_SHIFT) - 1;
