@@ -371,7 +371,7 @@ bool WAVSourceHIP::hip_configure()
     }
     const int rc = api().create(&c, 0, 1, 0, &m_hip);
     if(rc != WF_HIP_OK) {
-        // e.g. WF_HIP_ERR_UNSUPPORTED for an FFT size outside the implemented set (powers of two 128..32768, other multiples of 16 up to 10912)
+        // e.g. WF_HIP_ERR_UNSUPPORTED for a curve + filter combination whose staging does not fit the on-chip buffer
         LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
         m_hip = nullptr;
         return false;

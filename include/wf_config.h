@@ -28,7 +28,7 @@ typedef enum wf_interp { WF_INTERP_POINT = 0, WF_INTERP_LANCZOS, WF_INTERP_CATRO
 typedef enum wf_filter { WF_FILTER_NONE = 0, WF_FILTER_GAUSS } wf_filter;
 
 typedef struct wf_config {
-    uint32_t fft_size;          /* m_fft_size: multiple of 16; powers of two 128..32768, others up to 10912 */
+    uint32_t fft_size;          /* m_fft_size: a multiple of 16 in [128, 65536] (src/source.cpp:562-565) */
     uint32_t sample_rate;       /* m_audio_info.samples_per_sec */
     uint32_t capture_channels;  /* m_capture_channels: 1 or 2 */
     uint32_t stereo;            /* m_stereo (channel_mode == "stereo") */

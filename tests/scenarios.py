@@ -149,6 +149,21 @@ SCENARIOS = {
                                     steps=_steps(2) + [("noise_ch0_only", 33000), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 6
                                     + [("silence", 33000), ("tick",)] + [("silence", 800), ("tick",)] * 10 + [("noise_ch1_only", 800), ("tick",)] * 2,
                                     record=2),
+    # ---- transforms beyond a CU's LDS (wf_big.hpp): 65536 samples = 2 x 16384 complex points through device memory, and the
+    # Bluestein sizes above 10912 (L = 32768 / 65536 / 131072 complex points); rows of up to 32768 bins finished in two parts
+    "huge_65536_stereo_bars": dict(cfg=dict(fft_size=65536, stereo=1, slope=1.0, bars=1, interp_mode=1), steps=_steps(3), record=1),
+    "huge_65536_mono_mix_tv_curve": dict(cfg=dict(fft_size=65536, stereo=0, tsmoothing=2, fast_peaks=1, window=4, curve=1, interp_mode=2,
+                                                  filter_mode=1, filter_radius=1.5),
+                                         steps=[("noise", 441), ("tick",)] * 3 + [("noise", 1024), ("tick",)], record=2),
+    "huge_65536_half_silent": dict(cfg=dict(fft_size=65536, stereo=1, gravity=0.2, rolloff_q=1.5, rolloff_rate=12.0),
+                                   steps=_steps(2) + [("noise_ch0_only", 66000), ("tick",)] + [("noise_ch0_only", 800), ("tick",)] * 6
+                                   + [("silence", 66000), ("tick",)] + [("silence", 800), ("tick",)] * 10 + [("noise_ch1_only", 800), ("tick",)] * 2
+                                   + [("hide",), ("noise", 800), ("tick",), ("show",)] + _steps(2), record=3),
+    "any_16400_stereo_curve": dict(cfg=dict(fft_size=16400, stereo=1, slope=0.5, curve=1, interp_mode=1), steps=_steps(3), record=1),
+    "any_30000_mono_mix_bars": dict(cfg=dict(fft_size=30000, stereo=0, tsmoothing=2, bars=1, interp_mode=2, filter_mode=1, filter_radius=0.8),
+                                    steps=_steps(3), record=2),
+    "any_48000_single_dup": dict(cfg=dict(fft_size=48000, stereo=1, capture_channels=1, window=3, gravity=0.3),
+                                 steps=_steps(3) + [("silence", 49000), ("tick",)] + [("silence", 800), ("tick",)] * 8 + _steps(2), record=2),
     # ---- volume normalisation with its producer (capture_audio's RMS part + update_input_rms, src/source.cpp:1842-1871,
     # :810-835, src/source_generic.cpp:392-403): every backend derives m_input_rms from the audio itself; records add
     #   rms  float32 scalar  m_input_rms after the tick

@@ -71,10 +71,12 @@ def test_host_tables_bit_identical_to_oracle(ov):
 
 
 def test_unsupported_fft_sizes_are_rejected():
-    for n in (64, 65536, 3000, 12000):  # below the minimum, too long, not a multiple of 16, too long for Bluestein
+    for n in (64, 65552, 131072, 3000):  # below the reference's minimum, above its maximum (65536), not a multiple of 16
         cfg = scenarios.make_config(dict(fft_size=n))
         with pytest.raises(ValueError):
             emu.host_table(cfg, 0)
+    for n in (128, 800, 10912, 10928, 12000, 16400, 32768, 48000, 65520, 65536):  # every multiple of 16 in [128, 65536] is taken
+        emu.host_table(scenarios.make_config(dict(fft_size=n)), 0)
 
 
 def test_degenerate_display_configurations_are_rejected():
@@ -245,9 +247,10 @@ def _create_code(**overrides):
 
 
 def test_fft_sizes_accepted_and_rejected():
-    for n in (128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 144, 800, 4160, 8000, 10912):
+    # every multiple of 16 in [128, 65536] -- the reference's own range (src/source.cpp:349, :359-363, :562-565) -- is taken
+    for n in list(range(128, 65537, 16 * 97)) + [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 800, 10912, 10928, 16400, 48000, 65520]:
         assert _create_code(fft_size=n) == -3, n
-    for n in (64, 808, 10928, 65536):  # legal for the reference (multiples of 16 >= 128 up to 65536) or below its minimum
+    for n in (64, 808, 65552, 131072):  # below the minimum, not a multiple of 16, above the maximum
         assert _create_code(fft_size=n) == -2, n
 
 

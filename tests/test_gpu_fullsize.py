@@ -269,8 +269,8 @@ def test_delay_frames_is_the_av_sync_window():
 
 def test_errors_are_reported_not_thrown():
     with pytest.raises(wf.WfHipError) as e:
-        wf.SpectrumBatch(wf.Config.defaults(fft_size=12000), 1)
-    assert e.value.code == -2  # WF_HIP_ERR_UNSUPPORTED: legal for the reference with "large FFT", too long for the Bluestein path
+        wf.SpectrumBatch(wf.Config.defaults(fft_size=65552), 1)
+    assert e.value.code == -2  # WF_HIP_ERR_UNSUPPORTED: above the reference's own maximum (65536, "enable large FFT")
     cfg = wf.Config.defaults(fft_size=1024)
     with wf.SpectrumBatch(cfg, 2) as b:
         with pytest.raises(wf.WfHipError):

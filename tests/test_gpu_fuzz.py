@@ -21,11 +21,32 @@ BLU_SEEDS = range(500)     # every other multiple of 16 (Bluestein)
 REF_EVERY = 8              # every 8th spectrum / Bluestein seed is also played against libwfref.so (the reference, float FFTW)
 MAX_POW2 = 32768
 MAX_ANY = 10912
+HUGE_SEEDS = range(60)     # the sizes beyond a CU's LDS (wf_big.hpp): 65536 and every other multiple of 16 above 10912
+
+
+def _largest_prime_factor(n: int) -> int:
+    p, best = 2, 1
+    while p * p <= n:
+        while n % p == 0:
+            best, n = p, n // p
+        p += 1
+    return max(best, n) if n > 1 else best
 
 
 def draw(seed: int, family: str = "pow2"):
-    r = np.random.default_rng((1000 if family == "pow2" else 77000) + seed)
-    if family == "pow2":
+    r = np.random.default_rng({"pow2": 1000, "any": 77000, "huge": 555000}[family] + seed)
+    if family == "huge":
+        # 65536 itself a quarter of the time, else a multiple of 16 in (10912, 65536).  The restatement's DFT of a length with a
+        # large prime factor p costs O(n p) in double per channel and tick, so lengths are redrawn until p <= 61 (that
+        # keeps a case under a second on the CPU; the device path does not care: Bluestein)
+        if r.random() < 0.25:
+            n = 65536
+        else:
+            while True:
+                n = 16 * int(r.integers(10912 // 16 + 1, 65536 // 16))
+                if n & (n - 1) and _largest_prime_factor(n) <= 61:
+                    break
+    elif family == "pow2":
         sizes = [128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
         p = np.array([0.07, 0.07, 0.08, 0.2, 0.17, 0.17, 0.09, 0.07, 0.04, 0.04])
         keep = [i for i, v in enumerate(sizes) if v <= MAX_POW2]
@@ -140,6 +161,12 @@ def run_spectrum_case(seed, family):
 @pytest.mark.parametrize("seed", SPEC_SEEDS)
 def test_hip_matches_oracle_on_random_case(seed):
     run_spectrum_case(seed, "pow2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", HUGE_SEEDS)
+def test_hip_matches_oracle_on_random_huge_size(seed):
+    run_spectrum_case(seed, "huge")
 
 
 @pytest.mark.gpu

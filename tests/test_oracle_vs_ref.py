@@ -36,6 +36,13 @@ def test_restatement_matches_reference_any_size(seed):
     fuzz._compare(got, want, fuzz._undo_db(cfg), f"any-size case {seed} ({cfg_dict}): restatement vs libwfref")
 
 
+@pytest.mark.parametrize("seed", range(0, len(fuzz.HUGE_SEEDS), 6))
+def test_restatement_matches_reference_huge_size(seed):
+    cfg_dict, steps, sync_ms = fuzz.draw(seed, "huge")
+    cfg, got, want = _play_pair(cfg_dict, steps, f"huge {seed}", sync_ms=sync_ms)
+    fuzz._compare(got, want, fuzz._undo_db(cfg), f"huge-size case {seed} ({cfg_dict}): restatement vs libwfref")
+
+
 @pytest.mark.parametrize("seed", range(0, len(fuzz.METER_SEEDS), STEP))
 def test_restatement_matches_reference_meter(seed):
     import numpy as np

@@ -1,0 +1,400 @@
+// wf_big.hpp -- gfx950 kernels of the FFT sizes whose complex transform does not fit a CU's LDS (device code only; hipcc).
+//
+// The reference accepts every multiple of 16 up to 65536 samples with "enable large FFT" (src/source.cpp:349, :359-363,
+// :562-565).  Up to 32768 samples (16384 complex points, 132 KB) a spectrum lives in one workgroup's LDS
+// (spectrum_tick_kernel).  Beyond that:
+//   65536 samples                    -> 32768 complex points (the packed real transform)
+//   n = 10928 .. 65520, not 2^k      -> Bluestein over L = 32768 / 65536 / 131072 complex points (two transforms)
+// A transform of L = L1 * 16384 points (L1 = 2, 4, 8) is done in two steps through a scratch buffer in device memory
+// (decimation in frequency, n = n1 * 16384 + n2, k = k1 + L1 * k2):
+//   big_columns_kernel   v[k1][n2] = W_L^(n2 k1) * sum_n1 u[n1 * 16384 + n2] W_L1^(n1 k1)      (u = the windowed samples, see MODE)
+//   big_rows_kernel      U[k1 + L1 k2] = sum_n2 v[k1][n2] W_16384^(n2 k2)   -- the 32768-sample geometry's three LDS passes
+// then big_epilogue_kernel does what P4 and the end of spectrum_tick_kernel do (real split or |c_k|, slope, temporal
+// smoothing, silence state machine, dBFS, volume normalisation, roll-off; reference src/source_generic.cpp:63-179) on
+// 16384 bins per workgroup, and big_outputs_kernel what render_bars / render_curve derive from the finished rows
+// (src/source.cpp:1360-1425, :1500-1564).  The channels of a stream are coupled as in split mode: "has a non-zero sample"
+// through a word the columns kernel ORs into, "previous row entirely <= floor - 10" through the rotating verdict words.
+//
+// This is the compatibility path (every transform moves its data through L2 / Infinity Cache three times); the sizes
+// the slider produces by default never reach it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wf_geometry.hpp"
+#include "wf_tick_phases.hpp"
+
+namespace wf {
+
+using GBig = G32768;                       // the row transform: 16384 complex points, 1024 threads
+constexpr uint32_t BIG_L2 = GBig::M;       // 16384
+constexpr int BIG_TP = GBig::T * GBig::P;  // bins per epilogue workgroup (16384)
+
+struct BigArgs {
+    const float *ring;
+    const uint32_t *wpos;
+    const uint32_t *delay_stream;
+    uint32_t ring_mask, ring_stride, delay, cap_ch;
+    uint32_t n;              // samples per window (m_fft_size)
+    uint32_t L;              // complex points per transform (L1 * 16384)
+    const float *window;     // [n] (MODE 0)
+    const cf *blu_a;         // [L] window_j * conj(w_j), zero from n on (MODE 1)
+    const cf *blu_b;         // [L] FFT_L of the chirp (MODE 2)
+    const cf *tw_big;        // [L1][16384] W_L^(n2 k1)
+    const cf *tw1, *tw2;     // the row transform's tables
+    cf *v;                   // [n_spec][L1][16384] columns' output
+    cf *z;                   // [n_spec][L] rows' output, natural order
+    uint32_t *nz;            // [n_spec] != 0: the window has a non-zero sample
+    uint32_t spec_base;      // first spectrum of this launch
+};
+
+// MODE 0: u[j] = (x[2j] w[2j], x[2j+1] w[2j+1])  (packed real transform of n = 2L samples, reference :97-106)
+// MODE 1: u[j] = x[j] * blu_a[j]                  (Bluestein, first transform: the chirped window)
+// MODE 2: u[j] = conj(z[j] * blu_b[j])            (Bluestein, second transform)
+template<int L1, int MODE> __global__ __launch_bounds__(256) void big_columns_kernel(const BigArgs a)
+{
+    const uint32_t spec = a.spec_base + blockIdx.y;
+    const uint32_t n2 = 2u * (blockIdx.x * 256u + threadIdx.x); // this thread's pair of columns
+    cf u0[L1], u1[L1];
+    uint32_t acc = 0;
+    if constexpr(MODE == 2) {
+        const cf *zin = a.z + (size_t)spec * a.L;
+#pragma unroll
+        for(int n1 = 0; n1 < L1; ++n1) {
+            const uint32_t j = (uint32_t)n1 * BIG_L2 + n2;
+            const f4 s = ld4(reinterpret_cast<const float *>(zin + j));
+            const f4 b = ld4(reinterpret_cast<const float *>(a.blu_b + j));
+            const cf p0 = cmul(cf{s.x, s.y}, cf{b.x, b.y}), p1 = cmul(cf{s.z, s.w}, cf{b.z, b.w});
+            u0[n1] = cf{p0.x, -p0.y};
+            u1[n1] = cf{p1.x, -p1.y};
+        }
+    } else {
+        const uint32_t stream = spec >> (a.cap_ch - 1u);
+        const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+        const uint32_t start = (a.wpos[stream] - delay - a.n) & a.ring_mask;
+        const float *x = a.ring + (size_t)spec * a.ring_stride;
+#pragma unroll
+        for(int n1 = 0; n1 < L1; ++n1) {
+            const uint32_t j = (uint32_t)n1 * BIG_L2 + n2;
+            if constexpr(MODE == 0) {
+                float s[4];
+#pragma unroll
+                for(uint32_t e = 0; e < 4; ++e) {
+                    s[e] = x[(start + 2u * j + e) & a.ring_mask];
+                    acc |= f32_bits(s[e]);
+                }
+                const f4 w = ld4(a.window + 2u * j);
+                u0[n1] = cf{s[0] * w.x, s[1] * w.y};
+                u1[n1] = cf{s[2] * w.z, s[3] * w.w};
+            } else {
+                const bool in0 = j < a.n, in1 = j + 1u < a.n;
+                const float v0 = x[(start + (in0 ? j : 0u)) & a.ring_mask], v1 = x[(start + (in1 ? j + 1u : 0u)) & a.ring_mask];
+                const float s0 = in0 ? v0 : 0.0f, s1 = in1 ? v1 : 0.0f;
+                acc |= f32_bits(s0) | f32_bits(s1);
+                const f4 q = ld4(reinterpret_cast<const float *>(a.blu_a + j));
+                u0[n1] = cf{s0 * q.x, s0 * q.y};
+                u1[n1] = cf{s1 * q.z, s1 * q.w};
+            }
+        }
+    }
+    dft_dif<L1>(u0);
+    dft_dif<L1>(u1);
+    cf *v = a.v + (size_t)spec * a.L;
+    constexpr int LB = ilog2(L1);
+#pragma unroll
+    for(int k1 = 0; k1 < L1; ++k1) {
+        cf c0 = u0[brev(k1, LB)], c1 = u1[brev(k1, LB)];
+        if(k1 > 0) {
+            const f4 w = ld4(reinterpret_cast<const float *>(a.tw_big + (size_t)k1 * BIG_L2 + n2));
+            c0 = cmul(c0, cf{w.x, w.y});
+            c1 = cmul(c1, cf{w.z, w.w});
+        }
+        st4(reinterpret_cast<float *>(v + (size_t)k1 * BIG_L2 + n2), f4{c0.x, c0.y, c1.x, c1.y});
+    }
+    if constexpr(MODE != 2) {
+        // x != 0.0f for any sample of the window (reference :63-72): -0.0f is zero, NaNs are not
+        if(__any((acc & 0x7fffffffu) != 0u) && (threadIdx.x & 63u) == 0u)
+            atomicOr(a.nz + spec, 1u);
+    }
+}
+
+// one row of 16384 points per workgroup: the three LDS passes of the 32768-sample geometry, then out in natural order
+template<int L1> __global__ __launch_bounds__(GBig::T, 4) void big_rows_kernel(const BigArgs a)
+{
+    using G = GBig;
+    constexpr int T = G::T, P = G::P, R1 = G::R1, M1 = G::M1;
+    static_assert(G::B1 == 1, "the row loader fetches one point per pass-1 row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    cf *lds = reinterpret_cast<cf *>(big_smem);
+    cf *tw2_lds = lds + G::LDS_CF;
+    const int t = (int)threadIdx.x;
+    const uint32_t k1 = blockIdx.x, spec = a.spec_base + blockIdx.y;
+    const cf *v = a.v + (size_t)spec * a.L + (size_t)k1 * BIG_L2;
+    TickArgs ta{};
+    ta.tw1 = a.tw1;
+    P1Regs<G> r;
+#pragma unroll
+    for(int j = 0; j < R1; ++j) {
+        const f2 q = ld2(reinterpret_cast<const float *>(v + j * M1 + t));
+        r.smp[j][0] = q.x;
+        r.smp[j][1] = q.y;
+        r.win[j][0] = r.win[j][1] = 1.0f;
+        if(j >= 1 && tw1_row_loaded(j))
+            p1_load_tw1<G>(ta, t, j, r.tw1[j]);
+    }
+    // the pass-2 twiddles by LDS-DMA, as in spectrum_tick_kernel
+    {
+        constexpr int BYTES = G::R2 * G::R3 * (int)sizeof(cf), PER = 64 * 16;
+        const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+        for(int c = 0; c < BYTES / PER; ++c)
+            if((c % (T / 64)) == wave) {
+                const char *g = reinterpret_cast<const char *>(a.tw2) + c * PER + lane * 16;
+                char *l = reinterpret_cast<char *>(tw2_lds) + c * PER;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16,
+                                                 0, 0);
+            }
+    }
+    p1_window_pass1<G>(ta, t, r, lds);
+    __syncthreads();
+    cf pts[P];
+    p2_read<G>(t, lds, pts);
+    __syncthreads();
+    p2_pass2_write<G>(tw2_lds, t, lds, pts);
+    __syncthreads();
+    p3_read<G>(t, lds, pts);
+    __syncthreads();
+    p3_pass3_write<G>(t, lds, pts);
+    __syncthreads();
+    cf *z = a.z + (size_t)spec * a.L;
+#pragma unroll
+    for(int i = 0; i < P; ++i) {
+        const int k2 = t + T * i;
+        const cf c = lds_ld2(lds, ex3_addr<G>(k2));
+        *reinterpret_cast<f2 *>(z + (size_t)k1 + (size_t)L1 * k2) = f2{c.x, c.y};
+    }
+}
+template<int L1> constexpr size_t big_rows_lds_bytes() { return (size_t)GBig::LDS_CF * sizeof(cf) + (size_t)GBig::R2 * GBig::R3 * sizeof(cf) + 16; }
+
+// ---- epilogue ------------------------------------------------------------------------------------------------------
+// MODE 1: bins from the packed transform Z of big_m points: 2X[k] = (Z[k] + conj Z[m-k]) - i W_2m^k (Z[k] - conj Z[m-k])
+// MODE 2: bins are |c_k| of the Bluestein convolution
+template<int MODE, bool TS, bool FPK>
+WF_DEV void p4_big_impl(const TickArgs &a, int t, int kbase, int nb, const cf *z, float *ts, float (&mag)[GBig::P])
+{
+    using G = GBig;
+    constexpr int T = G::T, P = G::P;
+    const int m = (int)a.big_m;
+#pragma unroll
+    for(int u = 0; u < P / 4; ++u) {
+        const int k0 = 4 * (t + T * u);
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+            mag[4 * u + i] = 0.0f;
+        if(k0 >= nb)
+            continue;
+        const int kk = kbase + k0;
+        const f4 sv = ld4(a.slope + kk);
+        f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if(TS)
+            st = ld4(ts + k0);
+        const f4 za = ld4(reinterpret_cast<const float *>(z + kk)), zb = ld4(reinterpret_cast<const float *>(z + kk + 2));
+        const cf A[4] = {cf{za.x, za.y}, cf{za.z, za.w}, cf{zb.x, zb.y}, cf{zb.z, zb.w}};
+        if constexpr(MODE == 1) {
+            const f4 wa = ld4(reinterpret_cast<const float *>(a.big_tws + kk)), wb = ld4(reinterpret_cast<const float *>(a.big_tws + kk + 2));
+            const cf W[4] = {cf{wa.x, wa.y}, cf{wa.z, wa.w}, cf{wb.x, wb.y}, cf{wb.z, wb.w}};
+#pragma unroll
+            for(int i = 0; i < 4; ++i) {
+                const f2 bq = ld2(reinterpret_cast<const float *>(z + ((m - kk - i) & (m - 1)))); // Z[m] is Z[0]
+                const float er = A[i].x + bq.x, ei = A[i].y - bq.y;
+                const float dr = A[i].x - bq.x, di = A[i].y + bq.y;
+                const float pr = fmaf(W[i].x, dr, -(W[i].y * di));
+                const float pi = fmaf(W[i].x, di, W[i].y * dr);
+                mag[4 * u + i] = mag2(er + pi, ei - pr) * a.half_coef;
+            }
+        } else {
+#pragma unroll
+            for(int i = 0; i < 4; ++i)
+                mag[4 * u + i] = mag2(A[i].x, A[i].y) * a.half_coef;
+        }
+        const float sl4[4] = {sv.x, sv.y, sv.z, sv.w}, st4v[4] = {st.x, st.y, st.z, st.w};
+        p4_slope_smooth_group<G, TS, FPK>(a, t, u, ts, st4v, sl4, mag);
+    }
+}
+template<int MODE> WF_DEV void p4_big(const TickArgs &a, int t, int kbase, int nb, const cf *z, float *ts, float (&mag)[GBig::P])
+{
+    if(a.mode & WF_MODE_TSMOOTH) {
+        if(a.mode & WF_MODE_FAST_PEAKS)
+            p4_big_impl<MODE, true, true>(a, t, kbase, nb, z, ts, mag);
+        else
+            p4_big_impl<MODE, true, false>(a, t, kbase, nb, z, ts, mag);
+    } else
+        p4_big_impl<MODE, false, false>(a, t, kbase, nb, z, ts, mag);
+}
+
+// grid (parts, spectra): workgroup (part, spec) finishes bins [part * 16384, +16384) of the spectrum's row
+template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_kernel(const TickArgs a)
+{
+    using G = GBig;
+    using RG = RowG<G::T, G::P>;
+    constexpr int RP = G::P;
+    const int t = (int)threadIdx.x;
+    const int lane = t & 63;
+    const int kbase = (int)blockIdx.x * BIG_TP;
+    uint32_t spec = a.stream_base * a.cap_ch + blockIdx.y;
+    if(a.split_ch != 0xffffffffu) // mono mixdown: one channel of every stream per launch, channel 1 first
+        spec = 2u * (a.stream_base + blockIdx.y) + a.split_ch;
+    const uint32_t cap_shift = a.cap_ch - 1;
+    const uint32_t stream = spec >> cap_shift, ch = spec & cap_shift;
+    const bool stereo = (a.mode & WF_MODE_STEREO) != 0;
+    const bool mono_mix = (a.mode & WF_MODE_MONO_MIX) != 0;
+    const uint32_t wpos = a.wpos[stream];
+    const uint32_t sflags = a.stream_flags[stream];
+    const int MO = (int)a.row_bins;
+    const int NB = MO - kbase; // bins of this part (the row helpers skip groups at or beyond it)
+    float *ts = a.tsmooth + (size_t)spec * MO + kbase;
+    float *rows = a.decibels + (size_t)stream * a.out_ch * MO + kbase; // row r of this stream at rows + r * MO
+    const bool paused = (sflags & WF_STREAM_PAUSED) != 0;
+    const bool hidden = (sflags & (WF_STREAM_HIDDEN | WF_STREAM_PAUSED)) != 0;
+    const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0 || paused;
+    // the facts of the silence state machine (reference :63-95), as in split mode
+    const uint32_t s0 = stream * a.cap_ch;
+    const uint32_t vin0 = a.verdict_in[s0], vin1 = a.cap_ch > 1 ? a.verdict_in[s0 + 1u] : 0u;
+    const bool nz0 = !hidden && a.big_nz[s0] != 0u;
+    const bool nz1 = a.cap_ch > 1 && !hidden && a.big_nz[s0 + 1u] != 0u;
+    const bool below0 = vin0 == 0u;
+    const bool below1 = stereo ? (vin1 == 0u) : (vin0 == 0u); // mono display: channel 1 inspects row 0 too (reference :81)
+    StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nz0, nz1, below0, below1);
+    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const bool underflow = !(sflags & WF_STREAM_WRAPPED) && (wpos - a.blu_n) < delay; // reference :55-61
+    if(underflow) {
+        plan.process0 = plan.process1 = false;
+        plan.last_silent = was_silent;
+    }
+    const bool process = !hidden && (ch == 0 ? plan.process0 : plan.process1);
+    const bool do_db = !hidden && !plan.last_silent; // reference :138-139
+
+    float mag[RP];
+#pragma unroll
+    for(int i = 0; i < RP; ++i)
+        mag[i] = 0.0f;
+    if(process)
+        p4_big<MODE>(a, t, kbase, NB, a.big_z + (size_t)spec * a.big_l, ts, mag);
+    else if(do_db && (!(mono_mix && ch == 1) || underflow)) // skipped channel of a live stream: its stale row is re-dBFS'ed
+        load_row<RG, true>(rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
+
+    // hidden / capture timeout: reset branch (reference :34-48)
+    if(hidden && !was_silent) {
+        if(a.mode & WF_MODE_TSMOOTH)
+            fill_row<RG, true>(ts, t, 0.0f, NB);
+        if(ch < (stereo ? 2u : 1u)) {
+            fill_row<RG, true>(rows + (size_t)ch * MO, t, a.db_min, NB);
+            if(a.out_ch > a.cap_ch)
+                fill_row<RG, true>(rows + (size_t)MO, t, a.db_min, NB);
+        }
+    }
+    // mono mixdown (reference :150-154): channel 1 ran a launch ahead and left its magnitudes in m_decibels[1]
+    if(mono_mix) {
+        if(ch == 1) {
+            if(process)
+                store_row<RG, true>(rows + (size_t)MO, t, mag, NB);
+        } else if(do_db) {
+            float o[RP];
+#pragma unroll
+            for(int i = 0; i < RP; ++i)
+                o[i] = 0.0f;
+            load_row<RG, true>(rows + (size_t)MO, t, o, NB);
+#pragma unroll
+            for(int i = 0; i < RP; ++i)
+                mag[i] = (mag[i] + o[i]) * 0.5f;
+        }
+    }
+    const bool have_row = do_db && !(mono_mix && ch == 1);
+    const bool dup_row = have_row && (a.out_ch > a.cap_ch);
+    float d[RP];
+    bool exceeds = false;
+    if(have_row) {
+        p4_db<RG, true>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp, NB, kbase);
+#pragma unroll
+        for(int i = 0; i < RP; ++i)
+            exceeds = exceeds || (4 * (t + G::T * (i / 4)) < NB && d[i] > a.silent_floor);
+        store_row<RG, true, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
+        if(dup_row)
+            store_row<RG, true, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
+    } else if(!(hidden && !was_silent)) // row untouched this tick (the reset branch leaves DB_MIN everywhere: below)
+        exceeds = (ch == 0 ? vin0 : vin1) != 0u;
+    if(ch == 0 && t == 0)
+        a.flags_out[stream] = paused ? sflags
+                                     : ((sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED)) |
+                                        ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u));
+    // what the next tick's silence test will find in this channel's row (reference :78-86: any value > floor - 10?)
+    if(__any(exceeds) && lane == 0)
+        atomicOr(a.verdict_out + spec, 1u);
+    if(t == 0)
+        a.verdict_clear[spec] = 0u;
+}
+
+// ---- render-time outputs from the finished rows --------------------------------------------------------------------
+// One workgroup per displayed row: the row is parked in LDS, then bars (one wavefront per bar over the flat
+// coefficient tables, BarArgs) or curve points (curve_row_stream); the Gaussian filter stages its inputs behind the row.
+__global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
+{
+    using G = GBig;
+    constexpr int T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    float *dbl = reinterpret_cast<float *>(big_smem);
+    const int t = (int)threadIdx.x;
+    const BarArgs &b = a.bar;
+    const uint32_t stream = a.stream_base + blockIdx.x / b.disp_ch, r = blockIdx.x % b.disp_ch;
+    const int MO = (int)a.row_bins;
+    const float *row = a.decibels + ((size_t)stream * a.out_ch + r) * MO;
+    for(int i = 4 * t; i < MO; i += 4 * T)
+        st4(dbl + i, ld4(row + i));
+    if(t == 0)
+        dbl[MO] = dbl[MO + 1] = 0.0f; // the Catmull-Rom taps of the last points (curve_row_stream)
+    __syncthreads();
+    float *out_row = b.out + ((size_t)stream * b.disp_ch + r) * b.num_bars;
+    if(b.curve) {
+        curve_row_stream<G>(b, true, dbl, dbl, t, out_row, nullptr, [] { __syncthreads(); });
+        return;
+    }
+    const int n = b.num_bars;
+    const bool filtered = b.gauss_radius > 0;
+    const int pad = b.gauss_radius - 1, size = 2 * b.gauss_radius - 1;
+    float *vp = dbl + b.stage_off;  // [pad | n | pad]
+    float *wl = vp + n + 2 * pad;   // [size]
+    if(filtered) {
+        for(int i = t; i < pad; i += T) {
+            vp[i] = 0.0f;
+            vp[pad + n + i] = 0.0f;
+        }
+        for(int i = t; i < size; i += T)
+            wl[i] = b.gauss[i];
+    }
+    const int wave = t >> 6, lane = t & 63;
+    for(int bar = wave; bar < n; bar += T / 64) {
+        const int e0 = b.off[bar], e1 = b.off[bar + 1];
+        float acc = 0.0f;
+        for(int e = e0 + lane; e < e1; e += 64)
+            acc = fmaf(dbl[b.bin[e]], b.coef[e], acc);
+#pragma unroll
+        for(int m = 32; m >= 1; m >>= 1)
+            acc += __shfl_xor(acc, m, 64);
+        if(lane == 0) {
+            const float v = acc / (float)b.count[bar];
+            if(filtered)
+                vp[pad + bar] = v;
+            else
+                emit_output(b, bar, v, out_row, nullptr);
+        }
+    }
+    if(filtered) {
+        __syncthreads();
+        for(int o = t; o < n; o += T) {
+            float sum = 0.0f;
+            for(int tap = 0; tap < size; ++tap)
+                sum = fmaf(vp[o + tap], wl[tap], sum);
+            emit_output(b, o, sum / b.gauss_wsum[o], out_row, nullptr);
+        }
+    }
+}
+
+} // namespace wf

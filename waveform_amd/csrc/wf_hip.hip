@@ -14,6 +14,7 @@
 #include "wf_hip.h"
 #include "wf_host_tables.hpp"
 #include "wf_kernels.hpp"
+#include "wf_big.hpp"
 #include "wf_meter.hpp"
 #include "wf_rms.hpp"
 #include "wf_wave.hpp"
@@ -89,6 +90,11 @@ struct wf_hip {
     bool blu = false;
     uint32_t geom_n = 0;             // the fft size whose geometry runs the batch (N itself for the power-of-two sizes >= 1024)
     wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr;
+    // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
+    uint32_t big_l = 0, big_rows = 0;
+    wf::cf *d_big_v = nullptr, *d_big_z = nullptr, *d_big_tw = nullptr, *d_big_tws = nullptr;
+    uint32_t *d_big_nz = nullptr;
+    size_t big_out_lds = 0;          // dynamic LDS of big_outputs_kernel
     float *d_bars = nullptr;
     float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
@@ -330,6 +336,98 @@ template<class G, int SPW> int setup_launch(wf_hip *h)
     return setup_launch_impl<G, SPW, false>(h);
 }
 
+// FFT sizes whose transform does not fit a CU's LDS (wf_big.hpp): columns -> rows (twice for Bluestein) -> epilogue -> outputs
+template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
+{
+    const uint32_t n_spec = a0.stream_count * a0.cap_ch;
+    hipStream_t st = h->launch_stream;
+    wf::BigArgs b{};
+    b.ring = a0.ring;
+    b.wpos = a0.wpos;
+    b.delay_stream = a0.delay_stream;
+    b.ring_mask = a0.ring_mask;
+    b.ring_stride = a0.ring_stride;
+    b.delay = a0.delay;
+    b.cap_ch = a0.cap_ch;
+    b.n = h->N;
+    b.L = h->big_l;
+    b.window = a0.window;
+    b.blu_a = h->d_blu_a;
+    b.blu_b = h->d_blu_b;
+    b.tw_big = h->d_big_tw;
+    b.tw1 = a0.tw1;
+    b.tw2 = a0.tw2;
+    b.v = h->d_big_v;
+    b.z = h->d_big_z;
+    b.nz = h->d_big_nz;
+    b.spec_base = a0.stream_base * a0.cap_ch;
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_big_nz + b.spec_base, 0, (size_t)n_spec * sizeof(uint32_t), st));
+    const dim3 gcol(wf::BIG_L2 / 512u, n_spec), grow(L1, n_spec);
+    const size_t rows_lds = wf::big_rows_lds_bytes<L1>();
+    if(h->blu) {
+        hipLaunchKernelGGL((wf::big_columns_kernel<L1, 1>), gcol, dim3(256), 0, st, b);
+        hipLaunchKernelGGL((wf::big_rows_kernel<L1>), grow, dim3(wf::GBig::T), rows_lds, st, b);
+        hipLaunchKernelGGL((wf::big_columns_kernel<L1, 2>), gcol, dim3(256), 0, st, b);
+        hipLaunchKernelGGL((wf::big_rows_kernel<L1>), grow, dim3(wf::GBig::T), rows_lds, st, b);
+    } else {
+        hipLaunchKernelGGL((wf::big_columns_kernel<L1, 0>), gcol, dim3(256), 0, st, b);
+        hipLaunchKernelGGL((wf::big_rows_kernel<L1>), grow, dim3(wf::GBig::T), rows_lds, st, b);
+    }
+    const uint32_t parts = (h->M + (uint32_t)wf::BIG_TP - 1u) / (uint32_t)wf::BIG_TP;
+    // mono mixdown: channel 1 of every stream, then channel 0 (TickArgs::split_ch)
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
+        wf::TickArgs a = a0;
+        a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(parts, h->split_mono ? a.stream_count : n_spec);
+        if(h->blu)
+            hipLaunchKernelGGL((wf::big_epilogue_kernel<2>), grid, dim3(wf::GBig::T), 0, st, a);
+        else
+            hipLaunchKernelGGL((wf::big_epilogue_kernel<1>), grid, dim3(wf::GBig::T), 0, st, a);
+    }
+    if(a0.bar.out != nullptr)
+        hipLaunchKernelGGL(wf::big_outputs_kernel, dim3(a0.stream_count * a0.bar.disp_ch), dim3(wf::GBig::T), h->big_out_lds, st, a0);
+    WF_HIP_TRY(h, hipGetLastError());
+    return WF_HIP_OK;
+}
+
+void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool)
+{
+    switch(h->big_rows) {
+    case 2: (void)launch_tick_big_l<2>(h, a); break;
+    case 4: (void)launch_tick_big_l<4>(h, a); break;
+    default: (void)launch_tick_big_l<8>(h, a); break;
+    }
+}
+
+template<int L1> int setup_big_rows(wf_hip *h)
+{
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_rows_kernel<L1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)wf::big_rows_lds_bytes<L1>()));
+    return WF_HIP_OK;
+}
+
+int setup_launch_big(wf_hip *h)
+{
+    int rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
+    if(rc)
+        return rc;
+    if(h->big_out_lds)
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_outputs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)h->big_out_lds));
+    h->launch = &launch_tick_big;
+    h->split = true;
+    h->flag_bufs = 3;
+    char name[160];
+    if(h->blu)
+        snprintf(name, sizeof(name), "big_{columns,rows,epilogue}_kernel<N=%u by Bluestein over %u = %u x 16384 complex points through device memory>",
+                 h->N, h->big_l, h->big_rows);
+    else
+        snprintf(name, sizeof(name), "big_{columns,rows,epilogue}_kernel<N=%u: %u = %u x 16384 complex points through device memory>", h->N,
+                 h->big_l, h->big_rows);
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
 uint32_t next_pow2(uint32_t v)
 {
     uint32_t p = 1;
@@ -414,7 +512,15 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.blu_a = h->d_blu_a;
         a.blu_b = h->d_blu_b;
         a.blu_n = h->N;
-        a.half_coef = (2.0f / h->tab.window_sum) / (float)(h->geom_n / 2); // |c_k| / L, times mag_coefficient
+        a.half_coef = (2.0f / h->tab.window_sum) / (float)(h->big_l ? h->big_l : h->geom_n / 2); // |c_k| / L, times mag_coefficient
+    }
+    if(h->big_l) {
+        a.big_z = h->d_big_z;
+        a.big_tws = h->d_big_tws;
+        a.big_nz = h->d_big_nz;
+        a.big_m = h->blu ? 0u : h->N / 2;
+        a.big_l = h->big_l;
+        a.blu_n = h->N; // the window length the underflow test compares with
     }
     a.g = wf::gravity_for(h->cfg, p->seconds);
     a.g2 = 1.0f - a.g;
@@ -641,7 +747,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(rc == WF_HIP_ERR_UNSUPPORTED && cfg->waveform)
         return fail(nullptr, rc, "waveform display: width %u above 8192 points is not implemented", cfg->width);
     if(rc == WF_HIP_ERR_UNSUPPORTED)
-        return fail(nullptr, rc, "fft_size %u: implemented are the powers of two 128..32768 and every other multiple of 16 from 128 to 10912", cfg->fft_size);
+        return fail(nullptr, rc, "fft_size %u: implemented is every multiple of 16 from 128 to 65536 (the reference's own range)", cfg->fft_size);
     if(rc)
         return fail(nullptr, rc, "invalid configuration");
     const int ndev = wf_hip_device_count();
@@ -667,7 +773,9 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     {
         const uint32_t L = (cfg->meter || cfg->waveform) ? 0u : wf::bluestein_length(cfg->fft_size);
         h->blu = L != 0;
-        h->geom_n = L ? 2 * L : std::max(h->N, 1024u);
+        h->big_l = L > 16384u ? L : (!L && h->N == 65536u) ? 32768u : 0u;
+        h->big_rows = h->big_l / 16384u;
+        h->geom_n = h->big_l ? 32768u : L ? 2 * L : std::max(h->N, 1024u); // big: the row transform's geometry
     }
     if(cfg->waveform) {
         // rows of `width` points; the ring holds the history the points are picked from (+ the width zeros of update())
@@ -764,6 +872,11 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     // as well, channel 1 a launch ahead of channel 0
     h->split_mono = h->geom_n >= 32768 && cfg->capture_channels == 2 && !cfg->stereo;
     want_split = want_split || h->split_mono;
+    if(h->big_l) { // the epilogue couples the channels through the rotating verdict words, whatever the channel layout
+        want_split = true;
+        if(n_spec > 65535u)
+            return bail(fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: at most 65535 spectra per batch on the large-transform path", h->N));
+    }
     h->flag_bufs = want_split ? 3 : 1;
     WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->flag_bufs * h->n_streams));
     if(want_split)
@@ -811,12 +924,12 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 return bail(fail(h, WF_HIP_ERR_INVALID, "curve display: no point table for width %u at fft_size %u", cfg->width, h->N));
             h->out_steps = cl.steps;
             h->curve_catrom = !cl.x.empty();
-            h->stream_steps = cl.steps > kmax; // wider than a thread's registers hold: points are finished as they are produced
+            h->stream_steps = cl.steps > kmax || h->big_l != 0; // wider than a thread's registers hold (always on the large-transform path, whose outputs have a kernel of their own): points are finished as they are produced
             WF_CREATE_TRY(upload(h, &h->d_cur_coef, cl.coef));
             WF_CREATE_TRY(upload(h, &h->d_cur_base, cl.base));
             WF_CREATE_TRY(upload(h, &h->d_cur_x, cl.x));
             WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
-        } else {
+        } else if(h->big_l == 0) { // (the large-transform path reduces its bars from the flat tables, one wavefront per bar)
             wf::BarLaneTables lanes;
             if(wf::bar_segments(h->tab, threads, points / 4 + 1, lanes)) {
                 h->bar_segs = lanes.num_segs;
@@ -829,8 +942,21 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
             }
         }
-        size_t chunk_cap = lds_floats - h->M; // LDS scratch for the products: what is left behind the dB row
-        if(h->tab.gauss_radius > 0) {
+        size_t chunk_cap = lds_floats > h->M ? lds_floats - h->M : 0; // LDS scratch for the products: what is left behind the dB row
+        if(h->big_l) {
+            // big_outputs_kernel: the whole row in LDS, two guard zeros, then the filter's staging
+            const size_t staged = h->tab.gauss_radius > 0 ? (size_t)h->num_bars + 2 * (size_t)(h->tab.gauss_radius - 1) + h->tab.gauss.size() : 0;
+            h->bar_stage_off = (int)h->M + 2;
+            h->big_out_lds = (((size_t)h->M + 2 + staged) * sizeof(float) + 15) & ~(size_t)15;
+            if(h->big_out_lds > 160u * 1024u)
+                return bail(fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u with filter_mode gauss over %u outputs: row + staging exceed a CU's LDS", h->N,
+                                 h->num_bars));
+            if(h->tab.gauss_radius > 0) {
+                WF_CREATE_TRY(upload(h, &h->d_gauss, h->tab.gauss));
+                WF_CREATE_TRY(upload(h, &h->d_gauss_wsum, h->tab.gauss_wsum));
+                WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+            }
+        } else if(h->tab.gauss_radius > 0) {
             // staged in the spectrum's LDS: the row with radius-1 zeros on either side, then the weights
             const size_t staged = (size_t)h->num_bars + 2 * (size_t)(h->tab.gauss_radius - 1) + h->tab.gauss.size();
             if(h->stream_steps) {
@@ -863,7 +989,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             WF_CREATE_TRY(upload(h, &h->d_gauss_wsum, h->tab.gauss_wsum));
             WF_CREATE_HIP(hipStreamSynchronize(h->stream));
         }
-        if(h->bar_segs == 0 && !h->curve) { // chunked form: a chunk holds at least one whole bar
+        if(h->bar_segs == 0 && !h->curve && h->big_l == 0) { // chunked form: a chunk holds at least one whole bar
             int longest = 0;
             for(uint32_t b = 0; b < h->num_bars; ++b)
                 longest = std::max(longest, h->tab.bar_off[(size_t)b + 1] - h->tab.bar_off[(size_t)b]);
@@ -885,6 +1011,10 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         wf::build_twiddles(G::M, G::R1, G::R2, G::R3, tw1, tw2, tws);
         h->waves_per_spectrum = G::T / 64;
         // the channels of a stream share a workgroup (silence state machine, mono mixdown)
+        if(h->big_l) {
+            if constexpr(G::N == 32768)
+                setup_rc = setup_launch_big(h);
+        } else
 #ifdef WF_GEOM_ONLY // development builds: no Bluestein instantiations
         if(h->blu) {
             setup_rc = fail(h, WF_HIP_ERR_UNSUPPORTED, "development build without the Bluestein kernels");
@@ -946,6 +1076,20 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_blu_b, tb));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
+    if(h->big_l) {
+        std::vector<wf::cfloat> twb, twsb;
+        wf::build_big_twiddles(h->big_l, h->big_rows, h->blu ? 0u : h->N, twb, twsb);
+        std::vector<wf::cf> t1(twb.size()), t2(twsb.size());
+        std::memcpy(t1.data(), twb.data(), t1.size() * sizeof(wf::cf));
+        if(!t2.empty())
+            std::memcpy(t2.data(), twsb.data(), t2.size() * sizeof(wf::cf));
+        WF_CREATE_TRY(upload(h, &h->d_big_tw, t1));
+        WF_CREATE_TRY(upload(h, &h->d_big_tws, t2));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_big_v, n_spec * h->big_l));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_l));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_big_nz, n_spec));
+    }
     {
         // lanes (see struct wf_hip): two slices once each still fills the chip a couple of times over.  Measured on MI355X
         // (cfg3, 8192 spectra per tick, back-to-back ticks): 1 lane 66 us per tick, 2 lanes 58 us.  WF_HIP_LANES overrides.
@@ -954,6 +1098,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         if(const char *e = std::getenv("WF_HIP_LANES"))
             lanes = std::atoi(e);
         lanes = std::max(1, std::min({lanes, (int)wf_hip::MAX_LANES, (int)h->n_streams}));
+        if(h->big_l)
+            lanes = 1; // a handful of workgroups of a whole CU each: nothing to overlap
 #ifdef WF_PHASE_TIMING
         lanes = 1;
 #endif
@@ -1386,6 +1532,8 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         return WF_HIP_OK;
     }
     const bool mono_mix_rows = !h->cfg.stereo && h->cap_ch > 1;
+    if((p->flags & WF_HIP_TICK_NO_DECIBELS) && h->big_l)
+        return fail(h, WF_HIP_ERR_UNSUPPORTED, "WF_HIP_TICK_NO_DECIBELS is not available at fft_size %u (the outputs are derived from the stored rows)", h->N);
     if((p->flags & WF_HIP_TICK_NO_DECIBELS) && !mono_mix_rows && h->d_stale_row == nullptr) {
         if(h->cfg.floor_db - 10 >= 0)
             return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS needs floor_db < 10 (a skipped channel's row must be negative)");

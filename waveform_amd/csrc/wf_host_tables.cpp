@@ -523,7 +523,7 @@ int build_host_tables(const wf_config &cfg, HostTables &out)
     }
     if(cfg.fft_size < 128 || (cfg.fft_size & 15u)) // the reference raises / aligns such values itself (src/source.cpp:562-565)
         return WF_HIP_ERR_UNSUPPORTED;
-    if(is_pow2(cfg.fft_size) ? cfg.fft_size > 32768 : bluestein_length(cfg.fft_size) == 0)
+    if(cfg.fft_size > 65536u) // the reference's own ceiling ("enable large FFT", src/source.cpp:349, :359-363)
         return WF_HIP_ERR_UNSUPPORTED;
     if(cfg.capture_channels < 1 || cfg.capture_channels > 2 || cfg.sample_rate == 0)
         return WF_HIP_ERR_INVALID;
@@ -551,7 +551,27 @@ uint32_t bluestein_length(uint32_t n)
     uint32_t L = 512;
     while((uint64_t)L * 2 < (uint64_t)n * 3) // L >= 3n/2
         L <<= 1;
-    return L <= 16384u ? L : 0u; // 16384 complex points = the 32768 geometry
+    return L; // <= 16384 complex points: inside one workgroup (the 32768-sample geometry); 32768 .. 131072: wf_big.hpp
+}
+
+void build_big_twiddles(uint32_t L, uint32_t rows, uint32_t real_n, std::vector<cfloat> &tw_big, std::vector<cfloat> &tws_big)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    const uint32_t L2 = L / rows;
+    tw_big.resize((size_t)L);
+    for(uint32_t k1 = 0; k1 < rows; ++k1)
+        for(uint32_t n2 = 0; n2 < L2; ++n2) {
+            const double a = -two_pi * (double)(((uint64_t)n2 * k1) % L) / (double)L;
+            tw_big[(size_t)k1 * L2 + n2] = {(float)std::cos(a), (float)std::sin(a)};
+        }
+    tws_big.clear();
+    if(real_n) { // W_n^k for the real split of the packed n-sample transform
+        tws_big.resize((size_t)real_n / 2);
+        for(uint32_t k = 0; k < real_n / 2; ++k) {
+            const double a = -two_pi * (double)k / (double)real_n;
+            tws_big[k] = {(float)std::cos(a), (float)std::sin(a)};
+        }
+    }
 }
 
 namespace {

@@ -93,6 +93,9 @@ struct BluesteinTables {
 };
 // 0 when n is a power of two (no Bluestein needed) or too long for the largest geometry
 uint32_t bluestein_length(uint32_t n);
+// transforms of L = rows * 16384 complex points done in two steps (wf_big.hpp): tw_big[k1][n2] = W_L^(n2 k1); tws_big[k] =
+// W_real_n^k, the real-split twiddles of a packed real_n-sample transform (real_n == 0: not built)
+void build_big_twiddles(uint32_t L, uint32_t rows, uint32_t real_n, std::vector<cfloat> &tw_big, std::vector<cfloat> &tws_big);
 void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out);
 
 // get_gravity(seconds), src/source.hpp:301-312

@@ -171,6 +171,11 @@ struct TickArgs {
     const cf *blu_b;           // [M] FFT_M of the chirp
     uint32_t blu_n;
     uint32_t row_bins;         // bins per output / state row (M >> DEC for the power-of-two paths)
+    // transforms beyond a CU's LDS (wf_big.hpp): the finished transform in device memory and what the epilogue needs with it
+    const cf *big_z;           // [n_spec][big_l] rows' output, natural order
+    const cf *big_tws;         // [big_m] W_(2 big_m)^k (real split of the 65536-sample transform)
+    const uint32_t *big_nz;    // [n_spec] != 0: the window has a non-zero sample
+    uint32_t big_m, big_l;     // complex points of the packed real transform; complex points per transform (scratch stride)
     BarArgs bar;
     unsigned long long *phase_clock; // development aid (builds with -DWF_PHASE_TIMING): s_memtime stamps per workgroup
 };
@@ -1026,14 +1031,15 @@ WF_DEV void p4_split_smooth_dec(const TickArgs &a, int t, const cf *lds, float *
 // final m_decibels content, stored by store_row()
 // GUARD (rows shorter than T * P bins: the Bluestein path): groups of four bins at or beyond `nb` are skipped
 template<class G, bool GUARD = false>
-WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P], float vol_comp, int nb = 0)
+WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P], float vol_comp, int nb = 0, int kbase = 0)
 {
     constexpr int T = G::T, P = G::P;
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
-        const int k0 = 4 * (t + T * u);
+        int k0 = 4 * (t + T * u);
         if(GUARD && k0 >= nb)
             continue;
+        k0 += kbase; // rows longer than T * P bins are finished in parts (wf_big.hpp): the bin index of the whole row
         WF_UNROLL
         for(int i = 0; i < 4; ++i)
             d[4 * u + i] = dbfs(mag[4 * u + i], a.db_min);
