@@ -251,7 +251,7 @@ long wfemu_host_table(const wf_config *cfg, int which, float seconds, float *out
 }
 
 // the per-thread segment form of the bar tables (wf::bar_segments) for `threads` threads per spectrum.
-// which: 0 lane coef [blocks][threads][4], 1 lane bin (as float), 2 bar_seg (as float), 3 scalars {num_segs, blocks}
+// which: 0 lane coef [blocks][threads][4], 1 lane base [threads] (as float), 2 bar_seg (as float), 3 scalars {num_segs, blocks}
 // returns the element count, -1000 if the segment form does not exist for this configuration, other negatives on error
 long wfemu_bar_lanes(const wf_config *cfg, int threads, int max_blocks, int which, float *out, long cap)
 {
@@ -265,7 +265,7 @@ long wfemu_bar_lanes(const wf_config *cfg, int threads, int max_blocks, int whic
     std::vector<float> v;
     switch(which) {
     case 0: v = lanes.coef; break;
-    case 1: v.assign(lanes.bin.begin(), lanes.bin.end()); break;
+    case 1: v.assign(lanes.base.begin(), lanes.base.end()); break;
     case 2: v.assign(lanes.bar_seg.begin(), lanes.bar_seg.end()); break;
     case 3: v = {(float)lanes.num_segs, (float)lanes.blocks}; break;
     default: return -1;

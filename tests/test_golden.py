@@ -74,7 +74,8 @@ SPECTRUM_DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4
                    "hide_show", "muted_packets", "timeout_spectrum", "split_8192_half_silent", "small_512_stereo_bars",
                    "small_128_single_dup_curve", "large_32768_single_tv", "any_800_mono_mix_bars", "any_4160_stereo_silence",
                    "sync_spectrum_2048", "sync_spectrum_4096_normalize_mono", "normalize_4096_stereo", "normalize_mono_muted_ragged",
-                   "normalize_long_1024", "curve_4096_lanczos_gauss", "plugin_defaults_4096", "curve_4096_catrom_wide_gauss"]
+                   "normalize_long_1024", "curve_4096_lanczos_gauss", "plugin_defaults_4096", "curve_4096_catrom_wide_gauss",
+                   "huge_65536_stereo_bars", "huge_65536_mono_mix_tv_curve", "any_48000_single_dup"]
 DROPIN = SPECTRUM_DROPIN + [
     # WAVSourceHIP::tick_meter
     "meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-( time timeout 1500 python -m pytest tests -m gpu -x -q -n 4 2>&1 | tail -12 ) > gpurun_out/exp.txt 2>&1
-python tools/quick_bench.py 65536:256 48000:256 16400:256 32768:512 >> gpurun_out/exp.txt 2>&1
+for rep in 1 2; do
+for V in g1024 g1024w4 g1024t0; do WF_HIP_LIB=variants/lib_$V.so python tools/quick_bench.py 1024:16384 2>/dev/null | cut -c1-30,90-200; done
+done > gpurun_out/exp.txt 2>&1
+for V in g1024 g1024w4; do WF_HIP_LIB=variants/lib_$V.so python tools/quick_bench.py 512:16384 256:16384 128:16384 2>/dev/null | cut -c1-30,90-200; done >> gpurun_out/exp.txt 2>&1

@@ -139,7 +139,7 @@ struct wf_hip {
     float *d_cur_coef = nullptr, *d_gauss = nullptr, *d_gauss_wsum = nullptr;
     int *d_cur_base = nullptr;
     float *d_lane_coef = nullptr;
-    int *d_lane_bin = nullptr, *d_bar_seg = nullptr, *d_seg_group = nullptr;
+    int *d_lane_base = nullptr, *d_bar_seg = nullptr, *d_seg_group = nullptr;
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;
@@ -477,7 +477,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.chunk = h->d_bar_chunk;
         a.bar.num_chunks = h->bar_chunks;
         a.bar.lane_coef = h->d_lane_coef;
-        a.bar.lane_bin = h->d_lane_bin;
+        a.bar.lane_base = h->d_lane_base;
         a.bar.bar_seg = h->d_bar_seg;
         a.bar.seg_group = h->d_seg_group;
         a.bar.num_segs = h->bar_segs;
@@ -936,7 +936,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 h->bar_blocks = lanes.blocks;
                 h->out_steps = 1;
                 WF_CREATE_TRY(upload(h, &h->d_lane_coef, lanes.coef));
-                WF_CREATE_TRY(upload(h, &h->d_lane_bin, lanes.bin));
+                WF_CREATE_TRY(upload(h, &h->d_lane_base, lanes.base));
                 WF_CREATE_TRY(upload(h, &h->d_bar_seg, lanes.bar_seg));
                 WF_CREATE_TRY(upload(h, &h->d_seg_group, lanes.seg_group));
                 WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
@@ -1094,7 +1094,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         // lanes (see struct wf_hip): two slices once each still fills the chip a couple of times over.  Measured on MI355X
         // (cfg3, 8192 spectra per tick, back-to-back ticks): 1 lane 66 us per tick, 2 lanes 58 us.  WF_HIP_LANES overrides.
         const uint32_t wgs = (uint32_t)(n_spec / (h->split ? 1u : 2u));
-        int lanes = wgs >= 2048u ? 2 : 1;
+        int lanes = wgs >= 1024u ? 2 : 1; // (1024: the 32768-sample geometry's 512 stereo streams, a CU per workgroup: +7 %; 3 and 4 lanes: -1..-4 % everywhere)
         if(const char *e = std::getenv("WF_HIP_LANES"))
             lanes = std::atoi(e);
         lanes = std::max(1, std::min({lanes, (int)wf_hip::MAX_LANES, (int)h->n_streams}));

@@ -286,6 +286,7 @@ void build_bars(const wf_config &cfg, HostTables &t)
 
     // ---- composite per-bar kernels for the device (see BarArgs in wf_tick_phases.hpp) ---------------------------------
     const intmax_t M = (intmax_t)(cfg.fft_size / 2);
+    t.bar_rows_bins = (int)M;
     t.bar_off.assign((size_t)num_bars + 1, 0);
     size_t k = 0; // running sample index (interpolating modes)
     for(int i = 0; i < num_bars; ++i) {
@@ -346,48 +347,62 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
     out = BarLaneTables{};
     if(t.num_bars <= 0 || t.num_bars > threads)
         return false;
+    const int M = (int)t.bar_rows_bins;
+    // A bar's entries sit on consecutive bins [lo, lo + len).  Segments are cut at bins that are multiples of 4, counted
+    // from lo rounded down (the up to three bins before lo get coefficient 0), so that a thread reads its bins as 16-byte
+    // words of the row parked in LDS.
+    auto span = [&](int b, int &first, int &len) {
+        const int o = t.bar_off[(size_t)b];
+        len = t.bar_off[(size_t)b + 1] - o;
+        const int lo = len > 0 ? t.bar_bin[(size_t)o] : 0;
+        first = lo & ~3;
+        return lo - first; // leading bins with coefficient 0
+    };
     auto count_for = [&](int L) {
         long n = 0;
         for(int b = 0; b < t.num_bars; ++b) {
-            const int len = t.bar_off[(size_t)b + 1] - t.bar_off[(size_t)b];
-            n += len == 0 ? 1 : (len + L - 1) / L;
+            int first, len;
+            const int lead = span(b, first, len);
+            n += len == 0 ? 1 : (lead + len + L - 1) / L;
         }
         return n;
     };
     int L = 4;
     while(count_for(L) > threads) // smallest multiple of 4 whose segment count fits the threads (num_bars <= threads)
         L += 4;
-    if(L / 4 > max_blocks)
+    if(L / 4 > max_blocks || L > M)
         return false;
-    std::vector<int> seg_start, seg_len;
+    out.blocks = L / 4;
+    out.coef.assign((size_t)out.blocks * threads * 4, 0.0f);
+    out.base.assign((size_t)threads, 0);
+    int s = 0;
     for(int b = 0; b < t.num_bars; ++b) {
-        out.bar_seg.push_back((int)seg_start.size());
-        const int o = t.bar_off[(size_t)b], len = t.bar_off[(size_t)b + 1] - o;
-        if(len == 0) {
-            seg_start.push_back(o);
-            seg_len.push_back(0);
-        }
-        for(int k = 0; k < len; k += L) {
-            seg_start.push_back(o + k);
-            seg_len.push_back(len - k < L ? len - k : L);
+        out.bar_seg.push_back(s);
+        int first, len;
+        const int lead = span(b, first, len);
+        const int o = t.bar_off[(size_t)b];
+        const int segs = len == 0 ? 1 : (lead + len + L - 1) / L;
+        for(int g = 0; g < segs; ++g, ++s) {
+            // bins [start, start + L) of the row; a segment that would reach past the row moves down (its coefficients with it)
+            int start = first + g * L;
+            if(start + L > M)
+                start = M - L;
+            out.base[(size_t)s] = start;
+            for(int k = 0; k < L; ++k) {
+                const int bin = start + k, e = bin - (first + lead); // entry index within the bar
+                // every bin belongs to exactly one segment of the bar: the one whose nominal range [first + g L, +L) holds it
+                const bool mine = bin >= first + g * L && bin < first + (g + 1) * L;
+                if(mine && e >= 0 && e < len)
+                    out.coef[((size_t)(k / 4) * threads + s) * 4 + (size_t)(k % 4)] = t.bar_coef[(size_t)o + e];
+            }
         }
     }
-    out.bar_seg.push_back((int)seg_start.size());
-    out.num_segs = (int)seg_start.size();
+    out.bar_seg.push_back(s);
+    out.num_segs = s;
     out.seg_group.assign((size_t)threads, 0);
     for(int b = 0; b < t.num_bars; ++b)
         for(int k = out.bar_seg[(size_t)b]; k < out.bar_seg[(size_t)b + 1]; k += 8)
             out.seg_group[(size_t)k] = std::min(8, out.bar_seg[(size_t)b + 1] - k);
-    out.blocks = L / 4;
-    // lane-major: block c of lane s at [(c * threads + s) * 4, +4)  ->  one coalesced 16-byte load per lane and block
-    out.coef.assign((size_t)out.blocks * threads * 4, 0.0f);
-    out.bin.assign((size_t)out.blocks * threads * 4, 0);
-    for(int s = 0; s < out.num_segs; ++s)
-        for(int k = 0; k < seg_len[(size_t)s]; ++k) {
-            const size_t dst = ((size_t)(k / 4) * threads + s) * 4 + (size_t)(k % 4);
-            out.coef[dst] = t.bar_coef[(size_t)seg_start[(size_t)s] + k];
-            out.bin[dst] = t.bar_bin[(size_t)seg_start[(size_t)s] + k];
-        }
     return true;
 }
 

@@ -26,6 +26,7 @@ struct HostTables {
     // bars, or the points of the curve (cfg.curve): "outputs" of the render-time reduction
     int num_bars = 0;                    // m_num_bars, or m_width in curve mode
     std::vector<float> interp_indices;   // m_interp_indices after init_interp()
+    int bar_rows_bins = 0;               // bins per row the bar tables index (fft_size / 2)
     std::vector<int> band_widths;        // m_band_widths
     std::vector<float> interp_weights;   // m_interp_kernel.weights (Lanczos: 8/sample, Catmull-Rom: 4/sample)
     int interp_radius = 0;               // m_interp_kernel.radius
@@ -62,8 +63,8 @@ std::vector<int> bar_chunks(const HostTables &t, size_t cap_floats);
 // segments [bar_seg[b], bar_seg[b+1]); coefficient/bin tables re-laid lane-major and zero-padded.  false if the bars
 // outnumber the threads or the segments would be longer than the kernel holds in registers.
 struct BarLaneTables {
-    std::vector<float> coef;  // [blocks][threads][4]
-    std::vector<int> bin;     // [blocks][threads][4]
+    std::vector<float> coef;  // [blocks][threads][4] lane-major: block c of segment s at [(c * threads + s) * 4, +4)
+    std::vector<int> base;    // [threads] first bin of the segment's 4 * blocks consecutive bins, a multiple of 4
     std::vector<int> bar_seg; // [num_bars + 1]
     std::vector<int> seg_group; // [threads] > 0 where a group of that many (<= 8) consecutive segments of one bar starts
     int num_segs = 0, blocks = 0;

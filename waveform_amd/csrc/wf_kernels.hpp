@@ -74,7 +74,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #define WF_NT_ROWS true // m_decibels rows stored with the non-temporal hint
 #endif
 #ifndef WF_WPS_SMALL
-#define WF_WPS_SMALL 5 // 8-point geometry (N = 1024): 5 waves per SIMD measured +4 % over 4; 6 spills
+#define WF_WPS_SMALL 4 // 8-point geometry (N = 1024): 5 waves per SIMD was +4 % in round 1 (84 VGPRs); with what the kernel has
+                       // learned since (paused streams, underflow, bars-only tracking, lanes) it spilled 36 B per lane at the
+                       // 96-register cap and ran 10 % slower than at 4 (tests/test_cpu_units.py now checks for scratch)
 #endif
 #ifndef WF_WPS_2048
 #define WF_WPS_2048 3

@@ -57,10 +57,11 @@ struct BarArgs {
     const int *chunk;          // [num_chunks + 1] bar ranges whose entries fit the LDS scratch together
     // Usual case (bars <= threads per spectrum): every thread owns one segment of the entries -- near-equal lengths,
     // never straddling a bar (the bars' own lengths differ by two orders of magnitude on a log axis) -- with its
-    // (coefficient, bin) pairs laid lane-major: block c of thread s at [(c*T + s)*4, +4), zero-padded.  Bar b owns
+    // coefficients laid lane-major: block c of thread s at [(c*T + s)*4, +4), zero-padded, for 4 * lane_blocks consecutive
+    // bins from lane_base[s].  Bar b owns
     // segments [bar_seg[b], bar_seg[b+1]).  num_segs == 0: not built, the flat tables above are used chunk by chunk.
     const float *lane_coef;    // [lane_blocks][T][4]
-    const int *lane_bin;       // [lane_blocks][T][4]
+    const int *lane_base;      // [T] first of the segment's 4 * lane_blocks consecutive bins (a multiple of 4: 16-byte LDS reads)
     const int *bar_seg;        // [num_bars + 1]
     const int *seg_group;      // [T] > 0: this segment starts a group of that many (<= 8) consecutive segments of one bar
     int num_segs;
@@ -1204,23 +1205,19 @@ template<class G> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 template<class G> struct BarEntries {
     static constexpr int CMAX = G::P / 4 + 1; // the host builds segments of at most 4 * CMAX entries
     f4 coef[CMAX];
-    int bin[CMAX][4];
+    int base;
 };
 template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be)
 {
     constexpr int T = G::T;
+    be.base = 0;
     if(b.out == nullptr || b.num_segs == 0)
         return;
+    be.base = b.lane_base[t];
     WF_UNROLL
-    for(int c = 0; c < BarEntries<G>::CMAX; ++c) {
-        if(c < b.lane_blocks) { // uniform
-            const int e = (c * T + t) * 4;
-            be.coef[c] = ld4(b.lane_coef + e);
-            const f4 raw = ld4(reinterpret_cast<const float *>(b.lane_bin + e));
-            be.bin[c][0] = (int)f32_bits(raw.x); be.bin[c][1] = (int)f32_bits(raw.y);
-            be.bin[c][2] = (int)f32_bits(raw.z); be.bin[c][3] = (int)f32_bits(raw.w);
-        }
-    }
+    for(int c = 0; c < BarEntries<G>::CMAX; ++c)
+        if(c < b.lane_blocks) // uniform
+            be.coef[c] = ld4(b.lane_coef + (c * T + t) * 4);
 }
 
 // mean dB of output o -> pixel row (reference src/source.cpp:1548-1557 bars, :1411 curve):
@@ -1502,18 +1499,20 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
     constexpr int T = G::T;
     auto emit = [&](int bar, float sum, int cnt) { emit_output(b, bar, sum / (float)cnt, out_row, dup_row); };
     if(b.num_segs > 0) {
-        // A: every thread forms the dot product of its own segment (padded pairs have coefficient 0 and bin 0) -- four
+        // A: every thread forms the dot product of its own segment (padded bins have coefficient 0) -- four
         // independent partial sums in entry order -- and parks it behind the dB row
         if(has_row) {
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            const float *p = db + be.base;
             WF_UNROLL
             for(int cc = 0; cc < BarEntries<G>::CMAX; ++cc) {
                 if(cc < b.lane_blocks) { // uniform
                     const f4 w = be.coef[cc];
-                    a0 = fmaf(db[be.bin[cc][0]], w.x, a0);
-                    a1 = fmaf(db[be.bin[cc][1]], w.y, a1);
-                    a2 = fmaf(db[be.bin[cc][2]], w.z, a2);
-                    a3 = fmaf(db[be.bin[cc][3]], w.w, a3);
+                    const f4 v = *reinterpret_cast<const f4 *>(p + 4 * cc);
+                    a0 = fmaf(v.x, w.x, a0);
+                    a1 = fmaf(v.y, w.y, a1);
+                    a2 = fmaf(v.z, w.z, a2);
+                    a3 = fmaf(v.w, w.w, a3);
                 }
             }
             prod[t] = (a0 + a1) + (a2 + a3);
