@@ -381,6 +381,7 @@ bool WAVSourceHIP::hip_configure()
     m_hip_hidden = false;
     m_hip_state = WF_HIP_SHOWN;
     m_hip_pushed = (m_display_mode == DisplayMode::WAVEFORM) ? m_fft_size : 0; // update() pre-fills m_fft_size zeros; so does the device
+    m_hip_prev.assign((size_t)m_capture_channels * m_hip_pushed, 0.0f);          // ... and those zeros are what tick_waveform expects at the front
     return true;
 }
 
@@ -685,27 +686,38 @@ void WAVSourceHIP::tick_waveform(float seconds)
         for(auto i = 0u; i < m_capture_channels; ++i)
             if(m_capturebufs[i].size() <= reserve * sizeof(float)) // :293-295
                 return;
+        // The device ring holds every frame pushed so far and counts "what the reference's ring holds" as (frames pushed since
+        // the last tick) + (the reserve that tick left behind), :321.  Frames at the front of m_capturebufs that are already
+        // there -- the last tick's reserve, m_hip_pushed of them -- must not be pushed twice; but capture_audio drops from the
+        // front once a ring exceeds dtsamples + m_waveform_samples (src/source.cpp:1883-1886), and then what is left is
+        // re-sent whole: after a drop the ring is at its cap, the reference trims it to max_size and so does the device
+        // (avail > max_size), and the re-sent frames are contiguous.  Whether the old reserve is still at the front is
+        // checked against a copy of it (all-zero audio can match by accident: then both ways of pushing give zeros).
         size_t frames = 0, fresh = 0;
+        bool front_kept = true;
+        std::vector<std::vector<float>> all(m_capture_channels);
         for(auto channel = 0u; channel < m_capture_channels; ++channel) {
             auto &buf = m_capturebufs[channel];
             if(buf.size() > max_frames * sizeof(float)) // :303-304
                 buf.pop_front(nullptr, buf.size() - max_frames * sizeof(float));
             const size_t s = buf.size() / sizeof(float);
-            // capture_audio drops from the front only once the ring exceeds dtsamples + m_waveform_samples; below that
-            // nothing was dropped and the first m_hip_pushed frames are on the device already.  Above it the whole buffer
-            // is re-sent: the device only looks at the newest m_waveform_samples + reserve frames, which are then contiguous.
-            const size_t n = (s < m_waveform_samples && s >= m_hip_pushed) ? s - m_hip_pushed : s;
-            if(channel == 0) {
+            all[channel].resize(s);
+            buf.peek_front(all[channel].data(), s * sizeof(float));
+            if(channel == 0)
                 frames = s;
-                fresh = n;
-                m_hip_window.resize((size_t)m_capture_channels * fresh);
-            }
-            std::vector<float> all(s);
-            buf.peek_front(all.data(), s * sizeof(float));
-            std::memcpy(m_hip_window.data() + (size_t)channel * fresh, all.data() + (s - fresh), fresh * sizeof(float));
+            front_kept = front_kept && s >= m_hip_pushed && m_hip_prev.size() == (size_t)m_capture_channels * m_hip_pushed &&
+                         std::memcmp(all[channel].data(), m_hip_prev.data() + (size_t)channel * m_hip_pushed, m_hip_pushed * sizeof(float)) == 0;
+        }
+        fresh = front_kept ? frames - m_hip_pushed : frames;
+        m_hip_window.resize((size_t)m_capture_channels * fresh);
+        m_hip_prev.assign((size_t)m_capture_channels * reserve, 0.0f);
+        for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+            auto &buf = m_capturebufs[channel];
+            const size_t s = all[channel].size();
+            std::memcpy(m_hip_window.data() + (size_t)channel * fresh, all[channel].data() + (s - fresh), fresh * sizeof(float));
+            std::memcpy(m_hip_prev.data() + (size_t)channel * reserve, all[channel].data() + (s - reserve), reserve * sizeof(float));
             buf.pop_front(nullptr, (s - reserve) * sizeof(float)); // :321: only the reserve stays
         }
-        (void)frames;
         if(fresh > 0)
             ok = a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)fresh) == WF_HIP_OK;
         m_hip_pushed = reserve;

@@ -193,6 +193,11 @@ SCENARIOS = {
     "wave_normalize": dict(cfg=dict(waveform=1, stereo=1, width=400, normalize_volume=1),
                            steps=[("noise_amp", 800, 0.05), ("tick",)] * 6 + [("mute_noise", 800), ("tick",)] * 2 + [("noise_amp", 800, 0.5), ("tick",)] * 3,
                            record=3),
+    # an A/V-sync reserve (20 ms = 960 frames) together with stalls and a burst longer than the history: the reference's ring
+    # is at its cap, dropped from the front by capture_audio and trimmed again by the tick (:303-304) while a reserve stays
+    "wave_sync_burst": dict(cfg=dict(waveform=1, stereo=1, width=480), sync_ms=20,
+                            steps=_steps(4) + [("tick",)] * 2 + [("noise", 1024)] * 9 + [("tick",)] + _steps(2) + [("noise", 1024)] * 3 + [("tick",)]
+                            + _steps(2), record="all"),
     "wave_hide_timeout_sync": dict(cfg=dict(waveform=1, stereo=1, width=333), sync_ms=10,
                                    steps=_steps(4) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(3)
                                    + [("timeout",), ("tick",), ("tick",)] + _steps(3), record="all"),
