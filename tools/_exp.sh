@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
-for V in g1024 g1024w4 g1024t0; do WF_HIP_LIB=variants/lib_$V.so python tools/quick_bench.py 1024:16384 2>/dev/null | cut -c1-30,90-200; done
-done > gpurun_out/exp.txt 2>&1
-for V in g1024 g1024w4; do WF_HIP_LIB=variants/lib_$V.so python tools/quick_bench.py 512:16384 256:16384 128:16384 2>/dev/null | cut -c1-30,90-200; done >> gpurun_out/exp.txt 2>&1
+timeout 900 python -m pytest tests/test_golden.py tests/test_gpu_fuzz.py -m gpu -x -q -n 4 -k "any or random_size or huge" 2>&1 | tail -6 > gpurun_out/exp.txt
+for V in variants/lib_before_packed.so waveform_amd/libwaveform_hip.so; do WF_HIP_LIB=$V python tools/quick_bench.py 800:8192 1600:4096 4160:2048 8000:1024 10912:1024 2>/dev/null | cut -c1-30,60-110,150-250; done >> gpurun_out/exp.txt

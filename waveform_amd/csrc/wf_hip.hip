@@ -89,7 +89,7 @@ struct wf_hip {
     // FFT sizes that are not powers of two: Bluestein over the geometry of geom_n = 2 * L points (spectrum_tick_kernel<.., BLU>)
     bool blu = false;
     uint32_t geom_n = 0;             // the fft size whose geometry runs the batch (N itself for the power-of-two sizes >= 1024)
-    wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr;
+    wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr, *d_blu_q = nullptr, *d_blu_qr = nullptr, *d_blu_w = nullptr;
     // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
     uint32_t big_l = 0, big_rows = 0;
     wf::cf *d_big_v = nullptr, *d_big_z = nullptr, *d_big_tw = nullptr, *d_big_tws = nullptr;
@@ -512,7 +512,11 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.blu_a = h->d_blu_a;
         a.blu_b = h->d_blu_b;
         a.blu_n = h->N;
-        a.half_coef = (2.0f / h->tab.window_sum) / (float)(h->big_l ? h->big_l : h->geom_n / 2); // |c_k| / L, times mag_coefficient
+        a.blu_q = h->d_blu_q;
+        a.blu_qr = h->d_blu_qr;
+        a.blu_w = h->d_blu_w;
+        if(h->big_l) // direct form: |c_k| / L, times mag_coefficient (the packed form's tables carry the 1 / L, and its real split the 1 / 2)
+            a.half_coef = (2.0f / h->tab.window_sum) / (float)h->big_l;
     }
     if(h->big_l) {
         a.big_z = h->d_big_z;
@@ -1074,6 +1078,15 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         std::memcpy(tb.data(), bt.b.data(), tb.size() * sizeof(wf::cf));
         WF_CREATE_TRY(upload(h, &h->d_blu_a, ta));
         WF_CREATE_TRY(upload(h, &h->d_blu_b, tb));
+        std::vector<wf::cf> tq(bt.q.size()), tqr(bt.qr.size()), tw(bt.w.size());
+        if(!tq.empty()) {
+            std::memcpy(tq.data(), bt.q.data(), tq.size() * sizeof(wf::cf));
+            std::memcpy(tqr.data(), bt.qr.data(), tqr.size() * sizeof(wf::cf));
+            std::memcpy(tw.data(), bt.w.data(), tw.size() * sizeof(wf::cf));
+        }
+        WF_CREATE_TRY(upload(h, &h->d_blu_q, tq));
+        WF_CREATE_TRY(upload(h, &h->d_blu_qr, tqr));
+        WF_CREATE_TRY(upload(h, &h->d_blu_w, tw));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
     if(h->big_l) {

@@ -564,9 +564,14 @@ uint32_t bluestein_length(uint32_t n)
     if(is_pow2(n))
         return 0;
     uint32_t L = 512;
-    while((uint64_t)L * 2 < (uint64_t)n * 3) // L >= 3n/2
+    if(n <= 16384u) { // packed form: n/2 complex points, every output wanted: L >= 2 (n/2) - 1
+        while(L < n - 1u)
+            L <<= 1;
+        return L; // <= 16384 complex points: inside one workgroup (the 32768-sample geometry at most)
+    }
+    while((uint64_t)L * 2 < (uint64_t)n * 3) // direct form: L >= 3n/2
         L <<= 1;
-    return L; // <= 16384 complex points: inside one workgroup (the 32768-sample geometry); 32768 .. 131072: wf_big.hpp
+    return L; // 32768 .. 131072: wf_big.hpp
 }
 
 void build_big_twiddles(uint32_t L, uint32_t rows, uint32_t real_n, std::vector<cfloat> &tw_big, std::vector<cfloat> &tws_big)
@@ -631,29 +636,60 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
     if(out.L == 0)
         return;
     const uint32_t L = out.L;
+    out.packed = n <= 16384u;
+    const uint32_t np = out.packed ? n / 2 : n; // points of the transform Bluestein computes
     const double pi = 3.14159265358979323846264338327950288;
-    auto chirp = [&](uint64_t m, double &cr, double &ci) { // w_m = exp(i pi m^2 / n), the phase reduced exactly
-        const uint64_t ph = (m * m) % (2ull * n);
-        const double a = pi * (double)ph / (double)n;
+    auto chirp = [&](uint64_t m, double &cr, double &ci) { // w_m = exp(i pi m^2 / np), the phase reduced exactly
+        const uint64_t ph = (m * m) % (2ull * np);
+        const double a = pi * (double)ph / (double)np;
         cr = std::cos(a);
         ci = std::sin(a);
     };
-    out.a.assign(L, cfloat{0.0f, 0.0f});
-    for(uint32_t j = 0; j < n; ++j) {
-        double cr, ci;
-        chirp(j, cr, ci);
-        const double w = t.window.empty() ? 1.0 : (double)t.window[j];
-        out.a[j] = cfloat{(float)(w * cr), (float)(-w * ci)};
+    auto win = [&](uint32_t i) { return t.window.empty() ? 1.0 : (double)t.window[i]; };
+    if(out.packed) {
+        // a_j = (win_2j x_2j + i win_2j+1 x_2j+1) conj(w_j) = x_2j (win_2j conj w_j) + x_2j+1 (i win_2j+1 conj w_j)
+        out.a.assign((size_t)2 * L, cfloat{0.0f, 0.0f});
+        for(uint32_t j = 0; j < np; ++j) {
+            double cr, ci;
+            chirp(j, cr, ci);
+            const double w0 = win(2 * j), w1 = win(2 * j + 1);
+            out.a[(size_t)2 * j] = cfloat{(float)(w0 * cr), (float)(-w0 * ci)};
+            out.a[(size_t)2 * j + 1] = cfloat{(float)(w1 * ci), (float)(w1 * cr)}; // i * (cr - i ci) = ci + i cr
+        }
+    } else {
+        out.a.assign(L, cfloat{0.0f, 0.0f});
+        for(uint32_t j = 0; j < n; ++j) {
+            double cr, ci;
+            chirp(j, cr, ci);
+            out.a[j] = cfloat{(float)(win(j) * cr), (float)(-win(j) * ci)};
+        }
     }
     std::vector<double> br(L, 0.0), bi(L, 0.0);
-    for(uint32_t m = 0; m < n && m <= L - n; ++m) // non-negative lags; only m < n/2 is ever needed and L - n >= n/2
+    // lags k - j: packed wants every k < np, i.e. -(np-1) .. np-1 (L >= 2 np - 1); direct wants k < n/2: -(n-1) .. n/2-1 (L >= 3n/2)
+    const uint32_t pos = out.packed ? np : std::min(n, L - n + 1u);
+    for(uint32_t m = 0; m < pos; ++m)
         chirp(m, br[m], bi[m]);
-    for(uint32_t m = 1; m < n; ++m) // negative lags, wrapped
+    for(uint32_t m = 1; m < np; ++m) // negative lags, wrapped
         chirp(m, br[L - m], bi[L - m]);
     fft_double(br, bi);
     out.b.resize(L);
     for(uint32_t k = 0; k < L; ++k)
         out.b[k] = cfloat{(float)br[k], (float)bi[k]};
+    if(out.packed) {
+        out.q.resize(np);
+        out.qr.resize(np);
+        out.w.resize(np);
+        const double two_pi = 2.0 * pi;
+        for(uint32_t k = 0; k < np; ++k) {
+            double cr, ci;
+            chirp(k, cr, ci);
+            out.q[k] = cfloat{(float)(cr / (double)L), (float)(-ci / (double)L)};
+            const double a = -two_pi * (double)k / (double)n;
+            out.w[k] = cfloat{(float)std::cos(a), (float)std::sin(a)};
+        }
+        for(uint32_t k = 0; k < np; ++k)
+            out.qr[k] = out.q[(np - k) % np];
+    }
 }
 
 void build_twiddles(int M, int R1, int R2, int R3, std::vector<cfloat> &tw1, std::vector<cfloat> &tw2, std::vector<cfloat> &tws)

@@ -83,16 +83,25 @@ struct CurveLaneTables {
 bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max_steps, CurveLaneTables &out);
 
 // FFT sizes that are not powers of two: Bluestein's algorithm over the complex FFT core.
-//   X_k = conj(w_k) * sum_j (x_j conj(w_j)) w_(k-j),  w_m = exp(i pi m^2 / n)   (jk = (j^2 + k^2 - (k-j)^2) / 2)
-// i.e. |X_k| = |(a * b)_k| with a_j = window_j x_j conj(w_j), b_m = w_m: a circular convolution of length L >= 3n/2 (only
-// k < n/2 is wanted), computed as IFFT_L(FFT_L(a) . FFT_L(b)).  The tables: a's constant factor and FFT_L(b), in double,
-// rounded once.
+//   Y_k = conj(w_k) * sum_j (y_j conj(w_j)) w_(k-j),  w_m = exp(i pi m^2 / n')   (jk = (j^2 + k^2 - (k-j)^2) / 2)
+// i.e. a circular convolution a * b of length L with a_j = y_j conj(w_j), b_m = w_m, computed as IFFT_L(FFT_L(a) . FFT_L(b)).
+// Two forms:
+//  * packed (n <= 16384: inside one workgroup).  The n real samples are the n' = n/2 complex points
+//    z_j = window_2j x_2j + i window_2j+1 x_2j+1; their n'-point DFT Z needs L >= 2n' - 1 = n - 1 (every k < n' is wanted),
+//    and X_k follows from Z_k and Z_(n'-k) by the real split with W_n^k -- half the transform length of the direct form.
+//    Tables: a[2j], a[2j+1] = the two complex factors of x_2j and x_2j+1 in a_j; b = FFT_L of the chirp;
+//    q_k = conj(w_k) / L (Z_k = q_k * conj(R_k) for the twice-transformed R); qr_k = q_(n'-k mod n'); w[k] = W_n^k.
+//  * direct (n > 16384: through device memory, wf_big.hpp).  y = window * x, n' = n, only k < n/2 wanted: L >= 3n/2,
+//    |X_k| = |(a * b)_k|.  Tables: a_j = window_j conj(w_j), b.
+// All in double, rounded once.
 struct BluesteinTables {
-    uint32_t L = 0;            // complex transform length: smallest power of two >= 3n/2 (and >= 512)
-    std::vector<cfloat> a;     // [L] window_j * conj(w_j), zero for j >= n
-    std::vector<cfloat> b;     // [L] FFT_L of the chirp, b_m = w_m for -(n-1) <= m <= L-n (negative m wrapped)
+    uint32_t L = 0;            // complex transform length (a power of two >= 512)
+    bool packed = false;
+    std::vector<cfloat> a;     // packed: [2L] (two factors per point, zero from point n/2 on); direct: [L], zero from n on
+    std::vector<cfloat> b;     // [L] FFT_L of the chirp
+    std::vector<cfloat> q, qr, w; // packed only: [n/2] each
 };
-// 0 when n is a power of two (no Bluestein needed) or too long for the largest geometry
+// 0 when n is a power of two (no Bluestein needed)
 uint32_t bluestein_length(uint32_t n);
 // transforms of L = rows * 16384 complex points done in two steps (wf_big.hpp): tw_big[k1][n2] = W_L^(n2 k1); tws_big[k] =
 // W_real_n^k, the real-split twiddles of a packed real_n-sample transform (real_n == 0: not built)

@@ -168,7 +168,10 @@ struct TickArgs {
     const BarsOnlyState *bars_only;
     // FFT sizes that are not powers of two (Bluestein, spectrum_tick_kernel<.., BLU>): the geometry's M is the padded
     // convolution length L, the transform the host asked for has blu_n points and row_bins = blu_n / 2 output bins
-    const cf *blu_a;           // [M] window_j * conj(w_j), zero for j >= blu_n
+    const cf *blu_q;           // [blu_n / 2] conj(w_k) / L: Z_k = blu_q[k] * conj(R_k) for the twice-transformed R
+    const cf *blu_qr;          // [blu_n / 2] blu_q[(blu_n / 2 - k) mod (blu_n / 2)]
+    const cf *blu_w;           // [blu_n / 2] W_blu_n^k, the real-split twiddles
+    const cf *blu_a;           // [2 M] the factors of x_2j and x_2j+1 in point j of the chirped, windowed, packed input; zero from point blu_n / 2 on
     const cf *blu_b;           // [M] FFT_M of the chirp
     uint32_t blu_n;
     uint32_t row_bins;         // bins per output / state row (M >> DEC for the power-of-two paths)
@@ -543,27 +546,23 @@ template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float 
 // transform's input, already complex: it goes through p1_window_dft with a window of ones.
 template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
 {
+    // packed form (wf_host_tables.hpp): point j of the transform is x[2j] * blu_a[2j] + x[2j+1] * blu_a[2j+1], j < blu_n / 2
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    const uint32_t np = a.blu_n >> 1;
     uint32_t acc = 0;
     WF_UNROLL
     for(int j = 0; j < R1; ++j) {
-        float xs[B1];
         WF_UNROLL
         for(int b = 0; b < B1; ++b) {
             const uint32_t idx = (uint32_t)(j * M1 + B1 * t + b);
-            const bool in = idx < a.blu_n;
-            const float v = x[(start + (in ? idx : 0u)) & a.ring_mask];
-            xs[b] = in ? v : 0.0f;
-            acc |= f32_bits(xs[b]);
-        }
-        const float *tab = reinterpret_cast<const float *>(a.blu_a + j * M1 + B1 * t);
-        if(B1 == 2) {
-            const f4 q = ld4(tab);
-            r.smp[j][0] = xs[0] * q.x; r.smp[j][1] = xs[0] * q.y;
-            r.smp[j][2 * B1 - 2] = xs[B1 - 1] * q.z; r.smp[j][2 * B1 - 1] = xs[B1 - 1] * q.w;
-        } else {
-            const f2 q = ld2(tab);
-            r.smp[j][0] = xs[0] * q.x; r.smp[j][1] = xs[0] * q.y;
+            const bool in = idx < np;
+            const uint32_t s = start + 2u * (in ? idx : 0u);
+            const float v0 = x[s & a.ring_mask], v1 = x[(s + 1u) & a.ring_mask];
+            const float x0 = in ? v0 : 0.0f, x1 = in ? v1 : 0.0f;
+            acc |= f32_bits(x0) | f32_bits(x1);
+            const f4 q = ld4(reinterpret_cast<const float *>(a.blu_a + 2u * idx));
+            r.smp[j][2 * b] = fmaf(x1, q.z, x0 * q.x);
+            r.smp[j][2 * b + 1] = fmaf(x1, q.w, x0 * q.y);
         }
         WF_UNROLL
         for(int e = 0; e < 2 * B1; ++e)
@@ -573,9 +572,6 @@ template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float
     }
     return (acc & 0x7fffffffu) != 0;
 }
-
-// between the transforms: conj(FFT(a) . FFT(b)) for this thread's pass-1 points, read from the natural-order buffer
-// (IFFT(C) = conj(FFT(conj(C))) / M; the conjugation and the 1/M on the way out do not change a magnitude)
 template<class G> WF_DEV void blu_mid(const TickArgs &a, int t, const cf *lds, P1Regs<G> &r)
 {
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
@@ -605,25 +601,40 @@ template<class G> WF_DEV void blu_mid(const TickArgs &a, int t, const cf *lds, P
     }
 }
 
-// epilogue without a real split: |X_k| = |c_k| for the first row_bins outputs; slope, smoothing and the state store as in
-// p4_slope_smooth_group, on the groups of four bins that lie inside the row
+// Bluestein epilogue (packed form): the real split of the n/2-point transform the convolution delivers; slope, smoothing and
+// the state store as in p4_slope_smooth_group, on the groups of four bins that lie inside the row
 template<class G, bool TS, bool FPK>
-WF_DEV void p4_direct_impl(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
+WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
 {
+    // Z_k = blu_q[k] * conj(R_k), R = the twice-transformed buffer in natural order; X_k from Z_k and Z_(n'-k) by the real
+    // split with W_n^k, as p4_split_smooth does for the power-of-two sizes: 2X[k] = (A + conj B) - i W (A - conj B)
     constexpr int T = G::T, P = G::P;
+    const int np = (int)a.row_bins; // blu_n / 2
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         const int k0 = 4 * (t + T * u);
-        if(k0 < (int)a.row_bins) {
+        if(k0 < np) {
             const f4 sv = ld4(a.slope + k0);
             f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
             if(TS)
                 st = ld4(ts + k0);
+            const f4 qa = ld4(reinterpret_cast<const float *>(a.blu_q + k0)), qb = ld4(reinterpret_cast<const float *>(a.blu_q + k0 + 2));
+            const f4 ra = ld4(reinterpret_cast<const float *>(a.blu_qr + k0)), rb = ld4(reinterpret_cast<const float *>(a.blu_qr + k0 + 2));
+            const f4 wa = ld4(reinterpret_cast<const float *>(a.blu_w + k0)), wb = ld4(reinterpret_cast<const float *>(a.blu_w + k0 + 2));
+            const cf Q[4] = {cf{qa.x, qa.y}, cf{qa.z, qa.w}, cf{qb.x, qb.y}, cf{qb.z, qb.w}};
+            const cf QR[4] = {cf{ra.x, ra.y}, cf{ra.z, ra.w}, cf{rb.x, rb.y}, cf{rb.z, rb.w}};
+            const cf W[4] = {cf{wa.x, wa.y}, cf{wa.z, wa.w}, cf{wb.x, wb.y}, cf{wb.z, wb.w}};
             const float sl4[4] = {sv.x, sv.y, sv.z, sv.w}, st4v[4] = {st.x, st.y, st.z, st.w};
             WF_UNROLL
             for(int i = 0; i < 4; ++i) {
-                const cf z = lds_ld2(lds, ex3_addr<G>(k0 + i));
-                float m = mag2(z.x, z.y) * a.half_coef * sl4[i];
+                const int k = k0 + i, km = (k == 0) ? 0 : np - k;
+                const cf rk = lds_ld2(lds, ex3_addr<G>(k)), rm = lds_ld2(lds, ex3_addr<G>(km));
+                const cf A = cmul(cf{rk.x, -rk.y}, Q[i]), B = cmul(cf{rm.x, -rm.y}, QR[i]);
+                const float er = A.x + B.x, ei = A.y - B.y;
+                const float dr = A.x - B.x, di = A.y + B.y;
+                const float pr = fmaf(W[i].x, dr, -(W[i].y * di)); // Re(W D)
+                const float pi = fmaf(W[i].x, di, W[i].y * dr);    // Im(W D)
+                float m = mag2(er + pi, ei - pr) * a.half_coef * sl4[i];
                 if(TS) {
                     float old = st4v[i];
                     if(FPK)
@@ -641,11 +652,11 @@ template<class G> WF_DEV void p4_direct(const TickArgs &a, int t, const cf *lds,
 {
     if(a.mode & WF_MODE_TSMOOTH) {
         if(a.mode & WF_MODE_FAST_PEAKS)
-            p4_direct_impl<G, true, true>(a, t, lds, ts, mag);
+            p4_split_blu_impl<G, true, true>(a, t, lds, ts, mag);
         else
-            p4_direct_impl<G, true, false>(a, t, lds, ts, mag);
+            p4_split_blu_impl<G, true, false>(a, t, lds, ts, mag);
     } else
-        p4_direct_impl<G, false, false>(a, t, lds, ts, mag);
+        p4_split_blu_impl<G, false, false>(a, t, lds, ts, mag);
 }
 
 // ---- P2: pass 2 ---------------------------------------------------------------------------------
