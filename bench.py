@@ -105,8 +105,8 @@ def host_cores() -> int:
     return n
 
 
-def pmc_traffic(shape: str):
-    """HBM bytes per tick from the latest committed rocprofv3 PMC pass of this shape (profiles/rNN*_<shape>_pmc.json), or None."""
+def pmc_profile(shape: str):
+    """The latest committed rocprofv3 summary of this shape (profiles/rNN*_<shape>_pmc.json), or None."""
     best = None
     for p in sorted((ROOT / "profiles").glob(f"r*_{shape}_pmc.json")):
         try:
@@ -114,20 +114,26 @@ def pmc_traffic(shape: str):
         except Exception:
             continue
         if d.get("hbm_bytes_per_launch"):
-            best = d.get("hbm_bytes_per_tick") or d["hbm_bytes_per_launch"]
+            best = (p.name, d)
     return best
 
 
 def roofline(batch, shape, kernel_ms, flags=0):
     algo = batch.algorithmic_bytes_per_tick(flags)
     achieved = algo / (kernel_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic(shape) if shape else None, "kernel": batch.kernel_name(), "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": algo,
-            # "launch" = one wf_hip_tick: the batch goes out as this many concurrent launches of the kernel (lanes on their
-            # own HIP streams), timed together by the events; rocprofv3's per-launch average covers one slice sharing the
-            # chip with the others -- profiles/*_pmc.json carries the per-tick span taken from the same trace
-            "kernel_launches_per_tick": batch.launches_per_tick()}
+    prof = pmc_profile(shape) if shape else None
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+           "traffic": (prof[1].get("hbm_bytes_per_tick") or prof[1]["hbm_bytes_per_launch"]) if prof else None,
+           "kernel": batch.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
+           # "launch" = one wf_hip_tick: the batch goes out as this many concurrent launches of the kernel (lanes on their
+           # own HIP streams), timed together by the events.  rocprofv3's per-launch average is one slice sharing the chip
+           # with the others; what must agree with kernel_ms is the tick span of its kernel trace (below)
+           "kernel_launches_per_tick": batch.launches_per_tick()}
+    if prof:
+        tr, ks = prof[1].get("trace") or {}, prof[1].get("kernel_stats") or {}
+        out["profile"] = {"file": "profiles/" + prof[0], "tick_span_ms": (tr.get("tick_span_ns") or 0) * 1e-6 or None,
+                          "avg_launch_ms": (ks.get("avg_ns") or 0) * 1e-6 or None, "launches_per_tick": tr.get("launches_per_tick")}
+    return out
 
 
 def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0, shape=None):

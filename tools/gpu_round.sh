@@ -18,4 +18,12 @@ bash tools/profile_gpu.sh ${TAG}_cfg3 30 > /dev/null 2>&1
 WF_PMC_SET=short bash tools/profile_gpu.sh ${TAG}_cfg3_16384streams 20 "--streams 16384" > /dev/null 2>&1
 WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 2 30" bash tools/profile_gpu.sh ${TAG}_cfg4 > /dev/null 2>&1
 WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 4 30" bash tools/profile_gpu.sh ${TAG}_cfg5shape > /dev/null 2>&1
+# the kernels further from the roofline: durations only (rocprofv3 --kernel-trace --stats), one summary each
+for J in "plugindefaults:python $R/tools/quick_case.py plugin_defaults" "n32768:python $R/tools/quick_bench.py 32768:512" \
+         "blu800:python $R/tools/quick_bench.py 800:8192" "n65536:python $R/tools/quick_bench.py 65536:256" \
+         "meter:python $R/tools/meter_bench.py" "wave:python $R/tools/wave_bench.py"; do
+  NAME=${J%%:*}; CMD=${J#*:}
+  mkdir -p $O/prof/${TAG}_$NAME; ( cd /tmp; export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/${TAG}_$NAME/stats -o stats -- $CMD > $O/prof/${TAG}_$NAME/stats.log 2>&1 )
+done
 ls $O/prof
