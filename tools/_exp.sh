@@ -1,3 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_golden.py tests/test_gpu_fuzz.py -m gpu -x -q -n 4 -k "any or random_size or huge" 2>&1 | tail -6 > gpurun_out/exp.txt
-for V in variants/lib_before_packed.so waveform_amd/libwaveform_hip.so; do WF_HIP_LIB=$V python tools/quick_bench.py 800:8192 1600:4096 4160:2048 8000:1024 10912:1024 2>/dev/null | cut -c1-30,60-110,150-250; done >> gpurun_out/exp.txt
+q() { WF_HIP_LIB=variants/lib_$1.so python tools/quick_bench.py $2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms'], d['frac'])"; }
+for rep in 1 2; do
+q g2048 2048:8192; q g2048ps3 2048:8192
+q g4096 4096:4096; q g4096ps3 4096:4096
+q g8192 8192:2048; q g8192ps3 8192:2048
+q g16384 16384:1024; q g16384ps3 16384:1024
+done > gpurun_out/exp.txt 2>&1

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             p1_window_pass1<G>(a, t, r1, lds);
         if constexpr(DEC > 0)
             p4_prefetch_dec<G, DEC>(a, t, ts, r4);
-        else if constexpr(!BLU) // the Bluestein epilogue loads its (shorter) rows itself
+        else if constexpr(!BLU && !Policy<G>::PREFETCH_LATE) // the Bluestein epilogue loads its (shorter) rows itself
             p4_prefetch<G>(a, t, ts, r4);
     }
     __builtin_amdgcn_sched_barrier(0); // keep the prefetch up here: do not sink it to its first use in P4
@@ -318,6 +318,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(6);
     if(process)
         p3_pass3_write<G>(t, lds, v);
+    if constexpr(!BLU && DEC == 0 && Policy<G>::PREFETCH_LATE) {
+        if(process)
+            p4_prefetch<G>(a, t, ts, r4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     WF_STAMP(7);
     spectrum_sync<G>();
     if constexpr(BLU) {

@@ -307,10 +307,16 @@ WF_DEV float mag2(float xr, float xi)
 #endif
 template<class G> struct Policy {
     static_assert(G::P <= 16, "the phase functions keep a thread's operands in registers: at most 16 points per thread");
-    static constexpr int MODE = (WF_PREFETCH_STATE >= 0) ? WF_PREFETCH_STATE : (G::T <= 64 ? 1 : 2);
-    static constexpr bool PREFETCH_STATE = (MODE == 1);
-    static constexpr bool PREFETCH_SLOPE = (MODE == 1);
+    // 1: state + slope into registers right after pass 1; 2: their lines only "touched" there (into L2), loaded in P4;
+    // 0: everything requested at the start of P4, consumed after the real split.  Round 1 found 1 / 2 best (one wavefront /
+    // several); with the lanes and the non-temporal row stores of round 2 the early requests only lengthen the fetch
+    // burst's queue: mode 0 is +3 % at N = 4096, +1.7 % at 2048, +1..3 % at 8192 / 16384, +-0 at 32768 (interleaved A/B).
+    // The 8-point geometry keeps 1 (its decimated epilogue takes the operands from registers).
+    static constexpr int MODE = (WF_PREFETCH_STATE >= 0) ? WF_PREFETCH_STATE : (G::P <= 8 ? 1 : 0);
+    static constexpr bool PREFETCH_STATE = (MODE == 1 || MODE == 3);
+    static constexpr bool PREFETCH_SLOPE = (MODE == 1 || MODE == 3);
     static constexpr bool TOUCH_STATE = (MODE == 2);
+    static constexpr bool PREFETCH_LATE = (MODE == 3); // 3: as 1, but requested behind pass 3's stores, under the barrier in front of P4
 };
 // Pass-1 twiddle rows W_M^(n' k1), k1 = 1..R1-1: only the rows whose k1 is a power of two come from the table; the others
 // are products of two of those (or of one and an earlier product): k1 = hi + lo with lo the lowest set bit.  At R1 = 8 that
