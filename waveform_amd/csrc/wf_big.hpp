@@ -4,7 +4,7 @@
 // :562-565).  Up to 32768 samples (16384 complex points, 132 KB) a spectrum lives in one workgroup's LDS
 // (spectrum_tick_kernel).  Beyond that:
 //   65536 samples                    -> 32768 complex points (the packed real transform)
-//   n = 10928 .. 65520, not 2^k      -> Bluestein over L = 32768 / 65536 / 131072 complex points (two transforms)
+//   n = 16400 .. 65520, not 2^k      -> Bluestein (direct form) over L = 32768 / 65536 / 131072 complex points (two transforms)
 // A transform of L = L1 * 16384 points (L1 = 2, 4, 8) is done in two steps through a scratch buffer in device memory
 // (decimation in frequency, n = n1 * 16384 + n2, k = k1 + L1 * k2):
 //   big_columns_kernel   v[k1][n2] = W_L^(n2 k1) * sum_n1 u[n1 * 16384 + n2] W_L1^(n1 k1)      (u = the windowed samples, see MODE)
