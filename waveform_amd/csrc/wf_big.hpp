@@ -195,7 +195,7 @@ WF_DEV void p4_big_impl(const TickArgs &a, int t, int kbase, int nb, const cf *z
         const f4 sv = ld4(a.slope + kk);
         f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if(TS)
-            st = ld4(ts + k0);
+            st = ld_state(ts + k0);
         const f4 za = ld4(reinterpret_cast<const float *>(z + kk)), zb = ld4(reinterpret_cast<const float *>(z + kk + 2));
         const cf A[4] = {cf{za.x, za.y}, cf{za.z, za.w}, cf{zb.x, zb.y}, cf{zb.z, zb.w}};
         if constexpr(MODE == 1) {

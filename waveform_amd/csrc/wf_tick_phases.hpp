@@ -189,14 +189,18 @@ WF_DEV f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 WF_DEV f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
 WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 // Streaming accesses.  Measured on MI355X (cfg3, interleaved A/B on one box): the m_decibels rows -- output nothing on the
-// device reads again -- stored with the non-temporal hint +1.8 % (they stop displacing rings and state from the 256 MB
-// Infinity Cache); the same hint on the state stores +-0, on the window loads -2 % (consecutive ticks' windows overlap by
-// 80 %: those lines are wanted in the cache).  WF_NT_STATE / WF_NT_SMP keep the two rejected variants buildable.
+// device reads again -- stored with the non-temporal hint +1.8 % (they stop displacing the rings from the 256 MB Infinity
+// Cache).  The smoothing state is read once and written once per tick: the hint on its stores alone +-0, on its loads
+// alone +-0, on both +3.7 % (0.701 -> 0.727; 16384 streams 0.69 -> 0.72-0.75) -- then only the rings, whose consecutive
+// windows overlap by 80 %, compete for the cache.  On the window loads themselves the hint costs 2 % (WF_NT_SMP).
 #ifndef WF_NT_STATE
-#define WF_NT_STATE 0
+#define WF_NT_STATE 1
 #endif
 #ifndef WF_NT_SMP
 #define WF_NT_SMP 0
+#endif
+#ifndef WF_NT_STATE_LD
+#define WF_NT_STATE_LD 1
 #endif
 #if defined(__HIPCC__)
 WF_DEV f4 ld4_nt(const float *p)
@@ -214,6 +218,16 @@ WF_DEV void st4_nt(float *p, f4 v)
 WF_DEV f4 ld4_nt(const float *p) { return ld4(p); }
 WF_DEV void st4_nt(float *p, f4 v) { st4(p, v); }
 #endif
+
+// m_tsmooth_buf is read once and written once per tick: both with the hint (WF_NT_STATE / WF_NT_STATE_LD)
+WF_DEV f4 ld_state(const float *p) { return WF_NT_STATE_LD ? ld4_nt(p) : ld4(p); }
+WF_DEV void st_state(float *p, f4 v)
+{
+    if(WF_NT_STATE)
+        st4_nt(p, v);
+    else
+        st4(p, v);
+}
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
 // WF_LDS_TRACE is defined only by the g++ wavefront emulator in tests/emu to record
@@ -531,7 +545,7 @@ template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float 
         constexpr int S = Policy<G>::PREFETCH_STATE ? 1 : 0;
         WF_UNROLL
         for(int u = 0; u < P / 4; ++u) {
-            const f4 o = ld4(ts + 4 * (t + T * u));
+            const f4 o = ld_state(ts + 4 * (t + T * u));
             q.st[S * (4 * u)] = o.x; q.st[S * (4 * u + 1)] = o.y; q.st[S * (4 * u + 2)] = o.z; q.st[S * (4 * u + 3)] = o.w;
         }
     }
@@ -623,7 +637,7 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
             const f4 sv = ld4(a.slope + k0);
             f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
             if(TS)
-                st = ld4(ts + k0);
+                st = ld_state(ts + k0);
             const f4 qa = ld4(reinterpret_cast<const float *>(a.blu_q + k0)), qb = ld4(reinterpret_cast<const float *>(a.blu_q + k0 + 2));
             const f4 ra = ld4(reinterpret_cast<const float *>(a.blu_qr + k0)), rb = ld4(reinterpret_cast<const float *>(a.blu_qr + k0 + 2));
             const f4 wa = ld4(reinterpret_cast<const float *>(a.blu_w + k0)), wb = ld4(reinterpret_cast<const float *>(a.blu_w + k0 + 2));
@@ -650,7 +664,7 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
                 mag[4 * u + i] = m;
             }
             if(TS)
-                st4(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+                st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
         }
     }
 }
@@ -868,10 +882,7 @@ WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, co
             // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
             mag[4 * u + i] = fmaf(a.g, old, a.g2 * mag[4 * u + i]);
         }
-        if(WF_NT_STATE)
-            st4_nt(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
-        else
-            st4(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+        st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
     }
 }
 
@@ -889,7 +900,7 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
         for(int u = 0; u < P / 4; ++u) {
             const int k0 = 4 * (t + T * u);
             if(TS) {
-                const f4 o = ld4(ts + k0);
+                const f4 o = ld_state(ts + k0);
                 st_all[4 * u] = o.x; st_all[4 * u + 1] = o.y; st_all[4 * u + 2] = o.z; st_all[4 * u + 3] = o.w;
             }
             const f4 sv = ld4(a.slope + k0);
@@ -922,7 +933,7 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
                 for(int i = 0; i < 4; ++i)
                     st4v[i] = st_all[(LOAD_ALL_FIRST ? 1 : 0) * (4 * u + i)];
             } else {
-                const f4 o = ld4(ts + k0);
+                const f4 o = ld_state(ts + k0);
                 st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
             }
         }
@@ -990,7 +1001,7 @@ template<class G, int DEC> WF_DEV void p4_prefetch_dec(const TickArgs &a, int t,
     constexpr int TO = (G::M >> DEC) / 4;
     const int tt = t < TO ? t : 0;
     if(a.mode & WF_MODE_TSMOOTH) {
-        const f4 o = ld4(ts + 4 * tt);
+        const f4 o = ld_state(ts + 4 * tt);
         q.st[0] = o.x; q.st[1] = o.y; q.st[2] = o.z; q.st[3] = o.w;
     }
     const f4 sv = ld4(a.slope + 4 * tt);
@@ -1028,7 +1039,7 @@ WF_DEV f4 p4_split_smooth_dec_impl(const TickArgs &a, int t, const cf *lds, floa
     }
     const f4 r = f4{mag[0], mag[1], mag[2], mag[3]};
     if(TS)
-        st4(ts + 4 * t, r);
+        st_state(ts + 4 * t, r);
     return r;
 }
 template<class G, int DEC>
