@@ -1042,7 +1042,13 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             case 512: setup_rc = setup_launch_dec<G, 1>(h); break;
             case 256: setup_rc = setup_launch_dec<G, 2>(h); break;
             case 128: setup_rc = setup_launch_dec<G, 3>(h); break;
-            default: setup_rc = setup_launch<G, 2>(h); break;
+            default:
+#ifdef WF_SPW4_1024 // development builds: four spectra (two streams) per workgroup on the 8-point geometry
+                setup_rc = setup_launch_impl<G, 4, false>(h);
+#else
+                setup_rc = setup_launch<G, 2>(h);
+#endif
+                break;
             }
         } else if constexpr(G::N >= 32768) {
             // one spectrum fills a CU's LDS: a stereo pair runs split, a single captured channel alone; mono mixdown of two
