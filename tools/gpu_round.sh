@@ -14,7 +14,7 @@ fi
 ( time python bench.py ) > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 tail -c 600 $O/bench_$TAG.json | head -c 600; echo
 # headline shape: full counter set; the other shapes: durations + HBM bytes
-bash tools/profile_gpu.sh ${TAG}_cfg3 30 > /dev/null 2>&1
+bash tools/profile_gpu.sh ${TAG}_cfg3 200 "--warmup 20" > /dev/null 2>&1   # the default bench.py run: same ring depth, same ticks
 WF_PMC_SET=short bash tools/profile_gpu.sh ${TAG}_cfg3_16384streams 20 "--streams 16384" > /dev/null 2>&1
 WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 2 30" bash tools/profile_gpu.sh ${TAG}_cfg4 > /dev/null 2>&1
 WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 4 30" bash tools/profile_gpu.sh ${TAG}_cfg5shape > /dev/null 2>&1
