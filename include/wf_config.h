@@ -79,6 +79,12 @@ typedef struct wf_config {
      * hold m_waveform_samples = sample_rate * (meter_ms / 1000.0) samples (+ the A/V-sync reserve), window / slope / mirror /
      * log scale are off (:1133-1137). */
     uint32_t waveform;          /* m_display_mode == DisplayMode::WAVEFORM */
+    /* vertex fill (the loops of render_bars / render_curve that write the vertex buffer, src/source.cpp:1576-1659, :1436-1461):
+     * with vertices != 0 (and bars or curve) every tick also leaves, per displayed channel, the vertices the reference
+     * hands to gs_draw -- wf_hip_read_vertices.  1: filled geometry (bars: two triangles per bar, plus the cap fans with
+     * rounded_caps; curve: a triangle strip of 2 * width vertices, RenderMode SOLID / GRADIENT / ...); 2: the curve as a
+     * line strip of width vertices (RenderMode::LINE).  Stepped bars and the radial layout stay with the host. */
+    uint32_t vertices;
 } wf_config;
 
 /* get_defaults (src/source.cpp:119-174) + what update() derives for 48 kHz stereo OBS audio,

@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 4
+#define WF_HIP_ABI_VERSION 5
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -259,6 +259,14 @@ size_t wf_hip_table_interp_indices(const wf_hip *h, const float **out);
 size_t wf_hip_table_band_widths(const wf_hip *h, const int **out);
 size_t wf_hip_table_interp_weights(const wf_hip *h, const float **out, int *radius, int *taps);
 float wf_hip_gravity(const wf_hip *h, float seconds); /* get_gravity(), src/source.hpp:301-312 */
+/* Vertex fill (cfg.vertices): the vertices render_bars / render_curve write into their vertex buffer for one displayed
+ * channel (src/source.cpp:1576-1659, :1436-1461), produced by every tick from the bars / curve points of that tick.
+ * wf_hip_num_vertices: vertices per displayed channel (0 when cfg.vertices is off).  wf_hip_read_vertices: out is
+ * [count][display_channels][num_vertices][4] floats -- x, y, z, w as libobs' vec3 holds them (z = w = 0). */
+uint32_t wf_hip_num_vertices(const wf_hip *h);
+int wf_hip_read_vertices(wf_hip *h, uint32_t first, uint32_t count, float *out);
+const float *wf_hip_vertices_device(wf_hip *h); /* [n_streams][display_channels][num_vertices][4], device pointer */
+
 float wf_hip_db_min(void);                            /* DB_MIN, src/source.cpp:43 */
 
 /* ---- measurement ---------------------------------------------------------------------------- */

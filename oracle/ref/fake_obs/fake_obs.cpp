@@ -138,6 +138,13 @@ void data_set_from_text(obs_data *d, const char *name, const char *text)
 
 using namespace fakeobs;
 
+// gs_draw's log (fake_obs_world.hpp)
+struct gs_vertex_buffer;
+static thread_local gs_vertex_buffer *g_loaded_vb = nullptr;
+static thread_local std::vector<fakeobs::Draw> g_draws;
+std::vector<fakeobs::Draw> &fakeobs::draws() { return g_draws; }
+void fakeobs::clear_draws() { g_draws.clear(); }
+
 extern "C" {
 
 /* ---- audio / video info ------------------------------------------------- */
@@ -285,9 +292,18 @@ void gs_vertexbuffer_destroy(gs_vertbuffer_t *vb)
 }
 void gs_vertexbuffer_flush(gs_vertbuffer_t *) {}
 gs_vb_data *gs_vertexbuffer_get_data(const gs_vertbuffer_t *vb) { return vb->data; }
-void gs_load_vertexbuffer(gs_vertbuffer_t *) {}
+void gs_load_vertexbuffer(gs_vertbuffer_t *vb) { g_loaded_vb = vb; }
 void gs_load_indexbuffer(gs_indexbuffer_t *) {}
-void gs_draw(gs_draw_mode, uint32_t, uint32_t) {}
+void gs_draw(gs_draw_mode mode, uint32_t start, uint32_t num)
+{
+    fakeobs::Draw d{(int)mode, start, num, {}};
+    if(g_loaded_vb != nullptr && g_loaded_vb->data != nullptr && g_loaded_vb->data->points != nullptr) {
+        const size_t n = std::min<size_t>((size_t)start + num, g_loaded_vb->data->num);
+        d.points.resize(n * 4);
+        std::memcpy(d.points.data(), g_loaded_vb->data->points, n * 4 * sizeof(float));
+    }
+    g_draws.push_back(std::move(d));
+}
 gs_effect_t *gs_effect_create_from_file(const char *, char **) { return new gs_effect{0}; }
 void gs_effect_destroy(gs_effect_t *effect) { delete effect; }
 gs_technique_t *gs_effect_get_technique(const gs_effect_t *, const char *) { return &g_tech; }

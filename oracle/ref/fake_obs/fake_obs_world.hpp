@@ -45,6 +45,12 @@ obs_source *create_source(const char *name, uint32_t flags);
 void destroy_source(obs_source *src);
 void push_audio(obs_source *src, const audio_data *audio, bool muted);
 
+// every gs_draw call since the last clear_draws(): the draw mode, the vertex count and a copy of the loaded vertex buffer's
+// first `num` points (x, y, z, w as OBS' vec3 holds them) -- what render_bars / render_curve hand to the GPU
+struct Draw { int mode; uint32_t start, num; std::vector<float> points; };
+std::vector<Draw> &draws(); // thread-local
+void clear_draws();
+
 obs_data *data_create();
 void data_destroy(obs_data *d);
 void data_set_from_text(obs_data *d, const char *name, const char *text);

@@ -167,7 +167,22 @@ void wfref_feed_and_tick(wfref_t *h, const float *ch0, const float *ch1, uint32_
 }
 
 void wfref_tick(wfref_t *h, float seconds) { h->obj->tick(seconds); }
-void wfref_render(wfref_t *h) { h->obj->render(nullptr); }
+void wfref_render(wfref_t *h)
+{
+    fakeobs::clear_draws();
+    h->obj->render(nullptr);
+}
+/* the gs_draw calls of the last wfref_render(): render_bars / render_curve draw once per displayed channel */
+int wfref_draw_count(wfref_t *) { return (int)fakeobs::draws().size(); }
+size_t wfref_draw(wfref_t *, int i, int *mode, const float **points)
+{
+    auto &d = fakeobs::draws();
+    if(i < 0 || i >= (int)d.size())
+        return 0;
+    if(mode) *mode = d[(size_t)i].mode;
+    if(points) *points = d[(size_t)i].points.data();
+    return d[(size_t)i].num; /* vertices drawn; points holds 4 floats per vertex */
+}
 void wfref_show(wfref_t *h, int show)
 {
     h->self->showing = (show != 0);

@@ -51,6 +51,10 @@ void wfref_push_audio(wfref_t *h, const float *ch0, const float *ch1, uint32_t f
 void wfref_feed_and_tick(wfref_t *h, const float *ch0, const float *ch1, uint32_t frames, uint64_t now_ns, float seconds);
 void wfref_tick(wfref_t *h, float seconds);
 void wfref_render(wfref_t *h);
+/* what the last wfref_render() handed to gs_draw (src/source.cpp:1463-1465, :1661-1664): one call per displayed channel;
+ * returns the number of vertices drawn, *points = 4 floats (x, y, z, w) per vertex of the vertex buffer at that moment */
+int wfref_draw_count(wfref_t *h);
+size_t wfref_draw(wfref_t *h, int i, int *mode, const float **points);
 void wfref_show(wfref_t *h, int show);
 
 /* ---- state of the object (valid until the next update/destroy) ---- */

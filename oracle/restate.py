@@ -182,6 +182,15 @@ class OracleSource:
     def render_bars(self):
         self.L.wfo_render_bars(self.h)
 
+    def vertices(self, channel, line=False):
+        """the vertices render_bars / render_curve write for one displayed channel (after render_bars()): [n, 4]"""
+        self.L.wfo_fill_vertices.restype = C.c_size_t
+        self.L.wfo_fill_vertices.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_size_t]
+        n = self.L.wfo_fill_vertices(self.h, channel, 1 if line else 0, None, 0)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        self.L.wfo_fill_vertices(self.h, channel, 1 if line else 0, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+        return out[:n]
+
     @property
     def last_silent(self):
         return bool(self.L.wfo_last_silent(self.h))

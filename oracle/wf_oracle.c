@@ -796,6 +796,107 @@ void wfo_render_bars(wfo_source *s)
     }
 }
 
+/* ---- vertex fill: what render_bars / render_curve write into the vertex buffer for one channel -------------------------- */
+static void vset(float *out, size_t cap, size_t i, float x, float y)
+{
+    if(i < cap) {
+        out[4 * i] = x; out[4 * i + 1] = y; out[4 * i + 2] = 0.0f; out[4 * i + 3] = 0.0f; /* vec3_set / vec3_add leave w = 0 */
+    }
+}
+
+size_t wfo_fill_vertices(const wfo_source *s, int channel, int line, float *out, size_t cap)
+{
+    if(s->num_bars <= 0)
+        return 0;
+    const wf_config *c = &s->cfg;
+    const int curve = !c->bars && c->curve;
+    const float center = (float)c->height / 2;
+    const float bottom = (float)c->height;
+    const float cpos = c->stereo ? center : bottom;
+    const float channel_offset = c->channel_spacing * 0.5f;
+    const float *vals = s->bars[channel];
+    if(curve) { /* src/source.cpp:1436-1461; x = the column, set once in update() (:1027-1038) */
+        float offset = channel_offset;
+        if(channel)
+            offset = -offset;
+        const float bot = cpos - offset;
+        for(int i = 0; i < s->num_bars; ++i) {
+            const float val = vals[i];
+            const float y = channel == 0 ? val : bottom - val;
+            if(line)
+                vset(out, cap, (size_t)i, (float)i, y);
+            else {
+                vset(out, cap, (size_t)i * 2, (float)i, y);
+                vset(out, cap, (size_t)i * 2 + 1, (float)i, bot);
+            }
+        }
+        return line ? (size_t)s->num_bars : (size_t)s->num_bars * 2; /* gs_draw(.., vbdata->num), :1465, :985 */
+    }
+    /* render_bars, plain bars (:1609-1657) */
+    const int bar_stride = c->bar_width + c->bar_gap;
+    const float cap_radius = (float)c->bar_width / 2.0f; /* :1297 */
+    int cap_tris = 0;
+    float cap_xy[2 * 1024];
+    if(c->rounded_caps) { /* m_cap_verts, :1293-1309 */
+        const float pi = 3.14159265358979323846f; /* std::numbers::pi_v<float> */
+        cap_tris = (int)((2 * pi * cap_radius) / 3.0f);
+        if(cap_tris < 4)
+            cap_tris = 4;
+        if(cap_tris & 1)
+            cap_tris += 1;
+        if(cap_tris + 1 > 1024)
+            return 0;
+        const float angle = (2 * pi) / (float)cap_tris;
+        for(int j = 0; j < cap_tris + 1; ++j) {
+            const float a = j * angle;
+            cap_xy[2 * j] = cap_radius * cosf(a);
+            cap_xy[2 * j + 1] = cap_radius * sinf(a);
+        }
+    }
+    size_t vertpos = 0;
+    for(int i = 0; i < s->num_bars; ++i) {
+        float val = vals[i];
+        const float x1 = (float)(i * bar_stride);
+        const float x2 = x1 + c->bar_width;
+        float offset = (c->rounded_caps ? cap_radius : 0.0f) + channel_offset;
+        if(channel) {
+            val = bottom - val;
+            offset = -offset;
+        }
+        const float bot = ((c->rounded_caps && !c->stereo) || (c->channel_spacing > 0)) ? (cpos - offset) : cpos;
+        vset(out, cap, vertpos, x1, val);
+        vset(out, cap, vertpos + 1, x2, val);
+        vset(out, cap, vertpos + 2, x1, bot);
+        vset(out, cap, vertpos + 3, x2, val);
+        vset(out, cap, vertpos + 4, x1, bot);
+        vset(out, cap, vertpos + 5, x2, bot);
+        vertpos += 6;
+        if(c->rounded_caps) {
+            const float ccx = (float)(i * bar_stride) + cap_radius;
+            const int half = cap_tris / 2;
+            int start = channel ? 0 : half, stop = start + half; /* m_radial is off */
+            for(int j = start; j < stop; ++j) {
+                vset(out, cap, vertpos, cap_xy[2 * j] + ccx, cap_xy[2 * j + 1] + val);
+                vset(out, cap, vertpos + 1, cap_xy[2 * (j + 1)] + ccx, cap_xy[2 * (j + 1) + 1] + val);
+                vset(out, cap, vertpos + 2, ccx, val);
+                vertpos += 3;
+            }
+            if(!c->stereo || (c->channel_spacing > 0)) {
+                const float ccy = cpos - offset;
+                start = channel ? half : 0;
+                stop = start + half;
+                for(int j = start; j < stop; ++j) {
+                    vset(out, cap, vertpos, cap_xy[2 * j] + ccx, cap_xy[2 * j + 1] + ccy);
+                    vset(out, cap, vertpos + 1, cap_xy[2 * (j + 1)] + ccx, cap_xy[2 * (j + 1) + 1] + ccy);
+                    vset(out, cap, vertpos + 2, ccx, ccy);
+                    vertpos += 3;
+                }
+            }
+        }
+    }
+    return vertpos; /* gs_draw(GS_TRIS, 0, vertpos), :1663 */
+}
+
 /* ---- accessors ------------------------------------------------------------------------------------- */
 uint32_t wfo_fft_size(const wfo_source *s) { return s->n; }
 uint32_t wfo_output_channels(const wfo_source *s) { return s->out_ch; }

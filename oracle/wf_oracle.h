@@ -53,6 +53,10 @@ void wfo_update_input_rms(wfo_source *s);
 float wfo_input_rms(const wfo_source *s);
 void wfo_tick(wfo_source *s, float seconds);
 void wfo_render_bars(wfo_source *s);
+/* the vertex-buffer loops of render_bars (plain bars incl. rounded caps, src/source.cpp:1609-1657) and render_curve
+ * (:1436-1461) for one displayed channel, after wfo_render_bars: writes x, y, z, w per vertex (as libobs' vec3) and
+ * returns the number of vertices the reference passes to gs_draw; line != 0: RenderMode::LINE (curve only) */
+size_t wfo_fill_vertices(const wfo_source *s, int channel, int line, float *out, size_t cap);
 
 uint32_t wfo_fft_size(const wfo_source *s);
 uint32_t wfo_output_channels(const wfo_source *s);

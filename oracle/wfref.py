@@ -252,6 +252,19 @@ class RefSource:
         n = self.L.wfref_bars(self.h, ch, C.byref(p))
         return _arr(p, n)
 
+    def draws(self):
+        """the gs_draw calls of the last render(): [(mode, vertices [n, 4])], one per displayed channel"""
+        self.L.wfref_draw_count.restype = C.c_int
+        self.L.wfref_draw_count.argtypes = [C.c_void_p]
+        self.L.wfref_draw.restype = C.c_size_t
+        self.L.wfref_draw.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_float))]
+        out = []
+        for i in range(self.L.wfref_draw_count(self.h)):
+            mode, p = C.c_int(0), C.POINTER(C.c_float)()
+            n = self.L.wfref_draw(self.h, i, C.byref(mode), C.byref(p))
+            out.append((mode.value, _arr(p, n * 4).reshape(n, 4).copy()))
+        return out
+
 
 def hip_host_rms_updates() -> int:
     """update_input_rms calls of WAVSourceHIP sources that ran the reference's host loop"""

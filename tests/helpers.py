@@ -29,6 +29,7 @@ def ref_settings(cfg, **extra) -> dict:
         width=cfg.width, height=cfg.height, bar_width=cfg.bar_width, bar_gap=cfg.bar_gap,
         channel_spacing=cfg.channel_spacing, min_bar_height=cfg.min_bar_height, rounded_caps=bool(cfg.rounded_caps),
         filter_mode="gauss" if cfg.filter_mode == 1 else "none", filter_radius=repr(float(np.float32(cfg.filter_radius))),
+        render_mode="line" if getattr(cfg, "vertices", 0) == 2 else "solid",
     )
     s.update(extra)
     return s

@@ -86,6 +86,17 @@ SCENARIOS = {
                                            steps=_steps(3), record=1),
     "curve_1024_catrom_3840_linear": dict(cfg=dict(fft_size=1024, stereo=0, capture_channels=1, curve=1, interp_mode=2, width=3840, log_scale=0),
                                           steps=_steps(3), record=1),
+    # ---- vertex fill (cfg.vertices): what render_bars / render_curve hand to gs_draw, per displayed channel
+    "verts_bars_4096_stereo_caps": dict(cfg=dict(fft_size=4096, stereo=1, slope=1.0, bars=1, interp_mode=1, rounded_caps=1, channel_spacing=6, vertices=1),
+                                        steps=_steps(4), record=1),
+    "verts_bars_2048_mono_plain": dict(cfg=dict(fft_size=2048, stereo=0, bars=1, interp_mode=2, bar_width=10, bar_gap=3, min_bar_height=3, vertices=1),
+                                       steps=_steps(3), record=1),
+    "verts_bars_1024_mono_caps_mirror": dict(cfg=dict(fft_size=1024, stereo=0, capture_channels=1, bars=1, interp_mode=0, rounded_caps=1, bar_width=12,
+                                                      bar_gap=2, mirror_freq_axis=1, vertices=1), steps=_steps(3), record=1),
+    "verts_curve_2048_stereo_solid": dict(cfg=dict(fft_size=2048, stereo=1, curve=1, interp_mode=2, channel_spacing=8, width=640, vertices=1),
+                                          steps=_steps(3), record=1),
+    "verts_curve_1024_line": dict(cfg=dict(fft_size=1024, stereo=0, curve=1, interp_mode=1, width=500, filter_mode=1, filter_radius=1.5, vertices=2),
+                                  steps=_steps(3), record=1),
     "bars_gauss_4096": dict(cfg=dict(fft_size=4096, stereo=1, bars=1, interp_mode=1, filter_mode=1, filter_radius=0.8), steps=_steps(4), record=1),
     # ragged packets: 441-frame hops (window start not 16-byte aligned), then a 1024 packet
     "ragged_hops": dict(cfg=dict(fft_size=2048, stereo=1),
@@ -368,6 +379,10 @@ class RefBackend:
             self.src.render()
             bars = np.stack([self.src.bars(c) for c in range(self.disp)])
         rec = dict(db=db, bars=bars, silent=self.src.last_silent)
+        if self.cfg.vertices and bars is not None:
+            draws = self.src.draws()  # one gs_draw per displayed channel, the vertex buffer as it was at that call
+            assert len(draws) == self.disp, f"{len(draws)} draw calls for {self.disp} displayed channels"
+            rec["verts"] = np.stack([v for _, v in draws])
         if self.cfg.normalize_volume:
             rec["rms"] = np.float32(self.src.input_rms)
         return rec
@@ -454,6 +469,8 @@ class OracleBackend:
             self.src.render_bars()
             bars = self.src.bars()
         rec = dict(db=self.src.decibels(), bars=bars, silent=self.src.last_silent)
+        if self.cfg.vertices and bars is not None:
+            rec["verts"] = np.stack([self.src.vertices(c, line=self.cfg.vertices == 2) for c in range(bars.shape[0])])
         if self.auto_rms:
             rec["rms"] = np.float32(self.rms)
         return rec
@@ -530,6 +547,8 @@ class HipBackend:
         # every copy of the scenario must produce the same bits
         assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"
         rec = dict(db=db[self.probe][: self.disp], bars=None if bars is None else bars[self.probe], silent=bool(silent[self.probe]))
+        if self.cfg.vertices and bars is not None:
+            rec["verts"] = self.batch.vertices()[self.probe]
         if self.auto_rms:
             rec["rms"] = self.batch.input_rms()[self.probe]
         return rec

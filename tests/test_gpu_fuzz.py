@@ -95,6 +95,10 @@ def draw(seed: int, family: str = "pow2"):
     # a quarter of the cases run with an audio sync offset: a constant A/V-sync reserve of sync_ms * 48 frames behind the
     # window (dtaudio > 0, src/source_generic.cpp:50-59; sync_rms_buffer holds the RMS values back as well)
     sync_ms = int(r.choice([0, 0, 0, 5, 20]))
+    # (drawn last so that the cases of earlier rounds keep everything else) a third of the display cases also fill the vertex
+    # buffer: bars as triangles, the curve as a triangle strip or a line strip
+    if display and r.random() < 0.35:
+        cfg.update(vertices=1 if display == 1 else int(r.integers(1, 3)))
     return cfg, steps, sync_ms
 
 
@@ -123,6 +127,11 @@ def _compare(got, want, undo, what):
         if w["bars"] is not None:
             err = np.abs(g["bars"].astype(np.float64) - w["bars"])
             assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"{what} tick {t} bars/curve: max err {err.max():.3e} px"
+        if "verts" in w:
+            assert g["verts"].shape == w["verts"].shape, f"{what} tick {t}: vertex count"
+            assert np.array_equal(g["verts"][..., 0], w["verts"][..., 0]), f"{what} tick {t}: vertex x"
+            err = np.abs(g["verts"][..., 1].astype(np.float64) - w["verts"][..., 1])
+            assert np.all(err <= 1e-5 * np.abs(w["verts"][..., 1]) + 2e-3), f"{what} tick {t} vertex y: max err {err.max():.3e} px"
         if "rms" in w:
             assert abs(float(g["rms"]) - float(w["rms"])) <= 1e-5 * abs(float(w["rms"])) + 1e-9, f"{what} tick {t} m_input_rms"
 

@@ -46,6 +46,8 @@ def main():
             arrays[f"db_{t}"] = r["db"].astype(np.float32)
             if r["bars"] is not None:
                 arrays[f"bars_{t}"] = r["bars"].astype(np.float32)
+            if "verts" in r:
+                arrays[f"verts_{t}"] = r["verts"].astype(np.float32)
         meta = dict(scenario=name, cfg=sc["cfg"], n_ticks=len(recs), generator="tools/make_golden.py",
                     source="oracle/_ref/libwfref.so = phandasm/waveform v1.9.1 WAVSourceGeneric + vendored FFTW 3.3.11")
         p = out_dir / f"{name}.npz"

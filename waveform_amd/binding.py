@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("channel_spacing", C.c_int32), ("min_bar_height", C.c_int32), ("rounded_caps", C.c_uint32),
         ("curve", C.c_uint32), ("filter_mode", C.c_int32), ("filter_radius", C.c_float),
         ("meter", C.c_uint32), ("meter_rms", C.c_uint32), ("meter_ms", C.c_int32),
-        ("waveform", C.c_uint32),
+        ("waveform", C.c_uint32), ("vertices", C.c_uint32),
     ]
 
     @classmethod
@@ -107,6 +107,9 @@ def lib():
     L.wf_hip_sync.argtypes = [vp]
     L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_num_vertices.restype = u32
+    L.wf_hip_num_vertices.argtypes = [vp]
+    L.wf_hip_read_vertices.argtypes = [vp, u32, u32, fp]
     L.wf_hip_copy_bars_device.argtypes = [vp, u32, u32, vp]
     L.wf_hip_copy_bars_device_async.argtypes = [vp, u32, u32, vp, vp]
     L.wf_hip_time_begin.argtypes = [vp]
@@ -341,6 +344,14 @@ class SpectrumBatch:
 
     def decibels_device_ptr(self) -> int:
         return int(self.L.wf_hip_decibels_device(self.h) or 0)
+
+    def vertices(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """[count, display_channels, num_vertices, 4]: what render_bars / render_curve hand to gs_draw (cfg.vertices)"""
+        count = self.streams - first if count is None else count
+        n = int(self.L.wf_hip_num_vertices(self.h))
+        out = np.empty((count, self.display_channels, n, 4), np.float32)
+        self._ck(self.L.wf_hip_read_vertices(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def bars_device_ptr(self) -> int:
         return int(self.L.wf_hip_bars_device(self.h) or 0)

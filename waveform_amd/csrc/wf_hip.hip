@@ -18,6 +18,7 @@
 #include "wf_meter.hpp"
 #include "wf_rms.hpp"
 #include "wf_wave.hpp"
+#include "wf_vertex.hpp"
 
 namespace {
 
@@ -96,6 +97,9 @@ struct wf_hip {
     uint32_t *d_big_nz = nullptr;
     size_t big_out_lds = 0;          // dynamic LDS of big_outputs_kernel
     float *d_bars = nullptr;
+    wf::VertexTables vtab;           // cfg.vertices: the vertex fill behind every tick
+    wf::f4 *d_verts = nullptr;
+    float *d_cap_xy = nullptr;
     float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
     float *d_bar_coef = nullptr;
@@ -887,6 +891,15 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(dev_alloc(h, &h->d_verdict, 3 * n_spec));
     if(h->num_bars)
         WF_CREATE_TRY(dev_alloc(h, &h->d_bars, (size_t)h->n_streams * h->disp_ch * h->num_bars));
+    if(cfg->vertices) {
+        if(h->num_bars == 0 || cfg->vertices > 2u)
+            return bail(fail(h, WF_HIP_ERR_INVALID, "cfg.vertices needs cfg.bars or cfg.curve (and is 1 or 2)"));
+        wf::build_vertex_tables(*cfg, (int)h->num_bars, h->vtab);
+        WF_CREATE_TRY(dev_alloc(h, &h->d_verts, (size_t)h->n_streams * h->disp_ch * h->vtab.per_row));
+        WF_CREATE_HIP(hipMemsetAsync(h->d_verts, 0, (size_t)h->n_streams * h->disp_ch * h->vtab.per_row * sizeof(wf::f4), h->stream));
+        WF_CREATE_TRY(upload(h, &h->d_cap_xy, h->vtab.cap_xy));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+    }
 
 #ifdef WF_PHASE_TIMING
     WF_CREATE_TRY(dev_alloc(h, &h->d_phase_clock, n_spec * 16));
@@ -1597,6 +1610,30 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         a.stream_count = hi - lo;
         h->launch_stream = l == 0 ? h->stream : h->lane_stream[l];
         h->launch(h, a, aligned);
+        if(h->d_verts && hi > lo) { // the vertex fill of this slice, behind its bars
+            wf::VertexArgs v{};
+            v.bars = h->d_bars;
+            v.verts = h->d_verts;
+            v.cap_xy = h->d_cap_xy;
+            v.stream_base = lo;
+            v.stream_count = hi - lo;
+            v.disp_ch = h->disp_ch;
+            v.num_bars = (int)h->num_bars;
+            v.per_row = h->vtab.per_row;
+            v.per_bar = h->vtab.per_bar;
+            v.mode = h->vtab.mode;
+            v.bar_stride = h->vtab.bar_stride;
+            v.bar_width = h->cfg.bar_width;
+            v.cpos = h->vtab.cpos;
+            v.bottom = h->vtab.bottom;
+            v.channel_offset = h->vtab.channel_offset;
+            v.cap_radius = h->vtab.cap_radius;
+            v.rounded = h->cfg.rounded_caps ? 1 : 0;
+            v.cap_tris = h->vtab.cap_tris;
+            v.bottom_caps = h->vtab.bottom_caps;
+            v.bot_offset = h->vtab.bot_offset;
+            hipLaunchKernelGGL(wf::vertex_fill_kernel, dim3((hi - lo) * h->disp_ch), dim3(256), 0, h->launch_stream, v);
+        }
         if(l > 0)
             WF_HIP_TRY(h, hipEventRecord(h->ev_lane[l], h->lane_stream[l]));
     }
@@ -1895,6 +1932,27 @@ int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out)
         return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
     const size_t per = (size_t)h->disp_ch * h->num_bars;
     return read_back(h, h->d_bars + first * per, out, count * per * sizeof(float));
+}
+
+uint32_t wf_hip_num_vertices(const wf_hip *h) { return (h && h->d_verts) ? (uint32_t)h->vtab.per_row : 0u; }
+
+int wf_hip_read_vertices(wf_hip *h, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_verts == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "configuration has no vertex fill (cfg.vertices == 0)");
+    const size_t per = (size_t)h->disp_ch * h->vtab.per_row;
+    return read_back(h, h->d_verts + first * per, out, count * per * sizeof(wf::f4));
+}
+
+const float *wf_hip_vertices_device(wf_hip *h)
+{
+    if(h == nullptr || h->d_verts == nullptr)
+        return nullptr;
+    (void)join_lanes(h);
+    return reinterpret_cast<const float *>(h->d_verts);
 }
 
 int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)

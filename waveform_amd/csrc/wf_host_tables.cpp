@@ -444,6 +444,43 @@ bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max
     return true;
 }
 
+void build_vertex_tables(const wf_config &cfg, int num_bars, VertexTables &out)
+{
+    out = VertexTables{};
+    const bool curve = !cfg.bars && cfg.curve;
+    const float center = (float)cfg.height / 2;
+    out.bottom = (float)cfg.height;
+    out.cpos = cfg.stereo ? center : out.bottom;
+    out.channel_offset = cfg.channel_spacing * 0.5f;
+    if(curve) {
+        out.mode = cfg.vertices == 2 ? 2 : 1;
+        out.per_row = out.mode == 2 ? num_bars : 2 * num_bars; // src/source.cpp:985
+        return;
+    }
+    out.mode = 0;
+    out.bar_stride = cfg.bar_width + cfg.bar_gap;
+    out.per_bar = 6;
+    if(cfg.rounded_caps) { // :1293-1309, float throughout
+        constexpr float pi = std::numbers::pi_v<float>;
+        out.cap_radius = (float)cfg.bar_width / 2.0f;
+        out.cap_tris = std::max((int)((2 * pi * out.cap_radius) / 3.0f), 4);
+        if(out.cap_tris & 1)
+            out.cap_tris += 1;
+        const float angle = (2 * pi) / (float)out.cap_tris;
+        const int verts = out.cap_tris + 1;
+        out.cap_xy.resize((size_t)verts * 2);
+        for(int j = 0; j < verts; ++j) {
+            const float a = j * angle;
+            out.cap_xy[(size_t)2 * j] = out.cap_radius * std::cos(a);
+            out.cap_xy[(size_t)2 * j + 1] = out.cap_radius * std::sin(a);
+        }
+        out.bottom_caps = (!cfg.stereo || cfg.channel_spacing > 0) ? 1 : 0;                   // :1645
+        out.per_bar += 3 * (out.cap_tris / 2) * (1 + out.bottom_caps);
+    }
+    out.bot_offset = ((cfg.rounded_caps && !cfg.stereo) || cfg.channel_spacing > 0) ? 1 : 0; // :1619
+    out.per_row = out.per_bar * num_bars;
+}
+
 float db_min()
 {
     // const float WAVSource::DB_MIN = 20.0f * std::log10(std::numeric_limits<float>::min()); (src/source.cpp:43)

@@ -108,6 +108,17 @@ uint32_t bluestein_length(uint32_t n);
 void build_big_twiddles(uint32_t L, uint32_t rows, uint32_t real_n, std::vector<cfloat> &tw_big, std::vector<cfloat> &tws_big);
 void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out);
 
+// vertex fill (cfg.vertices): the geometry constants of render_bars / render_curve and m_cap_verts (src/source.cpp:1293-1309)
+struct VertexTables {
+    int mode = 0;          // 0: bars, 1: curve triangle strip, 2: curve line strip
+    int per_bar = 0, per_row = 0;
+    int bar_stride = 0, cap_tris = 0;
+    float cpos = 0, bottom = 0, channel_offset = 0, cap_radius = 0;
+    int bottom_caps = 0, bot_offset = 0;
+    std::vector<float> cap_xy; // [cap_tris + 1][2]
+};
+void build_vertex_tables(const wf_config &cfg, int num_bars, VertexTables &out);
+
 // get_gravity(seconds), src/source.hpp:301-312
 float gravity_for(const wf_config &cfg, float seconds);
 // DB_MIN, src/source.cpp:43
