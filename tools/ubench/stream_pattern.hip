@@ -21,8 +21,26 @@ struct alignas(16) f4 { float x, y, z, w; };
         }                                                                     \
     } while(0)
 
-// T threads per spectrum, SPW spectra per workgroup, N samples per window
-template<int N, int T, int SPW>
+typedef float v4f __attribute__((ext_vector_type(4)));
+template<bool NT> __device__ inline f4 ld(const f4 *p)
+{
+    if(NT) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        return f4{v.x, v.y, v.z, v.w};
+    }
+    return *p;
+}
+template<bool NT> __device__ inline void st_(f4 *p, f4 v)
+{
+    if(NT)
+        __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(p));
+    else
+        *p = v;
+}
+
+// T threads per spectrum, SPW spectra per workgroup, N samples per window; NT: state and rows with the non-temporal hint
+// (what the fused kernel does since round 2)
+template<int N, int T, int SPW, bool NT = false>
 __global__ __launch_bounds__(T *SPW) void pattern_kernel(const float *ring, size_t ring_cap, unsigned start, float *state, float *db, float g)
 {
     constexpr int M = N / 2;
@@ -39,18 +57,18 @@ __global__ __launch_bounds__(T *SPW) void pattern_kernel(const float *ring, size
         w[i] = x[t + T * i];
 #pragma unroll
     for(int i = 0; i < SV; ++i)
-        s[i] = st[t + T * i];
+        s[i] = ld<NT>(st + t + T * i);
 #pragma unroll
     for(int i = 0; i < SV; ++i) {
         const f4 a = w[2 * i], b = w[2 * i + 1];
         f4 m{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
         f4 o{g * s[i].x + m.x, g * s[i].y + m.y, g * s[i].z + m.z, g * s[i].w + m.w};
-        st[t + T * i] = o;
-        out[t + T * i] = f4{o.x * 2.0f, o.y * 2.0f, o.z * 2.0f, o.w * 2.0f};
+        st_<NT>(st + t + T * i, o);
+        st_<NT>(out + t + T * i, f4{o.x * 2.0f, o.y * 2.0f, o.z * 2.0f, o.w * 2.0f});
     }
 }
 
-template<int N, int T, int SPW> void run(size_t n_spec, int ticks, int hop, int lds_bytes)
+template<int N, int T, int SPW, bool NT = false> void run(size_t n_spec, int ticks, int hop, int lds_bytes)
 {
     const size_t ring_cap = (size_t)N + (size_t)hop * (ticks + 2);
     float *ring, *state, *db;
@@ -62,7 +80,7 @@ template<int N, int T, int SPW> void run(size_t n_spec, int ticks, int hop, int 
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    auto k = pattern_kernel<N, T, SPW>;
+    auto k = pattern_kernel<N, T, SPW, NT>;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     const dim3 grid((unsigned)(n_spec / SPW)), block(T * SPW);
     float best = 1e30f;
@@ -78,7 +96,7 @@ template<int N, int T, int SPW> void run(size_t n_spec, int ticks, int hop, int 
             best = ms / ticks;
     }
     const double bytes = 10.0 * N * n_spec;
-    printf("N=%5d T=%3d SPW=%d lds=%6d B  spectra=%zu  %.1f us/tick  %.0f GB/s  (%.1f %% of 8 TB/s)\n", N, T, SPW, lds_bytes, n_spec, best * 1e3,
+    printf("N=%5d T=%3d SPW=%d lds=%6d B nt=%d spectra=%zu  %.1f us/tick  %.0f GB/s  (%.1f %% of 8 TB/s)\n", N, T, SPW, lds_bytes, (int)NT, n_spec, best * 1e3,
            bytes / best / 1e6, bytes / best / 1e6 / 80.0);
     CHECK(hipFree(ring));
     CHECK(hipFree(state));
@@ -96,6 +114,12 @@ int main()
     run<1024, 64, 2>(32768, 40, 800, 10 * 1024);
     run<16384, 512, 2>(2048, 40, 800, 139 * 1024); // 1 per CU
     run<16384, 512, 2>(2048, 40, 800, 0);
-    run<4096, 128, 2>(32768, 40, 800, 36 * 1024);  // 4x the streams: launch ramp amortised
+    run<4096, 128, 2>(32768, 40, 800, 36 * 1024);  // 4x the streams: launch ramp amortised, working set past the Infinity Cache
+    // the same with state and rows non-temporal
+    run<4096, 128, 2, true>(8192, 40, 800, 36 * 1024);
+    run<4096, 128, 2, true>(16384, 40, 800, 36 * 1024);
+    run<4096, 128, 2>(16384, 40, 800, 36 * 1024);
+    run<4096, 128, 2, true>(32768, 40, 800, 36 * 1024);
+    run<16384, 512, 1, true>(2048, 40, 800, 74 * 1024);
     return 0;
 }
