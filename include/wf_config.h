@@ -83,8 +83,12 @@ typedef struct wf_config {
      * with vertices != 0 (and bars or curve) every tick also leaves, per displayed channel, the vertices the reference
      * hands to gs_draw -- wf_hip_read_vertices.  1: filled geometry (bars: two triangles per bar, plus the cap fans with
      * rounded_caps; curve: a triangle strip of 2 * width vertices, RenderMode SOLID / GRADIENT / ...); 2: the curve as a
-     * line strip of width vertices (RenderMode::LINE).  Stepped bars and the radial layout stay with the host. */
+     * line strip of width vertices (RenderMode::LINE); 3: stepped bars (display_mode STEPPED_BAR, :1583-1607): per bar as
+     * many step quads of step_width pixels, step_width + step_gap apart, as fit under its height -- the number of
+     * vertices then changes from tick to tick (wf_hip_read_vertex_counts).  The radial layout stays with the host. */
     uint32_t vertices;
+    int32_t step_width;         /* m_step_width (vertices == 3) */
+    int32_t step_gap;           /* m_step_gap */
 } wf_config;
 
 /* get_defaults (src/source.cpp:119-174) + what update() derives for 48 kHz stereo OBS audio,

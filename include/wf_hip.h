@@ -262,9 +262,14 @@ float wf_hip_gravity(const wf_hip *h, float seconds); /* get_gravity(), src/sour
 /* Vertex fill (cfg.vertices): the vertices render_bars / render_curve write into their vertex buffer for one displayed
  * channel (src/source.cpp:1576-1659, :1436-1461), produced by every tick from the bars / curve points of that tick.
  * wf_hip_num_vertices: vertices per displayed channel (0 when cfg.vertices is off).  wf_hip_read_vertices: out is
- * [count][display_channels][num_vertices][4] floats -- x, y, z, w as libobs' vec3 holds them (z = w = 0). */
+ * [count][display_channels][num_vertices][4] floats -- x, y, z, w as libobs' vec3 holds them (z = w = 0).
+ * Stepped bars (cfg.vertices == 3): num_vertices is the buffer's capacity per channel (num_bars * 6 * max_steps, create_vbuf
+ * src/source.cpp:988-1000); how many of them a tick's draw call uses -- gs_draw(GS_TRIS, 0, vertpos), :1663 -- comes from
+ * wf_hip_read_vertex_counts ([count][display_channels]); vertices beyond it are whatever earlier ticks left, as in the
+ * reference's buffer. */
 uint32_t wf_hip_num_vertices(const wf_hip *h);
 int wf_hip_read_vertices(wf_hip *h, uint32_t first, uint32_t count, float *out);
+int wf_hip_read_vertex_counts(wf_hip *h, uint32_t first, uint32_t count, uint32_t *out);
 const float *wf_hip_vertices_device(wf_hip *h); /* [n_streams][display_channels][num_vertices][4], device pointer */
 
 float wf_hip_db_min(void);                            /* DB_MIN, src/source.cpp:43 */

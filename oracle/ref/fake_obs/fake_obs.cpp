@@ -290,7 +290,7 @@ void gs_vertexbuffer_destroy(gs_vertbuffer_t *vb)
     }
     delete vb;
 }
-void gs_vertexbuffer_flush(gs_vertbuffer_t *) {}
+void gs_vertexbuffer_flush(gs_vertbuffer_t *) { g_draws.push_back(fakeobs::Draw{-1, 0, 0, {}}); } // logged: one flush per displayed channel, drawn or not
 gs_vb_data *gs_vertexbuffer_get_data(const gs_vertbuffer_t *vb) { return vb->data; }
 void gs_load_vertexbuffer(gs_vertbuffer_t *vb) { g_loaded_vb = vb; }
 void gs_load_indexbuffer(gs_indexbuffer_t *) {}

@@ -47,6 +47,8 @@ void push_audio(obs_source *src, const audio_data *audio, bool muted);
 
 // every gs_draw call since the last clear_draws(): the draw mode, the vertex count and a copy of the loaded vertex buffer's
 // first `num` points (x, y, z, w as OBS' vec3 holds them) -- what render_bars / render_curve hand to the GPU
+// (mode -1: a gs_vertexbuffer_flush -- render_bars / render_curve flush once per displayed channel and then draw, unless a
+// channel of stepped bars has no vertices at all, src/source.cpp:1661-1664)
 struct Draw { int mode; uint32_t start, num; std::vector<float> points; };
 std::vector<Draw> &draws(); // thread-local
 void clear_draws();

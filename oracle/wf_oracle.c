@@ -832,8 +832,35 @@ size_t wfo_fill_vertices(const wfo_source *s, int channel, int line, float *out,
         }
         return line ? (size_t)s->num_bars : (size_t)s->num_bars * 2; /* gs_draw(.., vbdata->num), :1465, :985 */
     }
-    /* render_bars, plain bars (:1609-1657) */
     const int bar_stride = c->bar_width + c->bar_gap;
+    if(c->vertices == 3) { /* stepped bars, :1583-1607 (m_step_verts: init_steps, :920-933) */
+        const int step_stride = c->step_width + c->step_gap;
+        size_t max_steps = (size_t)((cpos - channel_offset) / step_stride); /* :1496-1498 */
+        if(((int)cpos - (int)(max_steps * step_stride) - (int)channel_offset) > c->step_width)
+            ++max_steps;
+        const float sx[6] = {0.0f, (float)c->bar_width, 0.0f, (float)c->bar_width, 0.0f, (float)c->bar_width};
+        const float sy[6] = {0.0f, 0.0f, (float)c->step_width, 0.0f, (float)c->step_width, (float)c->step_width};
+        size_t vertpos = 0;
+        for(int i = 0; i < s->num_bars; ++i) {
+            const float val = vals[i];
+            const float x = (float)(i * bar_stride);
+            const float maxheight = (cpos - val - channel_offset);
+            for(unsigned j = 0u; j < max_steps; ++j) {
+                float y = (float)(j * step_stride);
+                if(y >= maxheight)
+                    break;
+                if(channel)
+                    y = cpos + y + channel_offset;
+                else
+                    y = cpos - y - channel_offset - c->step_width;
+                for(int k = 0; k < 6; ++k)
+                    vset(out, cap, vertpos + (size_t)k, sx[k] + x, sy[k] + y);
+                vertpos += 6;
+            }
+        }
+        return vertpos;
+    }
+    /* render_bars, plain bars (:1609-1657) */
     const float cap_radius = (float)c->bar_width / 2.0f; /* :1297 */
     int cap_tris = 0;
     float cap_xy[2 * 1024];

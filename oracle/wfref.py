@@ -262,7 +262,7 @@ class RefSource:
         for i in range(self.L.wfref_draw_count(self.h)):
             mode, p = C.c_int(0), C.POINTER(C.c_float)()
             n = self.L.wfref_draw(self.h, i, C.byref(mode), C.byref(p))
-            out.append((mode.value, _arr(p, n * 4).reshape(n, 4).copy()))
+            out.append((mode.value, _arr(p, n * 4).reshape(n, 4).copy() if n else np.zeros((0, 4), np.float32)))
         return out
 
 

@@ -23,7 +23,9 @@ def ref_settings(cfg, **extra) -> dict:
         rolloff_q=repr(float(np.float32(cfg.rolloff_q))), rolloff_rate=repr(float(np.float32(cfg.rolloff_rate))),
         cutoff_low=cfg.cutoff_low, cutoff_high=cfg.cutoff_high, floor=cfg.floor_db, ceiling=cfg.ceiling_db,
         normalize_volume=bool(cfg.normalize_volume), volume_target=int(cfg.volume_target), max_gain=int(cfg.max_gain),
-        display_mode="level_meter" if cfg.meter else "waveform" if cfg.waveform else ("bars" if cfg.bars else "curve"),
+        display_mode="level_meter" if cfg.meter else "waveform" if cfg.waveform else
+        (("stepped_bars" if getattr(cfg, "vertices", 0) == 3 else "bars") if cfg.bars else "curve"),
+        step_width=int(getattr(cfg, "step_width", 8)), step_gap=int(getattr(cfg, "step_gap", 4)),
         rms_mode=bool(cfg.meter_rms), meter_buf=int(cfg.meter_ms), interp_mode=INTERP_KEYS[cfg.interp_mode],
         log_scale=bool(cfg.log_scale), mirror_freq_axis=bool(cfg.mirror_freq_axis),
         width=cfg.width, height=cfg.height, bar_width=cfg.bar_width, bar_gap=cfg.bar_gap,

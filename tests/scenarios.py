@@ -97,6 +97,11 @@ SCENARIOS = {
                                           steps=_steps(3), record=1),
     "verts_curve_1024_line": dict(cfg=dict(fft_size=1024, stereo=0, curve=1, interp_mode=1, width=500, filter_mode=1, filter_radius=1.5, vertices=2),
                                   steps=_steps(3), record=1),
+    # stepped bars: the number of vertices follows the signal; narrow steps, stereo with spacing / mono
+    "verts_stepped_2048_stereo": dict(cfg=dict(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=1, channel_spacing=6, vertices=3),
+                                      steps=_steps(4), record=2),
+    "verts_stepped_1024_mono_fine": dict(cfg=dict(fft_size=1024, stereo=0, bars=1, interp_mode=2, bar_width=6, bar_gap=1, step_width=3, step_gap=1,
+                                                  min_bar_height=2, vertices=3), steps=_steps(3) + [("silence", 1200), ("tick",)], record=2),
     "bars_gauss_4096": dict(cfg=dict(fft_size=4096, stereo=1, bars=1, interp_mode=1, filter_mode=1, filter_radius=0.8), steps=_steps(4), record=1),
     # ragged packets: 441-frame hops (window start not 16-byte aligned), then a 1024 packet
     "ragged_hops": dict(cfg=dict(fft_size=2048, stereo=1),
@@ -380,9 +385,16 @@ class RefBackend:
             bars = np.stack([self.src.bars(c) for c in range(self.disp)])
         rec = dict(db=db, bars=bars, silent=self.src.last_silent)
         if self.cfg.vertices and bars is not None:
-            draws = self.src.draws()  # one gs_draw per displayed channel, the vertex buffer as it was at that call
-            assert len(draws) == self.disp, f"{len(draws)} draw calls for {self.disp} displayed channels"
-            rec["verts"] = np.stack([v for _, v in draws])
+            # per displayed channel one flush (mode -1) and then a gs_draw with the vertex buffer as it was at that call --
+            # unless the channel has no vertices (stepped bars at zero height): then nothing is drawn
+            verts = []
+            for mode, v in self.src.draws():
+                if mode < 0:
+                    verts.append(np.zeros((0, 4), np.float32))
+                else:
+                    verts[-1] = v
+            assert len(verts) == self.disp, f"{len(verts)} channels flushed for {self.disp} displayed channels"
+            rec["verts"] = verts  # [n, 4] each; n varies with the signal for stepped bars
         if self.cfg.normalize_volume:
             rec["rms"] = np.float32(self.src.input_rms)
         return rec
@@ -470,7 +482,7 @@ class OracleBackend:
             bars = self.src.bars()
         rec = dict(db=self.src.decibels(), bars=bars, silent=self.src.last_silent)
         if self.cfg.vertices and bars is not None:
-            rec["verts"] = np.stack([self.src.vertices(c, line=self.cfg.vertices == 2) for c in range(bars.shape[0])])
+            rec["verts"] = [self.src.vertices(c, line=self.cfg.vertices == 2) for c in range(bars.shape[0])]
         if self.auto_rms:
             rec["rms"] = np.float32(self.rms)
         return rec
@@ -548,7 +560,8 @@ class HipBackend:
         assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"
         rec = dict(db=db[self.probe][: self.disp], bars=None if bars is None else bars[self.probe], silent=bool(silent[self.probe]))
         if self.cfg.vertices and bars is not None:
-            rec["verts"] = self.batch.vertices()[self.probe]
+            v, n = self.batch.vertices()[self.probe], self.batch.vertex_counts()[self.probe]
+            rec["verts"] = [v[c, : int(n[c])] for c in range(v.shape[0])]  # what the draw call of that channel uses
         if self.auto_rms:
             rec["rms"] = self.batch.input_rms()[self.probe]
         return rec

@@ -49,15 +49,17 @@ def _check(name, backend):
             assert got is not None
             err = np.abs(got.astype(np.float64) - want)
             assert np.all(err <= 1e-5 * np.abs(want) + 2e-3), f"{name} tick {t} bars: max err {err.max():.3e} px"
-        if f"verts_{t}" in z.files:
-            # the vertex buffer at each channel's gs_draw: x bit for bit (integer products and the same float additions), y as
-            # close as the bars are, z = w = 0
-            got, want = r["verts"], z[f"verts_{t}"]
-            assert got.shape == want.shape, f"{name} tick {t}: {got.shape} vertices vs the reference's {want.shape}"
-            assert np.array_equal(got[..., 0], want[..., 0]), f"{name} tick {t}: vertex x coordinates differ"
+        c = 0
+        while f"verts_{t}_c{c}" in z.files:
+            # the vertex buffer at that channel's gs_draw: as many vertices, x bit for bit (integer products and the same float
+            # additions), y as close as the bars are, z = w = 0
+            got, want = r["verts"][c], z[f"verts_{t}_c{c}"]
+            assert got.shape == want.shape, f"{name} tick {t} channel {c}: {got.shape} vertices vs the reference's {want.shape}"
+            assert np.array_equal(got[..., 0], want[..., 0]), f"{name} tick {t} channel {c}: vertex x coordinates differ"
             err = np.abs(got[..., 1].astype(np.float64) - want[..., 1])
-            assert np.all(err <= 1e-5 * np.abs(want[..., 1]) + 2e-3), f"{name} tick {t} vertex y: max err {err.max():.3e} px"
+            assert np.all(err <= 1e-5 * np.abs(want[..., 1]) + 2e-3), f"{name} tick {t} channel {c} vertex y: max err {err.max():.3e} px"
             assert not got[..., 2:].any() and not want[..., 2:].any()
+            c += 1
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -98,7 +98,9 @@ def draw(seed: int, family: str = "pow2"):
     # (drawn last so that the cases of earlier rounds keep everything else) a third of the display cases also fill the vertex
     # buffer: bars as triangles, the curve as a triangle strip or a line strip
     if display and r.random() < 0.35:
-        cfg.update(vertices=1 if display == 1 else int(r.integers(1, 3)))
+        cfg.update(vertices=int(r.choice([1, 3])) if display == 1 else int(r.integers(1, 3)))
+        if cfg["vertices"] == 3:
+            cfg.update(step_width=int(r.choice([8, 3, 12])), step_gap=int(r.choice([4, 1, 0])), rounded_caps=0)
     return cfg, steps, sync_ms
 
 
@@ -119,7 +121,7 @@ def _undo_db(cfg):
     return ro
 
 
-def _compare(got, want, undo, what):
+def _compare(got, want, undo, what, cfg_stepped=False):
     assert len(got) == len(want)
     for t, (g, w) in enumerate(zip(got, want)):
         assert g["silent"] == w["silent"], f"{what} tick {t}: m_last_silent {g['silent']} != {w['silent']}"
@@ -128,10 +130,15 @@ def _compare(got, want, undo, what):
             err = np.abs(g["bars"].astype(np.float64) - w["bars"])
             assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"{what} tick {t} bars/curve: max err {err.max():.3e} px"
         if "verts" in w:
-            assert g["verts"].shape == w["verts"].shape, f"{what} tick {t}: vertex count"
-            assert np.array_equal(g["verts"][..., 0], w["verts"][..., 0]), f"{what} tick {t}: vertex x"
-            err = np.abs(g["verts"][..., 1].astype(np.float64) - w["verts"][..., 1])
-            assert np.all(err <= 1e-5 * np.abs(w["verts"][..., 1]) + 2e-3), f"{what} tick {t} vertex y: max err {err.max():.3e} px"
+            for c, (gv, wv) in enumerate(zip(g["verts"], w["verts"])):
+                # stepped bars: a bar whose height sits within rounding of a step boundary may gain or lose that step
+                if gv.shape != wv.shape and cfg_stepped:
+                    assert abs(gv.shape[0] - wv.shape[0]) <= 6 * 2, f"{what} tick {t} channel {c}: {gv.shape[0]} vs {wv.shape[0]} vertices"
+                    continue
+                assert gv.shape == wv.shape, f"{what} tick {t} channel {c}: vertex count {gv.shape} vs {wv.shape}"
+                assert np.array_equal(gv[..., 0], wv[..., 0]), f"{what} tick {t} channel {c}: vertex x"
+                err = np.abs(gv[..., 1].astype(np.float64) - wv[..., 1])
+                assert np.all(err <= 1e-5 * np.abs(wv[..., 1]) + 2e-3), f"{what} tick {t} channel {c} vertex y: max err {err.max():.3e} px"
         if "rms" in w:
             assert abs(float(g["rms"]) - float(w["rms"])) <= 1e-5 * abs(float(w["rms"])) + 1e-9, f"{what} tick {t} m_input_rms"
 
@@ -150,7 +157,7 @@ def run_spectrum_case(seed, family):
         want = scenarios.play(ora, sc)
     finally:
         hip.close()
-    _compare(got, want, undo, what + " vs the restatement")
+    _compare(got, want, undo, what + " vs the restatement", cfg_stepped=cfg_dict.get("vertices") == 3)
     if seed % REF_EVERY == 0:
         # the same script against the reference itself (its own float FFTW, its own update_input_rms); the device derives
         # m_input_rms from the audio too
@@ -163,7 +170,7 @@ def run_spectrum_case(seed, family):
                 want = scenarios.play(ref, sc)
             finally:
                 hip.close()
-            _compare(got, want, undo, what + " vs libwfref")
+            _compare(got, want, undo, what + " vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3)
 
 
 @pytest.mark.gpu

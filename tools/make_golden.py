@@ -47,7 +47,8 @@ def main():
             if r["bars"] is not None:
                 arrays[f"bars_{t}"] = r["bars"].astype(np.float32)
             if "verts" in r:
-                arrays[f"verts_{t}"] = r["verts"].astype(np.float32)
+                for c, v in enumerate(r["verts"]):
+                    arrays[f"verts_{t}_c{c}"] = v.astype(np.float32)
         meta = dict(scenario=name, cfg=sc["cfg"], n_ticks=len(recs), generator="tools/make_golden.py",
                     source="oracle/_ref/libwfref.so = phandasm/waveform v1.9.1 WAVSourceGeneric + vendored FFTW 3.3.11")
         p = out_dir / f"{name}.npz"

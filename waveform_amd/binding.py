@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("channel_spacing", C.c_int32), ("min_bar_height", C.c_int32), ("rounded_caps", C.c_uint32),
         ("curve", C.c_uint32), ("filter_mode", C.c_int32), ("filter_radius", C.c_float),
         ("meter", C.c_uint32), ("meter_rms", C.c_uint32), ("meter_ms", C.c_int32),
-        ("waveform", C.c_uint32), ("vertices", C.c_uint32),
+        ("waveform", C.c_uint32), ("vertices", C.c_uint32), ("step_width", C.c_int32), ("step_gap", C.c_int32),
     ]
 
     @classmethod
@@ -110,6 +110,7 @@ def lib():
     L.wf_hip_num_vertices.restype = u32
     L.wf_hip_num_vertices.argtypes = [vp]
     L.wf_hip_read_vertices.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_read_vertex_counts.argtypes = [vp, u32, u32, C.POINTER(C.c_uint32)]
     L.wf_hip_copy_bars_device.argtypes = [vp, u32, u32, vp]
     L.wf_hip_copy_bars_device_async.argtypes = [vp, u32, u32, vp, vp]
     L.wf_hip_time_begin.argtypes = [vp]
@@ -351,6 +352,13 @@ class SpectrumBatch:
         n = int(self.L.wf_hip_num_vertices(self.h))
         out = np.empty((count, self.display_channels, n, 4), np.float32)
         self._ck(self.L.wf_hip_read_vertices(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def vertex_counts(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """[count, display_channels]: vertices each row's draw call uses (constant unless the bars are stepped)"""
+        count = self.streams - first if count is None else count
+        out = np.empty((count, self.display_channels), np.uint32)
+        self._ck(self.L.wf_hip_read_vertex_counts(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
 
     def bars_device_ptr(self) -> int:

@@ -99,6 +99,7 @@ struct wf_hip {
     float *d_bars = nullptr;
     wf::VertexTables vtab;           // cfg.vertices: the vertex fill behind every tick
     wf::f4 *d_verts = nullptr;
+    uint32_t *d_vert_counts = nullptr; // [n_streams][disp_ch] vertices of each row's draw call
     float *d_cap_xy = nullptr;
     float *d_window = nullptr, *d_slope = nullptr, *d_rolloff = nullptr;
     wf::cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tws = nullptr;
@@ -892,9 +893,14 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(h->num_bars)
         WF_CREATE_TRY(dev_alloc(h, &h->d_bars, (size_t)h->n_streams * h->disp_ch * h->num_bars));
     if(cfg->vertices) {
-        if(h->num_bars == 0 || cfg->vertices > 2u)
-            return bail(fail(h, WF_HIP_ERR_INVALID, "cfg.vertices needs cfg.bars or cfg.curve (and is 1 or 2)"));
+        if(h->num_bars == 0 || cfg->vertices > 3u || (cfg->vertices == 3u && (!cfg->bars || cfg->step_width < 1 || cfg->step_gap < 0)) ||
+           (cfg->vertices == 2u && cfg->bars))
+            return bail(fail(h, WF_HIP_ERR_INVALID, "cfg.vertices: 1 needs bars or curve, 2 the curve, 3 bars with step_width >= 1 and step_gap >= 0"));
         wf::build_vertex_tables(*cfg, (int)h->num_bars, h->vtab);
+        if(h->vtab.per_row <= 0)
+            return bail(fail(h, WF_HIP_ERR_INVALID, "cfg.vertices: no room for a single step (height %u, step_width %d)", cfg->height, cfg->step_width));
+        WF_CREATE_TRY(dev_alloc(h, &h->d_vert_counts, (size_t)h->n_streams * h->disp_ch));
+        WF_CREATE_HIP(hipMemsetAsync(h->d_vert_counts, 0, (size_t)h->n_streams * h->disp_ch * sizeof(uint32_t), h->stream));
         WF_CREATE_TRY(dev_alloc(h, &h->d_verts, (size_t)h->n_streams * h->disp_ch * h->vtab.per_row));
         WF_CREATE_HIP(hipMemsetAsync(h->d_verts, 0, (size_t)h->n_streams * h->disp_ch * h->vtab.per_row * sizeof(wf::f4), h->stream));
         WF_CREATE_TRY(upload(h, &h->d_cap_xy, h->vtab.cap_xy));
@@ -1632,6 +1638,10 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
             v.cap_tris = h->vtab.cap_tris;
             v.bottom_caps = h->vtab.bottom_caps;
             v.bot_offset = h->vtab.bot_offset;
+            v.step_width = h->cfg.step_width;
+            v.step_stride = h->vtab.step_stride;
+            v.max_steps = h->vtab.max_steps;
+            v.counts = h->d_vert_counts;
             hipLaunchKernelGGL(wf::vertex_fill_kernel, dim3((hi - lo) * h->disp_ch), dim3(256), 0, h->launch_stream, v);
         }
         if(l > 0)
@@ -1945,6 +1955,16 @@ int wf_hip_read_vertices(wf_hip *h, uint32_t first, uint32_t count, float *out)
         return fail(h, WF_HIP_ERR_INVALID, "configuration has no vertex fill (cfg.vertices == 0)");
     const size_t per = (size_t)h->disp_ch * h->vtab.per_row;
     return read_back(h, h->d_verts + first * per, out, count * per * sizeof(wf::f4));
+}
+
+int wf_hip_read_vertex_counts(wf_hip *h, uint32_t first, uint32_t count, uint32_t *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_vert_counts == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "configuration has no vertex fill (cfg.vertices == 0)");
+    return read_back(h, h->d_vert_counts + (size_t)first * h->disp_ch, out, (size_t)count * h->disp_ch * sizeof(uint32_t));
 }
 
 const float *wf_hip_vertices_device(wf_hip *h)

@@ -460,6 +460,16 @@ void build_vertex_tables(const wf_config &cfg, int num_bars, VertexTables &out)
     out.mode = 0;
     out.bar_stride = cfg.bar_width + cfg.bar_gap;
     out.per_bar = 6;
+    if(cfg.vertices == 3) { // stepped bars: create_vbuf, src/source.cpp:988-1000
+        out.mode = 3;
+        out.step_stride = cfg.step_width + cfg.step_gap;
+        size_t max_steps = (size_t)((out.cpos - out.channel_offset) / out.step_stride);
+        if(((int)out.cpos - (int)(max_steps * out.step_stride) - (int)out.channel_offset) > cfg.step_width)
+            ++max_steps;
+        out.max_steps = (int)max_steps;
+        out.per_row = num_bars * 6 * out.max_steps;
+        return;
+    }
     if(cfg.rounded_caps) { // :1293-1309, float throughout
         constexpr float pi = std::numbers::pi_v<float>;
         out.cap_radius = (float)cfg.bar_width / 2.0f;
@@ -511,6 +521,8 @@ void normalize_config(wf_config &cfg)
     }
     if(!cfg.stereo || (((int)cfg.height - cfg.channel_spacing) < 1))
         cfg.channel_spacing = 0;
+    if(cfg.vertices == 3) // display_mode STEPPED_BAR: m_rounded_caps = false (src/source.cpp:648-649)
+        cfg.rounded_caps = 0;
 }
 
 uint32_t meter_config(wf_config &cfg)
@@ -796,4 +808,7 @@ extern "C" void wf_config_defaults(wf_config *cfg)
     cfg->meter_rms = 1;            // P_RMS_MODE default true
     cfg->meter_ms = 150;           // P_METER_BUF default
     cfg->waveform = 0;
+    cfg->vertices = 0;
+    cfg->step_width = 8;           // get_defaults, src/source.cpp:163-164
+    cfg->step_gap = 4;
 }

@@ -110,7 +110,8 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
 
 // vertex fill (cfg.vertices): the geometry constants of render_bars / render_curve and m_cap_verts (src/source.cpp:1293-1309)
 struct VertexTables {
-    int mode = 0;          // 0: bars, 1: curve triangle strip, 2: curve line strip
+    int mode = 0;          // 0: bars, 1: curve triangle strip, 2: curve line strip, 3: stepped bars
+    int step_stride = 0, max_steps = 0;
     int per_bar = 0, per_row = 0;
     int bar_stride = 0, cap_tris = 0;
     float cpos = 0, bottom = 0, channel_offset = 0, cap_radius = 0;
