@@ -137,6 +137,7 @@ struct wf_hip {
     float *d_meter_buf = nullptr;    // [n_streams * cap_ch] m_meter_buf
     float *d_meter_val = nullptr;    // [n_streams * cap_ch] m_meter_val
     bool curve = false;              // the outputs are curve points (render_curve), not bars
+    bool curve_both = false;         // ... finished by the threads of both spectra of a workgroup (mono mixdown)
     bool curve_catrom = false;       // ... Catmull-Rom: positions only, weights on the device (BarArgs::cur_x)
     bool stream_steps = false;       // ... more points per thread than OutVals holds (BarArgs::stream_steps)
     float *d_cur_x = nullptr;
@@ -492,6 +493,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.cur_x = h->d_cur_x;
         a.bar.curve = h->curve ? (h->curve_catrom ? 2 : 1) : 0;
         a.bar.stream_steps = h->stream_steps ? 1 : 0;
+        a.bar.both_subs = h->curve_both ? 1 : 0;
         a.bar.out_steps = h->out_steps;
         a.bar.gauss = h->d_gauss;
         a.bar.gauss_wsum = h->d_gauss_wsum;
@@ -943,6 +945,13 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         if(h->curve) {
             // one curve point per thread and step; the filter stages the row's points in the spectrum's LDS
             wf::CurveLaneTables cl;
+            // mono mixdown with both channels of a stream in one workgroup: the one displayed row is finished by the threads
+            // of both spectra (spectrum_tick_kernel, BarArgs::both_subs)
+            h->curve_both = !cfg->stereo && cfg->capture_channels == 2 && h->big_l == 0 && !want_split;
+            if(const char *e = std::getenv("WF_HIP_CURVE_BOTH"))
+                h->curve_both = h->curve_both && e[0] != '0';
+            if(h->curve_both)
+                threads *= 2;
             if(!wf::curve_lanes(h->tab, *cfg, threads, kmax, cl))
                 return bail(fail(h, WF_HIP_ERR_INVALID, "curve display: no point table for width %u at fft_size %u", cfg->width, h->N));
             h->out_steps = cl.steps;

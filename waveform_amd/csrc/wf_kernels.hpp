@@ -491,13 +491,22 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 
     // ---- bars: what render_bars derives from the rows just written (reference src/source.cpp:1500-1557) ---------------
     if(a.bar.out != nullptr) {
-        float *dbl = reinterpret_cast<float *>(lds);
-        spectrum_sync<G>(); // every thread of the spectrum is done reading its exchange buffer
+        // mono mixdown displays one row per stream: its curve points are shared by the threads of both spectra of the workgroup
+        // (the plugin's default configuration: 800 points, 4 steps of 256 threads instead of 7 of 128)
+        const bool both = SPW == 2 && !SPLIT && a.bar.both_subs != 0;
+        float *dbl = both ? reinterpret_cast<float *>(smem_raw) : reinterpret_cast<float *>(lds);
+        auto row_sync = [&] {
+            if(both)
+                __syncthreads();
+            else
+                spectrum_sync<G>();
+        };
+        row_sync(); // every thread of the spectrum is done reading its exchange buffer
         if(have_row && row_thread)
             store_row<RG, BLU>(dbl, t, d, NB);
         if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)
             dbl[MO] = dbl[MO + 1] = 0.0f;
-        spectrum_sync<G>();
+        row_sync();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
         float *out1 = dup_row ? out0 + a.bar.num_bars : nullptr;
 #ifdef WF_PHASE_TIMING
@@ -509,19 +518,37 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 #endif
         OutVals<G> ov;
         bool pending = true;
-        if(a.bar.stream_steps) {
-            curve_row_stream<G>(bar_args, have_row, dbl, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
-            pending = false;
-        } else if(a.bar.curve == 2)
-            curve_row_catrom<G>(bar_args, have_row, dbl, t, ov);
-        else if(a.bar.curve)
-            curve_row<G>(bar_args, have_row, dbl, t, ov);
-        else
-            pending = bars_reduce_row<G>(
-                bar_args, bar_pre, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
-                [](float v, int m) { return v + __shfl_xor(v, m, 64); });
-        if(pending)
-            outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
+        if constexpr(SPW == 2 && !SPLIT) {
+            if(both) {
+                constexpr int TT = 2 * T;
+                float *row0 = a.bar.out + (size_t)stream * a.bar.disp_ch * a.bar.num_bars; // the stream's only displayed row
+                if(a.bar.stream_steps) {
+                    curve_row_stream<G, TT>(bar_args, do_db, dbl, dbl, tid, row0, nullptr, [] { __syncthreads(); });
+                } else {
+                    if(a.bar.curve == 2)
+                        curve_row_catrom<G, TT>(bar_args, do_db, dbl, tid, ov);
+                    else
+                        curve_row<G, TT>(bar_args, do_db, dbl, tid, ov);
+                    outputs_finish<G, TT>(bar_args, do_db, ov, dbl, tid, row0, nullptr, [] { __syncthreads(); });
+                }
+                pending = false;
+            }
+        }
+        if(pending && !both) {
+            if(a.bar.stream_steps) {
+                curve_row_stream<G>(bar_args, have_row, dbl, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
+                pending = false;
+            } else if(a.bar.curve == 2)
+                curve_row_catrom<G>(bar_args, have_row, dbl, t, ov);
+            else if(a.bar.curve)
+                curve_row<G>(bar_args, have_row, dbl, t, ov);
+            else
+                pending = bars_reduce_row<G>(
+                    bar_args, bar_pre, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
+                    [](float v, int m) { return v + __shfl_xor(v, m, 64); });
+            if(pending)
+                outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
+        }
         if(defer_rows && have_row && row_thread && !a.skip_decibels) {
             store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
             if(dup_row)

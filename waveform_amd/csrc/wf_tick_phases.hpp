@@ -77,6 +77,8 @@ struct BarArgs {
     const float *cur_x;        // [out_steps rounded up to 4][T] m_interp_indices, lane-major; padding entries hold 1.0f
     int curve;                 // 2: Catmull-Rom curve from cur_x; 1: curve tables above; 0: bar tables
     int out_steps;             // ceil(num_bars / T) when the outputs are finished one per thread and step, else 0
+    int both_subs;             // != 0 (curve, mono mixdown, two spectra per workgroup): the threads of both spectra finish the
+                               // one displayed row; the tables are laid out for 2 * T threads
     int stream_steps;          // != 0: more steps than a thread's registers hold (wide curves): points are finished as they
                                // are produced -- mapped and stored at once, or staged behind the dB row for the filter
     // Gaussian filter across the outputs before the dB -> pixel mapping (apply_filter / weighted_avg,
@@ -1297,9 +1299,11 @@ template<class G> struct OutVals {
 
 // curve points of this thread from the dB row parked in LDS.  Steps are taken four at a time: the (L2) table loads of a
 // group are issued together; the tables are padded to whole groups with zero coefficients.
-template<class G> WF_DEV void curve_row(const BarArgs &b, bool has_row, const float *db, int t, OutVals<G> &ov)
+// (TT: threads that share the row -- G::T, or 2 * G::T when the threads of both spectra of a workgroup finish the one row a
+// mono mixdown displays, BarArgs::both_subs)
+template<class G, int TT = G::T> WF_DEV void curve_row(const BarArgs &b, bool has_row, const float *db, int t, OutVals<G> &ov)
 {
-    constexpr int T = G::T, K = OutVals<G>::KMAX;
+    constexpr int T = TT, K = OutVals<G>::KMAX;
     static_assert(K % 4 == 0, "curve steps are processed in groups of four");
     WF_UNROLL
     for(int k = 0; k < K; ++k)
@@ -1363,9 +1367,9 @@ WF_DEV float catrom_point(const float *db, float x)
     sum = sum + (p[3] * c.w3);
     return sum;
 }
-template<class G> WF_DEV void curve_row_catrom(const BarArgs &b, bool has_row, const float *db, int t, OutVals<G> &ov)
+template<class G, int TT = G::T> WF_DEV void curve_row_catrom(const BarArgs &b, bool has_row, const float *db, int t, OutVals<G> &ov)
 {
-    constexpr int T = G::T, K = OutVals<G>::KMAX;
+    constexpr int T = TT, K = OutVals<G>::KMAX;
     WF_UNROLL
     for(int k = 0; k < K; ++k)
         ov.v[k] = 0.0f;
@@ -1388,10 +1392,10 @@ template<class G> WF_DEV void curve_row_catrom(const BarArgs &b, bool has_row, c
 // Curves wider than KMAX points per thread: a run-time loop over the steps; every point is mapped and stored as soon as it
 // is produced, or -- with the Gaussian filter on -- staged behind the dB row ([pad | points | pad | weights] from
 // db + stage_off, sized on the host) and filtered in a second loop.
-template<class G, class Sync>
+template<class G, int TT = G::T, class Sync>
 WF_DEV void curve_row_stream(const BarArgs &b, bool has_row, const float *db, float *lds, int t, float *out_row, float *dup_row, Sync sync)
 {
-    constexpr int T = G::T;
+    constexpr int T = TT;
     const int n = b.num_bars;
     const bool filtered = b.gauss_radius > 0;
     const int pad = b.gauss_radius - 1, size = 2 * b.gauss_radius - 1;
@@ -1450,10 +1454,10 @@ WF_DEV void curve_row_stream(const BarArgs &b, bool has_row, const float *db, fl
 // row.  Here the row is staged with radius-1 zeros on either side (a dropped tap adds an exact 0), the weights sit next
 // to it, and the divisor of every output comes from a table the host accumulated in the reference's order -- so the
 // inner loop is one LDS read and one FMA per tap, no bounds logic.
-template<class G, class Sync>
+template<class G, int TT = G::T, class Sync>
 WF_DEV void outputs_finish(const BarArgs &b, bool has_row, OutVals<G> &ov, float *lds, int t, float *out_row, float *dup_row, Sync sync)
 {
-    constexpr int T = G::T, K = OutVals<G>::KMAX;
+    constexpr int T = TT, K = OutVals<G>::KMAX;
     static_assert(K % 4 == 0, "outputs are filtered in groups of four");
     const int n = b.num_bars;
     if(b.gauss_radius > 0) {
