@@ -300,28 +300,28 @@ template<class G, int SPW, bool SPLIT> int setup_launch_blu(wf_hip *h)
     return WF_HIP_OK;
 }
 
-template<class G, int SPW, bool TLDS> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
+template<class G, int SPW, bool TLDS, bool BOTH = false> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     const uint32_t n_spec = a.stream_count * a.cap_ch;
     const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
     const size_t lds = wf::tick_lds_bytes<G, SPW>();
     if(aligned)
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS>), grid, block, lds, h->launch_stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS, false, BOTH>), grid, block, lds, h->launch_stream, a);
     else
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS>), grid, block, lds, h->launch_stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS, false, BOTH>), grid, block, lds, h->launch_stream, a);
 }
 
-template<class G, int SPW, bool TLDS> int setup_launch_impl(wf_hip *h)
+template<class G, int SPW, bool TLDS, bool BOTH = false> int setup_launch_impl(wf_hip *h)
 {
     const int lds = (int)wf::tick_lds_bytes<G, SPW>();
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS>),
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS, false, BOTH>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS>),
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS, false, BOTH>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    h->launch = &launch_tick<G, SPW, TLDS>;
-    char name[96];
-    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=%d%s>", G::N, G::T, G::R1, G::R2, G::R3, SPW,
-             TLDS ? ",tables via LDS" : "");
+    h->launch = &launch_tick<G, SPW, TLDS, BOTH>;
+    char name[112];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=%d%s%s>", G::N, G::T, G::R1, G::R2, G::R3, SPW,
+             TLDS ? ",tables via LDS" : "", BOTH ? ",curve row shared by both spectra" : "");
     h->kernel_name = name;
     return WF_HIP_OK;
 }
@@ -336,6 +336,13 @@ template<class G, int SPW> int setup_launch(wf_hip *h)
         bool tlds = G::P <= 8;
         if(const char *e = std::getenv("WF_HIP_TLDS"))
             tlds = e[0] == '1';
+        // mono mixdown with a curve display: the kernel whose two spectra share the row (a TLDS override keeps the plain one)
+        if(h->curve_both && h->N == (uint32_t)G::N && tlds == (G::P <= 8)) {
+            if constexpr(G::P <= 8)
+                return setup_launch_impl<G, 2, true, true>(h);
+            else
+                return setup_launch_impl<G, 2, false, true>(h);
+        }
         if(tlds)
             return setup_launch_impl<G, 2, true>(h);
     }
@@ -947,7 +954,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             wf::CurveLaneTables cl;
             // mono mixdown with both channels of a stream in one workgroup: the one displayed row is finished by the threads
             // of both spectra (spectrum_tick_kernel, BarArgs::both_subs)
-            h->curve_both = !cfg->stereo && cfg->capture_channels == 2 && h->big_l == 0 && !want_split;
+            h->curve_both = !cfg->stereo && cfg->capture_channels == 2 && h->big_l == 0 && !want_split && !h->blu && h->N >= 1024u &&
+                            std::getenv("WF_HIP_TLDS") == nullptr; // (the kernels that exist with BOTH: setup_launch)
             if(const char *e = std::getenv("WF_HIP_CURVE_BOTH"))
                 h->curve_both = h->curve_both && e[0] != '0';
             if(h->curve_both)

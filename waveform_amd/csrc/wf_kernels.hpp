@@ -125,9 +125,14 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // twice -- on the chirped window, then (conjugated) on its product with the chirp's transform -- and the epilogue takes
 // |c_k| of the first a.row_bins bins directly, no real split.  Rows and state have a.row_bins (a run-time number) entries;
 // the threads whose groups of four bins lie beyond it sit the epilogue out.
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false>
+//
+// BOTH (SPW == 2, mono mixdown with a curve display): the stream's one displayed row is finished by the threads of both
+// spectra.  A template parameter, not a run-time flag: the extra code cost the 2048-point kernel a VGPR too many (129: three
+// waves per SIMD instead of four) and 5-15 % even on configurations that never take the path.
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false>
 __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
+    static_assert(!BOTH || (SPW == 2 && !SPLIT && DEC == 0 && !BLU), "shared curve row: two spectra per workgroup, power-of-two sizes");
     static_assert(!BLU || (DEC == 0 && !TLDS && !ALIGNED), "Bluestein path: scalar fetch, no decimation, no staged tables");
     static_assert(!TLDS || (SPW == 2 && !SPLIT && DEC == 0 && (size_t)SPW * G::LDS_CF * sizeof(cf) >= 2u * G::N * sizeof(float)),
                   "staged tables: window + pass-1 twiddles must fit the workgroup's exchange buffers");
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     if(a.bar.out != nullptr) {
         // mono mixdown displays one row per stream: its curve points are shared by the threads of both spectra of the workgroup
         // (the plugin's default configuration: 800 points, 4 steps of 256 threads instead of 7 of 128)
-        const bool both = SPW == 2 && !SPLIT && a.bar.both_subs != 0;
+        constexpr bool both = BOTH;
         float *dbl = both ? reinterpret_cast<float *>(smem_raw) : reinterpret_cast<float *>(lds);
         auto row_sync = [&] {
             if(both)
@@ -518,8 +523,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
 #endif
         OutVals<G> ov;
         bool pending = true;
-        if constexpr(SPW == 2 && !SPLIT) {
-            if(both) {
+        if constexpr(BOTH) {
+            {
                 constexpr int TT = 2 * T;
                 float *row0 = a.bar.out + (size_t)stream * a.bar.disp_ch * a.bar.num_bars; // the stream's only displayed row
                 if(a.bar.stream_steps) {
