@@ -124,10 +124,12 @@ def roofline(batch, shape, kernel_ms, flags=0):
     prof = pmc_profile(shape) if shape else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": (prof[1].get("hbm_bytes_per_tick") or prof[1]["hbm_bytes_per_launch"]) if prof else None,
-           "kernel": batch.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
-           # "launch" = one wf_hip_tick: the batch goes out as this many concurrent launches of the kernel (lanes on their
-           # own HIP streams), timed together by the events.  rocprofv3's per-launch average is one slice sharing the chip
-           # with the others; what must agree with kernel_ms is the tick span of its kernel trace (below)
+           "kernel": batch.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_tick": algo,
+           "algorithmic_bytes_per_kernel_launch": algo // max(batch.launches_per_tick(), 1),
+           # achieved = algorithmic_bytes_per_tick / kernel_ms.  A tick goes out as kernel_launches_per_tick concurrent
+           # launches of the kernel (lanes on their own HIP streams), timed together by the events (kernel_ms).  rocprofv3's
+           # per-launch average is one slice (algorithmic_bytes_per_kernel_launch) sharing the chip with the others; what
+           # must agree with kernel_ms is the tick span of its kernel trace (profile.tick_span_ms)
            "kernel_launches_per_tick": batch.launches_per_tick()}
     if prof:
         tr, ks = prof[1].get("trace") or {}, prof[1].get("kernel_stats") or {}

@@ -314,3 +314,32 @@ def test_pipelined_ingest_matches_the_blocking_one():
     for p in pin + out:
         p.close()
     assert np.array_equal(got_db, want_db) and np.array_equal(got_bars, want_bars)
+
+
+def test_two_handles_on_two_host_threads():
+    """distinct handles may be used concurrently (SURVEY.md section 8(b) threading): two host threads, each with its own batch,
+    tick the same audio at the same time; both must produce exactly what one handle produces alone"""
+    import threading
+    cfg = wf.Config.defaults(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    streams, ticks, hop = 256, 40, 800
+    audio = [synth.block(SEED, 0, streams, 2, t * hop, hop) for t in range(ticks)]
+
+    def run(out, idx):
+        with wf.SpectrumBatch(cfg, streams) as b:
+            for t in range(ticks):
+                b.push_audio(audio[t])
+                b.tick()
+            out[idx] = (b.decibels(), b.bars(), b.last_silent())
+
+    alone = [None]
+    run(alone, 0)
+    res = [None, None]
+    th = [threading.Thread(target=run, args=(res, i)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert res[i] is not None, "a worker thread died"
+        for got, want in zip(res[i], alone[0]):
+            assert np.array_equal(got, want), f"handle {i} on its own thread differs from the single-threaded run"
