@@ -145,7 +145,8 @@ struct wf_hip {
     float *d_cur_coef = nullptr, *d_gauss = nullptr, *d_gauss_wsum = nullptr;
     int *d_cur_base = nullptr;
     float *d_lane_coef = nullptr;
-    int *d_lane_base = nullptr, *d_bar_seg = nullptr, *d_seg_group = nullptr;
+    int *d_lane_base = nullptr, *d_bar_seg = nullptr, *d_seg_group = nullptr, *d_lead_bar = nullptr, *d_lead_end = nullptr;
+    bool bar_wave_local = false;
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;
@@ -493,6 +494,9 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.lane_base = h->d_lane_base;
         a.bar.bar_seg = h->d_bar_seg;
         a.bar.seg_group = h->d_seg_group;
+        a.bar.lead_bar = h->d_lead_bar;
+        a.bar.lead_end = h->d_lead_end;
+        a.bar.wave_local = h->bar_wave_local ? 1 : 0;
         a.bar.num_segs = h->bar_segs;
         a.bar.lane_blocks = h->bar_blocks;
         a.bar.cur_coef = h->d_cur_coef;
@@ -971,7 +975,13 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
         } else if(h->big_l == 0) { // (the large-transform path reduces its bars from the flat tables, one wavefront per bar)
             wf::BarLaneTables lanes;
-            if(wf::bar_segments(h->tab, threads, points / 4 + 1, lanes)) {
+            // (wave-local layout: no workgroup barrier inside the reduction; not with the filter, whose inputs are staged by
+            // bar index behind a barrier anyway.  WF_HIP_BARS_WAVE_LOCAL=0: the plain layout, development aid)
+            bool local = h->tab.gauss_radius == 0;
+            if(const char *e = std::getenv("WF_HIP_BARS_WAVE_LOCAL"))
+                local = local && e[0] != '0';
+            if(wf::bar_segments(h->tab, threads, points / 4 + 2, lanes, local)) {
+                h->bar_wave_local = lanes.wave_local;
                 h->bar_segs = lanes.num_segs;
                 h->bar_blocks = lanes.blocks;
                 h->out_steps = 1;
@@ -979,6 +989,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 WF_CREATE_TRY(upload(h, &h->d_lane_base, lanes.base));
                 WF_CREATE_TRY(upload(h, &h->d_bar_seg, lanes.bar_seg));
                 WF_CREATE_TRY(upload(h, &h->d_seg_group, lanes.seg_group));
+                WF_CREATE_TRY(upload(h, &h->d_lead_bar, lanes.lead_bar));
+                WF_CREATE_TRY(upload(h, &h->d_lead_end, lanes.lead_end));
                 WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
             }
         }

@@ -342,7 +342,7 @@ std::vector<int> bar_chunks(const HostTables &t, size_t cap_floats)
     return chunks;
 }
 
-bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out)
+bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out, bool wave_local)
 {
     out = BarLaneTables{};
     if(t.num_bars <= 0 || t.num_bars > threads)
@@ -358,51 +358,82 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
         first = lo & ~3;
         return lo - first; // leading bins with coefficient 0
     };
-    auto count_for = [&](int L) {
-        long n = 0;
-        for(int b = 0; b < t.num_bars; ++b) {
-            int first, len;
-            const int lead = span(b, first, len);
-            n += len == 0 ? 1 : (lead + len + L - 1) / L;
-        }
-        return n;
+    auto segs_of = [&](int b, int L) {
+        int first, len;
+        const int lead = span(b, first, len);
+        return len == 0 ? 1 : (lead + len + L - 1) / L;
     };
-    int L = 4;
-    while(count_for(L) > threads) // smallest multiple of 4 whose segment count fits the threads (num_bars <= threads)
-        L += 4;
-    if(L / 4 > max_blocks || L > M)
+    // slot of every bar's first segment for segment length L, or false if the layout does not fit the threads
+    auto place = [&](int L, bool local, std::vector<int> &start) {
+        start.assign((size_t)t.num_bars + 1, 0);
+        int s = 0;
+        for(int b = 0; b < t.num_bars; ++b) {
+            const int k = segs_of(b, L);
+            if(local) {
+                if(k > 64)
+                    return false;
+                if((s % 64) + k > 64) // the bar would straddle a wavefront: start it in the next one
+                    s = (s + 63) / 64 * 64;
+            }
+            start[(size_t)b] = s;
+            s += k;
+        }
+        start[(size_t)t.num_bars] = s;
+        return s <= threads;
+    };
+    std::vector<int> start;
+    int L = 0;
+    bool local = false;
+    if(wave_local && threads > 64)
+        for(int l = 4; l <= 4 * max_blocks && l <= M; l += 4)
+            if(place(l, true, start)) {
+                L = l;
+                local = true;
+                break;
+            }
+    if(L == 0)
+        for(int l = 4; l <= 4 * max_blocks && l <= M; l += 4) // smallest multiple of 4 whose segment count fits the threads
+            if(place(l, false, start)) {
+                L = l;
+                break;
+            }
+    if(L == 0)
         return false;
+    out.wave_local = local;
     out.blocks = L / 4;
     out.coef.assign((size_t)out.blocks * threads * 4, 0.0f);
     out.base.assign((size_t)threads, 0);
-    int s = 0;
+    out.seg_group.assign((size_t)threads, 0);
+    out.lead_bar.assign((size_t)threads, -1);
+    out.lead_end.assign((size_t)threads, 0);
     for(int b = 0; b < t.num_bars; ++b) {
-        out.bar_seg.push_back(s);
         int first, len;
         const int lead = span(b, first, len);
         const int o = t.bar_off[(size_t)b];
-        const int segs = len == 0 ? 1 : (lead + len + L - 1) / L;
-        for(int g = 0; g < segs; ++g, ++s) {
-            // bins [start, start + L) of the row; a segment that would reach past the row moves down (its coefficients with it)
-            int start = first + g * L;
-            if(start + L > M)
-                start = M - L;
-            out.base[(size_t)s] = start;
+        const int segs = segs_of(b, L), s0 = start[(size_t)b];
+        out.bar_seg.push_back(s0);
+        out.lead_bar[(size_t)s0] = b;
+        out.lead_end[(size_t)s0] = s0 + segs;
+        for(int g = 0; g < segs; ++g) {
+            const int s = s0 + g;
+            // bins [bstart, bstart + L) of the row; a segment that would reach past the row moves down (its coefficients with it)
+            int bstart = first + g * L;
+            if(bstart + L > M)
+                bstart = M - L;
+            out.base[(size_t)s] = bstart;
             for(int k = 0; k < L; ++k) {
-                const int bin = start + k, e = bin - (first + lead); // entry index within the bar
+                const int bin = bstart + k, e = bin - (first + lead); // entry index within the bar
                 // every bin belongs to exactly one segment of the bar: the one whose nominal range [first + g L, +L) holds it
                 const bool mine = bin >= first + g * L && bin < first + (g + 1) * L;
                 if(mine && e >= 0 && e < len)
                     out.coef[((size_t)(k / 4) * threads + s) * 4 + (size_t)(k % 4)] = t.bar_coef[(size_t)o + e];
             }
         }
+        for(int k = s0; k < s0 + segs; k += 8)
+            out.seg_group[(size_t)k] = std::min(8, s0 + segs - k);
     }
-    out.bar_seg.push_back(s);
-    out.num_segs = s;
-    out.seg_group.assign((size_t)threads, 0);
-    for(int b = 0; b < t.num_bars; ++b)
-        for(int k = out.bar_seg[(size_t)b]; k < out.bar_seg[(size_t)b + 1]; k += 8)
-            out.seg_group[(size_t)k] = std::min(8, out.bar_seg[(size_t)b + 1] - k);
+    out.bar_seg.push_back(start[(size_t)t.num_bars]); // (wave-local: bar_seg[b + 1] may lie beyond bar b's last segment: padding)
+    out.num_segs = start[(size_t)t.num_bars];
     return true;
 }
 

@@ -67,9 +67,14 @@ struct BarLaneTables {
     std::vector<int> base;    // [threads] first bin of the segment's 4 * blocks consecutive bins, a multiple of 4
     std::vector<int> bar_seg; // [num_bars + 1]
     std::vector<int> seg_group; // [threads] > 0 where a group of that many (<= 8) consecutive segments of one bar starts
+    // wave-local layout (all segments of a bar inside one wavefront, so that the partial sums are added without a workgroup
+    // barrier): lead_bar[s] = the bar whose first segment s is (else -1), lead_end[s] = one past that bar's last segment
+    std::vector<int> lead_bar, lead_end;
+    bool wave_local = false;
     int num_segs = 0, blocks = 0;
 };
-bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out);
+// wave_local: try the layout above first (needs every bar to fit 64 segments and the padded total to fit the threads)
+bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out, bool wave_local = false);
 
 // Curve mode (one output per thread and step): output o = k * threads + s reads the 8 consecutive dB bins starting at
 // base[o] with coefficients coef[o][0..8) (its composite kernel shifted/zero-padded to 8 taps inside [0, M)); tables are

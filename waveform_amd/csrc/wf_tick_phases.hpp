@@ -64,6 +64,11 @@ struct BarArgs {
     const int *lane_base;      // [T] first of the segment's 4 * lane_blocks consecutive bins (a multiple of 4: 16-byte LDS reads)
     const int *bar_seg;        // [num_bars + 1]
     const int *seg_group;      // [T] > 0: this segment starts a group of that many (<= 8) consecutive segments of one bar
+    // wave-local layout (T > 64, no filter): every bar's segments lie inside one wavefront, so the partials are added with
+    // wave-level ordering only -- no workgroup barrier between the dot products and the stores
+    const int *lead_bar;       // [T] the bar whose first segment this thread owns, or -1
+    const int *lead_end;       // [T] one past that bar's last segment
+    int wave_local;
     int num_segs;
     int lane_blocks;
     // Curve display (render_curve, reference src/source.cpp:1360-1425): num_bars = m_width points per row, point
@@ -230,6 +235,13 @@ WF_DEV void st_state(float *p, f4 v)
     else
         st4(p, v);
 }
+
+// ordering point between LDS operations of one wavefront (they execute in program order: a scheduling fence suffices)
+#if defined(__HIPCC__)
+WF_DEV void wave_fence() { __builtin_amdgcn_wave_barrier(); }
+#else
+WF_DEV void wave_fence() {}
+#endif
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
 // WF_LDS_TRACE is defined only by the g++ wavefront emulator in tests/emu to record
@@ -1206,12 +1218,19 @@ WF_DEV float lerp_std(float a, float b, float t)
 // What a thread needs to know about "its" bar in the first pass of the first chunk (bar = t / lanes_per_bar).  Fetched at
 // the very start of the kernel with the audio window, so that the bars phase at the end does not begin with a chain of
 // dependent table loads.
-struct BarPre { int off, len, count; int s0, s1; int glen; };
+struct BarPre { int off, len, count; int s0, s1; int glen; int lead; };
 template<class G> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 {
-    BarPre p{0, 0, 1, 0, 0, 0};
+    BarPre p{0, 0, 1, 0, 0, 0, -1};
     if(b.out != nullptr) {
-        if(b.num_segs > 0) { // bar t's segment range
+        if(b.num_segs > 0 && b.wave_local) { // the bar this thread leads, if any
+            p.glen = b.seg_group[t];
+            p.lead = b.lead_bar[t];
+            p.s0 = t;
+            p.s1 = b.lead_end[t];
+            if(p.lead >= 0)
+                p.count = b.count[p.lead];
+        } else if(b.num_segs > 0) { // bar t's segment range
             p.glen = b.seg_group[t];
             if(t < b.num_bars) {
                 p.s0 = b.bar_seg[t];
@@ -1233,7 +1252,7 @@ template<class G> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 // The (coefficient, bin) pairs of this thread's segment: 16-byte loads, coalesced across the threads, requested before
 // the dB math so that their L2 latency is off the critical path.
 template<class G> struct BarEntries {
-    static constexpr int CMAX = G::P / 4 + 1; // the host builds segments of at most 4 * CMAX entries
+    static constexpr int CMAX = G::P / 4 + 2; // the host builds segments of at most 4 * CMAX entries
     f4 coef[CMAX];
     int base;
 };
@@ -1548,6 +1567,38 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
                 }
             }
             prod[t] = (a0 + a1) + (a2 + a3);
+        }
+        if(b.wave_local) {
+            // every bar lives inside one wavefront: LDS operations of a wave execute in order, a scheduling fence is all the
+            // three steps need between them
+            wave_fence();
+            float *gs = prod + T + 8;
+            if(has_row && pre.glen > 0) {
+                float q[8];
+                WF_UNROLL
+                for(int j = 0; j < 8; ++j)
+                    q[j] = prod[t + j];
+                float a0 = q[0], a1 = 0.0f;
+                WF_UNROLL
+                for(int j = 1; j < 8; ++j) {
+                    const float v = (j < pre.glen) ? q[j] : 0.0f;
+                    if(j & 1) a1 += v; else a0 += v;
+                }
+                gs[t] = a0 + a1;
+            }
+            wave_fence();
+            if(has_row && pre.lead >= 0) {
+                float a0 = 0.0f, a1 = 0.0f;
+                int k = pre.s0;
+                for(; k + 8 < pre.s1; k += 16) {
+                    a0 += gs[k];
+                    a1 += gs[k + 8];
+                }
+                if(k < pre.s1)
+                    a0 += gs[k];
+                emit(pre.lead, a0 + a1, pre.count);
+            }
+            return false;
         }
         sync();
         WF_BAR_STAMP(14);
