@@ -40,6 +40,7 @@ struct wf_hip {
     // tick makes the lanes wait for `stream`: outside wf_hip_tick the handle behaves as if it had the one stream.
     static constexpr int MAX_LANES = 4;
     int n_lanes = 1;
+    uint32_t wg_lds = 0, wg_threads = 0; // dynamic LDS and threads of one workgroup of the tick kernel (how many fit a CU)
     hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_lane[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_fork = nullptr;
     bool lanes_pending = false; // a lane holds work `stream` has not waited for
@@ -238,6 +239,8 @@ template<class G> int setup_launch_split(wf_hip *h)
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 1, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     h->launch = &launch_tick_split<G>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)G::T;
     h->split = true;
     h->flag_bufs = 3;
     char name[96];
@@ -266,6 +269,8 @@ template<class G, int DEC> int setup_launch_dec(wf_hip *h)
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 2, false, false, DEC>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     h->launch = &launch_tick_dec<G, DEC>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)G::T * 2u;
     char name[96];
     snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d zero-padded to %d,T=%d,R=%dx%dx%d,SPW=2>", G::N >> DEC, G::N, G::T, G::R1, G::R2, G::R3);
     h->kernel_name = name;
@@ -293,6 +298,8 @@ template<class G, int SPW, bool SPLIT> int setup_launch_blu(wf_hip *h)
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     h->launch = &launch_tick_blu<G, SPW, SPLIT>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)(G::T * SPW);
     h->split = SPLIT;
     char name[128];
     snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%u by Bluestein over %d complex points,T=%d,R=%dx%dx%d,SPW=%d%s>", h->N, G::M, G::T,
@@ -320,6 +327,8 @@ template<class G, int SPW, bool TLDS, bool BOTH = false> int setup_launch_impl(w
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS, false, BOTH>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     h->launch = &launch_tick<G, SPW, TLDS, BOTH>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)(G::T * SPW);
     char name[112];
     snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=%d%s%s>", G::N, G::T, G::R1, G::R2, G::R3, SPW,
              TLDS ? ",tables via LDS" : "", BOTH ? ",curve row shared by both spectra" : "");
@@ -1160,8 +1169,13 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     {
         // lanes (see struct wf_hip): two slices once each still fills the chip a couple of times over.  Measured on MI355X
         // (cfg3, 8192 spectra per tick, back-to-back ticks): 1 lane 66 us per tick, 2 lanes 58 us.  WF_HIP_LANES overrides.
+        // Two lanes pay once the batch fills the chip at least twice over (a lane's drain and ramp-up then fall under the other's
+        // steady state); a batch of one round or less only pays the fork / join events: N = 4096 x 1024 streams -- exactly one
+        // round of 4 workgroups per CU -- 0.625 on one lane, 0.545 on two; 3 and 4 lanes: -1..-4 % everywhere.
         const uint32_t wgs = (uint32_t)(n_spec / (h->split ? 1u : 2u));
-        int lanes = wgs >= 1024u ? 2 : 1; // (1024: the 32768-sample geometry's 512 stereo streams, a CU per workgroup: +7 %; 3 and 4 lanes: -1..-4 % everywhere)
+        const uint32_t per_cu = std::max(1u, std::min(h->wg_lds ? (160u * 1024u) / h->wg_lds : 16u, h->wg_threads ? 1024u / h->wg_threads : 16u));
+        const uint32_t round = per_cu * (uint32_t)std::max(prop.multiProcessorCount, 1);
+        int lanes = wgs >= 2u * round ? 2 : 1;
         if(const char *e = std::getenv("WF_HIP_LANES"))
             lanes = std::atoi(e);
         lanes = std::max(1, std::min({lanes, (int)wf_hip::MAX_LANES, (int)h->n_streams}));
