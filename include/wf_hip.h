@@ -291,6 +291,13 @@ uint32_t wf_hip_launches_per_tick(const wf_hip *h);
 /* algorithmic HBM bytes one tick moves: per spectrum 4N in + state r/w + dB out */
 uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags);
 
+
+/* ---- test aid ------------------------------------------------------------------------------- */
+/* Moves the 32-bit sample counters of streams [first, first+count) on by `frames` (a multiple of the ring capacity), as
+ * if that much audio had been captured before what the rings hold: tests reach the 2^32-sample wrap-around (a day at
+ * 48 kHz; the reference's deques have no such counter) without feeding a day of audio. */
+int wf_hip_debug_age(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames);
+
 #ifdef __cplusplus
 }
 #endif

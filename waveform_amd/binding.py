@@ -139,6 +139,7 @@ def lib():
     L.wf_hip_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, fp]
     L.wf_hip_kernel_name.restype = C.c_char_p
     L.wf_hip_kernel_name.argtypes = [vp]
+    L.wf_hip_debug_age.argtypes = [vp, u32, u32, u32]
     L.wf_hip_launches_per_tick.restype = u32
     L.wf_hip_launches_per_tick.argtypes = [vp]
     L.wf_hip_algorithmic_bytes_per_tick.restype = u64

@@ -2304,6 +2304,26 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
     return WF_HIP_OK;
 }
 
+// Test aid: the streams' sample counters (write position, RMS / meter / waveform consumption points) move on by `frames`, as
+// if that much more audio had been captured before what the rings hold now -- `frames` must be a multiple of every ring
+// capacity, so that positions keep addressing the same ring cells.  Lets a test reach the 2^32-sample wrap-around (a day
+// of audio at 48 kHz) without pushing a day of audio.
+extern "C" int wf_hip_debug_age(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(frames % h->ring_cap || (h->d_rms_ring && frames % h->rms_cap))
+        return fail(h, WF_HIP_ERR_INVALID, "frames must be a multiple of the ring capacity %u%s", h->ring_cap, h->d_rms_ring ? " and of the RMS ring's" : "");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_TRY_RC(join_lanes(h));
+    hipLaunchKernelGGL(wf::age_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_wpos, h->d_rend, h->d_mend, h->d_cend, first, count,
+                       frames);
+    WF_HIP_TRY(h, hipGetLastError());
+    h->main_dirty = true;
+    return WF_HIP_OK;
+}
+
 #ifdef WF_PHASE_TIMING
 // development aid: copies the per-workgroup s_memtime stamps of the last tick (16 per workgroup)
 extern "C" int wf_hip_debug_phase_clock(wf_hip *h, unsigned long long *out, size_t n)

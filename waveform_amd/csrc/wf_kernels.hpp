@@ -638,6 +638,18 @@ __global__ void set_hidden_kernel(uint32_t *flags, uint32_t first, uint32_t coun
     }
 }
 
+// test aid (wf_hip_debug_age): every sample counter of the streams moves on by `frames`
+__global__ void age_kernel(uint32_t *a, uint32_t *b, uint32_t *c, uint32_t *d, uint32_t first, uint32_t count, uint32_t frames)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < count) {
+        if(a) a[first + i] += frames;
+        if(b) b[first + i] += frames;
+        if(c) c[first + i] += frames;
+        if(d) d[first + i] += frames;
+    }
+}
+
 __global__ void fill_f32_kernel(float *p, size_t n, float v)
 {
     for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
