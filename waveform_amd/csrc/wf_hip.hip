@@ -491,6 +491,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     a.skip_decibels = ((p->flags & WF_HIP_TICK_NO_DECIBELS) && !mono_mix_rows) ? 1u : 0u;
     a.split_ch = 0xffffffffu;
     a.bars_only = h->d_bars_only;
+    a.stale_row = h->d_stale_row;
     a.bar = wf::BarArgs{};
     if(h->d_bars) {
         a.bar.coef = h->d_bar_coef;

@@ -384,7 +384,7 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
     std::vector<int> start;
     int L = 0;
     bool local = false;
-    if(wave_local && threads > 64)
+    if(wave_local)
         for(int l = 4; l <= 4 * max_blocks && l <= M; l += 4)
             if(place(l, true, start)) {
                 L = l;
@@ -413,7 +413,8 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
         const int segs = segs_of(b, L), s0 = start[(size_t)b];
         out.bar_seg.push_back(s0);
         out.lead_bar[(size_t)s0] = b;
-        out.lead_end[(size_t)s0] = s0 + segs;
+        for(int g = 0; g < segs; ++g)
+            out.lead_end[(size_t)(s0 + g)] = s0 + segs;
         for(int g = 0; g < segs; ++g) {
             const int s = s0 + g;
             // bins [bstart, bstart + L) of the row; a segment that would reach past the row moves down (its coefficients with it)

@@ -67,8 +67,9 @@ struct BarLaneTables {
     std::vector<int> base;    // [threads] first bin of the segment's 4 * blocks consecutive bins, a multiple of 4
     std::vector<int> bar_seg; // [num_bars + 1]
     std::vector<int> seg_group; // [threads] > 0 where a group of that many (<= 8) consecutive segments of one bar starts
-    // wave-local layout (all segments of a bar inside one wavefront, so that the partial sums are added without a workgroup
-    // barrier): lead_bar[s] = the bar whose first segment s is (else -1), lead_end[s] = one past that bar's last segment
+    // wave-local layout (all segments of a bar inside one wavefront, so that the partial sums are added by lane shuffles: no
+    // LDS, no barrier): lead_bar[s] = the bar whose first segment s is (else -1), lead_end[s] = one past the last segment of
+    // the bar segment s belongs to (0: unused thread)
     std::vector<int> lead_bar, lead_end;
     bool wave_local = false;
     int num_segs = 0, blocks = 0;

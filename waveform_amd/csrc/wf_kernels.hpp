@@ -168,6 +168,11 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool mono_mix = (a.mode & WF_MODE_MONO_MIX) != 0;
     const uint32_t wpos = a.wpos[stream];
     const uint32_t sflags = a.stream_flags[stream];
+    // the stream's volume-normalisation gain: read here with the other per-stream words, as a scalar load (possible while
+    // the kernel has not stored anything yet).  Read where it is used -- behind the smoothing-state stores -- it was a vector
+    // load under a branch whose destination register the common path had to "wait for" before reusing it: vmcnt(0), i.e.
+    // the round trip of those stores, in front of the row stores of every workgroup.
+    const float vol_comp = a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp;
     // split mode: the previous tick's verdicts on both rows of the stream, requested with the other per-stream words
     uint32_t vin0 = 0, vin1 = 0;
     if constexpr(SPLIT) {
@@ -178,6 +183,9 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * G::LDS_CF;
     cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF;
     int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
+    // bars / curve display, several wavefronts per spectrum: how many of them are done with the last reads of the exchange
+    // buffer (see "arrivals" below).  In the spare words behind the facts.
+    int *arrivals = facts + 2 * SPW * WPS + sub;
     const float *x = a.ring + (size_t)spec * a.ring_stride;
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
     const uint32_t start = (wpos - delay - (BLU ? a.blu_n : (uint32_t)(G::N >> DEC))) & a.ring_mask;
@@ -223,6 +231,8 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     bool nz0 = wave_nz, nz1 = false, below0 = wave_below, below1 = true;
     if(lane == 0)
         facts[wave_in_block] = (wave_nz ? 1 : 0) | (wave_below ? 2 : 0);
+    if(T > 64 && t == 0)
+        *arrivals = 0;
     __syncthreads(); // facts + the LDS twiddle table are visible to the whole workgroup
     if constexpr(SPLIT) {
         int orf = 0;
@@ -372,7 +382,12 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         // store into a pointer phi over scratch and global memory, which its backend cannot select)
         // (underflow in mono mixdown: both channels take row 0, which no tick has filled yet -- DB_MIN, as m_decibels[1] is
         // in the reference at that point; the mean of two negative rows is negative: DB_MIN again)
-        load_row<RG, BLU>(((WF_TRACK && a.bars_only != nullptr) && !mono_mix) ? a.bars_only->stale_row : rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
+        load_row<RG, BLU>(((WF_TRACK && a.bars_only != nullptr) && !mono_mix) ? a.stale_row : rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
+        // Waited for here, inside the rare branch.  Left to the compiler the wait lands where the branches meet, in front of
+        // the dB math of every workgroup -- and as the loads are the youngest operations of this path, it is a wait for
+        // everything (vector-memory operations complete in order): the common path then sat out the acknowledgement of its
+        // smoothing-state stores, a full round trip to HBM, before it took its first logarithm.
+        wait_vmem_all();
     }
 
     // ---- hidden / capture timeout: reset branch (reference :34-48), complete in itself --------------------------
@@ -431,6 +446,18 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         }
     }
     WF_STAMP(9);
+    // The row of a bars / curve display is parked in the exchange buffer once every wavefront of the spectrum has read its
+    // last points from it.  That was a workgroup barrier in front of the row's LDS stores, a few hundred cycles before the
+    // one behind them; instead every wavefront counts itself in here, right behind its reads (LDS operations of a wave
+    // execute in order), and checks the count before it parks its part of the row: by then the dB math has passed and the
+    // others have long arrived.  (Mono mixdown inside one workgroup has barriers of its own between
+    // the last reads and here.)
+    const bool count_arrivals = T > 64 && a.bar.out != nullptr && (SPLIT || !mono_mix) && !BOTH;
+    if(count_arrivals) {
+        asm volatile("" ::: "memory");
+        if(lane == 0)
+            __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
     BarEntries<G> bar_entries;
     bars_fetch_entries<G>(a.bar, t, bar_entries);
@@ -441,7 +468,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     float d[RP];
     bool row_exceeds = false; // bars-only handles: this thread's part of the row has a value > floor - 10
     if(have_row && row_thread) {
-        p4_db<RG, BLU>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp, NB);
+        p4_db<RG, BLU>(a, t, mag, d, vol_comp, NB);
         if(!SPLIT && (WF_TRACK && a.bars_only != nullptr)) {
             // taken here, where d[] is produced: reading the array again under a later branch makes ROCm 7.2's clang merge
             // that read with a global load through a pointer phi, i.e. a flat pointer into scratch, and its backend aborts
@@ -506,7 +533,13 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             else
                 spectrum_sync<G>();
         };
-        row_sync(); // every thread of the spectrum is done reading its exchange buffer
+        // every thread of the spectrum is done reading its exchange buffer
+        if(count_arrivals) {
+            while(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        } else if(!(mono_mix && !SPLIT))
+            row_sync();
         if(have_row && row_thread)
             store_row<RG, BLU>(dbl, t, d, NB);
         if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)

@@ -173,6 +173,8 @@ struct TickArgs {
     // silence state machine must inspect (reference :78-86): see BarsOnlyState.  nullptr: rows are always stored (the usual
     // case; one pointer here instead of its fields keeps the kernel's scalar registers free).
     const BarsOnlyState *bars_only;
+    const float *stale_row;   // BarsOnlyState::stale_row again, as a kernel argument: a pointer read from memory is a generic one,
+                              // and a FLAT load anywhere on a path makes every later wait a wait for everything (see wf_kernels.hpp)
     // FFT sizes that are not powers of two (Bluestein, spectrum_tick_kernel<.., BLU>): the geometry's M is the padded
     // convolution length L, the transform the host asked for has blu_n points and row_bins = blu_n / 2 output bins
     const cf *blu_q;           // [blu_n / 2] conj(w_k) / L: Z_k = blu_q[k] * conj(R_k) for the twice-transformed R
@@ -238,9 +240,13 @@ WF_DEV void st_state(float *p, f4 v)
 
 // ordering point between LDS operations of one wavefront (they execute in program order: a scheduling fence suffices)
 #if defined(__HIPCC__)
+WF_DEV void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); } // vmcnt(0), the other counters untouched (gfx9 encoding)
 WF_DEV void wave_fence() { __builtin_amdgcn_wave_barrier(); }
+WF_DEV float wave_shfl_down(float v, int d) { return __shfl_down(v, d, 64); } // lane l gets lane l + d's value (its own past the wavefront)
 #else
+WF_DEV void wait_vmem_all() {}
 WF_DEV void wave_fence() {}
+WF_DEV float wave_shfl_down(float v, int) { return v; } // (the emulator does not run the bar reduction)
 #endif
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
@@ -1224,10 +1230,9 @@ template<class G> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
     BarPre p{0, 0, 1, 0, 0, 0, -1};
     if(b.out != nullptr) {
         if(b.num_segs > 0 && b.wave_local) { // the bar this thread leads, if any
-            p.glen = b.seg_group[t];
             p.lead = b.lead_bar[t];
             p.s0 = t;
-            p.s1 = b.lead_end[t];
+            p.s1 = b.lead_end[t]; // one past the last segment of this thread's bar
             if(p.lead >= 0)
                 p.count = b.count[p.lead];
         } else if(b.num_segs > 0) { // bar t's segment range
@@ -1551,7 +1556,8 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
     auto emit = [&](int bar, float sum, int cnt) { emit_output(b, bar, sum / (float)cnt, out_row, dup_row); };
     if(b.num_segs > 0) {
         // A: every thread forms the dot product of its own segment (padded bins have coefficient 0) -- four
-        // independent partial sums in entry order -- and parks it behind the dB row
+        // independent partial sums in entry order
+        float part = 0.0f;
         if(has_row) {
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
             const float *p = db + be.base;
@@ -1566,40 +1572,25 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
                     a3 = fmaf(v.w, w.w, a3);
                 }
             }
-            prod[t] = (a0 + a1) + (a2 + a3);
+            part = (a0 + a1) + (a2 + a3);
         }
         if(b.wave_local) {
-            // every bar lives inside one wavefront: LDS operations of a wave execute in order, a scheduling fence is all the
-            // three steps need between them
-            wave_fence();
-            float *gs = prod + T + 8;
-            if(has_row && pre.glen > 0) {
-                float q[8];
-                WF_UNROLL
-                for(int j = 0; j < 8; ++j)
-                    q[j] = prod[t + j];
-                float a0 = q[0], a1 = 0.0f;
-                WF_UNROLL
-                for(int j = 1; j < 8; ++j) {
-                    const float v = (j < pre.glen) ? q[j] : 0.0f;
-                    if(j & 1) a1 += v; else a0 += v;
-                }
-                gs[t] = a0 + a1;
+            // every bar lives inside one wavefront: its partials are added by a segmented reduction over the lanes (six
+            // shuffles; lane s ends up with the sum of segments [s, end of its bar)) -- no LDS round trip, no barrier
+            WF_BAR_STAMP(14);
+            WF_UNROLL
+            for(int d = 1; d < 64; d *= 2) {
+                const float o = wave_shfl_down(part, d);
+                if(t + d < pre.s1)
+                    part += o;
             }
-            wave_fence();
-            if(has_row && pre.lead >= 0) {
-                float a0 = 0.0f, a1 = 0.0f;
-                int k = pre.s0;
-                for(; k + 8 < pre.s1; k += 16) {
-                    a0 += gs[k];
-                    a1 += gs[k + 8];
-                }
-                if(k < pre.s1)
-                    a0 += gs[k];
-                emit(pre.lead, a0 + a1, pre.count);
-            }
+            WF_BAR_STAMP(15);
+            if(has_row && pre.lead >= 0)
+                emit(pre.lead, part, pre.count);
             return false;
         }
+        if(has_row)
+            prod[t] = part; // parked behind the dB row
         sync();
         WF_BAR_STAMP(14);
         WF_BAR_STAMP(15);
