@@ -70,6 +70,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_DEFER_ROWS
 #define WF_DEFER_ROWS 0 // (curve display: row stores after the points, so that the points' table loads do not queue behind them: measured +-0)
 #endif
+#ifndef WF_DEFER_ROWS_BARS
+#define WF_DEFER_ROWS_BARS 0 // (bars: the same, so that the wait for the bar coefficients is not a wait for the row stores' acknowledgement: +-0 again, -10 % at N = 2048)
+#endif
 #ifndef WF_NT_ROWS
 #define WF_NT_ROWS true // m_decibels rows stored with the non-temporal hint
 #endif
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
-    const bool defer_rows = WF_DEFER_ROWS && a.bar.out != nullptr && a.bar.curve != 0;
+    const bool defer_rows = a.bar.out != nullptr && (a.bar.curve != 0 ? WF_DEFER_ROWS != 0 : WF_DEFER_ROWS_BARS != 0);
     float d[RP];
     bool row_exceeds = false; // bars-only handles: this thread's part of the row has a value > floor - 10
     if(have_row && row_thread) {
