@@ -27,6 +27,8 @@ if __name__ == "__main__":
         extra = dict(curve=1, interp_mode=int(os.environ["WF_BENCH_CURVE"]))
     if os.environ.get("WF_BENCH_GAUSS"):
         extra.update(filter_mode=1, filter_radius=float(os.environ["WF_BENCH_GAUSS"]))
+    if os.environ.get("WF_BENCH_ROLLOFF"):  # roll-off on (q = 1, rate as given in dB per octave)
+        extra.update(rolloff_q=1.0, rolloff_rate=float(os.environ["WF_BENCH_ROLLOFF"]))
     jobs = [a.split(":") for a in sys.argv[1:]] or [("1024", "16384"), ("2048", "8192"), ("4096", "4096"), ("8192", "2048"), ("16384", "1024")]
     for n, s in jobs:
         run(int(n), int(s), **extra)

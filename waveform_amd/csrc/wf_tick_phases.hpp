@@ -1083,6 +1083,16 @@ template<class G, bool GUARD = false>
 WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)[G::P], float vol_comp, int nb = 0, int kbase = 0)
 {
     constexpr int T = G::T, P = G::P;
+    // roll-off row: all of this thread's vectors requested before the first logarithm -- one round trip to L2 under the dB
+    // math instead of one per group of four bins, each waited for on the spot
+    f4 roll[P / 4];
+    if(a.mode & WF_MODE_ROLLOFF) {
+        WF_UNROLL
+        for(int u = 0; u < P / 4; ++u) {
+            const int k0 = 4 * (t + T * u);
+            roll[u] = (GUARD && k0 >= nb) ? f4{0.0f, 0.0f, 0.0f, 0.0f} : ld4(a.rolloff + k0 + kbase);
+        }
+    }
     WF_UNROLL
     for(int u = 0; u < P / 4; ++u) {
         int k0 = 4 * (t + T * u);
@@ -1098,12 +1108,17 @@ WF_DEV void p4_db(const TickArgs &a, int t, const float (&mag)[G::P], float (&d)
                 if(k0 + i >= 1) // the generic path starts at i = 1 (reference :165)
                     d[4 * u + i] += vol_comp;
         }
-        if(a.mode & WF_MODE_ROLLOFF) {
-            const f4 r = ld4(a.rolloff + k0);
-            const float rr[4] = {r.x, r.y, r.z, r.w};
+    }
+    if(a.mode & WF_MODE_ROLLOFF) {
+        WF_UNROLL
+        for(int u = 0; u < P / 4; ++u) {
+            const int k0 = 4 * (t + T * u);
+            if(GUARD && k0 >= nb)
+                continue;
+            const float rr[4] = {roll[u].x, roll[u].y, roll[u].z, roll[u].w};
             WF_UNROLL
             for(int i = 0; i < 4; ++i)
-                if(k0 + i >= 1) // reference :173
+                if(k0 + kbase + i >= 1) // reference :173
                     d[4 * u + i] = fmaxf(d[4 * u + i] - rr[i], a.db_min);
         }
     }
