@@ -85,10 +85,15 @@ typedef struct wf_config {
      * rounded_caps; curve: a triangle strip of 2 * width vertices, RenderMode SOLID / GRADIENT / ...); 2: the curve as a
      * line strip of width vertices (RenderMode::LINE); 3: stepped bars (display_mode STEPPED_BAR, :1583-1607): per bar as
      * many step quads of step_width pixels, step_width + step_gap apart, as fit under its height -- the number of
-     * vertices then changes from tick to tick (wf_hip_read_vertex_counts).  The radial layout stays with the host. */
+     * vertices then changes from tick to tick (wf_hip_read_vertex_counts). */
     uint32_t vertices;
     int32_t step_width;         /* m_step_width (vertices == 3) */
     int32_t step_gap;           /* m_step_gap */
+    /* radial layout (m_radial, src/source.cpp:508, :658-666).  The polar transform itself is the plugin's vertex shader
+     * (:1745-1762); what changes on the CPU side -- and here -- are the cap fans of rounded bars, which become full circles
+     * "to avoid distortion issues" (:1296, :1632-1633, :1646-1647).  `height` is m_height as get_settings leaves it (halved,
+     * minus the dead zone). */
+    uint32_t radial;
 } wf_config;
 
 /* get_defaults (src/source.cpp:119-174) + what update() derives for 48 kHz stereo OBS audio,

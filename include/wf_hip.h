@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 5
+#define WF_HIP_ABI_VERSION 6
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,

@@ -901,7 +901,7 @@ size_t wfo_fill_vertices(const wfo_source *s, int channel, int line, float *out,
         if(c->rounded_caps) {
             const float ccx = (float)(i * bar_stride) + cap_radius;
             const int half = cap_tris / 2;
-            int start = channel ? 0 : half, stop = start + half; /* m_radial is off */
+            int start = c->radial ? 0 : (channel ? 0 : half), stop = c->radial ? cap_tris : start + half; /* :1632-1633 */
             for(int j = start; j < stop; ++j) {
                 vset(out, cap, vertpos, cap_xy[2 * j] + ccx, cap_xy[2 * j + 1] + val);
                 vset(out, cap, vertpos + 1, cap_xy[2 * (j + 1)] + ccx, cap_xy[2 * (j + 1) + 1] + val);
@@ -910,8 +910,8 @@ size_t wfo_fill_vertices(const wfo_source *s, int channel, int line, float *out,
             }
             if(!c->stereo || (c->channel_spacing > 0)) {
                 const float ccy = cpos - offset;
-                start = channel ? half : 0;
-                stop = start + half;
+                start = c->radial ? 0 : (channel ? half : 0); /* :1646-1647 */
+                stop = c->radial ? cap_tris : start + half;
                 for(int j = start; j < stop; ++j) {
                     vset(out, cap, vertpos, cap_xy[2 * j] + ccx, cap_xy[2 * j + 1] + ccy);
                     vset(out, cap, vertpos + 1, cap_xy[2 * (j + 1)] + ccx, cap_xy[2 * (j + 1) + 1] + ccy);

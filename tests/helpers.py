@@ -33,6 +33,10 @@ def ref_settings(cfg, **extra) -> dict:
         filter_mode="gauss" if cfg.filter_mode == 1 else "none", filter_radius=repr(float(np.float32(cfg.filter_radius))),
         render_mode="line" if getattr(cfg, "vertices", 0) == 2 else "solid",
     )
+    if getattr(cfg, "radial", 0):
+        # get_settings halves the height for the radial layout and takes the dead zone off it (src/source.cpp:658-666);
+        # wf_config.height is m_height after that
+        s.update(radial_layout=True, deadzone=0.0, height=2 * cfg.height)
     s.update(extra)
     return s
 

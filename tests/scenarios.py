@@ -93,6 +93,11 @@ SCENARIOS = {
                                        steps=_steps(3), record=1),
     "verts_bars_1024_mono_caps_mirror": dict(cfg=dict(fft_size=1024, stereo=0, capture_channels=1, bars=1, interp_mode=0, rounded_caps=1, bar_width=12,
                                                       bar_gap=2, mirror_freq_axis=1, vertices=1), steps=_steps(3), record=1),
+    # radial layout: the cap fans are full circles (the polar transform itself is the plugin's shader)
+    "verts_bars_2048_stereo_caps_radial": dict(cfg=dict(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=1, rounded_caps=1, channel_spacing=6,
+                                                        height=180, radial=1, vertices=1), steps=_steps(3), record=1),
+    "verts_bars_1024_mono_caps_radial": dict(cfg=dict(fft_size=1024, stereo=0, bars=1, interp_mode=2, rounded_caps=1, bar_width=14, bar_gap=4,
+                                                      height=150, radial=1, vertices=1), steps=_steps(3), record=1),
     "verts_curve_2048_stereo_solid": dict(cfg=dict(fft_size=2048, stereo=1, curve=1, interp_mode=2, channel_spacing=8, width=640, vertices=1),
                                           steps=_steps(3), record=1),
     "verts_curve_1024_line": dict(cfg=dict(fft_size=1024, stereo=0, curve=1, interp_mode=1, width=500, filter_mode=1, filter_radius=1.5, vertices=2),

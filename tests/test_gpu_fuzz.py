@@ -101,6 +101,8 @@ def draw(seed: int, family: str = "pow2"):
         cfg.update(vertices=int(r.choice([1, 3])) if display == 1 else int(r.integers(1, 3)))
         if cfg["vertices"] == 3:
             cfg.update(step_width=int(r.choice([8, 3, 12])), step_gap=int(r.choice([4, 1, 0])), rounded_caps=0)
+        elif display == 1 and cfg.get("rounded_caps") and r.random() < 0.5:
+            cfg.update(radial=1)  # full-circle cap fans
     return cfg, steps, sync_ms
 
 

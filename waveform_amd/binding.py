@@ -35,6 +35,7 @@ class Config(C.Structure):
         ("curve", C.c_uint32), ("filter_mode", C.c_int32), ("filter_radius", C.c_float),
         ("meter", C.c_uint32), ("meter_rms", C.c_uint32), ("meter_ms", C.c_int32),
         ("waveform", C.c_uint32), ("vertices", C.c_uint32), ("step_width", C.c_int32), ("step_gap", C.c_int32),
+        ("radial", C.c_uint32),
     ]
 
     @classmethod

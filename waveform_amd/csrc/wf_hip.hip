@@ -1681,6 +1681,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
             v.rounded = h->cfg.rounded_caps ? 1 : 0;
             v.cap_tris = h->vtab.cap_tris;
             v.bottom_caps = h->vtab.bottom_caps;
+            v.radial = h->vtab.radial;
             v.bot_offset = h->vtab.bot_offset;
             v.step_width = h->cfg.step_width;
             v.step_stride = h->vtab.step_stride;

@@ -517,7 +517,8 @@ void build_vertex_tables(const wf_config &cfg, int num_bars, VertexTables &out)
             out.cap_xy[(size_t)2 * j + 1] = out.cap_radius * std::sin(a);
         }
         out.bottom_caps = (!cfg.stereo || cfg.channel_spacing > 0) ? 1 : 0;                   // :1645
-        out.per_bar += 3 * (out.cap_tris / 2) * (1 + out.bottom_caps);
+        out.radial = cfg.radial ? 1 : 0;                                                      // :1632-1633, :1646-1647
+        out.per_bar += 3 * (out.radial ? out.cap_tris : out.cap_tris / 2) * (1 + out.bottom_caps);
     }
     out.bot_offset = ((cfg.rounded_caps && !cfg.stereo) || cfg.channel_spacing > 0) ? 1 : 0; // :1619
     out.per_row = out.per_bar * num_bars;
@@ -843,4 +844,5 @@ extern "C" void wf_config_defaults(wf_config *cfg)
     cfg->vertices = 0;
     cfg->step_width = 8;           // get_defaults, src/source.cpp:163-164
     cfg->step_gap = 4;
+    cfg->radial = 0;               // P_RADIAL default
 }

@@ -122,6 +122,7 @@ struct VertexTables {
     int bar_stride = 0, cap_tris = 0;
     float cpos = 0, bottom = 0, channel_offset = 0, cap_radius = 0;
     int bottom_caps = 0, bot_offset = 0;
+    int radial = 0;        // cap fans are full circles (m_radial)
     std::vector<float> cap_xy; // [cap_tris + 1][2]
 };
 void build_vertex_tables(const wf_config &cfg, int num_bars, VertexTables &out);

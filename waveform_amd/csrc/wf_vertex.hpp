@@ -24,6 +24,7 @@ struct VertexArgs {
     float cpos, bottom, channel_offset, cap_radius;
     int rounded, cap_tris;
     int bottom_caps;       // !m_stereo || m_channel_spacing > 0 (:1645)
+    int radial;            // m_radial: full-circle fans (:1632-1633, :1646-1647)
     int bot_offset;        // (m_rounded_caps && !m_stereo) || m_channel_spacing > 0 (:1619)
     // stepped bars (mode 3, :1583-1607)
     int step_width, step_stride, max_steps;
@@ -129,16 +130,17 @@ __global__ __launch_bounds__(256) void vertex_fill_kernel(const VertexArgs a)
         if(a.rounded) {
             int vp = 6;
             const float ccx = (float)(i * a.bar_stride) + a.cap_radius; // cap centre
-            int start = channel ? 0 : half; // (non-radial: the half of the circle that faces away from the base line)
-            for(int j = start; j < start + half; ++j, vp += 3) {
+            const int fan = a.radial ? a.cap_tris : half; // radial: full circles; else the half that faces away from the base line
+            int start = a.radial ? 0 : (channel ? 0 : half);
+            for(int j = start; j < start + fan; ++j, vp += 3) {
                 v[vp] = f4{a.cap_xy[2 * j] + ccx, a.cap_xy[2 * j + 1] + val, 0.0f, 0.0f};
                 v[vp + 1] = f4{a.cap_xy[2 * (j + 1)] + ccx, a.cap_xy[2 * (j + 1) + 1] + val, 0.0f, 0.0f};
                 v[vp + 2] = f4{ccx, val, 0.0f, 0.0f};
             }
             if(a.bottom_caps) {
                 const float ccy = a.cpos - offset;
-                start = channel ? half : 0;
-                for(int j = start; j < start + half; ++j, vp += 3) {
+                start = a.radial ? 0 : (channel ? half : 0);
+                for(int j = start; j < start + fan; ++j, vp += 3) {
                     v[vp] = f4{a.cap_xy[2 * j] + ccx, a.cap_xy[2 * j + 1] + ccy, 0.0f, 0.0f};
                     v[vp + 1] = f4{a.cap_xy[2 * (j + 1)] + ccx, a.cap_xy[2 * (j + 1) + 1] + ccy, 0.0f, 0.0f};
                     v[vp + 2] = f4{ccx, ccy, 0.0f, 0.0f};
