@@ -73,6 +73,10 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_DEFER_ROWS_BARS
 #define WF_DEFER_ROWS_BARS 0 // (bars: the same, so that the wait for the bar coefficients is not a wait for the row stores' acknowledgement: +-0 again, -10 % at N = 2048)
 #endif
+#ifndef WF_BAR_COEF_EARLY
+#define WF_BAR_COEF_EARLY 0 // (bar tables requested in front of the smoothing state instead of behind it, so that the dot products need
+                            // no wait of their own: up to 24 more registers across P4 -- 128 VGPRs and 20-36 B of scratch on every geometry from 4096)
+#endif
 #ifndef WF_NT_ROWS
 #define WF_NT_ROWS true // m_decibels rows stored with the non-temporal hint
 #endif
@@ -365,6 +369,14 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         spectrum_sync<G>();
     }
     WF_STAMP(8);
+#if WF_BAR_COEF_EARLY
+    // the bar tables of this thread, requested in front of the smoothing state: they are in when the state is (vector memory
+    // completes in order), so that the dot products at the end do not begin with a wait that also sits out the row stores
+    BarEntries<G> bar_entries;
+    bars_fetch_entries<G>(a.bar, t, bar_entries);
+    if(!process && a.bar.out != nullptr)
+        wait_vmem_all(); // (the rare path that skips P4 and its wait)
+#endif
     if(process) {
         if constexpr(BLU) {
             p4_direct<G>(a, t, lds, ts, mag);
@@ -462,8 +474,10 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
+#if !WF_BAR_COEF_EARLY
     BarEntries<G> bar_entries;
     bars_fetch_entries<G>(a.bar, t, bar_entries);
+#endif
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
