@@ -59,8 +59,9 @@ MAX_DEPTH = 512  # ticks of audio resident per stream (--depth); longer runs wal
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=500, help="untimed steps first: the device needs ~300 ticks (15-20 ms) of load before its "
+                    "clocks have settled -- 20 warm-up ticks measure 0.72-0.73 of peak, 300 and more 0.78-0.79 (profiles/r02j_warmup.txt)")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
     ap.add_argument("--fft", type=int, default=FFT_SIZE)
     ap.add_argument("--depth", type=int, default=MAX_DEPTH,
@@ -142,25 +143,28 @@ def roofline(batch, shape, kernel_ms, flags=0):
     return out
 
 
+WARM_MS, TIMED_MS = 40.0, 30.0  # other shapes: device time of the untimed lead-in (clocks settle in 15-20 ms) and of the timed region
+
+
 def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0, shape=None):
-    """One of the other shapes: `steps` back-to-back ticks over resident audio; wall clock and device events."""
-    depth = min(steps + warmup, 64)
+    """One of the other shapes: back-to-back ticks over resident audio (64 ticks of it, walked again and again); a lead-in
+    of at least `warmup` ticks and WARM_MS of device time, then at least `steps` ticks and TIMED_MS; wall clock and device events."""
+    depth = 64
     with wf.SpectrumBatch(cfg, streams, device=device, ring_frames=cfg.fft_size + HOP * (depth + 1)) as b:
         b.push_synth(SEED, 0, HOP * depth)
         b.sync()
-        if warmup:
-            b.time_ticks(min(warmup, depth), HOP, HOP * (min(warmup, depth) - 1), flags=flags)
+        first = HOP * (depth - 1)
+        probe = b.time_ticks(16, HOP, first, flags=flags)  # ms per tick, cold
+        warm = max(warmup, int(WARM_MS / probe) + 1)
+        steps = max(steps, int(TIMED_MS / probe) + 1)
+        b.time_ticks(warm, HOP, first, flags=flags)
         t0 = time.perf_counter()
-        ms, done = 0.0, 0
-        while done < steps:
-            n = min(depth, steps - done)
-            ms += b.time_ticks(n, HOP, HOP * (n - 1), flags=flags) * n
-            done += n
+        ms = b.time_ticks(steps, HOP, first, flags=flags)
         wall = time.perf_counter() - t0
         spectra = streams * b.capture_channels
-        return {"name": name, "streams": streams, "fft_size": int(cfg.fft_size), "spectra_per_tick": spectra, "steps": steps,
+        return {"name": name, "streams": streams, "fft_size": int(cfg.fft_size), "spectra_per_tick": spectra, "steps": steps, "warmup": warm + 16,
                 "value": spectra * steps / wall, "unit": "spectra/s", "ms_per_step": wall * 1e3 / steps,
-                "roofline": roofline(b, shape, ms / steps, flags)}
+                "roofline": roofline(b, shape, ms, flags)}
 
 
 def shape_list(wf):
@@ -191,7 +195,7 @@ def other_configs(wf, device):
     return out
 
 
-def pcie_inclusive(wf, cfg, streams, device, steps=40, warm=8):
+def pcie_inclusive(wf, cfg, streams, device, steps=100, warm=60):
     """The headline shape with every step's audio crossing the host boundary: one 60 fps hop per stream in page-locked
     memory -> wf_hip_push_audio_async (H2D on the copy stream under the previous tick) -> ring append -> tick."""
     import numpy as np
@@ -304,23 +308,18 @@ def main():
         gather = BarsGather(batch, shard_streams(args.streams * world, rank, world))
 
     def run(n_ticks):
-        """n_ticks steps over the resident audio, oldest window first; returns the average device time per tick in ms"""
-        ms, done = 0.0, 0
-        while done < n_ticks:
-            n = min(depth, n_ticks - done)
-            if gather is None:
-                ms += batch.time_ticks(n, HOP, HOP * (n - 1)) * n
-            else:
-                # tick i, its bars handed to the gather stream (wf_hip_copy_bars_device_async), the all-gather of tick i
-                # under tick i+1; nothing here waits on the host
-                batch.time_begin()
-                for i in range(n):
-                    batch.tick(delay_frames=HOP * (n - 1 - i), flags=flags)
-                    gather.launch()
-                ms += batch.time_end()
-            done += n
-        if gather is not None:
-            gather.wait()
+        """n_ticks steps over the resident audio, oldest window first (a walk that reaches the newest sample starts over, no
+        host synchronisation in between); returns the average device time per tick in ms"""
+        if gather is None:
+            return batch.time_ticks(n_ticks, HOP, HOP * (depth - 1))
+        # tick i, its bars handed to the gather stream (wf_hip_copy_bars_device_async), the all-gather of tick i under
+        # tick i+1; nothing here waits on the host
+        batch.time_begin()
+        for i in range(n_ticks):
+            batch.tick(delay_frames=HOP * (depth - 1 - i % depth), flags=flags)
+            gather.launch()
+        ms = batch.time_end()
+        gather.wait()
         return ms / n_ticks
 
     # warm-up: W untimed steps

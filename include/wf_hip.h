@@ -275,9 +275,10 @@ const float *wf_hip_vertices_device(wf_hip *h); /* [n_streams][display_channels]
 float wf_hip_db_min(void);                            /* DB_MIN, src/source.cpp:43 */
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* Runs `ticks` ticks back to back (each `hop` frames further into audio that must already be in
- * the rings: delay_frames = first_delay - i*hop) and returns the average duration of the fused
- * kernel in milliseconds, measured with hipEvents on the handle's stream. */
+/* Runs `ticks` ticks back to back, each `hop` frames further into audio that must already be in the rings
+ * (delay_frames = first_delay - i*hop; a walk that has reached the newest sample starts over at first_delay: the same work
+ * per tick on the same resident audio, with no host synchronisation in between), and returns the average device time per
+ * tick in milliseconds, measured with hipEvents on the handle's stream around all of the ticks' launches. */
 int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, uint32_t hop, float *avg_kernel_ms);
 /* The same measurement around calls of the host's choosing: wf_hip_time_begin records a hipEvent on the handle's stream,
  * wf_hip_time_end joins everything issued since (ticks on every lane, copies), records the second event, waits for it and

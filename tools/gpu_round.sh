@@ -2,7 +2,7 @@
 # tools/gpu_round.sh -- one gpurun call that gathers a round's evidence: GPU tests, bench line, rocprofv3 passes.
 #   usage (from the repo root on the GPU box): bash tools/gpu_round.sh TAG [tests|notests]
 set -u
-TAG=${1:-r02i}
+TAG=${1:-r02j}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
@@ -14,10 +14,11 @@ fi
 ( time python bench.py ) > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 tail -c 600 $O/bench_$TAG.json | head -c 600; echo
 # headline shape: full counter set; the other shapes: durations + HBM bytes
-bash tools/profile_gpu.sh ${TAG}_cfg3 200 "--warmup 20" > /dev/null 2>&1   # the default bench.py run: same ring depth, same ticks
-WF_PMC_SET=short bash tools/profile_gpu.sh ${TAG}_cfg3_16384streams 20 "--streams 16384" > /dev/null 2>&1
-WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 2 30" bash tools/profile_gpu.sh ${TAG}_cfg4 > /dev/null 2>&1
-WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 4 30" bash tools/profile_gpu.sh ${TAG}_cfg5shape > /dev/null 2>&1
+python tools/warmup_curve.py 40 > $O/warmup_$TAG.txt 2>&1
+bash tools/profile_gpu.sh ${TAG}_cfg3 1000 "--warmup 500" > /dev/null 2>&1   # the default bench.py run: same ring depth, same ticks
+WF_PMC_SET=short bash tools/profile_gpu.sh ${TAG}_cfg3_16384streams 250 "--streams 16384 --warmup 250" > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 2" bash tools/profile_gpu.sh ${TAG}_cfg4 > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 4" bash tools/profile_gpu.sh ${TAG}_cfg5shape > /dev/null 2>&1
 # the kernels further from the roofline: durations only (rocprofv3 --kernel-trace --stats), one summary each
 for J in "plugindefaults:python $R/tools/quick_case.py plugin_defaults" "n32768:python $R/tools/quick_bench.py 32768:512" \
          "blu800:python $R/tools/quick_bench.py 800:8192" "n65536:python $R/tools/quick_bench.py 65536:256" \

@@ -13,6 +13,8 @@ def run(streams, meter_ms=150, rms=1, ticks=30, hop=800, reps=3, **kw):
         assert b.fft_size == size
         b.push_synth(synth.DEFAULT_SEED, 0, hop * (ticks + 2))
         b.sync()
+        from tools.quick_bench import warm_clocks
+        warm_clocks()  # the device's clocks settle after 15-20 ms of load (profiles/r02j_warmup.txt)
         b.time_ticks(3, hop, hop * (ticks + 1))  # warm-up
         best = min(b.time_ticks(ticks, hop, hop * (ticks - 1)) for _ in range(reps))
         byt = b.algorithmic_bytes_per_tick()

@@ -36,14 +36,17 @@ def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None,
         rows = [r for r in csv.DictReader(open(tr)) if match in r["Kernel_Name"]]
         lanes = len({r["Stream_Id"] for r in rows}) or 1
         ticks = len(rows) // lanes
-        skip = min(3, ticks // 4) * lanes            # warm-up launches
+        # steady state = the last 40 % of the ticks: every profiled command spends at least half of its ticks on the lead-in
+        # its timed region follows (the device's clocks settle after 15-20 ms of load)
+        skip = (ticks - max(1, ticks * 2 // 5)) * lanes
         if ticks > 1:
             body = rows[skip:]
             span = max(int(r["End_Timestamp"]) for r in body) - min(int(r["Start_Timestamp"]) for r in body)
             trace = {"launches": len(rows), "launches_per_tick": lanes, "ticks_in_span": len(body) // lanes,
                      "tick_span_ns": span / (len(body) // lanes),
                      "note": "launches of a tick run concurrently on %d HIP stream(s); tick_span_ns = (last end - first start) / ticks "
-                             "over the steady-state launches, profiler attached" % lanes}
+                             "over the last 40 %% of the launches (steady state: behind the command's lead-in), profiler attached; "
+                             "kernel_stats averages every launch of the run, lead-in included" % lanes}
     fetch_b = tot.get("FETCH_SIZE", 0) * 1024 * 2
     write_b = tot.get("WRITE_SIZE", 0) * 1024
     cyc = tot.get("GRBM_GUI_ACTIVE", 0) / 8

@@ -14,6 +14,8 @@ def run(streams, width=800, ticks=30, hop=800):
         b.sync()
         # tick i looks at the audio up to hop*(i+1) frames: delay counts back from the newest sample, audio_ts is its time
         end_ns = (hop * (ticks + 2) + width) * 1_000_000_000 // 48000
+        from tools.quick_bench import warm_clocks
+        warm_clocks()  # the device's clocks settle after 15-20 ms of load (profiles/r02j_warmup.txt)
         ms = C.c_float(0.0)
         p = TickParams(1 / 60, hop * (ticks + 1), 0.0, 0, end_ns)
         b._ck(b.L.wf_hip_time_ticks(b.h, C.byref(p), 2, hop, C.byref(ms)))  # warm-up

@@ -2283,8 +2283,8 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
 {
     if(h == nullptr || p == nullptr || ticks == 0 || avg_kernel_ms == nullptr)
         return WF_HIP_ERR_INVALID;
-    if((uint64_t)hop * (ticks - 1) > p->delay_frames)
-        return fail(h, WF_HIP_ERR_INVALID, "delay_frames %u too small for %u ticks of hop %u", p->delay_frames, ticks, hop);
+    // the walk starts over at the oldest window when it has reached the newest sample
+    const uint32_t period = hop ? p->delay_frames / hop + 1 : ticks;
     WF_HIP_TRY(h, hipSetDevice(h->device));
     WF_TRY_RC(join_lanes(h));
     // events recorded on the handle's own stream, around the fused kernels only (the lanes fork behind ev0 and are joined
@@ -2292,7 +2292,7 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
     WF_HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     wf_hip_tick_params q = *p;
     for(uint32_t i = 0; i < ticks; ++i) {
-        q.delay_frames = p->delay_frames - i * hop;
+        q.delay_frames = p->delay_frames - (i % period) * hop;
         int rc = wf_hip_tick(h, &q);
         if(rc)
             return rc;
