@@ -67,12 +67,6 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_TRACK
 #define WF_TRACK 1
 #endif
-#ifndef WF_DEFER_ROWS
-#define WF_DEFER_ROWS 0 // (curve display: row stores after the points, so that the points' table loads do not queue behind them: measured +-0)
-#endif
-#ifndef WF_DEFER_ROWS_BARS
-#define WF_DEFER_ROWS_BARS 0 // (bars: the same, so that the wait for the bar coefficients is not a wait for the row stores' acknowledgement: +-0 again, -10 % at N = 2048)
-#endif
 #ifndef WF_BAR_COEF_EARLY
 #define WF_BAR_COEF_EARLY 0 // (bar tables requested in front of the smoothing state instead of behind it, so that the dot products need
                             // no wait of their own: up to 24 more registers across P4 -- 128 VGPRs and 20-36 B of scratch on every geometry from 4096)
@@ -481,7 +475,6 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);
-    const bool defer_rows = a.bar.out != nullptr && (a.bar.curve != 0 ? WF_DEFER_ROWS != 0 : WF_DEFER_ROWS_BARS != 0);
     float d[RP];
     bool row_exceeds = false; // bars-only handles: this thread's part of the row has a value > floor - 10
     if(have_row && row_thread) {
@@ -494,9 +487,10 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             for(int i = 0; i < RP; ++i)
                 row_exceeds = row_exceeds || ((!BLU || 4 * (t + RG::T * (i / 4)) < NB) && d[i] > a.silent_floor);
         }
-        // (curve display: the row goes out after the points -- their table loads would otherwise wait for these stores to be
-        // acknowledged, vector-memory operations complete in order)
-        if(!a.skip_decibels && !defer_rows) {
+        // (Storing the rows behind the bars / curve points instead -- so that the wait for their table loads, vector memory
+        // completing in order, is not a wait for these stores' acknowledgement -- measured +-0 for both, -10 % for bars at
+        // N = 2048, and is no longer in the tree.)
+        if(!a.skip_decibels) {
             store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
             if(dup_row)
                 store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
@@ -603,11 +597,6 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
                     [](float v, int m) { return v + __shfl_xor(v, m, 64); });
             if(pending)
                 outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
-        }
-        if(defer_rows && have_row && row_thread && !a.skip_decibels) {
-            store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
-            if(dup_row)
-                store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
         }
     }
     WF_STAMP(13);
