@@ -14,6 +14,7 @@ if os.environ.get("WF_BENCH_CURVE"):
 cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=1.0, **extra)
 b = wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * (ticks + 2))
 b.push_synth(synth.DEFAULT_SEED, 0, hop * (ticks + 1))
+b.time_ticks(int(os.environ.get("WF_WARM_TICKS", "600")), hop, hop * (ticks - 1))  # settled clocks (profiles/r02j_warmup.txt)
 for i in range(ticks):
     b.tick(delay_frames=hop * (ticks - 1 - i))
 b.sync()

@@ -1177,6 +1177,9 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         const uint32_t per_cu = std::max(1u, std::min(h->wg_lds ? (160u * 1024u) / h->wg_lds : 16u, h->wg_threads ? 1024u / h->wg_threads : 16u));
         const uint32_t round = per_cu * (uint32_t)std::max(prop.multiProcessorCount, 1);
         int lanes = wgs >= 2u * round ? 2 : 1;
+        if(h->M <= 512 && !h->cfg.meter && !h->cfg.waveform && wgs >= 6u * round)
+            lanes = 3; // the one-wavefront 8-point geometry in long launches: 0.714-0.717 against 0.682-0.683 of the HBM peak at
+                       // 16384 streams (steady state, r02j); +-2 % on every other geometry
         if(const char *e = std::getenv("WF_HIP_LANES"))
             lanes = std::atoi(e);
         lanes = std::max(1, std::min({lanes, (int)wf_hip::MAX_LANES, (int)h->n_streams}));
