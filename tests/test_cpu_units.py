@@ -90,7 +90,7 @@ def test_degenerate_display_configurations_are_rejected():
 
 
 # ---- kernel phases in the wavefront emulator vs the oracle --------------------------------------------
-@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384, 32768])
 @pytest.mark.parametrize("hop", [800, 441])
 def test_emulated_kernel_matches_oracle(n, hop):
     cfg = scenarios.make_config(dict(fft_size=n, stereo=1, slope=1.0, fast_peaks=1))
@@ -132,7 +132,7 @@ def test_emulated_kernel_window_delay():
 def test_lds_budget_and_conflicts():
     """LDS per spectrum stays within the occupancy plan and every exchange access is bank-conflict free under the
     lane-group model of MI355X_MICROARCH.md (reads and writes, all geometries)"""
-    budget = {1024: 5 * 1024, 2048: 9 * 1024, 4096: 17408, 8192: 34 * 1024, 16384: 68 * 1024, 32768: 133 * 1024}
+    budget = {512: 5 * 1024, 1024: 5 * 1024, 2048: 9 * 1024, 4096: 17408, 8192: 34 * 1024, 16384: 68 * 1024, 32768: 133 * 1024}
     for n, b in budget.items():
         assert 0 < emu.lib().wfemu_lds_bytes(n) <= b
         cfg = scenarios.make_config(dict(fft_size=n, stereo=1))
@@ -210,7 +210,7 @@ def test_power_of_two_kernels_do_not_spill():
         return out
 
     with cf.ThreadPoolExecutor(6) as ex:
-        results = list(ex.map(usage, (1024, 2048, 4096, 8192, 16384, 32768)))
+        results = list(ex.map(usage, (512, 1024, 2048, 4096, 8192, 16384, 32768)))
     seen = 0
     for res in results:
         for name, scratch, vgprs in res:

@@ -133,7 +133,11 @@ template<int N_, int T_, int R1_, int R2_, int R3_> struct Geom {
     static constexpr int EX2_SIZE = M;
     static constexpr int S3 = M / 4 + 4;    // ex3 plane stride (see ex3_addr)
     static constexpr int EX3_SIZE = 4 * S3;
-    static constexpr int LDS_CF = (EX1_SIZE > EX3_SIZE) ? EX1_SIZE : EX3_SIZE; // per spectrum, in cf
+    // per spectrum, in cf; never less than the 1024-point geometry's 576: the bars / curve phase parks the dB row and stages
+    // the filter's inputs in this buffer, and the smallest geometry would otherwise hold fewer outputs per row (800-point
+    // filtered curves) than the zero-padded runs on the 1024-point geometry it replaced did
+    static constexpr int LDS_NEED = (EX1_SIZE > EX3_SIZE) ? EX1_SIZE : EX3_SIZE;
+    static constexpr int LDS_CF = LDS_NEED > 576 ? LDS_NEED : 576;
     static_assert(R1_ * R2_ * R3_ == N_ / 2, "radices must multiply to M");
     static_assert(B1 == 1 || B1 == 2, "pass 1 loads 8 or 16 bytes per thread");
     static_assert(T_ * B1 == M1, "pass-1 butterflies must tile the threads");

@@ -6,6 +6,8 @@
 #include "wf_fft_core.hpp"
 
 namespace wf {
+using G512 = Geom<512, 64, 4, 8, 8>;         // four points per thread; both radix-8 passes shared by thread pairs.  256 and 128 run
+                                              // zero-padded on it (DEC)
 using G1024 = Geom<1024, 64, 8, 8, 8>;
 using G2048 = Geom<2048, 64, 8, 16, 8>;
 using G4096 = Geom<4096, 128, 8, 16, 16>;     // two wavefronts
@@ -27,6 +29,7 @@ template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)
 #define WF_GEOM_CASE(N_, G_) case N_: f(G_{}); return true;
 #endif
     switch(n) {
+    WF_GEOM_CASE(512, G512)
     WF_GEOM_CASE(1024, G1024)
     WF_GEOM_CASE(2048, G2048)
     WF_GEOM_CASE(4096, G4096)

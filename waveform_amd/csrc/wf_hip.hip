@@ -807,7 +807,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         h->blu = L != 0;
         h->big_l = L > 16384u ? L : (!L && h->N == 65536u) ? 32768u : 0u;
         h->big_rows = h->big_l / 16384u;
-        h->geom_n = h->big_l ? 32768u : L ? 2 * L : std::max(h->N, 1024u); // big: the row transform's geometry
+        h->geom_n = h->big_l ? 32768u : L ? 2 * L : std::max(h->N, 512u); // big: the row transform's geometry
     }
     if(cfg->waveform) {
         // rows of `width` points; the ring holds the history the points are picked from (+ the width zeros of update())
@@ -1095,18 +1095,11 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                                       : (cfg->capture_channels > 1) ? setup_launch_blu<G, 2, false>(h) : setup_launch_blu<G, 1, false>(h);
             else
                 setup_rc = setup_launch_blu<G, 2, false>(h);
-        } else if constexpr(G::N == 1024) {
+        } else if constexpr(G::N == 512) {
             switch(h->N) {
-            case 512: setup_rc = setup_launch_dec<G, 1>(h); break;
-            case 256: setup_rc = setup_launch_dec<G, 2>(h); break;
-            case 128: setup_rc = setup_launch_dec<G, 3>(h); break;
-            default:
-#ifdef WF_SPW4_1024 // development builds: four spectra (two streams) per workgroup on the 8-point geometry
-                setup_rc = setup_launch_impl<G, 4, false>(h);
-#else
-                setup_rc = setup_launch<G, 2>(h);
-#endif
-                break;
+            case 256: setup_rc = setup_launch_dec<G, 1>(h); break;
+            case 128: setup_rc = setup_launch_dec<G, 2>(h); break;
+            default: setup_rc = setup_launch<G, 2>(h); break;
             }
         } else if constexpr(G::N >= 32768) {
             // one spectrum fills a CU's LDS: a stereo pair runs split, a single captured channel alone; mono mixdown of two

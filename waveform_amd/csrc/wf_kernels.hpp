@@ -82,7 +82,10 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_WPS_2048
 #define WF_WPS_2048 3
 #endif
-#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 8) ? WF_WPS_SMALL : 4)
+#ifndef WF_WPS_512
+#define WF_WPS_512 6 // four points per thread: 80 VGPRs; 0.60 of the HBM peak at N = 512 against 0.53 at 4 and 5 waves, 0.44 at 8 (spills)
+#endif
+#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 4) ? WF_WPS_512 : (G::P <= 8) ? WF_WPS_SMALL : 4)
 
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \

@@ -708,7 +708,7 @@ template<class G> WF_DEV void p2_read(int t, const cf *lds, cf (&v)[G::P])
         // the whole column; thread h keeps the half of the first radix-2 stage that feeds the outputs k2 = 2k' + h, as
         // pass 3 does: u[j] = (v[j] + sg * v[j+16]) * (h ? W_32^j : 1).
         constexpr int HALF = R2 / 2;
-        static_assert(R2 == 32, "the shared second pass is written for radix 32");
+        static_assert(R2 == 32 || R2 == 8, "the shared second pass: radix 32 (16 points per thread) or radix 8 (4 points per thread)");
         const int c = t & (G::R1 * R3 - 1), h = t / (G::R1 * R3);
         const int k1 = c / R3, n3 = c % R3;
         const float hf = (float)h;
@@ -718,7 +718,7 @@ template<class G> WF_DEV void p2_read(int t, const cf *lds, cf (&v)[G::P])
             const cf lo = lds_ld2(lds, ex1_addr<G>(k1, j * R3 + n3));
             const cf hi = lds_ld2(lds, ex1_addr<G>(k1, (j + HALF) * R3 + n3));
             const cf e = cf{fmaf(sg, hi.x, lo.x), fmaf(sg, hi.y, lo.y)};
-            v[j] = cmul(e, half_twiddle32(j, hf));
+            v[j] = cmul(e, half_twiddle32(j * (32 / R2), hf)); // W_R2^j
         }
         return;
     }
@@ -823,8 +823,8 @@ template<class G> WF_DEV void p3_read(int t, const cf *lds, cf (&v)[G::P])
             const f4 hi = lds_ld4(lds, ex2_addr<G>(q, j + HALF));
             const cf e0 = cf{fmaf(sg, hi.x, lo.x), fmaf(sg, hi.y, lo.y)};
             const cf e1 = cf{fmaf(sg, hi.z, lo.z), fmaf(sg, hi.w, lo.w)};
-            v[j] = cmul(e0, half_twiddle32(j, hf));
-            v[j + 1] = cmul(e1, half_twiddle32(j + 1, hf));
+            v[j] = cmul(e0, half_twiddle32(j * (32 / R3), hf)); // W_R3^j
+            v[j + 1] = cmul(e1, half_twiddle32((j + 1) * (32 / R3), hf));
         }
         return;
     }
