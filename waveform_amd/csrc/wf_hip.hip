@@ -249,7 +249,7 @@ template<class G> int setup_launch_split(wf_hip *h)
     return WF_HIP_OK;
 }
 
-// FFT sizes 512 / 256 / 128 on the 1024-point geometry, zero-padded (spectrum_tick_kernel<.., DEC>)
+// FFT sizes 256 / 128 on the 512-point geometry, zero-padded (spectrum_tick_kernel<.., DEC>)
 template<class G, int DEC> void launch_tick_dec(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     const uint32_t n_spec = a.stream_count * a.cap_ch;

@@ -114,7 +114,7 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // window itself, "previous row entirely <= floor - 10" and m_last_silent from words the *previous* tick left (verdict_in,
 // stream_flags) while this tick writes the next tick's copies (verdict_out, flags_out).
 //
-// DEC > 0: FFT sizes below the smallest geometry (N >> DEC = 512, 256, 128 on the 1024-point one).  The N >> DEC samples are
+// DEC > 0: FFT sizes below the smallest geometry (N >> DEC = 256, 128 on the 512-point one).  The N >> DEC samples are
 // transformed zero-padded to N points -- bin o of the small transform is bin o << DEC of the padded one, exactly -- so
 // passes 1-3 run unchanged on the rows that hold samples and the epilogue keeps every (1 << DEC)-th bin: the first
 // (M >> DEC) / 4 threads of the spectrum own four consecutive output bins each; rows, state and tables have M >> DEC entries.
