@@ -379,3 +379,30 @@ def test_sample_counters_wrap_at_2_to_the_32(kind):
                 assert np.array_equal(fresh.input_rms(), old.input_rms()), f"push {i}: m_input_rms differs"
             assert np.array_equal(fresh.bars(), old.bars()) and np.array_equal(fresh.last_silent(), old.last_silent())
         assert total > rings_left * ring + 4 * push
+
+
+@pytest.mark.parametrize("n,streams,extra", [(16384, 2048, dict(bars=1, interp_mode=1)), (8192, 2048, dict(bars=1, interp_mode=2)),
+                                             (4096, 4096, dict(bars=1, interp_mode=1)), (4096, 2048, dict(curve=1, interp_mode=2, stereo=0)),
+                                             (1024, 8192, dict(bars=1, interp_mode=1)), (512, 8192, dict(bars=1, interp_mode=1))])
+def test_displays_are_deterministic_under_load(n, streams, extra):
+    """the bars / curve tail shares the exchange buffer between wavefronts by an arrival counter and one barrier, and adds
+    partial sums by lane shuffles: a race there would show as run-to-run differences under a chip full of workgroups.  Two
+    runs of 150 back-to-back ticks (lanes on) must leave the same bits everywhere; the second run's ticks overlap differently
+    (it starts on a busy device)."""
+    kw = dict(fft_size=n, stereo=1, slope=1.0)
+    kw.update(extra)
+    cfg = wf.Config.defaults(**kw)
+    ticks, hop = 150, 800
+    res = []
+    with wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * 66) as warm:  # keeps the device busy before the second run
+        warm.push_synth(SEED + 1, 0, hop * 64)
+        for rep in range(2):
+            with wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * 66) as b:
+                b.push_synth(SEED, 0, hop * 64)
+                if rep:
+                    warm.time_ticks(200, hop, hop * 63)
+                b.time_ticks(ticks, hop, hop * 63)
+                res.append((b.bars(), b.decibels(), b.last_silent()))
+    for a, c, what in zip(res[0], res[1], ("bars", "rows", "silence flags")):
+        assert np.array_equal(a, c), f"N={n}: {what} differ between two identical runs"
+    assert np.all(np.isfinite(res[0][0]))
