@@ -2,7 +2,7 @@
 # tools/gpu_round.sh -- one gpurun call that gathers a round's evidence: GPU tests, bench line, rocprofv3 passes.
 #   usage (from the repo root on the GPU box): bash tools/gpu_round.sh TAG [tests|notests]
 set -u
-TAG=${1:-r02j}
+TAG=${1:-r02k}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
