@@ -1,6 +1,6 @@
 // wf_geometry.hpp -- the FFT decompositions the library ships, one per supported FFT size.
 // T threads per spectrum (1, 1, 2, 4, 8 wavefronts for N = 1024 ... 16384); every thread owns
-// P = N/(2T) complex points (8 or 16); pass 1 fetches 16-byte vectors where the radices allow (8-byte ones at 1024 and 32768).  Measured alternatives with 32 points per
+// P = N/(2T) complex points (4, 8 or 16); pass 1 fetches 16-byte vectors where the radices allow (8-byte ones at 512 and 32768).  Measured alternatives with 32 points per
 // thread (N = 4096 on one wavefront, 8192 on two, 16384 on four) held 156-168 VGPRs and ran 15-20 % slower.
 #pragma once
 #include "wf_fft_core.hpp"
@@ -8,7 +8,8 @@
 namespace wf {
 using G512 = Geom<512, 64, 4, 8, 8>;         // four points per thread; both radix-8 passes shared by thread pairs.  256 and 128 run
                                               // zero-padded on it (DEC)
-using G1024 = Geom<1024, 64, 8, 8, 8>;
+using G1024 = Geom<1024, 64, 4, 16, 8>;      // radix 4 first: pass 1 fetches 16-byte vectors (10 requests per thread instead of 23 eight-byte
+                                              // ones), the radix-16 second pass shared by thread pairs: +1.3 % over 8x8x8 (0.693 -> 0.703), +1.8 % with bars
 using G2048 = Geom<2048, 64, 8, 16, 8>;
 using G4096 = Geom<4096, 128, 8, 16, 16>;     // two wavefronts
 using G8192 = Geom<8192, 256, 8, 16, 32>;     // four wavefronts; radix 8 first so that pass 1 fetches 16-byte vectors (23 requests

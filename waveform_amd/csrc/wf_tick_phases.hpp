@@ -708,7 +708,7 @@ template<class G> WF_DEV void p2_read(int t, const cf *lds, cf (&v)[G::P])
         // the whole column; thread h keeps the half of the first radix-2 stage that feeds the outputs k2 = 2k' + h, as
         // pass 3 does: u[j] = (v[j] + sg * v[j+16]) * (h ? W_32^j : 1).
         constexpr int HALF = R2 / 2;
-        static_assert(R2 == 32 || R2 == 8, "the shared second pass: radix 32 (16 points per thread) or radix 8 (4 points per thread)");
+        static_assert(R2 == 32 || R2 == 16 || R2 == 8, "the shared second pass: radix 32 / 16 / 8 with 16 / 8 / 4 points per thread");
         const int c = t & (G::R1 * R3 - 1), h = t / (G::R1 * R3);
         const int k1 = c / R3, n3 = c % R3;
         const float hf = (float)h;
