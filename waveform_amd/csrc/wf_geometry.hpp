@@ -15,6 +15,7 @@ using G4096 = Geom<4096, 128, 8, 16, 16>;     // two wavefronts
 using G8192 = Geom<8192, 256, 8, 16, 32>;     // four wavefronts; radix 8 first so that pass 1 fetches 16-byte vectors (23 requests
                                               // per thread instead of the 47 eight-byte ones of 16x16x16: 53 -> 57 % of the HBM peak),
                                               // radix-32 last pass shared by thread pairs
+// (measured alternatives in steady state: 2048 as 8x8x16 +-0, 4096 as 8x32x8 -2.5 %, 8192 as 8x32x16 -2 %)
 using G16384 = Geom<16384, 512, 8, 32, 32>;   // eight wavefronts; radix 8 first (16-byte pass-1 vectors: 51.7 -> 53.5 % over
                                               // 16x16x32), both radix-32 passes shared by thread pairs
 using G32768 = Geom<32768, 1024, 16, 32, 32>; // sixteen wavefronts = one workgroup per spectrum (132 KB of LDS); both radix-32
