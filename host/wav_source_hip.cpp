@@ -709,18 +709,25 @@ void WAVSourceHIP::tick_waveform(float seconds)
                          std::memcmp(all[channel].data(), m_hip_prev.data() + (size_t)channel * m_hip_pushed, m_hip_pushed * sizeof(float)) == 0;
         }
         fresh = front_kept ? frames - m_hip_pushed : frames;
+        // "timestamp rollover, give up" (:314-317; a tick before any audio has a timestamp): the reference has trimmed its
+        // ring but consumes nothing.  The device takes the same exit from the same timestamps (and records the trim); here the
+        // ring keeps what it holds, all of it now on the device.
+        const auto start_ts = m_audio_ts - audio_frames_to_ns(m_audio_info.samples_per_sec, frames);
+        const auto stop_ts = m_audio_ts - audio_frames_to_ns(m_audio_info.samples_per_sec, reserve);
+        const bool rollover = (start_ts >= m_audio_ts) || (stop_ts > m_audio_ts);
+        const size_t stay = rollover ? frames : reserve; // frames left in m_capturebufs behind this tick
         m_hip_window.resize((size_t)m_capture_channels * fresh);
-        m_hip_prev.assign((size_t)m_capture_channels * reserve, 0.0f);
+        m_hip_prev.assign((size_t)m_capture_channels * stay, 0.0f);
         for(auto channel = 0u; channel < m_capture_channels; ++channel) {
             auto &buf = m_capturebufs[channel];
             const size_t s = all[channel].size();
             std::memcpy(m_hip_window.data() + (size_t)channel * fresh, all[channel].data() + (s - fresh), fresh * sizeof(float));
-            std::memcpy(m_hip_prev.data() + (size_t)channel * reserve, all[channel].data() + (s - reserve), reserve * sizeof(float));
-            buf.pop_front(nullptr, (s - reserve) * sizeof(float)); // :321: only the reserve stays
+            std::memcpy(m_hip_prev.data() + (size_t)channel * stay, all[channel].data() + (s - stay), stay * sizeof(float));
+            buf.pop_front(nullptr, (s - stay) * sizeof(float)); // :321: only the reserve stays
         }
         if(fresh > 0)
             ok = a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)fresh) == WF_HIP_OK;
-        m_hip_pushed = reserve;
+        m_hip_pushed = stay;
         p.delay_frames = (uint32_t)reserve;
     }
     m_hip_out.resize((size_t)m_output_channels * outsz);

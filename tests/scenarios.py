@@ -219,6 +219,14 @@ SCENARIOS = {
     "wave_sync_burst": dict(cfg=dict(waveform=1, stereo=1, width=480), sync_ms=20,
                             steps=_steps(4) + [("tick",)] * 2 + [("noise", 1024)] * 9 + [("tick",)] + _steps(2) + [("noise", 1024)] * 3 + [("tick",)]
                             + _steps(2), record="all"),
+    # the first tick comes before any audio has a timestamp (the reference trims its ring, then gives up: "timestamp
+    # rollover", :303-317); small packets, 20 ms of history over 1024 points (fewer samples than points), one captured channel
+    # shown as two rows, a 5 ms reserve -- fuzz seed 7060, found by an extended sweep at the end of round 2
+    "wave_tick_before_audio_sync": dict(cfg=dict(waveform=1, capture_channels=1, stereo=1, width=1024, meter_ms=20), sync_ms=5,
+                                        steps=[("tick",), ("noise_amp", 37, 1.0), ("tick",), ("noise_amp", 37, 0.2), ("noise_amp", 37, 1.0), ("tick",),
+                                               ("tick",), ("tick",), ("noise_amp", 441, 0.2), ("tick",), ("noise_amp", 441, 0.2),
+                                               ("noise_amp", 800, 0.2), ("tick",), ("hide",), ("noise", 800), ("tick",), ("tick",), ("show",),
+                                               ("noise", 800), ("tick",)], record="all"),
     "wave_hide_timeout_sync": dict(cfg=dict(waveform=1, stereo=1, width=333), sync_ms=10,
                                    steps=_steps(4) + [("hide",), ("noise", 800), ("tick",), ("tick",), ("show",)] + _steps(3)
                                    + [("timeout",), ("tick",), ("tick",)] + _steps(3), record="all"),

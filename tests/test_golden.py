@@ -92,7 +92,8 @@ DROPIN = SPECTRUM_DROPIN + [
     "meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",
     "meter_hide_show_timeout",
     # WAVSourceHIP::tick_waveform
-    "wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync", "wave_sync_burst", "wave_normalize"]
+    "wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync", "wave_sync_burst", "wave_normalize",
+    "wave_tick_before_audio_sync"]
 
 
 def _hip_env(batched):

@@ -126,8 +126,13 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     const uint32_t sr = a.sample_rate;
     const unsigned long long start_ts = a.audio_ts - frames_to_ns(total, sr);
     const unsigned long long stop_ts = a.audio_ts - frames_to_ns(R, sr);
-    if(start_ts >= a.audio_ts || stop_ts > a.audio_ts)
-        return; // timestamp rollover, :316-317 (nothing has been written)
+    if(start_ts >= a.audio_ts || stop_ts > a.audio_ts) {
+        // timestamp rollover, :316-317 (a tick before any audio has a timestamp).  The rows are untouched, but the reference
+        // has already trimmed the ring to max_size on its way here (:303-304), and the samples it dropped stay dropped
+        if(tid == 0 && avail > max_size)
+            a.cend[stream] = wpos - max_size;
+        return;
+    }
     unsigned long long wts = a.wts[stream];
     if(wts < start_ts)
         wts = start_ts; // catch up
