@@ -123,16 +123,42 @@ def _undo_db(cfg):
     return ro
 
 
-def _compare(got, want, undo, what, cfg_stepped=False):
+def _render_from_rows(cfg, rows):
+    """what the restated render_bars / render_curve makes of the given dB rows: (bars [ch, n], vertices per channel or None)"""
+    import ctypes as C
+    from oracle import restate
+    o = restate.OracleSource(cfg)
+    try:
+        rows = np.ascontiguousarray(rows, np.float32)
+        for c in range(o.display_channels):
+            C.memmove(o.L.wfo_decibels(o.h, c), rows[c].ctypes.data, rows[c].nbytes)
+        o.render_bars()
+        bars = o.bars().copy()
+        verts = [o.vertices(c, line=cfg.vertices == 2).copy() for c in range(o.display_channels)] if cfg.vertices else None
+    finally:
+        o.close()
+    return bars, verts
+
+
+def _compare(got, want, undo, what, cfg_stepped=False, cfg=None):
+    """rows against rows (assert_db_close), then the display derived from them.  A bar or curve point averages dB values, and a
+    bin in a deep null may differ by whole dB between two correct float FFTs (the linear arm of assert_db_close allows it): where
+    the display misses the reference's by more than the pixel tolerance it is held, with the same tolerance, against what the
+    restated render loop makes of the *device's own rows* -- a stage is not faulted for the latitude of the stage before it."""
     assert len(got) == len(want)
     for t, (g, w) in enumerate(zip(got, want)):
         assert g["silent"] == w["silent"], f"{what} tick {t}: m_last_silent {g['silent']} != {w['silent']}"
         assert_db_close(g["db"], w["db"], f"{what} tick {t} decibels", undo_db=undo)
+        ref_bars, ref_verts = w["bars"], w.get("verts")
         if w["bars"] is not None:
             err = np.abs(g["bars"].astype(np.float64) - w["bars"])
-            assert np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3), f"{what} tick {t} bars/curve: max err {err.max():.3e} px"
+            if not np.all(err <= 1e-5 * np.abs(w["bars"]) + 2e-3) and cfg is not None:
+                ref_bars, alt_verts = _render_from_rows(cfg, g["db"])
+                ref_verts = alt_verts if alt_verts is not None else ref_verts
+                err = np.abs(g["bars"].astype(np.float64) - ref_bars)
+            assert np.all(err <= 1e-5 * np.abs(ref_bars) + 2e-3), f"{what} tick {t} bars/curve: max err {err.max():.3e} px"
         if "verts" in w:
-            for c, (gv, wv) in enumerate(zip(g["verts"], w["verts"])):
+            for c, (gv, wv) in enumerate(zip(g["verts"], ref_verts)):
                 # stepped bars: a bar whose height sits within rounding of a step boundary may gain or lose that step
                 if gv.shape != wv.shape and cfg_stepped:
                     assert abs(gv.shape[0] - wv.shape[0]) <= 6 * 2, f"{what} tick {t} channel {c}: {gv.shape[0]} vs {wv.shape[0]} vertices"
@@ -159,7 +185,7 @@ def run_spectrum_case(seed, family):
         want = scenarios.play(ora, sc)
     finally:
         hip.close()
-    _compare(got, want, undo, what + " vs the restatement", cfg_stepped=cfg_dict.get("vertices") == 3)
+    _compare(got, want, undo, what + " vs the restatement", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
     if seed % REF_EVERY == 0:
         # the same script against the reference itself (its own float FFTW, its own update_input_rms); the device derives
         # m_input_rms from the audio too
@@ -172,7 +198,7 @@ def run_spectrum_case(seed, family):
                 want = scenarios.play(ref, sc)
             finally:
                 hip.close()
-            _compare(got, want, undo, what + " vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3)
+            _compare(got, want, undo, what + " vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
 
 
 @pytest.mark.gpu

@@ -169,10 +169,10 @@ __global__ __launch_bounds__(METER_THREADS) void meter_tick_kernel(const MeterAr
         if(a.tsmooth) {
             const float old = buf[c];
             if(!a.fast_peaks || out <= old)
-                out = __fadd_rn(__fmul_rn(a.g, old), __fmul_rn(a.g2, out)); // (g * m_meter_buf) + (g2 * out), two roundings (:255)
+                out = meter_ema(a.g, old, a.g2, out); // (g * m_meter_buf) + (g2 * out), :255
         }
         buf[c] = out;
-        const float db = (out > 0.0f) ? __fmul_rn(20.0f, log10f(out)) : a.db_min; // dbfs(), src/source.hpp:293-299
+        const float db = (out > 0.0f) ? mul_unfused(20.0f, log10f(out)) : a.db_min; // dbfs(), src/source.hpp:293-299
         val[c] = db;
         if(db < a.silent_floor)
             ++silent_channels;

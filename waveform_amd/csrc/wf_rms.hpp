@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void input_rms_kernel(const RmsArgs a)
     if(lane == 0) {
         const float rms = __fsqrt_rn(__fdiv_rn(sum, (float)a.size)); // std::sqrt(sum / m_input_rms_size)
         a.input_rms[stream] = rms;
-        const float rms_db = (rms > 0.0f) ? __fmul_rn(20.0f, log10f(rms)) : a.db_min; // dbfs(), src/source.hpp:293-299
+        const float rms_db = (rms > 0.0f) ? mul_unfused(20.0f, log10f(rms)) : a.db_min; // dbfs(), src/source.hpp:293-299
         const float comp = a.volume_target - rms_db;                  // src/source_generic.cpp:163
         a.vol_comp[stream] = comp < a.max_gain ? comp : a.max_gain;
     }

@@ -238,6 +238,30 @@ WF_DEV void st_state(float *p, f4 v)
         st4(p, v);
 }
 
+// Products and sums that must be rounded on their own, as the reference's scalar code rounds them.  HIP compiles device code
+// with -ffp-contract=fast, and __fmul_rn / __fadd_rn are plain operators to the optimiser: `__fadd_rn(__fmul_rn(a, b), c)`
+// becomes one fma.  Harmless within a tolerance -- except where the sum cancels: the level meter's smoothing starts from
+// m_meter_buf = DB_MIN (a quirk of the reference: -758.6 taken as a linear level), and on the tick where g * old + g2 * new
+// first turns positive a fused product moved the level by 7e-4 dB (fuzz seed 14562 of an extended sweep).
+WF_DEV float mul_unfused(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+WF_DEV float add_unfused(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+// (g * old) + (g2 * cur), three roundings (reference src/source_generic.cpp:255)
+WF_DEV float meter_ema(float g, float old, float g2, float cur)
+{
+#pragma clang fp contract(off)
+    const float x = g * old;
+    const float y = g2 * cur;
+    return x + y;
+}
+
 // ordering point between LDS operations of one wavefront (they execute in program order: a scheduling fence suffices)
 #if defined(__HIPCC__)
 WF_DEV void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); } // vmcnt(0), the other counters untouched (gfx9 encoding)

@@ -63,7 +63,7 @@ WF_DEV unsigned long long ns_to_frames(unsigned long long ns, uint32_t sr)
 }
 
 // exact dbfs of the reference (20 * log10f) -- a few hundred points per stream and tick, so the library log is affordable
-WF_DEV float wave_dbfs(float mag, float db_min) { return (mag > 0.0f) ? __fmul_rn(20.0f, log10f(mag)) : db_min; }
+WF_DEV float wave_dbfs(float mag, float db_min) { return (mag > 0.0f) ? mul_unfused(20.0f, log10f(mag)) : db_min; }
 
 // V = 4: rows whose length is a multiple of 4 floats are 16-byte aligned; every row access is a 16-byte vector and a thread
 // handles four consecutive points per step.  V = 1: any width, dword accesses.
@@ -208,13 +208,13 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
                 if(a.stereo || a.cap_ch == 1)
                     r0[e] = wave_dbfs(__builtin_fabsf(r0[e]), a.db_min);
                 else
-                    r0[e] = wave_dbfs(__fmul_rn(__fadd_rn(__builtin_fabsf(r0[e]), __builtin_fabsf(s1)), 0.5f), a.db_min);
+                    r0[e] = wave_dbfs(mul_unfused(add_unfused(__builtin_fabsf(r0[e]), __builtin_fabsf(s1)), 0.5f), a.db_min);
                 if(a.normalize)
-                    r0[e] = __fadd_rn(r0[e], comp);
+                    r0[e] = add_unfused(r0[e], comp);
                 if(a.stereo && a.cap_ch > 1) {
                     o1[e] = wave_dbfs(__builtin_fabsf(s1), a.db_min);
                     if(a.normalize)
-                        o1[e] = __fadd_rn(o1[e], comp);
+                        o1[e] = add_unfused(o1[e], comp);
                 }
             }
         }
