@@ -1,4 +1,4 @@
-"""extended fuzz sweep (development aid): python tests/fuzz_sweep.py LO HI [pow2,any,meter,wave]
+"""extended fuzz sweep (development aid): python tests/fuzz_sweep.py LO HI [pow2,any,huge,meter,wave]
 runs the same case functions as tests/test_gpu_fuzz.py over seeds [LO, HI) and lists failures and skips"""
 import os
 import sys
@@ -11,7 +11,8 @@ import test_gpu_fuzz as f  # noqa: E402
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pow2", "any", "meter", "wave"]
-run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_spectrum_case(s, "any"), "meter": f.run_meter_case,
+run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_spectrum_case(s, "any"),
+       "huge": lambda s: f.run_spectrum_case(s, "huge"), "meter": f.run_meter_case,
        "wave": f.test_hip_waveform_matches_oracle_on_random_case}
 bad = skipped = 0
 for k in kinds:
