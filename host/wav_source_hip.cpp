@@ -461,7 +461,7 @@ void WAVSourceHIP::tick_spectrum_batched(float seconds)
     size_t dtframes = 0;
     if(!hidden) {
         if(!hip_window(dtframes)) {
-            st = WF_HIP_PAUSED; // underflow: the reference leaves the source as it is (:55-61)
+            st = WF_HIP_STARVED; // underflow (:55-61): no channel is processed, the end-of-tick pass still runs (see tick_spectrum)
         } else {
             // Which samples are new?  The device ring of this stream ends with the window handed over last time; the new
             // window overlaps it by fft_size - shift samples.  The shift the timestamps suggest is checked against the
@@ -566,19 +566,19 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     const auto dtcapture = m_tick_ts - m_capture_ts;
     const bool hidden = !m_show || (dtcapture > CAPTURE_TIMEOUT); // reference :34
     bool ok = true;
-    if(hidden != m_hip_hidden) {
-        const uint8_t mask = hidden ? 1 : 0;
+    size_t dtframes = 0;
+    // Underflow (fewer samples than window + A/V-sync delay, :55-61): every channel is skipped, but unless m_last_silent the
+    // reference's end-of-tick pass still runs over the rows as they are -- dbfs of a stale dB value is DB_MIN, and the volume
+    // normalisation gain goes on top (:138-179).  The device does the same for a stream marked WF_HIP_STARVED.
+    const bool starved = !hidden && !hip_window(dtframes);
+    const int state = hidden ? WF_HIP_HIDDEN : (starved ? WF_HIP_STARVED : WF_HIP_SHOWN);
+    if(state != m_hip_state) {
+        const uint8_t mask = (uint8_t)state;
         ok = a.set_hidden(m_hip, 0, 1, &mask) == WF_HIP_OK;
-        m_hip_hidden = hidden;
+        m_hip_state = state;
     }
-    if(ok && !hidden) {
-        size_t dtframes = 0;
-        if(!hip_window(dtframes))
-            return; // underflow: the reference leaves the source untouched (:55-61); so does this tick -- no CPU tick on
-                    // host state the device path does not maintain
-        // the whole window replaces the device ring's newest fft_size samples
+    if(ok && state == WF_HIP_SHOWN) // the whole window replaces the device ring's newest fft_size samples
         ok = a.push_audio(m_hip, 0, 1, m_hip_window.data(), (uint32_t)m_fft_size) == WF_HIP_OK;
-    }
     wf_hip_tick_params p{};
     p.seconds = seconds;
     p.delay_frames = 0;

@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 6
+#define WF_HIP_ABI_VERSION 7
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -174,6 +174,12 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
 #define WF_HIP_HIDDEN_TIMEOUT 2  /* m_tick_ts - m_capture_ts > CAPTURE_TIMEOUT */
 #define WF_HIP_PAUSED 3          /* spectrum batches: the source was not ticked in this video frame (OBS ticks only active sources) --
                                     the next wf_hip_tick leaves the stream exactly as it is; cleared by any other value */
+#define WF_HIP_STARVED 4         /* spectrum batches whose host keeps the sources' own buffers (the plugin binding): the source holds fewer
+                                    samples than window + A/V-sync delay (src/source_generic.cpp:55-61: every channel is skipped) -- the
+                                    next wf_hip_tick processes no channel of the stream but still runs the reference's end-of-tick pass
+                                    over the rows as they are (:138-179: dbfs of a stale dB value is DB_MIN; volume normalisation and
+                                    roll-off on top), as the kernel does for a stream whose device ring is that short; stays until
+                                    another value is set */
 int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *mask);
 /* A/V-sync delay per stream, in frames (dtaudio > 0 of each source, src/source_generic.cpp:50-51), for batches whose
  * sources run on their own audio timestamps: stream first+i analyses the window ending delay[i] + the tick's common

@@ -1,4 +1,4 @@
-"""extended fuzz sweep (development aid): python tests/fuzz_sweep.py LO HI [pow2,any,huge,meter,wave]
+"""extended fuzz sweep (development aid): python tests/fuzz_sweep.py LO HI [pow2,any,huge,meter,wave,dropin-pow2,dropin-any,dropin-meter,dropin-wave]
 runs the same case functions as tests/test_gpu_fuzz.py over seeds [LO, HI) and lists failures and skips"""
 import os
 import sys
@@ -14,6 +14,50 @@ kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pow2", "any", "meter"
 run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_spectrum_case(s, "any"),
        "huge": lambda s: f.run_spectrum_case(s, "huge"), "meter": f.run_meter_case,
        "wave": f.test_hip_waveform_matches_oracle_on_random_case}
+
+
+def run_dropin_case(seed, family):
+    """the fuzz script of `family` through the reference plugin itself, once with its own CPU class and once with WAVSourceHIP
+    (synchronous mode) as the tick implementation; the device path must stay in use, no tick may fall back"""
+    import numpy as np
+    from pathlib import Path
+    import scenarios
+    from oracle import wfref
+    from helpers import assert_db_close
+    os.environ["WF_HIP_LIBRARY"] = str(Path(ROOT) / "waveform_amd" / "libwaveform_hip.so")
+    os.environ["WF_HIP_BATCHED"] = "0"
+    if family == "meter":
+        cfg_dict, steps = f.draw_meter(seed)
+        sync_ms = 0
+    elif family == "wave":
+        cfg_dict, steps, sync_ms = f.draw_wave(seed)
+    else:
+        cfg_dict, steps, sync_ms = f.draw(seed, family)
+    cfg_dict = dict(cfg_dict)
+    cfg_dict.pop("vertices", None)  # the plugin's render loop stays the reference's own
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
+    before = wfref.hip_fallback_ticks()
+    hip = scenarios.RefBackend(cfg, isa="hip")
+    assert hip.src.using_hip, "WAVSourceHIP did not take the device path"
+    got = scenarios.play(hip, sc)
+    assert hip.src.using_hip and wfref.hip_fallback_ticks() == before, "fell back to the CPU class"
+    want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
+    assert len(got) == len(want)
+    undo = f._undo_db(cfg) if family in ("pow2", "any") else None
+    for t, (g, w) in enumerate(zip(got, want)):
+        what = f"drop-in {family} case {seed} tick {t} ({cfg_dict}, sync {sync_ms} ms)"
+        assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
+        if family == "meter":
+            err = np.abs(np.asarray(g["db"], np.float64) - np.asarray(w["db"], np.float64))
+            assert np.all(err <= 1e-5 * np.abs(w["db"]) + 1e-3), what + f": levels {g['db']} vs {w['db']}"
+        else:
+            assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({} if family in ("pow2", "any") else {"lin_eps": None}))
+
+
+for _fam in ("pow2", "any", "meter", "wave"):
+    run["dropin-" + _fam] = (lambda fam: (lambda s: run_dropin_case(s, fam)))(_fam)
+
 bad = skipped = 0
 for k in kinds:
     for s in range(lo, hi):

@@ -200,6 +200,11 @@ SCENARIOS = {
     "normalize_long_1024": dict(cfg=dict(fft_size=1024, stereo=1, normalize_volume=1, tsmoothing=0),
                                 steps=[("noise", 1000), ("noise", 600), ("tick",)] * 25
                                 + [("noise_amp", 1000, 0.1), ("noise_amp", 600, 0.1), ("tick",)] * 20, record=2),
+    # ticks that find fewer samples than window + A/V-sync delay (:55-61): every channel is skipped, but the end-of-tick pass
+    # still runs over the rows as they are -- with volume normalisation they read DB_MIN + gain until the first window is in
+    "underflow_normalize_sync_2048": dict(cfg=dict(fft_size=2048, stereo=1, normalize_volume=1, volume_target=-12, max_gain=21), sync_ms=20,
+                                          steps=[("noise_amp", 441, 0.3), ("tick",), ("noise_amp", 37, 0.3), ("tick",), ("noise_amp", 441, 0.3), ("tick",)]
+                                          + [("noise_amp", 800, 0.3), ("tick",)] * 6, record="all"),
     # ---- waveform display (tick_waveform, src/source_generic.cpp:271-390) ------------------------------------------------
     "wave_stereo_800": dict(cfg=dict(waveform=1, stereo=1), steps=_steps(10), record=3),
     # mono mixdown (row 1 keeps raw samples), ragged packets, shorter history

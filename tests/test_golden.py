@@ -80,7 +80,7 @@ def test_hip_reproduces_reference(name):
 
 
 # ---- the drop-in: the reference plugin itself, with only the per-tick DSP virtuals replaced by the HIP binding -------------
-SPECTRUM_DROPIN = ["cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4096_ema_slope", "cfg4_16384_tv_lanczos_bars",
+SPECTRUM_DROPIN = ["underflow_normalize_sync_2048", "cfg1_mono_1024", "cfg2_stereo_2048_nosmooth", "cfg3_stereo_4096_ema_slope", "cfg4_16384_tv_lanczos_bars",
                    "mono_mix_4096_tv_fastpeaks", "rolloff_catrom_linear", "ragged_hops", "silence_cycle", "half_silent_stereo",
                    "hide_show", "muted_packets", "timeout_spectrum", "split_8192_half_silent", "small_512_stereo_bars",
                    "small_128_single_dup_curve", "large_32768_single_tv", "any_800_mono_mix_bars", "any_4160_stereo_silence",

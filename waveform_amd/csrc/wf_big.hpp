@@ -264,7 +264,7 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
     const bool below1 = stereo ? (vin1 == 0u) : (vin0 == 0u); // mono display: channel 1 inspects row 0 too (reference :81)
     StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nz0, nz1, below0, below1);
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
-    const bool underflow = !(sflags & WF_STREAM_WRAPPED) && (wpos - a.blu_n) < delay; // reference :55-61
+    const bool underflow = (!(sflags & WF_STREAM_WRAPPED) && (wpos - a.blu_n) < delay) || (sflags & WF_STREAM_STARVED) != 0; // reference :55-61
     if(underflow) {
         plan.process0 = plan.process1 = false;
         plan.last_silent = was_silent;
@@ -323,7 +323,7 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
         exceeds = (ch == 0 ? vin0 : vin1) != 0u;
     if(ch == 0 && t == 0)
         a.flags_out[stream] = paused ? sflags
-                                     : ((sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED)) |
+                                     : ((sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED | WF_STREAM_STARVED)) |
                                         ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u));
     // what the next tick's silence test will find in this channel's row (reference :78-86: any value > floor - 10?)
     if(__any(exceeds) && lane == 0)

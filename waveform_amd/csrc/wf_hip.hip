@@ -1713,8 +1713,8 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
         return fail(h, WF_HIP_ERR_INVALID, "mask is NULL");
     if(h->meter || h->wave)
         for(uint32_t i = 0; i < count; ++i)
-            if(mask[i] == WF_HIP_PAUSED)
-                return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_PAUSED applies to spectrum batches only");
+            if(mask[i] == WF_HIP_PAUSED || mask[i] == WF_HIP_STARVED)
+                return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_PAUSED / WF_HIP_STARVED apply to spectrum batches only");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     if(h->mask_bytes < count) {
         rc = dev_alloc(h, &h->d_mask, (size_t)count);

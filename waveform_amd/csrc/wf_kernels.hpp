@@ -289,7 +289,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     // m_last_silent stays).  The ring is zero history before the first sample, so without this the window would be analysed
     // as digital silence.  Only ever true in the first `delay` samples after a reset (wpos starts at fft_size).
     const uint32_t fft_n = BLU ? a.blu_n : (uint32_t)(G::N >> DEC);
-    const bool underflow = !(sflags & WF_STREAM_WRAPPED) && (wpos - fft_n) < delay;
+    const bool underflow = (!(sflags & WF_STREAM_WRAPPED) && (wpos - fft_n) < delay) || (sflags & WF_STREAM_STARVED) != 0;
     if(underflow) {
         plan.process0 = plan.process1 = false;
         plan.last_silent = was_silent;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     if(active && ch == 0 && t == 0)
         (SPLIT ? a.flags_out : a.stream_flags)[stream] =
             paused ? sflags
-                   : ((sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u));
+                   : ((sflags & (WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_WRAPPED | WF_STREAM_STARVED)) | ((hidden || plan.last_silent) ? WF_STREAM_LAST_SILENT : 0u));
     if(!SPLIT && (WF_TRACK && a.bars_only != nullptr) && active) {
         // bars-only handles: what the next tick's silence test would find in the row this spectrum owns (see TickArgs)
         bool exceeds = false, write = true;
@@ -673,10 +673,11 @@ __global__ void set_hidden_kernel(uint32_t *flags, uint32_t first, uint32_t coun
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < count) {
-        const uint32_t f = flags[first + i] & ~(WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_PAUSED);
+        const uint32_t f = flags[first + i] & ~(WF_STREAM_HIDDEN | WF_STREAM_TIMEOUT | WF_STREAM_PAUSED | WF_STREAM_STARVED);
         const uint32_t m = mask[i];
-        flags[first + i] = m == WF_HIP_PAUSED ? (f | WF_STREAM_PAUSED)
-                                              : (f | (m ? WF_STREAM_HIDDEN : 0u) | (m == WF_HIP_HIDDEN_TIMEOUT ? WF_STREAM_TIMEOUT : 0u));
+        flags[first + i] = m == WF_HIP_PAUSED    ? (f | WF_STREAM_PAUSED)
+                           : m == WF_HIP_STARVED ? (f | WF_STREAM_STARVED)
+                                                 : (f | (m ? WF_STREAM_HIDDEN : 0u) | (m == WF_HIP_HIDDEN_TIMEOUT ? WF_STREAM_TIMEOUT : 0u));
     }
 }
 

@@ -39,6 +39,8 @@ enum : uint32_t {
     WF_STREAM_HIDDEN = 1u << 1,      // !m_show or capture timed out (host sets it)
     WF_STREAM_TIMEOUT = 1u << 2,     // set with HIDDEN when the cause is the capture timeout: tick_meter treats the two differently
     WF_STREAM_PAUSED = 1u << 4,      // the host did not tick this source in this video frame (WF_HIP_PAUSED): the stream is left exactly as it is
+    WF_STREAM_STARVED = 1u << 5,     // the host found fewer samples than window + A/V-sync delay in the source's own buffer (WF_HIP_STARVED):
+                                     // the tick takes the kernel's underflow path (no channel processed, the end-of-tick dB pass still runs)
     WF_STREAM_WRAPPED = 1u << 3,     // wpos has wrapped past 2^32 since the last reset: "fewer samples than the A/V-sync delay yet" is over for good
 };
 
