@@ -45,12 +45,19 @@ def run_dropin_case(seed, family):
     want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
     assert len(got) == len(want)
     undo = f._undo_db(cfg) if family in ("pow2", "any") else None
-    for t, (g, w) in enumerate(zip(got, want)):
+    truth = scenarios.play(scenarios.OracleBackend(cfg, exact=True), sc) if family == "meter" else [None] * len(want)
+    for t, (g, w, x) in enumerate(zip(got, want, truth)):
         what = f"drop-in {family} case {seed} tick {t} ({cfg_dict}, sync {sync_ms} ms)"
-        assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
         if family == "meter":
-            err = np.abs(np.asarray(g["db"], np.float64) - np.asarray(w["db"], np.float64))
-            assert np.all(err <= 1e-5 * np.abs(w["db"]) + 1e-3), what + f": levels {g['db']} vs {w['db']}"
+            # the criterion of the batch fuzz (helpers.assert_levels_close): within tolerance of the reference, or no farther
+            # from the exactly summed level than the reference's own sequential float sum is
+            assert g["silent"] == w["silent"] or g["silent"] == x["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
+            from helpers import assert_levels_close
+            assert_levels_close(g["db"], w["db"], x["db"], what + " levels")
+            continue
+        assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
+        if False:
+            pass
         else:
             assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({} if family in ("pow2", "any") else {"lin_eps": None}))
 
