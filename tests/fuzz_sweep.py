@@ -62,6 +62,38 @@ def run_dropin_case(seed, family):
             assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({} if family in ("pow2", "any") else {"lin_eps": None}))
 
 
+def run_dropin_batched_case(seed, family):
+    """spectrum scripts through the plugin's batched mode (sources share a handle, rows read one frame late)"""
+    import numpy as np
+    from pathlib import Path
+    import scenarios
+    import test_golden as tg
+    from oracle import wfref
+    from helpers import assert_db_close
+    os.environ["WF_HIP_LIBRARY"] = str(Path(ROOT) / "waveform_amd" / "libwaveform_hip.so")
+    os.environ["WF_HIP_BATCHED"] = "1"
+    cfg_dict, steps, sync_ms = f.draw(seed, family)
+    cfg_dict = dict(cfg_dict)
+    cfg_dict.pop("vertices", None)
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
+    before = wfref.hip_fallback_ticks()
+    late = tg._OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
+    assert late.be.src.using_hip
+    scenarios.play(late, sc)
+    got = late.finish()
+    assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before, "fell back to the CPU class"
+    want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
+    assert len(got) == len(want), (len(got), len(want))
+    undo = f._undo_db(cfg)
+    for t, (g, w) in enumerate(zip(got, want)):
+        what = f"batched drop-in {family} case {seed} tick {t} ({cfg_dict}, sync {sync_ms} ms)"
+        assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
+        assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo)
+
+
+for _fam in ("pow2", "any"):
+    run["batched-" + _fam] = (lambda fam: (lambda s: run_dropin_batched_case(s, fam)))(_fam)
 for _fam in ("pow2", "any", "meter", "wave"):
     run["dropin-" + _fam] = (lambda fam: (lambda s: run_dropin_case(s, fam)))(_fam)
 
