@@ -26,21 +26,21 @@ def _play_pair(cfg_dict, steps, what, sync_ms=0):
 def test_restatement_matches_reference_pow2(seed):
     cfg_dict, steps, sync_ms = fuzz.draw(seed, "pow2")
     cfg, got, want = _play_pair(cfg_dict, steps, f"pow2 {seed}", sync_ms=sync_ms)
-    fuzz._compare(got, want, fuzz._undo_db(cfg), f"pow2 case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3)
+    fuzz._compare(got, want, fuzz._undo_db(cfg), f"pow2 case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
 
 
 @pytest.mark.parametrize("seed", range(0, len(fuzz.BLU_SEEDS), STEP))
 def test_restatement_matches_reference_any_size(seed):
     cfg_dict, steps, sync_ms = fuzz.draw(seed, "any")
     cfg, got, want = _play_pair(cfg_dict, steps, f"any {seed}", sync_ms=sync_ms)
-    fuzz._compare(got, want, fuzz._undo_db(cfg), f"any-size case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3)
+    fuzz._compare(got, want, fuzz._undo_db(cfg), f"any-size case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
 
 
 @pytest.mark.parametrize("seed", range(0, len(fuzz.HUGE_SEEDS), 6))
 def test_restatement_matches_reference_huge_size(seed):
     cfg_dict, steps, sync_ms = fuzz.draw(seed, "huge")
     cfg, got, want = _play_pair(cfg_dict, steps, f"huge {seed}", sync_ms=sync_ms)
-    fuzz._compare(got, want, fuzz._undo_db(cfg), f"huge-size case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3)
+    fuzz._compare(got, want, fuzz._undo_db(cfg), f"huge-size case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
 
 
 @pytest.mark.parametrize("seed", range(0, len(fuzz.METER_SEEDS), STEP))
