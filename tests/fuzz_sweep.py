@@ -16,9 +16,9 @@ run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_
        "wave": f.test_hip_waveform_matches_oracle_on_random_case}
 
 
-for _fam in ("pow2", "any"):
+for _fam in ("pow2", "any", "huge"):
     run["batched-" + _fam] = (lambda fam: (lambda s: f.run_dropin_batched_case(s, fam)))(_fam)
-for _fam in ("pow2", "any", "meter", "wave"):
+for _fam in ("pow2", "any", "huge", "meter", "wave"):
     run["dropin-" + _fam] = (lambda fam: (lambda s: f.run_dropin_case(s, fam)))(_fam)
 
 bad = skipped = 0

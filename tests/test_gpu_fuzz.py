@@ -426,7 +426,7 @@ def run_dropin_case(seed, family):
     assert hip.src.using_hip and wfref.hip_fallback_ticks() == before, "fell back to the CPU class"
     want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
     assert len(got) == len(want)
-    undo = _undo_db(cfg) if family in ("pow2", "any") else None
+    undo = _undo_db(cfg) if family in ("pow2", "any", "huge") else None
     truth = scenarios.play(scenarios.OracleBackend(cfg, exact=True), sc) if family == "meter" else [None] * len(want)
     for t, (g, w, x) in enumerate(zip(got, want, truth)):
         what = f"drop-in {family} case {seed} tick {t} ({cfg_dict}, sync {sync_ms} ms)"
@@ -441,7 +441,7 @@ def run_dropin_case(seed, family):
         if False:
             pass
         else:
-            assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({} if family in ("pow2", "any") else {"lin_eps": None}))
+            assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({} if family in ("pow2", "any", "huge") else {"lin_eps": None}))
 
 
 def run_dropin_batched_case(seed, family):
