@@ -318,3 +318,19 @@ def test_headers_are_plain_c_and_the_example_links(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=f"{ROOT / 'waveform_amd'}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     run = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert run.returncode == 1 and "-3" in run.stderr, (run.returncode, run.stderr)
+
+
+def test_no_fusable_rounding_intrinsics_in_device_code():
+    """HIP compiles device code with -ffp-contract=fast and treats __fmul_rn / __fadd_rn as plain operators: a product fed
+    into a sum is one fma, not two roundings (the level meter's smoothing was 7e-4 dB off on a tick where the sum cancels).
+    Arithmetic that must round like the reference's scalar code goes through mul_unfused / add_unfused / meter_ema
+    (#pragma clang fp contract(off)); the intrinsics may only appear where nothing can fuse with them."""
+    import re
+    root = Path(__file__).resolve().parent.parent / "waveform_amd" / "csrc"
+    bad = []
+    for f in sorted(root.glob("*.h*")):
+        for n, line in enumerate(f.read_text().splitlines(), 1):
+            code = line.split("//")[0]
+            if re.search(r"__f(add|sub)_rn\s*\([^;]*__fmul_rn|__fmul_rn\s*\([^;]*__f(add|sub)_rn", code):
+                bad.append(f"{f.name}:{n}: {line.strip()}")
+    assert not bad, "products feeding sums through rounding intrinsics (they fuse):\n" + "\n".join(bad)

@@ -286,15 +286,6 @@ WF_DEV void lds_st2(cf *lds, int idx, cf a) { WF_LDS_TRACE(idx, 8, 1); lds[idx] 
 WF_DEV f4 lds_ld4(const cf *lds, int idx) { WF_LDS_TRACE(idx, 16, 0); return *reinterpret_cast<const f4 *>(lds + idx); }
 WF_DEV void lds_st4(cf *lds, int idx, cf a, cf b) { WF_LDS_TRACE(idx, 16, 1); *reinterpret_cast<f4 *>(lds + idx) = f4{a.x, a.y, b.x, b.y}; }
 
-// (g * oldval) + (g2 * mag) with every operation rounded separately, as the reference's generic
-// translation unit is built (no -mfma, -ffp-contract=off: SURVEY.md Appendix C.9)
-#if defined(__HIPCC__)
-WF_DEV float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-WF_DEV float add_rn(float a, float b) { return __fadd_rn(a, b); }
-#else
-WF_DEV float mul_rn(float a, float b) { volatile float r = a * b; return r; }
-WF_DEV float add_rn(float a, float b) { volatile float r = a + b; return r; }
-#endif
 
 WF_DEV uint32_t f32_bits(float v)
 {
