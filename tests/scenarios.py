@@ -349,7 +349,8 @@ class RefBackend:
         # update() stamps m_capture_ts with the clock (src/source.cpp:1242): the source is created "now", so that a tick
         # before the first packet is not a capture timeout of the harness's making
         wfref.lib().wfref_set_clock_ns(1_000_000_000)
-        self.src = wfref.RefSource(ref_settings(cfg), isa=isa, channels=int(cfg.capture_channels))
+        self.sr = int(cfg.sample_rate)
+        self.src = wfref.RefSource(ref_settings(cfg), isa=isa, sample_rate=self.sr, channels=int(cfg.capture_channels))
         assert self.src.capture_channels == cfg.capture_channels
         self.capture_channels = int(cfg.capture_channels)
         self.disp = 2 if cfg.stereo else 1
@@ -366,7 +367,7 @@ class RefBackend:
             return
         import ctypes as C
         n = audio.shape[1]
-        self.now += n * 1_000_000_000 // 48000 + 1
+        self.now += n * 1_000_000_000 // self.sr + 1
         L = self.src.L
         L.wfref_set_clock_ns(self.now)
         a = np.ascontiguousarray(audio, np.float32)
@@ -374,7 +375,7 @@ class RefBackend:
         p0 = a[0].ctypes.data_as(fp)
         p1 = a[1].ctypes.data_as(fp) if a.shape[0] > 1 else fp()
         # end-of-audio timestamp == now  ->  get_audio_sync() == 0 at the following tick
-        length = n * 1_000_000_000 // 48000
+        length = n * 1_000_000_000 // self.sr
         L.wfref_push_audio(self.src.h, p0, p1, n, self.now - length, 1 if muted else 0)
 
     def tick(self, seconds):
@@ -447,7 +448,7 @@ class OracleBackend:
 
     def _sync(self):
         """the A/V-sync reserve as of `now`, handed to the restatement the way a host computes it"""
-        reserve = sync_reserve_frames(self.audio_ts, self.sync_ns, self.now)
+        reserve = sync_reserve_frames(self.audio_ts, self.sync_ns, self.now, int(self.cfg.sample_rate))
         if self.cfg.waveform:
             self.src.set_time(self.audio_ts, reserve)
         else:
@@ -462,7 +463,7 @@ class OracleBackend:
 
     def push(self, audio, muted):
         self._state()  # a packet ends a capture timeout
-        self.now += audio.shape[1] * 1_000_000_000 // 48000 + 1
+        self.now += audio.shape[1] * 1_000_000_000 // int(self.cfg.sample_rate) + 1
         self.audio_ts = self.now  # m_audio_ts = end of this packet
         self._sync()
         self.src.push_audio(audio, muted=muted)
@@ -540,7 +541,7 @@ class HipBackend:
         self.timed_out = True
 
     def push(self, audio, muted):
-        self.now += audio.shape[1] * 1_000_000_000 // 48000 + 1
+        self.now += audio.shape[1] * 1_000_000_000 // int(self.cfg.sample_rate) + 1
         self.audio_ts = self.now
         if getattr(self, "timed_out", False):
             self.timed_out = False
@@ -553,7 +554,7 @@ class HipBackend:
             self.batch.push_audio(np.broadcast_to(audio[None], (self.streams,) + audio.shape))
 
     def tick(self, seconds):
-        reserve = sync_reserve_frames(self.audio_ts, self.sync_ns, self.now)  # what WAVSourceHIP derives from get_audio_sync
+        reserve = sync_reserve_frames(self.audio_ts, self.sync_ns, self.now, int(self.cfg.sample_rate))  # what WAVSourceHIP derives from get_audio_sync
         self.batch.tick(seconds=seconds, input_rms=self.input_rms, delay_frames=reserve, audio_ts_ns=self.audio_ts)
 
     def set_hidden(self, hidden):

@@ -103,6 +103,11 @@ def draw(seed: int, family: str = "pow2"):
             cfg.update(step_width=int(r.choice([8, 3, 12])), step_gap=int(r.choice([4, 1, 0])), rounded_caps=0)
         elif display == 1 and cfg.get("rounded_caps") and r.random() < 0.5:
             cfg.update(radial=1)  # full-circle cap fans
+    # (drawn after everything else, end of round 2) OBS's other audio rate, and display ranges other than 30 Hz - 17.5 kHz
+    if r.random() < 0.25:
+        cfg.update(sample_rate=44100)
+    if display and r.random() < 0.3:
+        cfg.update(cutoff_low=int(r.choice([20, 60, 120, 500])), cutoff_high=int(r.choice([6000, 12000, 20000, 22000])))
     return cfg, steps, sync_ms
 
 
@@ -294,6 +299,8 @@ def draw_meter(seed: int):
         steps += [("timeout",), ("tick",), ("tick",), ("noise", 800), ("tick",), ("noise", 800), ("tick",)]
     elif cfg["capture_channels"] == 2:
         steps += [("noise_ch0_only", 800), ("tick",)] * 10
+    if r.random() < 0.25:  # (drawn last) OBS's other audio rate: the meter buffer is sample_rate * meter_ms long
+        cfg.update(sample_rate=44100)
     return cfg, steps
 
 
@@ -373,7 +380,10 @@ def draw_wave(seed: int):
         steps += [("timeout",), ("tick",), ("noise", 800), ("tick",), ("noise", 800), ("tick",)]
     else:
         steps += [("silence", 1024)] * 8 + [("tick",), ("noise", 800), ("tick",)]
-    return cfg, steps, int(r.choice([0, 0, 5, 20]))
+    sync = int(r.choice([0, 0, 5, 20]))
+    if r.random() < 0.25:  # (drawn last) OBS's other audio rate
+        cfg.update(sample_rate=44100)
+    return cfg, steps, sync
 
 
 @pytest.mark.gpu
