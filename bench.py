@@ -31,6 +31,11 @@ One JSON line on rank 0.  Extra objects:
                  shape (8192 streams, bars only), each with its own roofline object
   pcie_inclusive (N=1) the headline shape fed through the host boundary every step (page-locked
                  buffers, wf_hip_push_audio_async under the previous tick) -- never `value`
+  configs4       (every N) BASELINE configs[4] in the same process group: 8192 stereo streams per rank, bars-only
+                 ticks, ONE all-gather of the bar heights per tick (RCCL when N > 1) under the next tick, verified
+                 by per-rank checksums; its own ms_per_step / roofline / per-rank device times
+  c_abi_multi    (N=1) the same configs[4] shape through the C ABI's single-process multi-device group
+                 (wf_hip_multi_*: one host thread per device, dlopen()ed RCCL) over every device this process sees
 """
 from __future__ import annotations
 
@@ -125,12 +130,19 @@ def pmc_profile(shape: str):
     return best
 
 
-def roofline(batch, shape, kernel_ms, flags=0):
+def roofline(batch, shape, kernel_ms, flags=0, wall_ms=None):
+    """frac: algorithmic bytes per tick / device time per tick (HIP events on the library's stream, no profiler attached).
+    frac_wall: the same bytes / the barrier-bracketed wall-clock time per step (host launch overhead and the final
+    synchronisation included) -- the figure the driver's own clock reproduces; it sits a few percent under frac.
+    traffic is NOT measured in this run (PMC counters need rocprofv3 passes of their own): it is replayed from the committed
+    summary named in traffic_source."""
     algo = batch.algorithmic_bytes_per_tick(flags)
     achieved = algo / (kernel_ms * 1e-3) / 1e9
     prof = pmc_profile(shape) if shape else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+           "frac_wall": (algo / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if wall_ms else None,
            "traffic": (prof[1].get("hbm_bytes_per_tick") or prof[1]["hbm_bytes_per_launch"]) if prof else None,
+           "traffic_source": (f"profiles/{prof[0]} (committed rocprofv3 --pmc passes of this shape; not measured in this run)" if prof else None),
            "kernel": batch.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_tick": algo,
            "algorithmic_bytes_per_kernel_launch": algo // max(batch.launches_per_tick(), 1),
            # achieved = algorithmic_bytes_per_tick / kernel_ms.  A tick goes out as kernel_launches_per_tick concurrent
@@ -166,7 +178,7 @@ def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0, shape=
         spectra = streams * b.capture_channels
         return {"name": name, "streams": streams, "fft_size": int(cfg.fft_size), "spectra_per_tick": spectra, "steps": steps, "warmup": warm + 16,
                 "value": spectra * steps / wall, "unit": "spectra/s", "ms_per_step": wall * 1e3 / steps,
-                "roofline": roofline(b, shape, ms, flags)}
+                "roofline": roofline(b, shape, ms, flags, wall_ms=wall * 1e3 / steps)}
 
 
 def shape_list(wf):
@@ -226,6 +238,111 @@ def pcie_inclusive(wf, cfg, streams, device, steps=200, warm=400):
     return {"value": streams * 2 / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3, "host_GBps": packet.nbytes / dt / 1e9,
             "path": "page-locked host buffer -> wf_hip_push_audio_async (H2D under the previous tick) -> ring append -> tick",
             "bytes_per_step": int(packet.nbytes), "steps": steps}
+
+
+CFG4_STREAMS_PER_GPU = 8192  # BASELINE configs[4]: 65536 concurrent streams over 8 GPUs
+
+
+def configs4_region(wf, torch, dist, rank, world, local_rank, steps, lead_in_ms=40.0):
+    """BASELINE configs[4] per GPU, in the same process group as the headline: 8192 stereo streams per rank (65536 over 8
+    GPUs), FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars-only ticks, and after every tick ONE all-gather of
+    [streams/rank][2][26] bar heights (RCCL over xGMI when world > 1) issued on a side stream under the next tick
+    (waveform_amd.dist.BarsGather).  Timed like the headline: barrier + synchronize on both sides, max over ranks.
+    Verified: every rank's block of the final gathered result must carry the checksum that rank computed over its own bars
+    (exact integer sums of the float bit patterns, all-gathered alongside)."""
+    from waveform_amd.dist import shard_streams, BarsGather
+    cfg = wf.Config.defaults(fft_size=FFT_SIZE, stereo=1, slope=1.0, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["exponential"],
+                             gravity=0.65, bars=1, interp_mode=wf.INTERP["lanczos"])
+    flags = wf.TICK_NO_DECIBELS
+    streams, depth = CFG4_STREAMS_PER_GPU, 16
+    total = streams * world
+    shard = shard_streams(total, rank, world)
+    batch = wf.SpectrumBatch(cfg, streams, device=local_rank, ring_frames=FFT_SIZE + HOP * (depth + 1))
+    try:
+        batch.push_synth(SEED, 0, HOP * depth, stream_id0=shard.first)
+        batch.sync()
+        gather = BarsGather(batch, shard)
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def run(n):
+            batch.time_begin()
+            for i in range(n):
+                batch.tick(delay_frames=HOP * (depth - 1 - i % depth), flags=flags)
+                gather.launch()
+            ms = batch.time_end()
+            gather.wait()
+            return ms / n
+
+        probe = run(8)
+        warm = 8 + int(lead_in_ms / max(probe, 1e-4)) + 1
+        run(warm - 8)
+        barrier()
+        t0 = time.perf_counter()
+        kernel_ms = run(steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # verification: the gathered result of the last tick, block by block, against what each rank holds itself
+        full = gather.wait()                                             # [total][2][26] on this rank
+        own = torch.empty((streams, batch.display_channels, batch.num_bars), dtype=torch.float32, device="cuda")
+        batch.copy_bars_to_device(own.data_ptr())
+        own_sum = own.view(torch.int32).to(torch.int64).sum().reshape(1)
+        blocks = full.view(torch.int32).to(torch.int64).reshape(world, -1).sum(dim=1)   # equal shards: total = world * streams
+        times = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            sums = [torch.empty_like(own_sum) for _ in range(world)]
+            dist.all_gather(sums, own_sum)
+            sums = torch.cat(sums)
+            tl = [torch.empty_like(times) for _ in range(world)]
+            dist.all_gather(tl, times)
+            tl = torch.stack(tl).cpu().numpy()
+            ok = torch.tensor([int(bool(torch.equal(blocks, sums)))], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank checks the copy it received
+            verified = bool(ok.item())
+        else:
+            sums = own_sum
+            tl = times.cpu().numpy()[None]
+            verified = bool(torch.equal(blocks, sums))
+        finite = bool(torch.isfinite(full).all().item())
+        wall = float(tl[:, 0].max())
+        dev_ms = [float(x) for x in tl[:, 1]]
+        spectra = streams * batch.capture_channels
+        out = {
+            "name": f"BASELINE configs[4]: {total} concurrent stereo streams sharded over {world} GPU(s) ({streams} per GPU), FFT {FFT_SIZE}, "
+                    "EMA + slope, 26 Lanczos bars per channel, bars-only ticks; all-gather of the bar heights under the next tick",
+            "streams_total": total, "streams_per_gpu": streams, "spectra_per_tick": spectra * world, "steps": steps, "warmup": warm,
+            "value": spectra * world * steps / wall, "unit": "spectra/s", "ms_per_step": wall * 1e3 / steps,
+            "device_ms_per_tick": {"min": min(dev_ms), "max": max(dev_ms), "per_rank": dev_ms},
+            "collective": ("all_gather_into_tensor (RCCL, backend nccl)" if world > 1 else "none (world 1: the local device copy of the same path)"),
+            "gathered_bytes_per_rank_per_tick": int(streams * batch.display_channels * batch.num_bars * 4),
+            "gathered_bytes_total_per_tick": int(total * batch.display_channels * batch.num_bars * 4),
+            "verified": verified and finite,
+            "verification": "per-rank integer checksum of the float bit patterns of its own bars == checksum of its block in every rank's gathered copy; all values finite",
+            "roofline": roofline(batch, "cfg5shape_8192streams_barsonly", max(dev_ms), flags, wall_ms=wall * 1e3 / steps),
+        }
+    finally:
+        batch.close()
+    return out
+
+
+def c_abi_multi(timeout_s=240):
+    """BASELINE configs[4] through the C ABI's own multi-device group (wf_hip_multi_*: single process, one host thread per
+    device, ncclAllGather of a dlopen()ed librccl.so) over every device this process can see -- tools/multi_bench.py in a child
+    process (no torch there; a wedged RCCL costs the child, not the line)."""
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "multi_bench.py")], capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"rc {r.returncode}: {r.stderr[-400:]}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s} s"}
+    except Exception as e:
+        return {"error": str(e)}
 
 
 def self_launch(args):
@@ -364,6 +481,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_total": args.warmup + lead_in_ticks,  # every untimed tick in front of the timed region: lead-in + the W requested
             "lead_in": {"ms": args.lead_in_ms, "ticks": lead_in_ticks, "why": "untimed ticks until the device's clocks have settled (15-20 ms of load), in front of the warm-up steps"},
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
@@ -381,7 +499,8 @@ def main():
                 "parallelism": (f"streams sharded over {world} GPU(s); bar heights all-gathered after every step" if args.bars_allgather
                                 else f"streams sharded over {world} GPU(s), no data-path collective"),
             },
-            "roofline": roofline(batch, "cfg3_n4096" if (args.streams, args.fft, flags) == (STREAMS_PER_GPU, FFT_SIZE, 0) else None, kernel_ms, flags),
+            "roofline": roofline(batch, "cfg3_n4096" if (args.streams, args.fft, flags) == (STREAMS_PER_GPU, FFT_SIZE, 0) else None, kernel_ms, flags,
+                                 wall_ms=ms_per_step),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -391,6 +510,14 @@ def main():
                 print(f"bench.py: cpu_baseline failed: {e}", file=sys.stderr)
 
     batch.close()
+    # BASELINE configs[4] in the line the driver's one command prints: at every N, all ranks (the collective is the point)
+    cfg4 = None
+    if not args.no_other_configs and not args.bars_allgather and world > 1:
+        try:
+            cfg4 = configs4_region(wf, torch, dist, rank, world, local_rank, min(args.steps, 300))
+        except Exception as e:
+            cfg4 = {"error": str(e)}
+            print(f"bench.py: configs4 failed on rank {rank}: {e}", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_other_configs and not args.bars_allgather:
         try:  # before the other shapes allocate and free their tens of gigabytes (see pcie_inclusive)
             out["pcie_inclusive"] = pcie_inclusive(wf, cfg, args.streams, local_rank)
@@ -400,7 +527,17 @@ def main():
             out["other_configs"] = other_configs(wf, local_rank)
         except Exception as e:
             print(f"bench.py: other_configs failed: {e}", file=sys.stderr)
+    if world == 1 and not args.no_other_configs and not args.bars_allgather:
+        try:  # last at N=1: its 8192-stream rings are the largest allocation of the run (see pcie_inclusive)
+            cfg4 = configs4_region(wf, torch, None, 0, 1, local_rank, min(args.steps, 300))
+        except Exception as e:
+            cfg4 = {"error": str(e)}
+            print(f"bench.py: configs4 failed: {e}", file=sys.stderr)
     if rank == 0:
+        if cfg4 is not None:
+            out["configs4"] = cfg4
+        if world == 1 and not args.no_other_configs and not args.bars_allgather:
+            out["c_abi_multi"] = c_abi_multi()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -143,13 +143,15 @@ struct WFHipGroup {
     std::vector<uint32_t> sq_frames;      // [capacity] values staged for the batch being assembled
     float seconds = 1.0f / 60.0f;
     bool failed = false;
+    int device = 0;
 
-    bool create(const wf_config &c)
+    bool create(const wf_config &c, int dev)
     {
         auto &a = api();
         cfg = c;
+        device = dev;
         capacity = group_capacity();
-        if(a.create(&c, 0, capacity, 0, &h) != WF_HIP_OK) {
+        if(a.create(&c, dev, capacity, 0, &h) != WF_HIP_OK) {
             h = nullptr;
             return false;
         }
@@ -344,20 +346,40 @@ bool WAVSourceHIP::hip_configure()
                 g = p.get();
                 break;
             }
+        bool opened = false;
         if(g == nullptr) {
+            // batches spread over the devices the box has: a new group goes to the device that serves the fewest
+            // (sources share nothing; WF_HIP_DEVICE pins everything to one device)
+            const int ndev = std::max(api().device_count(), 1);
+            std::vector<int> load((size_t)ndev, 0);
+            for(auto &p : r.groups)
+                if(p->device >= 0 && p->device < ndev)
+                    ++load[(size_t)p->device];
+            int dev = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            if(const char *e = std::getenv("WF_HIP_DEVICE"))
+                dev = std::min(std::max(std::atoi(e), 0), ndev - 1);
             auto fresh = std::make_unique<WFHipGroup>();
-            if(!fresh->create(c)) {
+            if(!fresh->create(c, dev)) {
                 LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
                 return false;
             }
             g = fresh.get();
             r.groups.push_back(std::move(fresh));
+            opened = true;
         }
         uint32_t slot = 0;
         while(g->member[slot] != nullptr)
             ++slot;
-        if(api().reset(g->h, slot, 1) != WF_HIP_OK) // the stream starts as update() leaves a source
+        if(api().reset(g->h, slot, 1) != WF_HIP_OK) { // the stream starts as update() leaves a source
+            if(opened) // nobody joined: the group would stay in the registry with no member for ever
+                r.groups.erase(std::remove_if(r.groups.begin(), r.groups.end(), [g](const auto &p) { return p.get() == g; }), r.groups.end());
             return false;
+        }
+        // reset has put the device's view of the slot back to SHOWN with no per-stream RMS: the cache of what the device holds
+        // must say so, or a flush before this member's first submit would skip re-sending PAUSED and the device would tick the
+        // fresh stream on its zero ring (m_last_silent = 1 where the reference still has false)
+        g->state_dev[slot] = WF_HIP_SHOWN;
+        g->rms_dev[slot] = -1.0f;
         g->member[slot] = this;
         m_hip_joined = g->batch; // rows read back for earlier batches belong to whoever held the slot then
         g->submitted[slot] = 0;
@@ -369,7 +391,10 @@ bool WAVSourceHIP::hip_configure()
         m_hip_prev.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
         return true;
     }
-    const int rc = api().create(&c, 0, 1, 0, &m_hip);
+    int dev = 0;
+    if(const char *e = std::getenv("WF_HIP_DEVICE"))
+        dev = std::min(std::max(std::atoi(e), 0), std::max(api().device_count(), 1) - 1);
+    const int rc = api().create(&c, dev, 1, 0, &m_hip);
     if(rc != WF_HIP_OK) {
         // e.g. WF_HIP_ERR_UNSUPPORTED for a curve + filter combination whose staging does not fit the on-chip buffer
         LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
@@ -444,6 +469,15 @@ void WAVSourceHIP::tick_spectrum_batched(float seconds)
     if(!ok) {
         lock.unlock();
         LogWarn << "HIP batch unavailable; this source continues on the CPU path";
+        if(g->rms_feed && m_input_rms_buf && m_input_rms_size > 0) {
+            // the device kept the one-second window of squared peaks; the host's ring was never advanced.  Seed it so that its
+            // sum reproduces the last m_input_rms that came back (every entry = the mean square), instead of a window of zeros
+            // that would clamp the gain to max_gain for the next second
+            const float ms = m_input_rms * m_input_rms;
+            for(size_t i = 0; i < m_input_rms_size; ++i)
+                m_input_rms_buf[i] = ms;
+            m_input_rms_pos = 0;
+        }
         hip_release();
         g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_spectrum(seconds);

@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 7
+#define WF_HIP_ABI_VERSION 8
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -297,6 +297,63 @@ const char *wf_hip_kernel_name(const wf_hip *h);
 uint32_t wf_hip_launches_per_tick(const wf_hip *h);
 /* algorithmic HBM bytes one tick moves: per spectrum 4N in + state r/w + dB out */
 uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags);
+
+
+/* ---- one batch over several devices (BASELINE.json configs[4]) ----------------------------------
+ * The reference has nothing distributed: its sources share nothing (one WAVSource per OBS source, src/source.cpp:87-102), so
+ * a batch shards embarrassingly.  A wf_hip_multi is ONE batch of `streams_total` streams split into contiguous shards over
+ * n devices of one node -- shard i = streams [first_i, first_i + count_i), sizes differing by at most one, the first
+ * (streams_total % n) shards holding one more -- each shard a plain wf_hip handle on its device, driven by its own host
+ * thread (single process; the calls below fan out to the threads and return when every device has *enqueued* its part, as
+ * wf_hip_tick does).  There is no collective on the data path.  The one exchange is the result the north star asks for:
+ * wf_hip_multi_allgather_bars leaves the bar heights of ALL streams on EVERY device ([streams_total][display_channels]
+ * [num_bars] floats, global stream order) for a combined render -- by ncclAllGather of a dlopen()ed librccl.so over xGMI
+ * (transport "rccl"; shards of unequal size are padded to the largest and compacted on the device), or, where RCCL is
+ * absent or refuses the device list (e.g. the same device named twice, which this library allows), by direct peer copies
+ * (hipMemcpyPeerAsync, transport "peer"); WF_HIP_MULTI_TRANSPORT=rccl|peer forces one.  The gather is asynchronous and
+ * double-buffered: it is enqueued on a side stream of every device behind the ticks issued so far, the next tick runs
+ * meanwhile, and a result stays valid until the second-next gather.
+ * A wf_hip_multi is used by one thread at a time, like a handle.  Shard handles may be used directly (shard-local stream
+ * indices) between multi calls -- every wf_hip_* entry point works on them. */
+typedef struct wf_hip_multi wf_hip_multi;
+int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_devices, uint32_t streams_total, uint32_t ring_frames,
+                        wf_hip_multi **out);
+void wf_hip_multi_destroy(wf_hip_multi *m);
+/* text of the last error on this group (or of the last failed wf_hip_multi_create when m == NULL) */
+const char *wf_hip_multi_last_error(const wf_hip_multi *m);
+uint32_t wf_hip_multi_num_devices(const wf_hip_multi *m);
+uint32_t wf_hip_multi_num_streams(const wf_hip_multi *m);
+/* "rccl", "peer" or "local" (one shard: the gather is a device copy) */
+const char *wf_hip_multi_transport(const wf_hip_multi *m);
+/* shard i: its handle, its HIP device, its first global stream and its stream count (any out pointer may be NULL) */
+wf_hip *wf_hip_multi_shard(wf_hip_multi *m, uint32_t i, int *device, uint32_t *first, uint32_t *count);
+/* wf_hip_push_audio / wf_hip_push_synth / wf_hip_set_hidden / wf_hip_reset with global stream indices (a range may span
+ * shards; stream s of wf_hip_multi_push_synth receives wf_synth_noise(seed, stream_id0 + s, ..): the same audio whatever
+ * the number of devices) */
+int wf_hip_multi_push_audio(wf_hip_multi *m, uint32_t first, uint32_t count, const float *samples, uint32_t frames);
+int wf_hip_multi_push_synth(wf_hip_multi *m, uint32_t first, uint32_t count, uint64_t seed, uint32_t stream_id0, uint64_t index0, uint32_t frames);
+int wf_hip_multi_set_hidden(wf_hip_multi *m, uint32_t first, uint32_t count, const uint8_t *mask);
+int wf_hip_multi_reset(wf_hip_multi *m, uint32_t first, uint32_t count);
+/* WAVSource*::tick_spectrum for every stream of every shard (wf_hip_tick on each device, issued concurrently by the
+ * devices' host threads) */
+int wf_hip_multi_tick(wf_hip_multi *m, const wf_hip_tick_params *p);
+int wf_hip_multi_sync(wf_hip_multi *m); /* every device's streams, the gather streams included */
+/* results with global stream indices, as wf_hip_read_decibels / _bars / _last_silent */
+int wf_hip_multi_read_decibels(wf_hip_multi *m, uint32_t first, uint32_t count, float *out);
+int wf_hip_multi_read_bars(wf_hip_multi *m, uint32_t first, uint32_t count, float *out);
+int wf_hip_multi_read_last_silent(wf_hip_multi *m, uint32_t first, uint32_t count, uint8_t *out);
+/* the exchange (see above); needs cfg.bars or cfg.curve */
+int wf_hip_multi_allgather_bars(wf_hip_multi *m);
+/* device i's copy of the newest gathered result: a pointer on that device (valid until the second-next gather; ordered behind
+ * the gather on wf_hip_multi_gather_stream(m, i)), or copied to the host after waiting for it */
+const float *wf_hip_multi_gathered_device(wf_hip_multi *m, uint32_t i);
+void *wf_hip_multi_gather_stream(wf_hip_multi *m, uint32_t i); /* hipStream_t */
+int wf_hip_multi_read_gathered(wf_hip_multi *m, uint32_t i, float *out);
+/* measurement: `ticks` ticks back to back on every device as wf_hip_time_ticks does (each device's host thread runs its own
+ * loop), with an all-gather of the bars behind every tick when gather != 0; returns the largest per-device average device
+ * time per tick (ms) and, in per_device_ms[n_devices] when not NULL, each device's own */
+int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32_t ticks, uint32_t hop, int gather, float *avg_ms,
+                            float *per_device_ms);
 
 
 /* ---- test aid ------------------------------------------------------------------------------- */

@@ -247,7 +247,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name)
     L.wf_hip_abi_version.restype = C.c_int
-    assert L.wf_hip_abi_version() == 7
+    assert L.wf_hip_abi_version() == 8
 
 
 def test_no_device_fails_loudly():
@@ -270,6 +270,19 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
     ldd = subprocess.run(["ldd", str(ROOT / "waveform_amd" / "libwaveform_hip.so")], capture_output=True, text=True).stdout
     assert "wforacle" not in ldd and "wfref" not in ldd and "fftw" not in ldd
+    assert "rccl" not in ldd, "librccl.so is dlopen()ed by the multi-device group, never linked"
+
+
+def test_multi_device_group_fails_loudly_without_a_device():
+    import waveform_amd as wf
+    if wf.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(wf.WfHipError) as e:
+        wf.MultiBatch(wf.Config.defaults(bars=1), 8, [0, 1])
+    assert e.value.code == -3  # WF_HIP_ERR_NO_DEVICE
+    with pytest.raises(wf.WfHipError) as e:
+        wf.MultiBatch(wf.Config.defaults(bars=1), 8, [])
+    assert e.value.code == -1  # WF_HIP_ERR_INVALID before any device is looked at
 
 
 # ---- configuration checks that run before any device is touched ---------------------------------------------------------

@@ -174,20 +174,33 @@ def test_batch_position_independence():
 
 
 def test_cfg4_full_batch_bars():
-    """configs[3]: FFT 16384, gravity (TV-EMA) smoothing, Lanczos bars, 1024 streams; oracle spot checks"""
+    """configs[3]: FFT 16384, gravity (TV-EMA) smoothing, 26 Lanczos bars, 1024 stereo streams.  16 warm-up ticks (the TV-EMA at
+    g = 0.876 needs them to settle) + 8 checked ticks; the first and last 32 streams of the batch -- rows and bars -- against
+    the oracle on every checked tick; two identical batches must agree bit for bit."""
     cfg = wf.Config.defaults(fft_size=16384, stereo=1, tsmoothing=wf.TSMOOTH["tvexponential"], bars=1, interp_mode=wf.INTERP["lanczos"])
-    streams, ticks, hop = 1024, 3, 800
-    with wf.SpectrumBatch(cfg, streams, ring_frames=16384 + hop * (ticks + 1)) as b:
-        b.push_synth(SEED, 0, hop * ticks)
-        for t in range(ticks):
-            b.tick(delay_frames=hop * (ticks - 1 - t))
-        db, bars = b.decibels(), b.bars()
-    ids = [0, 1, 2, 3, streams - 2, streams - 1]
-    want, wantb = _oracle_rows(cfg, ids, ticks, hop, bars=True)
-    assert_db_close(db[ids], want, "cfg4 decibels vs oracle")
-    err = np.abs(bars[ids].astype(np.float64) - wantb)
-    assert np.all(err <= 1e-5 * np.abs(wantb) + 2e-3), f"cfg4 bars: max err {err.max():.3e} px"
-    assert bars.shape == (streams, 2, 26)
+    streams, warm, checked, hop = 1024, 16, 8, 800
+    ticks = warm + checked
+    ids = list(range(32)) + list(range(streams - 32, streams))
+    res = []
+    for rep in range(2):
+        rows, bars = [], []
+        with wf.SpectrumBatch(cfg, streams, ring_frames=16384 + hop * (ticks + 1)) as b:
+            b.push_synth(SEED, 0, hop * ticks)
+            for t in range(ticks):
+                b.tick(delay_frames=hop * (ticks - 1 - t))
+                if t >= warm:
+                    rows.append(np.concatenate([b.decibels(0, 32), b.decibels(streams - 32, 32)]))
+                    bars.append(np.concatenate([b.bars(0, 32), b.bars(streams - 32, 32)]))
+            full_rows, full_bars = b.decibels(), b.bars()
+        res.append((np.stack(rows, axis=1), np.stack(bars, axis=1), full_rows, full_bars))
+    for a, c, what in zip(res[0], res[1], ("checked rows", "checked bars", "rows of the whole batch", "bars of the whole batch")):
+        assert np.array_equal(a, c), f"cfg4: {what} differ between two identical runs"
+    assert res[0][3].shape == (streams, 2, 26) and np.all(np.isfinite(res[0][3])) and np.all(np.isfinite(res[0][2]))
+    want, wantb = _oracle_ticks(cfg, ids, ticks, hop, checked, bars=True)
+    for k in range(checked):
+        assert_db_close(res[0][0][:, k], want[:, k], f"cfg4 full batch rows vs oracle, tick {warm + k} (first/last 32 streams)")
+        err = np.abs(res[0][1][:, k].astype(np.float64) - wantb[:, k])
+        assert np.all(err <= 1e-5 * np.abs(wantb[:, k]) + 2e-3), f"cfg4 bars, tick {warm + k}: max err {err.max():.3e} px"
 
 
 def test_bars_only_mode_matches_full_mode():

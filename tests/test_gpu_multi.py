@@ -1,0 +1,204 @@
+"""The single-process multi-device group of the C ABI (wf_hip_multi_*, include/wf_hip.h): shards of
+one batch on their own host threads, results identical to one plain handle, and the all-gather of the bar heights over every
+transport this box can run -- "local" (one shard), "peer" (several shards; the same device may be named more than once, so a
+1-GPU box exercises the shard arithmetic, the threads, the cross-stream ordering and the double buffering), "rccl" (ncclAllGather
+of the dlopen()ed librccl.so: one rank on a 1-GPU box, every visible device where there are more)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import waveform_amd as wf
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+SEED = synth.DEFAULT_SEED
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _cfg(**kw):
+    base = dict(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    base.update(kw)
+    return wf.Config.defaults(**base)
+
+
+def _script(b, streams, ticks, hop, cc=2, gather=None):
+    """the same calls on a SpectrumBatch or a MultiBatch: pushes that span shards, a hidden range that spans shards"""
+    out = []
+    for t in range(ticks):
+        a = synth.block(SEED, 0, streams, cc, t * hop, hop)
+        if t == 3:
+            a[1:streams - 1] = 0.0
+        b.push_audio(a[:2], first=0)
+        b.push_audio(a[2:], first=2)
+        if t == 4:
+            m = np.zeros(streams, np.uint8)
+            m[1:streams - 2] = 1
+            b.set_hidden(m)
+        if t == 6:
+            b.set_hidden(np.zeros(streams - 1, np.uint8), first=1)
+        b.tick()
+        if gather is not None:
+            gather(t)
+        out.append((b.decibels(), b.bars(), b.last_silent()))
+    return out
+
+
+def test_one_device_group_is_bit_identical_to_a_plain_handle():
+    cfg = _cfg()
+    streams, ticks, hop = 9, 8, 800
+    with wf.SpectrumBatch(cfg, streams) as plain:
+        want = _script(plain, streams, ticks, hop)
+    with wf.MultiBatch(cfg, streams, [0]) as m:
+        assert m.n_devices == 1 and m.transport == "local" and m.shards[0][2:] == (0, streams)
+        gathered = []
+
+        def g(t):
+            m.allgather_bars()
+            gathered.append(m.gathered(0))
+        got = _script(m, streams, ticks, hop, gather=g)
+    for t, (w, g_) in enumerate(zip(want, got)):
+        for a, c, what in zip(w, g_, ("rows", "bars", "m_last_silent")):
+            assert np.array_equal(a, c), f"tick {t}: {what} of the one-device group differ from the plain handle"
+        assert np.array_equal(gathered[t], w[1]), f"tick {t}: gathered bars differ"
+
+
+@pytest.mark.parametrize("devices,streams", [([0, 0], 8), ([0, 0, 0], 7), ([0] * 5, 13)])
+def test_shards_equal_one_handle_and_every_device_holds_every_bar(devices, streams):
+    """several shards (on this box's one device, or cycling over all it has): rows, bars and silence flags equal the plain
+    handle's; after the gather EVERY shard's device holds the bars of ALL streams in global order -- equal and ragged shards"""
+    have = wf.device_count()
+    devices = [(i % have) for i in range(len(devices))]
+    cfg = _cfg()
+    ticks, hop = 8, 800
+    with wf.SpectrumBatch(cfg, streams) as plain:
+        want = _script(plain, streams, ticks, hop)
+    with wf.MultiBatch(cfg, streams, devices) as m:
+        assert m.n_devices == len(devices)
+        assert m.transport in ("peer", "rccl")
+        assert sum(s[3] for s in m.shards) == streams and m.shards[0][2] == 0
+        for a, c in zip(m.shards, m.shards[1:]):
+            assert c[2] == a[2] + a[3] and 0 <= a[3] - c[3] <= 1
+        gathered = []
+
+        def g(t):
+            m.allgather_bars()
+            gathered.append([m.gathered(i) for i in range(m.n_devices)])
+        got = _script(m, streams, ticks, hop, gather=g)
+    for t, (w, g_) in enumerate(zip(want, got)):
+        for a, c, what in zip(w, g_, ("rows", "bars", "m_last_silent")):
+            assert np.array_equal(a, c), f"tick {t}: {what} of the sharded batch differ from the plain handle"
+        for i, full in enumerate(gathered[t]):
+            assert np.array_equal(full, w[1]), f"tick {t}: device index {i} holds different gathered bars"
+
+
+def test_gather_runs_under_the_next_tick_and_is_double_buffered():
+    """allgather_bars() after tick t does not wait; tick t+1 is issued right behind it; the result read afterwards is tick t's
+    (not t+1's), on every device, over many back-to-back rounds (a send buffer is reused every second gather)"""
+    cfg = _cfg(fft_size=4096)
+    streams, ticks, hop = 384, 24, 800
+    devices = [i % wf.device_count() for i in range(3)]
+    with wf.SpectrumBatch(cfg, streams, ring_frames=4096 + hop * (ticks + 2)) as plain:
+        plain.push_synth(SEED, 0, hop * (ticks + 1))
+        per_tick = []
+        for t in range(ticks + 1):
+            plain.tick(delay_frames=hop * (ticks - t))
+            per_tick.append(plain.bars())
+    with wf.MultiBatch(cfg, streams, devices, ring_frames=4096 + hop * (ticks + 2)) as m:
+        m.push_synth(SEED, 0, hop * (ticks + 1))
+        m.tick(delay_frames=hop * ticks)
+        for t in range(ticks):
+            m.allgather_bars()                               # bars of tick t ...
+            m.tick(delay_frames=hop * (ticks - 1 - t))       # ... while tick t+1 runs
+            for i in range(m.n_devices):
+                assert np.array_equal(m.gathered(i), per_tick[t]), f"gather {t} on device index {i}"
+        assert np.array_equal(m.bars(), per_tick[ticks])
+        # the timed loop: the same ticks + gathers driven by the devices' own threads
+        ms, per = m.time_ticks(50, hop, hop * ticks, gather=True)
+        assert ms > 0 and len(per) == m.n_devices and max(per) == pytest.approx(ms)
+        last = [m.gathered(i) for i in range(m.n_devices)]
+        assert all(np.array_equal(x, last[0]) for x in last) and np.array_equal(last[0], m.bars())
+
+
+def test_rccl_transport_in_a_fresh_process():
+    """ncclAllGather through the dlopen()ed librccl.so: one rank per visible device (one on a 1-GPU box), equal and ragged
+    shards; in a child process so that a broken RCCL cannot take the test session with it"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import waveform_amd as wf
+from tools import synth
+n = wf.device_count()
+for streams in (8 * n, 8 * n + (1 if n > 1 else 0)):
+    cfg = wf.Config.defaults(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    with wf.MultiBatch(cfg, streams, list(range(n))) as m:
+        assert m.transport == "rccl", m.transport
+        for t in range(6):
+            m.push_audio(synth.block(synth.DEFAULT_SEED, 0, streams, 2, t * 800, 800))
+            m.tick()
+            m.allgather_bars()
+        want = m.bars()
+        for i in range(n):
+            assert np.array_equal(m.gathered(i), want), (streams, i)
+        ms, per = m.time_ticks(20, 0, 0, gather=True)
+        assert np.array_equal(m.gathered(n - 1), m.bars())
+    with wf.SpectrumBatch(cfg, streams) as p:
+        for t in range(6):
+            p.push_audio(synth.block(synth.DEFAULT_SEED, 0, streams, 2, t * 800, 800))
+            p.tick()
+        assert np.array_equal(p.bars(), want)
+print("rccl ok", n)
+''' % str(ROOT)
+    env = dict(os.environ, WF_HIP_MULTI_TRANSPORT="rccl", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_every_visible_device_takes_a_shard():
+    """n = wf_hip_device_count(): the default transport (RCCL when the devices are distinct and there is more than one) and the
+    forced peer copies must agree with one plain handle -- runs with n = 1 on a 1-GPU box, n = 8 on a full node"""
+    n = wf.device_count()
+    cfg = _cfg(fft_size=1024)
+    streams, ticks, hop = 4 * n + 3, 5, 800
+    with wf.SpectrumBatch(cfg, streams) as plain:
+        for t in range(ticks):
+            plain.push_audio(synth.block(SEED, 0, streams, 2, t * hop, hop))
+            plain.tick()
+        want = (plain.decibels(), plain.bars())
+    for force in (None, "peer"):
+        old = os.environ.pop("WF_HIP_MULTI_TRANSPORT", None)
+        if force:
+            os.environ["WF_HIP_MULTI_TRANSPORT"] = force
+        try:
+            with wf.MultiBatch(cfg, streams, list(range(n))) as m:
+                for t in range(ticks):
+                    m.push_audio(synth.block(SEED, 0, streams, 2, t * hop, hop))
+                    m.tick()
+                m.allgather_bars()
+                assert np.array_equal(m.decibels(), want[0]) and np.array_equal(m.bars(), want[1])
+                for i in range(n):
+                    assert np.array_equal(m.gathered(i), want[1]), (force, m.transport, i)
+        finally:
+            os.environ.pop("WF_HIP_MULTI_TRANSPORT", None)
+            if old is not None:
+                os.environ["WF_HIP_MULTI_TRANSPORT"] = old
+
+
+def test_multi_errors_are_reported():
+    cfg = _cfg()
+    with pytest.raises(wf.WfHipError) as e:
+        wf.MultiBatch(cfg, 4, [wf.device_count()])     # no such device
+    assert e.value.code == -1
+    with pytest.raises(wf.WfHipError):
+        wf.MultiBatch(cfg, 1, [0, 0])                   # fewer streams than shards
+    with wf.MultiBatch(wf.Config.defaults(fft_size=1024), 4, [0, 0]) as m:   # no bars: nothing to gather
+        with pytest.raises(wf.WfHipError):
+            m.allgather_bars()
+        with pytest.raises(wf.WfHipError):
+            m.decibels(first=3, count=2)
+        m.push_synth(SEED, 0, 800)
+        m.tick()
+        assert m.decibels().shape == (4, 2, 512)

@@ -5,6 +5,6 @@ package is a thin ctypes binding used by the tests and by bench.py.  There is no
 implementation in here: if the library (or a gfx950 device) is missing, calls fail loudly.
 """
 from .binding import (  # noqa: F401
-    Config, SpectrumBatch, PinnedBuffer, WfHipError, lib, library_path, device_count, db_min,
+    Config, SpectrumBatch, MultiBatch, PinnedBuffer, WfHipError, lib, library_path, device_count, db_min,
     WINDOW, TSMOOTH, INTERP, TICK_NO_DECIBELS,
 )

@@ -145,6 +145,35 @@ def lib():
     L.wf_hip_launches_per_tick.argtypes = [vp]
     L.wf_hip_algorithmic_bytes_per_tick.restype = u64
     L.wf_hip_algorithmic_bytes_per_tick.argtypes = [vp, u32]
+    # one batch over several devices (wf_hip_multi_*)
+    L.wf_hip_multi_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), u32, u32, u32, C.POINTER(vp)]
+    L.wf_hip_multi_destroy.argtypes = [vp]
+    L.wf_hip_multi_last_error.restype = C.c_char_p
+    L.wf_hip_multi_last_error.argtypes = [vp]
+    L.wf_hip_multi_transport.restype = C.c_char_p
+    L.wf_hip_multi_transport.argtypes = [vp]
+    for n in ("num_devices", "num_streams"):
+        f = getattr(L, "wf_hip_multi_" + n)
+        f.restype = u32
+        f.argtypes = [vp]
+    L.wf_hip_multi_shard.restype = vp
+    L.wf_hip_multi_shard.argtypes = [vp, u32, C.POINTER(C.c_int), C.POINTER(u32), C.POINTER(u32)]
+    L.wf_hip_multi_push_audio.argtypes = [vp, u32, u32, fp, u32]
+    L.wf_hip_multi_push_synth.argtypes = [vp, u32, u32, u64, u32, u64, u32]
+    L.wf_hip_multi_set_hidden.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
+    L.wf_hip_multi_reset.argtypes = [vp, u32, u32]
+    L.wf_hip_multi_tick.argtypes = [vp, C.POINTER(TickParams)]
+    L.wf_hip_multi_sync.argtypes = [vp]
+    L.wf_hip_multi_read_decibels.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_multi_read_bars.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_multi_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
+    L.wf_hip_multi_allgather_bars.argtypes = [vp]
+    L.wf_hip_multi_gathered_device.restype = vp
+    L.wf_hip_multi_gathered_device.argtypes = [vp, u32]
+    L.wf_hip_multi_gather_stream.restype = vp
+    L.wf_hip_multi_gather_stream.argtypes = [vp, u32]
+    L.wf_hip_multi_read_gathered.argtypes = [vp, u32, fp]
+    L.wf_hip_multi_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, C.c_int, fp, fp]
     _LIB = L
     return L
 
@@ -423,3 +452,117 @@ class PinnedBuffer:
             self.close()
         except Exception:
             pass
+
+
+class MultiBatch:
+    """One batch of `streams` sources sharded contiguously over several devices of one node, single process, one host thread
+    per device (wf_hip_multi_*); all stream indices are global.  allgather_bars() leaves every stream's bars on every device."""
+
+    def __init__(self, cfg: Config, streams: int, devices, ring_frames: int = 0):
+        self.L = lib()
+        self.cfg = cfg
+        devs = (C.c_int * len(devices))(*devices)
+        m = C.c_void_p()
+        rc = self.L.wf_hip_multi_create(C.byref(cfg), devs, len(devices), streams, ring_frames, C.byref(m))
+        if rc != 0:
+            raise WfHipError(rc, self.L.wf_hip_multi_last_error(None).decode())
+        self.m = m
+        self.streams = streams
+        self.n_devices = int(self.L.wf_hip_multi_num_devices(m))
+        self.transport = self.L.wf_hip_multi_transport(m).decode()
+        self.shards = []
+        for i in range(self.n_devices):
+            dev, first, count = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+            h = self.L.wf_hip_multi_shard(m, i, C.byref(dev), C.byref(first), C.byref(count))
+            self.shards.append((C.c_void_p(h), int(dev.value), int(first.value), int(count.value)))
+        h0 = self.shards[0][0]
+        self.fft_size = self.L.wf_hip_fft_size(h0)
+        self.bins = self.fft_size // 2
+        self.capture_channels = self.L.wf_hip_capture_channels(h0)
+        self.output_channels = self.L.wf_hip_output_channels(h0)
+        self.display_channels = self.L.wf_hip_display_channels(h0)
+        self.num_bars = self.L.wf_hip_num_bars(h0)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise WfHipError(rc, self.L.wf_hip_multi_last_error(self.m).decode())
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.L.wf_hip_multi_destroy(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def push_audio(self, samples: np.ndarray, first: int = 0):
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        assert s.ndim == 3 and s.shape[1] == self.capture_channels, s.shape
+        self._ck(self.L.wf_hip_multi_push_audio(self.m, first, s.shape[0], s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[2]))
+
+    def push_synth(self, seed: int, index0: int, frames: int, first: int = 0, count: int | None = None, stream_id0: int = 0):
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_multi_push_synth(self.m, first, count, seed, stream_id0, index0, frames))
+
+    def set_hidden(self, mask, first: int = 0):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._ck(self.L.wf_hip_multi_set_hidden(self.m, first, len(m), m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def reset(self, first: int = 0, count: int | None = None):
+        count = self.streams - first if count is None else count
+        self._ck(self.L.wf_hip_multi_reset(self.m, first, count))
+
+    def tick(self, seconds: float = 1.0 / 60.0, delay_frames: int = 0, input_rms: float = 0.0, flags: int = 0):
+        p = TickParams(seconds, delay_frames, input_rms, flags, 0)
+        self._ck(self.L.wf_hip_multi_tick(self.m, C.byref(p)))
+
+    def sync(self):
+        self._ck(self.L.wf_hip_multi_sync(self.m))
+
+    def decibels(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty((count, self.output_channels, self.bins), np.float32)
+        self._ck(self.L.wf_hip_multi_read_decibels(self.m, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def bars(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty((count, self.display_channels, self.num_bars), np.float32)
+        self._ck(self.L.wf_hip_multi_read_bars(self.m, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def last_silent(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.streams - first if count is None else count
+        out = np.empty(count, np.uint8)
+        self._ck(self.L.wf_hip_multi_read_last_silent(self.m, first, count, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out.astype(bool)
+
+    def allgather_bars(self):
+        """asynchronous: enqueued behind the ticks so far on every device's gather stream"""
+        self._ck(self.L.wf_hip_multi_allgather_bars(self.m))
+
+    def gathered(self, device_index: int) -> np.ndarray:
+        """device `device_index`'s copy of the newest gathered result: [streams, display_channels, num_bars]"""
+        out = np.empty((self.streams, self.display_channels, self.num_bars), np.float32)
+        self._ck(self.L.wf_hip_multi_read_gathered(self.m, device_index, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def time_ticks(self, ticks: int, hop: int, first_delay: int, gather: bool = False, seconds: float = 1.0 / 60.0, flags: int = 0):
+        """(largest per-device average device ms per tick, [per-device ms])"""
+        p = TickParams(seconds, first_delay, 0.0, flags, 0)
+        ms = C.c_float(0.0)
+        per = (C.c_float * self.n_devices)()
+        self._ck(self.L.wf_hip_multi_time_ticks(self.m, C.byref(p), ticks, hop, 1 if gather else 0, C.byref(ms), per))
+        return float(ms.value), [float(x) for x in per]
+
+    def algorithmic_bytes_per_tick(self, flags: int = 0) -> int:
+        return sum(int(self.L.wf_hip_algorithmic_bytes_per_tick(h, flags)) for h, _, _, _ in self.shards)

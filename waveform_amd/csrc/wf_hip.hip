@@ -159,6 +159,7 @@ struct wf_hip {
     // launch description, fixed at create
     void (*launch)(wf_hip *, const wf::TickArgs &, bool aligned) = nullptr;
     hipStream_t launch_stream = nullptr; // where `launch` enqueues (the lane's stream, set by wf_hip_tick)
+    int launch_rc = 0;                   // status of the last `launch` that can fail before its kernels (the big path's memset)
 };
 
 namespace {
@@ -415,10 +416,12 @@ template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
 
 void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool)
 {
+    // (a failure leaves its text in last_error and its HIP error sticky: wf_hip_tick's hipGetLastError() behind the launches
+    // reports it; launch_rc carries the code for the errors that are not HIP's)
     switch(h->big_rows) {
-    case 2: (void)launch_tick_big_l<2>(h, a); break;
-    case 4: (void)launch_tick_big_l<4>(h, a); break;
-    default: (void)launch_tick_big_l<8>(h, a); break;
+    case 2: h->launch_rc = launch_tick_big_l<2>(h, a); break;
+    case 4: h->launch_rc = launch_tick_big_l<4>(h, a); break;
+    default: h->launch_rc = launch_tick_big_l<8>(h, a); break;
     }
 }
 
@@ -652,6 +655,19 @@ int join_lanes(wf_hip *h)
         h->lanes_pending = false;
     }
     h->main_dirty = true;
+    return WF_HIP_OK;
+}
+
+// wf_hip_read_rows_async copies straight out of m_decibels on the readback stream: whatever is about to overwrite rows (a
+// tick of a spectrum or waveform batch, wf_hip_reset) first makes `stream` wait -- on the device -- for copies in flight
+int wait_rows_in_flight(wf_hip *h)
+{
+    for(int i = 0; i < 2; ++i)
+        if(h->rows_in_flight[i]) {
+            WF_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_read[i], 0));
+            h->rows_in_flight[i] = false;
+            h->main_dirty = true;
+        }
     return WF_HIP_OK;
 }
 
@@ -1260,6 +1276,7 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
     if(rc)
         return rc;
     WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_TRY_RC(wait_rows_in_flight(h)); // the fills below overwrite rows a readback may still be copying
     const size_t spec0 = (size_t)first * h->cap_ch, nspec = (size_t)count * h->cap_ch;
     if(h->wave) {
         // update() in waveform mode (src/source.cpp:1142, :1172-1182, :1243-1248): rows = DB_MIN, rings = width zeros, m_waveform_ts = 0
@@ -1567,6 +1584,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_TICK_NO_DECIBELS on a configuration without bars or curve: the tick would produce nothing");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     if(h->wave) {
+        WF_TRY_RC(wait_rows_in_flight(h)); // the waveform rows are read back the same way
         launch_input_rms(h, p);
         wf::WaveArgs w{};
         w.ring = h->d_ring;
@@ -1632,12 +1650,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `st` dies here
         h->main_dirty = true;
     }
-    for(int i = 0; i < 2; ++i)
-        if(h->rows_in_flight[i]) { // wf_hip_read_rows_async reads m_decibels itself: this tick's stores wait for it (on the device)
-            WF_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_read[i], 0));
-            h->rows_in_flight[i] = false;
-            h->main_dirty = true;
-        }
+    WF_TRY_RC(wait_rows_in_flight(h)); // this tick's row stores wait for a readback still in flight
     if(h->d_rms_ring)
         WF_TRY_RC(join_lanes(h)); // (never pending: the RMS producer keeps the batch on one lane)
     launch_input_rms(h, p);
@@ -1655,7 +1668,10 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         a.stream_base = lo;
         a.stream_count = hi - lo;
         h->launch_stream = l == 0 ? h->stream : h->lane_stream[l];
+        h->launch_rc = WF_HIP_OK;
         h->launch(h, a, aligned);
+        if(h->launch_rc != WF_HIP_OK)
+            return h->launch_rc;
         if(h->d_verts && hi > lo) { // the vertex fill of this slice, behind its bars
             wf::VertexArgs v{};
             v.bars = h->d_bars;

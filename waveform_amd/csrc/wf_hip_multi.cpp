@@ -1,0 +1,742 @@
+// wf_hip_multi.cpp -- one batch over the devices of a node (include/wf_hip.h, "one batch over several devices").
+//
+// Shape: the reference's sources share nothing, so the streams shard contiguously; every shard is a
+// plain wf_hip handle on its own device and is driven by its own host thread, which keeps that device current for its whole
+// life (hipSetDevice is per thread) -- the API thread only hands jobs to the workers and collects their status, so the n
+// devices' launches are issued concurrently instead of one after the other.  No collective on the data path.  The one
+// exchange is the all-gather of the bar heights: ncclAllGather (RCCL over xGMI; librccl.so is dlopen()ed, the library does
+// not link it) on a side stream per device, or direct peer copies where RCCL is unavailable.  Host code only: gfx950 kernels
+// live in wf_hip.hip.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h> // types and prototypes only: every RCCL entry point is resolved with dlsym
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <barrier>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "wf_hip.h"
+
+namespace {
+
+thread_local std::string g_multi_create_error;
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *path = std::getenv("WF_HIP_RCCL_LIBRARY");
+        for(const char *name : {path, "librccl.so.1", "librccl.so"}) {
+            if(name == nullptr)
+                continue;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if(r.lib)
+                break;
+        }
+        if(r.lib == nullptr) {
+            const char *e = dlerror();
+            r.why = std::string("librccl.so not loadable: ") + (e ? e : "?");
+            return;
+        }
+#define WF_NCCL_SYM(name)                                                          \
+    r.name = reinterpret_cast<decltype(r.name)>(dlsym(r.lib, "nccl" #name));      \
+    if(r.name == nullptr) {                                                        \
+        r.why = "librccl.so lacks nccl" #name;                                     \
+        return;                                                                    \
+    }
+        WF_NCCL_SYM(CommInitAll)
+        WF_NCCL_SYM(CommDestroy)
+        WF_NCCL_SYM(AllGather)
+        WF_NCCL_SYM(GetErrorString)
+#undef WF_NCCL_SYM
+        r.ok = true;
+    });
+    return r;
+}
+
+// A device's host thread: runs the jobs it is handed, one at a time, with its device current.
+struct Worker {
+    std::thread th;
+    std::mutex mtx;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = true, quit = false;
+    int rc = 0;
+
+    void start(int device)
+    {
+        th = std::thread([this, device] {
+            (void)hipSetDevice(device);
+            std::unique_lock lock(mtx);
+            for(;;) {
+                cv.wait(lock, [this] { return has_job || quit; });
+                if(quit)
+                    return;
+                auto fn = std::move(job);
+                has_job = false;
+                lock.unlock();
+                const int r = fn();
+                lock.lock();
+                rc = r;
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<int()> fn)
+    {
+        std::lock_guard lock(mtx);
+        job = std::move(fn);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock lock(mtx);
+        cv.wait(lock, [this] { return done; });
+        return rc;
+    }
+    void stop()
+    {
+        {
+            std::lock_guard lock(mtx);
+            quit = true;
+            cv.notify_all();
+        }
+        if(th.joinable())
+            th.join();
+    }
+};
+
+enum class Transport { LOCAL, RCCL, PEER };
+
+struct Shard {
+    int device = 0;
+    wf_hip *h = nullptr;
+    uint32_t first = 0, count = 0;
+    hipStream_t gstream = nullptr;       // the gather's side stream on this device
+    float *send[2] = {nullptr, nullptr}; // this shard's bars, [largest][disp_ch][num_bars] (padded for ragged RCCL gathers)
+    float *recv_pad[2] = {nullptr, nullptr}; // RCCL with shards of unequal size: [n][largest][...] before compaction
+    float *gathered[2] = {nullptr, nullptr}; // [streams_total][disp_ch][num_bars]
+    hipEvent_t ev_sent[2] = {nullptr, nullptr}; // peer transport: this shard's copies into every device's buffer have run
+    hipEvent_t ev_done[2] = {nullptr, nullptr}; // the gathered result of the slot is complete on this device
+    bool slot_used[2] = {false, false};
+    ncclComm_t comm = nullptr;
+    Worker worker;
+    std::string err;
+};
+
+} // namespace
+
+struct wf_hip_multi {
+    wf_config cfg{};
+    uint32_t n = 0, total = 0, largest = 0;
+    bool ragged = false;
+    size_t per = 0; // floats per stream in the bars buffer: display_channels * num_bars
+    std::vector<std::unique_ptr<Shard>> shard;
+    Transport transport = Transport::LOCAL;
+    std::string transport_note;
+    uint32_t gathers = 0; // slot of the next gather = gathers & 1
+    std::string last_error;
+};
+
+namespace {
+
+int mfail(wf_hip_multi *m, int code, const char *fmt, ...)
+{
+    char buf[640];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if(m)
+        m->last_error = buf;
+    else
+        g_multi_create_error = buf;
+    return code;
+}
+
+// fn(i) on every device's own thread, concurrently; the first failure wins (its text is kept)
+int run_all(wf_hip_multi *m, const std::function<int(uint32_t)> &fn)
+{
+    for(uint32_t i = 0; i < m->n; ++i)
+        m->shard[i]->worker.post([&fn, i] { return fn(i); });
+    int rc = WF_HIP_OK;
+    for(uint32_t i = 0; i < m->n; ++i) {
+        const int r = m->shard[i]->worker.wait();
+        if(r != WF_HIP_OK && rc == WF_HIP_OK) {
+            rc = r;
+            Shard &s = *m->shard[i];
+            m->last_error = "device " + std::to_string(s.device) + " (shard " + std::to_string(i) + "): " +
+                            (s.err.empty() ? std::string(wf_hip_last_error(s.h)) : s.err);
+        }
+        m->shard[i]->err.clear();
+    }
+    return rc;
+}
+
+int hip_rc(Shard &s, hipError_t e, const char *what)
+{
+    if(e == hipSuccess)
+        return WF_HIP_OK;
+    s.err = std::string(what) + " failed: " + hipGetErrorString(e);
+    return WF_HIP_ERR_RUNTIME;
+}
+#define WF_MHIP(s, expr)                          \
+    do {                                          \
+        const int rc_ = hip_rc((s), (expr), #expr); \
+        if(rc_)                                   \
+            return rc_;                           \
+    } while(0)
+
+// the part of the global range [first, first+count) that falls into shard s: local first / count, offset into the range
+bool overlap(const Shard &s, uint32_t first, uint32_t count, uint32_t *lfirst, uint32_t *lcount, uint32_t *off)
+{
+    const uint64_t lo = std::max<uint64_t>(first, s.first), hi = std::min<uint64_t>((uint64_t)first + count, (uint64_t)s.first + s.count);
+    if(lo >= hi)
+        return false;
+    *lfirst = (uint32_t)(lo - s.first);
+    *lcount = (uint32_t)(hi - lo);
+    *off = (uint32_t)(lo - first);
+    return true;
+}
+
+int check_range(wf_hip_multi *m, uint32_t first, uint32_t count)
+{
+    if(m == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if(count == 0 || first >= m->total || count > m->total - first)
+        return mfail(m, WF_HIP_ERR_INVALID, "stream range [%u, %u+%u) outside 0..%u", first, first, count, m->total);
+    return WF_HIP_OK;
+}
+
+// The gather of shard i, first half: its bars into the slot's send buffer behind the ticks issued so far, then -- on the
+// device's gather stream, which waits only for that copy -- the collective (RCCL) or this shard's copies into every
+// device's result (peer).  Nothing here waits on the host.
+int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
+{
+    Shard &s = *m->shard[i];
+    hipStream_t hs = static_cast<hipStream_t>(wf_hip_stream(s.h));
+    if(s.slot_used[k]) // the gather that read this send buffer two gathers ago must have run before the buffer is rewritten
+        WF_MHIP(s, hipStreamWaitEvent(hs, s.ev_done[k], 0));
+    float *dst = (m->transport == Transport::LOCAL) ? s.gathered[k] : s.send[k];
+    int rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, dst, s.gstream);
+    if(rc)
+        return rc;
+    const size_t per = m->per;
+    switch(m->transport) {
+    case Transport::LOCAL: break;
+    case Transport::RCCL: {
+        float *recv = m->ragged ? s.recv_pad[k] : s.gathered[k];
+        const ncclResult_t r = rccl().AllGather(s.send[k], recv, (size_t)m->largest * per, ncclFloat, s.comm, s.gstream);
+        if(r != ncclSuccess) {
+            s.err = std::string("ncclAllGather failed: ") + rccl().GetErrorString(r);
+            return WF_HIP_ERR_RUNTIME;
+        }
+        if(m->ragged) // rank r's block of `largest` streams holds count_r valid ones: compact into global stream order
+            for(uint32_t r2 = 0; r2 < m->n; ++r2) {
+                const Shard &o = *m->shard[r2];
+                WF_MHIP(s, hipMemcpyAsync(s.gathered[k] + (size_t)o.first * per, recv + (size_t)r2 * m->largest * per,
+                                          (size_t)o.count * per * sizeof(float), hipMemcpyDeviceToDevice, s.gstream));
+            }
+        break;
+    }
+    case Transport::PEER:
+        for(uint32_t j = 0; j < m->n; ++j) {
+            Shard &o = *m->shard[j];
+            WF_MHIP(s, hipMemcpyPeerAsync(o.gathered[k] + (size_t)s.first * per, o.device, s.send[k], s.device,
+                                          (size_t)s.count * per * sizeof(float), s.gstream));
+        }
+        WF_MHIP(s, hipEventRecord(s.ev_sent[k], s.gstream));
+        break;
+    }
+    return WF_HIP_OK;
+}
+
+// Second half: the result on device i is complete when every shard's copies into it have run (peer transport: events of the
+// other devices' gather streams, all recorded by now -- the caller put a host barrier between the halves).
+int gather_complete(wf_hip_multi *m, uint32_t i, uint32_t k)
+{
+    Shard &s = *m->shard[i];
+    if(m->transport == Transport::PEER)
+        for(uint32_t j = 0; j < m->n; ++j)
+            if(j != i)
+                WF_MHIP(s, hipStreamWaitEvent(s.gstream, m->shard[j]->ev_sent[k], 0));
+    WF_MHIP(s, hipEventRecord(s.ev_done[k], s.gstream));
+    s.slot_used[k] = true;
+    return WF_HIP_OK;
+}
+
+int gather_check(wf_hip_multi *m)
+{
+    if(m == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if(m->per == 0)
+        return mfail(m, WF_HIP_ERR_INVALID, "the configuration has no bars or curve (cfg.bars == 0 and cfg.curve == 0): nothing to gather");
+    return WF_HIP_OK;
+}
+
+void destroy_impl(wf_hip_multi *m)
+{
+    if(m == nullptr)
+        return;
+    // the workers' last job: drain and free what lives on their device
+    for(auto &sp : m->shard) {
+        Shard &s = *sp;
+        if(!s.worker.th.joinable())
+            continue;
+        s.worker.post([&s] {
+            if(s.gstream)
+                (void)hipStreamSynchronize(s.gstream);
+            if(s.h)
+                (void)wf_hip_sync(s.h);
+            return 0;
+        });
+        (void)s.worker.wait();
+    }
+    for(auto &sp : m->shard) // communicators go first, all of them, from one thread (ncclCommDestroy may synchronise with peers)
+        if(sp->comm) {
+            (void)hipSetDevice(sp->device);
+            (void)rccl().CommDestroy(sp->comm);
+            sp->comm = nullptr;
+        }
+    for(auto &sp : m->shard) {
+        Shard &s = *sp;
+        if(s.worker.th.joinable()) {
+            s.worker.post([&s] {
+                for(int k = 0; k < 2; ++k) {
+                    if(s.send[k]) (void)hipFree(s.send[k]);
+                    if(s.recv_pad[k]) (void)hipFree(s.recv_pad[k]);
+                    if(s.gathered[k]) (void)hipFree(s.gathered[k]);
+                    if(s.ev_sent[k]) (void)hipEventDestroy(s.ev_sent[k]);
+                    if(s.ev_done[k]) (void)hipEventDestroy(s.ev_done[k]);
+                }
+                if(s.gstream)
+                    (void)hipStreamDestroy(s.gstream);
+                if(s.h)
+                    wf_hip_destroy(s.h);
+                return 0;
+            });
+            (void)s.worker.wait();
+            s.worker.stop();
+        }
+    }
+    delete m;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *wf_hip_multi_last_error(const wf_hip_multi *m) { return m ? m->last_error.c_str() : g_multi_create_error.c_str(); }
+uint32_t wf_hip_multi_num_devices(const wf_hip_multi *m) { return m ? m->n : 0; }
+uint32_t wf_hip_multi_num_streams(const wf_hip_multi *m) { return m ? m->total : 0; }
+
+const char *wf_hip_multi_transport(const wf_hip_multi *m)
+{
+    if(m == nullptr)
+        return "";
+    return m->transport == Transport::RCCL ? "rccl" : m->transport == Transport::PEER ? "peer" : "local";
+}
+
+int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_devices, uint32_t streams_total, uint32_t ring_frames,
+                        wf_hip_multi **out)
+{
+    if(out == nullptr)
+        return WF_HIP_ERR_INVALID;
+    *out = nullptr;
+    if(cfg == nullptr || devices == nullptr || n_devices == 0 || n_devices > 64)
+        return mfail(nullptr, WF_HIP_ERR_INVALID, "cfg / devices NULL, or n_devices %u outside 1..64", n_devices);
+    if(streams_total < n_devices)
+        return mfail(nullptr, WF_HIP_ERR_INVALID, "%u streams cannot be spread over %u devices (every shard needs one)", streams_total, n_devices);
+    const int have = wf_hip_device_count();
+    if(have <= 0)
+        return mfail(nullptr, WF_HIP_ERR_NO_DEVICE, "no usable HIP device");
+    bool duplicates = false;
+    for(uint32_t i = 0; i < n_devices; ++i) {
+        if(devices[i] < 0 || devices[i] >= have)
+            return mfail(nullptr, WF_HIP_ERR_INVALID, "devices[%u] = %d, the box has %d", i, devices[i], have);
+        for(uint32_t j = 0; j < i; ++j)
+            duplicates = duplicates || devices[j] == devices[i];
+    }
+    auto *m = new(std::nothrow) wf_hip_multi;
+    if(m == nullptr)
+        return mfail(nullptr, WF_HIP_ERR_NOMEM, "out of host memory");
+    m->cfg = *cfg;
+    m->n = n_devices;
+    m->total = streams_total;
+    const uint32_t base = streams_total / n_devices, extra = streams_total % n_devices;
+    m->largest = base + (extra ? 1u : 0u);
+    m->ragged = extra != 0;
+    for(uint32_t i = 0; i < n_devices; ++i) {
+        auto s = std::make_unique<Shard>();
+        s->device = devices[i];
+        s->count = base + (i < extra ? 1u : 0u);
+        s->first = i * base + std::min(i, extra);
+        s->worker.start(s->device);
+        m->shard.push_back(std::move(s));
+    }
+    // the shards' handles, every device building its own concurrently
+    int rc = run_all(m, [m, cfg, ring_frames](uint32_t i) {
+        Shard &s = *m->shard[i];
+        const int r = wf_hip_create(cfg, s.device, s.count, ring_frames, &s.h);
+        if(r != WF_HIP_OK)
+            s.err = wf_hip_last_error(nullptr);
+        return r;
+    });
+    if(rc) {
+        g_multi_create_error = m->last_error;
+        destroy_impl(m);
+        return rc;
+    }
+    m->per = (size_t)wf_hip_display_channels(m->shard[0]->h) * wf_hip_num_bars(m->shard[0]->h);
+    // transport of the gather
+    const char *force = std::getenv("WF_HIP_MULTI_TRANSPORT");
+    const bool want_rccl = force ? std::strcmp(force, "rccl") == 0 : (n_devices > 1 && !duplicates);
+    const bool want_peer = force ? std::strcmp(force, "peer") == 0 : false;
+    m->transport = n_devices == 1 ? Transport::LOCAL : Transport::PEER;
+    if(force && !want_rccl && !want_peer && std::strcmp(force, "local") != 0) {
+        destroy_impl(m);
+        return mfail(nullptr, WF_HIP_ERR_INVALID, "WF_HIP_MULTI_TRANSPORT=%s: expected rccl or peer", force);
+    }
+    if(want_peer)
+        m->transport = Transport::PEER;
+    if(m->per != 0 && want_rccl) {
+        Rccl &r = rccl();
+        if(!r.ok)
+            m->transport_note = r.why;
+        else {
+            std::vector<ncclComm_t> comms(n_devices, nullptr);
+            const ncclResult_t e = r.CommInitAll(comms.data(), (int)n_devices, devices);
+            if(e == ncclSuccess) {
+                for(uint32_t i = 0; i < n_devices; ++i)
+                    m->shard[i]->comm = comms[i];
+                m->transport = Transport::RCCL;
+            } else
+                m->transport_note = std::string("ncclCommInitAll failed: ") + r.GetErrorString(e);
+        }
+        if(m->transport != Transport::RCCL && force) { // asked for by name: do not quietly use something else
+            const std::string why = m->transport_note;
+            destroy_impl(m);
+            return mfail(nullptr, WF_HIP_ERR_RUNTIME, "WF_HIP_MULTI_TRANSPORT=rccl: %s", why.c_str());
+        }
+    }
+    if(m->per != 0) {
+        rc = run_all(m, [m](uint32_t i) {
+            Shard &s = *m->shard[i];
+            WF_MHIP(s, hipStreamCreateWithFlags(&s.gstream, hipStreamNonBlocking));
+            const size_t per = m->per;
+            for(int k = 0; k < 2; ++k) {
+                WF_MHIP(s, hipEventCreateWithFlags(&s.ev_sent[k], hipEventDisableTiming));
+                WF_MHIP(s, hipEventCreateWithFlags(&s.ev_done[k], hipEventDisableTiming));
+                WF_MHIP(s, hipMalloc((void **)&s.gathered[k], (size_t)m->total * per * sizeof(float)));
+                if(m->transport != Transport::LOCAL) {
+                    WF_MHIP(s, hipMalloc((void **)&s.send[k], (size_t)m->largest * per * sizeof(float)));
+                    WF_MHIP(s, hipMemset(s.send[k], 0, (size_t)m->largest * per * sizeof(float)));
+                }
+                if(m->transport == Transport::RCCL && m->ragged)
+                    WF_MHIP(s, hipMalloc((void **)&s.recv_pad[k], (size_t)m->n * m->largest * per * sizeof(float)));
+            }
+            if(m->transport == Transport::PEER) // direct xGMI stores where the link allows; hipMemcpyPeerAsync stages otherwise
+                for(uint32_t j = 0; j < m->n; ++j) {
+                    const int other = m->shard[j]->device;
+                    int can = 0;
+                    if(other != s.device && hipDeviceCanAccessPeer(&can, s.device, other) == hipSuccess && can) {
+                        const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+                        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                            (void)hipGetLastError(); // not fatal: the copies still work, staged
+                        else
+                            (void)hipGetLastError();
+                    }
+                }
+            return (int)WF_HIP_OK;
+        });
+        if(rc) {
+            g_multi_create_error = m->last_error;
+            destroy_impl(m);
+            return rc;
+        }
+    }
+    *out = m;
+    return WF_HIP_OK;
+}
+
+void wf_hip_multi_destroy(wf_hip_multi *m) { destroy_impl(m); }
+
+wf_hip *wf_hip_multi_shard(wf_hip_multi *m, uint32_t i, int *device, uint32_t *first, uint32_t *count)
+{
+    if(m == nullptr || i >= m->n)
+        return nullptr;
+    const Shard &s = *m->shard[i];
+    if(device) *device = s.device;
+    if(first) *first = s.first;
+    if(count) *count = s.count;
+    return s.h;
+}
+
+int wf_hip_multi_push_audio(wf_hip_multi *m, uint32_t first, uint32_t count, const float *samples, uint32_t frames)
+{
+    int rc = check_range(m, first, count);
+    if(rc)
+        return rc;
+    if(samples == nullptr)
+        return mfail(m, WF_HIP_ERR_INVALID, "samples is NULL");
+    const size_t per_stream = (size_t)wf_hip_capture_channels(m->shard[0]->h) * frames;
+    return run_all(m, [=](uint32_t i) {
+        Shard &s = *m->shard[i];
+        uint32_t lf, lc, off;
+        if(!overlap(s, first, count, &lf, &lc, &off))
+            return (int)WF_HIP_OK;
+        return wf_hip_push_audio(s.h, lf, lc, samples + (size_t)off * per_stream, frames);
+    });
+}
+
+int wf_hip_multi_push_synth(wf_hip_multi *m, uint32_t first, uint32_t count, uint64_t seed, uint32_t stream_id0, uint64_t index0, uint32_t frames)
+{
+    int rc = check_range(m, first, count);
+    if(rc)
+        return rc;
+    return run_all(m, [=](uint32_t i) {
+        Shard &s = *m->shard[i];
+        uint32_t lf, lc, off;
+        if(!overlap(s, first, count, &lf, &lc, &off))
+            return (int)WF_HIP_OK;
+        return wf_hip_push_synth(s.h, lf, lc, seed, stream_id0 + off, index0, frames);
+    });
+}
+
+int wf_hip_multi_set_hidden(wf_hip_multi *m, uint32_t first, uint32_t count, const uint8_t *mask)
+{
+    int rc = check_range(m, first, count);
+    if(rc)
+        return rc;
+    if(mask == nullptr)
+        return mfail(m, WF_HIP_ERR_INVALID, "mask is NULL");
+    return run_all(m, [=](uint32_t i) {
+        Shard &s = *m->shard[i];
+        uint32_t lf, lc, off;
+        if(!overlap(s, first, count, &lf, &lc, &off))
+            return (int)WF_HIP_OK;
+        return wf_hip_set_hidden(s.h, lf, lc, mask + off);
+    });
+}
+
+int wf_hip_multi_reset(wf_hip_multi *m, uint32_t first, uint32_t count)
+{
+    int rc = check_range(m, first, count);
+    if(rc)
+        return rc;
+    return run_all(m, [=](uint32_t i) {
+        Shard &s = *m->shard[i];
+        uint32_t lf, lc, off;
+        if(!overlap(s, first, count, &lf, &lc, &off))
+            return (int)WF_HIP_OK;
+        return wf_hip_reset(s.h, lf, lc);
+    });
+}
+
+int wf_hip_multi_tick(wf_hip_multi *m, const wf_hip_tick_params *p)
+{
+    if(m == nullptr || p == nullptr)
+        return WF_HIP_ERR_INVALID;
+    const wf_hip_tick_params q = *p;
+    return run_all(m, [m, q](uint32_t i) { return wf_hip_tick(m->shard[i]->h, &q); });
+}
+
+int wf_hip_multi_sync(wf_hip_multi *m)
+{
+    if(m == nullptr)
+        return WF_HIP_ERR_INVALID;
+    return run_all(m, [m](uint32_t i) {
+        Shard &s = *m->shard[i];
+        const int rc = wf_hip_sync(s.h);
+        if(rc)
+            return rc;
+        if(s.gstream)
+            WF_MHIP(s, hipStreamSynchronize(s.gstream));
+        return (int)WF_HIP_OK;
+    });
+}
+
+int wf_hip_multi_read_decibels(wf_hip_multi *m, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(m, first, count);
+    if(rc)
+        return rc;
+    if(out == nullptr)
+        return mfail(m, WF_HIP_ERR_INVALID, "out is NULL");
+    const size_t per_stream = (size_t)wf_hip_output_channels(m->shard[0]->h) * (wf_hip_fft_size(m->shard[0]->h) / 2);
+    return run_all(m, [=](uint32_t i) {
+        Shard &s = *m->shard[i];
+        uint32_t lf, lc, off;
+        if(!overlap(s, first, count, &lf, &lc, &off))
+            return (int)WF_HIP_OK;
+        return wf_hip_read_decibels(s.h, lf, lc, out + (size_t)off * per_stream);
+    });
+}
+
+int wf_hip_multi_read_bars(wf_hip_multi *m, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(m, first, count);
+    if(rc)
+        return rc;
+    if(out == nullptr)
+        return mfail(m, WF_HIP_ERR_INVALID, "out is NULL");
+    const size_t per = m->per;
+    return run_all(m, [=](uint32_t i) {
+        Shard &s = *m->shard[i];
+        uint32_t lf, lc, off;
+        if(!overlap(s, first, count, &lf, &lc, &off))
+            return (int)WF_HIP_OK;
+        return wf_hip_read_bars(s.h, lf, lc, out + (size_t)off * per);
+    });
+}
+
+int wf_hip_multi_read_last_silent(wf_hip_multi *m, uint32_t first, uint32_t count, uint8_t *out)
+{
+    int rc = check_range(m, first, count);
+    if(rc)
+        return rc;
+    if(out == nullptr)
+        return mfail(m, WF_HIP_ERR_INVALID, "out is NULL");
+    return run_all(m, [=](uint32_t i) {
+        Shard &s = *m->shard[i];
+        uint32_t lf, lc, off;
+        if(!overlap(s, first, count, &lf, &lc, &off))
+            return (int)WF_HIP_OK;
+        return wf_hip_read_last_silent(s.h, lf, lc, out + off);
+    });
+}
+
+int wf_hip_multi_allgather_bars(wf_hip_multi *m)
+{
+    int rc = gather_check(m);
+    if(rc)
+        return rc;
+    const uint32_t k = m->gathers & 1u;
+    rc = run_all(m, [m, k](uint32_t i) { return gather_issue(m, i, k); });
+    if(rc)
+        return rc;
+    // (run_all returning is the host barrier between the halves: every ev_sent of this slot has been recorded)
+    rc = run_all(m, [m, k](uint32_t i) { return gather_complete(m, i, k); });
+    if(rc)
+        return rc;
+    ++m->gathers;
+    return WF_HIP_OK;
+}
+
+const float *wf_hip_multi_gathered_device(wf_hip_multi *m, uint32_t i)
+{
+    if(m == nullptr || i >= m->n || m->gathers == 0)
+        return nullptr;
+    return m->shard[i]->gathered[(m->gathers - 1) & 1u];
+}
+
+void *wf_hip_multi_gather_stream(wf_hip_multi *m, uint32_t i) { return (m && i < m->n) ? m->shard[i]->gstream : nullptr; }
+
+int wf_hip_multi_read_gathered(wf_hip_multi *m, uint32_t i, float *out)
+{
+    int rc = gather_check(m);
+    if(rc)
+        return rc;
+    if(i >= m->n || out == nullptr)
+        return mfail(m, WF_HIP_ERR_INVALID, "device index %u outside 0..%u, or out is NULL", i, m->n);
+    if(m->gathers == 0)
+        return mfail(m, WF_HIP_ERR_INVALID, "no gather has been issued yet");
+    const uint32_t k = (m->gathers - 1) & 1u;
+    Shard &s = *m->shard[i];
+    s.worker.post([m, &s, k, out] {
+        WF_MHIP(s, hipMemcpyAsync(out, s.gathered[k], (size_t)m->total * m->per * sizeof(float), hipMemcpyDeviceToHost, s.gstream));
+        WF_MHIP(s, hipStreamSynchronize(s.gstream));
+        return (int)WF_HIP_OK;
+    });
+    rc = s.worker.wait();
+    if(rc) {
+        m->last_error = "device " + std::to_string(s.device) + ": " + s.err;
+        s.err.clear();
+    }
+    return rc;
+}
+
+int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32_t ticks, uint32_t hop, int gather, float *avg_ms,
+                            float *per_device_ms)
+{
+    if(m == nullptr || p == nullptr || ticks == 0 || avg_ms == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if(gather) {
+        const int rc = gather_check(m);
+        if(rc)
+            return rc;
+    }
+    const uint32_t period = hop ? p->delay_frames / hop + 1 : ticks;
+    const wf_hip_tick_params p0 = *p;
+    std::vector<float> ms(m->n, 0.0f);
+    std::vector<int> status(m->n, WF_HIP_OK);
+    // the halves of a peer gather need every device's events recorded in between: a barrier among the workers.  A worker that
+    // fails keeps arriving at the barriers (doing nothing) so that the others do not wait for it for ever.
+    std::barrier sync((std::ptrdiff_t)m->n);
+    const uint32_t k0 = m->gathers;
+    int rc = run_all(m, [&, m](uint32_t i) {
+        Shard &s = *m->shard[i];
+        int &st = status[i];
+        st = wf_hip_time_begin(s.h);
+        wf_hip_tick_params q = p0;
+        for(uint32_t t = 0; t < ticks; ++t) {
+            q.delay_frames = p0.delay_frames - (t % period) * hop;
+            if(st == WF_HIP_OK)
+                st = wf_hip_tick(s.h, &q);
+            if(gather) {
+                const uint32_t k = (k0 + t) & 1u;
+                if(st == WF_HIP_OK)
+                    st = gather_issue(m, i, k);
+                if(m->transport == Transport::PEER)
+                    sync.arrive_and_wait();
+                if(st == WF_HIP_OK)
+                    st = gather_complete(m, i, k);
+            }
+        }
+        if(st == WF_HIP_OK)
+            st = wf_hip_time_end(s.h, &ms[i]);
+        if(st == WF_HIP_OK && s.gstream && hipStreamSynchronize(s.gstream) != hipSuccess)
+            st = WF_HIP_ERR_RUNTIME;
+        return st;
+    });
+    if(gather)
+        m->gathers = k0 + ticks;
+    if(rc)
+        return rc;
+    float worst = 0.0f;
+    for(uint32_t i = 0; i < m->n; ++i) {
+        ms[i] /= (float)ticks;
+        worst = std::max(worst, ms[i]);
+        if(per_device_ms)
+            per_device_ms[i] = ms[i];
+    }
+    *avg_ms = worst;
+    return WF_HIP_OK;
+}
+
+} // extern "C"
