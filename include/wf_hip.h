@@ -160,7 +160,9 @@ typedef struct wf_hip_tick_params {
 /* bars/curve-only batch mode: skip the m_decibels store (cfg.bars or cfg.curve must be set).  The silence state machine
  * (src/source_generic.cpp:74-95) keeps working: the kernel leaves a one-word verdict per row ("a value > floor - 10") for the
  * next tick's test instead.  After the first such tick, wf_hip_read_decibels returns rows only as fresh as the last tick
- * without the flag that rewrote them.  Mono mixdown of two captured channels stores its (single) row regardless. */
+ * without the flag that rewrote them.  Mono mixdown of two captured channels stores its (single) row regardless, and so do
+ * the batches whose outputs are derived from the stored rows by a kernel of their own (fft sizes beyond a CU's LDS; displays
+ * whose Gaussian-filter staging does not fit the tick kernel's on-chip buffer): there the flag is accepted and changes nothing. */
 #define WF_HIP_TICK_NO_DECIBELS 1u
 
 /* Asynchronous: enqueues the fused kernel for all streams on the handle's stream. */
@@ -240,10 +242,15 @@ int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pin
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);
-/* the same without waiting: the copy is enqueued behind the ticks issued so far and `consumer_stream` (a hipStream_t of
- * the caller, e.g. the stream its RCCL all-gather runs on) is made to wait for it; the handle's own stream goes on with the
- * next tick meanwhile.  The caller keeps `d_out` untouched by anything else until its consumer has run. */
+/* the same without waiting: the copy is enqueued behind the ticks issued so far (every lane of a large batch copies the bars
+ * of its own slice: the tick's concurrent launches are not joined) and `consumer_stream` (a hipStream_t of the caller, e.g.
+ * the stream its RCCL all-gather runs on) is made to wait for it; the handle goes on with the next tick meanwhile.  The
+ * caller keeps `d_out` untouched by anything else until its consumer has run (wf_hip_wait_event orders a reuse). */
 int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, void *d_out, void *consumer_stream);
+/* everything the handle issues after this call (on all of its internal streams) waits, on the device, for `event` (a
+ * hipEvent_t of the caller, recorded before the call) -- e.g. "the gather that read the buffer the next
+ * wf_hip_copy_bars_device_async overwrites has run".  Does not wait on the host. */
+int wf_hip_wait_event(wf_hip *h, void *event);
 /* meter batches: m_meter_val (dBFS) of streams [first, first+count): [count][capture_channels] */
 int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* m_tsmooth_buf: [count][capture_channels][fft_size/2] */

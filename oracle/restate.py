@@ -237,6 +237,8 @@ class OracleSource:
         return _arr(p, n), r.value, t.value
 
     def bars(self, ch=None):
+        if self.num_bars == 0:  # a display narrower than one bar: m_num_bars == 0, nothing is drawn
+            return None
         if ch is not None:
             return _arr(self.L.wfo_bars(self.h, ch), self.num_bars)
         return np.stack([_arr(self.L.wfo_bars(self.h, c), self.num_bars) for c in range(self.display_channels)])

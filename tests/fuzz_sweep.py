@@ -12,7 +12,7 @@ import test_gpu_fuzz as f  # noqa: E402
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pow2", "any", "meter", "wave"]
 run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_spectrum_case(s, "any"),
-       "huge": lambda s: f.run_spectrum_case(s, "huge"), "meter": f.run_meter_case,
+       "huge": lambda s: f.run_spectrum_case(s, "huge"), "wide": lambda s: f.run_spectrum_case(s, "wide"), "meter": f.run_meter_case,
        "wave": f.test_hip_waveform_matches_oracle_on_random_case}
 
 
@@ -35,4 +35,7 @@ for k in kinds:
             print("FAIL", k, s, m[-260:] if len(m) > 260 else m, flush=True)
             if os.environ.get("WF_FUZZ_VERBOSE"):
                 print("     ", m[:700], flush=True)
-print("done", lo, hi, kinds, "failures", bad, "skips", skipped)
+print("display checks", f.ARM["display_checks"], "second arm", f.ARM["display_arm"], f.ARM["arm_cases"][:20])
+for u in f.ARM["unsupported"]:
+    print("UNSUPPORTED", u[-400:])
+print("done", lo, hi, kinds, "failures", bad, "skips", skipped, "unsupported", len(f.ARM["unsupported"]))

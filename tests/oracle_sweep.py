@@ -14,7 +14,7 @@ def one(job):
     kind, seed = job
     import test_oracle_vs_ref as t
     fn = {"pow2": t.test_restatement_matches_reference_pow2, "any": t.test_restatement_matches_reference_any_size,
-          "huge": t.test_restatement_matches_reference_huge_size, "meter": t.test_restatement_matches_reference_meter,
+          "huge": t.test_restatement_matches_reference_huge_size, "wide": t.test_restatement_matches_reference_wide_ranges, "meter": t.test_restatement_matches_reference_meter,
           "wave": t.test_restatement_matches_reference_waveform}[kind]
     try:
         fn(seed)

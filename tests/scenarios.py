@@ -305,6 +305,21 @@ def sync_reserve_frames(audio_ts_ns: int, sync_ns: int, tick_ts_ns: int, sample_
     return (dt * sample_rate) // 1_000_000_000 if dt > 0 else 0
 
 
+def no_vertex_buffer(cfg) -> bool:
+    """stepped bars whose step is taller than the channel: create_vbuf computes max_steps == 0 (src/source.cpp:988-1000), logs
+    "Tried to allocate vbuf of size: 0" and leaves m_vbuf null -- render() then returns before render_bars (:1351), so the
+    reference computes no bars at all.  Every backend records bars=None for such a configuration."""
+    if getattr(cfg, "vertices", 0) != 3 or not cfg.bars:
+        return False
+    stride = int(cfg.step_width) + int(cfg.step_gap)
+    cpos = np.float32(cfg.height) / np.float32(2) if cfg.stereo else np.float32(cfg.height)
+    off = np.float32(cfg.channel_spacing) * np.float32(0.5)
+    steps = int((cpos - off) / np.float32(stride))
+    if (int(cpos) - steps * stride - int(off)) > int(cfg.step_width):
+        steps += 1
+    return steps == 0
+
+
 def play(backend, scenario: dict):
     """returns list of per-tick records: dict(db=..., bars=... | None, silent=bool)"""
     feeder = _Feeder(backend.capture_channels)
@@ -401,7 +416,13 @@ class RefBackend:
         bars = None
         if (self.cfg.bars or self.cfg.curve) and not self.cfg.waveform:
             self.src.render()
-            bars = np.stack([self.src.bars(c) for c in range(self.disp)])
+            rows = [self.src.bars(c) for c in range(self.disp)]
+            # a display narrower than one bar has m_num_bars == 0: render_bars draws nothing (src/source.cpp:988-1000 logs
+            # "Tried to allocate vbuf of size: 0"); every backend then records no bars
+            bars = None if any(r is None or len(r) == 0 for r in rows) else np.stack(rows)
+            if no_vertex_buffer(self.cfg):
+                assert not self.src.draws(), "a draw call without a vertex buffer?"
+                bars = None
         rec = dict(db=db, bars=bars, silent=self.src.last_silent)
         if self.cfg.vertices and bars is not None:
             # per displayed channel one flush (mode -1) and then a gs_draw with the vertex buffer as it was at that call --
@@ -499,6 +520,8 @@ class OracleBackend:
         if self.cfg.bars or self.cfg.curve:
             self.src.render_bars()
             bars = self.src.bars()
+            if bars is None or bars.shape[-1] == 0 or no_vertex_buffer(self.cfg):
+                bars = None
         rec = dict(db=self.src.decibels(), bars=bars, silent=self.src.last_silent)
         if self.cfg.vertices and bars is not None:
             rec["verts"] = [self.src.vertices(c, line=self.cfg.vertices == 2) for c in range(bars.shape[0])]
@@ -573,7 +596,7 @@ class HipBackend:
             if self.auto_rms:
                 rec["rms"] = self.batch.input_rms()[self.probe]
             return rec
-        bars = self.batch.bars() if (self.cfg.bars or self.cfg.curve) else None
+        bars = self.batch.bars() if ((self.cfg.bars or self.cfg.curve) and self.batch.num_bars > 0 and not no_vertex_buffer(self.cfg)) else None
         silent = self.batch.last_silent()
         # every copy of the scenario must produce the same bits
         assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"

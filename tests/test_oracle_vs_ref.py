@@ -36,11 +36,29 @@ def test_restatement_matches_reference_any_size(seed):
     fuzz._compare(got, want, fuzz._undo_db(cfg), f"any-size case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
 
 
-@pytest.mark.parametrize("seed", range(0, len(fuzz.HUGE_SEEDS), 6))
+def _huge_seeds(count=10):
+    """the first seeds of the huge family whose length the restatement's O(n p) DFT can do in reasonable time (the GPU suite
+    checks the others against libwfref.so alone)"""
+    out = []
+    for s in fuzz.HUGE_SEEDS:
+        if fuzz._largest_prime_factor(fuzz.draw(s, "huge")[0]["fft_size"]) <= fuzz.RESTATEMENT_MAX_PRIME:
+            out.append(s)
+    return out[::max(1, len(out) // count)][:count]
+
+
+@pytest.mark.parametrize("seed", _huge_seeds())
 def test_restatement_matches_reference_huge_size(seed):
     cfg_dict, steps, sync_ms = fuzz.draw(seed, "huge")
     cfg, got, want = _play_pair(cfg_dict, steps, f"huge {seed}", sync_ms=sync_ms)
     fuzz._compare(got, want, fuzz._undo_db(cfg), f"huge-size case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
+
+
+@pytest.mark.parametrize("seed", range(0, len(fuzz.WIDE_SEEDS), STEP))
+def test_restatement_matches_reference_wide_ranges(seed):
+    """the reference's full slider ranges (fuzz.draw_wide)"""
+    cfg_dict, steps, sync_ms = fuzz.draw_wide(seed)
+    cfg, got, want = _play_pair(cfg_dict, steps, f"wide {seed}", sync_ms=sync_ms)
+    fuzz._compare(got, want, fuzz._undo_db(cfg), f"wide-range case {seed} ({cfg_dict}): restatement vs libwfref", cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
 
 
 @pytest.mark.parametrize("seed", range(0, len(fuzz.METER_SEEDS), STEP))

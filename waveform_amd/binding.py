@@ -114,6 +114,7 @@ def lib():
     L.wf_hip_read_vertex_counts.argtypes = [vp, u32, u32, C.POINTER(C.c_uint32)]
     L.wf_hip_copy_bars_device.argtypes = [vp, u32, u32, vp]
     L.wf_hip_copy_bars_device_async.argtypes = [vp, u32, u32, vp, vp]
+    L.wf_hip_wait_event.argtypes = [vp, vp]
     L.wf_hip_time_begin.argtypes = [vp]
     L.wf_hip_time_end.argtypes = [vp, fp]
     L.wf_hip_read_meter.argtypes = [vp, u32, u32, fp]

@@ -239,9 +239,11 @@ int check_range(wf_hip_multi *m, uint32_t first, uint32_t count)
 int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
 {
     Shard &s = *m->shard[i];
-    hipStream_t hs = static_cast<hipStream_t>(wf_hip_stream(s.h));
-    if(s.slot_used[k]) // the gather that read this send buffer two gathers ago must have run before the buffer is rewritten
-        WF_MHIP(s, hipStreamWaitEvent(hs, s.ev_done[k], 0));
+    if(s.slot_used[k]) { // the gather that read this send buffer two gathers ago must have run before the buffer is rewritten
+        const int rc = wf_hip_wait_event(s.h, s.ev_done[k]);
+        if(rc)
+            return rc;
+    }
     float *dst = (m->transport == Transport::LOCAL) ? s.gathered[k] : s.send[k];
     int rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, dst, s.gstream);
     if(rc)

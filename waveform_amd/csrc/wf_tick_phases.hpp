@@ -324,6 +324,14 @@ WF_DEV float mag2(float xr, float xi)
 {
     const float s = fmaf(xi, xi, xr * xr);
 #if defined(__HIPCC__) && WF_FAST_SQRT
+#if defined(WF_MAG_SAFE)
+    // squares of parts below ~1e-19 underflow (the first ticks behind a reset through a narrow window: a few samples under
+    // sin^16 tails give |X| ~ 1e-26 where hypotf still answers): rare branch with the parts scaled by 2^64
+    if(__builtin_expect(s < 0x1p-100f, 0)) {
+        const float a = xr * 0x1p64f, b = xi * 0x1p64f;
+        return __builtin_amdgcn_sqrtf(fmaf(b, b, a * a)) * 0x1p-64f;
+    }
+#endif
     return __builtin_amdgcn_sqrtf(s);
 #else
     return sqrtf(s);
