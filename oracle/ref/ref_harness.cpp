@@ -111,6 +111,11 @@ wfref_t *wfref_create(const char *isa, const char *settings, uint32_t sample_rat
     fakeobs::set_video_fps(fps_num ? fps_num : 60, fps_den ? fps_den : 1);
 
     std::string which = isa ? isa : "generic";
+    if(which == "create") {
+        // the plugin's own factory (obs_source_info::create = callbacks::create, src/source.cpp:87-102), which also runs update()
+        h->obj = static_cast<WAVSource *>(info->create(h->settings, h->self));
+        return h;
+    }
     if(which == "hip")
         h->obj = new WAVSourceHIP(h->self);
     else if(which == "avx2")
@@ -240,6 +245,15 @@ size_t wfref_decibels_size(wfref_t *h)
 {
     const bool spectrum = !h->obj->m_meter_mode && (h->obj->m_display_mode != DisplayMode::WAVEFORM);
     return spectrum ? h->obj->m_fft_size / 2 : h->obj->m_fft_size;
+}
+
+/* the class callbacks::create (or the harness) instantiated: "hip", "avx2", "avx", "generic" */
+const char *wfref_class_name(wfref_t *h)
+{
+    if(dynamic_cast<WAVSourceHIP *>(h->obj)) return "hip";
+    if(dynamic_cast<WAVSourceAVX2 *>(h->obj)) return "avx2";
+    if(dynamic_cast<WAVSourceAVX *>(h->obj)) return "avx";
+    return "generic";
 }
 
 int wfref_using_hip(wfref_t *h)

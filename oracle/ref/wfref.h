@@ -65,6 +65,9 @@ int wfref_stereo(wfref_t *h);
 int wfref_last_silent(wfref_t *h);
 size_t wfref_ring_bytes(wfref_t *h, int ch);
 int wfref_using_hip(wfref_t *h);
+/* the class instantiated for this source: "hip", "avx2", "avx" or "generic" (isa "create": whatever the plugin's own
+ * obs_source_info::create -- callbacks::create, src/source.cpp:87-102 -- chose) */
+const char *wfref_class_name(wfref_t *h);
 /* process-wide: ticks a WAVSourceHIP had to hand to the reference's CPU class since the library was loaded (0 for a
  * device path that never fell back; ticks skipped for lack of audio are not fallbacks) */
 uint64_t wfref_hip_fallback_ticks(void);

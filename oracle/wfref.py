@@ -14,7 +14,9 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "_ref" / "libwfref.so"
+# WFREF_LIBRARY: another build of the harness -- oracle/_ref/libwfref_plugin.so is the reference with
+# integration/waveform-hip.patch applied (sources created through its own callbacks::create)
+LIB_PATH = Path(os.environ["WFREF_LIBRARY"]) if os.environ.get("WFREF_LIBRARY") else _HERE / "_ref" / "libwfref.so"
 
 _lib = None
 
@@ -51,6 +53,8 @@ def lib():
     for name in ("wfref_stereo", "wfref_last_silent", "wfref_num_bars", "wfref_using_hip"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp]
+    L.wfref_class_name.restype = C.c_char_p
+    L.wfref_class_name.argtypes = [vp]
     L.wfref_hip_fallback_ticks.restype = C.c_uint64
     L.wfref_hip_fallback_ticks.argtypes = []
     L.wfref_hip_host_rms_updates.restype = C.c_uint64
@@ -184,6 +188,11 @@ class RefSource:
     @property
     def using_hip(self):
         return bool(self.L.wfref_using_hip(self.h))
+
+    @property
+    def class_name(self) -> str:
+        """"hip" / "avx2" / "avx" / "generic": the WAVSource subclass behind this source"""
+        return self.L.wfref_class_name(self.h).decode()
 
     @property
     def last_silent(self):

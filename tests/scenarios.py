@@ -107,6 +107,17 @@ SCENARIOS = {
                                       steps=_steps(4), record=2),
     "verts_stepped_1024_mono_fine": dict(cfg=dict(fft_size=1024, stereo=0, bars=1, interp_mode=2, bar_width=6, bar_gap=1, step_width=3, step_gap=1,
                                                   min_bar_height=2, vertices=3), steps=_steps(3) + [("silence", 1200), ("tick",)], record=2),
+    # the reference's whole slider range (width <= 3840, filter radius <= 32, src/source.cpp:287, :409) at small fft sizes: the
+    # points + the filter's staging do not fit the tick kernel's exchange buffer; big_outputs_kernel derives the display from
+    # the stored rows (formerly WF_HIP_ERR_UNSUPPORTED)
+    "curve_1024_3840_gauss32": dict(cfg=dict(fft_size=1024, stereo=1, slope=1.0, curve=1, interp_mode=2, width=3840, filter_mode=1, filter_radius=32.0),
+                                    steps=_steps(4), record=2),
+    "bars_512_1px_gauss12_mono": dict(cfg=dict(fft_size=512, stereo=0, bars=1, interp_mode=1, width=3840, bar_width=1, bar_gap=0, filter_mode=1,
+                                               filter_radius=12.5, log_scale=0), steps=_steps(3) + [("silence", 1400), ("tick",), ("noise", 800), ("tick",)],
+                                      record=3),
+    "curve_2048_lanczos_2560_gauss20_hide": dict(cfg=dict(fft_size=2048, stereo=1, capture_channels=1, curve=1, interp_mode=1, width=2560, filter_mode=1,
+                                                          filter_radius=20.0, mirror_freq_axis=1),
+                                                 steps=_steps(3) + [("hide",), ("noise", 800), ("tick",), ("show",)] + _steps(2), record=3),
     "bars_gauss_4096": dict(cfg=dict(fft_size=4096, stereo=1, bars=1, interp_mode=1, filter_mode=1, filter_radius=0.8), steps=_steps(4), record=1),
     # ragged packets: 441-frame hops (window start not 16-byte aligned), then a 1024 packet
     "ragged_hops": dict(cfg=dict(fft_size=2048, stereo=1),
