@@ -196,6 +196,15 @@ WF_DEV void p4_big_impl(const TickArgs &a, int t, int kbase, int nb, const cf *z
         f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if(TS)
             st = ld_state(ts + k0);
+        if constexpr(MODE == 3) {
+            // fft_size 65536: the rows kernel has done the real split; bins kk .. kk + 3 are k2 = kk / 2, kk / 2 + 1 of both rows
+            const float *mb = reinterpret_cast<const float *>(z); // (this spectrum's [2][16384] magnitudes)
+            const f2 m0 = ld2(mb + kk / 2), m1 = ld2(mb + BIG_L2 + kk / 2);
+            mag[4 * u] = m0.x; mag[4 * u + 1] = m1.x; mag[4 * u + 2] = m0.y; mag[4 * u + 3] = m1.y;
+            const float sl4[4] = {sv.x, sv.y, sv.z, sv.w}, st4v[4] = {st.x, st.y, st.z, st.w};
+            p4_slope_smooth_group<G, TS, FPK>(a, t, u, ts, st4v, sl4, mag);
+            continue;
+        }
         const f4 za = ld4(reinterpret_cast<const float *>(z + kk)), zb = ld4(reinterpret_cast<const float *>(z + kk + 2));
         const cf A[4] = {cf{za.x, za.y}, cf{za.z, za.w}, cf{zb.x, zb.y}, cf{zb.z, zb.w}};
         if constexpr(MODE == 1) {
@@ -277,7 +286,7 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
     for(int i = 0; i < RP; ++i)
         mag[i] = 0.0f;
     if(process)
-        p4_big<MODE>(a, t, kbase, NB, a.big_z + (size_t)spec * a.big_l, ts, mag);
+        p4_big<MODE>(a, t, kbase, NB, MODE == 3 ? reinterpret_cast<const cf *>(a.big_mag + (size_t)spec * (2u * BIG_L2)) : a.big_z + (size_t)spec * a.big_l, ts, mag);
     else if(do_db && (!(mono_mix && ch == 1) || underflow)) // skipped channel of a live stream: its stale row is re-dBFS'ed
         load_row<RG, true>(rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
 
@@ -330,6 +339,163 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
         atomicOr(a.verdict_out + spec, 1u);
     if(t == 0)
         a.verdict_clear[spec] = 0u;
+}
+
+// ---- fft_size 65536: the column step folded into the rows kernel, the real split too -----------------------------------
+// The packed real transform of 65536 samples is L = 2 x 16384 complex points.  Decimation in frequency over n1 (two columns)
+// leaves two independent 16384-point rows, and row k1 delivers exactly the bins of parity k1: U[k1 + 2 k2].  The real split
+// pairs bin k with bin m - k (m = 32768) -- the SAME parity -- so a row needs nothing from the other one.
+// big_rows_kernel<2, FOLD> therefore (1) forms its input itself: windowed sample pairs straight from the ring, u0 +- u1, times
+// W_L^n2 for row 1 (what big_columns_kernel wrote to the scratch buffer and this kernel read back: 8 N bytes per transform
+// gone, and a launch), and (2) finishes with the real split and stores |2X| coef / 2 of its 16384 bins as floats, planar
+// ([row][k2], 2 N bytes per transform instead of 4 N of complex points); big_epilogue_kernel<3> picks the magnitudes up --
+// no mirrored reads -- and does the rest.  Device-memory traffic per transform: 26 N -> 18 N bytes; three kernels -> two.
+
+// the 16 points of row K1 this thread feeds into pass 1: u0 +- u1 (times W_L^n2 for K1 = 1), u = windowed sample pairs.
+// Eight to ten registers per point are in flight until its sum is formed; all sixteen at once do not fit the 128 registers
+// a thread of a 1024-thread workgroup has, so the burst goes out in groups of BIG_FETCH_ROWS points.
+#ifndef BIG_FETCH_ROWS
+#define BIG_FETCH_ROWS 4
+#endif
+// (32-bit byte offsets from a uniform base: the loads take the SGPR-base + VGPR-offset form instead of a 64-bit address pair
+// per request -- sixty-four of those do not fit the register file)
+#ifdef BIG_PLAIN_INDEX
+WF_DEV float big_ring1(const float *x, uint32_t i) { return x[i]; }
+WF_DEV f2 big_ring2(const float *x, uint32_t i) { return ld2(x + i); }
+#else
+WF_DEV float big_ring1(const float *x, uint32_t i) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (size_t)(i * 4u)); }
+WF_DEV f2 big_ring2(const float *x, uint32_t i) { return *reinterpret_cast<const f2 *>(reinterpret_cast<const char *>(x) + (size_t)(i * 4u)); }
+#endif
+template<bool ALIGNED> WF_DEV uint32_t big_fused_fetch(const TickArgs &a, int t, int k1, const float *x, uint32_t start, P1Regs<GBig> &r)
+{
+    using G = GBig;
+    constexpr int R1 = G::R1, M1 = G::M1;
+    constexpr int ROWS = ALIGNED ? BIG_FETCH_ROWS : BIG_FETCH_ROWS / 2;
+    uint32_t acc = 0;
+    const float sgn = k1 ? -1.0f : 1.0f; // row 0: u0 + u1; row 1: (u0 - u1) W_L^n2 (row 0 of the table is all ones)
+    const float *tw_row = reinterpret_cast<const float *>(a.big_tw + (size_t)k1 * BIG_L2);
+#pragma unroll
+    for(int j0 = 0; j0 < R1; j0 += ROWS) {
+        f2 s0[ROWS], s1[ROWS], w0[ROWS], w1[ROWS], tw[ROWS];
+#pragma unroll
+        for(int jj = 0; jj < ROWS; ++jj) {
+            const int j = j0 + jj;
+            const uint32_t n2 = (uint32_t)(j * M1 + t);
+            const uint32_t i0 = start + 2u * n2, i1 = start + 2u * (n2 + BIG_L2);
+            if(ALIGNED) { // start is a multiple of 4: a pair never straddles the ring's wrap
+                s0[jj] = big_ring2(x, i0 & a.ring_mask);
+                s1[jj] = big_ring2(x, i1 & a.ring_mask);
+            } else {
+                s0[jj] = f2{big_ring1(x, i0 & a.ring_mask), big_ring1(x, (i0 + 1u) & a.ring_mask)};
+                s1[jj] = f2{big_ring1(x, i1 & a.ring_mask), big_ring1(x, (i1 + 1u) & a.ring_mask)};
+            }
+            w0[jj] = big_ring2(a.window, 2u * n2);
+            w1[jj] = big_ring2(a.window, 2u * (n2 + BIG_L2));
+            tw[jj] = big_ring2(tw_row, 2u * n2);
+            if(j >= 1 && tw1_row_loaded(j))
+                p1_load_tw1<G>(a, t, j, r.tw1[j]);
+        }
+#pragma unroll
+        for(int jj = 0; jj < ROWS; ++jj) {
+            const int j = j0 + jj;
+            acc |= f32_bits(s0[jj].x) | f32_bits(s0[jj].y) | f32_bits(s1[jj].x) | f32_bits(s1[jj].y);
+            const cf u0 = cf{s0[jj].x * w0[jj].x, s0[jj].y * w0[jj].y}, u1 = cf{s1[jj].x * w1[jj].x, s1[jj].y * w1[jj].y};
+            const cf c = cmul(cf{fmaf(sgn, u1.x, u0.x), fmaf(sgn, u1.y, u0.y)}, cf{tw[jj].x, tw[jj].y});
+            r.smp[j][0] = c.x;
+            r.smp[j][1] = c.y;
+            r.win[j][0] = r.win[j][1] = 1.0f;
+        }
+#ifndef BIG_NO_FENCE
+        if(j0 + ROWS < R1)
+            __builtin_amdgcn_sched_barrier(0); // the next group's requests stay behind this group's sums
+#endif
+    }
+    return acc;
+}
+
+// bins of parity K1 from row K1's transform (natural order in LDS): mag[4 u + 2 h + K1] = |2 X[k]| coef / 2 for
+// k = 4 (t + T u) + 2 h + K1, i.e. Z[k2] with k2 = 2 (t + T u) + h and its mirror image m - k, which is row K1's
+// k2' = (16384 - K1 - k2) mod 16384
+WF_DEV void big_fused_split(const TickArgs &a, int t, int k1, const cf *lds, float (&out)[GBig::P])
+{
+    using G = GBig;
+    constexpr int T = G::T, P = G::P;
+    static_assert(4 * T * 16 == 2 * 2 * (int)BIG_L2, "W_65536^(4 T u) = W_16^u");
+    // W_65536^k for k = 4 t + 2 h + k1; the bins 4 T u further on are that times W_16^u = W_32^(2u) (compile-time constants),
+    // as p4_split_smooth forms its twiddles.  out[2 u + h] is bin 4 (t + T u) + 2 h + k1.
+    cf wh[2];
+#pragma unroll
+    for(int h = 0; h < 2; ++h) {
+        const f2 w = ld2(reinterpret_cast<const float *>(a.big_tws + 4 * t + 2 * h + k1));
+        wh[h] = cf{w.x, w.y};
+    }
+#pragma unroll
+    for(int u = 0; u < P / 2; ++u) {
+#pragma unroll
+        for(int h = 0; h < 2; ++h) {
+            const int k2 = 2 * (t + T * u) + h;
+            const int km = ((int)BIG_L2 - k1 - k2) & ((int)BIG_L2 - 1);
+            const cf A = lds_ld2(lds, ex3_addr<G>(k2)), B = lds_ld2(lds, ex3_addr<G>(km));
+            const cf w = mul_w32(wh[h], 2 * u);
+            const float er = A.x + B.x, ei = A.y - B.y;
+            const float dr = A.x - B.x, di = A.y + B.y;
+            const float pr = fmaf(w.x, dr, -(w.y * di));
+            const float pi = fmaf(w.x, di, w.y * dr);
+            out[2 * u + h] = mag2(er + pi, ei - pr) * a.half_coef;
+        }
+    }
+}
+
+// one row (blockIdx.x = k1) of one spectrum per workgroup: fetch + column step, the three LDS passes of the 32768-sample
+// geometry, the real split, 16384 magnitudes out
+template<bool ALIGNED> __global__ __launch_bounds__(GBig::T, 4) void big_rows_fold_kernel(const TickArgs a)
+{
+    using G = GBig;
+    constexpr int T = G::T, P = G::P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    cf *lds = reinterpret_cast<cf *>(big_smem);
+    cf *tw2_lds = lds + G::LDS_CF;
+    const int t = (int)threadIdx.x;
+    const int k1 = (int)blockIdx.x;
+    const uint32_t spec = a.stream_base * a.cap_ch + blockIdx.y;
+    const uint32_t stream = spec >> (a.cap_ch - 1u);
+    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const uint32_t start = (a.wpos[stream] - delay - (uint32_t)(2 * G::N)) & a.ring_mask;
+    const float *x = a.ring + (size_t)spec * a.ring_stride;
+    P1Regs<G> r;
+    const uint32_t acc = big_fused_fetch<ALIGNED>(a, t, k1, x, start, r);
+    {   // the pass-2 twiddles by LDS-DMA, as in spectrum_tick_kernel
+        constexpr int BYTES = G::R2 * G::R3 * (int)sizeof(cf), PER = 64 * 16;
+        const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+        for(int c = 0; c < BYTES / PER; ++c)
+            if((c % (T / 64)) == wave) {
+                const char *g = reinterpret_cast<const char *>(a.tw2) + c * PER + lane * 16;
+                char *l = reinterpret_cast<char *>(tw2_lds) + c * PER;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16,
+                                                 0, 0);
+            }
+    }
+    // x != 0.0f for any sample of the window (reference :63-72): row 0 has seen all of it
+    if(k1 == 0 && __any((acc & 0x7fffffffu) != 0u) && (t & 63) == 0)
+        atomicOr(a.big_nz_out + spec, 1u);
+    p1_window_pass1<G>(a, t, r, lds);
+    __syncthreads();
+    cf pts[P];
+    p2_read<G>(t, lds, pts);
+    __syncthreads();
+    p2_pass2_write<G>(tw2_lds, t, lds, pts);
+    __syncthreads();
+    p3_read<G>(t, lds, pts);
+    __syncthreads();
+    p3_pass3_write<G>(t, lds, pts);
+    __syncthreads();
+    float out[P];
+    big_fused_split(a, t, k1, lds, out);
+    float *mb = a.big_mag + (size_t)spec * (2u * BIG_L2) + (size_t)k1 * BIG_L2;
+#pragma unroll
+    for(int u = 0; u < P / 2; ++u) // out[2 u + h] is k2 = 2 (t + T u) + h
+        *reinterpret_cast<f2 *>(mb + 2 * (t + T * u)) = f2{out[2 * u], out[2 * u + 1]};
 }
 
 // ---- render-time outputs from the finished rows --------------------------------------------------------------------

@@ -94,6 +94,8 @@ struct wf_hip {
     wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr, *d_blu_q = nullptr, *d_blu_qr = nullptr, *d_blu_w = nullptr;
     // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
     uint32_t big_l = 0, big_rows = 0;
+    bool big_fused = false;          // fft_size 65536: column step and real split folded into the rows kernel (big_rows_fold_kernel)
+    float *d_big_mag = nullptr;      // [n_spec][2][16384] its output: magnitudes by bin parity
     wf::cf *d_big_v = nullptr, *d_big_z = nullptr, *d_big_tw = nullptr, *d_big_tws = nullptr;
     uint32_t *d_big_nz = nullptr;
     size_t big_out_lds = 0;          // dynamic LDS of big_outputs_kernel
@@ -371,6 +373,33 @@ template<class G, int SPW> int setup_launch(wf_hip *h)
 }
 
 // FFT sizes whose transform does not fit a CU's LDS (wf_big.hpp): columns -> rows (twice for Bluestein) -> epilogue -> outputs
+// fft_size 65536: rows kernel with the column step and the real split folded in, then the epilogue on magnitudes (wf_big.hpp)
+int launch_tick_big_fold(wf_hip *h, const wf::TickArgs &a0, bool aligned)
+{
+    const uint32_t n_spec = a0.stream_count * a0.cap_ch;
+    hipStream_t st = h->launch_stream;
+    const uint32_t spec_base = a0.stream_base * a0.cap_ch;
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_big_nz + spec_base, 0, (size_t)n_spec * sizeof(uint32_t), st));
+    const dim3 grow(2, n_spec);
+    const size_t rows_lds = wf::big_rows_lds_bytes<2>();
+    if(aligned)
+        hipLaunchKernelGGL(wf::big_rows_fold_kernel<true>, grow, dim3(wf::GBig::T), rows_lds, st, a0);
+    else
+        hipLaunchKernelGGL(wf::big_rows_fold_kernel<false>, grow, dim3(wf::GBig::T), rows_lds, st, a0);
+    const uint32_t parts = (h->M + (uint32_t)wf::BIG_TP - 1u) / (uint32_t)wf::BIG_TP;
+    // mono mixdown: channel 1 of every stream, then channel 0 (TickArgs::split_ch)
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
+        wf::TickArgs a = a0;
+        a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(parts, h->split_mono ? a.stream_count : n_spec);
+        hipLaunchKernelGGL((wf::big_epilogue_kernel<3>), grid, dim3(wf::GBig::T), 0, st, a);
+    }
+    if(a0.bar.out != nullptr)
+        hipLaunchKernelGGL(wf::big_outputs_kernel, dim3(a0.stream_count * a0.bar.disp_ch), dim3(wf::GBig::T), h->big_out_lds, st, a0);
+    WF_HIP_TRY(h, hipGetLastError());
+    return WF_HIP_OK;
+}
+
 template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
 {
     const uint32_t n_spec = a0.stream_count * a0.cap_ch;
@@ -424,7 +453,7 @@ template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
     return WF_HIP_OK;
 }
 
-void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool)
+void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     // (a failure leaves its text in last_error and its HIP error sticky: wf_hip_tick's hipGetLastError() behind the launches
     // reports it; launch_rc carries the code for the errors that are not HIP's)
@@ -434,6 +463,10 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool)
         wf::TickArgs s = a;
         s.stream_base = a.stream_base + off;
         s.stream_count = std::min(part, a.stream_count - off);
+        if(h->big_fused) {
+            h->launch_rc = launch_tick_big_fold(h, s, aligned);
+            continue;
+        }
         switch(h->big_rows) {
         case 2: h->launch_rc = launch_tick_big_l<2>(h, s); break;
         case 4: h->launch_rc = launch_tick_big_l<4>(h, s); break;
@@ -454,6 +487,17 @@ int setup_launch_big(wf_hip *h)
     int rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
     if(rc)
         return rc;
+    // fft_size 65536 (the one power of two up here): everything in one kernel.  WF_HIP_BIG_FUSED=0 keeps the three-kernel path
+    // (development aid: A/B, and the path every Bluestein size above 16384 takes)
+    h->big_fused = !h->blu && h->big_rows == 2;
+    if(const char *e = std::getenv("WF_HIP_BIG_FUSED"))
+        h->big_fused = h->big_fused && e[0] != '0';
+    if(h->big_fused) {
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_rows_fold_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)wf::big_rows_lds_bytes<2>()));
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_rows_fold_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)wf::big_rows_lds_bytes<2>()));
+    }
     if(h->big_out_lds)
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_outputs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)h->big_out_lds));
@@ -461,7 +505,9 @@ int setup_launch_big(wf_hip *h)
     h->split = true;
     h->flag_bufs = 3;
     char name[160];
-    if(h->blu)
+    if(h->big_fused)
+        snprintf(name, sizeof(name), "big_rows_fold_kernel + big_epilogue_kernel<N=%u: two rows of 16384 complex points, column step and real split folded into the rows>", h->N);
+    else if(h->blu)
         snprintf(name, sizeof(name), "big_{columns,rows,epilogue}_kernel<N=%u by Bluestein over %u = %u x 16384 complex points through device memory>",
                  h->N, h->big_l, h->big_rows);
     else
@@ -569,6 +615,9 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     if(h->big_l) {
         a.big_z = h->d_big_z;
         a.big_tws = h->d_big_tws;
+        a.big_tw = h->d_big_tw;
+        a.big_mag = h->d_big_mag;
+        a.big_nz_out = h->d_big_nz;
         a.big_nz = h->d_big_nz;
         a.big_m = h->blu ? 0u : h->N / 2;
         a.big_l = h->big_l;
@@ -1248,8 +1297,12 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_big_tw, t1));
         WF_CREATE_TRY(upload(h, &h->d_big_tws, t2));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
-        WF_CREATE_TRY(dev_alloc(h, &h->d_big_v, n_spec * h->big_l));
-        WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_l));
+        if(h->big_fused) { // (no complex scratch: the rows kernel reads the ring and leaves magnitudes)
+            WF_CREATE_TRY(dev_alloc(h, &h->d_big_mag, n_spec * 2u * 16384u));
+        } else {
+            WF_CREATE_TRY(dev_alloc(h, &h->d_big_v, n_spec * h->big_l));
+            WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_l));
+        }
         WF_CREATE_TRY(dev_alloc(h, &h->d_big_nz, n_spec));
     }
     {

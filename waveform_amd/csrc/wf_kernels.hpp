@@ -67,6 +67,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_TRACK
 #define WF_TRACK 1
 #endif
+#ifndef WF_DEFER_STATE
+#define WF_DEFER_STATE 0 // 1: smoothing-state stores issued behind the display's table requests (p4_split_smooth<.., DEFER>)
+#endif
 #ifndef WF_BAR_COEF_EARLY
 #define WF_BAR_COEF_EARLY 0 // (bar tables requested in front of the smoothing state instead of behind it, so that the dot products need
                             // no wait of their own: up to 24 more registers across P4 -- 128 VGPRs and 20-36 B of scratch on every geometry from 4096)
@@ -85,7 +88,13 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_WPS_512
 #define WF_WPS_512 6 // four points per thread: 80 VGPRs; 0.60 of the HBM peak at N = 512 against 0.53 at 4 and 5 waves, 0.44 at 8 (spills)
 #endif
-#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 4) ? WF_WPS_512 : (G::P <= 8) ? WF_WPS_SMALL : 4)
+#ifndef WF_WPS_LARGE
+#define WF_WPS_LARGE 4 // sixteen points per thread on two wavefronts and more: 104-115 VGPRs.  Five waves per SIMD (96 VGPRs: the
+                       // register file hands out blocks of 8) were compiled for the record at the end of round 3
+                       // (profiles/r03_occupancy5_isa.txt): the N = 4096 kernel then keeps 72 B per lane in scratch, the 16384 one 48 B --
+                       // and a fifth workgroup per CU would also need its LDS down from 36.9 KB to 32 KB
+#endif
+#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 4) ? WF_WPS_512 : (G::P <= 8) ? WF_WPS_SMALL : WF_WPS_LARGE)
 
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \
@@ -381,7 +390,9 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
             if(row_thread)
                 p4_split_smooth_dec<G, DEC>(a, t, lds, ts, r1.wb, r4, mag);
         } else {
-            p4_split_smooth<G>(a, t, lds, ts, r1.wb, r4, mag);
+            p4_split_smooth<G, WF_DEFER_STATE != 0>(a, t, lds, ts, r1.wb, r4, mag);
+            if(WF_DEFER_STATE && mono_mix) // (the mixdown below overwrites mag[]: no deferral there)
+                p4_store_state<G>(a, t, ts, mag);
             if(Policy<G>::TOUCH_STATE)
                 asm volatile("" ::"v"(r4.touch[0]), "v"(r4.touch[1])); // the touched dwords are only ever waited for
         }
@@ -475,6 +486,10 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     BarEntries<G> bar_entries;
     bars_fetch_entries<G>(a.bar, t, bar_entries);
 #endif
+    if constexpr(WF_DEFER_STATE && !BLU && DEC == 0) {
+        if(process && !mono_mix)
+            p4_store_state<G>(a, t, ts, mag); // behind the table requests (p4_split_smooth<.., DEFER>)
+    }
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
                                                             // captured channel is shown as stereo, reference :141-142)
     const bool dup_row = have_row && (a.out_ch > a.cap_ch);

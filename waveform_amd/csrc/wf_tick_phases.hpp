@@ -189,6 +189,9 @@ struct TickArgs {
     // transforms beyond a CU's LDS (wf_big.hpp): the finished transform in device memory and what the epilogue needs with it
     const cf *big_z;           // [n_spec][big_l] rows' output, natural order
     const cf *big_tws;         // [big_m] W_(2 big_m)^k (real split of the 65536-sample transform)
+    const cf *big_tw;          // [L1][16384] W_L^(n2 k1): the column twiddles (big_rows_fold_kernel folds the column step into its fetch)
+    float *big_mag;            // [n_spec][2][16384] fft_size 65536: |2X| coef / 2 of the bins of parity 0 / 1 (big_rows_fold_kernel -> epilogue)
+    uint32_t *big_nz_out;      // big_nz, writable (row 0 of big_rows_fold_kernel ORs "the window has a non-zero sample" into it)
     const uint32_t *big_nz;    // [n_spec] != 0: the window has a non-zero sample
     uint32_t big_m, big_l;     // complex points of the packed real transform; complex points per transform (scratch stride)
     BarArgs bar;
@@ -634,6 +637,13 @@ template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float
             r.win[j][e] = 1.0f;
         if(j >= 1 && tw1_row_loaded(j))
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
+#if defined(__HIPCC__) && defined(WF_BLU_FETCH_SPLIT)
+        // six registers per point are in flight until a point's product is formed (two samples, four table values): issued as
+        // one burst over all R1 rows that is 96 registers and more, and the kernel spills; in WF_BLU_FETCH_SPLIT groups of rows
+        // the burst stays inside the register file at the price of R1 / WF_BLU_FETCH_SPLIT round trips instead of one
+        if((j + 1) % WF_BLU_FETCH_SPLIT == 0 && j + 1 < R1)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     return (acc & 0x7fffffffu) != 0;
 }
@@ -711,6 +721,9 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
             if(TS)
                 st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
         }
+#if defined(__HIPCC__) && defined(WF_BLU_P4_FENCE)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 template<class G> WF_DEV void p4_direct(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
@@ -908,7 +921,7 @@ template<class G> WF_DEV void p3_pass3_write(int t, cf *lds, cf (&v)[G::P])
 //
 // slope (reference :121-122) and temporal smoothing incl. fast peaks (:124-132) of bin group u; the slope table is all ones
 // when m_slope <= 0.  st4v/sl4 are this group's m_tsmooth_buf / m_slope_modifiers values.
-template<class G, bool TS, bool FPK>
+template<class G, bool TS, bool FPK, bool DEFER = false>
 WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, const float (&st4v)[4], const float (&sl4)[4],
                                   float (&mag)[G::P])
 {
@@ -927,11 +940,21 @@ WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, co
             // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
             mag[4 * u + i] = fmaf(a.g, old, a.g2 * mag[4 * u + i]);
         }
-        st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+        if(!DEFER)
+            st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
     }
 }
+// the state stores a DEFER-ed P4 left out: m_tsmooth_buf = the smoothed magnitudes (reference :131), for the whole row
+template<class G> WF_DEV void p4_store_state(const TickArgs &a, int t, float *ts, const float (&mag)[G::P])
+{
+    if(!(a.mode & WF_MODE_TSMOOTH))
+        return;
+    WF_UNROLL
+    for(int u = 0; u < G::P / 4; ++u)
+        st_state(ts + 4 * (t + G::T * u), f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+}
 
-template<class G, bool TS, bool FPK>
+template<class G, bool TS, bool FPK, bool DEFER = false>
 WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q,
                                  float (&mag)[G::P])
 {
@@ -982,7 +1005,7 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
                 st4v[0] = o.x; st4v[1] = o.y; st4v[2] = o.z; st4v[3] = o.w;
             }
         }
-        p4_slope_smooth_group<G, TS, FPK>(a, t, u, ts, st4v, sl4, mag);
+        p4_slope_smooth_group<G, TS, FPK, DEFER>(a, t, u, ts, st4v, sl4, mag);
     };
     // ---- loop 1: real split -> |2X| * coef/2 -------------------------------------------------------------------------
     // LDS addresses: bins advance by 4T per group, i.e. by T words inside every ex3 plane, so every group is the first
@@ -1024,16 +1047,19 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
     }
 }
 
-template<class G>
+// DEFER: the smoothing-state stores are left to the caller (p4_store_state), which issues them behind the requests for the
+// display's tables: vector memory completes in order, so tables requested behind the state stores are not in before the
+// stores' acknowledgement -- a round trip to HBM the dot products at the end of the kernel then sit out
+template<class G, bool DEFER = false>
 WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[G::P])
 {
     if(a.mode & WF_MODE_TSMOOTH) {
         if(a.mode & WF_MODE_FAST_PEAKS)
-            p4_split_smooth_impl<G, true, true>(a, t, lds, ts, wb, q, mag);
+            p4_split_smooth_impl<G, true, true, DEFER>(a, t, lds, ts, wb, q, mag);
         else
-            p4_split_smooth_impl<G, true, false>(a, t, lds, ts, wb, q, mag);
+            p4_split_smooth_impl<G, true, false, DEFER>(a, t, lds, ts, wb, q, mag);
     } else
-        p4_split_smooth_impl<G, false, false>(a, t, lds, ts, wb, q, mag);
+        p4_split_smooth_impl<G, false, false, DEFER>(a, t, lds, ts, wb, q, mag);
 }
 
 // ---- decimated epilogue (DEC > 0): the N >> DEC point transform's bin o is bin o << DEC of the zero-padded one --------------
