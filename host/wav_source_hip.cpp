@@ -41,6 +41,7 @@ struct HipApi {
     decltype(&wf_hip_enable_input_rms_feed) enable_input_rms_feed = nullptr;
     decltype(&wf_hip_push_rms_ragged_async) push_rms_ragged_async = nullptr;
     decltype(&wf_hip_read_input_rms_async) read_input_rms_async = nullptr;
+    decltype(&wf_hip_read_meter_async) read_meter_async = nullptr;
     bool ok = false;
 };
 
@@ -78,6 +79,7 @@ HipApi &api()
         WF_SYM(enable_input_rms_feed)
         WF_SYM(push_rms_ragged_async)
         WF_SYM(read_input_rms_async)
+        WF_SYM(read_meter_async)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
         auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
@@ -242,11 +244,127 @@ struct WFHipGroup {
     }
 };
 
+// The level meter's batch (same idea as WFHipGroup; reference tick_meter src/source_generic.cpp:182-269): every member's
+// tick_meter collects the levels the PREVIOUS frame's tick left for it and submits what its own tick_meter would consume this
+// frame -- every captured frame older than the A/V-sync point, :201-220 -- with its show / hide / timeout state; the member that
+// completes the frame flushes: ONE ragged ingest, ONE wf_hip_tick (meter_tick_kernel over all streams), ONE readback.
+struct WFHipMeterGroup {
+    wf_config cfg{};
+    wf_hip *h = nullptr;
+    int device = 0;
+    uint32_t capacity = 0, cap_ch = 0;
+    std::vector<WAVSourceHIP *> member;
+    uint32_t members = 0;
+    uint64_t batch = 1;
+    std::vector<uint64_t> submitted;
+    uint32_t n_submitted = 0;
+    std::vector<std::vector<float>> pending; // [capacity] what the member consumed this frame: [cap_ch][frames[i]]
+    std::vector<uint32_t> frames;
+    std::vector<uint8_t> state, state_dev;
+    float *stage[2] = {nullptr, nullptr};    // page-locked [capacity][cap_ch][stage_frames[b]], rebuilt at every flush
+    size_t stage_floats[2] = {0, 0};
+    float *levels[2] = {nullptr, nullptr};   // page-locked [capacity][cap_ch]
+    uint8_t *silent[2] = {nullptr, nullptr};
+    bool valid[2] = {false, false};
+    float seconds = 1.0f / 60.0f;
+    bool failed = false;
+
+    bool create(const wf_config &c, int dev)
+    {
+        auto &a = api();
+        cfg = c;
+        device = dev;
+        capacity = group_capacity();
+        if(a.create(&c, dev, capacity, 0, &h) != WF_HIP_OK) {
+            h = nullptr;
+            return false;
+        }
+        cap_ch = c.capture_channels;
+        member.assign(capacity, nullptr);
+        submitted.assign(capacity, 0);
+        pending.assign(capacity, {});
+        frames.assign(capacity, 0);
+        state.assign(capacity, WF_HIP_PAUSED);
+        state_dev.assign(capacity, WF_HIP_SHOWN);
+        for(int i = 0; i < 2; ++i) {
+            levels[i] = static_cast<float *>(a.host_alloc((size_t)capacity * cap_ch * sizeof(float)));
+            silent[i] = static_cast<uint8_t *>(a.host_alloc(capacity));
+            if(levels[i] == nullptr || silent[i] == nullptr)
+                return false;
+        }
+        return true;
+    }
+
+    ~WFHipMeterGroup()
+    {
+        auto &a = api();
+        if(h)
+            a.destroy(h);
+        for(int i = 0; i < 2; ++i) {
+            if(stage[i]) a.host_free(stage[i]);
+            if(levels[i]) a.host_free(levels[i]);
+            if(silent[i]) a.host_free(silent[i]);
+        }
+    }
+
+    bool flush()
+    {
+        auto &a = api();
+        const uint32_t b = (uint32_t)(batch & 1);
+        uint32_t maxf = 0;
+        for(uint32_t i = 0; i < capacity; ++i) {
+            if(submitted[i] != batch) { // not ticked in this frame: left exactly as it is
+                state[i] = WF_HIP_PAUSED;
+                frames[i] = 0;
+            }
+            maxf = std::max(maxf, frames[i]);
+        }
+        bool ok = true;
+        if(state != state_dev) {
+            ok = a.set_hidden(h, 0, capacity, state.data()) == WF_HIP_OK;
+            state_dev = state;
+        }
+        if(ok && maxf > 0) {
+            a.ingest_done(h, b); // the slot's block has been copied out (two frames ago)
+            const size_t need = (size_t)capacity * cap_ch * maxf;
+            if(stage_floats[b] < need) {
+                if(stage[b]) a.host_free(stage[b]);
+                stage_floats[b] = need + need / 2;
+                stage[b] = static_cast<float *>(a.host_alloc(stage_floats[b] * sizeof(float)));
+                if(stage[b] == nullptr) {
+                    stage_floats[b] = 0;
+                    ok = false;
+                }
+            }
+            if(ok) {
+                for(uint32_t i = 0; i < capacity; ++i)
+                    for(uint32_t c = 0; c < cap_ch && frames[i]; ++c)
+                        std::memcpy(stage[b] + ((size_t)i * cap_ch + c) * maxf, pending[i].data() + (size_t)c * frames[i], (size_t)frames[i] * sizeof(float));
+                ok = a.push_audio_ragged_async(h, 0, capacity, stage[b], frames.data(), maxf, b) == WF_HIP_OK;
+            }
+        }
+        wf_hip_tick_params p{};
+        p.seconds = seconds;
+        ok = ok && a.tick(h, &p) == WF_HIP_OK;
+        ok = ok && a.read_meter_async(h, 0, capacity, levels[b], silent[b], b) == WF_HIP_OK;
+        valid[b] = ok;
+        ++batch;
+        n_submitted = 0;
+        std::fill(frames.begin(), frames.end(), 0u);
+        if(!ok) {
+            LogWarn << "HIP meter batch tick failed (" << a.last_error(h) << "); its sources fall back to the CPU path";
+            failed = true;
+        }
+        return ok;
+    }
+};
+
 namespace {
 
 struct Registry {
     std::mutex mtx;
     std::vector<std::unique_ptr<WFHipGroup>> groups;
+    std::vector<std::unique_ptr<WFHipMeterGroup>> mgroups;
 };
 Registry &registry()
 {
@@ -276,6 +394,20 @@ void WAVSourceHIP::hip_release()
     if(m_hip != nullptr) {
         api().destroy(m_hip);
         m_hip = nullptr;
+    }
+    if(m_mgroup != nullptr) {
+        auto &r = registry();
+        std::lock_guard lock(r.mtx);
+        auto g = m_mgroup;
+        m_mgroup = nullptr;
+        g->member[m_slot] = nullptr;
+        if(g->submitted[m_slot] == g->batch && g->n_submitted > 0)
+            --g->n_submitted;
+        g->submitted[m_slot] = 0;
+        g->frames[m_slot] = 0;
+        g->state[m_slot] = WF_HIP_PAUSED;
+        if(--g->members == 0)
+            r.mgroups.erase(std::remove_if(r.mgroups.begin(), r.mgroups.end(), [g](const auto &p) { return p.get() == g; }), r.mgroups.end());
     }
     if(m_group != nullptr) {
         auto &r = registry();
@@ -389,6 +521,58 @@ bool WAVSourceHIP::hip_configure()
         m_slot = slot;
         m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
         m_hip_prev.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
+        return true;
+    }
+    // level meter: join (or open) the batch of this meter configuration.  Meter buffers beyond 65536 samples (meter_buf above
+    // ~1.3 s; the reference allows 600 s) stay synchronous: a member's first hand-over is the whole buffer.
+    const char *mb = std::getenv("WF_HIP_BATCHED_METER"); // 0: the meter stays synchronous while the spectrum batches
+    if(c.meter && batched_mode() && m_fft_size <= 65536 && !(mb && mb[0] == '0')) {
+        auto &r = registry();
+        std::lock_guard lock(r.mtx);
+        WFHipMeterGroup *g = nullptr;
+        for(auto &p : r.mgroups)
+            if(!p->failed && p->members < p->capacity && std::memcmp(&p->cfg, &c, sizeof(c)) == 0) {
+                g = p.get();
+                break;
+            }
+        bool opened = false;
+        if(g == nullptr) {
+            const int ndev = std::max(api().device_count(), 1);
+            std::vector<int> load((size_t)ndev, 0);
+            for(auto &p : r.groups)
+                if(p->device >= 0 && p->device < ndev)
+                    ++load[(size_t)p->device];
+            for(auto &p : r.mgroups)
+                if(p->device >= 0 && p->device < ndev)
+                    ++load[(size_t)p->device];
+            int dev = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            if(const char *e = std::getenv("WF_HIP_DEVICE"))
+                dev = std::min(std::max(std::atoi(e), 0), ndev - 1);
+            auto fresh = std::make_unique<WFHipMeterGroup>();
+            if(!fresh->create(c, dev)) {
+                LogWarn << "HIP meter path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
+                return false;
+            }
+            g = fresh.get();
+            r.mgroups.push_back(std::move(fresh));
+            opened = true;
+        }
+        uint32_t slot = 0;
+        while(g->member[slot] != nullptr)
+            ++slot;
+        if(api().reset(g->h, slot, 1) != WF_HIP_OK) {
+            if(opened)
+                r.mgroups.erase(std::remove_if(r.mgroups.begin(), r.mgroups.end(), [g](const auto &p) { return p.get() == g; }), r.mgroups.end());
+            return false;
+        }
+        g->state_dev[slot] = WF_HIP_SHOWN; // (what reset leaves on the device: the next flush re-sends the slot's mask)
+        g->member[slot] = this;
+        m_hip_joined = g->batch;
+        g->submitted[slot] = 0;
+        g->state[slot] = WF_HIP_PAUSED;
+        ++g->members;
+        m_mgroup = g;
+        m_slot = slot;
         return true;
     }
     int dev = 0;
@@ -636,8 +820,69 @@ void WAVSourceHIP::tick_spectrum(float seconds)
 // would pop into its meter buffer this tick (everything older than the A/V-sync point, :201-220) goes to the device ring
 // instead; the device takes the level over the last m_fft_size consumed samples, smooths it, converts to dBFS and
 // decides m_last_silent; m_meter_val / m_last_silent come back for render_bars (src/source.cpp:1505-1509).
+// The batched meter path (struct WFHipMeterGroup): m_meter_val / m_last_silent are the device's results for the previous frame.
+void WAVSourceHIP::tick_meter_batched(float seconds)
+{
+    auto &a = api();
+    auto &r = registry();
+    std::unique_lock lock(r.mtx);
+    WFHipMeterGroup *g = m_mgroup;
+    const uint32_t slot = m_slot;
+    bool ok = !g->failed;
+    if(ok && g->submitted[slot] == g->batch) // came round again while the frame was still being assembled: complete it
+        ok = g->flush();
+    // 1. collect the levels the last flushed batch left for this source
+    const uint32_t last = (uint32_t)((g->batch - 1) & 1);
+    if(ok && g->batch > 1 && g->valid[last] && g->batch - 1 >= m_hip_joined) {
+        ok = a.readback_done(g->h, last) == WF_HIP_OK;
+        if(ok) {
+            for(auto channel = 0u; channel < m_capture_channels; ++channel)
+                m_meter_val[channel] = g->levels[last][(size_t)slot * g->cap_ch + channel];
+            m_last_silent = g->silent[last][slot] != 0;
+        }
+    }
+    if(!ok) {
+        lock.unlock();
+        LogWarn << "HIP meter batch unavailable; this source continues on the CPU path";
+        hip_release();
+        g_fallback_ticks.fetch_add(1);
+        WAVSourceGeneric::tick_meter(seconds);
+        return;
+    }
+    // 2. submit this frame: state, and what tick_meter would pop into its meter buffer (:201-220)
+    const auto dtcapture = m_tick_ts - m_capture_ts;
+    const bool timed_out = dtcapture > CAPTURE_TIMEOUT; // :184
+    uint32_t frames = 0;
+    if(!timed_out) {
+        const int64_t dtaudio = get_audio_sync(m_tick_ts);
+        const size_t dtsize = (dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) * sizeof(float) : 0;
+        size_t n_min = 0;
+        for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+            const auto sz = m_capturebufs[channel].size();
+            const size_t n = (sz > dtsize) ? (sz - dtsize) / sizeof(float) : 0;
+            n_min = (channel == 0) ? n : std::min(n_min, n);
+        }
+        frames = (uint32_t)n_min;
+        auto &dst = g->pending[slot];
+        dst.resize((size_t)m_capture_channels * frames);
+        for(auto channel = 0u; channel < m_capture_channels && frames; ++channel)
+            m_capturebufs[channel].pop_front(dst.data() + (size_t)channel * frames, (size_t)frames * sizeof(float));
+    }
+    g->frames[slot] = frames;
+    g->state[slot] = timed_out ? WF_HIP_HIDDEN_TIMEOUT : (m_show ? WF_HIP_SHOWN : WF_HIP_HIDDEN);
+    g->seconds = seconds;
+    g->submitted[slot] = g->batch;
+    ++g->n_submitted;
+    if(g->n_submitted >= g->members)
+        g->flush();
+}
+
 void WAVSourceHIP::tick_meter(float seconds)
 {
+    if(m_mgroup != nullptr) {
+        tick_meter_batched(seconds);
+        return;
+    }
     if(m_hip == nullptr) {
         g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_meter(seconds);

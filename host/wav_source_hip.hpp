@@ -34,9 +34,12 @@ protected:
     //  * batched (the default for the spectrum display): sources that share a configuration share one handle, as streams of
     //    one batch; every video frame each source hands over the audio its capture buffers gained, the frame's last source
     //    enqueues ONE tick for all of them and every source picks up its row one frame later (m_group / m_slot);
-    //  * synchronous (WF_HIP_BATCHED=0; always for the level meter and the waveform display): a handle of one stream per
-    //    source, push -> tick -> read inside the call, zero latency (m_hip).
+    //    The level meter batches the same way (m_mgroup): one ragged ingest of what every source's tick_meter consumes, one
+    //    meter_tick_kernel per video frame, levels one frame later;
+    //  * synchronous (WF_HIP_BATCHED=0; always for the waveform display): a handle of one stream per source,
+    //    push -> tick -> read inside the call, zero latency (m_hip).
     struct WFHipGroup *m_group = nullptr;
+    struct WFHipMeterGroup *m_mgroup = nullptr; // level meter, batched: the sources of one meter configuration share a handle too
     uint32_t m_slot = 0;
     uint64_t m_hip_joined = 0;         // the group's batch counter when this source took its slot
     bool m_hip_have_prev = false;      // m_hip_prev holds the window handed over at the previous tick
@@ -61,7 +64,7 @@ public:
 
     // true when a gfx950 device and libwaveform_hip.so are available (callbacks::create asks this first)
     static bool available();
-    bool using_hip() const { return m_hip != nullptr || m_group != nullptr; }
+    bool using_hip() const { return m_hip != nullptr || m_group != nullptr || m_mgroup != nullptr; }
     // ticks a HIP-configured source had to hand to the CPU class (underflow excepted: the reference skips those too)
     static uint64_t fallback_ticks();
     // update_input_rms calls served by the reference's host loop (0 for batched sources: the device keeps the RMS window)
@@ -69,6 +72,8 @@ public:
 
 private:
     void tick_spectrum_batched(float seconds);
+    void tick_meter_batched(float seconds);
     bool hip_window(size_t &dtframes);  // the A/V-synchronised window of every channel -> m_hip_window; false on underflow
     friend struct WFHipGroup;
+    friend struct WFHipMeterGroup;
 };

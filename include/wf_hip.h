@@ -174,7 +174,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
 #define WF_HIP_SHOWN 0
 #define WF_HIP_HIDDEN 1          /* !m_show */
 #define WF_HIP_HIDDEN_TIMEOUT 2  /* m_tick_ts - m_capture_ts > CAPTURE_TIMEOUT */
-#define WF_HIP_PAUSED 3          /* spectrum batches: the source was not ticked in this video frame (OBS ticks only active sources) --
+#define WF_HIP_PAUSED 3          /* spectrum and meter batches: the source was not ticked in this video frame (OBS ticks only active sources) --
                                     the next wf_hip_tick leaves the stream exactly as it is; cleared by any other value */
 #define WF_HIP_STARVED 4         /* spectrum batches whose host keeps the sources' own buffers (the plugin binding): the source holds fewer
                                     samples than window + A/V-sync delay (src/source_generic.cpp:55-61: every channel is skipped) -- the
@@ -239,6 +239,10 @@ int wf_hip_readback_done(wf_hip *h, uint32_t slot);
  * wf_hip_readback_done(slot) blocks until both have landed.  The next wf_hip_tick waits (on the device, not the host) for a
  * copy still in flight before it overwrites the rows. */
 int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_rows, uint8_t *pinned_last_silent, uint32_t slot);
+/* meter batches: m_meter_val ([count][capture_channels], dBFS) and m_last_silent (one byte per stream) as the ticks issued so
+ * far leave them, copied into page-locked memory on the readback stream without waiting; wf_hip_readback_done(slot) blocks
+ * until both have landed (the plugin's batched mode reads every source's level one video frame late) */
+int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_levels, uint8_t *pinned_last_silent, uint32_t slot);
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);

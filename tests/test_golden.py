@@ -183,6 +183,95 @@ def test_reference_plugin_with_batched_hip_tick(name):
             assert np.all(err <= 1e-5 * np.abs(z[f"bars_{t}"]) + 2e-3), f"{name} tick {t} bars: max err {err.max():.3e} px"
 
 
+METER_DROPIN = ["meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",
+                "meter_hide_show_timeout"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", METER_DROPIN)
+def test_reference_plugin_with_batched_hip_meter(name):
+    """The level meter in the plugin's batched mode (WFHipMeterGroup: sources of one meter configuration share a handle, one
+    meter_tick_kernel per video frame, levels read one frame later): every meter golden scenario, shifted by exactly one tick."""
+    wfref = _hip_env(batched=True)
+    sc = scenarios.SCENARIOS[name]
+    cfg = scenarios.make_config(sc["cfg"])
+    z, meta = _load(name)
+    before = wfref.hip_fallback_ticks()
+    late = _OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
+    assert late.be.src.using_hip
+    scenarios.play(late, sc)
+    recs = late.finish()
+    assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before
+    assert len(recs) == meta["n_ticks"]
+    silent = np.array([r["silent"] for r in recs], np.uint8)
+    assert np.array_equal(silent, z["silent"]), f"{name}: m_last_silent sequence {silent} != reference {z['silent']} (one frame late)"
+    for t, r in scenarios.recorded(recs, sc["record"]):
+        assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} levels, read one frame later", lin_eps=None)
+        if f"bars_{t}" in z.files:
+            err = np.abs(r["bars"].astype(np.float64) - z[f"bars_{t}"])
+            assert np.all(err <= 1e-5 * np.abs(z[f"bars_{t}"]) + 2e-3), f"{name} tick {t} bars: max err {err.max():.3e} px"
+
+
+@pytest.mark.gpu
+def test_sixty_four_meter_sources_share_one_batch():
+    """64 level-meter sources of one configuration: one handle, one ragged ingest + one meter_tick_kernel + one readback per
+    video frame.  Every source has its own audio and amplitude, some hide, stall or lose their capture along the way; each
+    one's m_meter_val at frame t+1 is what the restatement has at frame t.  Then the cost per source and frame against the
+    reference's AVX tick_meter in the same harness."""
+    import os
+    from tools import synth
+    from helpers import assert_levels_close
+    wfref = _hip_env(batched=True)
+    os.environ["WF_HIP_BATCH_CAPACITY"] = "64"
+    cfg_dict = dict(meter=1, meter_ms=150, gravity=0.3)
+    cfg = scenarios.make_config(cfg_dict)
+    n_src, frames, hop = 64, 40, 800
+    before = wfref.hip_fallback_ticks()
+    srcs = [scenarios.RefBackend(cfg, isa="hip") for _ in range(n_src)]
+    oras = [scenarios.OracleBackend(cfg) for _ in range(n_src)]
+    exact = [scenarios.OracleBackend(cfg, exact=True) for _ in range(n_src)]
+    assert all(s.src.using_hip for s in srcs)
+    want_prev = [None] * n_src
+    for f in range(frames):
+        for i, (s, o, x) in enumerate(zip(srcs, oras, exact)):
+            stalled = (i % 7 == 3) and f in (25, 26)         # no packet and no tick in these frames: the stream is paused
+            if f == 24 and i % 5 == 1:
+                s.set_hidden(True), o.set_hidden(True), x.set_hidden(True)
+            if f == 28 and i % 5 == 1:
+                s.set_hidden(False), o.set_hidden(False), x.set_hidden(False)
+            if stalled:
+                continue
+            if i % 11 == 4 and f == 30:
+                s.timeout(), o.timeout(), x.timeout()        # capture lost: the meter buffer is cleared, nothing is consumed
+            else:
+                a = synth.block(scenarios.SEED, 100 + i, 1, 2, f * hop, hop)[0] * np.float32(1.0 if i % 3 else 0.05)
+                for b in (s, o, x):
+                    b.push(a, muted=False)
+            for b in (s, o, x):
+                b.tick(1.0 / 60.0)
+            got = s.observe()
+            if want_prev[i] is not None:
+                w, e = want_prev[i]
+                assert got["silent"] == w["silent"] or got["silent"] == e["silent"], f"source {i} frame {f}"
+                assert_levels_close(got["db"], w["db"], e["db"], f"source {i} frame {f}: levels of the previous frame")
+            want_prev[i] = (o.observe(), x.observe())
+    assert all(s.src.using_hip for s in srcs) and wfref.hip_fallback_ticks() == before
+    del srcs
+    settings = dict(display_mode="level_meter", rms_mode=True, meter_buf=150, temporal_smoothing="exp_moving_avg", gravity=0.3)
+    v_hip, _ = wfref.bench("hip", settings, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED)
+    v_avx, _ = wfref.bench("avx2", settings, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED)
+    os.environ["WF_HIP_BATCHED_METER"] = "0"
+    try:
+        v_sync, _ = wfref.bench("hip", settings, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED)
+    finally:
+        del os.environ["WF_HIP_BATCHED_METER"]
+    us = lambda v: 2e6 / v  # (wfref_bench counts capture channels: a stereo source = 2 per frame)
+    print(f"\nplugin mode, 64 level meters (150 ms RMS, stereo): batched HIP {us(v_hip):.2f} us per source and frame, "
+          f"synchronous HIP {us(v_sync):.2f} us, reference AVX {us(v_avx):.2f} us")
+    assert wfref.hip_fallback_ticks() == before
+    assert us(v_hip) < us(v_sync) / 3, "one batch per frame must be several times cheaper than 64 upload/launch/download round trips"
+
+
 @pytest.mark.gpu
 def test_sixty_four_sources_share_one_batch():
     """64 WAVSourceHIP sources of one configuration in one fake-OBS process: one handle, one tick per video frame.  Every

@@ -445,8 +445,35 @@ def draw_meter(seed: int):
     return cfg, steps
 
 
-def run_meter_case(seed):
-    cfg_dict, steps = draw_meter(seed)
+METER_WIDE_SEEDS = range(60)
+
+
+def draw_meter_wide(seed: int):
+    """the level meter over the reference's slider ranges: meter_buf 10 ms ... 60 s (the property allows 600 s,
+    src/source.cpp:323: test_meter_buffer_up_to_the_reference_maximum plays that once), gravity 0 ... 1.0 inclusive, floor and
+    ceiling anywhere, bar geometry anywhere"""
+    r = np.random.default_rng(77000 + seed)
+    cfg = dict(meter=1, meter_rms=int(r.integers(0, 2)), meter_ms=int(r.choice([10, 20, 1000, 5000, 20000, 60000])),
+               capture_channels=int(r.integers(1, 3)), tsmoothing=int(r.integers(0, 3)),
+               gravity=float(np.float32(r.choice([0.0, 1.0, round(float(r.uniform(0, 1)), 2)]))), fast_peaks=int(r.integers(0, 2)),
+               floor_db=int(r.integers(-120, 1)), ceiling_db=int(r.integers(-120, 1)), height=int(r.choice([32, 225, 2160])),
+               rounded_caps=int(r.random() < 0.3), min_bar_height=int(r.choice([0, 3, 400])), bar_width=int(r.choice([1, 24, 256])))
+    steps = []
+    for _ in range(int(r.integers(8, 14))):
+        steps += [("noise_amp", int(r.choice([800, 441, 1024, 4800, 48000])), float(np.float32(r.choice([1.0, 0.3, 0.01])))),
+                  ("tick", float(np.float32(r.choice([1 / 60, 1 / 30, 1 / 144]))))]
+    kind = int(r.integers(0, 3))
+    if kind == 0:
+        steps += [("hide",), ("noise", 800), ("tick",), ("show",), ("noise", 800), ("tick",)]
+    elif kind == 1:
+        steps += [("timeout",), ("tick",), ("noise", 800), ("tick",)]
+    if r.random() < 0.25:
+        cfg.update(sample_rate=44100)
+    return cfg, steps
+
+
+def run_meter_case(seed, wide=False):
+    cfg_dict, steps = draw_meter_wide(seed) if wide else draw_meter(seed)
     cfg = scenarios.make_config(cfg_dict)
     sc = dict(cfg=cfg_dict, steps=steps, record="all")
     hip = scenarios.HipBackend(cfg, streams=3, probe=2)
@@ -475,6 +502,37 @@ def run_meter_case(seed):
 @pytest.mark.parametrize("seed", METER_SEEDS)
 def test_hip_meter_matches_oracle_on_random_case(seed):
     run_meter_case(seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", METER_WIDE_SEEDS)
+def test_hip_meter_matches_oracle_over_the_full_slider_ranges(seed):
+    run_meter_case(seed, wide=True)
+
+
+@pytest.mark.gpu
+def test_meter_buffer_up_to_the_reference_maximum():
+    """meter_buf = 600 000 ms, the property's maximum (src/source.cpp:323): a meter buffer of 28.8 M samples per channel -- a
+    512 MB ring per stereo stream on the device.  Levels after each of a few one-second packets against the restatement
+    (and its exactly summed twin: the reference's sequential float sum over 28.8 M squares drifts by itself)."""
+    import waveform_amd as wf
+    from oracle import restate
+    from tools import synth
+    cfg = wf.Config.defaults(meter=1, meter_rms=1, meter_ms=600000, tsmoothing=0)
+    ora, exact = restate.OracleMeter(cfg), restate.OracleMeter(cfg)
+    exact.set_exact(True)
+    with wf.SpectrumBatch(cfg, 2) as b:
+        assert b.fft_size == (48000 * 600) & ~15
+        for t in range(3):
+            audio = synth.block(synth.DEFAULT_SEED, 0, 1, 2, t * 48000, 48000) * np.float32(0.5 if t == 1 else 1.0)
+            b.push_audio(np.broadcast_to(audio, (2, 2, 48000)))
+            b.tick()
+            for o in (ora, exact):
+                o.push_audio(audio[0])
+                o.tick()
+            got = b.meter()
+            assert np.array_equal(got[0], got[1])
+            assert_levels_close(got[0], ora.levels(), exact.levels(), f"600 s meter buffer, packet {t}")
 
 
 @pytest.mark.gpu

@@ -1873,8 +1873,8 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
         return fail(h, WF_HIP_ERR_INVALID, "mask is NULL");
     if(h->meter || h->wave)
         for(uint32_t i = 0; i < count; ++i)
-            if(mask[i] == WF_HIP_PAUSED || mask[i] == WF_HIP_STARVED)
-                return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_PAUSED / WF_HIP_STARVED apply to spectrum batches only");
+            if((mask[i] == WF_HIP_PAUSED && h->wave) || mask[i] == WF_HIP_STARVED)
+                return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_STARVED applies to spectrum batches only, WF_HIP_PAUSED to spectrum and meter batches");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     if(h->mask_bytes < count) {
         rc = dev_alloc(h, &h->d_mask, (size_t)count);
@@ -2267,6 +2267,61 @@ int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pin
     WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
     h->read_used[slot] = true;
     h->rows_in_flight[slot] = true;
+    return WF_HIP_OK;
+}
+
+int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_levels, uint8_t *pinned_last_silent, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(!h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "not a meter batch (cfg.meter == 0)");
+    if(pinned_levels == nullptr || pinned_last_silent == nullptr || slot > 1)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL or slot is not 0 / 1");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->read_stream == nullptr) {
+        WF_HIP_TRY(h, hipStreamCreateWithFlags(&h->read_stream, hipStreamNonBlocking));
+        for(int i = 0; i < 2; ++i) {
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_snap[i], hipEventDisableTiming));
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_read[i], hipEventDisableTiming));
+        }
+    }
+    const size_t n = (size_t)count * h->cap_ch;
+    if(h->read_used[slot])
+        WF_HIP_TRY(h, hipEventSynchronize(h->ev_read[slot])); // the slot's previous copy has left its snapshot
+    if(h->snap_floats[slot] < n) {
+        dev_release(h, h->d_snap[slot]);
+        h->d_snap[slot] = nullptr;
+        const size_t want = std::max<size_t>(grown(h->snap_floats[slot], n), 64);
+        h->snap_floats[slot] = 0;
+        float *p = nullptr;
+        rc = dev_alloc(h, &p, want);
+        if(rc)
+            return rc;
+        h->d_snap[slot] = p;
+        h->snap_floats[slot] = want;
+    }
+    if(h->silent_bytes_cap[slot] < count) {
+        dev_release(h, h->d_silent_bytes[slot]);
+        h->d_silent_bytes[slot] = nullptr;
+        h->silent_bytes_cap[slot] = 0;
+        const size_t want = std::max<size_t>(count, 256);
+        rc = dev_alloc(h, &h->d_silent_bytes[slot], want);
+        if(rc)
+            return rc;
+        h->silent_bytes_cap[slot] = want;
+    }
+    // compute stream: a snapshot of the few floats behind the ticks enqueued so far (the next tick overwrites m_meter_val)
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_snap[slot], h->d_meter_val + (size_t)first * h->cap_ch, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(silent_bytes_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_flags, first, count, h->d_silent_bytes[slot]);
+    WF_HIP_TRY(h, hipGetLastError());
+    WF_HIP_TRY(h, hipEventRecord(h->ev_snap[slot], h->stream));
+    WF_HIP_TRY(h, hipStreamWaitEvent(h->read_stream, h->ev_snap[slot], 0));
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_levels, h->d_snap[slot], n * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_last_silent, h->d_silent_bytes[slot], count, hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
+    h->read_used[slot] = true;
     return WF_HIP_OK;
 }
 

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(METER_THREADS) void meter_tick_kernel(const MeterAr
     float *val = a.meter_val + (size_t)stream * a.cap_ch;
     float *bar = a.bars ? a.bars + (size_t)stream * a.cap_ch : nullptr;
 
+    // a source that was not ticked in this video frame (the plugin's batched mode: OBS ticks only active sources): nothing is
+    // consumed, nothing changes
+    if(sflags & WF_STREAM_PAUSED)
+        return;
     // the window in aligned 16-byte chunks: chunk j covers ring positions base + 4j .. +3 (never straddles the wrap)
     const uint32_t start = mend - a.size;
 
