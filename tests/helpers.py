@@ -41,6 +41,12 @@ def ref_settings(cfg, **extra) -> dict:
     return s
 
 
+# how often the linear arm decided (values that miss the dB arm and pass the linear one), and how many of those lie in the
+# range a display or the silence state machine can see (above -75 dB: the default floor - 10) -- reported by
+# tests/test_gpu_fuzz.py::test_zz_display_arm_stays_rare so that a regression leaning on the arm shows up as a count
+ARM_STATS = {"calls": 0, "values": 0, "linear_arm": 0, "linear_arm_visible": 0}
+VISIBLE_DB = -75.0
+
 LIN_EPS = 1e-6  # linear-domain arm: |d magnitude| <= LIN_EPS * the largest magnitude of the same frame (row)
 
 
@@ -62,11 +68,16 @@ def assert_db_close(got, want, what="", lin_eps=LIN_EPS, undo_db=None):
     err = np.abs(g64 - w64)
     tol = RTOL * np.abs(w64) + ATOL
     bad = err > tol
+    ARM_STATS["calls"] += 1
+    ARM_STATS["values"] += int(bad.size)
     if bad.any() and lin_eps and got.ndim >= 1 and got.shape[-1] > 1:
         off = 0.0 if undo_db is None else np.asarray(undo_db, np.float64)
         lg, lw = 10.0 ** ((g64 + off) / 20.0), 10.0 ** ((w64 + off) / 20.0)
         peak = lw.max(axis=-1, keepdims=True)
-        bad &= ~(np.abs(lg - lw) <= lin_eps * peak)
+        saved = bad & (np.abs(lg - lw) <= lin_eps * peak)
+        ARM_STATS["linear_arm"] += int(saved.sum())
+        ARM_STATS["linear_arm_visible"] += int((saved & (w64 > VISIBLE_DB)).sum())
+        bad &= ~saved
     if bad.any():
         i = int(np.argmax(np.where(bad, err - tol, -np.inf)))
         raise AssertionError(f"{what}: {int(bad.sum())} of {bad.size} values off; worst at flat index {i}: "

@@ -419,3 +419,40 @@ def test_displays_are_deterministic_under_load(n, streams, extra):
     for a, c, what in zip(res[0], res[1], ("bars", "rows", "silence flags")):
         assert np.array_equal(a, c), f"N={n}: {what} differ between two identical runs"
     assert np.all(np.isfinite(res[0][0]))
+
+
+@pytest.mark.parametrize("n", [1024, 4096, 16384])
+def test_starved_tick_in_the_middle_of_a_mono_mixdown(n):
+    """WF_HIP_STARVED in the middle of a stream (the host's buffers hold less than window + A/V-sync delay: every channel is
+    skipped, reference src/source_generic.cpp:55-61) with mono mixdown and volume normalisation: the end-of-tick pass still
+    runs (:138-179) and mixes row 0's stale dB values with channel 1's last smoothed magnitudes, which the reference keeps
+    linear in m_decibels[1] (:150-154).  With a gain that lifts row 0 above 0 dB the sum is positive and survives dbfs():
+    the device must reproduce it (from channel 1's smoothing state), tick for tick, and recover afterwards."""
+    cfg = wf.Config.defaults(fft_size=n, stereo=0, capture_channels=2, slope=1.0, normalize_volume=1, volume_target=-3.0, max_gain=45.0)
+    hop, streams = 800, 3
+    o = restate.OracleSource(cfg)
+    o.set_input_rms(0.004)  # -48 dBFS measured -> the full 45 dB of gain: most of row 0 ends up above 0 dB
+    with wf.SpectrumBatch(cfg, streams) as b:
+        for t in range(10):
+            a = synth.block(SEED, 0, 1, 2, t * hop, hop)
+            starved = t == 5  # (one tick: a second one would feed on the first one's ill-conditioned output)
+            if not starved:
+                b.push_audio(np.broadcast_to(a, (streams, 2, hop)))
+                o.push_audio(a[0])
+            b.set_hidden(np.full(streams, 4 if starved else 0, np.uint8))  # WF_HIP_STARVED
+            o.set_sync_delay(10 ** 7 if starved else 0)                     # the restatement underflows the reference's way
+            b.tick(input_rms=0.004)
+            o.tick(1.0 / 60.0)
+            got = b.decibels()
+            assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+            if t == 5:
+                assert np.any(o.decibels()[0] > wf.db_min() + 1), "the scenario must leave values above DB_MIN on the starved tick"
+            want = o.decibels()[:1]
+            if starved:
+                # dbfs((dB0 + mag1) / 2): a sum of a dB value of order 10 and a magnitude of order 1, both good to 1e-5 relative
+                # -- where the two nearly cancel, the dB of the sum is as ill-conditioned as it is meaningless.  Held in the
+                # domain of the sum itself: 1e-5 of the operands' size (|dB0| <= ~60) is 6e-4
+                lg, lw = 10.0 ** (got[0][:1].astype(np.float64) / 20), 10.0 ** (want.astype(np.float64) / 20)
+                assert np.all(np.abs(lg - lw) <= 1e-3 + 1e-5 * lw), f"N={n} tick {t} (starved): max {np.abs(lg - lw).max():.3e} in the mixed sum"
+            else:
+                assert_db_close(got[0][:1], want, f"N={n} tick {t}")

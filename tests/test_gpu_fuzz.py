@@ -715,6 +715,11 @@ def test_zz_display_arm_stays_rare():
     """runs last in this module: the second arm of the display check (bars / curve held against the render of the device's
     own rows) may be taken by at most 5 of 1000 display checks, and every configuration the draws produce must have been
     accepted -- WF_HIP_ERR_UNSUPPORTED is legal only for the corners include/wf_hip.h documents, none of which a draw reaches"""
+    import helpers
+    st = helpers.ARM_STATS
+    print(f"rows: {st['values']} dB values in {st['calls']} comparisons; decided by the linear arm {st['linear_arm']} "
+          f"({st['linear_arm'] / max(st['values'], 1):.2e}), of them above {helpers.VISIBLE_DB} dB {st['linear_arm_visible']} "
+          f"({st['linear_arm_visible'] / max(st['values'], 1):.2e})")
     print(f"display checks {ARM['display_checks']}, second arm taken {ARM['display_arm']}: {ARM['arm_cases'][:10]}")
     print(f"unsupported configurations: {len(ARM['unsupported'])}: {ARM['unsupported'][:10]}")
     if ARM["display_checks"] >= 200:

@@ -405,7 +405,14 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         // store into a pointer phi over scratch and global memory, which its backend cannot select)
         // (underflow in mono mixdown: both channels take row 0, which no tick has filled yet -- DB_MIN, as m_decibels[1] is
         // in the reference at that point; the mean of two negative rows is negative: DB_MIN again)
-        load_row<RG, BLU>(((WF_TRACK && a.bars_only != nullptr) && !mono_mix) ? a.stale_row : rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
+        // (mono mixdown, channel 1: the reference adds m_decibels[1] -- channel 1's last smoothed magnitudes, left linear by
+        // :150-154 -- to row 0's stale dB values.  With temporal smoothing on those magnitudes are this channel's smoothing
+        // state; with smoothing off nothing holds them and row 0 stands in: a stated deviation for a starved tick in the middle
+        // of a stream, where the sum is garbage either way)
+        const float *stale = ((WF_TRACK && a.bars_only != nullptr) && !mono_mix) ? a.stale_row
+                             : (mono_mix && ch == 1 && (a.mode & WF_MODE_TSMOOTH)) ? ts
+                                                                                    : rows + (size_t)(mono_mix ? 0u : ch) * MO;
+        load_row<RG, BLU>(stale, t, mag, NB);
         // Waited for here, inside the rare branch.  Left to the compiler the wait lands where the branches meet, in front of
         // the dB math of every workgroup -- and as the loads are the youngest operations of this path, it is a wait for
         // everything (vector-memory operations complete in order): the common path then sat out the acknowledgement of its
