@@ -290,23 +290,15 @@ def configs4_region(wf, torch, dist, rank, world, local_rank, steps, lead_in_ms=
         full = gather.wait()                                             # [total][2][26] on this rank
         own = torch.empty((streams, batch.display_channels, batch.num_bars), dtype=torch.float32, device="cuda")
         batch.copy_bars_to_device(own.data_ptr())
-        own_sum = own.view(torch.int32).to(torch.int64).sum().reshape(1)
-        blocks = full.view(torch.int32).to(torch.int64).reshape(world, -1).sum(dim=1)   # equal shards: total = world * streams
+        from waveform_amd.dist import verify_gathered
+        verified = verify_gathered(full, own, shard)   # (collective when world > 1: every rank checks the copy it received)
         times = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         if dist is not None:
-            sums = [torch.empty_like(own_sum) for _ in range(world)]
-            dist.all_gather(sums, own_sum)
-            sums = torch.cat(sums)
             tl = [torch.empty_like(times) for _ in range(world)]
             dist.all_gather(tl, times)
             tl = torch.stack(tl).cpu().numpy()
-            ok = torch.tensor([int(bool(torch.equal(blocks, sums)))], dtype=torch.int32, device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank checks the copy it received
-            verified = bool(ok.item())
         else:
-            sums = own_sum
             tl = times.cpu().numpy()[None]
-            verified = bool(torch.equal(blocks, sums))
         finite = bool(torch.isfinite(full).all().item())
         wall = float(tl[:, 0].max())
         dev_ms = [float(x) for x in tl[:, 1]]
@@ -317,7 +309,8 @@ def configs4_region(wf, torch, dist, rank, world, local_rank, steps, lead_in_ms=
             "streams_total": total, "streams_per_gpu": streams, "spectra_per_tick": spectra * world, "steps": steps, "warmup": warm,
             "value": spectra * world * steps / wall, "unit": "spectra/s", "ms_per_step": wall * 1e3 / steps,
             "device_ms_per_tick": {"min": min(dev_ms), "max": max(dev_ms), "per_rank": dev_ms},
-            "collective": ("all_gather_into_tensor (RCCL, backend nccl)" if world > 1 else "none (world 1: the local device copy of the same path)"),
+            "collective": (f"all_gather_into_tensor (backend {dist.get_backend()}{': RCCL' if dist.get_backend() == 'nccl' else ''})" if world > 1
+                           else "none (world 1: the local device copy of the same path)"),
             "gathered_bytes_per_rank_per_tick": int(streams * batch.display_channels * batch.num_bars * 4),
             "gathered_bytes_total_per_tick": int(total * batch.display_channels * batch.num_bars * 4),
             "verified": verified and finite,
@@ -387,6 +380,9 @@ def main():
         args.gpus = self_launch(args)  # returns only when a single device is measured in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test aid (tests/test_gpu_fullsize.py): the multi-rank code path on a box with fewer devices than ranks -- the ranks share
+    # the devices there are and the collectives run on gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    share = os.environ.get("WF_BENCH_SHARE_DEVICES") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
     import torch
@@ -395,12 +391,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (torch.cuda.is_available() is False)", file=sys.stderr)
         sys.exit(3)
+    if share:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = wf.Config.defaults(fft_size=args.fft, stereo=1, slope=1.0, window=wf.WINDOW["hann"],
                              tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)

@@ -54,6 +54,13 @@ def _worker(rank, world, port, total, out_dir):
         o.render_bars()
         local[i] = o.bars()
     full = allgather_bars(torch.from_numpy(local), sh)
+    # the verification bench.py's configs4 region runs after its timed gathers: every rank's copy, block by block
+    from waveform_amd.dist import verify_gathered
+    assert verify_gathered(full, torch.from_numpy(local), sh)
+    broken = full.clone()
+    if rank == 1:
+        broken[0, 0, 0] += 1.0          # one rank holds one wrong value: every rank must hear about it
+    assert not verify_gathered(broken, torch.from_numpy(local), sh)
     # the timing reduction bench.py does: max over ranks
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

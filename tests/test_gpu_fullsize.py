@@ -139,6 +139,37 @@ def test_bars_gather_world1_and_self_launching_bench():
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
 
 
+def test_bench_multi_rank_path_with_the_collective():
+    """bench.py as the driver launches it for N > 1 -- torch.distributed.run, one process per rank, the headline region, then
+    BASELINE configs[4] with the all-gather of the bar heights under the next tick and the per-rank checksum verification --
+    on this box's devices: with fewer devices than ranks the ranks share them and the collectives run on gloo (test aid
+    WF_BENCH_SHARE_DEVICES; on a box with two devices and more this is RCCL).  The line must carry n_gpus = 2 and a verified
+    configs4 object with both ranks' device times."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    import socket
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if wf.device_count() < 2:
+        env["WF_BENCH_SHARE_DEVICES"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--lead-in-ms", "5"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    c4 = line["configs4"]
+    assert "error" not in c4, c4
+    assert c4["verified"] is True and c4["streams_total"] == 2 * 8192 and len(c4["device_ms_per_tick"]["per_rank"]) == 2
+    assert "all_gather" in c4["collective"]
+
+
 def test_cfg3_gain_invariance_full_batch():
     """linearity of the path up to the dB stage: doubling every sample adds exactly 20*log10(2) dB
     (float scaling by 2 is exact through window, FFT, |X|, slope and the EMA)."""

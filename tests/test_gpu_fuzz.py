@@ -722,6 +722,8 @@ def test_zz_display_arm_stays_rare():
           f"({st['linear_arm_visible'] / max(st['values'], 1):.2e})")
     print(f"display checks {ARM['display_checks']}, second arm taken {ARM['display_arm']}: {ARM['arm_cases'][:10]}")
     print(f"unsupported configurations: {len(ARM['unsupported'])}: {ARM['unsupported'][:10]}")
+    if st["values"] >= 10_000_000:  # the whole module ran in this process
+        assert st["linear_arm"] <= 1e-5 * st["values"] and st["linear_arm_visible"] <= 1e-6 * st["values"], st
     if ARM["display_checks"] >= 200:
         assert ARM["display_arm"] <= max(1, 5 * ARM["display_checks"] // 1000), ARM["arm_cases"][:20]
     assert not ARM["unsupported"], ARM["unsupported"][:20]

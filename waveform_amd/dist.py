@@ -59,6 +59,32 @@ def allgather_bars(local, shard: Shard, group=None):
     return torch.cat(parts, dim=0)
 
 
+def bars_checksum(t):
+    """exact, order-independent checksum of a float32 tensor: the int64 sum of its bit patterns"""
+    import torch
+    return t.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
+
+
+def verify_gathered(full, own, shard: Shard, group=None) -> bool:
+    """Every rank checks the gathered copy it received: block r of `full` ([shard.total, ...] in global stream order) must
+    carry the checksum rank r computed over its own bars (`own`: [shard.count, ...]); the per-rank checksums travel by
+    all_gather, the verdicts by an all_reduce(MIN) -- True on every rank only if every copy is right on every rank."""
+    import torch
+    import torch.distributed as dist
+    mine = bars_checksum(own)
+    if shard.world == 1:
+        return bool(torch.equal(bars_checksum(full), mine))
+    sums = [torch.empty_like(mine) for _ in range(shard.world)]
+    dist.all_gather(sums, mine, group=group)
+    ok = True
+    for r in range(shard.world):
+        sh = shard_streams(shard.total, r, shard.world)
+        ok = ok and bool(torch.equal(bars_checksum(full[sh.first:sh.first + sh.count]), sums[r]))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=full.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
 class BarsGather:
     """The per-tick exchange of BASELINE configs[4], overlapped: after tick i the handle copies its bars into one of two
     send buffers on its own stream (wf_hip_copy_bars_device_async) and goes on with tick i+1; the all-gather of tick i runs
