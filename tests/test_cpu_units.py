@@ -224,6 +224,43 @@ def test_power_of_two_kernels_do_not_spill():
     assert seen >= 12
 
 
+def test_compatibility_path_kernels_stay_near_their_register_budget(tmp_path):
+    """The Bluestein instantiations (two transforms and a chirped fetch of six registers per point in one kernel) and the
+    65536-sample rows kernel (column step folded into its fetch) do not fit 128 registers: they keep 48-200 B per lane in
+    scratch.  Tolerated on these paths -- but bounded here, so that a change that pushes a kernel into
+    a kilobyte of scratch (the fused 65536 kernel that was abandoned had 1-2 KB) is seen."""
+    src = ROOT / "waveform_amd" / "csrc"
+    tu = tmp_path / "compat.hip"
+    tu.write_text('''#include <hip/hip_runtime.h>
+#include "wf_hip.h"
+#include "wf_host_tables.hpp"
+#include "wf_kernels.hpp"
+#include "wf_big.hpp"
+template __global__ void wf::spectrum_tick_kernel<wf::G2048, 2, false, false, 0, false, true, false>(wf::TickArgs);
+template __global__ void wf::spectrum_tick_kernel<wf::G4096, 2, false, false, 0, false, true, false>(wf::TickArgs);
+template __global__ void wf::spectrum_tick_kernel<wf::G16384, 1, false, true, 0, false, true, false>(wf::TickArgs);
+template __global__ void wf::big_rows_fold_kernel<true>(wf::TickArgs);
+template __global__ void wf::big_rows_fold_kernel<false>(wf::TickArgs);
+template __global__ void wf::big_epilogue_kernel<3>(wf::TickArgs);
+''')
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-slp-vectorize", f"-I{ROOT / 'include'}", f"-I{src}",
+           "-Rpass-analysis=kernel-resource-usage", "-c", str(tu), "-o", "/dev/null"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, seen = None, {}
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and ("spectrum_tick_kernel" in name or "big_rows_fold" in name or "big_epilogue_kernelILi3" in name):
+            seen[name] = int(m.group(1))
+    assert len(seen) == 6, seen
+    for name, scratch in seen.items():
+        limit = 0 if "epilogue" in name else 256
+        assert scratch <= limit, f"{name}: {scratch} B of scratch per lane (limit {limit})"
+
+
 # ---- C ABI -----------------------------------------------------------------------------------------------
 def _declared_functions(header: Path):
     text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)

@@ -637,13 +637,6 @@ template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float
             r.win[j][e] = 1.0f;
         if(j >= 1 && tw1_row_loaded(j))
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
-#if defined(__HIPCC__) && defined(WF_BLU_FETCH_SPLIT)
-        // six registers per point are in flight until a point's product is formed (two samples, four table values): issued as
-        // one burst over all R1 rows that is 96 registers and more, and the kernel spills; in WF_BLU_FETCH_SPLIT groups of rows
-        // the burst stays inside the register file at the price of R1 / WF_BLU_FETCH_SPLIT round trips instead of one
-        if((j + 1) % WF_BLU_FETCH_SPLIT == 0 && j + 1 < R1)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
     }
     return (acc & 0x7fffffffu) != 0;
 }
@@ -721,9 +714,6 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
             if(TS)
                 st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
         }
-#if defined(__HIPCC__) && defined(WF_BLU_P4_FENCE)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 }
 template<class G> WF_DEV void p4_direct(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
