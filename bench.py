@@ -141,7 +141,7 @@ def roofline(batch, shape, kernel_ms, flags=0, wall_ms=None):
     prof = pmc_profile(shape) if shape else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "frac_wall": (algo / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if wall_ms else None,
-           "traffic": (prof[1].get("hbm_bytes_per_tick") or prof[1]["hbm_bytes_per_launch"]) if prof else None,
+           "traffic": (prof[1].get("hbm_bytes_per_tick_all_kernels") or prof[1].get("hbm_bytes_per_tick") or prof[1]["hbm_bytes_per_launch"]) if prof else None,
            "traffic_source": (f"profiles/{prof[0]} (committed rocprofv3 --pmc passes of this shape; not measured in this run)" if prof else None),
            "kernel": batch.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_tick": algo,
            "algorithmic_bytes_per_kernel_launch": algo // max(batch.launches_per_tick(), 1),
@@ -195,6 +195,11 @@ def shape_list(wf):
          wf.Config.defaults(fft_size=2048, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["none"]), 256, 60, 0, "cfg2_batch"),
         ("configs[4] per-GPU shape: 8192 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars only (no m_decibels store)",
          wf.Config.defaults(fft_size=4096, bars=1, interp_mode=wf.INTERP["lanczos"], **ema), 8192, 60, wf.TICK_NO_DECIBELS, "cfg5shape_8192streams_barsonly"),
+        # the ends of the reference's FFT range (not BASELINE configs; reported so that the driver's line carries them too)
+        ("fft_size 65536 (the reference's maximum, 'enable large FFT'): 256 stereo streams, EMA + slope; rows kernel with the column step and the "
+         "real split folded in + epilogue", wf.Config.defaults(fft_size=65536, **ema), 256, 30, 0, "n65536"),
+        ("fft_size 800 (the plugin's automatic size at 48 kHz / 60 fps; packed Bluestein over 1024 complex points): 8192 stereo streams, EMA + slope",
+         wf.Config.defaults(fft_size=800, **ema), 8192, 60, 0, "blu800"),
     ]
     return shapes
 
