@@ -487,3 +487,29 @@ def test_starved_tick_in_the_middle_of_a_mono_mixdown(n):
                 assert np.all(np.abs(lg - lw) <= 1e-3 + 1e-5 * lw), f"N={n} tick {t} (starved): max {np.abs(lg - lw).max():.3e} in the mixed sum"
             else:
                 assert_db_close(got[0][:1], want, f"N={n} tick {t}")
+
+
+@pytest.mark.parametrize("n,loud,quiet", [(4096, 2000.0, 1e-24), (65536, 200.0, 1e-24), (800, 2000.0, 1e-24), (30000, 8.0, 1e-16)])
+def test_magnitude_range_headroom_and_floor(n, loud, quiet):
+    """|X|^2 = re^2 + im^2 is the one place where the path squares.  The device's window tables carry 2^40 (2^24 on the
+    Bluestein path through device memory) so that the square neither underflows for very quiet frames -- the reference's
+    hypotf answers for the whole float range; here down to |X| ~ 1e-31 -- nor overflows below the documented amplitudes
+    (256 at N = 65536, 4000 at N = 4096).  Audio scaled by a power of two far outside [-1, 1] in both directions must give
+    the oracle's rows, shifted by exactly 20 log10 of the factor."""
+    cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=0.0, tsmoothing=wf.TSMOOTH["none"])
+    hop, ticks = 800, 3
+    blocks = [synth.block(SEED, 0, 1, 2, t * hop, hop)[0] for t in range(ticks)]
+    for factor in (1.0, loud, quiet):
+        g = np.float32(2.0 ** np.round(np.log2(factor)))   # a power of two: the scaling is exact
+        o = restate.OracleSource(cfg)
+        with wf.SpectrumBatch(cfg, 2) as b:
+            for t in range(ticks):
+                a = blocks[t] * g
+                b.push_audio(np.broadcast_to(a, (2, 2, hop)))
+                b.tick()
+                o.feed_and_tick(a)
+            got = b.decibels()[1]
+        assert np.all(np.isfinite(got)), f"N={n} factor {g}: non-finite rows"
+        assert_db_close(got, o.decibels(), f"N={n}, audio scaled by {g}")
+        if factor != 1.0:
+            assert np.median(got) > wf.db_min() + 50, "the scaled frame must not have collapsed to DB_MIN"
