@@ -467,11 +467,8 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
                     const int other = m->shard[j]->device;
                     int can = 0;
                     if(other != s.device && hipDeviceCanAccessPeer(&can, s.device, other) == hipSuccess && can) {
-                        const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
-                        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-                            (void)hipGetLastError(); // not fatal: the copies still work, staged
-                        else
-                            (void)hipGetLastError();
+                        (void)hipDeviceEnablePeerAccess(other, 0); // (already enabled / refused: not fatal, the copies still work, staged)
+                        (void)hipGetLastError();
                     }
                 }
             return (int)WF_HIP_OK;

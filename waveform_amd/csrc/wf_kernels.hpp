@@ -82,6 +82,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
                        // learned since (paused streams, underflow, bars-only tracking, lanes) it spilled 36 B per lane at the
                        // 96-register cap and ran 10 % slower than at 4 (tests/test_cpu_units.py now checks for scratch)
 #endif
+#ifndef WF_WPS_2048_BLU
+#define WF_WPS_2048_BLU 4 // (+3-4 % over three waves and no scratch, measured: 52 B of scratch per lane weigh less than a fourth wave) the Bluestein instantiation of the same geometry (fft sizes 528 ... 1008, the automatic size 800 among them)
+#endif
 #ifndef WF_WPS_2048
 #define WF_WPS_2048 3
 #endif
@@ -143,7 +146,7 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // spectra.  A template parameter, not a run-time flag: the extra code cost the 2048-point kernel a VGPR too many (129: three
 // waves per SIMD instead of four) and 5-15 % even on configurations that never take the path.
 template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false>
-__global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
+__global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
     static_assert(!BOTH || (SPW == 2 && !SPLIT && DEC == 0 && !BLU), "shared curve row: two spectra per workgroup, power-of-two sizes");
     static_assert(!BLU || (DEC == 0 && !TLDS && !ALIGNED), "Bluestein path: scalar fetch, no decimation, no staged tables");
@@ -220,13 +223,15 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     bool nz = false;
     if constexpr(BLU) {
         if(active)
-            nz = p1_fetch_blu<G>(a, t, x, start, r1) && !hidden;
+            nz = (blu_table_via_lds<G>() ? p1_fetch_blu<G>(a, t, x, start, r1) : p1_fetch_blu_direct<G>(a, t, x, start, r1)) && !hidden;
     } else if(active)
         nz = p1_fetch<G, ALIGNED, DEC, TLDS>(a, t, x, start, r1) && !hidden;
     if constexpr(TLDS) {
         lds_dma_copy<G::N * (int)sizeof(float)>(a.window, smem_raw, wave_in_block, T * SPW / 64, lane);
         lds_dma_copy<G::M * (int)sizeof(cf)>(a.tw1, smem_raw + G::N * sizeof(float), wave_in_block, T * SPW / 64, lane);
     }
+    if constexpr(BLU && blu_table_via_lds<G>()) // the chirped window: staged in the (still free) exchange buffer, see p1_fetch_blu
+        blu_table_to_lds(a, smem_raw, wave_in_block, T * SPW / 64, lane);
     // the workgroup's copy of the pass-2 twiddles: LDS-DMA (no staging registers), requested behind the window so that it
     // costs no round trip of its own; complete at the barrier below
     lds_dma_copy<G::R2 * G::R3 * (int)sizeof(cf)>(a.tw2, tw2_lds, wave_in_block, T * SPW / 64, lane);
@@ -321,8 +326,18 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
         if(process)
             p1_store<G>(t, lds, o1);
     }
+    if constexpr(BLU && blu_table_via_lds<G>()) {
+        cf o1[G::R1][G::B1];
+        if(process) {
+            blu_products_from_lds<G>(a, t, reinterpret_cast<const cf *>(smem_raw), r1);
+            p1_window_dft<G>(r1, o1);
+        }
+        __syncthreads(); // every thread has taken its table entries: pass 1 may overwrite the staged table
+        if(process)
+            p1_store<G>(t, lds, o1);
+    }
     if(process) {
-        if constexpr(!TLDS)
+        if constexpr(!TLDS && !(BLU && blu_table_via_lds<G>()))
             p1_window_pass1<G>(a, t, r1, lds);
         if constexpr(DEC > 0)
             p4_prefetch_dec<G, DEC>(a, t, ts, r4);
@@ -354,24 +369,31 @@ __global__ __launch_bounds__(G::T *SPW, WF_WAVES_PER_SIMD(G)) void spectrum_tick
     WF_STAMP(7);
     spectrum_sync<G>();
     if constexpr(BLU) {
-        // second transform: conj(FFT(a) . FFT(b)) read from the natural-order buffer, then passes 1-3 again
+        // second transform: conj(FFT(a) . FFT(b)) read from the natural-order buffer, then passes 1-3 again.
+        // The thread index goes through an opaque move first: with the same `t` the compiler shares the exchange-buffer address
+        // arithmetic of the two transforms and keeps the first one's addresses alive across everything in between (44-116 B of
+        // scratch per lane became 24-68 B); recomputing a few integer operations is free
+        int t2 = t;
+#if defined(__HIPCC__)
+        asm volatile("" : "+v"(t2));
+#endif
         if(process)
-            blu_mid<G>(a, t, lds, r1);
+            blu_mid<G>(a, t2, lds, r1);
         spectrum_sync<G>(); // every thread has read its points: pass 1 may overwrite the buffer
         if(process)
-            p1_window_pass1<G>(a, t, r1, lds);
+            p1_window_pass1<G>(a, t2, r1, lds);
         spectrum_sync<G>();
         if(process)
-            p2_read<G>(t, lds, v);
+            p2_read<G>(t2, lds, v);
         spectrum_sync<G>();
         if(process)
-            p2_pass2_write<G>(tw2_lds, t, lds, v);
+            p2_pass2_write<G>(tw2_lds, t2, lds, v);
         spectrum_sync<G>();
         if(process)
-            p3_read<G>(t, lds, v);
+            p3_read<G>(t2, lds, v);
         spectrum_sync<G>();
         if(process)
-            p3_pass3_write<G>(t, lds, v);
+            p3_pass3_write<G>(t2, lds, v);
         spectrum_sync<G>();
     }
     WF_STAMP(8);

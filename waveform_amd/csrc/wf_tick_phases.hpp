@@ -612,9 +612,41 @@ template<class G> WF_DEV void p4_prefetch(const TickArgs &a, int t, const float 
 // X_k = conj(w_k) sum_j (x_j conj(w_j)) w_(k-j), w_m = exp(i pi m^2 / n): a circular convolution of length M >= 3n/2 done
 // with two M-point complex transforms of the same core.  The product a_j = x_j * (window_j conj(w_j)) is the first
 // transform's input, already complex: it goes through p1_window_dft with a window of ones.
+// The chirped window (two complex factors per point, 16 bytes -- twice the samples' own size) does not come in with the samples:
+// six registers per point in flight were 96 and more for the burst, and the Bluestein kernels spilled (48-108 B per lane,
+// rounds 1-2).  The workgroup stages the table in its exchange buffers by LDS-DMA instead (blu_table_to_lds: np * 16 bytes
+// <= one buffer, free until pass 1 stores into it), p1_fetch_blu fetches the raw sample pairs only, and the products are
+// formed behind the workgroup's first barrier from LDS (blu_products_from_lds) -- the structure of the TLDS path.
 template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
 {
-    // packed form (wf_host_tables.hpp): point j of the transform is x[2j] * blu_a[2j] + x[2j+1] * blu_a[2j+1], j < blu_n / 2
+    // packed form (wf_host_tables.hpp): point j of the transform is x[2j] * blu_a[2j] + x[2j+1] * blu_a[2j+1], j < blu_n / 2;
+    // here: the pair (x[2j], x[2j+1]) of every point of this thread, zero beyond the window
+    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    const uint32_t np = a.blu_n >> 1;
+    uint32_t acc = 0;
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        WF_UNROLL
+        for(int b = 0; b < B1; ++b) {
+            const uint32_t idx = (uint32_t)(j * M1 + B1 * t + b);
+            const bool in = idx < np;
+            const uint32_t s = start + 2u * (in ? idx : 0u);
+            const float v0 = x[s & a.ring_mask], v1 = x[(s + 1u) & a.ring_mask];
+            const float x0 = in ? v0 : 0.0f, x1 = in ? v1 : 0.0f;
+            acc |= f32_bits(x0) | f32_bits(x1);
+            r.smp[j][2 * b] = x0;
+            r.smp[j][2 * b + 1] = x1;
+        }
+        if(j >= 1 && tw1_row_loaded(j))
+            p1_load_tw1<G>(a, t, j, r.tw1[j]);
+    }
+    return (acc & 0x7fffffffu) != 0;
+}
+// the one- and two-round-trip form for the smallest geometries (eight points per thread and fewer: 48 registers in flight fit,
+// and the staging barrier costs more than it saves there: N = 496 0.283 -> 0.277 with the table through LDS, measured):
+// table entries fetched with the samples, products formed on the spot
+template<class G> WF_DEV bool p1_fetch_blu_direct(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r)
+{
     constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
     const uint32_t np = a.blu_n >> 1;
     uint32_t acc = 0;
@@ -639,6 +671,49 @@ template<class G> WF_DEV bool p1_fetch_blu(const TickArgs &a, int t, const float
             p1_load_tw1<G>(a, t, j, r.tw1[j]);
     }
     return (acc & 0x7fffffffu) != 0;
+}
+template<class G> constexpr bool blu_table_via_lds() { return G::P > 8; }
+#if defined(__HIPCC__)
+// blu_a[0 .. 2 np) -> the start of the workgroup's LDS, 1 KB per wave-wide request, the waves sharing the requests
+WF_DEV void blu_table_to_lds(const TickArgs &a, void *lds_dst, int wave, int n_waves, int lane)
+{
+    const uint32_t bytes = (a.blu_n >> 1) * 16u;
+    for(uint32_t c = (uint32_t)wave; c * 1024u < bytes; c += (uint32_t)n_waves) { // wave-uniform
+        const uint32_t off = c * 1024u + (uint32_t)lane * 16u;
+        if(off < bytes) {
+            const char *g = reinterpret_cast<const char *>(a.blu_a) + off;
+            char *l = static_cast<char *>(lds_dst) + c * 1024u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+        }
+    }
+}
+#else
+WF_DEV void blu_table_to_lds(const TickArgs &a, void *lds_dst, int wave, int, int lane)
+{
+    if(wave == 0 && lane == 0)
+        for(uint32_t i = 0; i < (a.blu_n >> 1) * 2u; ++i)
+            static_cast<cf *>(lds_dst)[i] = a.blu_a[i];
+}
+#endif
+// a_j = x[2j] T1_j + x[2j+1] T2_j with (T1_j, T2_j) = tab[2j], tab[2j+1] from LDS; r.smp holds the sample pairs on entry
+template<class G> WF_DEV void blu_products_from_lds(const TickArgs &a, int t, const cf *tab, P1Regs<G> &r)
+{
+    constexpr int R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    const uint32_t np = a.blu_n >> 1;
+    WF_UNROLL
+    for(int j = 0; j < R1; ++j) {
+        WF_UNROLL
+        for(int b = 0; b < B1; ++b) {
+            const uint32_t idx = (uint32_t)(j * M1 + B1 * t + b);
+            const f4 q = lds_ld4(tab, (int)(2u * (idx < np ? idx : 0u))); // (beyond the window the samples are zero: any finite entry does)
+            const float x0 = r.smp[j][2 * b], x1 = r.smp[j][2 * b + 1];
+            r.smp[j][2 * b] = fmaf(x1, q.z, x0 * q.x);
+            r.smp[j][2 * b + 1] = fmaf(x1, q.w, x0 * q.y);
+        }
+        WF_UNROLL
+        for(int e = 0; e < 2 * B1; ++e)
+            r.win[j][e] = 1.0f;
+    }
 }
 template<class G> WF_DEV void blu_mid(const TickArgs &a, int t, const cf *lds, P1Regs<G> &r)
 {
