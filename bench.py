@@ -429,7 +429,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     gather = None
     if args.bars_allgather:
