@@ -580,7 +580,10 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     }
 
     // ---- bars: what render_bars derives from the rows just written (reference src/source.cpp:1500-1557) ---------------
-    if(a.bar.out != nullptr) {
+#ifndef WF_EXP_NO_TAIL
+#define WF_EXP_NO_TAIL 0 // 1 (measurement only, the bars come out wrong): the display phase skipped -- what a tick would cost if the tail were free
+#endif
+    if(a.bar.out != nullptr && !WF_EXP_NO_TAIL) {
         // mono mixdown displays one row per stream: its curve points are shared by the threads of both spectra of the workgroup
         // (the plugin's default configuration: 800 points, 4 steps of 256 threads instead of 7 of 128)
         constexpr bool both = BOTH;
