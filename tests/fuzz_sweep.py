@@ -18,6 +18,7 @@ run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_
 
 for _fam in ("pow2", "any", "huge"):
     run["batched-" + _fam] = (lambda fam: (lambda s: f.run_dropin_batched_case(s, fam)))(_fam)
+run["batched-meter"] = f.run_dropin_batched_meter_case
 for _fam in ("pow2", "any", "huge", "meter", "wave"):
     run["dropin-" + _fam] = (lambda fam: (lambda s: f.run_dropin_case(s, fam)))(_fam)
 

@@ -686,6 +686,35 @@ def run_dropin_batched_case(seed, family):
 
 
 
+def run_dropin_batched_meter_case(seed):
+    """level-meter scripts through the plugin's batched meter mode (WFHipMeterGroup: levels read one frame late), against the
+    plugin's own CPU class; judged like the batch fuzz (within tolerance of the reference, or no farther from the exactly summed
+    level than the reference itself is)"""
+    import os
+    from pathlib import Path
+    import test_golden as tg
+    from oracle import wfref
+    from helpers import assert_levels_close
+    os.environ["WF_HIP_LIBRARY"] = str(Path(__file__).resolve().parent.parent / "waveform_amd" / "libwaveform_hip.so")
+    os.environ["WF_HIP_BATCHED"] = "1"
+    cfg_dict, steps = draw_meter(seed)
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all")
+    before = wfref.hip_fallback_ticks()
+    late = tg._OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
+    assert late.be.src.using_hip
+    scenarios.play(late, sc)
+    got = late.finish()
+    assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before, "fell back to the CPU class"
+    want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
+    truth = scenarios.play(scenarios.OracleBackend(cfg, exact=True), sc)
+    assert len(got) == len(want) == len(truth)
+    for t, (g, w, x) in enumerate(zip(got, want, truth)):
+        what = f"batched drop-in meter case {seed} tick {t} ({cfg_dict})"
+        assert g["silent"] == w["silent"] or g["silent"] == x["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
+        assert_levels_close(g["db"], w["db"], x["db"], what + " levels")
+
+
 DROPIN_SEEDS = {"pow2": range(0, 80), "any": range(0, 40), "meter": range(0, 60), "wave": range(0, 60)}
 
 
@@ -698,6 +727,16 @@ def test_reference_plugin_with_hip_tick_on_random_case(family, seed):
     if not wfref.available():
         pytest.skip("oracle/_ref/libwfref.so not built")
     run_dropin_case(seed, family)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(0, 60))
+def test_reference_plugin_with_batched_hip_meter_on_random_case(seed):
+    """the batched meter mode of the plugin on consecutive seeds of the meter family"""
+    from oracle import wfref
+    if not wfref.available():
+        pytest.skip("oracle/_ref/libwfref.so not built")
+    run_dropin_batched_meter_case(seed)
 
 
 @pytest.mark.gpu
@@ -719,7 +758,7 @@ def test_zz_display_arm_stays_rare():
     st = helpers.ARM_STATS
     print(f"rows: {st['values']} dB values in {st['calls']} comparisons; decided by the linear arm {st['linear_arm']} "
           f"({st['linear_arm'] / max(st['values'], 1):.2e}), of them above {helpers.VISIBLE_DB} dB {st['linear_arm_visible']} "
-          f"({st['linear_arm_visible'] / max(st['values'], 1):.2e})")
+          f"({st['linear_arm_visible'] / max(st['values'], 1):.2e}); below {helpers.DEEP_DB} dB and lower than the reference: {st['deep']}")
     print(f"display checks {ARM['display_checks']}, second arm taken {ARM['display_arm']}: {ARM['arm_cases'][:10]}")
     print(f"unsupported configurations: {len(ARM['unsupported'])}: {ARM['unsupported'][:10]}")
     if st["values"] >= 10_000_000:  # the whole module ran in this process
