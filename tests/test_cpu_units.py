@@ -356,18 +356,19 @@ def test_meter_and_waveform_configurations():
 def test_headers_are_plain_c_and_the_example_links(tmp_path):
     """include/*.h compile as C99 with no warnings, and the C example links against the library and fails loudly
     (WF_HIP_ERR_NO_DEVICE) where there is no GPU"""
-    exe = tmp_path / "batch_spectrum"
-    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "batch_spectrum.c"),
-           f"-L{ROOT / 'waveform_amd'}", "-lwaveform_hip", "-lm", "-o", str(exe)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    import waveform_amd as wf
-    if wf.device_count() > 0:
-        pytest.skip("a GPU is present: the example would run")
     import os
-    env = dict(os.environ, LD_LIBRARY_PATH=f"{ROOT / 'waveform_amd'}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    run = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
-    assert run.returncode == 1 and "-3" in run.stderr, (run.returncode, run.stderr)
+    import waveform_amd as wf
+    for name in ("batch_spectrum", "multi_gpu_bars"):
+        exe = tmp_path / name
+        cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(ROOT / "examples" / f"{name}.c"),
+               f"-L{ROOT / 'waveform_amd'}", "-lwaveform_hip", "-lm", "-o", str(exe)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        if wf.device_count() > 0:
+            continue  # a GPU is present: the example would run (tests/test_gpu_multi.py runs multi_gpu_bars there)
+        env = dict(os.environ, LD_LIBRARY_PATH=f"{ROOT / 'waveform_amd'}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        run = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+        assert run.returncode == 1 and "-3" in run.stderr, (name, run.returncode, run.stderr)
 
 
 def test_no_fusable_rounding_intrinsics_in_device_code():

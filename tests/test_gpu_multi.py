@@ -202,3 +202,15 @@ def test_multi_errors_are_reported():
         m.push_synth(SEED, 0, 800)
         m.tick()
         assert m.decibels().shape == (4, 2, 512)
+
+
+def test_the_c_example_runs(tmp_path):
+    """examples/multi_gpu_bars.c: the multi-device group from plain C, every device of the box, 120 ticks with the gather"""
+    exe = tmp_path / "multi_gpu_bars"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "multi_gpu_bars.c"),
+           f"-L{ROOT / 'waveform_amd'}", "-lwaveform_hip", "-lm", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{ROOT / 'waveform_amd'}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0 and "streams over" in run.stdout, (run.stdout, run.stderr[-2000:])
