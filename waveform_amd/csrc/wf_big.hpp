@@ -362,53 +362,106 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
 #ifdef BIG_PLAIN_INDEX
 WF_DEV float big_ring1(const float *x, uint32_t i) { return x[i]; }
 WF_DEV f2 big_ring2(const float *x, uint32_t i) { return ld2(x + i); }
+WF_DEV f4 big_ring4(const float *x, uint32_t i) { return ld4(x + i); }
 #else
 WF_DEV float big_ring1(const float *x, uint32_t i) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (size_t)(i * 4u)); }
 WF_DEV f2 big_ring2(const float *x, uint32_t i) { return *reinterpret_cast<const f2 *>(reinterpret_cast<const char *>(x) + (size_t)(i * 4u)); }
+WF_DEV f4 big_ring4(const float *x, uint32_t i) { return *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(x) + (size_t)(i * 4u)); }
 #endif
-template<bool ALIGNED> WF_DEV uint32_t big_fused_fetch(const TickArgs &a, int t, int k1, const float *x, uint32_t start, P1Regs<GBig> &r)
+// The row transform of the fused path runs on 512 threads of 32 points (two waves per SIMD, 256 registers each) rather than
+// GBig's 1024 of 16: at 128 registers the fused fetch and split spilled 196 B per lane, and with one workgroup per CU the
+// spill traffic of 1024 workgroups went all the way to device memory -- 420 MB of the 770 MB a launch moved for 201 MB of
+// payload (profiles/r03a_n65536_pmc.json).
+#ifndef WF_FOLD_T
+#define WF_FOLD_T 512
+#endif
+using GFold = Geom<32768, WF_FOLD_T, 16, 32, 32>;
+static_assert(GFold::LDS_CF == GBig::LDS_CF && GFold::R2 == GBig::R2 && GFold::R3 == GBig::R3 && GFold::R1 == GBig::R1, "the fused rows use GBig's tables and LDS budget");
+
+template<class G, bool ALIGNED> WF_DEV uint32_t big_fused_fetch(const TickArgs &a, int t, int k1, const float *x, uint32_t start, P1Regs<G> &r, cf *lds)
 {
-    using G = GBig;
-    constexpr int R1 = G::R1, M1 = G::M1;
-    constexpr int ROWS = ALIGNED ? BIG_FETCH_ROWS : BIG_FETCH_ROWS / 2;
+    constexpr int R1 = G::R1, M1 = G::M1, B1 = G::B1;
+    constexpr int ROWS = (ALIGNED ? BIG_FETCH_ROWS : BIG_FETCH_ROWS / 2) / B1 > 0 ? (ALIGNED ? BIG_FETCH_ROWS : BIG_FETCH_ROWS / 2) / B1 : 1;
     uint32_t acc = 0;
     const float sgn = k1 ? -1.0f : 1.0f; // row 0: u0 + u1; row 1: (u0 - u1) W_L^n2 (row 0 of the table is all ones)
     const float *tw_row = reinterpret_cast<const float *>(a.big_tw + (size_t)k1 * BIG_L2);
 #pragma unroll
     for(int j0 = 0; j0 < R1; j0 += ROWS) {
-        f2 s0[ROWS], s1[ROWS], w0[ROWS], w1[ROWS], tw[ROWS];
+        f2 s0[ROWS][B1], s1[ROWS][B1], w0[ROWS][B1], w1[ROWS][B1], tw[ROWS][B1];
 #pragma unroll
         for(int jj = 0; jj < ROWS; ++jj) {
             const int j = j0 + jj;
-            const uint32_t n2 = (uint32_t)(j * M1 + t);
+            const uint32_t n2 = (uint32_t)(j * M1 + B1 * t); // this thread's B1 consecutive points of pass-1 row j
             const uint32_t i0 = start + 2u * n2, i1 = start + 2u * (n2 + BIG_L2);
-            if(ALIGNED) { // start is a multiple of 4: a pair never straddles the ring's wrap
-                s0[jj] = big_ring2(x, i0 & a.ring_mask);
-                s1[jj] = big_ring2(x, i1 & a.ring_mask);
+            if(ALIGNED && B1 == 2) { // start is a multiple of 4: a 16-byte group never straddles the ring's wrap
+                const f4 q0 = big_ring4(x, i0 & a.ring_mask), q1 = big_ring4(x, i1 & a.ring_mask);
+                s0[jj][0] = f2{q0.x, q0.y}; s0[jj][B1 - 1] = f2{q0.z, q0.w};
+                s1[jj][0] = f2{q1.x, q1.y}; s1[jj][B1 - 1] = f2{q1.z, q1.w};
             } else {
-                s0[jj] = f2{big_ring1(x, i0 & a.ring_mask), big_ring1(x, (i0 + 1u) & a.ring_mask)};
-                s1[jj] = f2{big_ring1(x, i1 & a.ring_mask), big_ring1(x, (i1 + 1u) & a.ring_mask)};
+#pragma unroll
+                for(int b = 0; b < B1; ++b) {
+                    const uint32_t e0 = i0 + 2u * b, e1 = i1 + 2u * b;
+                    if(ALIGNED) {
+                        s0[jj][b] = big_ring2(x, e0 & a.ring_mask);
+                        s1[jj][b] = big_ring2(x, e1 & a.ring_mask);
+                    } else {
+                        s0[jj][b] = f2{big_ring1(x, e0 & a.ring_mask), big_ring1(x, (e0 + 1u) & a.ring_mask)};
+                        s1[jj][b] = f2{big_ring1(x, e1 & a.ring_mask), big_ring1(x, (e1 + 1u) & a.ring_mask)};
+                    }
+                }
             }
-            w0[jj] = big_ring2(a.window, 2u * n2);
-            w1[jj] = big_ring2(a.window, 2u * (n2 + BIG_L2));
-            tw[jj] = big_ring2(tw_row, 2u * n2);
+            if(B1 == 2) {
+                const f4 a0 = big_ring4(a.window, 2u * n2), a1 = big_ring4(a.window, 2u * (n2 + BIG_L2)), tq = big_ring4(tw_row, 2u * n2);
+                w0[jj][0] = f2{a0.x, a0.y}; w0[jj][B1 - 1] = f2{a0.z, a0.w};
+                w1[jj][0] = f2{a1.x, a1.y}; w1[jj][B1 - 1] = f2{a1.z, a1.w};
+                tw[jj][0] = f2{tq.x, tq.y}; tw[jj][B1 - 1] = f2{tq.z, tq.w};
+            } else {
+                w0[jj][0] = big_ring2(a.window, 2u * n2);
+                w1[jj][0] = big_ring2(a.window, 2u * (n2 + BIG_L2));
+                tw[jj][0] = big_ring2(tw_row, 2u * n2);
+            }
             if(j >= 1 && tw1_row_loaded(j))
                 p1_load_tw1<G>(a, t, j, r.tw1[j]);
         }
 #pragma unroll
         for(int jj = 0; jj < ROWS; ++jj) {
             const int j = j0 + jj;
-            acc |= f32_bits(s0[jj].x) | f32_bits(s0[jj].y) | f32_bits(s1[jj].x) | f32_bits(s1[jj].y);
-            const cf u0 = cf{s0[jj].x * w0[jj].x, s0[jj].y * w0[jj].y}, u1 = cf{s1[jj].x * w1[jj].x, s1[jj].y * w1[jj].y};
-            const cf c = cmul(cf{fmaf(sgn, u1.x, u0.x), fmaf(sgn, u1.y, u0.y)}, cf{tw[jj].x, tw[jj].y});
-            r.smp[j][0] = c.x;
-            r.smp[j][1] = c.y;
-            r.win[j][0] = r.win[j][1] = 1.0f;
+            cf pt[B1];
+#pragma unroll
+            for(int b = 0; b < B1; ++b) {
+                const f2 p0 = s0[jj][b], p1 = s1[jj][b], v0 = w0[jj][b], v1 = w1[jj][b], q = tw[jj][b];
+                acc |= f32_bits(p0.x) | f32_bits(p0.y) | f32_bits(p1.x) | f32_bits(p1.y);
+                const cf u0 = cf{p0.x * v0.x, p0.y * v0.y}, u1 = cf{p1.x * v1.x, p1.y * v1.y};
+                pt[b] = cmul(cf{fmaf(sgn, u1.x, u0.x), fmaf(sgn, u1.y, u0.y)}, cf{q.x, q.y});
+            }
+            // parked in the exchange buffer, in the very slots this thread's pass-1 outputs will take (p1_store): the sixteen
+            // sums of a thread would otherwise occupy 2 R1 B1 registers for the whole burst
+            if(B1 == 2)
+                lds_st4(lds, ex1_addr<G>(j, B1 * t), pt[0], pt[B1 - 1]);
+            else
+                lds_st2(lds, ex1_addr<G>(j, t), pt[0]);
         }
 #ifndef BIG_NO_FENCE
         if(j0 + ROWS < R1)
             __builtin_amdgcn_sched_barrier(0); // the next group's requests stay behind this group's sums
 #endif
+    }
+    // ... and back: the thread's own slots, read through an index the compiler cannot match with the stores above (it
+    // would forward the stored values and keep them in registers after all)
+    int tr = t;
+    asm volatile("" : "+v"(tr));
+#pragma unroll
+    for(int j = 0; j < R1; ++j) {
+        if(B1 == 2) {
+            const f4 q = lds_ld4(lds, ex1_addr<G>(j, B1 * tr));
+            r.smp[j][0] = q.x; r.smp[j][1] = q.y; r.smp[j][2 * B1 - 2] = q.z; r.smp[j][2 * B1 - 1] = q.w;
+        } else {
+            const cf q = lds_ld2(lds, ex1_addr<G>(j, tr));
+            r.smp[j][0] = q.x; r.smp[j][1] = q.y;
+        }
+#pragma unroll
+        for(int b = 0; b < 2 * B1; ++b)
+            r.win[j][b] = 1.0f;
     }
     return acc;
 }
@@ -416,12 +469,12 @@ template<bool ALIGNED> WF_DEV uint32_t big_fused_fetch(const TickArgs &a, int t,
 // bins of parity K1 from row K1's transform (natural order in LDS): mag[4 u + 2 h + K1] = |2 X[k]| coef / 2 for
 // k = 4 (t + T u) + 2 h + K1, i.e. Z[k2] with k2 = 2 (t + T u) + h and its mirror image m - k, which is row K1's
 // k2' = (16384 - K1 - k2) mod 16384
-WF_DEV void big_fused_split(const TickArgs &a, int t, int k1, const cf *lds, float (&out)[GBig::P])
+template<class G> WF_DEV void big_fused_split(const TickArgs &a, int t, int k1, const cf *lds, float (&out)[G::P])
 {
-    using G = GBig;
     constexpr int T = G::T, P = G::P;
-    static_assert(4 * T * 16 == 2 * 2 * (int)BIG_L2, "W_65536^(4 T u) = W_16^u");
-    // W_65536^k for k = 4 t + 2 h + k1; the bins 4 T u further on are that times W_16^u = W_32^(2u) (compile-time constants),
+    constexpr int WSTEP = 32 / ((2 * 2 * (int)BIG_L2) / (4 * T)); // W_65536^(4 T u) = W_32^(WSTEP u)
+    static_assert(WSTEP >= 1 && WSTEP * (P / 2) <= 16 && 4 * T * 32 == 2 * 2 * (int)BIG_L2 * WSTEP, "the bins of a thread are W_32 steps apart");
+    // W_65536^k for k = 4 t + 2 h + k1; the bins 4 T u further on are that times W_32^(WSTEP u) (compile-time constants),
     // as p4_split_smooth forms its twiddles.  out[2 u + h] is bin 4 (t + T u) + 2 h + k1.
     cf wh[2];
 #pragma unroll
@@ -436,7 +489,7 @@ WF_DEV void big_fused_split(const TickArgs &a, int t, int k1, const cf *lds, flo
             const int k2 = 2 * (t + T * u) + h;
             const int km = ((int)BIG_L2 - k1 - k2) & ((int)BIG_L2 - 1);
             const cf A = lds_ld2(lds, ex3_addr<G>(k2)), B = lds_ld2(lds, ex3_addr<G>(km));
-            const cf w = mul_w32(wh[h], 2 * u);
+            const cf w = mul_w32(wh[h], WSTEP * u);
             const float er = A.x + B.x, ei = A.y - B.y;
             const float dr = A.x - B.x, di = A.y + B.y;
             const float pr = fmaf(w.x, dr, -(w.y * di));
@@ -446,24 +499,31 @@ WF_DEV void big_fused_split(const TickArgs &a, int t, int k1, const cf *lds, flo
     }
 }
 
-// one row (blockIdx.x = k1) of one spectrum per workgroup: fetch + column step, the three LDS passes of the 32768-sample
+// one row of one spectrum per workgroup: fetch + column step, the three LDS passes of the 32768-sample
 // geometry, the real split, 16384 magnitudes out
-template<bool ALIGNED> __global__ __launch_bounds__(GBig::T, 4) void big_rows_fold_kernel(const TickArgs a)
+template<bool ALIGNED> __global__ __launch_bounds__(GFold::T, GFold::T / 256) void big_rows_fold_kernel(const TickArgs a)
 {
-    using G = GBig;
+    using G = GFold;
     constexpr int T = G::T, P = G::P;
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
     cf *lds = reinterpret_cast<cf *>(big_smem);
     cf *tw2_lds = lds + G::LDS_CF;
     const int t = (int)threadIdx.x;
-    const int k1 = (int)blockIdx.x;
-    const uint32_t spec = a.stream_base * a.cap_ch + blockIdx.y;
+    // Both rows of a spectrum read the whole window.  Workgroups go to the eight XCDs round-robin by their linear index, and
+    // every XCD has its own L2: the two rows sit eight indices apart -- same XCD, dispatched back to back -- so that the
+    // second read of a window is an L2 hit instead of a second trip to device memory.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const int k1 = (int)(slot & 1u);
+    const uint32_t rel = (slot >> 1) * 8u + xcd;
+    if(rel >= a.stream_count * a.cap_ch)
+        return;
+    const uint32_t spec = a.stream_base * a.cap_ch + rel;
     const uint32_t stream = spec >> (a.cap_ch - 1u);
     const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
     const uint32_t start = (a.wpos[stream] - delay - (uint32_t)(2 * G::N)) & a.ring_mask;
     const float *x = a.ring + (size_t)spec * a.ring_stride;
     P1Regs<G> r;
-    const uint32_t acc = big_fused_fetch<ALIGNED>(a, t, k1, x, start, r);
+    const uint32_t acc = big_fused_fetch<G, ALIGNED>(a, t, k1, x, start, r, lds);
     {   // the pass-2 twiddles by LDS-DMA, as in spectrum_tick_kernel
         constexpr int BYTES = G::R2 * G::R3 * (int)sizeof(cf), PER = 64 * 16;
         const int wave = t >> 6, lane = t & 63;
@@ -491,7 +551,7 @@ template<bool ALIGNED> __global__ __launch_bounds__(GBig::T, 4) void big_rows_fo
     p3_pass3_write<G>(t, lds, pts);
     __syncthreads();
     float out[P];
-    big_fused_split(a, t, k1, lds, out);
+    big_fused_split<G>(a, t, k1, lds, out);
     float *mb = a.big_mag + (size_t)spec * (2u * BIG_L2) + (size_t)k1 * BIG_L2;
 #pragma unroll
     for(int u = 0; u < P / 2; ++u) // out[2 u + h] is k2 = 2 (t + T u) + h

@@ -380,12 +380,12 @@ int launch_tick_big_fold(wf_hip *h, const wf::TickArgs &a0, bool aligned)
     hipStream_t st = h->launch_stream;
     const uint32_t spec_base = a0.stream_base * a0.cap_ch;
     WF_HIP_TRY(h, hipMemsetAsync(h->d_big_nz + spec_base, 0, (size_t)n_spec * sizeof(uint32_t), st));
-    const dim3 grow(2, n_spec);
+    const dim3 grow(2u * ((n_spec + 7u) & ~7u)); // (row, spectrum) by XCD: see big_rows_fold_kernel
     const size_t rows_lds = wf::big_rows_lds_bytes<2>();
     if(aligned)
-        hipLaunchKernelGGL(wf::big_rows_fold_kernel<true>, grow, dim3(wf::GBig::T), rows_lds, st, a0);
+        hipLaunchKernelGGL(wf::big_rows_fold_kernel<true>, grow, dim3(wf::GFold::T), rows_lds, st, a0);
     else
-        hipLaunchKernelGGL(wf::big_rows_fold_kernel<false>, grow, dim3(wf::GBig::T), rows_lds, st, a0);
+        hipLaunchKernelGGL(wf::big_rows_fold_kernel<false>, grow, dim3(wf::GFold::T), rows_lds, st, a0);
     const uint32_t parts = (h->M + (uint32_t)wf::BIG_TP - 1u) / (uint32_t)wf::BIG_TP;
     // mono mixdown: channel 1 of every stream, then channel 0 (TickArgs::split_ch)
     for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
