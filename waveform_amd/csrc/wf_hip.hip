@@ -950,11 +950,6 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(dev_alloc(h, &h->d_wts, (size_t)h->n_streams));
         WF_CREATE_TRY(dev_alloc(h, &h->d_decibels, (size_t)h->n_streams * h->out_ch * h->M));
         WF_CREATE_TRY(dev_alloc(h, &h->d_flags, (size_t)h->n_streams));
-        const int lds = (int)(2u * h->cap_ch * h->N * sizeof(float));
-        WF_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::waveform_tick_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        WF_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::waveform_tick_kernel<4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         h->kernel_name = "waveform_tick_kernel";
         WF_CREATE_TRY(wf_hip_reset(h, 0, h->n_streams));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
@@ -1743,11 +1738,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
             w.vol_comp_stream = h->d_vol_comp;
         }
         w.db_min = wf::db_min();
-        const size_t lds = 2u * (size_t)h->cap_ch * h->N * sizeof(float);
-        if(h->N % 4u == 0) // rows are 16-byte aligned: vector accesses
-            hipLaunchKernelGGL(wf::waveform_tick_kernel<4>, dim3(h->n_streams), dim3(wf::WAVE_THREADS), lds, h->stream, w);
-        else
-            hipLaunchKernelGGL(wf::waveform_tick_kernel<1>, dim3(h->n_streams), dim3(wf::WAVE_THREADS), lds, h->stream, w);
+        hipLaunchKernelGGL(wf::waveform_tick_kernel, dim3((h->n_streams + wf::WAVE_STREAMS - 1) / wf::WAVE_STREAMS), dim3(wf::WAVE_THREADS), 0, h->stream, w);
         WF_HIP_TRY(h, hipGetLastError());
         return WF_HIP_OK;
     }

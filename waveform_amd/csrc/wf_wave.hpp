@@ -9,9 +9,7 @@
 // The reference pops the ring into a scratch buffer and indexes it backwards from the newest sample
 // (temp[total - index]); on the device that is ring[wpos - index], so nothing is copied.  All time arithmetic is the
 // reference's 64-bit integer arithmetic (libobs util_mul_div64 behind ns_to_audio_frames / audio_frames_to_ns).
-// One workgroup per stream: the old rows are staged in LDS (the shift is in place in memory), the new rows assembled in a
-// second LDS area because what is finally stored depends on whether *every* channel's row is all zeros (m_last_silent).
-// HBM traffic: read + write of out_ch * width floats per stream and tick plus the few samples picked from the ring.
+// One wavefront per stream (see waveform_tick_kernel).  HBM traffic: read + write of out_ch * width floats per stream and tick plus the few samples picked from the ring.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "wf_tick_phases.hpp"
@@ -40,7 +38,6 @@ struct WaveArgs {
     float db_min;
 };
 
-constexpr int WAVE_THREADS = 256;
 
 // libobs util_mul_div64 (media-io/audio-io.h helpers are built on it): (num / div) * mul + ((num % div) * mul) / div
 // audio_frames_to_ns(sr, frames) = util_mul_div64(frames, 10^9, sr) for frames, sr < 2^32: the quotient and remainder are
@@ -65,46 +62,92 @@ WF_DEV unsigned long long ns_to_frames(unsigned long long ns, uint32_t sr)
 // exact dbfs of the reference (20 * log10f) -- a few hundred points per stream and tick, so the library log is affordable
 WF_DEV float wave_dbfs(float mag, float db_min) { return (mag > 0.0f) ? mul_unfused(20.0f, log10f(mag)) : db_min; }
 
-// V = 4: rows whose length is a multiple of 4 floats are 16-byte aligned; every row access is a 16-byte vector and a thread
-// handles four consecutive points per step.  V = 1: any width, dword accesses.
-template<int V> WF_DEV void wave_ld(const float *p, float (&v)[V])
+// One WAVEFRONT per stream, WAVE_STREAMS of them per workgroup, no LDS and no barrier: lane l owns the points l + 64 k of every
+// row.  The shift is in place in memory -- rows[i] = rows[i + counts] -- which a single wavefront may do in ascending batches:
+// a batch's loads (all 64 lanes) are complete before its stores are issued, and what a batch stores lies below everything a
+// later batch reads.  What is stored depends on whether *every* channel's rotated row is all zeros (m_last_silent), so the
+// rows are looked at before anything is written: SINGLE (width <= 64 U, every default) keeps the whole stream in registers
+// between the look and the store; wider rows are scanned first and fetched again (from L2) batch by batch.
+// (Round 2's kernel staged the rows of a stream in LDS with one 256-thread workgroup per stream and three barriers: eight
+// streams in flight per CU at most, 0.25-0.36 of the HBM roofline.)
+constexpr int WAVE_STREAMS = 4;
+constexpr int WAVE_THREADS = 64 * WAVE_STREAMS;
+constexpr int WAVE_U = 16; // points per lane and batch: widths up to 1024 in one
+
+struct WavePlan { // per stream, identical in every lane
+    const float *x0, *x1; // ring rows of the captured channels
+    float *rows;
+    uint32_t W, keep, counts, wpos, R, total, sr, mask;
+    unsigned long long wts, audio_ts, step_ns;
+    bool two;
+};
+// the value of point i of the rotated row of channel c (reference :332 + :322-331): old history or the sample nearest to its time
+WF_DEV void wave_gather(const WavePlan &p, uint32_t i, bool live, float &v0, float &v1)
 {
-    if constexpr(V == 4) {
-        const f4 q = ld4(p);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else
-        v[0] = *p;
-}
-template<int V> WF_DEV void wave_st(float *p, const float (&v)[V])
-{
-    if constexpr(V == 4)
-        st4(p, f4{v[0], v[1], v[2], v[3]});
-    else
-        *p = v[0];
+    v0 = v1 = 0.0f;
+    if(!live)
+        return;
+    if(i < p.keep) {
+        v0 = p.rows[i + p.counts];
+        if(p.two)
+            v1 = p.rows[p.W + i + p.counts];
+    } else {
+        const unsigned long long ts = p.wts + (unsigned long long)(i - p.keep) * p.step_ns;
+        unsigned long long index = ns_to_frames(p.audio_ts - ts, p.sr);
+        const unsigned long long lo = (unsigned long long)p.R + 1ull, hi = p.total;
+        index = index < lo ? lo : (hi < index ? hi : index);
+        const uint32_t at = (p.wpos - (uint32_t)index) & p.mask; // temp[total - index]
+        v0 = p.x0[at];
+        if(p.two)
+            v1 = p.x1[at];
+    }
 }
 
-template<int V>
+struct WaveOut { // how a rotated point becomes what is stored (reference :361-388)
+    bool stereo, two, dup, normalize;
+    float comp, db_min;
+};
+WF_DEV void wave_convert(const WaveOut &o, bool fresh, float r0, float r1, float &out0, float &out1, float &dup)
+{
+    dup = r0;  // one captured channel shown twice: row 1 is row 0 *before* its new points are converted, and its own count is 0,
+               // so they stay raw (:361-362, :364-368)
+    const float s1 = o.two ? r1 : r0;
+    out0 = r0;
+    out1 = s1; // mono display: the raw history of channel 1
+    if(fresh) {
+        if(o.stereo || !o.two)
+            out0 = wave_dbfs(__builtin_fabsf(r0), o.db_min);
+        else
+            out0 = wave_dbfs(mul_unfused(add_unfused(__builtin_fabsf(r0), __builtin_fabsf(s1)), 0.5f), o.db_min);
+        if(o.normalize)
+            out0 = add_unfused(out0, o.comp);
+        if(o.stereo && o.two) {
+            out1 = wave_dbfs(__builtin_fabsf(s1), o.db_min);
+            if(o.normalize)
+                out1 = add_unfused(out1, o.comp);
+        }
+    }
+}
+
 __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float wave_lds[]; // old rows [cap_ch][W], then new rows [cap_ch][W]
-    const uint32_t stream = blockIdx.x;
-    const uint32_t tid = threadIdx.x;
+    constexpr int U = WAVE_U;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stream = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVE_STREAMS + (threadIdx.x >> 6)));
+    if(stream >= a.n_streams)
+        return;
     const uint32_t W = a.width;
     const uint32_t sflags = a.stream_flags[stream];
     const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
     float *rows = a.rows + (size_t)stream * a.out_ch * W;
     const uint32_t disp = a.stereo ? 2u : 1u;
-    float dbm[V];
-#pragma unroll
-    for(int e = 0; e < V; ++e)
-        dbm[e] = a.db_min;
 
     if(sflags & WF_STREAM_HIDDEN) { // !m_show || capture timed out, :279-288
         if(was_silent)
             return;
-        for(uint32_t i = V * tid; i < disp * W; i += V * WAVE_THREADS)
-            wave_st<V>(rows + i, dbm);
-        if(tid == 0)
+        for(uint32_t i = lane; i < disp * W; i += 64u)
+            rows[i] = a.db_min;
+        if(lane == 0)
             a.stream_flags[stream] = sflags | WF_STREAM_LAST_SILENT;
         return;
     }
@@ -114,13 +157,6 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     const uint32_t avail = wpos - cend;
     if(avail <= R) // not enough audio in advance, :293-295
         return;
-    // the old rows are on their way while the time arithmetic runs
-    float *old_rows = wave_lds, *new_rows = wave_lds + (size_t)a.cap_ch * W;
-    for(uint32_t i = V * tid; i < a.cap_ch * W; i += V * WAVE_THREADS) {
-        float v[V];
-        wave_ld<V>(rows + i, v);
-        wave_st<V>(old_rows + i, v);
-    }
     const uint32_t max_size = a.waveform_samples + R;
     const uint32_t total = avail < max_size ? avail : max_size; // :303-304
     const uint32_t sr = a.sample_rate;
@@ -129,7 +165,7 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     if(start_ts >= a.audio_ts || stop_ts > a.audio_ts) {
         // timestamp rollover, :316-317 (a tick before any audio has a timestamp).  The rows are untouched, but the reference
         // has already trimmed the ring to max_size on its way here (:303-304), and the samples it dropped stay dropped
-        if(tid == 0 && avail > max_size)
+        if(lane == 0 && avail > max_size)
             a.cend[stream] = wpos - max_size;
         return;
     }
@@ -144,83 +180,69 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
         const unsigned long long c = (stop_ts - wts + a.step_ns - 1ull) / a.step_ns;
         counts = c < (unsigned long long)W ? (uint32_t)c : W;
     }
-    __syncthreads();
-    // assemble the rotated rows (:332) and look for a non-zero value (:334-343)
-    int nz0 = 0, nz1 = 0;
-    const uint32_t keep = W - counts;
-    for(uint32_t c = 0; c < a.cap_ch; ++c) {
-        const float *x = a.ring + ((size_t)stream * a.cap_ch + c) * a.ring_stride;
-        int nz = 0;
-        for(uint32_t i0 = V * tid; i0 < W; i0 += V * WAVE_THREADS) {
-            float v[V];
+    WavePlan p;
+    p.x0 = a.ring + (size_t)stream * a.cap_ch * a.ring_stride;
+    p.x1 = p.x0 + a.ring_stride;
+    p.rows = rows;
+    p.W = W; p.keep = W - counts; p.counts = counts; p.wpos = wpos; p.R = R; p.total = total; p.sr = sr; p.mask = a.ring_mask;
+    p.wts = wts; p.audio_ts = a.audio_ts; p.step_ns = a.step_ns;
+    p.two = a.cap_ch > 1;
+    WaveOut o;
+    o.stereo = a.stereo != 0; o.two = p.two; o.dup = a.out_ch > a.cap_ch; o.normalize = a.normalize != 0;
+    o.comp = a.normalize ? (a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp) : 0.0f;
+    o.db_min = a.db_min;
+
+    const bool single = W <= 64u * U;
+    float r0[U], r1[U];
+    bool nz0 = false, nz1 = false;
+    // the rotated rows (:332) and whether they hold a non-zero value (:334-343)
+    for(uint32_t base = 0; base < W; base += 64u * U) {
 #pragma unroll
-            for(int e = 0; e < V; ++e) {
-                const uint32_t i = i0 + (uint32_t)e;
-                if(i < keep)
-                    v[e] = old_rows[c * W + i + counts];
-                else {
-                    const unsigned long long ts = wts + (unsigned long long)(i - keep) * a.step_ns;
-                    unsigned long long index = ns_to_frames(a.audio_ts - ts, sr);
-                    const unsigned long long lo = (unsigned long long)R + 1ull, hi = total;
-                    index = index < lo ? lo : (hi < index ? hi : index);
-                    v[e] = x[(wpos - (uint32_t)index) & a.ring_mask]; // temp[total - index]
-                }
-                nz |= (v[e] != 0.0f) ? 1 : 0;
-            }
-            wave_st<V>(new_rows + c * W + i0, v);
+        for(int k = 0; k < U; ++k) {
+            const uint32_t i = base + lane + 64u * (uint32_t)k;
+            wave_gather(p, i, i < W, r0[k], r1[k]);
         }
-        if(c == 0) nz0 = nz; else nz1 = nz;
+#pragma unroll
+        for(int k = 0; k < U; ++k) {
+            nz0 = nz0 || r0[k] != 0.0f;
+            nz1 = nz1 || r1[k] != 0.0f;
+        }
     }
-    const int any0 = __syncthreads_or(nz0);
-    const int any1 = a.cap_ch > 1 ? __syncthreads_or(nz1) : 0;
-    const bool all_silent = !any0 && (a.cap_ch == 1 || !any1); // every channel's row is zeros -> m_last_silent (:345-349)
-    if(tid == 0) {
+    const bool all_silent = !__any(nz0) && !__any(nz1); // every channel's row is zeros -> m_last_silent (:345-349)
+    if(lane == 0) {
         a.cend[stream] = wpos - R;                               // everything but the reserve has been popped, :321
         a.wts[stream] = wts + (unsigned long long)counts * a.step_ns; // :351
         a.stream_flags[stream] = (sflags & ~WF_STREAM_LAST_SILENT) | (all_silent ? WF_STREAM_LAST_SILENT : 0u);
     }
-    if(all_silent) { // :353-359
-        for(uint32_t i = V * tid; i < disp * W; i += V * WAVE_THREADS)
-            wave_st<V>(rows + i, dbm);
-        // a captured channel that is not displayed keeps its (rotated) raw history
-        for(uint32_t c = disp; c < a.cap_ch; ++c)
-            for(uint32_t i = V * tid; i < W; i += V * WAVE_THREADS) {
-                float v[V];
-                wave_ld<V>(new_rows + c * W + i, v);
-                wave_st<V>(rows + c * W + i, v);
-            }
-        return;
-    }
-    const float comp = a.normalize ? (a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp) : 0.0f;
-    for(uint32_t i0 = V * tid; i0 < W; i0 += V * WAVE_THREADS) {
-        float r0[V], r1[V], o1[V];
-        wave_ld<V>(new_rows + i0, r0);
-        if(a.cap_ch > 1)
-            wave_ld<V>(new_rows + W + i0, r1);
-        if(a.out_ch > a.cap_ch)             // one captured channel shown twice: row 1 is row 0 *before* its new points are
-            wave_st<V>(rows + W + i0, r0);  // converted, and its own count is 0, so they stay raw (:361-362, :364-368)
+    for(uint32_t base = 0; base < W; base += 64u * U) {
+        if(!single) { // the batch again (the scan has been through all of them)
 #pragma unroll
-        for(int e = 0; e < V; ++e) {
-            const bool fresh = i0 + (uint32_t)e >= keep;
-            const float s1 = a.cap_ch > 1 ? r1[e] : r0[e];
-            o1[e] = s1;
-            if(fresh) {
-                if(a.stereo || a.cap_ch == 1)
-                    r0[e] = wave_dbfs(__builtin_fabsf(r0[e]), a.db_min);
-                else
-                    r0[e] = wave_dbfs(mul_unfused(add_unfused(__builtin_fabsf(r0[e]), __builtin_fabsf(s1)), 0.5f), a.db_min);
-                if(a.normalize)
-                    r0[e] = add_unfused(r0[e], comp);
-                if(a.stereo && a.cap_ch > 1) {
-                    o1[e] = wave_dbfs(__builtin_fabsf(s1), a.db_min);
-                    if(a.normalize)
-                        o1[e] = add_unfused(o1[e], comp);
-                }
+            for(int k = 0; k < U; ++k) {
+                const uint32_t i = base + lane + 64u * (uint32_t)k;
+                wave_gather(p, i, i < W, r0[k], r1[k]);
             }
         }
-        wave_st<V>(rows + i0, r0);
-        if(a.cap_ch > 1)
-            wave_st<V>(rows + W + i0, o1); // mono display: the raw history of channel 1
+#pragma unroll
+        for(int k = 0; k < U; ++k) {
+            const uint32_t i = base + lane + 64u * (uint32_t)k;
+            if(i >= W)
+                continue;
+            if(all_silent) { // :353-359: the displayed rows read DB_MIN; a captured channel that is not displayed keeps its
+                rows[i] = a.db_min; // (rotated) raw history
+                if(disp > 1u)
+                    rows[W + i] = a.db_min;
+                else if(p.two)
+                    rows[W + i] = r1[k];
+            } else {
+                float out0, out1, dup;
+                wave_convert(o, i >= p.keep, r0[k], r1[k], out0, out1, dup);
+                if(o.dup)
+                    rows[W + i] = dup;
+                rows[i] = out0;
+                if(p.two)
+                    rows[W + i] = out1;
+            }
+        }
     }
 }
 
