@@ -61,6 +61,9 @@ MAX_DEPTH = 64   # ticks of audio resident per stream (--depth); the walk starts
                  # measure 0.79-0.80 of peak alike (r02j)
 
 
+CFG4_WATCHDOG_S = 240.0  # multi-rank runs: the configs[4] region (a few seconds when healthy) may take this long at most
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -519,11 +522,26 @@ def main():
     # BASELINE configs[4] in the line the driver's one command prints: at every N, all ranks (the collective is the point)
     cfg4 = None
     if not args.no_other_configs and not args.bars_allgather and world > 1:
+        # A collective that never completes (a rank that died, a fabric problem) must not take the headline with it: it has been
+        # measured by now.  After CFG4_WATCHDOG_S every rank gives up on its own; rank 0 prints the line first.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["configs4"] = {"error": f"configs[4] region did not finish within {CFG4_WATCHDOG_S} s (collective hung?); headline unaffected"}
+                print(json.dumps(out), flush=True)
+            print(f"bench.py: rank {rank}: configs4 watchdog fired after {CFG4_WATCHDOG_S} s", file=sys.stderr, flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(CFG4_WATCHDOG_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             cfg4 = configs4_region(wf, torch, dist, rank, world, local_rank, min(args.steps, 300))
         except Exception as e:
             cfg4 = {"error": str(e)}
             print(f"bench.py: configs4 failed on rank {rank}: {e}", file=sys.stderr)
+        # (the timer keeps running over the closing barrier below: a rank that failed above leaves the others waiting there)
     if rank == 0 and world == 1 and not args.no_other_configs and not args.bars_allgather:
         try:  # before the other shapes allocate and free their tens of gigabytes (see pcie_inclusive)
             out["pcie_inclusive"] = pcie_inclusive(wf, cfg, args.streams, local_rank)
@@ -546,6 +564,8 @@ def main():
             out["c_abi_multi"] = c_abi_multi()
         print(json.dumps(out), flush=True)
     if dist is not None:
+        if cfg4 is not None and "error" in cfg4:
+            os._exit(0)  # this rank left the collective sequence of the configs[4] region: no barrier can be trusted any more
         dist.barrier()
         dist.destroy_process_group()
 
