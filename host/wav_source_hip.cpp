@@ -42,6 +42,9 @@ struct HipApi {
     decltype(&wf_hip_push_rms_ragged_async) push_rms_ragged_async = nullptr;
     decltype(&wf_hip_read_input_rms_async) read_input_rms_async = nullptr;
     decltype(&wf_hip_read_meter_async) read_meter_async = nullptr;
+    decltype(&wf_hip_set_stream_delay) set_stream_delay = nullptr;
+    decltype(&wf_hip_set_stream_audio_ts) set_stream_audio_ts = nullptr;
+    decltype(&wf_hip_output_channels) output_channels = nullptr;
     bool ok = false;
 };
 
@@ -80,6 +83,9 @@ HipApi &api()
         WF_SYM(push_rms_ragged_async)
         WF_SYM(read_input_rms_async)
         WF_SYM(read_meter_async)
+        WF_SYM(set_stream_delay)
+        WF_SYM(set_stream_audio_ts)
+        WF_SYM(output_channels)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
         auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
@@ -268,6 +274,13 @@ struct WFHipMeterGroup {
     bool valid[2] = {false, false};
     float seconds = 1.0f / 60.0f;
     bool failed = false;
+    // waveform display (cfg.waveform): the same frame-by-frame hand-over, with every member's A/V-sync reserve and audio
+    // timestamp, and the rows of the whole group coming back instead of the levels
+    bool wave = false;
+    uint32_t out_ch = 0, width = 0;
+    std::vector<uint32_t> delay, delay_dev;  // [capacity] the reserve tick_waveform leaves in the ring (:291-292), frames
+    std::vector<uint64_t> audio_ts;          // [capacity] m_audio_ts
+    float *rows[2] = {nullptr, nullptr};     // page-locked [capacity][out_ch][width]
 
     bool create(const wf_config &c, int dev)
     {
@@ -280,16 +293,27 @@ struct WFHipMeterGroup {
             return false;
         }
         cap_ch = c.capture_channels;
+        wave = c.waveform != 0;
         member.assign(capacity, nullptr);
         submitted.assign(capacity, 0);
         pending.assign(capacity, {});
         frames.assign(capacity, 0);
         state.assign(capacity, WF_HIP_PAUSED);
         state_dev.assign(capacity, WF_HIP_SHOWN);
+        if(wave) {
+            out_ch = a.output_channels(h);
+            width = c.fft_size;
+            delay.assign(capacity, 0);
+            delay_dev.assign(capacity, 0);
+            audio_ts.assign(capacity, 0);
+        }
         for(int i = 0; i < 2; ++i) {
-            levels[i] = static_cast<float *>(a.host_alloc((size_t)capacity * cap_ch * sizeof(float)));
             silent[i] = static_cast<uint8_t *>(a.host_alloc(capacity));
-            if(levels[i] == nullptr || silent[i] == nullptr)
+            if(wave)
+                rows[i] = static_cast<float *>(a.host_alloc((size_t)capacity * out_ch * width * sizeof(float)));
+            else
+                levels[i] = static_cast<float *>(a.host_alloc((size_t)capacity * cap_ch * sizeof(float)));
+            if(silent[i] == nullptr || (wave ? rows[i] : levels[i]) == nullptr)
                 return false;
         }
         return true;
@@ -303,6 +327,7 @@ struct WFHipMeterGroup {
         for(int i = 0; i < 2; ++i) {
             if(stage[i]) a.host_free(stage[i]);
             if(levels[i]) a.host_free(levels[i]);
+            if(rows[i]) a.host_free(rows[i]);
             if(silent[i]) a.host_free(silent[i]);
         }
     }
@@ -343,16 +368,26 @@ struct WFHipMeterGroup {
                 ok = a.push_audio_ragged_async(h, 0, capacity, stage[b], frames.data(), maxf, b) == WF_HIP_OK;
             }
         }
+        if(ok && wave) {
+            if(delay != delay_dev) {
+                ok = a.set_stream_delay(h, 0, capacity, delay.data()) == WF_HIP_OK;
+                delay_dev = delay;
+            }
+            ok = ok && a.set_stream_audio_ts(h, 0, capacity, audio_ts.data()) == WF_HIP_OK;
+        }
         wf_hip_tick_params p{};
         p.seconds = seconds;
         ok = ok && a.tick(h, &p) == WF_HIP_OK;
-        ok = ok && a.read_meter_async(h, 0, capacity, levels[b], silent[b], b) == WF_HIP_OK;
+        if(wave)
+            ok = ok && a.read_rows_async(h, 0, capacity, rows[b], silent[b], b) == WF_HIP_OK;
+        else
+            ok = ok && a.read_meter_async(h, 0, capacity, levels[b], silent[b], b) == WF_HIP_OK;
         valid[b] = ok;
         ++batch;
         n_submitted = 0;
         std::fill(frames.begin(), frames.end(), 0u);
         if(!ok) {
-            LogWarn << "HIP meter batch tick failed (" << a.last_error(h) << "); its sources fall back to the CPU path";
+            LogWarn << "HIP " << (wave ? "waveform" : "meter") << " batch tick failed (" << a.last_error(h) << "); its sources fall back to the CPU path";
             failed = true;
         }
         return ok;
@@ -526,7 +561,11 @@ bool WAVSourceHIP::hip_configure()
     // level meter: join (or open) the batch of this meter configuration.  Meter buffers beyond 65536 samples (meter_buf above
     // ~1.3 s; the reference allows 600 s) stay synchronous: a member's first hand-over is the whole buffer.
     const char *mb = std::getenv("WF_HIP_BATCHED_METER"); // 0: the meter stays synchronous while the spectrum batches
-    if(c.meter && batched_mode() && m_fft_size <= 65536 && !(mb && mb[0] == '0')) {
+    const char *wb = std::getenv("WF_HIP_BATCHED_WAVE");  // 0: so does the waveform display
+    // waveform display: the same kind of batch (a group's configuration has either cfg.meter or cfg.waveform set, so the two never
+    // share one).  With volume normalisation a source stays synchronous: its m_input_rms is computed on the host per call.
+    const bool wave_batch = c.waveform && !c.normalize_volume && !(wb && wb[0] == '0');
+    if(((c.meter && m_fft_size <= 65536 && !(mb && mb[0] == '0')) || wave_batch) && batched_mode()) {
         auto &r = registry();
         std::lock_guard lock(r.mtx);
         WFHipMeterGroup *g = nullptr;
@@ -573,6 +612,12 @@ bool WAVSourceHIP::hip_configure()
         ++g->members;
         m_mgroup = g;
         m_slot = slot;
+        if(g->wave) {
+            g->delay[slot] = 0;
+            g->audio_ts[slot] = 0;
+            m_hip_pushed = m_fft_size; // update() pre-fills m_fft_size zeros; so does the device (wf_hip_reset)
+            m_hip_prev.assign((size_t)m_capture_channels * m_hip_pushed, 0.0f);
+        }
         return true;
     }
     int dev = 0;
@@ -933,12 +978,109 @@ void WAVSourceHIP::tick_meter(float seconds)
     m_last_silent = silent != 0;
 }
 
+// The batched waveform path (struct WFHipMeterGroup with cfg.waveform): m_decibels / m_last_silent are the device's results for
+// the previous video frame.  What this frame hands over is exactly what the synchronous path below pushes inside the call.
+void WAVSourceHIP::tick_waveform_batched(float seconds)
+{
+    auto &a = api();
+    auto &r = registry();
+    std::unique_lock lock(r.mtx);
+    WFHipMeterGroup *g = m_mgroup;
+    const uint32_t slot = m_slot;
+    const size_t outsz = m_fft_size;
+    bool ok = !g->failed;
+    if(ok && g->submitted[slot] == g->batch) // came round again while the frame was still being assembled: complete it
+        ok = g->flush();
+    // 1. collect the rows the last flushed batch left for this source
+    const uint32_t last = (uint32_t)((g->batch - 1) & 1);
+    if(ok && g->batch > 1 && g->valid[last] && g->batch - 1 >= m_hip_joined) {
+        ok = a.readback_done(g->h, last) == WF_HIP_OK;
+        if(ok) {
+            const float *row = g->rows[last] + (size_t)slot * g->out_ch * g->width;
+            for(auto channel = 0u; channel < m_output_channels; ++channel)
+                std::memcpy(m_decibels[channel].get(), row + (size_t)channel * outsz, outsz * sizeof(float));
+            m_last_silent = g->silent[last][slot] != 0;
+        }
+    }
+    if(!ok) {
+        lock.unlock();
+        LogWarn << "HIP waveform batch unavailable; this source continues on the CPU path";
+        hip_release();
+        g_fallback_ticks.fetch_add(1);
+        WAVSourceGeneric::tick_waveform(seconds);
+        return;
+    }
+    // 2. submit this frame
+    const auto dtcapture = m_tick_ts - m_capture_ts;
+    const bool hidden = !m_show || (dtcapture > CAPTURE_TIMEOUT); // :279
+    uint8_t st = hidden ? WF_HIP_HIDDEN : WF_HIP_SHOWN;
+    size_t fresh = 0;
+    if(!hidden) {
+        const int64_t dtaudio = get_audio_sync(m_tick_ts);
+        const size_t reserve = (dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) : 0; // frames
+        const size_t max_frames = m_waveform_samples + reserve;
+        bool enough = true;
+        for(auto i = 0u; i < m_capture_channels; ++i)
+            if(m_capturebufs[i].size() <= reserve * sizeof(float)) // :293-295: the reference returns before it touches anything
+                enough = false;
+        if(!enough) {
+            st = WF_HIP_PAUSED;
+        } else {
+            // (see the synchronous path below for what is pushed and why)
+            size_t frames = 0;
+            bool front_kept = true;
+            std::vector<std::vector<float>> all(m_capture_channels);
+            for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+                auto &buf = m_capturebufs[channel];
+                if(buf.size() > max_frames * sizeof(float)) // :303-304
+                    buf.pop_front(nullptr, buf.size() - max_frames * sizeof(float));
+                const size_t s = buf.size() / sizeof(float);
+                all[channel].resize(s);
+                buf.peek_front(all[channel].data(), s * sizeof(float));
+                if(channel == 0)
+                    frames = s;
+                front_kept = front_kept && s >= m_hip_pushed && m_hip_prev.size() == (size_t)m_capture_channels * m_hip_pushed &&
+                             std::memcmp(all[channel].data(), m_hip_prev.data() + (size_t)channel * m_hip_pushed, m_hip_pushed * sizeof(float)) == 0;
+            }
+            fresh = front_kept ? frames - m_hip_pushed : frames;
+            const auto start_ts = m_audio_ts - audio_frames_to_ns(m_audio_info.samples_per_sec, frames);
+            const auto stop_ts = m_audio_ts - audio_frames_to_ns(m_audio_info.samples_per_sec, reserve);
+            const bool rollover = (start_ts >= m_audio_ts) || (stop_ts > m_audio_ts); // :314-317
+            const size_t stay = rollover ? frames : reserve; // frames left in m_capturebufs behind this tick
+            auto &dst = g->pending[slot];
+            dst.resize((size_t)m_capture_channels * fresh);
+            m_hip_prev.assign((size_t)m_capture_channels * stay, 0.0f);
+            for(auto channel = 0u; channel < m_capture_channels; ++channel) {
+                auto &buf = m_capturebufs[channel];
+                const size_t s = all[channel].size();
+                std::memcpy(dst.data() + (size_t)channel * fresh, all[channel].data() + (s - fresh), fresh * sizeof(float));
+                std::memcpy(m_hip_prev.data() + (size_t)channel * stay, all[channel].data() + (s - stay), stay * sizeof(float));
+                buf.pop_front(nullptr, (s - stay) * sizeof(float)); // :321: only the reserve stays
+            }
+            m_hip_pushed = stay;
+            g->delay[slot] = (uint32_t)reserve;
+            g->audio_ts[slot] = m_audio_ts;
+        }
+    }
+    g->frames[slot] = (uint32_t)fresh;
+    g->state[slot] = st;
+    g->seconds = seconds;
+    g->submitted[slot] = g->batch;
+    ++g->n_submitted;
+    if(g->n_submitted >= g->members)
+        g->flush();
+}
+
 // Same observable behaviour as WAVSourceGeneric::tick_waveform (src/source_generic.cpp:271-390).  The device ring mirrors
 // m_capturebufs: every tick the frames captured since the last one are appended to it, the device picks the new points
 // from its ring exactly where the reference picks them from its scratch copy (both count back from the newest sample),
 // and m_capturebufs is popped down to the A/V-sync reserve as the reference does (:321).  m_waveform_ts lives on the device.
 void WAVSourceHIP::tick_waveform(float seconds)
 {
+    if(m_mgroup != nullptr) {
+        tick_waveform_batched(seconds);
+        return;
+    }
     if(m_hip == nullptr) {
         g_fallback_ticks.fetch_add(1);
         WAVSourceGeneric::tick_waveform(seconds);

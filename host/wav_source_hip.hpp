@@ -36,7 +36,9 @@ protected:
     //    enqueues ONE tick for all of them and every source picks up its row one frame later (m_group / m_slot);
     //    The level meter batches the same way (m_mgroup): one ragged ingest of what every source's tick_meter consumes, one
     //    meter_tick_kernel per video frame, levels one frame later;
-    //  * synchronous (WF_HIP_BATCHED=0; always for the waveform display): a handle of one stream per source,
+    //    and so does the waveform display (its group hands over every member's A/V-sync reserve and audio timestamp too; sources
+    //    with volume normalisation stay synchronous);
+    //  * synchronous (WF_HIP_BATCHED=0): a handle of one stream per source,
     //    push -> tick -> read inside the call, zero latency (m_hip).
     struct WFHipGroup *m_group = nullptr;
     struct WFHipMeterGroup *m_mgroup = nullptr; // level meter, batched: the sources of one meter configuration share a handle too
@@ -73,6 +75,7 @@ public:
 private:
     void tick_spectrum_batched(float seconds);
     void tick_meter_batched(float seconds);
+    void tick_waveform_batched(float seconds);
     bool hip_window(size_t &dtframes);  // the A/V-synchronised window of every channel -> m_hip_window; false on underflow
     friend struct WFHipGroup;
     friend struct WFHipMeterGroup;

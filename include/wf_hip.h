@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 8
+#define WF_HIP_ABI_VERSION 9
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -174,7 +174,8 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p);
 #define WF_HIP_SHOWN 0
 #define WF_HIP_HIDDEN 1          /* !m_show */
 #define WF_HIP_HIDDEN_TIMEOUT 2  /* m_tick_ts - m_capture_ts > CAPTURE_TIMEOUT */
-#define WF_HIP_PAUSED 3          /* spectrum and meter batches: the source was not ticked in this video frame (OBS ticks only active sources) --
+#define WF_HIP_PAUSED 3          /* the source was not ticked in this video frame (OBS ticks only active sources; a waveform source whose buffers
+                                    hold no more than the A/V-sync reserve returns before it touches anything, src/source_generic.cpp:293-295) --
                                     the next wf_hip_tick leaves the stream exactly as it is; cleared by any other value */
 #define WF_HIP_STARVED 4         /* spectrum batches whose host keeps the sources' own buffers (the plugin binding): the source holds fewer
                                     samples than window + A/V-sync delay (src/source_generic.cpp:55-61: every channel is skipped) -- the
@@ -188,6 +189,12 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
  * delay_frames before its newest sample; stays in force until the next call for that stream.  Each delay[i] + fft_size
  * must fit the ring (and so must their sum with any wf_hip_tick_params::delay_frames used later). */
 int wf_hip_set_stream_delay(wf_hip *h, uint32_t first, uint32_t count, const uint32_t *delay_frames);
+/* Waveform batches whose sources run on their own audio timestamps (the plugin's batched mode): m_audio_ts of stream
+ * first+i (src/source.hpp; what tick_waveform measures every point's time against, src/source_generic.cpp:306-331), in
+ * nanoseconds.  Stays in force until the next call for that stream; once any stream has been given one,
+ * wf_hip_tick_params::audio_ts_ns is ignored (streams never set read 0: "no audio has a timestamp yet").
+ * WF_HIP_ERR_INVALID for batches that are not waveform displays. */
+int wf_hip_set_stream_audio_ts(wf_hip *h, uint32_t first, uint32_t count, const uint64_t *audio_ts_ns);
 /* m_input_rms per stream (what update_input_rms leaves, src/source_generic.cpp:392-403), for batches whose streams are
  * normalised independently (cfg.normalize_volume): rms[i] belongs to stream first+i and stays in force until the next
  * call for that stream.  Once any stream has been given a value, wf_hip_tick_params::input_rms is ignored (streams never

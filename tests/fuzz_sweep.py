@@ -1,4 +1,4 @@
-"""extended fuzz sweep (development aid): python tests/fuzz_sweep.py LO HI [pow2,any,huge,meter,wave,dropin-pow2,dropin-any,dropin-meter,dropin-wave]
+"""extended fuzz sweep (development aid): python tests/fuzz_sweep.py LO HI [pow2,any,huge,meter,wave,dropin-pow2,dropin-any,dropin-meter,dropin-wave,batched-pow2,batched-any,batched-huge,batched-meter,batched-wave]
 runs the same case functions as tests/test_gpu_fuzz.py over seeds [LO, HI) and lists failures and skips"""
 import os
 import sys
@@ -19,6 +19,7 @@ run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_
 for _fam in ("pow2", "any", "huge"):
     run["batched-" + _fam] = (lambda fam: (lambda s: f.run_dropin_batched_case(s, fam)))(_fam)
 run["batched-meter"] = f.run_dropin_batched_meter_case
+run["batched-wave"] = f.run_dropin_batched_wave_case
 for _fam in ("pow2", "any", "huge", "meter", "wave"):
     run["dropin-" + _fam] = (lambda fam: (lambda s: f.run_dropin_case(s, fam)))(_fam)
 

@@ -212,6 +212,96 @@ def test_reference_plugin_with_batched_hip_meter(name):
             assert np.all(err <= 1e-5 * np.abs(z[f"bars_{t}"]) + 2e-3), f"{name} tick {t} bars: max err {err.max():.3e} px"
 
 
+WAVE_BATCHED = ["wave_stereo_800", "wave_mono_mix_ragged", "wave_single_dup_stall", "wave_hide_timeout_sync", "wave_sync_burst",
+                "wave_tick_before_audio_sync"]  # (wave_normalize: sources with volume normalisation stay synchronous)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", WAVE_BATCHED)
+def test_reference_plugin_with_batched_hip_waveform(name):
+    """The waveform display in the plugin's batched mode (WFHipMeterGroup with cfg.waveform: sources of one configuration share
+    a handle; every frame one ragged ingest of what each tick_waveform consumed, every member's A/V-sync reserve and audio
+    timestamp, one waveform_tick_kernel, rows read one frame later): every waveform golden scenario, shifted by exactly one tick."""
+    wfref = _hip_env(batched=True)
+    sc = scenarios.SCENARIOS[name]
+    cfg = scenarios.make_config(sc["cfg"])
+    z, meta = _load(name)
+    before = wfref.hip_fallback_ticks()
+    late = _OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
+    assert late.be.src.using_hip
+    scenarios.play(late, sc)
+    recs = late.finish()
+    assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before
+    assert len(recs) == meta["n_ticks"]
+    silent = np.array([r["silent"] for r in recs], np.uint8)
+    assert np.array_equal(silent, z["silent"]), f"{name}: m_last_silent sequence {silent} != reference {z['silent']} (one frame late)"
+    for t, r in scenarios.recorded(recs, sc["record"]):
+        assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} rows, read one frame later", lin_eps=None)
+
+
+@pytest.mark.gpu
+def test_waveform_sources_share_one_batch():
+    """24 waveform sources of one configuration: one handle, one ragged ingest + one waveform_tick_kernel + one readback per
+    video frame.  Every source has its own audio, amplitude and packet sizes, some hide, stall or lose their capture along the way;
+    each one's rows at frame t+1 are what the reference's own CPU class has at frame t.  Then the cost per source and frame
+    against the synchronous device path and the reference's AVX class in the same harness."""
+    import os
+    from tools import synth
+    wfref = _hip_env(batched=True)
+    os.environ["WF_HIP_BATCH_CAPACITY"] = "64"
+    cfg_dict = dict(waveform=1, stereo=1, width=800, meter_ms=150)
+    cfg = scenarios.make_config(cfg_dict)
+    n_src, frames = 24, 40
+    before = wfref.hip_fallback_ticks()
+    srcs = [scenarios.RefBackend(cfg, isa="hip") for _ in range(n_src)]
+    refs = [scenarios.RefBackend(cfg, isa="generic") for _ in range(n_src)]
+    assert all(s.src.using_hip for s in srcs)
+    want_prev = [None] * n_src
+    pos = [0] * n_src
+    for f in range(frames):
+        for i, (s, o) in enumerate(zip(srcs, refs)):
+            stalled = (i % 7 == 3) and f in (25, 26)          # no packet and no tick in these frames: the stream is paused
+            if f == 20 and i % 5 == 1:
+                s.set_hidden(True), o.set_hidden(True)
+            if f == 24 and i % 5 == 1:
+                s.set_hidden(False), o.set_hidden(False)
+            if stalled:
+                continue
+            if i % 11 == 4 and f == 30:
+                s.timeout(), o.timeout()
+            else:
+                hop = (800, 441, 1024, 960)[i % 4] if f % 3 != 2 or i % 2 else 0   # some frames bring no packet at all
+                if hop:
+                    a = synth.block(scenarios.SEED, 300 + i, 1, 2, pos[i], hop)[0] * np.float32(1.0 if i % 3 else 0.05)
+                    pos[i] += hop
+                    for b in (s, o):
+                        b.push(a, muted=False)
+            for b in (s, o):
+                b.tick(1.0 / 60.0)
+            got = s.observe()
+            if want_prev[i] is not None:
+                w = want_prev[i]
+                assert got["silent"] == w["silent"], f"source {i} frame {f}: m_last_silent"
+                assert_db_close(got["db"], w["db"], f"source {i} frame {f}: rows of the previous frame", lin_eps=None)
+            want_prev[i] = o.observe()
+    assert all(s.src.using_hip for s in srcs) and wfref.hip_fallback_ticks() == before
+    del srcs, refs
+    from helpers import ref_settings
+    settings = ref_settings(cfg)
+    v_hip, _ = wfref.bench("hip", settings, 64, 1, 20, 300, hop=800, seed=scenarios.SEED)
+    v_avx, _ = wfref.bench("avx2", settings, 64, 1, 20, 300, hop=800, seed=scenarios.SEED)
+    os.environ["WF_HIP_BATCHED_WAVE"] = "0"
+    try:
+        v_sync, _ = wfref.bench("hip", settings, 64, 1, 20, 300, hop=800, seed=scenarios.SEED)
+    finally:
+        del os.environ["WF_HIP_BATCHED_WAVE"]
+    us = lambda v: 2e6 / v  # (wfref_bench counts capture channels: a stereo source = 2 per frame)
+    print(f"\nplugin mode, 64 waveform displays (800 points, stereo): batched HIP {us(v_hip):.2f} us per source and frame, "
+          f"synchronous HIP {us(v_sync):.2f} us, reference AVX {us(v_avx):.2f} us")
+    assert wfref.hip_fallback_ticks() == before
+    assert us(v_hip) < us(v_sync) / 3, "one batch per frame must be several times cheaper than 64 upload/launch/download round trips"
+
+
 @pytest.mark.gpu
 def test_sixty_four_meter_sources_share_one_batch():
     """64 level-meter sources of one configuration: one handle, one ragged ingest + one meter_tick_kernel + one readback per

@@ -715,6 +715,34 @@ def run_dropin_batched_meter_case(seed):
         assert_levels_close(g["db"], w["db"], x["db"], what + " levels")
 
 
+def run_dropin_batched_wave_case(seed):
+    """waveform scripts through the plugin's batched waveform mode (rows read one frame late), against the plugin's own CPU
+    class.  Volume normalisation is taken out of the drawn configuration: such sources stay synchronous by design."""
+    import os
+    from pathlib import Path
+    import test_golden as tg
+    from oracle import wfref
+    from helpers import assert_db_close
+    os.environ["WF_HIP_LIBRARY"] = str(Path(__file__).resolve().parent.parent / "waveform_amd" / "libwaveform_hip.so")
+    os.environ["WF_HIP_BATCHED"] = "1"
+    cfg_dict, steps, sync_ms = draw_wave(seed)
+    cfg_dict = {k: v for k, v in cfg_dict.items() if k not in ("normalize_volume", "volume_target", "max_gain")}
+    cfg = scenarios.make_config(cfg_dict)
+    sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
+    before = wfref.hip_fallback_ticks()
+    late = tg._OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
+    assert late.be.src.using_hip
+    scenarios.play(late, sc)
+    got = late.finish()
+    assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before, "fell back to the CPU class"
+    want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
+    assert len(got) == len(want), (len(got), len(want))
+    for t, (g, w) in enumerate(zip(got, want)):
+        what = f"batched drop-in wave case {seed} tick {t} ({cfg_dict}, sync {sync_ms} ms)"
+        assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
+        assert_db_close(g["db"], w["db"], what + " rows", lin_eps=None)
+
+
 DROPIN_SEEDS = {"pow2": range(0, 80), "any": range(0, 40), "meter": range(0, 60), "wave": range(0, 60)}
 
 
@@ -737,6 +765,16 @@ def test_reference_plugin_with_batched_hip_meter_on_random_case(seed):
     if not wfref.available():
         pytest.skip("oracle/_ref/libwfref.so not built")
     run_dropin_batched_meter_case(seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(0, 60))
+def test_reference_plugin_with_batched_hip_waveform_on_random_case(seed):
+    """the batched waveform mode of the plugin on consecutive seeds of the wave family"""
+    from oracle import wfref
+    if not wfref.available():
+        pytest.skip("oracle/_ref/libwfref.so not built")
+    run_dropin_batched_wave_case(seed)
 
 
 @pytest.mark.gpu

@@ -105,6 +105,7 @@ def lib():
     L.wf_hip_set_hidden.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
     L.wf_hip_set_input_rms.argtypes = [vp, u32, u32, fp]
     L.wf_hip_set_stream_delay.argtypes = [vp, u32, u32, C.POINTER(C.c_uint32)]
+    L.wf_hip_set_stream_audio_ts.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     L.wf_hip_sync.argtypes = [vp]
     L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
@@ -303,6 +304,11 @@ class SpectrumBatch:
         """delay_frames: uint32[count], A/V-sync delay of streams first.. in frames (added to the tick's delay_frames)"""
         d = np.ascontiguousarray(delay_frames, dtype=np.uint32)
         self._ck(self.L.wf_hip_set_stream_delay(self.h, first, len(d), d.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+    def set_stream_audio_ts(self, audio_ts_ns, first: int = 0):
+        """waveform batches: m_audio_ts per stream (ns) instead of TickParams.audio_ts_ns (wf_hip_set_stream_audio_ts)"""
+        d = np.ascontiguousarray(audio_ts_ns, dtype=np.uint64)
+        self._ck(self.L.wf_hip_set_stream_audio_ts(self.h, first, len(d), d.ctypes.data_as(C.POINTER(C.c_uint64))))
 
     def set_input_rms(self, rms, first: int = 0):
         """rms: float32[count], m_input_rms of streams first.. (per-stream volume normalisation)"""

@@ -113,6 +113,7 @@ struct wf_hip {
     int bar_stage_off = 0;           // BarArgs::stage_off
     uint32_t *d_delay = nullptr;     // [n_streams] A/V-sync delay per stream (wf_hip_set_stream_delay), or nullptr
     uint32_t max_stream_delay = 0;   // largest value ever set (ring-capacity check of the tick)
+    unsigned long long *d_audio_ts = nullptr; // [n_streams] m_audio_ts per stream of a waveform batch (wf_hip_set_stream_audio_ts), or nullptr
     bool stream_delays_aligned = true; // all of them multiples of 4 frames (vector fetch without straddling)
     float *d_vol_comp = nullptr;     // [n_streams] volume compensation per stream (wf_hip_set_input_rms), or nullptr
     // volume-normalisation producer on the device (wf_hip_enable_input_rms): update_input_rms per stream and tick
@@ -1723,6 +1724,7 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
         w.rows = h->d_decibels;
         w.stream_flags = h->d_flags;
         w.audio_ts = p->audio_ts_ns;
+        w.audio_ts_stream = h->d_audio_ts;
         w.step_ns = ((unsigned long long)h->cfg.meter_ms * 1000000ull) / h->N; // src/source_generic.cpp:299
         w.waveform_samples = h->wave_samples;
         w.width = h->N;
@@ -1864,8 +1866,8 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
         return fail(h, WF_HIP_ERR_INVALID, "mask is NULL");
     if(h->meter || h->wave)
         for(uint32_t i = 0; i < count; ++i)
-            if((mask[i] == WF_HIP_PAUSED && h->wave) || mask[i] == WF_HIP_STARVED)
-                return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_STARVED applies to spectrum batches only, WF_HIP_PAUSED to spectrum and meter batches");
+            if(mask[i] == WF_HIP_STARVED)
+                return fail(h, WF_HIP_ERR_INVALID, "WF_HIP_STARVED applies to spectrum batches only");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     if(h->mask_bytes < count) {
         rc = dev_alloc(h, &h->d_mask, (size_t)count);
@@ -1908,6 +1910,28 @@ int wf_hip_set_stream_delay(wf_hip *h, uint32_t first, uint32_t count, const uin
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `delay_frames` is borrowed for the call only
     h->max_stream_delay = std::max(h->max_stream_delay, mx);
     h->stream_delays_aligned = h->stream_delays_aligned && al; // conservative: never switches back to the vector fetch
+    return WF_HIP_OK;
+}
+
+int wf_hip_set_stream_audio_ts(wf_hip *h, uint32_t first, uint32_t count, const uint64_t *audio_ts_ns)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(!h->wave)
+        return fail(h, WF_HIP_ERR_INVALID, "per-stream audio timestamps belong to waveform batches");
+    if(audio_ts_ns == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "audio_ts_ns is NULL");
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit timestamps");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    if(h->d_audio_ts == nullptr) {
+        rc = dev_alloc(h, &h->d_audio_ts, (size_t)h->n_streams);
+        if(rc)
+            return rc;
+        WF_HIP_TRY(h, hipMemsetAsync(h->d_audio_ts, 0, (size_t)h->n_streams * sizeof(unsigned long long), h->stream));
+    }
+    WF_HIP_TRY(h, hipMemcpyAsync(h->d_audio_ts + first, audio_ts_ns, (size_t)count * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `audio_ts_ns` is borrowed for the call only
     return WF_HIP_OK;
 }
 

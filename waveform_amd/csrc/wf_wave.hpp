@@ -27,6 +27,7 @@ struct WaveArgs {
     float *rows;               // [n_streams][out_ch][width] m_decibels
     uint32_t *stream_flags;
     unsigned long long audio_ts; // m_audio_ts: end-of-audio timestamp of the newest captured sample (ns)
+    const unsigned long long *audio_ts_stream; // per stream instead (wf_hip_set_stream_audio_ts), or nullptr
     unsigned long long step_ns;  // (m_meter_ms * 1000000) / width, :299
     uint32_t waveform_samples; // m_waveform_samples
     uint32_t width;            // m_fft_size = m_width
@@ -141,6 +142,9 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     const bool was_silent = (sflags & WF_STREAM_LAST_SILENT) != 0;
     float *rows = a.rows + (size_t)stream * a.out_ch * W;
     const uint32_t disp = a.stereo ? 2u : 1u;
+    if(sflags & WF_STREAM_PAUSED) // not ticked in this video frame: nothing of the stream moves
+        return;
+    const unsigned long long audio_ts = a.audio_ts_stream ? a.audio_ts_stream[stream] : a.audio_ts;
 
     if(sflags & WF_STREAM_HIDDEN) { // !m_show || capture timed out, :279-288
         if(was_silent)
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     const uint32_t max_size = a.waveform_samples + R;
     const uint32_t total = avail < max_size ? avail : max_size; // :303-304
     const uint32_t sr = a.sample_rate;
-    const unsigned long long start_ts = a.audio_ts - frames_to_ns(total, sr);
-    const unsigned long long stop_ts = a.audio_ts - frames_to_ns(R, sr);
-    if(start_ts >= a.audio_ts || stop_ts > a.audio_ts) {
+    const unsigned long long start_ts = audio_ts - frames_to_ns(total, sr);
+    const unsigned long long stop_ts = audio_ts - frames_to_ns(R, sr);
+    if(start_ts >= audio_ts || stop_ts > audio_ts) {
         // timestamp rollover, :316-317 (a tick before any audio has a timestamp).  The rows are untouched, but the reference
         // has already trimmed the ring to max_size on its way here (:303-304), and the samples it dropped stay dropped
         if(lane == 0 && avail > max_size)
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(WAVE_THREADS) void waveform_tick_kernel(const WaveA
     p.x1 = p.x0 + a.ring_stride;
     p.rows = rows;
     p.W = W; p.keep = W - counts; p.counts = counts; p.wpos = wpos; p.R = R; p.total = total; p.sr = sr; p.mask = a.ring_mask;
-    p.wts = wts; p.audio_ts = a.audio_ts; p.step_ns = a.step_ns;
+    p.wts = wts; p.audio_ts = audio_ts; p.step_ns = a.step_ns;
     p.two = a.cap_ch > 1;
     WaveOut o;
     o.stereo = a.stereo != 0; o.two = p.two; o.dup = a.out_ch > a.cap_ch; o.normalize = a.normalize != 0;
