@@ -513,3 +513,46 @@ def test_magnitude_range_headroom_and_floor(n, loud, quiet):
         assert_db_close(got, o.decibels(), f"N={n}, audio scaled by {g}")
         if factor != 1.0:
             assert np.median(got) > wf.db_min() + 50, "the scaled frame must not have collapsed to DB_MIN"
+
+
+def test_waveform_batch_with_per_stream_timestamps_and_paused_streams():
+    """wf_hip_set_stream_audio_ts / wf_hip_set_stream_delay / WF_HIP_PAUSED on a waveform batch (ABI 9; what the plugin's batched
+    waveform mode hands over): three streams that receive different amounts of audio per frame, each with its own end-of-audio
+    timestamp and A/V-sync reserve, one of them sitting frames out -- every stream must equal a single-stream handle that was
+    driven with the same values through wf_hip_tick_params, bit for bit."""
+    import waveform_amd as wf
+    from tools import synth
+    cfg = wf.Config.defaults(waveform=1, stereo=1, width=640, meter_ms=100)
+    sr = 48000
+    hops = [(800, 441, 1024), (800, 800, 37), (0, 960, 800), (800, 441, 1024), (1024, 0, 800), (800, 800, 800), (441, 441, 441), (800, 0, 0)]
+    delays = (0, 240, 960)
+    paused_frames = {(2, 2), (2, 5)}  # (stream, frame): not ticked, nothing pushed
+    with wf.SpectrumBatch(cfg, 3) as b, wf.SpectrumBatch(cfg, 1) as s0, wf.SpectrumBatch(cfg, 1) as s1, wf.SpectrumBatch(cfg, 1) as s2:
+        singles = (s0, s1, s2)
+        pos, ts = [0, 0, 0], [0, 0, 0]
+        b.set_stream_delay(np.array(delays, np.uint32))
+        for f, hop in enumerate(hops):
+            state = np.zeros(3, np.uint8)
+            for i in range(3):
+                if (i, f) in paused_frames:
+                    state[i] = 3  # WF_HIP_PAUSED
+                    continue
+                if hop[i]:
+                    a = synth.block(SEED, 40 + i, 1, 2, pos[i], hop[i])
+                    pos[i] += hop[i]
+                    ts[i] = 5_000_000_000 + pos[i] * 1_000_000_000 // sr + 7 * i
+                    b.push_audio(a, first=i)
+                    singles[i].push_audio(a)
+            b.set_hidden(state)
+            b.set_stream_audio_ts(np.array(ts, np.uint64))
+            b.tick(seconds=1 / 60)
+            rows, silent = b.decibels(), b.last_silent()
+            for i in range(3):
+                if (i, f) not in paused_frames:
+                    singles[i].tick(seconds=1 / 60, delay_frames=delays[i], audio_ts_ns=ts[i])
+                assert np.array_equal(rows[i], singles[i].decibels()[0]), f"frame {f} stream {i}: rows differ from the single-stream handle"
+                assert silent[i] == singles[i].last_silent()[0], f"frame {f} stream {i}: m_last_silent"
+    mcfg = wf.Config.defaults(meter=1)
+    with wf.SpectrumBatch(mcfg, 2) as m:
+        with pytest.raises(wf.WfHipError):
+            m.set_stream_audio_ts(np.zeros(2, np.uint64))   # not a waveform batch
