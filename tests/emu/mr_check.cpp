@@ -1,0 +1,123 @@
+// mr_check.cpp -- host check of the mixed-radix path (waveform_amd/csrc/wf_mixed.hpp + plan_mixed_radix), built and run by
+// tests/test_cpu_units.py::test_mixed_radix_plans_and_transforms.  Test infrastructure, not part of the product.
+//  * every in-register DFT against the definition in double;
+//  * for EVERY multiple of 16 in [128, 16384]: the plan exists exactly for the sizes with no prime factor above 5 that are not
+//    powers of two, multiplies to n / 2, uses the radices the kernel instantiates, keeps radices above 16 in the first pass and
+//    leaves the last pass one butterfly per thread of the container geometry;
+//  * for a spread of sizes: the passes themselves (mr_pass_first / mr_pass / the last pass's butterflies), lane by lane,
+//    against a double DFT.
+#include <cstdio>
+#include <cmath>
+#include <complex>
+#include <vector>
+#include "wf_geometry.hpp"
+#include "wf_mixed.hpp"
+#include "wf_host_tables.hpp"
+using namespace wf;
+static int failures = 0;
+#define CHECK(c, ...) do { if(!(c)) { ++failures; std::printf("FAIL " __VA_ARGS__); std::printf("\n"); } } while(0)
+
+template<int R> static void check_dft()
+{
+    cf v[R];
+    std::complex<double> x[R];
+    for(int i = 0; i < R; ++i) {
+        x[i] = {std::sin(1.0 + i * 0.7), std::cos(0.3 * i * i)};
+        v[i] = cf{(float)x[i].real(), (float)x[i].imag()};
+    }
+    MrDft<R>::run(v);
+    double err = 0;
+    for(int k = 0; k < R; ++k) {
+        std::complex<double> s = 0;
+        for(int n = 0; n < R; ++n)
+            s += x[n] * std::polar(1.0, -2 * M_PI * k * n / R);
+        err = std::max(err, std::abs(s - std::complex<double>(v[k].x, v[k].y)));
+    }
+    CHECK(err < 2e-6, "radix %d: max error %g", R, err);
+}
+
+static unsigned container_threads(unsigned n) // threads of the geometry the Bluestein / mixed-radix instantiation runs in (M >= n - 1)
+{
+    unsigned L = 512;
+    while(L < n - 1)
+        L <<= 1;
+    switch(2 * L) { case 1024: return 64; case 2048: return 64; case 4096: return 128; case 8192: return 256; case 16384: return 512; default: return 1024; }
+}
+
+int main()
+{
+    check_dft<2>(); check_dft<3>(); check_dft<4>(); check_dft<5>(); check_dft<6>(); check_dft<8>(); check_dft<9>(); check_dft<10>();
+    check_dft<12>(); check_dft<15>(); check_dft<16>(); check_dft<20>(); check_dft<25>();
+    int planned = 0;
+    for(unsigned n = 128; n <= 16384; n += 16) {
+        unsigned r = n;
+        for(unsigned p : {2u, 3u, 5u})
+            while(r % p == 0)
+                r /= p;
+        const bool smooth = r == 1, pow2 = (n & (n - 1)) == 0;
+        if(pow2)
+            continue;
+        int radix[4];
+        const unsigned np = n / 2, T = container_threads(n);
+        const int passes = plan_mixed_radix(np, T, radix);
+        CHECK((passes > 0) == smooth, "n = %u: plan %d passes, smooth %d", n, passes, (int)smooth);
+        if(passes <= 0)
+            continue;
+        ++planned;
+        unsigned long long prod = 1;
+        for(int i = 0; i < passes; ++i) {
+            const int v = radix[i];
+            prod *= (unsigned long long)v;
+            const bool known = v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 20 || v == 25;
+            CHECK(known && (v <= 16 || i == 0), "n = %u: radix %d in pass %d", n, v, i);
+        }
+        CHECK(passes >= 2 && passes <= 4 && prod == np, "n = %u: %d passes, product %llu", n, passes, prod);
+        CHECK(np / (unsigned)radix[passes - 1] <= T, "n = %u: last pass has %u butterflies for %u threads", n, np / radix[passes - 1], T);
+    }
+    std::printf("planned %d sizes\n", planned);
+    for(unsigned n : {800u, 1600u, 960u, 1920u, 2000u, 320u, 144u, 8000u, 1536u, 15552u, 12288u, 6000u}) {
+        int radix[4], off[4];
+        const unsigned np = n / 2, T = container_threads(n);
+        const int passes = plan_mixed_radix(np, T, radix);
+        std::vector<cfloat> twf, w;
+        build_mixed_radix_tables(n, passes, radix, twf, off, w);
+        std::vector<cf> tw(twf.size());
+        for(size_t i = 0; i < tw.size(); ++i)
+            tw[i] = cf{twf[i].re, twf[i].im};
+        unsigned M = 1;
+        while(M < 2 * np)
+            M <<= 1;
+        const unsigned H = M / 2;
+        std::vector<cf> lds(2 * M + 64);
+        std::vector<std::complex<double>> x(np);
+        for(unsigned i = 0; i < np; ++i) {
+            x[i] = {std::sin(0.1 * i) + 0.3 * std::cos(1.7 * i), std::cos(0.37 * i)};
+            lds[i] = cf{(float)x[i].real(), (float)x[i].imag()};
+        }
+        int ns = radix[0], cur = 1;
+        for(unsigned t = 0; t < T; ++t)
+            mr_pass_first(radix[0], lds.data(), lds.data() + H, (int)np, (int)t, (int)T);
+        for(int s = 1; s + 1 < passes; ++s) {
+            for(unsigned t = 0; t < T; ++t)
+                mr_pass(radix[s], lds.data() + cur * H, lds.data() + (1 - cur) * H, tw.data() + off[s], (int)np, ns, (int)t, (int)T);
+            cur ^= 1;
+            ns *= radix[s];
+        }
+        // the last pass through the middle-pass code (same butterflies, linear output): one butterfly per thread
+        std::vector<cf> out(np);
+        for(unsigned t = 0; t < T; ++t)
+            mr_pass(radix[passes - 1], lds.data() + cur * H, out.data(), tw.data() + off[passes - 1], (int)np, ns, (int)t, (int)T);
+        double err = 0, mx = 0;
+        for(unsigned k = 0; k < np; k += 3) {
+            std::complex<double> s = 0;
+            for(unsigned m = 0; m < np; ++m)
+                s += x[m] * std::polar(1.0, -2 * M_PI * (double)((unsigned long long)k * m % np) / np);
+            err = std::max(err, std::abs(s - std::complex<double>(out[k].x, out[k].y)));
+            mx = std::max(mx, std::abs(s));
+        }
+        std::printf("n = %u: %d passes %dx%dx%dx%d, max error %.3g of %.3g\n", n, passes, radix[0], radix[1], radix[2], radix[3], err, mx);
+        CHECK(err <= 2e-6 * mx, "n = %u: transform error %g of %g", n, err, mx);
+    }
+    std::printf(failures ? "FAILED %d\n" : "ok\n", failures);
+    return failures ? 1 : 0;
+}

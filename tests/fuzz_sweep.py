@@ -12,7 +12,7 @@ import test_gpu_fuzz as f  # noqa: E402
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pow2", "any", "meter", "wave"]
 run = {"pow2": lambda s: f.run_spectrum_case(s, "pow2"), "any": lambda s: f.run_spectrum_case(s, "any"),
-       "huge": lambda s: f.run_spectrum_case(s, "huge"), "wide": lambda s: f.run_spectrum_case(s, "wide"), "meter": f.run_meter_case, "meter-wide": lambda s: f.run_meter_case(s, wide=True),
+       "huge": lambda s: f.run_spectrum_case(s, "huge"), "smooth": lambda s: f.run_spectrum_case(s, "smooth"), "wide": lambda s: f.run_spectrum_case(s, "wide"), "meter": f.run_meter_case, "meter-wide": lambda s: f.run_meter_case(s, wide=True),
        "wave": f.test_hip_waveform_matches_oracle_on_random_case}
 
 

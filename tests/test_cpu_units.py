@@ -211,17 +211,23 @@ def test_power_of_two_kernels_do_not_spill():
 
     with cf.ThreadPoolExecutor(6) as ex:
         results = list(ex.map(usage, (512, 1024, 2048, 4096, 8192, 16384, 32768)))
-    seen = 0
+    seen = seen_mixed = 0
     for res in results:
         for name, scratch, vgprs in res:
-            blu = name.endswith("ELb1ELb0EEEvNS_8TickArgsE")  # <.., BLU = true, BOTH = false>: the compatibility path, a few spills tolerated
-            if blu:
+            m = re.search(r"ELb([01])ELb([01])ELb([01])EEEvNS_8TickArgsE$", name)  # <.., BLU, BOTH, MR>
+            assert m, name
+            blu, mixed = m.group(1) == "1", m.group(3) == "1"
+            if blu and not mixed:
+                continue  # Bluestein: the compatibility path, a few spills tolerated (bounded by the next test)
+            if mixed:     # the mixed-radix transform inside the same instantiation (wf_mixed.hpp): no scratch either
+                seen_mixed += 1
+                assert scratch == 0 and vgprs <= 128, f"{name}: {scratch} B of scratch per lane, {vgprs} VGPRs"
                 continue
             seen += 1
             assert scratch == 0, f"{name} uses {scratch} bytes of scratch per lane"
             # four waves per SIMD: one VGPR over 128 cost N = 2048 a quarter of its occupancy (and 5-15 %) in round 2
             assert vgprs <= 128, f"{name} needs {vgprs} VGPRs: three waves per SIMD instead of four"
-    assert seen >= 12
+    assert seen >= 12 and seen_mixed >= 6
 
 
 def test_compatibility_path_kernels_stay_near_their_register_budget(tmp_path):
@@ -260,6 +266,20 @@ template __global__ void wf::big_epilogue_kernel<3>(wf::TickArgs);
     for name, scratch in seen.items():
         limit = 0 if "big_" in name else 256
         assert scratch <= limit, f"{name}: {scratch} B of scratch per lane (limit {limit})"
+
+
+def test_mixed_radix_plans_and_transforms(tmp_path):
+    """wf_mixed.hpp (fft sizes 2^a 3^b 5^c computed directly instead of by Bluestein) on the host: tests/emu/mr_check.cpp runs
+    every in-register DFT against the definition, checks the plan of EVERY multiple of 16 up to 16384 (exists exactly for the
+    smooth sizes, multiplies to n / 2, respects the kernel's constraints), and replays the passes lane by lane against a double
+    DFT for a spread of sizes"""
+    exe = tmp_path / "mr_check"
+    src = ROOT / "waveform_amd" / "csrc"
+    cmd = ["g++", "-std=c++20", "-O1", f"-I{ROOT / 'include'}", f"-I{src}", str(ROOT / "tests" / "emu" / "mr_check.cpp"), str(src / "wf_host_tables.cpp"), "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok") and "planned 73 sizes" in run.stdout, run.stdout[-3000:]
 
 
 # ---- C ABI -----------------------------------------------------------------------------------------------

@@ -22,6 +22,7 @@ REF_EVERY = 1              # every spectrum seed is also played against libwfref
 MAX_POW2 = 32768
 MAX_ANY = 10912
 RESTATEMENT_MAX_PRIME = 61  # lengths whose largest prime factor exceeds this are checked against libwfref.so only
+SMOOTH_SEEDS = range(200)  # fft sizes 2^a 3^b 5^c that are not powers of two: the mixed-radix path (wf_mixed.hpp)
 HUGE_SEEDS = range(60)     # the sizes beyond a CU's LDS (wf_big.hpp): 65536 and every other multiple of 16 above 10912
 
 
@@ -34,8 +35,18 @@ def _largest_prime_factor(n: int) -> int:
     return max(best, n) if n > 1 else best
 
 
+def _five_smooth(n):
+    for p in (2, 3, 5):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+SMOOTH_SIZES = [n for n in range(128, 16384 + 1, 16) if _five_smooth(n) and n & (n - 1)]
+
+
 def draw(seed: int, family: str = "pow2"):
-    r = np.random.default_rng({"pow2": 1000, "any": 77000, "huge": 555000}[family] + seed)
+    r = np.random.default_rng({"pow2": 1000, "any": 77000, "huge": 555000, "smooth": 880000}[family] + seed)
     if family == "huge":
         # 65536 itself a quarter of the time, else ANY multiple of 16 in (10912, 65536) -- awkward prime factors included: that
         # is where the device's Bluestein path matters.  The restatement's DFT of a length with a large prime factor p costs
@@ -48,6 +59,13 @@ def draw(seed: int, family: str = "pow2"):
                 n = 16 * int(r.integers(10912 // 16 + 1, 65536 // 16))
                 if n & (n - 1):
                     break
+    elif family == "smooth":
+        # the sizes the mixed-radix path takes (wf_mixed.hpp): multiples of 16 up to 16384 with no prime factor above 5 that are
+        # not powers of two -- the automatic sizes at 48 kHz (800, 1600, 960, 1920, 2000) a fifth of the time
+        if r.random() < 0.2:
+            n = int(r.choice([800, 1600, 960, 1920, 2000, 400, 320]))
+        else:
+            n = int(r.choice(SMOOTH_SIZES))
     elif family == "pow2":
         sizes = [128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
         p = np.array([0.07, 0.07, 0.08, 0.2, 0.17, 0.17, 0.09, 0.07, 0.04, 0.04])
@@ -357,6 +375,21 @@ def test_hip_matches_oracle_on_random_huge_size(seed):
 @pytest.mark.parametrize("seed", BLU_SEEDS)
 def test_hip_matches_oracle_on_random_size(seed):
     run_spectrum_case(seed, "any")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SMOOTH_SEEDS)
+def test_hip_matches_oracle_on_random_smooth_size(seed):
+    run_spectrum_case(seed, "smooth")
+
+
+@pytest.mark.gpu
+def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
+    import waveform_amd as wf
+    for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, False), (4160, False), (176, False), (144, True), (15552, True)):
+        with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
+            name = b.kernel_name()
+            assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)
 
 
 @pytest.mark.gpu

@@ -90,6 +90,9 @@ struct wf_hip {
     bool split_mono = false;         // ... and, for mono mixdown, in different launches (TickArgs::split_ch)
     // FFT sizes that are not powers of two: Bluestein over the geometry of geom_n = 2 * L points (spectrum_tick_kernel<.., BLU>)
     bool blu = false;
+    int mr_passes = 0;               // > 0: fft_size = 2^a 3^b 5^c, the transform runs as mixed-radix passes inside the Bluestein instantiation (wf_mixed.hpp)
+    int mr_radix[4] = {0, 0, 0, 0}, mr_tw_off[4] = {0, 0, 0, 0};
+    wf::cf *d_mr_tw = nullptr;       // the passes' twiddle tables (wf::build_mixed_radix_tables)
     uint32_t geom_n = 0;             // the fft size whose geometry runs the batch (N itself for the power-of-two sizes >= 1024)
     wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr, *d_blu_q = nullptr, *d_blu_qr = nullptr, *d_blu_w = nullptr;
     // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
@@ -292,7 +295,7 @@ template<class G, int DEC> int setup_launch_dec(wf_hip *h)
 }
 
 // Bluestein path (FFT sizes that are not powers of two): always the scalar fetch
-template<class G, int SPW, bool SPLIT> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a0, bool)
+template<class G, int SPW, bool SPLIT, bool MR = false> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a0, bool)
 {
     const uint32_t n_spec = a0.stream_count * a0.cap_ch;
     const dim3 block(G::T * SPW);
@@ -302,22 +305,60 @@ template<class G, int SPW, bool SPLIT> void launch_tick_blu(wf_hip *h, const wf:
         wf::TickArgs a = a0;
         a.split_ch = two ? (uint32_t)(1 - pass) : 0xffffffffu;
         const dim3 grid(two ? a.stream_count : (n_spec + SPW - 1) / SPW);
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>), grid, block, lds, h->launch_stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR>), grid, block, lds, h->launch_stream, a);
     }
 }
 
-template<class G, int SPW, bool SPLIT> int setup_launch_blu(wf_hip *h)
+template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_hip *h)
 {
+    if constexpr(!MR && G::N >= 1024) { // (the smallest container a size that is not a power of two ever gets: wf::bluestein_length)
+        // sizes with no prime factor above 5 take the same instantiation's fetch and epilogue around a direct transform
+        const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX"); // (development: A/B against Bluestein)
+        if(!(off && off[0] == '1') && wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix) > 0) {
+            h->mr_passes = wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix);
+            if(const char *e = std::getenv("WF_HIP_MR_PLAN")) { // (development: "25,16" -- another order or split of the same product)
+                int r[4] = {0, 0, 0, 0}, n = 0;
+                uint64_t prod = 1;
+                for(const char *q = e; *q && n < 4;) {
+                    r[n] = std::atoi(q);
+                    prod *= (uint64_t)std::max(r[n], 1);
+                    ++n;
+                    while(*q && *q != ',') ++q;
+                    if(*q == ',') ++q;
+                }
+                bool ok = n >= 2 && prod == h->N / 2 && r[n - 1] <= 16 && (h->N / 2) / (uint32_t)r[n - 1] <= (uint32_t)G::T;
+                for(int i = 0; i < n; ++i) {
+                    const int v = r[i];
+                    ok = ok && (v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 ||
+                                (i == 0 && (v == 20 || v == 25)));
+                }
+                if(ok) {
+                    h->mr_passes = n;
+                    for(int i = 0; i < 4; ++i)
+                        h->mr_radix[i] = r[i];
+                }
+            }
+            return setup_launch_blu<G, SPW, SPLIT, true>(h);
+        }
+    }
     const int lds = (int)wf::tick_lds_bytes<G, SPW>();
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true>),
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    h->launch = &launch_tick_blu<G, SPW, SPLIT>;
+    h->launch = &launch_tick_blu<G, SPW, SPLIT, MR>;
     h->wg_lds = (uint32_t)lds;
     h->wg_threads = (uint32_t)(G::T * SPW);
     h->split = SPLIT;
-    char name[128];
-    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%u by Bluestein over %d complex points,T=%d,R=%dx%dx%d,SPW=%d%s>", h->N, G::M, G::T,
-             G::R1, G::R2, G::R3, SPW, SPLIT ? ",split" : "");
+    char name[160];
+    if(MR) {
+        char rad[48];
+        int o = 0;
+        for(int i = 0; i < h->mr_passes; ++i)
+            o += snprintf(rad + o, sizeof(rad) - (size_t)o, "%s%d", i ? "x" : "", h->mr_radix[i]);
+        snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%u: %u complex points as mixed radix %s,T=%d,SPW=%d%s>", h->N, h->N / 2, rad, G::T, SPW,
+                 SPLIT ? ",split" : "");
+    } else
+        snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%u by Bluestein over %d complex points,T=%d,R=%dx%dx%d,SPW=%d%s>", h->N, G::M, G::T,
+                 G::R1, G::R2, G::R3, SPW, SPLIT ? ",split" : "");
     h->kernel_name = name;
     return WF_HIP_OK;
 }
@@ -610,6 +651,12 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.blu_q = h->d_blu_q;
         a.blu_qr = h->d_blu_qr;
         a.blu_w = h->d_blu_w;
+        a.mr.passes = h->mr_passes;
+        for(int i = 0; i < 4; ++i) {
+            a.mr.radix[i] = h->mr_radix[i];
+            a.mr.tw_off[i] = h->mr_tw_off[i];
+        }
+        a.mr.tw = h->d_mr_tw;
         if(h->big_l) // direct form: |c_k| / L, times mag_coefficient (the packed form's tables carry the 1 / L, and its real split the 1 / 2)
             a.half_coef = (2.0f / h->tab.window_sum) / (float)h->big_l;
     }
@@ -1260,7 +1307,18 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_tws, t3));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
     }
-    if(h->blu) {
+    if(h->blu && h->mr_passes > 0) {
+        // mixed radix: the window table the power-of-two kernels use (it is uploaded for every handle), W_(N/2)^m for the passes
+        // and W_N^k for the real split; none of Bluestein's chirp tables
+        std::vector<wf::cfloat> twf, wf_;
+        wf::build_mixed_radix_tables(h->N, h->mr_passes, h->mr_radix, twf, h->mr_tw_off, wf_);
+        std::vector<wf::cf> t1(twf.size()), t2(wf_.size());
+        std::memcpy(t1.data(), twf.data(), t1.size() * sizeof(wf::cf));
+        std::memcpy(t2.data(), wf_.data(), t2.size() * sizeof(wf::cf));
+        WF_CREATE_TRY(upload(h, &h->d_mr_tw, t1));
+        WF_CREATE_TRY(upload(h, &h->d_blu_w, t2));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+    } else if(h->blu) {
         wf::BluesteinTables bt;
         wf::build_bluestein(h->cfg, h->tab, bt);
         std::vector<wf::cf> ta(bt.a.size()), tb(bt.b.size());

@@ -774,6 +774,113 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
     }
 }
 
+int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4])
+{
+    static const int kRadices[] = {25, 20, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+    {
+        uint32_t r = np;
+        for(uint32_t p : {2u, 3u, 5u})
+            while(r % p == 0)
+                r /= p;
+        if(np < 4 || r != 1) {
+            radix[0] = radix[1] = radix[2] = radix[3] = 0;
+            return 0;
+        }
+    }
+    int best[4] = {0, 0, 0, 0}, best_n = 0, best_min = 0, cur[4];
+    // multisets of 2 .. 4 radices (non-increasing) with product np
+    auto consider = [&](int n) {
+        // order: a radix above 16 must be first (at most one); the last one is the largest radix <= 16 with np / R <= threads;
+        // the first one otherwise an odd radix (its stores go out with stride R: conflict-free when R is odd)
+        int order[4], used[4] = {0, 0, 0, 0}, big = 0;
+        for(int i = 0; i < n; ++i)
+            big += cur[i] > 16;
+        if(big > 1)
+            return;
+        int last = -1;
+        for(int i = 0; i < n; ++i)
+            if(cur[i] <= 16 && np / (uint32_t)cur[i] <= threads && (last < 0 || cur[i] > cur[last]))
+                last = i;
+        if(last < 0)
+            return;
+        used[last] = 1;
+        int first = -1;
+        for(int i = 0; i < n; ++i)
+            if(!used[i] && cur[i] > 16)
+                first = i;
+        if(first < 0)
+            for(int i = 0; i < n; ++i)
+                if(!used[i] && (cur[i] & 1) && (first < 0 || cur[i] > cur[first]))
+                    first = i;
+        if(first < 0)
+            for(int i = 0; i < n; ++i)
+                if(!used[i] && (first < 0 || cur[i] > cur[first]))
+                    first = i;
+        if(first < 0)
+            return; // (n >= 2: cannot happen)
+        used[first] = 1;
+        int k = 0;
+        order[k++] = cur[first];
+        for(int i = 0; i < n; ++i)
+            if(!used[i])
+                order[k++] = cur[i];
+        order[k++] = cur[last];
+        int mn = order[0];
+        for(int i = 1; i < n; ++i)
+            mn = std::min(mn, order[i]);
+        if(best_n == 0 || n < best_n || (n == best_n && mn > best_min)) {
+            best_n = n;
+            best_min = mn;
+            for(int i = 0; i < n; ++i)
+                best[i] = order[i];
+        }
+    };
+    auto rec = [&](auto &&self, uint32_t rest, int depth, int max_idx) -> void {
+        if(rest == 1) {
+            if(depth >= 2)
+                consider(depth);
+            return;
+        }
+        if(depth == 4)
+            return;
+        for(int i = max_idx; i < (int)(sizeof(kRadices) / sizeof(kRadices[0])); ++i)
+            if(rest % (uint32_t)kRadices[i] == 0) {
+                cur[depth] = kRadices[i];
+                self(self, rest / (uint32_t)kRadices[i], depth + 1, i);
+            }
+    };
+    rec(rec, np, 0, 0);
+    for(int i = 0; i < 4; ++i)
+        radix[i] = i < best_n ? best[i] : 0;
+    return best_n;
+}
+
+void build_mixed_radix_tables(uint32_t n, int passes, const int radix[4], std::vector<cfloat> &tw, int tw_off[4], std::vector<cfloat> &w)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    const uint32_t np = n / 2;
+    tw.clear();
+    uint64_t ns = 1;
+    for(int s = 0; s < 4; ++s) {
+        tw_off[s] = (int)tw.size();
+        if(s >= passes)
+            continue;
+        const uint64_t R = (uint64_t)radix[s], len = ns * R;
+        if(s >= 1)
+            for(uint64_t k = 0; k < R; ++k)
+                for(uint64_t jm = 0; jm < ns; ++jm) {
+                    const double a = -two_pi * (double)((k * jm) % len) / (double)len;
+                    tw.push_back(cfloat{(float)std::cos(a), (float)std::sin(a)});
+                }
+        ns = len;
+    }
+    w.resize(np);
+    for(uint32_t m = 0; m < np; ++m) {
+        const double b = -two_pi * (double)m / (double)n;
+        w[m] = cfloat{(float)std::cos(b), (float)std::sin(b)};
+    }
+}
+
 void build_twiddles(int M, int R1, int R2, int R3, std::vector<cfloat> &tw1, std::vector<cfloat> &tw2, std::vector<cfloat> &tws)
 {
     const double two_pi = 6.283185307179586476925286766559;

@@ -114,6 +114,15 @@ uint32_t bluestein_length(uint32_t n);
 void build_big_twiddles(uint32_t L, uint32_t rows, uint32_t real_n, std::vector<cfloat> &tw_big, std::vector<cfloat> &tws_big);
 void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out);
 
+// FFT sizes with no prime factor above 5 (wf_mixed.hpp): the n/2-point transform as two to four mixed-radix passes instead of
+// Bluestein.  plan_mixed_radix fills radix[] in pass order and returns the number of passes, 0 when np has another prime
+// factor or no ordering fits: radices above 16 only in the first pass (the twiddled passes hold 2 (R - 1) more registers), and
+// the last pass has one butterfly per thread at most (np / radix[last] <= threads).
+int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4]);
+// tw: for every pass s >= 1 its twiddles [R_s][Ns] = W_(Ns R_s)^(k jm) (Ns = product of the radices before it), concatenated;
+// tw_off[s] = where pass s starts.  w[k] = W_n^k, the real-split twiddles (k < n / 2)
+void build_mixed_radix_tables(uint32_t n, int passes, const int radix[4], std::vector<cfloat> &tw, int tw_off[4], std::vector<cfloat> &w);
+
 // vertex fill (cfg.vertices): the geometry constants of render_bars / render_curve and m_cap_verts (src/source.cpp:1293-1309)
 struct VertexTables {
     int mode = 0;          // 0: bars, 1: curve triangle strip, 2: curve line strip, 3: stepped bars

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include "wf_geometry.hpp"
 #include "wf_tick_phases.hpp"
+#include "wf_mixed.hpp"
 #include "wf_synth.h"
 #include "wf_hip.h"
 
@@ -145,11 +146,12 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // BOTH (SPW == 2, mono mixdown with a curve display): the stream's one displayed row is finished by the threads of both
 // spectra.  A template parameter, not a run-time flag: the extra code cost the 2048-point kernel a VGPR too many (129: three
 // waves per SIMD instead of four) and 5-15 % even on configurations that never take the path.
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false>
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false>
 __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
     static_assert(!BOTH || (SPW == 2 && !SPLIT && DEC == 0 && !BLU), "shared curve row: two spectra per workgroup, power-of-two sizes");
     static_assert(!BLU || (DEC == 0 && !TLDS && !ALIGNED), "Bluestein path: scalar fetch, no decimation, no staged tables");
+    static_assert(!MR || BLU, "the mixed-radix transform (wf_mixed.hpp) runs inside the Bluestein instantiation's fetch and epilogue");
     static_assert(!TLDS || (SPW == 2 && !SPLIT && DEC == 0 && (size_t)SPW * G::LDS_CF * sizeof(cf) >= 2u * G::N * sizeof(float)),
                   "staged tables: window + pass-1 twiddles must fit the workgroup's exchange buffers");
     static_assert(!SPLIT || SPW == 1, "split mode: one spectrum per workgroup");
@@ -221,7 +223,18 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     // (hidden streams are fetched too: the flags word is not waited for before the loads are issued)
     P1Regs<G> r1;
     bool nz = false;
-    if constexpr(BLU) {
+    float mr_touch[2] = {0.0f, 0.0f};
+    if constexpr(BLU && MR) {
+        if(active) // windowed sample pairs straight into the exchange buffer, natural order (wf_mixed.hpp)
+            nz = mr_fetch<G>(a, t, x, start, lds) && !hidden;
+        // one dword of every 64-byte line of the smoothing state and the slope table of this row, requested now and never
+        // used: the epilogue's own loads (it keeps no operands across the passes) find the lines in the L2 (+2.5 ... 4 % from
+        // 128 threads per spectrum; -2 % on the one-wavefront geometries, where it is left out)
+        if(G::T > 64 && active && 16 * t < MO) {
+            mr_touch[0] = (a.mode & WF_MODE_TSMOOTH) ? ts[16 * t] : 0.0f;
+            mr_touch[1] = a.slope[16 * t];
+        }
+    } else if constexpr(BLU) {
         if(active)
             nz = (blu_table_via_lds<G>() ? p1_fetch_blu<G>(a, t, x, start, r1) : p1_fetch_blu_direct<G>(a, t, x, start, r1)) && !hidden;
     } else if(active)
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
         lds_dma_copy<G::N * (int)sizeof(float)>(a.window, smem_raw, wave_in_block, T * SPW / 64, lane);
         lds_dma_copy<G::M * (int)sizeof(cf)>(a.tw1, smem_raw + G::N * sizeof(float), wave_in_block, T * SPW / 64, lane);
     }
-    if constexpr(BLU && blu_table_via_lds<G>()) // the chirped window: staged in the (still free) exchange buffer, see p1_fetch_blu
+    if constexpr(BLU && !MR && blu_table_via_lds<G>()) // the chirped window: staged in the (still free) exchange buffer, see p1_fetch_blu
         blu_table_to_lds(a, smem_raw, wave_in_block, T * SPW / 64, lane);
     // the workgroup's copy of the pass-2 twiddles: LDS-DMA (no staging registers), requested behind the window so that it
     // costs no round trip of its own; complete at the barrier below
@@ -316,85 +329,91 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     float mag[RP];
     WF_STAMP(2);
     P4Regs<G> r4;
-    if constexpr(TLDS) {
-        cf o1[G::R1][G::B1];
-        if(process) {
-            p1_tables_from_lds<G>(t, reinterpret_cast<const cf *>(smem_raw), r1);
-            p1_window_dft<G>(r1, o1);
+    if constexpr(BLU && MR) {
+        // FFT sizes with no prime factor above 5: the n/2-point transform itself, two to four mixed-radix passes between the two
+        // halves of the exchange buffer (wf_mixed.hpp) instead of Bluestein's two power-of-two transforms
+        mr_transform<G>(a.mr, process, (int)a.row_bins, t, lds, [] { spectrum_sync<G>(); });
+    } else {
+        if constexpr(TLDS) {
+            cf o1[G::R1][G::B1];
+            if(process) {
+                p1_tables_from_lds<G>(t, reinterpret_cast<const cf *>(smem_raw), r1);
+                p1_window_dft<G>(r1, o1);
+            }
+            __syncthreads(); // every thread has taken its operands: pass 1 may overwrite the staged tables
+            if(process)
+                p1_store<G>(t, lds, o1);
         }
-        __syncthreads(); // every thread has taken its operands: pass 1 may overwrite the staged tables
-        if(process)
-            p1_store<G>(t, lds, o1);
-    }
-    if constexpr(BLU && blu_table_via_lds<G>()) {
-        cf o1[G::R1][G::B1];
-        if(process) {
-            blu_products_from_lds<G>(a, t, reinterpret_cast<const cf *>(smem_raw), r1);
-            p1_window_dft<G>(r1, o1);
+        if constexpr(BLU && blu_table_via_lds<G>()) {
+            cf o1[G::R1][G::B1];
+            if(process) {
+                blu_products_from_lds<G>(a, t, reinterpret_cast<const cf *>(smem_raw), r1);
+                p1_window_dft<G>(r1, o1);
+            }
+            __syncthreads(); // every thread has taken its table entries: pass 1 may overwrite the staged table
+            if(process)
+                p1_store<G>(t, lds, o1);
         }
-        __syncthreads(); // every thread has taken its table entries: pass 1 may overwrite the staged table
-        if(process)
-            p1_store<G>(t, lds, o1);
-    }
-    if(process) {
-        if constexpr(!TLDS && !(BLU && blu_table_via_lds<G>()))
-            p1_window_pass1<G>(a, t, r1, lds);
-        if constexpr(DEC > 0)
-            p4_prefetch_dec<G, DEC>(a, t, ts, r4);
-        else if constexpr(!BLU && !Policy<G>::PREFETCH_LATE) // the Bluestein epilogue loads its (shorter) rows itself
-            p4_prefetch<G>(a, t, ts, r4);
-    }
-    __builtin_amdgcn_sched_barrier(0); // keep the prefetch up here: do not sink it to its first use in P4
-    WF_STAMP(3);
-    spectrum_sync<G>();
-    if(process)
-        p2_read<G>(t, lds, v);
-    spectrum_sync<G>();
-    WF_STAMP(4);
-    if(process)
-        p2_pass2_write<G>(tw2_lds, t, lds, v);
-    WF_STAMP(5);
-    spectrum_sync<G>();
-    if(process)
-        p3_read<G>(t, lds, v);
-    spectrum_sync<G>();
-    WF_STAMP(6);
-    if(process)
-        p3_pass3_write<G>(t, lds, v);
-    if constexpr(!BLU && DEC == 0 && Policy<G>::PREFETCH_LATE) {
-        if(process)
-            p4_prefetch<G>(a, t, ts, r4);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    WF_STAMP(7);
-    spectrum_sync<G>();
-    if constexpr(BLU) {
-        // second transform: conj(FFT(a) . FFT(b)) read from the natural-order buffer, then passes 1-3 again.
-        // The thread index goes through an opaque move first: with the same `t` the compiler shares the exchange-buffer address
-        // arithmetic of the two transforms and keeps the first one's addresses alive across everything in between (44-116 B of
-        // scratch per lane became 24-68 B); recomputing a few integer operations is free
-        int t2 = t;
-#if defined(__HIPCC__)
-        asm volatile("" : "+v"(t2));
-#endif
-        if(process)
-            blu_mid<G>(a, t2, lds, r1);
-        spectrum_sync<G>(); // every thread has read its points: pass 1 may overwrite the buffer
-        if(process)
-            p1_window_pass1<G>(a, t2, r1, lds);
+        if(process) {
+            if constexpr(!TLDS && !(BLU && blu_table_via_lds<G>()))
+                p1_window_pass1<G>(a, t, r1, lds);
+            if constexpr(DEC > 0)
+                p4_prefetch_dec<G, DEC>(a, t, ts, r4);
+            else if constexpr(!BLU && !Policy<G>::PREFETCH_LATE) // the Bluestein epilogue loads its (shorter) rows itself
+                p4_prefetch<G>(a, t, ts, r4);
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the prefetch up here: do not sink it to its first use in P4
+        WF_STAMP(3);
         spectrum_sync<G>();
         if(process)
-            p2_read<G>(t2, lds, v);
+            p2_read<G>(t, lds, v);
+        spectrum_sync<G>();
+        WF_STAMP(4);
+        if(process)
+            p2_pass2_write<G>(tw2_lds, t, lds, v);
+        WF_STAMP(5);
         spectrum_sync<G>();
         if(process)
-            p2_pass2_write<G>(tw2_lds, t2, lds, v);
+            p3_read<G>(t, lds, v);
         spectrum_sync<G>();
+        WF_STAMP(6);
         if(process)
-            p3_read<G>(t2, lds, v);
+            p3_pass3_write<G>(t, lds, v);
+        if constexpr(!BLU && DEC == 0 && Policy<G>::PREFETCH_LATE) {
+            if(process)
+                p4_prefetch<G>(a, t, ts, r4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        WF_STAMP(7);
         spectrum_sync<G>();
-        if(process)
-            p3_pass3_write<G>(t2, lds, v);
-        spectrum_sync<G>();
+        if constexpr(BLU) {
+            // second transform: conj(FFT(a) . FFT(b)) read from the natural-order buffer, then passes 1-3 again.
+            // The thread index goes through an opaque move first: with the same `t` the compiler shares the exchange-buffer address
+            // arithmetic of the two transforms and keeps the first one's addresses alive across everything in between (44-116 B of
+            // scratch per lane became 24-68 B); recomputing a few integer operations is free
+            int t2 = t;
+    #if defined(__HIPCC__)
+            asm volatile("" : "+v"(t2));
+    #endif
+            if(process)
+                blu_mid<G>(a, t2, lds, r1);
+            spectrum_sync<G>(); // every thread has read its points: pass 1 may overwrite the buffer
+            if(process)
+                p1_window_pass1<G>(a, t2, r1, lds);
+            spectrum_sync<G>();
+            if(process)
+                p2_read<G>(t2, lds, v);
+            spectrum_sync<G>();
+            if(process)
+                p2_pass2_write<G>(tw2_lds, t2, lds, v);
+            spectrum_sync<G>();
+            if(process)
+                p3_read<G>(t2, lds, v);
+            spectrum_sync<G>();
+            if(process)
+                p3_pass3_write<G>(t2, lds, v);
+            spectrum_sync<G>();
+        }
     }
     WF_STAMP(8);
 #if WF_BAR_COEF_EARLY
@@ -407,7 +426,9 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
 #endif
     if(process) {
         if constexpr(BLU) {
-            p4_direct<G>(a, t, lds, ts, mag);
+            if constexpr(MR)
+                asm volatile("" ::"v"(mr_touch[0]), "v"(mr_touch[1])); // (waited for here at the latest; see the fetch)
+            p4_direct<G, MR>(a, t, lds, ts, mag);
         } else if constexpr(DEC > 0) {
             if(row_thread)
                 p4_split_smooth_dec<G, DEC>(a, t, lds, ts, r1.wb, r4, mag);

@@ -1,0 +1,355 @@
+// wf_mixed.hpp -- FFT sizes whose only prime factors are 2, 3 and 5, computed directly (device code; also compiled by g++ for
+// tests/emu, which replays these functions lane by lane).
+//
+// The reference takes every multiple of 16 as fft_size (src/source.cpp:562-565) and FFTW gives it an O(n log n) plan for each.
+// Here the sizes that are not powers of two ran Bluestein's algorithm (two power-of-two transforms of L >= n - 1 points for the
+// n/2-point transform that is wanted: four to eight times the work of a neighbouring power of two).  Most sizes a user meets
+// are "smooth", though: the automatic size is sample_rate / fps & -16 (src/source.cpp:1161-1167) -- 800, 1600, 960, 1920, 2000
+// at 48 kHz -- and the slider moves in steps of 64.  For n/2 = 2^a 3^b 5^c the packed n/2-point transform is a Stockham
+// autosort FFT of two to four passes whose radices come from {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25}:
+//   * it lives where Bluestein's first transform lived: the fetch (windowed sample pairs, p1_fetch_blu) and the epilogue (real split
+//     with W_n^k, slope, smoothing: p4_direct) are the Bluestein path's own, with tables that carry the plain window and ones;
+//   * the exchange buffer of the power-of-two container (M >= n - 1 complex points) is two halves of >= n/2 points: a pass reads one
+//     half and writes the other, one barrier per pass, a thread takes the butterflies t, t + T, ... one at a time (R points in
+//     registers);
+//   * the last pass has at most one butterfly per thread (the planner sees to it), keeps it across a barrier and leaves the
+//     spectrum in the natural-order layout the epilogue reads (ex3).
+// Pass s (radix R, Ns = product of the radices before it, nb = np / R butterflies): butterfly j reads x[j + k nb], k < R,
+// multiplies by W_(Ns R)^(k (j mod Ns)) (a table per pass, [k][j mod Ns]: consecutive butterflies read consecutive entries), transforms, and writes
+// y[(j / Ns) Ns R + (j mod Ns) + k Ns].  Natural order in, natural order out.
+#pragma once
+#include "wf_tick_phases.hpp"
+
+namespace wf {
+
+// ---- compile-time twiddles: cos / sin of 2 pi m / r as literals after unrolling -------------------------------------
+constexpr double mr_pi = 3.14159265358979323846264338327950288;
+constexpr double mr_sin_series(double x) // |x| <= pi / 4
+{
+    const double x2 = x * x;
+    double term = x, sum = x;
+    for(int i = 1; i < 12; ++i) {
+        term *= -x2 / (double)((2 * i) * (2 * i + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double mr_cos_series(double x) // |x| <= pi / 4
+{
+    const double x2 = x * x;
+    double term = 1.0, sum = 1.0;
+    for(int i = 1; i < 12; ++i) {
+        term *= -x2 / (double)((2 * i - 1) * (2 * i));
+        sum += term;
+    }
+    return sum;
+}
+struct mr_cd { double c, s; };
+// (cos, sin) of 2 pi m / r, reduced to the first octant by the symmetries of the circle (exact for the multiples of pi / 4)
+constexpr mr_cd mr_cis(int m, int r)
+{
+    m %= r;
+    if(m < 0)
+        m += r;
+    // angle = 2 pi m / r = (pi / 4) * (8 m / r): octant o and remainder
+    const int num = 8 * m;        // angle in units of (pi / 4) / r ... o = floor(num / r)
+    const int o = num / r;        // 0 .. 7
+    const int rem = num - o * r;  // angle = (o + rem / r) pi / 4
+    const double f = (double)rem / (double)r * (mr_pi / 4.0); // in [0, pi / 4)
+    const double g = mr_pi / 4.0 - f;                          // in (0, pi / 4]
+    double c = 0.0, s = 0.0;
+    switch(o) {
+    case 0: c = mr_cos_series(f); s = mr_sin_series(f); break;
+    case 1: c = mr_sin_series(g); s = mr_cos_series(g); break;   // pi/4 + f = pi/2 - g
+    case 2: c = -mr_sin_series(f); s = mr_cos_series(f); break;  // pi/2 + f
+    case 3: c = -mr_cos_series(g); s = mr_sin_series(g); break;  // 3pi/4 + f = pi - g
+    case 4: c = -mr_cos_series(f); s = -mr_sin_series(f); break; // pi + f
+    case 5: c = -mr_sin_series(g); s = -mr_cos_series(g); break; // 5pi/4 + f = 3pi/2 - g
+    case 6: c = mr_sin_series(f); s = -mr_cos_series(f); break;  // 3pi/2 + f
+    default: c = mr_cos_series(g); s = -mr_sin_series(g); break; // 7pi/4 + f = 2pi - g
+    }
+    if(rem == 0) { // multiples of pi / 4: exact zeros and ones instead of 6e-17
+        const int q = o & 7;
+        const double h = 0.70710678118654752440084436210485;
+        const double cc[8] = {1, h, 0, -h, -1, -h, 0, h}, ss[8] = {0, h, 1, h, 0, -h, -1, -h};
+        c = cc[q];
+        s = ss[q];
+    }
+    return mr_cd{c, s};
+}
+// W_R^m, m < R, as floats: a literal table per radix; the index is a compile-time constant after unrolling, so what reaches
+// the instruction stream is the pair of immediates
+template<int R> struct MrTwiddles {
+    float c[R], s[R];
+    constexpr MrTwiddles() : c{}, s{}
+    {
+        for(int m = 0; m < R; ++m) {
+            const mr_cd w = mr_cis(m, R);
+            c[m] = (float)w.c;
+            s[m] = (float)w.s;
+        }
+    }
+};
+// d * W_R^m, W_R = exp(-2 pi i / R)
+template<int R> WF_DEV cf mr_mul_w(cf d, int m)
+{
+    constexpr MrTwiddles<R> tab{};
+    m %= R;
+    if(m == 0)
+        return d;
+    if(4 * m == R)
+        return cf{d.y, -d.x};
+    if(2 * m == R)
+        return cf{-d.x, -d.y};
+    if(4 * m == 3 * R)
+        return cf{-d.y, d.x};
+    const float wr = tab.c[m], wi = -tab.s[m];
+    return cf{fmaf(d.x, wr, -(d.y * wi)), fmaf(d.x, wi, d.y * wr)};
+}
+
+// ---- in-register DFTs, natural order in and out ------------------------------------------------------------------------
+template<int R> struct MrDft;
+template<> struct MrDft<2> {
+    static WF_DEV void run(cf (&v)[2])
+    {
+        const cf a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+template<> struct MrDft<3> {
+    static WF_DEV void run(cf (&v)[3])
+    {
+        const float s = 0.86602540378443864676f; // sin(2 pi / 3)
+        const cf t1 = cadd(v[1], v[2]), t2 = csub(v[1], v[2]);
+        const cf m = cf{fmaf(-0.5f, t1.x, v[0].x), fmaf(-0.5f, t1.y, v[0].y)};
+        const cf r = cf{s * t2.y, -s * t2.x}; // -i s (v1 - v2)
+        v[0] = cadd(v[0], t1);
+        v[1] = cadd(m, r);
+        v[2] = csub(m, r);
+    }
+};
+template<> struct MrDft<4> {
+    static WF_DEV void run(cf (&v)[4])
+    {
+        const cf a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+        const cf jd = cf{d.y, -d.x}; // -i d
+        v[0] = cadd(a, c);
+        v[1] = cadd(b, jd);
+        v[2] = csub(a, c);
+        v[3] = csub(b, jd);
+    }
+};
+template<> struct MrDft<5> {
+    static WF_DEV void run(cf (&v)[5])
+    {
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f; // cos(2 pi / 5), cos(4 pi / 5)
+        const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;  // sin(2 pi / 5), sin(4 pi / 5)
+        const cf a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]), a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
+        const cf m1 = cf{fmaf(c2, a2.x, fmaf(c1, a1.x, v[0].x)), fmaf(c2, a2.y, fmaf(c1, a1.y, v[0].y))};
+        const cf m2 = cf{fmaf(c1, a2.x, fmaf(c2, a1.x, v[0].x)), fmaf(c1, a2.y, fmaf(c2, a1.y, v[0].y))};
+        const cf n1 = cf{fmaf(s2, b2.x, s1 * b1.x), fmaf(s2, b2.y, s1 * b1.y)};    // s1 b1 + s2 b2
+        const cf n2 = cf{fmaf(-s1, b2.x, s2 * b1.x), fmaf(-s1, b2.y, s2 * b1.y)};  // s2 b1 - s1 b2
+        const cf r1 = cf{n1.y, -n1.x}, r2 = cf{n2.y, -n2.x}; // -i n
+        v[0] = cadd(v[0], cadd(a1, a2));
+        v[1] = cadd(m1, r1);
+        v[4] = csub(m1, r1);
+        v[2] = cadd(m2, r2);
+        v[3] = csub(m2, r2);
+    }
+};
+// R = A B by one Cooley-Tukey step in registers: n = B n1 + n2, k = k1 + A k2
+template<int A, int B> struct MrDftCT {
+    static WF_DEV void run(cf (&v)[A * B])
+    {
+        cf y[A * B];
+        WF_UNROLL
+        for(int n2 = 0; n2 < B; ++n2) {
+            cf u[A];
+            WF_UNROLL
+            for(int n1 = 0; n1 < A; ++n1)
+                u[n1] = v[B * n1 + n2];
+            MrDft<A>::run(u);
+            WF_UNROLL
+            for(int k1 = 0; k1 < A; ++k1)
+                y[k1 * B + n2] = mr_mul_w<A * B>(u[k1], k1 * n2);
+        }
+        WF_UNROLL
+        for(int k1 = 0; k1 < A; ++k1) {
+            cf u[B];
+            WF_UNROLL
+            for(int n2 = 0; n2 < B; ++n2)
+                u[n2] = y[k1 * B + n2];
+            MrDft<B>::run(u);
+            WF_UNROLL
+            for(int k2 = 0; k2 < B; ++k2)
+                v[k1 + A * k2] = u[k2];
+        }
+    }
+};
+template<> struct MrDft<6> : MrDftCT<3, 2> {};
+template<> struct MrDft<8> : MrDftCT<4, 2> {};
+template<> struct MrDft<9> : MrDftCT<3, 3> {};
+template<> struct MrDft<10> : MrDftCT<5, 2> {};
+template<> struct MrDft<12> : MrDftCT<3, 4> {};
+template<> struct MrDft<15> : MrDftCT<3, 5> {};
+template<> struct MrDft<16> : MrDftCT<4, 4> {};
+template<> struct MrDft<20> : MrDftCT<5, 4> {};
+template<> struct MrDft<25> : MrDftCT<5, 5> {};
+
+// one butterfly: inputs from `src` (linear), twiddles (TW: every pass but the first), DFT; X[k] left in v.
+// The twiddled form holds 2 (R - 1) more registers while its table entries and its points are in flight: radices above 16
+// are planned into the first pass only (plan_mixed_radix).
+template<int R, bool TW> WF_DEV void mr_butterfly(const cf *src, const cf *tw, int j, int nb, int ns, cf (&v)[R])
+{
+    if constexpr(TW) {
+        const int jm = j % ns;
+        cf w[R];
+        WF_UNROLL
+        for(int k = 1; k < R; ++k) { // requested before the LDS reads so that the two latencies overlap
+            const f2 q = ld2(reinterpret_cast<const float *>(tw + k * ns + jm));
+            w[k] = cf{q.x, q.y};
+        }
+        WF_UNROLL
+        for(int k = 0; k < R; ++k)
+            v[k] = lds_ld2(src, j + k * nb);
+        WF_UNROLL
+        for(int k = 1; k < R; ++k)
+            v[k] = cmul(v[k], w[k]);
+    } else {
+        WF_UNROLL
+        for(int k = 0; k < R; ++k)
+            v[k] = lds_ld2(src, j + k * nb);
+    }
+    MrDft<R>::run(v);
+}
+template<int R, bool TW> WF_DEV void mr_pass_r(const cf *src, cf *dst, const cf *tw, int np, int ns, int t, int T)
+{
+    const int nb = np / R;
+    for(int j = t; j < nb; j += T) {
+        cf v[R];
+        mr_butterfly<R, TW>(src, tw, j, nb, ns, v);
+        const int base = TW ? (j / ns) * ns * R + (j % ns) : j * R;
+        WF_UNROLL
+        for(int k = 0; k < R; ++k)
+            lds_st2(dst, base + k * ns, v[k]);
+    }
+}
+// first pass (ns == 1: no twiddles): every planned radix
+WF_DEV void mr_pass_first(int R, const cf *src, cf *dst, int np, int t, int T)
+{
+    switch(R) {
+    case 2: mr_pass_r<2, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 3: mr_pass_r<3, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 4: mr_pass_r<4, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 5: mr_pass_r<5, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 6: mr_pass_r<6, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 8: mr_pass_r<8, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 9: mr_pass_r<9, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 10: mr_pass_r<10, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 12: mr_pass_r<12, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 15: mr_pass_r<15, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 16: mr_pass_r<16, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 20: mr_pass_r<20, false>(src, dst, nullptr, np, 1, t, T); break;
+    default: mr_pass_r<25, false>(src, dst, nullptr, np, 1, t, T); break;
+    }
+}
+// middle passes: radices up to 16
+WF_DEV void mr_pass(int R, const cf *src, cf *dst, const cf *tw, int np, int ns, int t, int T)
+{
+    switch(R) {
+    case 2: mr_pass_r<2, true>(src, dst, tw, np, ns, t, T); break;
+    case 3: mr_pass_r<3, true>(src, dst, tw, np, ns, t, T); break;
+    case 4: mr_pass_r<4, true>(src, dst, tw, np, ns, t, T); break;
+    case 5: mr_pass_r<5, true>(src, dst, tw, np, ns, t, T); break;
+    case 6: mr_pass_r<6, true>(src, dst, tw, np, ns, t, T); break;
+    case 8: mr_pass_r<8, true>(src, dst, tw, np, ns, t, T); break;
+    case 9: mr_pass_r<9, true>(src, dst, tw, np, ns, t, T); break;
+    case 10: mr_pass_r<10, true>(src, dst, tw, np, ns, t, T); break;
+    case 12: mr_pass_r<12, true>(src, dst, tw, np, ns, t, T); break;
+    case 15: mr_pass_r<15, true>(src, dst, tw, np, ns, t, T); break;
+    default: mr_pass_r<16, true>(src, dst, tw, np, ns, t, T); break;
+    }
+}
+// the last pass: ns R == np, at most one butterfly per thread (j = t < nb = ns); X[j + k ns] into the ex3 layout of
+// geometry G behind `sync` (every thread has read its inputs: the layout overlaps both halves of the buffer)
+template<class G, int R, class Sync> WF_DEV void mr_last_r(bool process, const cf *src, cf *lds, const cf *tw, int ns, int t, Sync sync)
+{
+    cf v[R];
+    const bool mine = process && t < ns;
+    if(mine)
+        mr_butterfly<R, true>(src, tw, t, ns, ns, v);
+    sync();
+    if(mine) {
+        WF_UNROLL
+        for(int k = 0; k < R; ++k)
+            lds_st2(lds, ex3_addr<G>(t + k * ns), v[k]);
+    }
+}
+template<class G, class Sync> WF_DEV void mr_last(int R, bool process, const cf *src, cf *lds, const cf *tw, int ns, int t, Sync sync)
+{
+    switch(R) {
+    case 2: mr_last_r<G, 2>(process, src, lds, tw, ns, t, sync); break;
+    case 3: mr_last_r<G, 3>(process, src, lds, tw, ns, t, sync); break;
+    case 4: mr_last_r<G, 4>(process, src, lds, tw, ns, t, sync); break;
+    case 5: mr_last_r<G, 5>(process, src, lds, tw, ns, t, sync); break;
+    case 6: mr_last_r<G, 6>(process, src, lds, tw, ns, t, sync); break;
+    case 8: mr_last_r<G, 8>(process, src, lds, tw, ns, t, sync); break;
+    case 9: mr_last_r<G, 9>(process, src, lds, tw, ns, t, sync); break;
+    case 10: mr_last_r<G, 10>(process, src, lds, tw, ns, t, sync); break;
+    case 12: mr_last_r<G, 12>(process, src, lds, tw, ns, t, sync); break;
+    case 15: mr_last_r<G, 15>(process, src, lds, tw, ns, t, sync); break;
+    default: mr_last_r<G, 16>(process, src, lds, tw, ns, t, sync); break;
+    }
+}
+
+// The window of this spectrum as np complex points z_j = (win_2j x_2j, win_2j+1 x_2j+1), natural order, into lds[0 .. np).
+// Returns whether any of this thread's samples is non-zero (the reference's silence scan, :63-72).
+template<class G> WF_DEV bool mr_fetch(const TickArgs &a, int t, const float *x, uint32_t start, cf *lds)
+{
+    constexpr int T = G::T, P = G::P;
+    const uint32_t np = a.blu_n >> 1; // <= M / 2 = T P / 2
+    uint32_t acc = 0;
+    f2 v[P / 2], w[P / 2];
+    WF_UNROLL
+    for(int i = 0; i < P / 2; ++i) {
+        const uint32_t idx = (uint32_t)(t + T * i);
+        const bool in = idx < np;
+        const uint32_t s = start + 2u * (in ? idx : 0u);
+        v[i] = f2{x[s & a.ring_mask], x[(s + 1u) & a.ring_mask]};
+        w[i] = ld2(a.window + 2u * (in ? idx : 0u));
+    }
+    WF_UNROLL
+    for(int i = 0; i < P / 2; ++i) {
+        const uint32_t idx = (uint32_t)(t + T * i);
+        if(idx < np) {
+            acc |= f32_bits(v[i].x) | f32_bits(v[i].y);
+            lds_st2(lds, (int)idx, cf{v[i].x * w[i].x, v[i].y * w[i].y});
+        }
+    }
+    return (acc & 0x7fffffffu) != 0;
+}
+
+// The whole transform.  On entry the np windowed points sit in lds[0 .. np) (natural order); on return Z[k] sits at
+// ex3_addr<G>(k), visible to every thread of the spectrum.  Called by ALL threads of the spectrum (sync is its barrier).
+template<class G, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool process, int np, int t, cf *lds, Sync sync)
+{
+    constexpr int H = G::M / 2; // second half of the exchange buffer (M >= 2 np)
+    sync(); // the fetch has written the first half
+    if(process)
+        mr_pass_first(p.radix[0], lds, lds + H, np, t, G::T);
+    int ns = p.radix[0], cur = 1;
+    for(int s = 1; s + 1 < p.passes; ++s) {
+        const int R = p.radix[s];
+        sync();
+        if(process)
+            mr_pass(R, lds + cur * H, lds + (1 - cur) * H, p.tw + p.tw_off[s], np, ns, t, G::T);
+        cur ^= 1;
+        ns *= R;
+    }
+    sync();
+    mr_last<G>(p.radix[p.passes - 1], process, lds + cur * H, lds, p.tw + p.tw_off[p.passes - 1], ns, t, sync);
+    sync();
+}
+
+} // namespace wf

@@ -127,6 +127,15 @@ struct BarsOnlyState {
     uint32_t use_verdict;
 };
 
+// FFT sizes with no prime factor above 5 (wf_mixed.hpp): the passes of the direct n/2-point transform
+constexpr int MR_MAX_PASSES = 4;
+struct MrPlan {
+    int passes;                 // 0: no plan (Bluestein runs)
+    int radix[MR_MAX_PASSES];
+    int tw_off[MR_MAX_PASSES];  // pass s >= 1: its twiddles start at tw + tw_off[s]
+    const cf *tw;               // per pass [R][Ns]: W_(Ns R)^(k jm), Ns = product of the radices before it (coalesced across a wavefront's butterflies)
+};
+
 struct TickArgs {
     // audio rings: one per (stream, captured channel), ring_cap samples each (power of two)
     const float *ring;
@@ -182,6 +191,7 @@ struct TickArgs {
     const cf *blu_q;           // [blu_n / 2] conj(w_k) / L: Z_k = blu_q[k] * conj(R_k) for the twice-transformed R
     const cf *blu_qr;          // [blu_n / 2] blu_q[(blu_n / 2 - k) mod (blu_n / 2)]
     const cf *blu_w;           // [blu_n / 2] W_blu_n^k, the real-split twiddles
+    MrPlan mr;                 // blu_n = 2^a 3^b 5^c: the transform is computed directly (blu_a, blu_b, blu_q, blu_qr unused)
     const cf *blu_a;           // [2 M] the factors of x_2j and x_2j+1 in point j of the chirped, windowed, packed input; zero from point blu_n / 2 on
     const cf *blu_b;           // [M] FFT_M of the chirp
     uint32_t blu_n;
@@ -746,7 +756,8 @@ template<class G> WF_DEV void blu_mid(const TickArgs &a, int t, const cf *lds, P
 
 // Bluestein epilogue (packed form): the real split of the n/2-point transform the convolution delivers; slope, smoothing and
 // the state store as in p4_slope_smooth_group, on the groups of four bins that lie inside the row
-template<class G, bool TS, bool FPK>
+// MR (wf_mixed.hpp): the buffer holds Z itself -- no chirp factors, no conjugation
+template<class G, bool TS, bool FPK, bool MR = false>
 WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
 {
     // Z_k = blu_q[k] * conj(R_k), R = the twice-transformed buffer in natural order; X_k from Z_k and Z_(n'-k) by the real
@@ -761,8 +772,13 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
             f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
             if(TS)
                 st = ld_state(ts + k0);
-            const f4 qa = ld4(reinterpret_cast<const float *>(a.blu_q + k0)), qb = ld4(reinterpret_cast<const float *>(a.blu_q + k0 + 2));
-            const f4 ra = ld4(reinterpret_cast<const float *>(a.blu_qr + k0)), rb = ld4(reinterpret_cast<const float *>(a.blu_qr + k0 + 2));
+            f4 qa = f4{1.0f, 0.0f, 1.0f, 0.0f}, qb = qa, ra = qa, rb = qa;
+            if constexpr(!MR) {
+                qa = ld4(reinterpret_cast<const float *>(a.blu_q + k0));
+                qb = ld4(reinterpret_cast<const float *>(a.blu_q + k0 + 2));
+                ra = ld4(reinterpret_cast<const float *>(a.blu_qr + k0));
+                rb = ld4(reinterpret_cast<const float *>(a.blu_qr + k0 + 2));
+            }
             const f4 wa = ld4(reinterpret_cast<const float *>(a.blu_w + k0)), wb = ld4(reinterpret_cast<const float *>(a.blu_w + k0 + 2));
             const cf Q[4] = {cf{qa.x, qa.y}, cf{qa.z, qa.w}, cf{qb.x, qb.y}, cf{qb.z, qb.w}};
             const cf QR[4] = {cf{ra.x, ra.y}, cf{ra.z, ra.w}, cf{rb.x, rb.y}, cf{rb.z, rb.w}};
@@ -772,7 +788,7 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
             for(int i = 0; i < 4; ++i) {
                 const int k = k0 + i, km = (k == 0) ? 0 : np - k;
                 const cf rk = lds_ld2(lds, ex3_addr<G>(k)), rm = lds_ld2(lds, ex3_addr<G>(km));
-                const cf A = cmul(cf{rk.x, -rk.y}, Q[i]), B = cmul(cf{rm.x, -rm.y}, QR[i]);
+                const cf A = MR ? rk : cmul(cf{rk.x, -rk.y}, Q[i]), B = MR ? rm : cmul(cf{rm.x, -rm.y}, QR[i]);
                 const float er = A.x + B.x, ei = A.y - B.y;
                 const float dr = A.x - B.x, di = A.y + B.y;
                 const float pr = fmaf(W[i].x, dr, -(W[i].y * di)); // Re(W D)
@@ -791,15 +807,15 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
         }
     }
 }
-template<class G> WF_DEV void p4_direct(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
+template<class G, bool MR = false> WF_DEV void p4_direct(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
 {
     if(a.mode & WF_MODE_TSMOOTH) {
         if(a.mode & WF_MODE_FAST_PEAKS)
-            p4_split_blu_impl<G, true, true>(a, t, lds, ts, mag);
+            p4_split_blu_impl<G, true, true, MR>(a, t, lds, ts, mag);
         else
-            p4_split_blu_impl<G, true, false>(a, t, lds, ts, mag);
+            p4_split_blu_impl<G, true, false, MR>(a, t, lds, ts, mag);
     } else
-        p4_split_blu_impl<G, false, false>(a, t, lds, ts, mag);
+        p4_split_blu_impl<G, false, false, MR>(a, t, lds, ts, mag);
 }
 
 // ---- P2: pass 2 ---------------------------------------------------------------------------------
