@@ -201,7 +201,7 @@ def shape_list(wf):
         # the ends of the reference's FFT range (not BASELINE configs; reported so that the driver's line carries them too)
         ("fft_size 65536 (the reference's maximum, 'enable large FFT'): 256 stereo streams, EMA + slope; rows kernel with the column step and the "
          "real split folded in + epilogue", wf.Config.defaults(fft_size=65536, **ema), 256, 30, 0, "n65536"),
-        ("fft_size 800 (the plugin's automatic size at 48 kHz / 60 fps; packed Bluestein over 1024 complex points): 8192 stereo streams, EMA + slope",
+        ("fft_size 800 (the plugin's automatic size at 48 kHz / 60 fps; 400 complex points as mixed radix 25 x 16): 8192 stereo streams, EMA + slope",
          wf.Config.defaults(fft_size=800, **ema), 8192, 60, 0, "blu800"),
     ]
     return shapes
