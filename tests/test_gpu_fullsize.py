@@ -252,12 +252,14 @@ def test_bars_only_mode_matches_full_mode():
 @pytest.mark.parametrize("layout", [
     dict(fft_size=1024, stereo=1), dict(fft_size=4096, stereo=1), dict(fft_size=2048, stereo=1, capture_channels=1),
     dict(fft_size=4096, stereo=0, capture_channels=1), dict(fft_size=2048, stereo=0), dict(fft_size=512, stereo=1),
-    dict(fft_size=8192, stereo=1), dict(fft_size=800, stereo=1), dict(fft_size=8192, stereo=0, capture_channels=1)])
+    dict(fft_size=8192, stereo=1), dict(fft_size=800, stereo=1), dict(fft_size=8192, stereo=0, capture_channels=1),
+    dict(fft_size=8000, stereo=1), dict(fft_size=1600, stereo=0), dict(fft_size=4160, stereo=1), dict(fft_size=1120, stereo=1)])
 def test_bars_only_mode_keeps_the_silence_state_machine(layout):
     """WF_HIP_TICK_NO_DECIBELS through noise -> digital silence (the display decays below floor - 10, m_last_silent latches,
     reference src/source_generic.cpp:74-95) -> one live channel (the skipped one is re-dBFS'ed) -> hide/show -> noise:
     bars and m_last_silent of a bars-only batch equal the full mode's on every tick, on the geometries that keep a stereo
-    pair in one workgroup, on the split ones, zero-padded, Bluestein and mono mixdown (which stores its row regardless)."""
+    pair in one workgroup, on the split ones, zero-padded, mixed radix (800, 1600, 8000), Bluestein (4160, 1120) and mono mixdown
+    (which stores its row regardless)."""
     cfg = wf.Config.defaults(slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"], gravity=0.2, **layout)
     n, streams, hop = cfg.fft_size, 5, 800
     cc = int(cfg.capture_channels)
