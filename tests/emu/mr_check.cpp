@@ -2,7 +2,7 @@
 // tests/test_cpu_units.py::test_mixed_radix_plans_and_transforms.  Test infrastructure, not part of the product.
 //  * every in-register DFT against the definition in double;
 //  * for EVERY multiple of 16 in [128, 16384]: the plan exists exactly for the sizes with no prime factor above 5 that are not
-//    powers of two, multiplies to n / 2, uses the radices the kernel instantiates, keeps radices above 16 in the first pass and
+//    powers of two (prime factors up to 13), multiplies to n / 2, uses the radices the kernel instantiates, keeps radices above 16 in the first pass and
 //    leaves the last pass one butterfly per thread of the container geometry;
 //  * for a spread of sizes: the passes themselves (mr_pass_first / mr_pass / the last pass's butterflies), lane by lane,
 //    against a double DFT.
@@ -47,11 +47,11 @@ static unsigned container_threads(unsigned n) // threads of the geometry the Blu
 int main()
 {
     check_dft<2>(); check_dft<3>(); check_dft<4>(); check_dft<5>(); check_dft<6>(); check_dft<8>(); check_dft<9>(); check_dft<10>();
-    check_dft<12>(); check_dft<15>(); check_dft<16>(); check_dft<20>(); check_dft<25>();
+    check_dft<12>(); check_dft<15>(); check_dft<16>(); check_dft<20>(); check_dft<25>(); check_dft<7>(); check_dft<11>(); check_dft<13>();
     int planned = 0;
     for(unsigned n = 128; n <= 16384; n += 16) {
         unsigned r = n;
-        for(unsigned p : {2u, 3u, 5u})
+        for(unsigned p : {2u, 3u, 5u, 7u, 11u, 13u})
             while(r % p == 0)
                 r /= p;
         const bool smooth = r == 1, pow2 = (n & (n - 1)) == 0;
@@ -68,14 +68,14 @@ int main()
         for(int i = 0; i < passes; ++i) {
             const int v = radix[i];
             prod *= (unsigned long long)v;
-            const bool known = v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 20 || v == 25;
+            const bool known = v == 7 || v == 11 || v == 13 || v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 20 || v == 25;
             CHECK(known && (v <= 16 || i == 0), "n = %u: radix %d in pass %d", n, v, i);
         }
         CHECK(passes >= 2 && passes <= 4 && prod == np, "n = %u: %d passes, product %llu", n, passes, prod);
         CHECK(np / (unsigned)radix[passes - 1] <= T, "n = %u: last pass has %u butterflies for %u threads", n, np / radix[passes - 1], T);
     }
     std::printf("planned %d sizes\n", planned);
-    for(unsigned n : {800u, 1600u, 960u, 1920u, 2000u, 320u, 144u, 8000u, 1536u, 15552u, 12288u, 6000u}) {
+    for(unsigned n : {800u, 1600u, 960u, 1920u, 2000u, 320u, 144u, 8000u, 1536u, 15552u, 12288u, 6000u, 4160u, 1760u, 1456u, 880u, 352u, 16016u, 224u}) {
         int radix[4], off[4];
         const unsigned np = n / 2, T = container_threads(n);
         const int passes = plan_mixed_radix(np, T, radix);

@@ -22,7 +22,7 @@ REF_EVERY = 1              # every spectrum seed is also played against libwfref
 MAX_POW2 = 32768
 MAX_ANY = 10912
 RESTATEMENT_MAX_PRIME = 61  # lengths whose largest prime factor exceeds this are checked against libwfref.so only
-SMOOTH_SEEDS = range(200)  # fft sizes 2^a 3^b 5^c that are not powers of two: the mixed-radix path (wf_mixed.hpp)
+SMOOTH_SEEDS = range(200)  # fft sizes with no prime factor above 13 that are not powers of two: the mixed-radix path (wf_mixed.hpp)
 HUGE_SEEDS = range(60)     # the sizes beyond a CU's LDS (wf_big.hpp): 65536 and every other multiple of 16 above 10912
 
 
@@ -35,8 +35,8 @@ def _largest_prime_factor(n: int) -> int:
     return max(best, n) if n > 1 else best
 
 
-def _five_smooth(n):
-    for p in (2, 3, 5):
+def _five_smooth(n):  # (no prime factor above 13: what plan_mixed_radix takes)
+    for p in (2, 3, 5, 7, 11, 13):
         while n % p == 0:
             n //= p
     return n == 1
@@ -60,10 +60,10 @@ def draw(seed: int, family: str = "pow2"):
                 if n & (n - 1):
                     break
     elif family == "smooth":
-        # the sizes the mixed-radix path takes (wf_mixed.hpp): multiples of 16 up to 16384 with no prime factor above 5 that are
-        # not powers of two -- the automatic sizes at 48 kHz (800, 1600, 960, 1920, 2000) a fifth of the time
+        # the sizes the mixed-radix path takes (wf_mixed.hpp): multiples of 16 up to 16384 with no prime factor above 13 that
+        # are not powers of two -- the automatic sizes (800, 1600, 960, 1920, 2000 at 48 kHz; 1760, 1456, 880 at 44.1 kHz) a fifth of the time
         if r.random() < 0.2:
-            n = int(r.choice([800, 1600, 960, 1920, 2000, 400, 320]))
+            n = int(r.choice([800, 1600, 960, 1920, 2000, 400, 320, 1760, 1456, 880]))
         else:
             n = int(r.choice(SMOOTH_SIZES))
     elif family == "pow2":
@@ -386,7 +386,7 @@ def test_hip_matches_oracle_on_random_smooth_size(seed):
 @pytest.mark.gpu
 def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
     import waveform_amd as wf
-    for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, False), (4160, False), (176, False), (144, True), (15552, True)):
+    for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, False), (4160, True), (1760, True), (1456, True), (272, False), (4144, False), (144, True), (15552, True)):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
             name = b.kernel_name()
             assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)

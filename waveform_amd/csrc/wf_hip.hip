@@ -329,7 +329,7 @@ template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_
                 bool ok = n >= 2 && prod == h->N / 2 && r[n - 1] <= 16 && (h->N / 2) / (uint32_t)r[n - 1] <= (uint32_t)G::T;
                 for(int i = 0; i < n; ++i) {
                     const int v = r[i];
-                    ok = ok && (v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 ||
+                    ok = ok && (v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 7 || v == 11 || v == 13 ||
                                 (i == 0 && (v == 20 || v == 25)));
                 }
                 if(ok) {

@@ -1,12 +1,13 @@
-// wf_mixed.hpp -- FFT sizes whose only prime factors are 2, 3 and 5, computed directly (device code; also compiled by g++ for
+// wf_mixed.hpp -- FFT sizes with no prime factor above 13, computed directly (device code; also compiled by g++ for
 // tests/emu, which replays these functions lane by lane).
 //
 // The reference takes every multiple of 16 as fft_size (src/source.cpp:562-565) and FFTW gives it an O(n log n) plan for each.
 // Here the sizes that are not powers of two ran Bluestein's algorithm (two power-of-two transforms of L >= n - 1 points for the
 // n/2-point transform that is wanted: four to eight times the work of a neighbouring power of two).  Most sizes a user meets
 // are "smooth", though: the automatic size is sample_rate / fps & -16 (src/source.cpp:1161-1167) -- 800, 1600, 960, 1920, 2000
-// at 48 kHz -- and the slider moves in steps of 64.  For n/2 = 2^a 3^b 5^c the packed n/2-point transform is a Stockham
-// autosort FFT of two to four passes whose radices come from {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25}:
+// at 48 kHz, 1760, 1456, 880, 720, 352 at 44.1 kHz -- and the slider moves in steps of 64.  For n/2 = 2^a 3^b 5^c 7^d 11^e 13^f the
+// packed n/2-point transform is a Stockham autosort FFT of two to four passes whose radices come from
+// {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 20, 25}:
 //   * it lives where Bluestein's first transform lived: the fetch (windowed sample pairs, p1_fetch_blu) and the epilogue (real split
 //     with W_n^k, slope, smoothing: p4_direct) are the Bluestein path's own, with tables that carry the plain window and ones;
 //   * the exchange buffer of the power-of-two container (M >= n - 1 complex points) is two halves of >= n/2 points: a pass reads one
@@ -158,6 +159,43 @@ template<> struct MrDft<5> {
         v[3] = csub(m2, r2);
     }
 };
+// an odd prime radix by the definition, halved by symmetry: with a_j = x_j + x_(P-j), b_j = x_j - x_(P-j), j = 1 .. (P-1)/2,
+//   X[k], X[P-k] = (x_0 + sum_j a_j cos(2 pi j k / P)) -+ i (sum_j b_j sin(2 pi j k / P));  (P-1)^2 real multiply-adds in all
+template<int P> struct MrDftPrime {
+    static WF_DEV void run(cf (&v)[P])
+    {
+        constexpr int H = (P - 1) / 2;
+        constexpr MrTwiddles<P> tab{};
+        cf a[H], b[H];
+        WF_UNROLL
+        for(int j = 0; j < H; ++j) {
+            a[j] = cadd(v[j + 1], v[P - 1 - j]);
+            b[j] = csub(v[j + 1], v[P - 1 - j]);
+        }
+        const cf x0 = v[0];
+        cf s0 = x0;
+        WF_UNROLL
+        for(int j = 0; j < H; ++j)
+            s0 = cadd(s0, a[j]);
+        v[0] = s0;
+        WF_UNROLL
+        for(int k = 1; k <= H; ++k) {
+            cf c = x0, d = cf{0.0f, 0.0f};
+            WF_UNROLL
+            for(int j = 0; j < H; ++j) {
+                const int m = ((j + 1) * k) % P;
+                c = cf{fmaf(tab.c[m], a[j].x, c.x), fmaf(tab.c[m], a[j].y, c.y)};
+                d = cf{fmaf(tab.s[m], b[j].x, d.x), fmaf(tab.s[m], b[j].y, d.y)};
+            }
+            // -i d = (d.y, -d.x)
+            v[k] = cf{c.x + d.y, c.y - d.x};
+            v[P - k] = cf{c.x - d.y, c.y + d.x};
+        }
+    }
+};
+template<> struct MrDft<7> : MrDftPrime<7> {};
+template<> struct MrDft<11> : MrDftPrime<11> {};
+template<> struct MrDft<13> : MrDftPrime<13> {};
 // R = A B by one Cooley-Tukey step in registers: n = B n1 + n2, k = k1 + A k2
 template<int A, int B> struct MrDftCT {
     static WF_DEV void run(cf (&v)[A * B])
@@ -244,10 +282,13 @@ WF_DEV void mr_pass_first(int R, const cf *src, cf *dst, int np, int t, int T)
     case 4: mr_pass_r<4, false>(src, dst, nullptr, np, 1, t, T); break;
     case 5: mr_pass_r<5, false>(src, dst, nullptr, np, 1, t, T); break;
     case 6: mr_pass_r<6, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 7: mr_pass_r<7, false>(src, dst, nullptr, np, 1, t, T); break;
     case 8: mr_pass_r<8, false>(src, dst, nullptr, np, 1, t, T); break;
     case 9: mr_pass_r<9, false>(src, dst, nullptr, np, 1, t, T); break;
     case 10: mr_pass_r<10, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 11: mr_pass_r<11, false>(src, dst, nullptr, np, 1, t, T); break;
     case 12: mr_pass_r<12, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 13: mr_pass_r<13, false>(src, dst, nullptr, np, 1, t, T); break;
     case 15: mr_pass_r<15, false>(src, dst, nullptr, np, 1, t, T); break;
     case 16: mr_pass_r<16, false>(src, dst, nullptr, np, 1, t, T); break;
     case 20: mr_pass_r<20, false>(src, dst, nullptr, np, 1, t, T); break;
@@ -263,10 +304,13 @@ WF_DEV void mr_pass(int R, const cf *src, cf *dst, const cf *tw, int np, int ns,
     case 4: mr_pass_r<4, true>(src, dst, tw, np, ns, t, T); break;
     case 5: mr_pass_r<5, true>(src, dst, tw, np, ns, t, T); break;
     case 6: mr_pass_r<6, true>(src, dst, tw, np, ns, t, T); break;
+    case 7: mr_pass_r<7, true>(src, dst, tw, np, ns, t, T); break;
     case 8: mr_pass_r<8, true>(src, dst, tw, np, ns, t, T); break;
     case 9: mr_pass_r<9, true>(src, dst, tw, np, ns, t, T); break;
     case 10: mr_pass_r<10, true>(src, dst, tw, np, ns, t, T); break;
+    case 11: mr_pass_r<11, true>(src, dst, tw, np, ns, t, T); break;
     case 12: mr_pass_r<12, true>(src, dst, tw, np, ns, t, T); break;
+    case 13: mr_pass_r<13, true>(src, dst, tw, np, ns, t, T); break;
     case 15: mr_pass_r<15, true>(src, dst, tw, np, ns, t, T); break;
     default: mr_pass_r<16, true>(src, dst, tw, np, ns, t, T); break;
     }
@@ -294,10 +338,13 @@ template<class G, class Sync> WF_DEV void mr_last(int R, bool process, const cf 
     case 4: mr_last_r<G, 4>(process, src, lds, tw, ns, t, sync); break;
     case 5: mr_last_r<G, 5>(process, src, lds, tw, ns, t, sync); break;
     case 6: mr_last_r<G, 6>(process, src, lds, tw, ns, t, sync); break;
+    case 7: mr_last_r<G, 7>(process, src, lds, tw, ns, t, sync); break;
     case 8: mr_last_r<G, 8>(process, src, lds, tw, ns, t, sync); break;
     case 9: mr_last_r<G, 9>(process, src, lds, tw, ns, t, sync); break;
     case 10: mr_last_r<G, 10>(process, src, lds, tw, ns, t, sync); break;
+    case 11: mr_last_r<G, 11>(process, src, lds, tw, ns, t, sync); break;
     case 12: mr_last_r<G, 12>(process, src, lds, tw, ns, t, sync); break;
+    case 13: mr_last_r<G, 13>(process, src, lds, tw, ns, t, sync); break;
     case 15: mr_last_r<G, 15>(process, src, lds, tw, ns, t, sync); break;
     default: mr_last_r<G, 16>(process, src, lds, tw, ns, t, sync); break;
     }
