@@ -35,7 +35,11 @@ def _largest_prime_factor(n: int) -> int:
     return max(best, n) if n > 1 else best
 
 
-def _five_smooth(n):  # (no prime factor above 13: what plan_mixed_radix takes)
+def _five_smooth(n):  # (what plan_mixed_radix takes: no prime factor above 13, one factor 17 / 19 / 23 on top at most)
+    for p in (17, 19, 23):
+        if n % p == 0:
+            n //= p
+            break
     for p in (2, 3, 5, 7, 11, 13):
         while n % p == 0:
             n //= p
@@ -386,7 +390,7 @@ def test_hip_matches_oracle_on_random_smooth_size(seed):
 @pytest.mark.gpu
 def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
     import waveform_amd as wf
-    for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, False), (4160, True), (1760, True), (1456, True), (272, False), (4144, False), (144, True), (15552, True)):
+    for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, True), (16336, False), (4160, True), (1760, True), (1456, True), (1824, True), (1088, True), (1472, True), (464, False), (4144, False), (144, True), (15552, True)):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
             name = b.kernel_name()
             assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)

@@ -330,7 +330,7 @@ template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_
                 for(int i = 0; i < n; ++i) {
                     const int v = r[i];
                     ok = ok && (v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 7 || v == 11 || v == 13 ||
-                                (i == 0 && (v == 20 || v == 25)));
+                                (i == 0 && (v == 20 || v == 25 || v == 17 || v == 19 || v == 23)));
                 }
                 if(ok) {
                     h->mr_passes = n;

@@ -776,10 +776,10 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
 
 int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4])
 {
-    static const int kRadices[] = {25, 20, 16, 15, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    static const int kRadices[] = {25, 23, 20, 19, 17, 16, 15, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
     {
         uint32_t r = np;
-        for(uint32_t p : {2u, 3u, 5u, 7u, 11u, 13u})
+        for(uint32_t p : {2u, 3u, 5u, 7u, 11u, 13u, 17u, 19u, 23u})
             while(r % p == 0)
                 r /= p;
         if(np < 4 || r != 1) {

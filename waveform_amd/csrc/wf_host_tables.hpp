@@ -114,7 +114,7 @@ uint32_t bluestein_length(uint32_t n);
 void build_big_twiddles(uint32_t L, uint32_t rows, uint32_t real_n, std::vector<cfloat> &tw_big, std::vector<cfloat> &tws_big);
 void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out);
 
-// FFT sizes with no prime factor above 13 (wf_mixed.hpp): the n/2-point transform as two to four mixed-radix passes instead of
+// FFT sizes with no prime factor above 23 and at most one of 17, 19, 23, 20, 25 (wf_mixed.hpp): the n/2-point transform as two to four mixed-radix passes instead of
 // Bluestein.  plan_mixed_radix fills radix[] in pass order and returns the number of passes, 0 when np has another prime
 // factor or no ordering fits: radices above 16 only in the first pass (the twiddled passes hold 2 (R - 1) more registers), and
 // the last pass has one butterfly per thread at most (np / radix[last] <= threads).

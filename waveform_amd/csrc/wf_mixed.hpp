@@ -1,13 +1,13 @@
-// wf_mixed.hpp -- FFT sizes with no prime factor above 13, computed directly (device code; also compiled by g++ for
+// wf_mixed.hpp -- FFT sizes with no prime factor above 23 (one factor 17, 19 or 23 at most), computed directly (device code; also compiled by g++ for
 // tests/emu, which replays these functions lane by lane).
 //
 // The reference takes every multiple of 16 as fft_size (src/source.cpp:562-565) and FFTW gives it an O(n log n) plan for each.
 // Here the sizes that are not powers of two ran Bluestein's algorithm (two power-of-two transforms of L >= n - 1 points for the
 // n/2-point transform that is wanted: four to eight times the work of a neighbouring power of two).  Most sizes a user meets
 // are "smooth", though: the automatic size is sample_rate / fps & -16 (src/source.cpp:1161-1167) -- 800, 1600, 960, 1920, 2000
-// at 48 kHz, 1760, 1456, 880, 720, 352 at 44.1 kHz -- and the slider moves in steps of 64.  For n/2 = 2^a 3^b 5^c 7^d 11^e 13^f the
-// packed n/2-point transform is a Stockham autosort FFT of two to four passes whose radices come from
-// {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 20, 25}:
+// at 48 kHz, 1760, 1456, 880, 720, 352 at 44.1 kHz -- and the slider moves in steps of 64.  For n/2 = 2^a 3^b 5^c 7^d 11^e 13^f (times one of 17, 19, 23)
+// the packed n/2-point transform is a Stockham autosort FFT of two to four passes whose radices come from
+// {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16} and, in the first pass only, {17, 19, 20, 23, 25}:
 //   * it lives where Bluestein's first transform lived: the fetch (windowed sample pairs, p1_fetch_blu) and the epilogue (real split
 //     with W_n^k, slope, smoothing: p4_direct) are the Bluestein path's own, with tables that carry the plain window and ones;
 //   * the exchange buffer of the power-of-two container (M >= n - 1 complex points) is two halves of >= n/2 points: a pass reads one
@@ -196,6 +196,9 @@ template<int P> struct MrDftPrime {
 template<> struct MrDft<7> : MrDftPrime<7> {};
 template<> struct MrDft<11> : MrDftPrime<11> {};
 template<> struct MrDft<13> : MrDftPrime<13> {};
+template<> struct MrDft<17> : MrDftPrime<17> {}; // (17, 19, 23: first pass only, like 20 and 25)
+template<> struct MrDft<19> : MrDftPrime<19> {};
+template<> struct MrDft<23> : MrDftPrime<23> {};
 // R = A B by one Cooley-Tukey step in registers: n = B n1 + n2, k = k1 + A k2
 template<int A, int B> struct MrDftCT {
     static WF_DEV void run(cf (&v)[A * B])
@@ -291,6 +294,9 @@ WF_DEV void mr_pass_first(int R, const cf *src, cf *dst, int np, int t, int T)
     case 13: mr_pass_r<13, false>(src, dst, nullptr, np, 1, t, T); break;
     case 15: mr_pass_r<15, false>(src, dst, nullptr, np, 1, t, T); break;
     case 16: mr_pass_r<16, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 17: mr_pass_r<17, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 19: mr_pass_r<19, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 23: mr_pass_r<23, false>(src, dst, nullptr, np, 1, t, T); break;
     case 20: mr_pass_r<20, false>(src, dst, nullptr, np, 1, t, T); break;
     default: mr_pass_r<25, false>(src, dst, nullptr, np, 1, t, T); break;
     }
