@@ -47,6 +47,7 @@ def _five_smooth(n):  # (what plan_mixed_radix takes: no prime factor above 13, 
 
 
 SMOOTH_SIZES = [n for n in range(128, 16384 + 1, 16) if _five_smooth(n) and n & (n - 1)]
+HUGE_SMOOTH_SIZES = [n for n in range(16384 + 16, 65536, 16) if _five_smooth(n) and n & (n - 1)]
 
 
 def draw(seed: int, family: str = "pow2"):
@@ -56,8 +57,11 @@ def draw(seed: int, family: str = "pow2"):
         # is where the device's Bluestein path matters.  The restatement's DFT of a length with a large prime factor p costs
         # O(n p) in double per channel and tick, so run_spectrum_case checks such lengths against libwfref.so (the reference's
         # own FFTW, fast at every length) alone and plays the restatement only where p <= RESTATEMENT_MAX_PRIME
-        if r.random() < 0.25:
+        u = r.random()
+        if u < 0.25:
             n = 65536
+        elif u < 0.5:  # the sizes above 16384 with small prime factors: rows of a mixed-radix transform (big_mr_rows_kernel)
+            n = int(r.choice(HUGE_SMOOTH_SIZES))
         else:
             while True:
                 n = 16 * int(r.integers(10912 // 16 + 1, 65536 // 16))
@@ -394,6 +398,10 @@ def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
             name = b.kernel_name()
             assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)
+    for n, big_mr in ((48000, True), (32000, True), (65520, True), (20480, True), (16400, False), (48016, False)):
+        with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 1) as b:
+            name = b.kernel_name()
+            assert ("big_mr_rows_kernel" in name) == big_mr and ("Bluestein" in name) != big_mr, (n, name)
 
 
 @pytest.mark.gpu

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include "wf_geometry.hpp"
 #include "wf_tick_phases.hpp"
+#include "wf_mixed.hpp"
 
 namespace wf {
 
@@ -212,7 +213,7 @@ WF_DEV void p4_big_impl(const TickArgs &a, int t, int kbase, int nb, const cf *z
             const cf W[4] = {cf{wa.x, wa.y}, cf{wa.z, wa.w}, cf{wb.x, wb.y}, cf{wb.z, wb.w}};
 #pragma unroll
             for(int i = 0; i < 4; ++i) {
-                const f2 bq = ld2(reinterpret_cast<const float *>(z + ((m - kk - i) & (m - 1)))); // Z[m] is Z[0]
+                const f2 bq = ld2(reinterpret_cast<const float *>(z + ((kk + i) == 0 ? 0 : m - kk - i))); // Z[m] is Z[0]; m need not be a power of two
                 const float er = A[i].x + bq.x, ei = A[i].y - bq.y;
                 const float dr = A[i].x - bq.x, di = A[i].y + bq.y;
                 const float pr = fmaf(W[i].x, dr, -(W[i].y * di));
@@ -556,6 +557,59 @@ template<bool ALIGNED> __global__ __launch_bounds__(GFold::T, GFold::T / 256) vo
 #pragma unroll
     for(int u = 0; u < P / 2; ++u) // out[2 u + h] is k2 = 2 (t + T u) + h
         *reinterpret_cast<f2 *>(mb + 2 * (t + T * u)) = f2{out[2 * u], out[2 * u + 1]};
+}
+
+// ---- fft sizes above 16384 with small prime factors: big_c rows of a mixed-radix transform ------------------------------------
+// n/2 = C R complex points, R <= 8192 with a mixed-radix plan (wf_mixed.hpp), C <= 8.  Decimation in frequency over the C
+// columns: row k1 transforms a[n2] = (sum_c z[n2 + R c] W_C^(c k1)) W_(n/2)^(n2 k1), n2 < R, and delivers the bins
+// Z[k1 + C k2].  As in big_rows_fold_kernel the column step is folded into the fetch -- every row reads the whole window, the
+// rows of a spectrum sit eight workgroup indices apart (same XCD, one trip to device memory) --, the R points go through the
+// passes between the two halves of the exchange buffer, and the last pass stores Z in natural order; big_epilogue_kernel<1>
+// does the real split (it pairs k with n/2 - k: another row) and everything behind it.  Replaces Bluestein through device
+// memory (four kernels, L >= 3 n / 2 points three times through memory) for these sizes: 48000 = 3 x 8000, 32000 = 2 x 8000, ...
+__global__ __launch_bounds__(GBig::T, 4) void big_mr_rows_kernel(const TickArgs a)
+{
+    using G = GBig;
+    constexpr int T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    cf *lds = reinterpret_cast<cf *>(big_smem);
+    const int t = (int)threadIdx.x;
+    const uint32_t C = a.big_c, R = a.big_r;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t k1 = slot % C, rel = (slot / C) * 8u + xcd;
+    if(rel >= a.stream_count * a.cap_ch)
+        return;
+    const uint32_t spec = a.stream_base * a.cap_ch + rel;
+    const uint32_t stream = spec >> (a.cap_ch - 1u);
+    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const uint32_t start = (a.wpos[stream] - delay - a.blu_n) & a.ring_mask;
+    const float *x = a.ring + (size_t)spec * a.ring_stride;
+    const cf *wc = a.big_wc + k1 * 8u;
+    const cf *twc = a.big_tw + (size_t)k1 * R;
+    uint32_t acc = 0;
+    for(uint32_t n2 = (uint32_t)t; n2 < R; n2 += (uint32_t)T) {
+        cf s = cf{0.0f, 0.0f};
+        for(uint32_t c = 0; c < C; ++c) {
+            const uint32_t idx = n2 + R * c, si = start + 2u * idx;
+            const float x0 = x[si & a.ring_mask], x1 = x[(si + 1u) & a.ring_mask];
+            const f2 w = ld2(a.window + 2u * idx);
+            acc |= f32_bits(x0) | f32_bits(x1);
+            const cf u = cf{x0 * w.x, x1 * w.y};
+            s = (k1 == 0) ? cadd(s, u) : cadd(s, cmul(u, wc[c]));
+        }
+        if(k1 != 0) {
+            const f2 q = ld2(reinterpret_cast<const float *>(twc + n2));
+            s = cmul(s, cf{q.x, q.y});
+        }
+        lds_st2(lds, (int)n2, s);
+    }
+    // x != 0.0f for any sample of the window (reference :63-72): row 0 has seen all of it
+    if(k1 == 0 && __any((acc & 0x7fffffffu) != 0u) && (t & 63) == 0)
+        atomicOr(a.big_nz_out + spec, 1u);
+    cf *z = const_cast<cf *>(a.big_z) + (size_t)spec * a.big_l; // (the epilogue's input; this kernel is its producer)
+    mr_transform_to<G>(a.mr, true, (int)R, t, lds, [] { __syncthreads(); }, [=](int k2, cf v) {
+        *reinterpret_cast<f2 *>(z + (size_t)k2 * C + k1) = f2{v.x, v.y};
+    });
 }
 
 // ---- render-time outputs from the finished rows --------------------------------------------------------------------

@@ -97,6 +97,8 @@ struct wf_hip {
     wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr, *d_blu_q = nullptr, *d_blu_qr = nullptr, *d_blu_w = nullptr;
     // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
     uint32_t big_l = 0, big_rows = 0;
+    bool big_mr = false;             // fft sizes above 16384 with small prime factors: big_rows rows of a mixed-radix transform (big_mr_rows_kernel)
+    wf::cf *d_big_wc = nullptr;      // [8][8] W_big_rows^(c k1)
     bool big_fused = false;          // fft_size 65536: column step and real split folded into the rows kernel (big_rows_fold_kernel)
     float *d_big_mag = nullptr;      // [n_spec][2][16384] its output: magnitudes by bin parity
     wf::cf *d_big_v = nullptr, *d_big_z = nullptr, *d_big_tw = nullptr, *d_big_tws = nullptr;
@@ -495,6 +497,29 @@ template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
     return WF_HIP_OK;
 }
 
+// fft sizes above 16384 with small prime factors: rows of a mixed-radix transform (column step folded into the fetch), then the
+// epilogue of the packed real transform (wf_big.hpp)
+int launch_tick_big_mr(wf_hip *h, const wf::TickArgs &a0)
+{
+    const uint32_t n_spec = a0.stream_count * a0.cap_ch;
+    hipStream_t st = h->launch_stream;
+    const uint32_t spec_base = a0.stream_base * a0.cap_ch;
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_big_nz + spec_base, 0, (size_t)n_spec * sizeof(uint32_t), st));
+    const dim3 grow(h->big_rows * ((n_spec + 7u) & ~7u)); // (row, spectrum) by XCD: see big_mr_rows_kernel
+    hipLaunchKernelGGL(wf::big_mr_rows_kernel, grow, dim3(wf::GBig::T), (size_t)wf::GBig::LDS_CF * sizeof(wf::cf), st, a0);
+    const uint32_t parts = (h->M + (uint32_t)wf::BIG_TP - 1u) / (uint32_t)wf::BIG_TP;
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) { // mono mixdown: channel 1 of every stream, then channel 0
+        wf::TickArgs a = a0;
+        a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(parts, h->split_mono ? a.stream_count : n_spec);
+        hipLaunchKernelGGL((wf::big_epilogue_kernel<1>), grid, dim3(wf::GBig::T), 0, st, a);
+    }
+    if(a0.bar.out != nullptr)
+        hipLaunchKernelGGL(wf::big_outputs_kernel, dim3(a0.stream_count * a0.bar.disp_ch), dim3(wf::GBig::T), h->big_out_lds, st, a0);
+    WF_HIP_TRY(h, hipGetLastError());
+    return WF_HIP_OK;
+}
+
 void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     // (a failure leaves its text in last_error and its HIP error sticky: wf_hip_tick's hipGetLastError() behind the launches
@@ -505,6 +530,10 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
         wf::TickArgs s = a;
         s.stream_base = a.stream_base + off;
         s.stream_count = std::min(part, a.stream_count - off);
+        if(h->big_mr) {
+            h->launch_rc = launch_tick_big_mr(h, s);
+            continue;
+        }
         if(h->big_fused) {
             h->launch_rc = launch_tick_big_fold(h, s, aligned);
             continue;
@@ -526,12 +555,17 @@ template<int L1> int setup_big_rows(wf_hip *h)
 
 int setup_launch_big(wf_hip *h)
 {
-    int rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
+    int rc = WF_HIP_OK;
+    if(h->big_mr)
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_mr_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)((size_t)wf::GBig::LDS_CF * sizeof(wf::cf))));
+    else
+        rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
     if(rc)
         return rc;
     // fft_size 65536 (the one power of two up here): everything in one kernel.  WF_HIP_BIG_FUSED=0 keeps the three-kernel path
     // (development aid: A/B, and the path every Bluestein size above 16384 takes)
-    h->big_fused = !h->blu && h->big_rows == 2;
+    h->big_fused = !h->blu && !h->big_mr && h->big_rows == 2;
     if(const char *e = std::getenv("WF_HIP_BIG_FUSED"))
         h->big_fused = h->big_fused && e[0] != '0';
     if(h->big_fused) {
@@ -546,8 +580,15 @@ int setup_launch_big(wf_hip *h)
     h->launch = &launch_tick_big;
     h->split = true;
     h->flag_bufs = 3;
-    char name[160];
-    if(h->big_fused)
+    char name[200];
+    if(h->big_mr) {
+        char rad[48];
+        int o = 0;
+        for(int i = 0; i < h->mr_passes; ++i)
+            o += snprintf(rad + o, sizeof(rad) - (size_t)o, "%s%d", i ? "x" : "", h->mr_radix[i]);
+        snprintf(name, sizeof(name), "big_mr_rows_kernel + big_epilogue_kernel<N=%u: %u rows of %u complex points as mixed radix %s, column step folded into the fetch>",
+                 h->N, h->big_rows, h->M / h->big_rows, rad);
+    } else if(h->big_fused)
         snprintf(name, sizeof(name), "big_rows_fold_kernel + big_epilogue_kernel<N=%u: two rows of 16384 complex points, column step and real split folded into the rows>", h->N);
     else if(h->blu)
         snprintf(name, sizeof(name), "big_{columns,rows,epilogue}_kernel<N=%u by Bluestein over %u = %u x 16384 complex points through device memory>",
@@ -659,6 +700,17 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.mr.tw = h->d_mr_tw;
         if(h->big_l) // direct form: |c_k| / L, times mag_coefficient (the packed form's tables carry the 1 / L, and its real split the 1 / 2)
             a.half_coef = (2.0f / h->tab.window_sum) / (float)h->big_l;
+    }
+    if(h->big_mr) {
+        a.mr.passes = h->mr_passes;
+        for(int i = 0; i < 4; ++i) {
+            a.mr.radix[i] = h->mr_radix[i];
+            a.mr.tw_off[i] = h->mr_tw_off[i];
+        }
+        a.mr.tw = h->d_mr_tw;
+        a.big_c = h->big_rows;
+        a.big_r = h->M / h->big_rows;
+        a.big_wc = h->d_big_wc;
     }
     if(h->big_l) {
         a.big_z = h->d_big_z;
@@ -939,6 +991,24 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         h->big_l = L > 16384u ? L : (!L && h->N == 65536u) ? 32768u : 0u;
         h->big_rows = h->big_l / 16384u;
         h->geom_n = h->big_l ? 32768u : L ? 2 * L : std::max(h->N, 512u); // big: the row transform's geometry
+        // above 16384 samples and not a power of two: where n/2 = C R with R <= 8192 a length that has a mixed-radix plan, C <= 8
+        // rows of that transform (big_mr_rows_kernel) instead of Bluestein through device memory
+        const char *no_mr = std::getenv("WF_HIP_NO_MIXED_RADIX");
+        if(h->blu && h->big_l && !(no_mr && no_mr[0] == '1')) {
+            const uint32_t np = h->N / 2;
+            for(uint32_t c = 2; c <= 8 && !h->big_mr; ++c) {
+                if(np % c || np / c > 8192u)
+                    continue;
+                const int passes = wf::plan_mixed_radix(np / c, 1024u, h->mr_radix);
+                if(passes > 0) {
+                    h->big_mr = true;
+                    h->mr_passes = passes;
+                    h->blu = false;      // no chirp tables, no chirped window: the plain packed real transform
+                    h->big_l = np;       // (complex points per spectrum in the scratch buffer)
+                    h->big_rows = c;
+                }
+            }
+        }
     }
     if(cfg->waveform) {
         // rows of `width` points; the ring holds the history the points are picked from (+ the width zeros of update())
@@ -1341,6 +1411,22 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_blu_w, tw));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
+    if(h->big_mr) {
+        // the rows' passes (a transform of R = n / 2 / C points) and the column step's W_C^(c k1)
+        std::vector<wf::cfloat> twf, unused;
+        wf::build_mixed_radix_tables(2u * (h->M / h->big_rows), h->mr_passes, h->mr_radix, twf, h->mr_tw_off, unused);
+        std::vector<wf::cf> t1(twf.size()), wc(64, wf::cf{1.0f, 0.0f});
+        std::memcpy(t1.data(), twf.data(), t1.size() * sizeof(wf::cf));
+        const double two_pi = 6.283185307179586476925286766559;
+        for(uint32_t k1 = 0; k1 < h->big_rows; ++k1)
+            for(uint32_t c = 0; c < h->big_rows; ++c) {
+                const double ang = -two_pi * (double)((c * k1) % h->big_rows) / (double)h->big_rows;
+                wc[k1 * 8u + c] = wf::cf{(float)std::cos(ang), (float)std::sin(ang)};
+            }
+        WF_CREATE_TRY(upload(h, &h->d_mr_tw, t1));
+        WF_CREATE_TRY(upload(h, &h->d_big_wc, wc));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+    }
     if(h->big_l) {
         std::vector<wf::cfloat> twb, twsb;
         wf::build_big_twiddles(h->big_l, h->big_rows, h->blu ? 0u : h->N, twb, twsb);
@@ -1353,6 +1439,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
         if(h->big_fused) { // (no complex scratch: the rows kernel reads the ring and leaves magnitudes)
             WF_CREATE_TRY(dev_alloc(h, &h->d_big_mag, n_spec * 2u * 16384u));
+        } else if(h->big_mr) { // (the rows read the ring themselves: one scratch buffer, for Z)
+            WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_l));
         } else {
             WF_CREATE_TRY(dev_alloc(h, &h->d_big_v, n_spec * h->big_l));
             WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_l));

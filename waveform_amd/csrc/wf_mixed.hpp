@@ -321,9 +321,9 @@ WF_DEV void mr_pass(int R, const cf *src, cf *dst, const cf *tw, int np, int ns,
     default: mr_pass_r<16, true>(src, dst, tw, np, ns, t, T); break;
     }
 }
-// the last pass: ns R == np, at most one butterfly per thread (j = t < nb = ns); X[j + k ns] into the ex3 layout of
-// geometry G behind `sync` (every thread has read its inputs: the layout overlaps both halves of the buffer)
-template<class G, int R, class Sync> WF_DEV void mr_last_r(bool process, const cf *src, cf *lds, const cf *tw, int ns, int t, Sync sync)
+// the last pass: ns R == np, at most one butterfly per thread (j = t < nb = ns); X[j + k ns] handed to `store` behind `sync`
+// (every thread has read its inputs: a store into the exchange buffer may overlap both halves)
+template<int R, class Sync, class Store> WF_DEV void mr_last_r(bool process, const cf *src, const cf *tw, int ns, int t, Sync sync, Store store)
 {
     cf v[R];
     const bool mine = process && t < ns;
@@ -333,26 +333,26 @@ template<class G, int R, class Sync> WF_DEV void mr_last_r(bool process, const c
     if(mine) {
         WF_UNROLL
         for(int k = 0; k < R; ++k)
-            lds_st2(lds, ex3_addr<G>(t + k * ns), v[k]);
+            store(t + k * ns, v[k]);
     }
 }
-template<class G, class Sync> WF_DEV void mr_last(int R, bool process, const cf *src, cf *lds, const cf *tw, int ns, int t, Sync sync)
+template<class Sync, class Store> WF_DEV void mr_last(int R, bool process, const cf *src, const cf *tw, int ns, int t, Sync sync, Store store)
 {
     switch(R) {
-    case 2: mr_last_r<G, 2>(process, src, lds, tw, ns, t, sync); break;
-    case 3: mr_last_r<G, 3>(process, src, lds, tw, ns, t, sync); break;
-    case 4: mr_last_r<G, 4>(process, src, lds, tw, ns, t, sync); break;
-    case 5: mr_last_r<G, 5>(process, src, lds, tw, ns, t, sync); break;
-    case 6: mr_last_r<G, 6>(process, src, lds, tw, ns, t, sync); break;
-    case 7: mr_last_r<G, 7>(process, src, lds, tw, ns, t, sync); break;
-    case 8: mr_last_r<G, 8>(process, src, lds, tw, ns, t, sync); break;
-    case 9: mr_last_r<G, 9>(process, src, lds, tw, ns, t, sync); break;
-    case 10: mr_last_r<G, 10>(process, src, lds, tw, ns, t, sync); break;
-    case 11: mr_last_r<G, 11>(process, src, lds, tw, ns, t, sync); break;
-    case 12: mr_last_r<G, 12>(process, src, lds, tw, ns, t, sync); break;
-    case 13: mr_last_r<G, 13>(process, src, lds, tw, ns, t, sync); break;
-    case 15: mr_last_r<G, 15>(process, src, lds, tw, ns, t, sync); break;
-    default: mr_last_r<G, 16>(process, src, lds, tw, ns, t, sync); break;
+    case 2: mr_last_r<2>(process, src, tw, ns, t, sync, store); break;
+    case 3: mr_last_r<3>(process, src, tw, ns, t, sync, store); break;
+    case 4: mr_last_r<4>(process, src, tw, ns, t, sync, store); break;
+    case 5: mr_last_r<5>(process, src, tw, ns, t, sync, store); break;
+    case 6: mr_last_r<6>(process, src, tw, ns, t, sync, store); break;
+    case 7: mr_last_r<7>(process, src, tw, ns, t, sync, store); break;
+    case 8: mr_last_r<8>(process, src, tw, ns, t, sync, store); break;
+    case 9: mr_last_r<9>(process, src, tw, ns, t, sync, store); break;
+    case 10: mr_last_r<10>(process, src, tw, ns, t, sync, store); break;
+    case 11: mr_last_r<11>(process, src, tw, ns, t, sync, store); break;
+    case 12: mr_last_r<12>(process, src, tw, ns, t, sync, store); break;
+    case 13: mr_last_r<13>(process, src, tw, ns, t, sync, store); break;
+    case 15: mr_last_r<15>(process, src, tw, ns, t, sync, store); break;
+    default: mr_last_r<16>(process, src, tw, ns, t, sync, store); break;
     }
 }
 
@@ -383,9 +383,9 @@ template<class G> WF_DEV bool mr_fetch(const TickArgs &a, int t, const float *x,
     return (acc & 0x7fffffffu) != 0;
 }
 
-// The whole transform.  On entry the np windowed points sit in lds[0 .. np) (natural order); on return Z[k] sits at
-// ex3_addr<G>(k), visible to every thread of the spectrum.  Called by ALL threads of the spectrum (sync is its barrier).
-template<class G, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool process, int np, int t, cf *lds, Sync sync)
+// The whole transform.  On entry the np windowed points sit in lds[0 .. np) (natural order); Z[k] is handed to store(k, Z[k]) by
+// the thread that finishes it.  Called by ALL threads of the spectrum (sync is its barrier).
+template<class G, class Sync, class Store> WF_DEV void mr_transform_to(const MrPlan &p, bool process, int np, int t, cf *lds, Sync sync, Store store)
 {
     constexpr int H = G::M / 2; // second half of the exchange buffer (M >= 2 np)
     sync(); // the fetch has written the first half
@@ -401,7 +401,12 @@ template<class G, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool pro
         ns *= R;
     }
     sync();
-    mr_last<G>(p.radix[p.passes - 1], process, lds + cur * H, lds, p.tw + p.tw_off[p.passes - 1], ns, t, sync);
+    mr_last(p.radix[p.passes - 1], process, lds + cur * H, p.tw + p.tw_off[p.passes - 1], ns, t, sync, store);
+}
+// ... with Z[k] left at ex3_addr<G>(k) of the exchange buffer, visible to every thread of the spectrum on return
+template<class G, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool process, int np, int t, cf *lds, Sync sync)
+{
+    mr_transform_to<G>(p, process, np, t, lds, sync, [lds](int k, cf v) { lds_st2(lds, ex3_addr<G>(k), v); });
     sync();
 }
 
