@@ -288,6 +288,12 @@ def configs4_region(wf, torch, dist, rank, world, local_rank, steps, lead_in_ms=
 
         probe = run(8)
         warm = 8 + int(lead_in_ms / max(probe, 1e-4)) + 1
+        if dist is not None:
+            # every tick carries a collective: the ranks must agree on the number of ticks, and each derived its own from its
+            # own clock (a count that differs by one between two ranks leaves one of them in an all-gather nobody answers)
+            w = torch.tensor([warm], dtype=torch.int64, device="cuda")
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            warm = int(w.item())
         run(warm - 8)
         barrier()
         t0 = time.perf_counter()
@@ -461,6 +467,10 @@ def main():
     if args.lead_in_ms > 0:
         probe = run(16)
         lead_in_ticks = 16 + int(args.lead_in_ms / max(probe, 1e-4)) + 1
+        if dist is not None:  # (the same count on every rank: with --bars-allgather every tick carries a collective)
+            w = torch.tensor([lead_in_ticks], dtype=torch.int64, device="cuda")
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            lead_in_ticks = int(w.item())
         run(lead_in_ticks - 16)
     # warm-up: W untimed steps
     if args.warmup > 0:

@@ -1,9 +1,10 @@
 // mr_check.cpp -- host check of the mixed-radix path (waveform_amd/csrc/wf_mixed.hpp + plan_mixed_radix), built and run by
 // tests/test_cpu_units.py::test_mixed_radix_plans_and_transforms.  Test infrastructure, not part of the product.
 //  * every in-register DFT against the definition in double;
-//  * for EVERY multiple of 16 in [128, 16384]: the plan exists exactly for the sizes with no prime factor above 5 that are not
-//    powers of two (prime factors up to 13), multiplies to n / 2, uses the radices the kernel instantiates, keeps radices above 16 in the first pass and
-//    leaves the last pass one butterfly per thread of the container geometry;
+//  * for EVERY multiple of 16 in [128, 16384] that is not a power of two: a plan exists for every size with no prime factor above
+//    13 and for none with two large prime factors; one prime factor of 17 .. 127 on top is the planner's call (it weighs a prime
+//    first pass against Bluestein's transforms); every plan multiplies to n / 2, uses the radices the kernel instantiates, keeps
+//    radices above 16 in the first pass and leaves the last pass one butterfly per thread of the container geometry;
 //  * for a spread of sizes: the passes themselves (mr_pass_first / mr_pass / the last pass's butterflies), lane by lane,
 //    against a double DFT.
 #include <cstdio>
@@ -55,10 +56,11 @@ int main()
             while(r % p == 0)
                 r /= p;
         const bool pow2 = (n & (n - 1)) == 0;
-        // one factor 17 / 19 / 23 may come on top (a radix of the first pass only, like 20 and 25); whether the rest then still
-        // orders into a plan is the planner's business: such sizes are checked for consistency only
+        // one factor 17 / 19 / 23 (a radix of the first pass only, like 20 and 25) or one prime of 29 .. 127 (the first pass by the
+        // definition) may come on top; whether the rest then still orders into a plan is the planner's business: such sizes are
+        // checked for consistency only
         bool one_big = false;
-        for(unsigned p : {17u, 19u, 23u})
+        for(unsigned p = 17; p <= 127; ++p)
             if(r == p)
                 one_big = true;
         const bool smooth = r == 1;
@@ -66,7 +68,10 @@ int main()
             continue;
         int radix[4];
         const unsigned np = n / 2, T = container_threads(n);
-        const int passes = plan_mixed_radix(np, T, radix);
+        unsigned Lb = 512; // what Bluestein would transform instead: the planner weighs a prime first pass against it
+        while(Lb < n - 1)
+            Lb <<= 1;
+        const int passes = plan_mixed_radix(np, T, radix, Lb);
         if(!one_big)
             CHECK((passes > 0) == smooth, "n = %u: plan %d passes, smooth %d", n, passes, (int)smooth);
         if(passes <= 0)
@@ -76,14 +81,17 @@ int main()
         for(int i = 0; i < passes; ++i) {
             const int v = radix[i];
             prod *= (unsigned long long)v;
-            const bool known = ((v == 17 || v == 19 || v == 23) && i == 0) || v == 7 || v == 11 || v == 13 || v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 20 || v == 25;
-            CHECK(known && (v <= 16 || i == 0), "n = %u: radix %d in pass %d", n, v, i);
+            bool lead_prime = i == 0 && v >= 29 && v <= 127;
+            for(int d = 2; lead_prime && d * d <= v; ++d)
+                lead_prime = v % d != 0;
+            const bool known = lead_prime || ((v == 17 || v == 19 || v == 23) && i == 0) || v == 7 || v == 11 || v == 13 || v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 20 || v == 25;
+            CHECK(known && (v <= 16 || i == 0) && !(radix[0] > 25 && i > 0 && v > 16), "n = %u: radix %d in pass %d", n, v, i);
         }
         CHECK(passes >= 2 && passes <= 4 && prod == np, "n = %u: %d passes, product %llu", n, passes, prod);
         CHECK(np / (unsigned)radix[passes - 1] <= T, "n = %u: last pass has %u butterflies for %u threads", n, np / radix[passes - 1], T);
     }
     std::printf("planned %d sizes\n", planned);
-    for(unsigned n : {800u, 1600u, 960u, 1920u, 2000u, 320u, 144u, 8000u, 1536u, 15552u, 12288u, 6000u, 4160u, 1760u, 1456u, 880u, 352u, 16016u, 224u, 1824u, 304u, 1088u, 1472u, 5888u, 14720u}) {
+    for(unsigned n : {800u, 1600u, 960u, 1920u, 2000u, 320u, 144u, 8000u, 1536u, 15552u, 12288u, 6000u, 4160u, 1760u, 1456u, 880u, 352u, 16016u, 224u, 1824u, 304u, 1088u, 1472u, 5888u, 14720u, 4144u, 2368u, 1856u, 8128u, 16256u, 592u, 7808u}) {
         int radix[4], off[4];
         const unsigned np = n / 2, T = container_threads(n);
         const int passes = plan_mixed_radix(np, T, radix);
@@ -103,8 +111,17 @@ int main()
             lds[i] = cf{(float)x[i].real(), (float)x[i].imag()};
         }
         int ns = radix[0], cur = 1;
-        for(unsigned t = 0; t < T; ++t)
-            mr_pass_first(radix[0], lds.data(), lds.data() + H, (int)np, (int)t, (int)T);
+        std::vector<cfloat> wpf;
+        build_prime_twiddles(radix[0] > 25 ? radix[0] : 2, 128, wpf);
+        std::vector<cf> wp(wpf.size());
+        for(size_t i = 0; i < wp.size(); ++i)
+            wp[i] = cf{wpf[i].re, wpf[i].im};
+        for(unsigned t = 0; t < T; ++t) {
+            if(radix[0] > 25)
+                mr_pass_prime(radix[0], lds.data(), lds.data() + H, wp.data(), (int)np, (int)t, (int)T);
+            else
+                mr_pass_first(radix[0], lds.data(), lds.data() + H, (int)np, (int)t, (int)T);
+        }
         for(int s = 1; s + 1 < passes; ++s) {
             for(unsigned t = 0; t < T; ++t)
                 mr_pass(radix[s], lds.data() + cur * H, lds.data() + (1 - cur) * H, tw.data() + off[s], (int)np, ns, (int)t, (int)T);

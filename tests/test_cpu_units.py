@@ -269,7 +269,7 @@ template __global__ void wf::big_epilogue_kernel<3>(wf::TickArgs);
 
 
 def test_mixed_radix_plans_and_transforms(tmp_path):
-    """wf_mixed.hpp (fft sizes with no prime factor above 23 computed directly instead of by Bluestein) on the host: tests/emu/mr_check.cpp runs
+    """wf_mixed.hpp (fft sizes with small prime factors and at most one prime factor of 17 .. 127, computed directly instead of by Bluestein) on the host: tests/emu/mr_check.cpp runs
     every in-register DFT against the definition, checks the plan of EVERY multiple of 16 up to 16384 (exists exactly for the
     smooth sizes, multiplies to n / 2, respects the kernel's constraints), and replays the passes lane by lane against a double
     DFT for a spread of sizes"""
@@ -279,7 +279,7 @@ def test_mixed_radix_plans_and_transforms(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
-    assert run.returncode == 0 and run.stdout.strip().endswith("ok") and "planned 347 sizes" in run.stdout, run.stdout[-3000:]
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok") and "planned 624 sizes" in run.stdout, run.stdout[-3000:]
 
 
 # ---- C ABI -----------------------------------------------------------------------------------------------

@@ -35,8 +35,8 @@ def _largest_prime_factor(n: int) -> int:
     return max(best, n) if n > 1 else best
 
 
-def _five_smooth(n):  # (what plan_mixed_radix takes: no prime factor above 13, one factor 17 / 19 / 23 on top at most)
-    for p in (17, 19, 23):
+def _five_smooth(n):  # (what plan_mixed_radix takes: no prime factor above 13, one prime factor of 17 .. 127 on top at most)
+    for p in (17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113, 127):
         if n % p == 0:
             n //= p
             break
@@ -394,11 +394,11 @@ def test_hip_matches_oracle_on_random_smooth_size(seed):
 @pytest.mark.gpu
 def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
     import waveform_amd as wf
-    for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, True), (16336, False), (4160, True), (1760, True), (1456, True), (1824, True), (1088, True), (1472, True), (464, False), (4144, False), (144, True), (15552, True)):
+    for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, True), (16336, False), (4160, True), (1760, True), (1456, True), (1824, True), (1088, True), (1472, True), (464, True), (4144, True), (7808, True), (8128, False), (2096, False), (13456, False), (144, True), (15552, True)):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
             name = b.kernel_name()
             assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)
-    for n, big_mr in ((48000, True), (32000, True), (65520, True), (20480, True), (16400, False), (48016, False)):
+    for n, big_mr in ((48000, True), (32000, True), (65520, True), (20480, True), (16400, True), (48016, False), (33824, False)):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 1) as b:
             name = b.kernel_name()
             assert ("big_mr_rows_kernel" in name) == big_mr and ("Bluestein" in name) != big_mr, (n, name)

@@ -606,8 +606,11 @@ __global__ __launch_bounds__(GBig::T, 4) void big_mr_rows_kernel(const TickArgs 
     // x != 0.0f for any sample of the window (reference :63-72): row 0 has seen all of it
     if(k1 == 0 && __any((acc & 0x7fffffffu) != 0u) && (t & 63) == 0)
         atomicOr(a.big_nz_out + spec, 1u);
+    cf *wp_lds = lds + G::LDS_CF; // behind the exchange buffer: the prime pass's W_p^m (128 entries at most)
+    if(a.mr.radix[0] > 25 && t < a.mr.radix[0])
+        wp_lds[t] = a.mr.wp[t];
     cf *z = const_cast<cf *>(a.big_z) + (size_t)spec * a.big_l; // (the epilogue's input; this kernel is its producer)
-    mr_transform_to<G>(a.mr, true, (int)R, t, lds, [] { __syncthreads(); }, [=](int k2, cf v) {
+    mr_transform_to<G>(a.mr, true, (int)R, t, lds, wp_lds, [] { __syncthreads(); }, [=](int k2, cf v) {
         *reinterpret_cast<f2 *>(z + (size_t)k2 * C + k1) = f2{v.x, v.y};
     });
 }

@@ -93,6 +93,7 @@ struct wf_hip {
     int mr_passes = 0;               // > 0: fft_size = 2^a 3^b 5^c, the transform runs as mixed-radix passes inside the Bluestein instantiation (wf_mixed.hpp)
     int mr_radix[4] = {0, 0, 0, 0}, mr_tw_off[4] = {0, 0, 0, 0};
     wf::cf *d_mr_tw = nullptr;       // the passes' twiddle tables (wf::build_mixed_radix_tables)
+    wf::cf *d_mr_wp = nullptr;       // W_p^m of a prime first pass (wf::build_prime_twiddles)
     uint32_t geom_n = 0;             // the fft size whose geometry runs the batch (N itself for the power-of-two sizes >= 1024)
     wf::cf *d_blu_a = nullptr, *d_blu_b = nullptr, *d_blu_q = nullptr, *d_blu_qr = nullptr, *d_blu_w = nullptr;
     // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
@@ -316,8 +317,8 @@ template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_
     if constexpr(!MR && G::N >= 1024) { // (the smallest container a size that is not a power of two ever gets: wf::bluestein_length)
         // sizes with no prime factor above 5 take the same instantiation's fetch and epilogue around a direct transform
         const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX"); // (development: A/B against Bluestein)
-        if(!(off && off[0] == '1') && wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix) > 0) {
-            h->mr_passes = wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix);
+        if(!(off && off[0] == '1') && wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix, (uint64_t)G::M) > 0) {
+            h->mr_passes = wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix, (uint64_t)G::M);
             if(const char *e = std::getenv("WF_HIP_MR_PLAN")) { // (development: "25,16" -- another order or split of the same product)
                 int r[4] = {0, 0, 0, 0}, n = 0;
                 uint64_t prod = 1;
@@ -332,7 +333,7 @@ template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_
                 for(int i = 0; i < n; ++i) {
                     const int v = r[i];
                     ok = ok && (v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 7 || v == 11 || v == 13 ||
-                                (i == 0 && (v == 20 || v == 25 || v == 17 || v == 19 || v == 23)));
+                                (i == 0 && (v == 20 || v == 25 || v == 17 || v == 19 || v == 23 || v == h->mr_radix[0])));
                 }
                 if(ok) {
                     h->mr_passes = n;
@@ -506,7 +507,7 @@ int launch_tick_big_mr(wf_hip *h, const wf::TickArgs &a0)
     const uint32_t spec_base = a0.stream_base * a0.cap_ch;
     WF_HIP_TRY(h, hipMemsetAsync(h->d_big_nz + spec_base, 0, (size_t)n_spec * sizeof(uint32_t), st));
     const dim3 grow(h->big_rows * ((n_spec + 7u) & ~7u)); // (row, spectrum) by XCD: see big_mr_rows_kernel
-    hipLaunchKernelGGL(wf::big_mr_rows_kernel, grow, dim3(wf::GBig::T), (size_t)wf::GBig::LDS_CF * sizeof(wf::cf), st, a0);
+    hipLaunchKernelGGL(wf::big_mr_rows_kernel, grow, dim3(wf::GBig::T), (size_t)(wf::GBig::LDS_CF + 128) * sizeof(wf::cf), st, a0);
     const uint32_t parts = (h->M + (uint32_t)wf::BIG_TP - 1u) / (uint32_t)wf::BIG_TP;
     for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) { // mono mixdown: channel 1 of every stream, then channel 0
         wf::TickArgs a = a0;
@@ -558,7 +559,7 @@ int setup_launch_big(wf_hip *h)
     int rc = WF_HIP_OK;
     if(h->big_mr)
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_mr_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)((size_t)wf::GBig::LDS_CF * sizeof(wf::cf))));
+                                          (int)((size_t)(wf::GBig::LDS_CF + 128) * sizeof(wf::cf))));
     else
         rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
     if(rc)
@@ -698,6 +699,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
             a.mr.tw_off[i] = h->mr_tw_off[i];
         }
         a.mr.tw = h->d_mr_tw;
+        a.mr.wp = h->d_mr_wp;
         if(h->big_l) // direct form: |c_k| / L, times mag_coefficient (the packed form's tables carry the 1 / L, and its real split the 1 / 2)
             a.half_coef = (2.0f / h->tab.window_sum) / (float)h->big_l;
     }
@@ -708,6 +710,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
             a.mr.tw_off[i] = h->mr_tw_off[i];
         }
         a.mr.tw = h->d_mr_tw;
+        a.mr.wp = h->d_mr_wp;
         a.big_c = h->big_rows;
         a.big_r = h->M / h->big_rows;
         a.big_wc = h->d_big_wc;
@@ -1372,6 +1375,15 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         std::memcpy(t1.data(), tw1.data(), tw1.size() * sizeof(wf::cf));
         std::memcpy(t2.data(), tw2.data(), tw2.size() * sizeof(wf::cf));
         std::memcpy(t3.data(), tws.data(), tws.size() * sizeof(wf::cf));
+        if(h->mr_passes > 0 && h->mr_radix[0] > 25) {
+            // a mixed-radix plan that opens with a prime pass (wf::mr_pass_prime): its W_p^m goes where the power-of-two kernels keep
+            // their pass-2 twiddles -- the tick kernel stages that table in LDS anyway and the mixed-radix passes do not use it
+            std::vector<wf::cfloat> wp;
+            wf::build_prime_twiddles(h->mr_radix[0], t2.size(), wp);
+            t2.resize(wp.size());
+            std::memcpy(t2.data(), wp.data(), wp.size() * sizeof(wf::cf));
+            WF_CREATE_TRY(upload(h, &h->d_mr_wp, t2)); // (the large-FFT rows kernel reads it from device memory)
+        }
         WF_CREATE_TRY(upload(h, &h->d_tw1, t1));
         WF_CREATE_TRY(upload(h, &h->d_tw2, t2));
         WF_CREATE_TRY(upload(h, &h->d_tws, t3));

@@ -774,28 +774,42 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
     }
 }
 
-int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4])
+int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4], uint64_t bluestein_points)
 {
     static const int kRadices[] = {25, 23, 20, 19, 17, 16, 15, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
-    {
-        uint32_t r = np;
-        for(uint32_t p : {2u, 3u, 5u, 7u, 11u, 13u, 17u, 19u, 23u})
-            while(r % p == 0)
-                r /= p;
-        if(np < 4 || r != 1) {
-            radix[0] = radix[1] = radix[2] = radix[3] = 0;
+    radix[0] = radix[1] = radix[2] = radix[3] = 0;
+    if(np < 4)
+        return 0;
+    // what is left of np beyond the primes the radix set is made of: nothing, or ONE prime of 29 .. 127, which becomes the
+    // first pass (mr_pass_prime: the DFTs by the definition); the rest of np is then planned behind it
+    uint32_t lead = np;
+    for(uint32_t p : {2u, 3u, 5u, 7u, 11u, 13u, 17u, 19u, 23u})
+        while(lead % p == 0)
+            lead /= p;
+    if(lead != 1) {
+        bool prime = lead >= 29 && lead <= 127;
+        for(uint32_t d = 2; prime && d * d <= lead; ++d)
+            prime = lead % d != 0;
+        if(!prime || (np / lead) % 4u != 0) // (the prime pass takes its butterflies four at a time, 16-byte aligned)
             return 0;
-        }
+        // p^2 multiply-adds per butterfly against Bluestein's two transforms of L points: measured on MI355X the
+        // kernel's time goes like np (57 + p) here and like 66 L there -- N = 7808 (p = 61, L = 8192) +17 %, 6208 (97) +-0,
+        // 8128 (127) -30 %
+        if(bluestein_points && (uint64_t)np * (57u + lead) > 60u * bluestein_points)
+            return 0;
     }
+    const uint32_t rest = np / lead;    // planned from kRadices
+    const bool led = lead != 1;         // ... behind a prime first pass: at most three more, none above 16
+    const int max_n = led ? 3 : 4, min_n = led ? 1 : 2;
     int best[4] = {0, 0, 0, 0}, best_n = 0, best_min = 0, cur[4];
-    // multisets of 2 .. 4 radices (non-increasing) with product np
     auto consider = [&](int n) {
-        // order: a radix above 16 must be first (at most one); the last one is the largest radix <= 16 with np / R <= threads;
-        // the first one otherwise an odd radix (its stores go out with stride R: conflict-free when R is odd)
+        // order: a radix above 16 must be first (at most one, none behind a prime first pass); the last one is the largest radix
+        // <= 16 with np / R <= threads; the first one otherwise an odd radix (its stores go out with stride R: conflict-free when
+        // R is odd)
         int order[4], used[4] = {0, 0, 0, 0}, big = 0;
         for(int i = 0; i < n; ++i)
             big += cur[i] > 16;
-        if(big > 1)
+        if(big > (led ? 0 : 1))
             return;
         int last = -1;
         for(int i = 0; i < n; ++i)
@@ -804,23 +818,23 @@ int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4])
         if(last < 0)
             return;
         used[last] = 1;
-        int first = -1;
-        for(int i = 0; i < n; ++i)
-            if(!used[i] && cur[i] > 16)
-                first = i;
-        if(first < 0)
-            for(int i = 0; i < n; ++i)
-                if(!used[i] && (cur[i] & 1) && (first < 0 || cur[i] > cur[first]))
-                    first = i;
-        if(first < 0)
-            for(int i = 0; i < n; ++i)
-                if(!used[i] && (first < 0 || cur[i] > cur[first]))
-                    first = i;
-        if(first < 0)
-            return; // (n >= 2: cannot happen)
-        used[first] = 1;
         int k = 0;
-        order[k++] = cur[first];
+        if(n >= 2) {
+            int first = -1;
+            for(int i = 0; i < n; ++i)
+                if(!used[i] && cur[i] > 16)
+                    first = i;
+            if(first < 0 && !led)
+                for(int i = 0; i < n; ++i)
+                    if(!used[i] && (cur[i] & 1) && (first < 0 || cur[i] > cur[first]))
+                        first = i;
+            if(first < 0)
+                for(int i = 0; i < n; ++i)
+                    if(!used[i] && (first < 0 || cur[i] > cur[first]))
+                        first = i;
+            used[first] = 1;
+            order[k++] = cur[first];
+        }
         for(int i = 0; i < n; ++i)
             if(!used[i])
                 order[k++] = cur[i];
@@ -835,24 +849,39 @@ int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4])
                 best[i] = order[i];
         }
     };
-    auto rec = [&](auto &&self, uint32_t rest, int depth, int max_idx) -> void {
-        if(rest == 1) {
-            if(depth >= 2)
+    auto rec = [&](auto &&self, uint32_t left, int depth, int max_idx) -> void {
+        if(left == 1) {
+            if(depth >= min_n)
                 consider(depth);
             return;
         }
-        if(depth == 4)
+        if(depth == max_n)
             return;
         for(int i = max_idx; i < (int)(sizeof(kRadices) / sizeof(kRadices[0])); ++i)
-            if(rest % (uint32_t)kRadices[i] == 0) {
+            if(left % (uint32_t)kRadices[i] == 0) {
                 cur[depth] = kRadices[i];
-                self(self, rest / (uint32_t)kRadices[i], depth + 1, i);
+                self(self, left / (uint32_t)kRadices[i], depth + 1, i);
             }
     };
-    rec(rec, np, 0, 0);
-    for(int i = 0; i < 4; ++i)
-        radix[i] = i < best_n ? best[i] : 0;
-    return best_n;
+    rec(rec, rest, 0, 0);
+    if(best_n == 0)
+        return 0;
+    int o = 0;
+    if(led)
+        radix[o++] = (int)lead;
+    for(int i = 0; i < best_n; ++i)
+        radix[o++] = best[i];
+    return o;
+}
+
+void build_prime_twiddles(int p, size_t entries, std::vector<cfloat> &wp)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    wp.assign(std::max(entries, (size_t)p), cfloat{1.0f, 0.0f});
+    for(int m = 0; m < p; ++m) {
+        const double a = -two_pi * (double)m / (double)p;
+        wp[(size_t)m] = cfloat{(float)std::cos(a), (float)std::sin(a)};
+    }
 }
 
 void build_mixed_radix_tables(uint32_t n, int passes, const int radix[4], std::vector<cfloat> &tw, int tw_off[4], std::vector<cfloat> &w)

@@ -118,7 +118,12 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
 // Bluestein.  plan_mixed_radix fills radix[] in pass order and returns the number of passes, 0 when np has another prime
 // factor or no ordering fits: radices above 16 only in the first pass (the twiddled passes hold 2 (R - 1) more registers), and
 // the last pass has one butterfly per thread at most (np / radix[last] <= threads).
-int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4]);
+int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4], uint64_t bluestein_points = 0);
+// (bluestein_points: the length L of the transforms Bluestein would run instead, 0: no alternative worth weighing -- a prime first
+// pass is only planned where its p^2 work is expected to beat them)
+// radix[0] a prime of 29 .. 127 (the rest of np is then planned behind it, radices up to 16): wp[m] = W_p^m, padded with ones to
+// `entries` (the tick kernel stages the table where the power-of-two kernels keep R2 x R3 pass-2 twiddles)
+void build_prime_twiddles(int p, size_t entries, std::vector<cfloat> &wp);
 // tw: for every pass s >= 1 its twiddles [R_s][Ns] = W_(Ns R_s)^(k jm) (Ns = product of the radices before it), concatenated;
 // tw_off[s] = where pass s starts.  w[k] = W_n^k, the real-split twiddles (k < n / 2)
 void build_mixed_radix_tables(uint32_t n, int passes, const int radix[4], std::vector<cfloat> &tw, int tw_off[4], std::vector<cfloat> &w);

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     if constexpr(BLU && MR) {
         // FFT sizes with no prime factor above 5: the n/2-point transform itself, two to four mixed-radix passes between the two
         // halves of the exchange buffer (wf_mixed.hpp) instead of Bluestein's two power-of-two transforms
-        mr_transform<G>(a.mr, process, (int)a.row_bins, t, lds, [] { spectrum_sync<G>(); });
+        mr_transform<G>(a.mr, process, (int)a.row_bins, t, lds, tw2_lds, [] { spectrum_sync<G>(); }); // (tw2_lds: the prime pass's W_p^m, staged where the power-of-two kernels keep their pass-2 twiddles: TickArgs::tw2 points at it)
     } else {
         if constexpr(TLDS) {
             cf o1[G::R1][G::B1];

@@ -1,4 +1,4 @@
-// wf_mixed.hpp -- FFT sizes with no prime factor above 23 (one factor 17, 19 or 23 at most), computed directly (device code; also compiled by g++ for
+// wf_mixed.hpp -- FFT sizes with small prime factors and at most one prime factor of 17 .. 127, computed directly (device code; also compiled by g++ for
 // tests/emu, which replays these functions lane by lane).
 //
 // The reference takes every multiple of 16 as fft_size (src/source.cpp:562-565) and FFTW gives it an O(n log n) plan for each.
@@ -276,6 +276,45 @@ template<int R, bool TW> WF_DEV void mr_pass_r(const cf *src, cf *dst, const cf 
             lds_st2(dst, base + k * ns, v[k]);
     }
 }
+// A first pass whose radix is a prime p of 29 .. 127 (sizes such as 64 x 37: one position of the FFT-size slider in three has
+// such a factor): the p-point DFTs by the definition, p^2 complex multiply-adds each -- up to p ~ 100 fewer operations than the two
+// transforms of >= 2 np points Bluestein's algorithm takes, and no chirp tables.  Work item = (four consecutive butterflies, one
+// output index k): per input index n one table entry W_p^(n k mod p) (LDS; k is the same across most of a wavefront) and JB
+// consecutive points (16-byte LDS reads) feed JB accumulators.  np / p is a multiple of 4 (the planner sees to it).
+template<int JB> WF_DEV void mr_pass_prime_jb(int p, const cf *src, cf *dst, const cf *wp, int np, int t, int T)
+{
+    const int nb = np / p, nq = nb / JB;
+    for(int it = t; it < nq * p; it += T) {
+        const int k = it / nq, j = JB * (it - k * nq);
+        cf acc[JB];
+        WF_UNROLL
+        for(int i = 0; i < JB; ++i)
+            acc[i] = cf{0.0f, 0.0f};
+        int idx = 0;
+        for(int n = 0; n < p; ++n) {
+            const cf w = lds_ld2(wp, idx);
+            WF_UNROLL
+            for(int i = 0; i < JB; i += 2) {
+                const f4 x = lds_ld4(src, j + n * nb + i);
+                acc[i] = cf{fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[i].x)), fmaf(x.x, w.y, fmaf(x.y, w.x, acc[i].y))};
+                acc[i + 1] = cf{fmaf(x.z, w.x, fmaf(-x.w, w.y, acc[i + 1].x)), fmaf(x.z, w.y, fmaf(x.w, w.x, acc[i + 1].y))};
+            }
+            idx += k;
+            idx = idx >= p ? idx - p : idx;
+        }
+        WF_UNROLL
+        for(int i = 0; i < JB; ++i)
+            lds_st2(dst, (j + i) * p + k, acc[i]);
+    }
+}
+// (eight butterflies per work item where np / p allows: five LDS reads per 32 multiply-adds instead of three per 16)
+WF_DEV void mr_pass_prime(int p, const cf *src, cf *dst, const cf *wp, int np, int t, int T)
+{
+    if(((np / p) & 7) == 0)
+        mr_pass_prime_jb<8>(p, src, dst, wp, np, t, T);
+    else
+        mr_pass_prime_jb<4>(p, src, dst, wp, np, t, T);
+}
 // first pass (ns == 1: no twiddles): every planned radix
 WF_DEV void mr_pass_first(int R, const cf *src, cf *dst, int np, int t, int T)
 {
@@ -385,12 +424,16 @@ template<class G> WF_DEV bool mr_fetch(const TickArgs &a, int t, const float *x,
 
 // The whole transform.  On entry the np windowed points sit in lds[0 .. np) (natural order); Z[k] is handed to store(k, Z[k]) by
 // the thread that finishes it.  Called by ALL threads of the spectrum (sync is its barrier).
-template<class G, class Sync, class Store> WF_DEV void mr_transform_to(const MrPlan &p, bool process, int np, int t, cf *lds, Sync sync, Store store)
+template<class G, class Sync, class Store> WF_DEV void mr_transform_to(const MrPlan &p, bool process, int np, int t, cf *lds, const cf *wp_lds, Sync sync, Store store)
 {
     constexpr int H = G::M / 2; // second half of the exchange buffer (M >= 2 np)
     sync(); // the fetch has written the first half
-    if(process)
-        mr_pass_first(p.radix[0], lds, lds + H, np, t, G::T);
+    if(process) {
+        if(p.radix[0] > 25) // (uniform) a prime of 29 .. 127: by the definition, its twiddles in LDS at wp_lds
+            mr_pass_prime(p.radix[0], lds, lds + H, wp_lds, np, t, G::T);
+        else
+            mr_pass_first(p.radix[0], lds, lds + H, np, t, G::T);
+    }
     int ns = p.radix[0], cur = 1;
     for(int s = 1; s + 1 < p.passes; ++s) {
         const int R = p.radix[s];
@@ -404,9 +447,9 @@ template<class G, class Sync, class Store> WF_DEV void mr_transform_to(const MrP
     mr_last(p.radix[p.passes - 1], process, lds + cur * H, p.tw + p.tw_off[p.passes - 1], ns, t, sync, store);
 }
 // ... with Z[k] left at ex3_addr<G>(k) of the exchange buffer, visible to every thread of the spectrum on return
-template<class G, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool process, int np, int t, cf *lds, Sync sync)
+template<class G, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool process, int np, int t, cf *lds, const cf *wp_lds, Sync sync)
 {
-    mr_transform_to<G>(p, process, np, t, lds, sync, [lds](int k, cf v) { lds_st2(lds, ex3_addr<G>(k), v); });
+    mr_transform_to<G>(p, process, np, t, lds, wp_lds, sync, [lds](int k, cf v) { lds_st2(lds, ex3_addr<G>(k), v); });
     sync();
 }
 

@@ -133,6 +133,8 @@ struct MrPlan {
     int passes;                 // 0: no plan (Bluestein runs)
     int radix[MR_MAX_PASSES];
     int tw_off[MR_MAX_PASSES];  // pass s >= 1: its twiddles start at tw + tw_off[s]
+    const cf *wp;               // radix[0] a prime above 25 (mr_pass_prime): [radix[0]] W_p^m in device memory (the tick kernel finds it in
+                                // its LDS twiddle area, staged with the other tables; the large-FFT rows kernel copies it there itself)
     const cf *tw;               // per pass [R][Ns]: W_(Ns R)^(k jm), Ns = product of the radices before it (coalesced across a wavefront's butterflies)
 };
 
