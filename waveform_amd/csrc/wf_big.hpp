@@ -587,21 +587,48 @@ __global__ __launch_bounds__(GBig::T, 4) void big_mr_rows_kernel(const TickArgs 
     const cf *wc = a.big_wc + k1 * 8u;
     const cf *twc = a.big_tw + (size_t)k1 * R;
     uint32_t acc = 0;
-    for(uint32_t n2 = (uint32_t)t; n2 < R; n2 += (uint32_t)T) {
-        cf s = cf{0.0f, 0.0f};
-        for(uint32_t c = 0; c < C; ++c) {
-            const uint32_t idx = n2 + R * c, si = start + 2u * idx;
-            const float x0 = x[si & a.ring_mask], x1 = x[(si + 1u) & a.ring_mask];
-            const f2 w = ld2(a.window + 2u * idx);
-            acc |= f32_bits(x0) | f32_bits(x1);
-            const cf u = cf{x0 * w.x, x1 * w.y};
-            s = (k1 == 0) ? cadd(s, u) : cadd(s, cmul(u, wc[c]));
+    if(((start | R) & 1u) == 0u && (start & 3u) == 0u) {
+        // (uniform) the window starts on a 16-byte boundary of the ring and the rows have an even length: two points per
+        // request -- samples, window coefficients and column twiddles as 16-byte vectors
+        for(uint32_t n2 = 2u * (uint32_t)t; n2 < R; n2 += 2u * (uint32_t)T) {
+            cf s0 = cf{0.0f, 0.0f}, s1 = s0;
+            for(uint32_t c = 0; c < C; ++c) {
+                const uint32_t idx = n2 + R * c;
+                const f4 xs = ld4(x + ((start + 2u * idx) & a.ring_mask)), w = ld4(a.window + 2u * idx);
+                acc |= f32_bits(xs.x) | f32_bits(xs.y) | f32_bits(xs.z) | f32_bits(xs.w);
+                const cf u0 = cf{xs.x * w.x, xs.y * w.y}, u1 = cf{xs.z * w.z, xs.w * w.w};
+                if(k1 == 0) {
+                    s0 = cadd(s0, u0);
+                    s1 = cadd(s1, u1);
+                } else {
+                    s0 = cadd(s0, cmul(u0, wc[c]));
+                    s1 = cadd(s1, cmul(u1, wc[c]));
+                }
+            }
+            if(k1 != 0) {
+                const f4 q = ld4(reinterpret_cast<const float *>(twc + n2));
+                s0 = cmul(s0, cf{q.x, q.y});
+                s1 = cmul(s1, cf{q.z, q.w});
+            }
+            lds_st4(lds, (int)n2, s0, s1);
         }
-        if(k1 != 0) {
-            const f2 q = ld2(reinterpret_cast<const float *>(twc + n2));
-            s = cmul(s, cf{q.x, q.y});
+    } else {
+        for(uint32_t n2 = (uint32_t)t; n2 < R; n2 += (uint32_t)T) {
+            cf s = cf{0.0f, 0.0f};
+            for(uint32_t c = 0; c < C; ++c) {
+                const uint32_t idx = n2 + R * c, si = start + 2u * idx;
+                const float x0 = x[si & a.ring_mask], x1 = x[(si + 1u) & a.ring_mask];
+                const f2 w = ld2(a.window + 2u * idx);
+                acc |= f32_bits(x0) | f32_bits(x1);
+                const cf u = cf{x0 * w.x, x1 * w.y};
+                s = (k1 == 0) ? cadd(s, u) : cadd(s, cmul(u, wc[c]));
+            }
+            if(k1 != 0) {
+                const f2 q = ld2(reinterpret_cast<const float *>(twc + n2));
+                s = cmul(s, cf{q.x, q.y});
+            }
+            lds_st2(lds, (int)n2, s);
         }
-        lds_st2(lds, (int)n2, s);
     }
     // x != 0.0f for any sample of the window (reference :63-72): row 0 has seen all of it
     if(k1 == 0 && __any((acc & 0x7fffffffu) != 0u) && (t & 63) == 0)

@@ -402,6 +402,28 @@ template<class G> WF_DEV bool mr_fetch(const TickArgs &a, int t, const float *x,
     constexpr int T = G::T, P = G::P;
     const uint32_t np = a.blu_n >> 1; // <= M / 2 = T P / 2
     uint32_t acc = 0;
+    if((start & 3u) == 0u) {
+        // (uniform per spectrum) the window starts on a 16-byte boundary of the ring: two points per request -- samples and window
+        // coefficients as 16-byte vectors, a group never straddles the ring's wrap.  np is a multiple of 8.
+        constexpr int IT = P / 4; // 2 T IT = M / 2 >= np
+        f4 v[IT], w[IT];
+        WF_UNROLL
+        for(int i = 0; i < IT; ++i) {
+            const uint32_t idx = 2u * (uint32_t)(t + T * i);
+            const uint32_t at = idx < np ? idx : 0u;
+            v[i] = ld4(x + ((start + 2u * at) & a.ring_mask));
+            w[i] = ld4(a.window + 2u * at);
+        }
+        WF_UNROLL
+        for(int i = 0; i < IT; ++i) {
+            const uint32_t idx = 2u * (uint32_t)(t + T * i);
+            if(idx < np) {
+                acc |= f32_bits(v[i].x) | f32_bits(v[i].y) | f32_bits(v[i].z) | f32_bits(v[i].w);
+                lds_st4(lds, (int)idx, cf{v[i].x * w[i].x, v[i].y * w[i].y}, cf{v[i].z * w[i].z, v[i].w * w[i].w});
+            }
+        }
+        return (acc & 0x7fffffffu) != 0;
+    }
     f2 v[P / 2], w[P / 2];
     WF_UNROLL
     for(int i = 0; i < P / 2; ++i) {
