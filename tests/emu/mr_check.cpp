@@ -42,7 +42,7 @@ static unsigned container_threads(unsigned n) // threads of the geometry the Blu
     unsigned L = 512;
     while(L < n - 1)
         L <<= 1;
-    switch(2 * L) { case 1024: return 64; case 2048: return 64; case 4096: return 128; case 8192: return 256; case 16384: return 512; default: return 1024; }
+    switch(2 * L) { case 1024: return 64; case 2048: return 64; case 4096: return 128; case 8192: return 256; case 16384: return 512; default: return 1024; } // (GBig: the power-of-two kernel of that container runs on 512 threads of 32 points)
 }
 
 int main()

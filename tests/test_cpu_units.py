@@ -226,7 +226,9 @@ def test_power_of_two_kernels_do_not_spill():
             seen += 1
             assert scratch == 0, f"{name} uses {scratch} bytes of scratch per lane"
             # four waves per SIMD: one VGPR over 128 cost N = 2048 a quarter of its occupancy (and 5-15 %) in round 2
-            assert vgprs <= 128, f"{name} needs {vgprs} VGPRs: three waves per SIMD instead of four"
+            # (N = 32768: 512 threads of 32 points, one workgroup per CU by its LDS = two waves per SIMD with 256 registers each)
+            limit = 256 if "GeomILi32768ELi512E" in name else 128
+            assert vgprs <= limit, f"{name} needs {vgprs} VGPRs (limit {limit}): a wave per SIMD fewer"
     assert seen >= 12 and seen_mixed >= 6
 
 

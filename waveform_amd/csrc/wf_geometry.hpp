@@ -1,6 +1,6 @@
 // wf_geometry.hpp -- the FFT decompositions the library ships, one per supported FFT size.
-// T threads per spectrum (1, 1, 2, 4, 8 wavefronts for N = 1024 ... 16384); every thread owns
-// P = N/(2T) complex points (4, 8 or 16); pass 1 fetches 16-byte vectors where the radices allow (8-byte ones at 512 and 32768).  Measured alternatives with 32 points per
+// T threads per spectrum (1, 1, 2, 4, 8, 8 wavefronts for N = 1024 ... 32768); every thread owns
+// P = N/(2T) complex points (4, 8 or 16; 32 at N = 32768, where a workgroup has a CU to itself anyway); pass 1 fetches 16-byte vectors where the radices allow (8-byte ones at 512 and 32768).  Measured alternatives with 32 points per
 // thread (N = 4096 on one wavefront, 8192 on two, 16384 on four) held 156-168 VGPRs and ran 15-20 % slower.
 #pragma once
 #include "wf_fft_core.hpp"
@@ -18,8 +18,12 @@ using G8192 = Geom<8192, 256, 8, 16, 32>;     // four wavefronts; radix 8 first 
 // (measured alternatives in steady state: 2048 as 8x8x16 +-0, 4096 as 8x32x8 -2.5 %, 8192 as 8x32x16 -2 %)
 using G16384 = Geom<16384, 512, 8, 32, 32>;   // eight wavefronts; radix 8 first (16-byte pass-1 vectors: 51.7 -> 53.5 % over
                                               // 16x16x32), both radix-32 passes shared by thread pairs
-using G32768 = Geom<32768, 1024, 16, 32, 32>; // sixteen wavefronts = one workgroup per spectrum (132 KB of LDS); both radix-32
-                                              // passes are shared by thread pairs.  The reference's "large FFT" range.
+#ifndef WF_G32768_T
+#define WF_G32768_T 512 // (1024 threads of 16 points: 0.54 / 0.48 of the HBM peak at 512 / 2048 streams where 512 threads of 32 reach 0.56 / 0.53)
+#endif
+using G32768 = Geom<32768, WF_G32768_T, 16, 32, 32>; // eight wavefronts of 32 points per thread = one workgroup per spectrum (132 KB of LDS: one per CU,
+                                              // two waves per SIMD with 256 registers each -- 177-199 used, no scratch); both radix-32 passes
+                                              // whole in a thread.  The reference's "large FFT" range.
 
 // calls f(G{}) for the geometry of fft_size n; returns false for unsupported sizes
 template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)

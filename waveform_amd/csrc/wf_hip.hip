@@ -1178,12 +1178,21 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             lds_floats = (size_t)G::LDS_CF * 2;
             threads = G::T;
         });
+        // the kernels that run on wf::GBig's 1024 threads of 16 points whatever the power-of-two kernel of that size does:
+        // big_outputs_kernel, and the Bluestein / mixed-radix instantiations of the largest container (setup_launch_blu)
+        const bool on_gbig = own_kernel || (h->blu && h->geom_n == 32768u);
+        if(on_gbig) {
+            lds_floats = (size_t)wf::GBig::LDS_CF * 2;
+            threads = wf::GBig::T;
+        }
         int lpb = 1;
         while(lpb < 64 && (uint32_t)(threads / (lpb * 2)) >= h->num_bars)
             lpb *= 2;
         h->bar_lpb = lpb;
         int points = 16;
         wf::dispatch_geometry(ext ? 32768u : h->geom_n, [&](auto g) { points = decltype(g)::P; });
+        if(on_gbig)
+            points = wf::GBig::P;
         const int kmax = threads <= 64 ? 16 : 8; // wf::OutVals<G>::KMAX
         h->curve = !cfg->bars && cfg->curve;
         if(h->curve) {
@@ -1337,10 +1346,14 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
 #endif
         if(h->blu) {
             if constexpr(G::N >= 32768) {
+                // (the Bluestein and mixed-radix instantiations of this container keep 1024 threads of 16 points: a mixed-radix
+                // plan's last pass has one butterfly per thread at most, and 39 sizes have no plan on 512 threads)
+                using GB = wf::GBig;
+                h->waves_per_spectrum = GB::T / 64;
                 if(want_split)
-                    setup_rc = setup_launch_blu<G, 1, true>(h);
+                    setup_rc = setup_launch_blu<GB, 1, true>(h);
                 else if(cfg->capture_channels == 1)
-                    setup_rc = setup_launch_blu<G, 1, false>(h);
+                    setup_rc = setup_launch_blu<GB, 1, false>(h);
                 else
                     setup_rc = fail(h, WF_HIP_ERR_RUNTIME, "fft_size %u: no launch plan", cfg->fft_size);
             } else if constexpr(G::T >= 256)

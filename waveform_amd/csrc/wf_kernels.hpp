@@ -98,7 +98,7 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
                        // (profiles/r03_occupancy5_isa.txt): the N = 4096 kernel then keeps 72 B per lane in scratch, the 16384 one 48 B --
                        // and a fifth workgroup per CU would also need its LDS down from 36.9 KB to 32 KB
 #endif
-#define WF_WAVES_PER_SIMD(G) ((G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 4) ? WF_WPS_512 : (G::P <= 8) ? WF_WPS_SMALL : WF_WPS_LARGE)
+#define WF_WAVES_PER_SIMD(G) ((G::P > 16) ? 2 : (G::P > 8 && G::T <= 64) ? WF_WPS_2048 : (G::P <= 4) ? WF_WPS_512 : (G::P <= 8) ? WF_WPS_SMALL : WF_WPS_LARGE)
 
 #ifdef WF_PHASE_TIMING
 #define WF_STAMP(i)                                                                      \

@@ -382,7 +382,7 @@ WF_DEV float mag2(float xr, float xi)
 #define WF_PREFETCH_STATE -1
 #endif
 template<class G> struct Policy {
-    static_assert(G::P <= 16, "the phase functions keep a thread's operands in registers: at most 16 points per thread");
+    static_assert(G::P <= 32, "the phase functions keep a thread's operands in registers: at most 32 points per thread (two waves per SIMD)");
     // 1: state + slope into registers right after pass 1; 2: their lines only "touched" there (into L2), loaded in P4;
     // 0: everything requested at the start of P4, consumed after the real split.  Round 1 found 1 / 2 best (one wavefront /
     // several); with the lanes and the non-temporal row stores of round 2 the early requests only lengthen the fetch
