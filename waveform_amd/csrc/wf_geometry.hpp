@@ -1,7 +1,8 @@
 // wf_geometry.hpp -- the FFT decompositions the library ships, one per supported FFT size.
 // T threads per spectrum (1, 1, 2, 4, 8, 8 wavefronts for N = 1024 ... 32768); every thread owns
 // P = N/(2T) complex points (4, 8 or 16; 32 at N = 32768, where a workgroup has a CU to itself anyway); pass 1 fetches 16-byte vectors where the radices allow (8-byte ones at 512 and 32768).  Measured alternatives with 32 points per
-// thread (N = 4096 on one wavefront, 8192 on two, 16384 on four) held 156-168 VGPRs and ran 15-20 % slower.
+// thread (N = 4096 on one wavefront, 8192 on two, 16384 on four) held 156-168 VGPRs and ran 15-20 % slower (16384 as 16x16x32 on
+// four wavefronts again at the end of round 3: +-0 plain, -2 % with the bars of BASELINE configs[3]).
 #pragma once
 #include "wf_fft_core.hpp"
 
