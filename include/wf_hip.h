@@ -30,9 +30,11 @@
  *                        capture_audio's RMS part + sync_rms_buffer + update_input_rms
  *                        (src/source.cpp:1842-1871, :810-835; src/source_generic.cpp:392-403)
  * FFT sizes: every multiple of 16 from 128 to 65536, the reference's own range with "enable large FFT" (src/source.cpp:349,
- * :359-363, :562-565).  Powers of two up to 32768 and, by Bluestein's algorithm, the other sizes up to 16384 run inside one
- * fused kernel; 65536 and the other sizes above 16384 take their transform through device memory in two steps (wf_big.hpp:
- * the compatibility path, 2-15 % of the HBM roofline).  Anything else -> WF_HIP_ERR_UNSUPPORTED.
+ * :359-363, :562-565).  Powers of two up to 32768 and the other sizes up to 16384 -- as a mixed-radix transform where the
+ * size has small prime factors and at most one prime factor of up to 127 (the automatic sizes, 114 of the slider's 120
+ * positions that are not powers of two), by Bluestein's algorithm otherwise -- run inside one fused kernel; 65536 and the other
+ * sizes above 16384 take their transform through device memory in two steps (wf_big.hpp: 1-33 % of the HBM roofline).
+ * Anything else -> WF_HIP_ERR_UNSUPPORTED.
  *
  * Waveform display.  A handle created from a configuration with cfg.waveform != 0 is a *waveform batch*: wf_hip_tick runs
  * WAVSource*::tick_waveform (src/source_generic.cpp:271-390) for every stream -- a history of cfg.width dBFS points per
