@@ -643,8 +643,9 @@ __global__ __launch_bounds__(GBig::T, 4) void big_mr_rows_kernel(const TickArgs 
 }
 
 // ---- render-time outputs from the finished rows --------------------------------------------------------------------
-// One workgroup per displayed row: the row is parked in LDS, then bars (one wavefront per bar over the flat
-// coefficient tables, BarArgs) or curve points (curve_row_stream); the Gaussian filter stages its inputs behind the row.
+// One workgroup per displayed row: bars (one wavefront per bar over the flat coefficient tables, BarArgs, the bins read from the
+// row in device memory) or curve points (the row parked in LDS, curve_row_stream); the Gaussian filter stages its inputs in LDS
+// (bars: at its start; curve: behind the row).
 __global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
 {
     using G = GBig;
@@ -656,16 +657,20 @@ __global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
     const uint32_t stream = a.stream_base + blockIdx.x / b.disp_ch, r = blockIdx.x % b.disp_ch;
     const int MO = (int)a.row_bins;
     const float *row = a.decibels + ((size_t)stream * a.out_ch + r) * MO;
-    for(int i = 4 * t; i < MO; i += 4 * T)
-        st4(dbl + i, ld4(row + i));
-    if(t == 0)
-        dbl[MO] = dbl[MO + 1] = 0.0f; // the Catmull-Rom taps of the last points (curve_row_stream)
-    __syncthreads();
     float *out_row = b.out + ((size_t)stream * b.disp_ch + r) * b.num_bars;
     if(b.curve) {
+        // a curve point takes its taps from anywhere in the row: the row is parked in LDS first
+        for(int i = 4 * t; i < MO; i += 4 * T)
+            st4(dbl + i, ld4(row + i));
+        if(t == 0)
+            dbl[MO] = dbl[MO + 1] = 0.0f; // the Catmull-Rom taps of the last points (curve_row_stream)
+        __syncthreads();
         curve_row_stream<G>(b, true, dbl, dbl, t, out_row, nullptr, [] { __syncthreads(); });
         return;
     }
+    // bars: every bin is read once, by the wavefront of its bar, straight from the row (the tick kernel or the epilogue stored it
+    // a moment ago: L2 / Infinity Cache) -- no parked row, so the workgroup needs LDS only for the filter's staging and many of
+    // them share a CU (parked, a 32768-bin row was 128 KB: one workgroup per CU, 67 us for 512 rows)
     const int n = b.num_bars;
     const bool filtered = b.gauss_radius > 0;
     const int pad = b.gauss_radius - 1, size = 2 * b.gauss_radius - 1;
@@ -680,21 +685,45 @@ __global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
             wl[i] = b.gauss[i];
     }
     const int wave = t >> 6, lane = t & 63;
-    for(int bar = wave; bar < n; bar += T / 64) {
-        const int e0 = b.off[bar], e1 = b.off[bar + 1];
+    float *part = filtered ? wl + size : dbl; // [num_tasks] partial sums, behind the filter's staging
+    for(int task = wave; task < b.big_num_tasks; task += T / 64) {
+        const int e0 = b.big_task[3 * task + 1], e1 = b.big_task[3 * task + 2];
+        // eight of a lane's (index, coefficient, bin) triples in flight at a time instead of one dependent chain per entry
         float acc = 0.0f;
-        for(int e = e0 + lane; e < e1; e += 64)
-            acc = fmaf(dbl[b.bin[e]], b.coef[e], acc);
+        int e = e0 + lane;
+        for(; e + 7 * 64 < e1; e += 8 * 64) {
+            int bi[8];
+            float cv[8], rv[8];
+#pragma unroll
+            for(int i = 0; i < 8; ++i) {
+                bi[i] = b.bin[e + 64 * i];
+                cv[i] = b.coef[e + 64 * i];
+            }
+#pragma unroll
+            for(int i = 0; i < 8; ++i)
+                rv[i] = row[bi[i]];
+#pragma unroll
+            for(int i = 0; i < 8; ++i)
+                acc = fmaf(rv[i], cv[i], acc);
+        }
+        for(; e < e1; e += 64)
+            acc = fmaf(row[b.bin[e]], b.coef[e], acc);
 #pragma unroll
         for(int m = 32; m >= 1; m >>= 1)
             acc += __shfl_xor(acc, m, 64);
-        if(lane == 0) {
-            const float v = acc / (float)b.count[bar];
-            if(filtered)
-                vp[pad + bar] = v;
-            else
-                emit_output(b, bar, v, out_row, nullptr);
-        }
+        if(lane == 0)
+            part[task] = acc;
+    }
+    __syncthreads();
+    for(int bar = t; bar < n; bar += T) { // the tasks of a bar, added in their order
+        float acc = 0.0f;
+        for(int task = b.big_bar_task[bar]; task < b.big_bar_task[bar + 1]; ++task)
+            acc += part[task];
+        const float v = acc / (float)b.count[bar];
+        if(filtered)
+            vp[pad + bar] = v;
+        else
+            emit_output(b, bar, v, out_row, nullptr);
     }
     if(filtered) {
         __syncthreads();

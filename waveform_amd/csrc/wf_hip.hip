@@ -105,6 +105,8 @@ struct wf_hip {
     wf::cf *d_big_v = nullptr, *d_big_z = nullptr, *d_big_tw = nullptr, *d_big_tws = nullptr;
     uint32_t *d_big_nz = nullptr;
     size_t big_out_lds = 0;          // dynamic LDS of big_outputs_kernel
+    int *d_big_task = nullptr, *d_big_bar_task = nullptr; // BarArgs::big_task / big_bar_task
+    int big_num_tasks = 0;
     float *d_bars = nullptr;
     wf::VertexTables vtab;           // cfg.vertices: the vertex fill behind every tick
     wf::f4 *d_verts = nullptr;
@@ -648,6 +650,9 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.bin = h->d_bar_bin;
         a.bar.off = h->d_bar_off;
         a.bar.count = h->d_band_widths;
+        a.bar.big_task = h->d_big_task;
+        a.bar.big_bar_task = h->d_big_bar_task;
+        a.bar.big_num_tasks = h->big_num_tasks;
         a.bar.chunk = h->d_bar_chunk;
         a.bar.num_chunks = h->bar_chunks;
         a.bar.lane_coef = h->d_lane_coef;
@@ -1240,8 +1245,34 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         if(own_kernel) {
             // big_outputs_kernel: the whole row in LDS, two guard zeros, then the filter's staging
             const size_t staged = h->tab.gauss_radius > 0 ? (size_t)h->num_bars + 2 * (size_t)(h->tab.gauss_radius - 1) + h->tab.gauss.size() : 0;
-            h->bar_stage_off = (int)h->M + 2;
-            h->big_out_lds = (((size_t)h->M + 2 + staged) * sizeof(float) + 15) & ~(size_t)15;
+            // (bars read their bins from the row in device memory: only the staging lives in LDS; a curve parks the row first)
+            const size_t parked = h->curve ? (size_t)h->M + 2 : 0;
+            h->bar_stage_off = (int)parked;
+            // bars: the entries in tasks of at most 2048 (a multiple of 64), one wavefront each; their sums meet in LDS
+            h->big_num_tasks = 0;
+            if(!h->curve && !h->tab.bar_off.empty()) {
+                std::vector<int> task, bar_task(h->tab.bar_off.size(), 0);
+                for(size_t bq = 0; bq + 1 < h->tab.bar_off.size(); ++bq) {
+                    bar_task[bq] = (int)(task.size() / 3);
+                    const int e0 = h->tab.bar_off[bq], e1 = h->tab.bar_off[bq + 1];
+                    const int parts = std::max(1, (e1 - e0 + 2047) / 2048);
+                    const int per = (((e1 - e0 + parts - 1) / parts) + 63) & ~63;
+                    for(int q = 0; q < parts; ++q) {
+                        const int lo = std::min(e0 + q * per, e1), hi = std::min(lo + per, e1);
+                        if(q == 0 || lo < hi) {
+                            task.push_back((int)bq);
+                            task.push_back(lo);
+                            task.push_back(hi);
+                        }
+                    }
+                }
+                bar_task.back() = (int)(task.size() / 3);
+                h->big_num_tasks = (int)(task.size() / 3);
+                WF_PLAN_TRY(upload(h, &h->d_big_task, task));
+                WF_PLAN_TRY(upload(h, &h->d_big_bar_task, bar_task));
+                WF_PLAN_HIP(hipStreamSynchronize(h->stream));
+            }
+            h->big_out_lds = std::max<size_t>(((parked + staged + (size_t)h->big_num_tasks) * sizeof(float) + 15) & ~(size_t)15, 16);
             if(h->big_out_lds > 160u * 1024u)
                 return (fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u with filter_mode gauss over %u outputs: row + staging exceed a CU's LDS", h->N,
                                  h->num_bars));
