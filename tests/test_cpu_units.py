@@ -233,8 +233,9 @@ def test_power_of_two_kernels_do_not_spill():
 
 
 def test_compatibility_path_kernels_stay_near_their_register_budget(tmp_path):
-    """The Bluestein instantiations (two transforms and a chirped fetch of six registers per point in one kernel) do not fit
-    128 registers: they keep 24-68 B per lane in scratch.  Tolerated on that path -- but bounded
+    """The Bluestein instantiations (two transforms and a chirped fetch of six registers per point in one kernel) do not all fit
+    128 registers: up to 28 B per lane in scratch (none on the 16384- and 32768-sample geometries since the display's per-thread
+    words are fetched where they are used).  Tolerated on that path -- but bounded
     here, so that a change that pushes a kernel into a kilobyte of scratch (the fused 65536 kernel that was abandoned had 1-2 KB)
     is seen.  The 65536-sample rows kernel (column step folded into its fetch) spilled 196 B per lane until its sums were
     parked in the exchange buffer -- with one workgroup per CU that was 420 MB of device-memory traffic per launch: zero now."""
@@ -266,7 +267,7 @@ template __global__ void wf::big_epilogue_kernel<3>(wf::TickArgs);
             seen[name] = int(m.group(1))
     assert len(seen) == 6, seen
     for name, scratch in seen.items():
-        limit = 0 if "big_" in name else 256
+        limit = 0 if ("big_" in name or "GeomILi16384ELi512E" in name) else 32
         assert scratch <= limit, f"{name}: {scratch} B of scratch per lane (limit {limit})"
 
 

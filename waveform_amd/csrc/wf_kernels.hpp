@@ -248,7 +248,11 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     // the workgroup's copy of the pass-2 twiddles: LDS-DMA (no staging registers), requested behind the window so that it
     // costs no round trip of its own; complete at the barrier below
     lds_dma_copy<G::R2 * G::R3 * (int)sizeof(cf)>(a.tw2, tw2_lds, wave_in_block, T * SPW / 64, lane);
-    const BarPre bar_pre = bars_preload<G>(a.bar, t);
+    // (the Bluestein instantiations -- not the mixed-radix ones -- are at the register cap through two transforms: they fetch these
+    // few words where they are used instead of holding them from here)
+    BarPre bar_pre_early{0, 0, 1, 0, 0, 0, -1};
+    if constexpr(!(BLU && !MR))
+        bar_pre_early = bars_preload<G>(a.bar, t);
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
     bool wave_below = true;
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
                 curve_row<G>(bar_args, have_row, dbl, t, ov);
             else
                 pending = bars_reduce_row<G>(
-                    bar_args, bar_pre, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
+                    bar_args, (BLU && !MR) ? bars_preload<G>(a.bar, t) : bar_pre_early, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
                     [](float v, int m) { return v + __shfl_xor(v, m, 64); });
             if(pending)
                 outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
