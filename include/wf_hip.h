@@ -333,6 +333,10 @@ uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags);
  * (hipMemcpyPeerAsync, transport "peer"); WF_HIP_MULTI_TRANSPORT=rccl|peer forces one.  The gather is asynchronous and
  * double-buffered: it is enqueued on a side stream of every device behind the ticks issued so far, the next tick runs
  * meanwhile, and a result stays valid until the second-next gather.
+ * A gather that fails on one device (the others may have their half in flight) takes the exchange out of service for the
+ * group: the failing call returns the error, the RCCL communicators are aborted (ncclCommAbort -- no device keeps waiting for
+ * a rank that never joined), every later gather returns WF_HIP_ERR_RUNTIME, and everything else -- ticks, reads,
+ * wf_hip_multi_sync, wf_hip_multi_destroy -- keeps working.
  * A wf_hip_multi is used by one thread at a time, like a handle.  Shard handles may be used directly (shard-local stream
  * indices) between multi calls -- every wf_hip_* entry point works on them. */
 typedef struct wf_hip_multi wf_hip_multi;
@@ -381,6 +385,11 @@ int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32
  * if that much audio had been captured before what the rings hold: tests reach the 2^32-sample wrap-around (a day at
  * 48 kHz; the reference's deques have no such counter) without feeding a day of audio. */
 int wf_hip_debug_age(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames);
+/* Shard `shard` of the group reports a failure in its half of the next gather (wf_hip_multi_allgather_bars or a gathering
+ * wf_hip_multi_time_ticks) before it enqueues anything -- what a failed wait or copy on one device looks like to the others,
+ * which have their collective / copies in flight by then.  Tests use it to check that the group survives: the call returns
+ * the error, the communicators are aborted, later gathers are refused, ticks, reads, sync and destroy go on working. */
+int wf_hip_multi_debug_fail_next_gather(wf_hip_multi *m, uint32_t shard);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ def _check(name, backend):
         got = np.array([r["rms"] for r in recs], np.float64)
         assert np.all(np.abs(got - z["rms"]) <= 1e-5 * np.abs(z["rms"]) + 1e-9), f"{name}: m_input_rms {got} vs reference {z['rms']}"
     for t, r in scenarios.recorded(recs, sc["record"]):
-        assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels")
+        assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels", deep=True)
         if f"bars_{t}" in z.files:
             got, want = r["bars"], z[f"bars_{t}"]
             assert got is not None
@@ -177,7 +177,7 @@ def test_reference_plugin_with_batched_hip_tick(name):
         got = np.array([r["rms"] for r in recs], np.float64)
         assert np.all(np.abs(got - z["rms"]) <= 1e-5 * np.abs(z["rms"]) + 1e-9), f"{name}: m_input_rms {got} vs reference {z['rms']} (one frame late)"
     for t, r in scenarios.recorded(recs, sc["record"]):
-        assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels, read one frame later")
+        assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels, read one frame later", deep=True)
         if f"bars_{t}" in z.files:
             err = np.abs(r["bars"].astype(np.float64) - z[f"bars_{t}"])
             assert np.all(err <= 1e-5 * np.abs(z[f"bars_{t}"]) + 2e-3), f"{name} tick {t} bars: max err {err.max():.3e} px"
@@ -398,7 +398,7 @@ def test_sixty_four_sources_share_one_batch():
             got = s.observe()
             if want_prev[i] is not None:
                 assert got["silent"] == want_prev[i]["silent"], f"source {i} frame {f}"
-                assert_db_close(got["db"], want_prev[i]["db"], f"source {i} frame {f}: row of the previous frame{' (hidden)' if hidden else ''}")
+                assert_db_close(got["db"], want_prev[i]["db"], f"source {i} frame {f}: row of the previous frame{' (hidden)' if hidden else ''}", deep=True)
             want_prev[i] = o.observe()
     assert all(s.src.using_hip for s in srcs) and wfref.hip_fallback_ticks() == before
     del srcs

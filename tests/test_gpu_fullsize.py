@@ -44,31 +44,64 @@ def _oracle_ticks(cfg, stream_ids, ticks, hop, keep, bars=False):
     return np.stack(rows), (np.stack(bar_rows) if bars else None)
 
 
+# cfg3's checked streams: the first and last 32 of the batch, the 32 around the boundary between the
+# two concurrent launches wf_hip_tick issues ("lanes": streams [0, 2048) and [2048, 4096)), and one block in the middle of each
+CFG3_BLOCKS = ((0, 32), (1008, 32), (2032, 32), (3056, 32), (4064, 32))
+
+
 def test_cfg3_full_batch_spot_checks_and_determinism():
     """configs[2]: 4096 stereo streams, FFT 4096, EMA + slope.  Device-generated audio (wf_synth) for every stream; 16 warm-up
-    ticks (the EMA settles) + 8 checked ticks, the first and last 32 streams of the batch against the oracle on every
-    checked tick; two identical batches must agree bit for bit."""
+    ticks (the EMA settles) + 8 checked ticks.  Against the oracle on every checked tick: the first and last 32 streams of the
+    batch, streams 2032-2063 -- the batch is ticked as two concurrent launches split at stream 2048 --
+    and a block in the middle of either launch; two identical batches must agree bit for bit."""
     cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0)
     streams, warm, checked, hop = 4096, 16, 8, 800
     ticks = warm + checked
-    ids = list(range(32)) + list(range(streams - 32, streams))
+    ids = [s for first, n in CFG3_BLOCKS for s in range(first, first + n)]
     res = []
     for rep in range(2):
         got = []
         with wf.SpectrumBatch(cfg, streams, ring_frames=4096 + hop * (ticks + 1)) as b:
+            assert b.launches_per_tick() == 2, "the lane boundary this test straddles"
             b.push_synth(SEED, 0, hop * ticks)
             for t in range(ticks):
                 b.tick(delay_frames=hop * (ticks - 1 - t))
                 if t >= warm:
-                    got.append(np.concatenate([b.decibels(0, 32), b.decibels(streams - 32, 32)]))
+                    got.append(np.concatenate([b.decibels(first, n) for first, n in CFG3_BLOCKS]))
             full = b.decibels()
         res.append((np.stack(got, axis=1), full))
     assert np.array_equal(res[0][1], res[1][1]), "two identical runs differ: the kernel is not deterministic"
     assert np.array_equal(res[0][0], res[1][0])
     want, _ = _oracle_ticks(cfg, ids, ticks, hop, checked)
     for k in range(checked):
-        assert_db_close(res[0][0][:, k], want[:, k], f"cfg3 full batch vs oracle, tick {warm + k} (first/last 32 streams)")
+        assert_db_close(res[0][0][:, k], want[:, k], f"cfg3 full batch vs oracle, tick {warm + k} (first/last 32 streams, lane boundary, mid-lane)", deep=True)
     assert np.all(np.isfinite(res[0][1]))
+
+
+def test_cfg3_whole_batch_equals_small_handles():
+    """Every one of cfg3's 4096 streams, not a sample: the whole batch after 24 ticks must equal, bit for bit, the same streams
+    replayed 64 at a time through 64-stream handles (one launch, no lanes, another workgroup count) -- and a 64-stream handle is
+    checked against the oracle stream by stream (all 64 of the block that straddles the large batch's lane boundary)."""
+    cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0)
+    streams, ticks, hop, part = 4096, 24, 800, 64
+    with wf.SpectrumBatch(cfg, streams, ring_frames=4096 + hop * (ticks + 1)) as b:
+        b.push_synth(SEED, 0, hop * ticks)
+        for t in range(ticks):
+            b.tick(delay_frames=hop * (ticks - 1 - t))
+        full, full_state = b.decibels(), b.tsmooth()
+    checked_base = 2048 - part // 2  # streams 2016 .. 2079
+    for base in list(range(0, streams, part)) + [checked_base]:
+        with wf.SpectrumBatch(cfg, part, ring_frames=4096 + hop * (ticks + 1)) as s:
+            assert s.launches_per_tick() == 1
+            s.push_synth(SEED, 0, hop * ticks, stream_id0=base)
+            for t in range(ticks):
+                s.tick(delay_frames=hop * (ticks - 1 - t))
+            rows, state = s.decibels(), s.tsmooth()
+        assert np.array_equal(rows, full[base:base + part]), f"streams {base}..{base + part - 1}: rows of the 4096-stream batch differ from a 64-stream handle"
+        assert np.array_equal(state, full_state[base:base + part]), f"streams {base}..{base + part - 1}: smoothing state differs"
+        if base == checked_base:
+            want, _ = _oracle_rows(cfg, range(base, base + part), ticks, hop)
+            assert_db_close(rows, want, f"64-stream handle, streams {base}..{base + part - 1} vs oracle", deep=True)
 
 
 def test_cfg2_256_consecutive_frames():
@@ -87,7 +120,7 @@ def test_cfg2_256_consecutive_frames():
             b.tick()
             o.feed_and_tick(blk)
             got = b.decibels()[0]
-            assert_db_close(got, o.decibels(), f"cfg2 frame {t}")
+            assert_db_close(got, o.decibels(), f"cfg2 frame {t}", deep=True)
             seq.append(got)
     seq = np.stack(seq)
     with wf.SpectrumBatch(cfg, frames, ring_frames=2048 + hop * (frames + 1)) as b:
@@ -117,6 +150,43 @@ def test_cfg5_per_gpu_shape_bars_only():
     _, want = _oracle_ticks(cfg, ids, ticks, hop, checked, bars=True)
     err = np.abs(got.astype(np.float64) - want)
     assert np.all(err <= 1e-5 * np.abs(want) + 2e-3), f"cfg5 per-GPU shape bars: max err {err.max():.3e} px"
+
+
+def test_cfg5_full_size_65536_streams_in_eight_shards():
+    """BASELINE configs[4] at its stated size: 65536 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, sharded
+    contiguously over eight devices (wf_hip_multi_*: on a box with fewer, the shards cycle over what it has -- eight shards of
+    8192 streams on the one MI355X of a gpurun box: 6 GB of rings, state and rows), bars-only ticks, the all-gather of the bar
+    heights after EVERY tick.  16 warm-up + 8 checked ticks; on every checked tick the first and last 32 streams OF EVERY SHARD
+    against the oracle ("first + last 32 streams per GPU"), and every device index's gathered copy must
+    hold the same bits, which must be the shards' own bars in global stream order."""
+    cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    streams, shards, warm, checked, hop = 65536, 8, 16, 8, 800
+    ticks = warm + checked
+    devices = [i % wf.device_count() for i in range(shards)]
+    per = streams // shards
+    blocks = [(i * per + off, 32) for i in range(shards) for off in (0, per - 32)]
+    ids = [s for first, n in blocks for s in range(first, first + n)]
+    got = []
+    with wf.MultiBatch(cfg, streams, devices) as m:
+        assert m.n_devices == shards and [(s[2], s[3]) for s in m.shards] == [(i * per, per) for i in range(shards)]
+        assert m.transport == ("rccl" if len(set(devices)) == shards else "peer")
+        for t in range(ticks):
+            m.push_synth(SEED, t * hop, hop)
+            m.tick(flags=wf.TICK_NO_DECIBELS)
+            m.allgather_bars()
+            if t >= warm:
+                g0 = m.gathered(0)
+                for i in range(1, shards):
+                    assert np.array_equal(m.gathered(i), g0), f"tick {t}: device index {i} holds other gathered bars than index 0"
+                assert np.array_equal(g0, m.bars()), f"tick {t}: the gathered bars are not the shards' bars in stream order"
+                got.append(g0[ids])
+        assert m.bars().shape == (streams, 2, 26)
+        assert m.algorithmic_bytes_per_tick(wf.TICK_NO_DECIBELS) == streams * 2 * (4 * 4096 + 8 * 2048 + 4 * 26)
+    got = np.stack(got, axis=1)
+    assert np.all(np.isfinite(got))
+    _, want = _oracle_ticks(cfg, ids, ticks, hop, checked, bars=True)
+    err = np.abs(got.astype(np.float64) - want)
+    assert np.all(err <= 1e-5 * np.abs(want) + 2e-3), f"cfg5 full size, bars of the first / last 32 streams of every shard: max err {err.max():.3e} px"
 
 
 def test_bars_gather_world1_and_self_launching_bench():
@@ -229,7 +299,7 @@ def test_cfg4_full_batch_bars():
     assert res[0][3].shape == (streams, 2, 26) and np.all(np.isfinite(res[0][3])) and np.all(np.isfinite(res[0][2]))
     want, wantb = _oracle_ticks(cfg, ids, ticks, hop, checked, bars=True)
     for k in range(checked):
-        assert_db_close(res[0][0][:, k], want[:, k], f"cfg4 full batch rows vs oracle, tick {warm + k} (first/last 32 streams)")
+        assert_db_close(res[0][0][:, k], want[:, k], f"cfg4 full batch rows vs oracle, tick {warm + k} (first/last 32 streams)", deep=True)
         err = np.abs(res[0][1][:, k].astype(np.float64) - wantb[:, k])
         assert np.all(err <= 1e-5 * np.abs(wantb[:, k]) + 2e-3), f"cfg4 bars, tick {warm + k}: max err {err.max():.3e} px"
 
@@ -310,7 +380,7 @@ def test_delay_frames_is_the_av_sync_window():
         o = restate.OracleSource(cfg)
         for t in range(ticks):
             o.feed_and_tick(audio[s][:, t * hop:(t + 1) * hop])
-            assert_db_close(got[t][s], o.decibels(), f"delay tick {t} stream {s}")
+            assert_db_close(got[t][s], o.decibels(), f"delay tick {t} stream {s}", deep=True)
 
 
 def test_errors_are_reported_not_thrown():
@@ -488,7 +558,7 @@ def test_starved_tick_in_the_middle_of_a_mono_mixdown(n):
                 lg, lw = 10.0 ** (got[0][:1].astype(np.float64) / 20), 10.0 ** (want.astype(np.float64) / 20)
                 assert np.all(np.abs(lg - lw) <= 1e-3 + 1e-5 * lw), f"N={n} tick {t} (starved): max {np.abs(lg - lw).max():.3e} in the mixed sum"
             else:
-                assert_db_close(got[0][:1], want, f"N={n} tick {t}")
+                assert_db_close(got[0][:1], want, f"N={n} tick {t}", deep=True)
 
 
 @pytest.mark.parametrize("n,loud,quiet", [(4096, 2000.0, 1e-24), (65536, 200.0, 1e-24), (800, 2000.0, 1e-24), (30000, 8.0, 1e-16)])
@@ -512,7 +582,7 @@ def test_magnitude_range_headroom_and_floor(n, loud, quiet):
                 o.feed_and_tick(a)
             got = b.decibels()[1]
         assert np.all(np.isfinite(got)), f"N={n} factor {g}: non-finite rows"
-        assert_db_close(got, o.decibels(), f"N={n}, audio scaled by {g}")
+        assert_db_close(got, o.decibels(), f"N={n}, audio scaled by {g}", deep=True)
         if factor != 1.0:
             assert np.median(got) > wf.db_min() + 50, "the scaled frame must not have collapsed to DB_MIN"
 

@@ -283,7 +283,7 @@ def _compare(got, want, undo, what, cfg_stepped=False, cfg=None):
     px = _px_tol(cfg)
     for t, (g, w) in enumerate(zip(got, want)):
         assert g["silent"] == w["silent"], f"{what} tick {t}: m_last_silent {g['silent']} != {w['silent']}"
-        assert_db_close(g["db"], w["db"], f"{what} tick {t} decibels", undo_db=undo)
+        assert_db_close(g["db"], w["db"], f"{what} tick {t} decibels", undo_db=undo, deep=True)
         ref_bars, ref_verts = w["bars"], w.get("verts")
         assert (g["bars"] is None) == (w["bars"] is None), f"{what} tick {t}: one side has no bars"
         if w["bars"] is not None:
@@ -432,7 +432,7 @@ def test_per_stream_input_rms():
         for t in range(4):
             ora.push(audio[:, t * 800:(t + 1) * 800], muted=False)
             ora.tick(1.0 / 60.0)
-        assert_db_close(got[i], ora.observe()["db"], f"stream {i} (input_rms {r})")
+        assert_db_close(got[i], ora.observe()["db"], f"stream {i} (input_rms {r})", deep=True)
     assert not np.allclose(got[0], got[1])
 
 
@@ -458,7 +458,7 @@ def test_per_stream_av_sync_delay():
             ora = scenarios.OracleBackend(cfg)
             ora.push(audio[:, : total - di - common], muted=False)  # the oracle sees the audio up to the window's end
             ora.tick(1.0 / 60.0)
-            assert_db_close(got[i], ora.observe()["db"], f"delays {delays}: stream {i}")
+            assert_db_close(got[i], ora.observe()["db"], f"delays {delays}: stream {i}", deep=True)
 
 
 # ---- level meter --------------------------------------------------------------------------------------------------------
@@ -695,7 +695,7 @@ def run_dropin_case(seed, family):
         if False:
             pass
         else:
-            assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({} if family in ("pow2", "any", "huge") else {"lin_eps": None}))
+            assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({"deep": True} if family in ("pow2", "any", "huge") else {"lin_eps": None}))
 
 
 def run_dropin_batched_case(seed, family):
@@ -726,7 +726,7 @@ def run_dropin_batched_case(seed, family):
     for t, (g, w) in enumerate(zip(got, want)):
         what = f"batched drop-in {family} case {seed} tick {t} ({cfg_dict}, sync {sync_ms} ms)"
         assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
-        assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo)
+        assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, deep=True)
 
 
 

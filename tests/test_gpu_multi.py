@@ -187,6 +187,60 @@ def test_every_visible_device_takes_a_shard():
                 os.environ["WF_HIP_MULTI_TRANSPORT"] = old
 
 
+@pytest.mark.parametrize("shards,transport,timed", [(3, "peer", False), (3, "peer", True), (1, "rccl", False), (1, "rccl", True)])
+def test_a_failed_gather_leaves_a_working_group(shards, transport, timed):
+    """One shard fails inside a gather while the others have their half of the exchange enqueued (test aid
+    wf_hip_multi_debug_fail_next_gather): the call reports it, later gathers are refused, and nothing hangs -- the group goes on
+    ticking, its results still equal a plain handle's, sync and destroy return.  Peer copies with three shards; ncclAllGather with
+    the ranks this box has (ncclCommAbort is what releases the other ranks on a node).  In a child process with a timeout: the
+    failure mode under test is a hang."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import waveform_amd as wf
+from tools import synth
+shards, timed = %d, %d
+n = wf.device_count()
+devices = [i %% n for i in range(shards)] if %r == "peer" else list(range(n))
+cfg = wf.Config.defaults(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+streams, hop = 12 * len(devices), 800
+with wf.SpectrumBatch(cfg, streams, ring_frames=2048 + 40 * hop) as plain, wf.MultiBatch(cfg, streams, devices, ring_frames=2048 + 40 * hop) as m:
+    assert m.transport == %r, m.transport
+    for b in (plain, m):
+        b.push_synth(synth.DEFAULT_SEED, 0, 30 * hop)
+    for t in range(3):
+        plain.tick(delay_frames=hop * (29 - t)); m.tick(delay_frames=hop * (29 - t)); m.allgather_bars()
+    assert np.array_equal(m.gathered(0), plain.bars())
+    assert m.L.wf_hip_multi_debug_fail_next_gather(m.m, len(devices) - 1) == 0
+    try:
+        if timed:
+            m.time_ticks(6, hop, hop * 26, gather=True)
+        else:
+            m.tick(delay_frames=hop * 26); m.allgather_bars()
+        raise SystemExit("the injected failure was not reported")
+    except wf.WfHipError as e:
+        assert "injected failure" in str(e), str(e)
+    try:
+        m.allgather_bars()
+        raise SystemExit("a gather after the failure was accepted")
+    except wf.WfHipError as e:
+        assert "out of service" in str(e), str(e)
+    m.sync()
+    m.reset(); plain.reset()
+    for b in (plain, m):
+        b.push_synth(synth.DEFAULT_SEED, 0, 30 * hop)
+    for t in range(5):
+        plain.tick(delay_frames=hop * (29 - t)); m.tick(delay_frames=hop * (29 - t))
+    assert np.array_equal(m.bars(), plain.bars()) and np.array_equal(m.decibels(), plain.decibels())
+    ms, per = m.time_ticks(10, hop, hop * 20)
+    assert ms > 0
+print("survived")
+''' % (str(ROOT), shards, int(timed), transport, transport)
+    env = dict(os.environ, WF_HIP_MULTI_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_multi_errors_are_reported():
     cfg = _cfg()
     with pytest.raises(wf.WfHipError) as e:

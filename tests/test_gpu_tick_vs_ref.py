@@ -35,7 +35,7 @@ def _run_pair(cfg, streams, ticks, hop, channels=2, seconds=1 / 60):
                 nch = 2 if cfg.stereo else 1
                 for c in range(nch):
                     want = r.decibels(c)
-                    worst = max(worst, assert_db_close(got[s, c], want, f"N={cfg.fft_size} tick {t} stream {s} ch {c}"))
+                    worst = max(worst, assert_db_close(got[s, c], want, f"N={cfg.fft_size} tick {t} stream {s} ch {c}", deep=True))
     return worst
 
 

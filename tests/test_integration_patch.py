@@ -93,7 +93,7 @@ for name in names:
         assert len(recs) == meta["n_ticks"]
         assert np.array_equal(np.array([r["silent"] for r in recs], np.uint8), z["silent"]), name
         for t, r in scenarios.recorded(recs, sc["record"]):
-            tg.assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels, one frame late, through callbacks::create")
+            tg.assert_db_close(r["db"], z[f"db_{t}"], f"{name} tick {t} decibels, one frame late, through callbacks::create", deep=True)
     assert be.src.using_hip, name
 assert wfref.hip_fallback_ticks() == before, "ticks were served by the CPU class"
 if batched:

@@ -176,6 +176,7 @@ def lib():
     L.wf_hip_multi_gather_stream.argtypes = [vp, u32]
     L.wf_hip_multi_read_gathered.argtypes = [vp, u32, fp]
     L.wf_hip_multi_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, C.c_int, fp, fp]
+    L.wf_hip_multi_debug_fail_next_gather.argtypes = [vp, u32]
     _LIB = L
     return L
 

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <barrier>
 #include <condition_variable>
 #include <cstdarg>
@@ -36,6 +37,7 @@ struct Rccl {
     void *lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
@@ -68,6 +70,7 @@ Rccl &rccl()
     }
         WF_NCCL_SYM(CommInitAll)
         WF_NCCL_SYM(CommDestroy)
+        WF_NCCL_SYM(CommAbort)
         WF_NCCL_SYM(AllGather)
         WF_NCCL_SYM(GetErrorString)
 #undef WF_NCCL_SYM
@@ -160,6 +163,12 @@ struct wf_hip_multi {
     Transport transport = Transport::LOCAL;
     std::string transport_note;
     uint32_t gathers = 0; // slot of the next gather = gathers & 1
+    // A gather that failed on one shard leaves the others with a collective nobody answers (RCCL) or with copies that never
+    // come (peer): the group then aborts its communicators (ncclCommAbort ends the kernels already enqueued, so the gather
+    // streams drain), refuses every later gather and goes on ticking, reading and destroying normally.
+    bool gather_failed = false;
+    std::string gather_failure;
+    int debug_fail_shard = -1; // test aid (wf_hip_multi_debug_fail_next_gather): that shard's next gather_issue reports an error
     std::string last_error;
 };
 
@@ -239,6 +248,10 @@ int check_range(wf_hip_multi *m, uint32_t first, uint32_t count)
 int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
 {
     Shard &s = *m->shard[i];
+    if(m->debug_fail_shard == (int)i) { // (test aid: fails before anything is enqueued, as a failed wait or copy would)
+        s.err = "injected failure (wf_hip_multi_debug_fail_next_gather)";
+        return WF_HIP_ERR_RUNTIME;
+    }
     if(s.slot_used[k]) { // the gather that read this send buffer two gathers ago must have run before the buffer is rewritten
         const int rc = wf_hip_wait_event(s.h, s.ev_done[k]);
         if(rc)
@@ -298,7 +311,43 @@ int gather_check(wf_hip_multi *m)
         return WF_HIP_ERR_INVALID;
     if(m->per == 0)
         return mfail(m, WF_HIP_ERR_INVALID, "the configuration has no bars or curve (cfg.bars == 0 and cfg.curve == 0): nothing to gather");
+    if(m->gather_failed)
+        return mfail(m, WF_HIP_ERR_RUNTIME, "the group's gather is out of service after an earlier failure (%s); ticks and reads go on", m->gather_failure.c_str());
     return WF_HIP_OK;
+}
+
+// A shard failed inside a gather while others had already enqueued their half of it.  From the API thread, no worker running:
+// the communicators are aborted (every one of them, so that no rank keeps waiting in a kernel for a peer that never launched),
+// the events the handles' streams may be waiting for are recorded afresh on the (now draining) gather streams, and the group
+// is marked so that sync / destroy / later gathers do not count on a collective any more.  m->last_error keeps the cause.
+void gather_fail(wf_hip_multi *m)
+{
+    if(m->gather_failed)
+        return;
+    m->gather_failed = true;
+    m->gather_failure = m->last_error;
+    m->debug_fail_shard = -1;
+    for(auto &sp : m->shard)
+        if(sp->comm) {
+            (void)hipSetDevice(sp->device);
+            (void)rccl().CommAbort(sp->comm);
+            sp->comm = nullptr;
+        }
+    // whatever a handle's streams were told to wait for (ev_done of a slot whose collective is gone) completes now
+    for(auto &sp : m->shard) {
+        Shard &s = *sp;
+        if(!s.worker.th.joinable() || s.gstream == nullptr)
+            continue;
+        s.worker.post([&s] {
+            for(int k = 0; k < 2; ++k) {
+                if(s.ev_sent[k]) (void)hipEventRecord(s.ev_sent[k], s.gstream);
+                if(s.ev_done[k]) (void)hipEventRecord(s.ev_done[k], s.gstream);
+                s.slot_used[k] = false;
+            }
+            return 0;
+        });
+        (void)s.worker.wait();
+    }
 }
 
 void destroy_impl(wf_hip_multi *m)
@@ -637,12 +686,13 @@ int wf_hip_multi_allgather_bars(wf_hip_multi *m)
         return rc;
     const uint32_t k = m->gathers & 1u;
     rc = run_all(m, [m, k](uint32_t i) { return gather_issue(m, i, k); });
-    if(rc)
-        return rc;
     // (run_all returning is the host barrier between the halves: every ev_sent of this slot has been recorded)
-    rc = run_all(m, [m, k](uint32_t i) { return gather_complete(m, i, k); });
-    if(rc)
+    if(rc == WF_HIP_OK)
+        rc = run_all(m, [m, k](uint32_t i) { return gather_complete(m, i, k); });
+    if(rc) { // some shards have enqueued their half: see gather_fail
+        gather_fail(m);
         return rc;
+    }
     ++m->gathers;
     return WF_HIP_OK;
 }
@@ -652,6 +702,16 @@ const float *wf_hip_multi_gathered_device(wf_hip_multi *m, uint32_t i)
     if(m == nullptr || i >= m->n || m->gathers == 0)
         return nullptr;
     return m->shard[i]->gathered[(m->gathers - 1) & 1u];
+}
+
+// Test aid: shard `shard`'s next gather reports a failure before it enqueues anything -- what a failed wait or copy on one
+// device looks like to the others, which have their half of the exchange in flight by then.
+int wf_hip_multi_debug_fail_next_gather(wf_hip_multi *m, uint32_t shard)
+{
+    if(m == nullptr || shard >= m->n)
+        return WF_HIP_ERR_INVALID;
+    m->debug_fail_shard = (int)shard;
+    return WF_HIP_OK;
 }
 
 void *wf_hip_multi_gather_stream(wf_hip_multi *m, uint32_t i) { return (m && i < m->n) ? m->shard[i]->gstream : nullptr; }
@@ -697,6 +757,7 @@ int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32
     // the halves of a peer gather need every device's events recorded in between: a barrier among the workers.  A worker that
     // fails keeps arriving at the barriers (doing nothing) so that the others do not wait for it for ever.
     std::barrier sync((std::ptrdiff_t)m->n);
+    std::atomic<bool> any_failed{false};
     const uint32_t k0 = m->gathers;
     int rc = run_all(m, [&, m](uint32_t i) {
         Shard &s = *m->shard[i];
@@ -716,6 +777,16 @@ int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32
                 if(st == WF_HIP_OK)
                     st = gather_complete(m, i, k);
             }
+            if(st != WF_HIP_OK)
+                any_failed.store(true, std::memory_order_relaxed);
+        }
+        // Nothing above waits on the host.  Below it does -- for streams that, after a failure anywhere, may be waiting for a
+        // collective one rank never joined: every worker first learns whether all of them got through (gather_fail, called by
+        // the API thread once the workers are back, is what releases those streams).
+        if(gather) {
+            sync.arrive_and_wait();
+            if(any_failed.load(std::memory_order_relaxed))
+                return st; // (a bystander returns OK: the failing shard's own status and text are the call's)
         }
         if(st == WF_HIP_OK)
             st = wf_hip_time_end(s.h, &ms[i]);
@@ -723,10 +794,13 @@ int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32
             st = WF_HIP_ERR_RUNTIME;
         return st;
     });
-    if(gather)
+    if(gather && !(rc && any_failed.load()))
         m->gathers = k0 + ticks;
-    if(rc)
+    if(rc) {
+        if(gather && any_failed.load())
+            gather_fail(m);
         return rc;
+    }
     float worst = 0.0f;
     for(uint32_t i = 0; i < m->n; ++i) {
         ms[i] /= (float)ticks;
