@@ -193,7 +193,7 @@ def test_power_of_two_kernels_do_not_spill():
 
     def usage(n):
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-slp-vectorize", f"-I{ROOT / 'include'}",
-               f"-I{src}", f"-DWF_GEOM_ONLY={n}", "-Rpass-analysis=kernel-resource-usage", "-c", str(src / "wf_hip.hip"), "-o", "/dev/null"]
+               f"-I{src}", f"-DWF_TU_GEOM={n}", "-Rpass-analysis=kernel-resource-usage", "-c", str(src / "wf_tick_geom.hip"), "-o", "/dev/null"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         out, name, vgprs = [], None, 0

@@ -25,9 +25,7 @@
 
 namespace wf {
 
-using GBig = Geom<32768, 1024, 16, 32, 32>; // the row transform: 16384 complex points, 1024 threads (G32768's radices)
-constexpr uint32_t BIG_L2 = GBig::M;       // 16384
-constexpr int BIG_TP = GBig::T * GBig::P;  // bins per epilogue workgroup (16384)
+// (GBig, BIG_L2, BIG_TP: wf_geometry.hpp)
 
 struct BigArgs {
     const float *ring;

@@ -26,6 +26,12 @@ using G32768 = Geom<32768, WF_G32768_T, 16, 32, 32>; // eight wavefronts of 32 p
                                               // two waves per SIMD with 256 registers each -- 177-199 used, no scratch); both radix-32 passes
                                               // whole in a thread.  The reference's "large FFT" range.
 
+// the row transform of the paths through device memory (wf_big.hpp), and the container of the Bluestein / mixed-radix
+// instantiations of the largest geometry: 16384 complex points on 1024 threads of 16 (G32768's radices)
+using GBig = Geom<32768, 1024, 16, 32, 32>;
+constexpr uint32_t BIG_L2 = GBig::M;       // 16384
+constexpr int BIG_TP = GBig::T * GBig::P;  // bins per epilogue workgroup (16384)
+
 // calls f(G{}) for the geometry of fft_size n; returns false for unsupported sizes
 template<class F> inline bool dispatch_geometry(uint32_t n, F &&f)
 {

@@ -1,0 +1,271 @@
+// wf_tick_geom.hip -- kernel dispatch of ONE FFT geometry: compiled once per geometry (-DWF_TU_GEOM=512 ... 32768, see the
+// Makefile), so that the ~70 instantiations of spectrum_tick_kernel build in parallel instead of in one translation unit.
+// Host side: the launch functions wf_hip_tick calls through wf_hip::launch, and setup_tick_<N>() which wf_hip_create
+// (wf_hip_plan.hip) calls to pick one.  gfx950 only.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "wf_hip_internal.hpp"
+#include "wf_kernels.hpp"
+
+#ifndef WF_TU_GEOM
+#error "compile with -DWF_TU_GEOM=<fft size of the geometry>"
+#endif
+
+namespace {
+
+using wf::host::fail;
+
+template<class G> void launch_tick_split(wf_hip *h, const wf::TickArgs &a0, bool aligned)
+{
+    const dim3 block(G::T);
+    const size_t lds = wf::tick_lds_bytes<G, 1>();
+    // mono mixdown: channel 1 of every stream, then channel 0 (TickArgs::split_ch); stereo pairs: everything at once
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
+        wf::TickArgs a = a0;
+        a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(h->split_mono ? a.stream_count : a.stream_count * a.cap_ch);
+        if(aligned)
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, true, true>), grid, block, lds, h->launch_stream, a);
+        else
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, false, true>), grid, block, lds, h->launch_stream, a);
+    }
+}
+
+template<class G> int setup_launch_split(wf_hip *h)
+{
+    const int lds = (int)wf::tick_lds_bytes<G, 1>();
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 1, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 1, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick_split<G>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)G::T;
+    h->split = true;
+    h->flag_bufs = 3;
+    char name[96];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=1,split>", G::N, G::T, G::R1, G::R2, G::R3);
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
+// FFT sizes 256 / 128 on the 512-point geometry, zero-padded (spectrum_tick_kernel<.., DEC>)
+template<class G, int DEC> void launch_tick_dec(wf_hip *h, const wf::TickArgs &a, bool aligned)
+{
+    const uint32_t n_spec = a.stream_count * a.cap_ch;
+    const dim3 grid((n_spec + 1) / 2), block(G::T * 2);
+    const size_t lds = wf::tick_lds_bytes<G, 2>();
+    if(aligned)
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, true, false, DEC>), grid, block, lds, h->launch_stream, a);
+    else
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, false, false, DEC>), grid, block, lds, h->launch_stream, a);
+}
+
+template<class G, int DEC> int setup_launch_dec(wf_hip *h)
+{
+    const int lds = (int)wf::tick_lds_bytes<G, 2>();
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 2, true, false, DEC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 2, false, false, DEC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick_dec<G, DEC>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)G::T * 2u;
+    char name[96];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d zero-padded to %d,T=%d,R=%dx%dx%d,SPW=2>", G::N >> DEC, G::N, G::T, G::R1, G::R2, G::R3);
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
+// Bluestein path (FFT sizes that are not powers of two): always the scalar fetch
+template<class G, int SPW, bool SPLIT, bool MR = false> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a0, bool)
+{
+    const uint32_t n_spec = a0.stream_count * a0.cap_ch;
+    const dim3 block(G::T * SPW);
+    const size_t lds = wf::tick_lds_bytes<G, SPW>();
+    const bool two = SPLIT && h->split_mono; // mono mixdown in two launches (TickArgs::split_ch)
+    for(int pass = 0; pass < (two ? 2 : 1); ++pass) {
+        wf::TickArgs a = a0;
+        a.split_ch = two ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(two ? a.stream_count : (n_spec + SPW - 1) / SPW);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR>), grid, block, lds, h->launch_stream, a);
+    }
+}
+
+template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_hip *h)
+{
+    if constexpr(!MR && G::N >= 1024) { // (the smallest container a size that is not a power of two ever gets: wf::bluestein_length)
+        // sizes with small prime factors take the same instantiation's fetch and epilogue around a direct transform
+        bool direct = true;
+#ifdef WF_DEV_OVERRIDES
+        if(const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX")) // (development: A/B against Bluestein)
+            direct = off[0] != '1';
+#endif
+        const int passes = direct ? wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix, (uint64_t)G::M) : 0;
+        if(passes > 0) {
+            h->mr_passes = passes;
+#ifdef WF_DEV_OVERRIDES
+            if(const char *e = std::getenv("WF_HIP_MR_PLAN")) { // (development: "25,16" -- another order or split of the same product)
+                int r[4] = {0, 0, 0, 0}, n = 0;
+                uint64_t prod = 1;
+                for(const char *q = e; *q && n < 4;) {
+                    r[n] = std::atoi(q);
+                    prod *= (uint64_t)std::max(r[n], 1);
+                    ++n;
+                    while(*q && *q != ',') ++q;
+                    if(*q == ',') ++q;
+                }
+                bool ok = n >= 2 && prod == h->N / 2 && r[n - 1] <= 16 && (h->N / 2) / (uint32_t)r[n - 1] <= (uint32_t)G::T;
+                for(int i = 0; i < n; ++i) {
+                    const int v = r[i];
+                    ok = ok && (v == 2 || v == 3 || v == 4 || v == 5 || v == 6 || v == 8 || v == 9 || v == 10 || v == 12 || v == 15 || v == 16 || v == 7 || v == 11 || v == 13 ||
+                                (i == 0 && (v == 20 || v == 25 || v == 17 || v == 19 || v == 23 || v == h->mr_radix[0])));
+                }
+                if(ok) {
+                    h->mr_passes = n;
+                    for(int i = 0; i < 4; ++i)
+                        h->mr_radix[i] = r[i];
+                }
+            }
+#endif
+            return setup_launch_blu<G, SPW, SPLIT, true>(h);
+        }
+    }
+    const int lds = (int)wf::tick_lds_bytes<G, SPW>();
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick_blu<G, SPW, SPLIT, MR>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)(G::T * SPW);
+    h->split = SPLIT;
+    char name[160];
+    if(MR) {
+        char rad[48];
+        int o = 0;
+        for(int i = 0; i < h->mr_passes; ++i)
+            o += snprintf(rad + o, sizeof(rad) - (size_t)o, "%s%d", i ? "x" : "", h->mr_radix[i]);
+        snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%u: %u complex points as mixed radix %s,T=%d,SPW=%d%s>", h->N, h->N / 2, rad, G::T, SPW,
+                 SPLIT ? ",split" : "");
+    } else
+        snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%u by Bluestein over %d complex points,T=%d,R=%dx%dx%d,SPW=%d%s>", h->N, G::M, G::T,
+                 G::R1, G::R2, G::R3, SPW, SPLIT ? ",split" : "");
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
+template<class G, int SPW, bool TLDS, bool BOTH = false> void launch_tick(wf_hip *h, const wf::TickArgs &a, bool aligned)
+{
+    const uint32_t n_spec = a.stream_count * a.cap_ch;
+    const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
+    const size_t lds = wf::tick_lds_bytes<G, SPW>();
+    if(aligned)
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS, false, BOTH>), grid, block, lds, h->launch_stream, a);
+    else
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS, false, BOTH>), grid, block, lds, h->launch_stream, a);
+}
+
+template<class G, int SPW, bool TLDS, bool BOTH = false> int setup_launch_impl(wf_hip *h)
+{
+    const int lds = (int)wf::tick_lds_bytes<G, SPW>();
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS, false, BOTH>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS, false, BOTH>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->launch = &launch_tick<G, SPW, TLDS, BOTH>;
+    h->wg_lds = (uint32_t)lds;
+    h->wg_threads = (uint32_t)(G::T * SPW);
+    char name[112];
+    snprintf(name, sizeof(name), "spectrum_tick_kernel<N=%d,T=%d,R=%dx%dx%d,SPW=%d%s%s>", G::N, G::T, G::R1, G::R2, G::R3, SPW,
+             TLDS ? ",tables via LDS" : "", BOTH ? ",curve row shared by both spectra" : "");
+    h->kernel_name = name;
+    return WF_HIP_OK;
+}
+
+// Workgroups of two spectra can stage the window / pass-1 twiddle tables in LDS once (spectrum_tick_kernel<.., TLDS>).
+// Measured on MI355X (interleaved A/B): N = 1024 63.4 -> 68.7 % of the HBM peak (8-byte table loads, 23 per thread, become
+// 8 DMA requests per wavefront), N = 2048 +-1 %, N = 4096 -1.5 % (the extra barrier costs what the halved table traffic
+// saves), N = 8192 +1 %: on for the 8-point geometry only.  WF_HIP_TLDS=0/1 overrides (development aid).
+template<class G, int SPW> int setup_launch(wf_hip *h)
+{
+    if constexpr(SPW == 2) {
+        bool tlds = G::P <= 8;
+#ifdef WF_DEV_OVERRIDES
+        if(const char *e = std::getenv("WF_HIP_TLDS"))
+            tlds = e[0] == '1';
+#endif
+        // mono mixdown with a curve display: the kernel whose two spectra share the row (a TLDS override keeps the plain one)
+        if(h->curve_both && h->N == (uint32_t)G::N && tlds == (G::P <= 8)) {
+            if constexpr(G::P <= 8)
+                return setup_launch_impl<G, 2, true, true>(h);
+            else
+                return setup_launch_impl<G, 2, false, true>(h);
+        }
+        if(tlds)
+            return setup_launch_impl<G, 2, true>(h);
+    }
+    return setup_launch_impl<G, SPW, false>(h);
+}
+
+// the kernel of this handle on geometry G: which of the instantiations above its configuration takes
+template<class G> int setup_tick_geometry(wf_hip *h, bool want_split)
+{
+    const wf_config *cfg = &h->cfg;
+    h->waves_per_spectrum = G::T / 64;
+    if(h->blu) {
+        if constexpr(G::N >= 32768) {
+            // (the Bluestein and mixed-radix instantiations of this container keep 1024 threads of 16 points: a mixed-radix
+            // plan's last pass has one butterfly per thread at most, and 39 sizes have no plan on 512 threads)
+            using GB = wf::GBig;
+            h->waves_per_spectrum = GB::T / 64;
+            if(want_split)
+                return setup_launch_blu<GB, 1, true>(h);
+            if(cfg->capture_channels == 1)
+                return setup_launch_blu<GB, 1, false>(h);
+            return fail(h, WF_HIP_ERR_RUNTIME, "fft_size %u: no launch plan", cfg->fft_size);
+        } else if constexpr(G::T >= 256)
+            return want_split ? setup_launch_blu<G, 1, true>(h) : (cfg->capture_channels > 1) ? setup_launch_blu<G, 2, false>(h) : setup_launch_blu<G, 1, false>(h);
+        else
+            return setup_launch_blu<G, 2, false>(h);
+    } else if constexpr(G::N == 512) {
+        switch(h->N) {
+        case 256: return setup_launch_dec<G, 1>(h);
+        case 128: return setup_launch_dec<G, 2>(h);
+        default: return setup_launch<G, 2>(h);
+        }
+    } else if constexpr(G::N >= 32768) {
+        // one spectrum fills a CU's LDS: a stereo pair runs split, a single captured channel alone; mono mixdown of two
+        // channels runs split too, as two launches (TickArgs::split_ch)
+        if(want_split)
+            return setup_launch_split<G>(h);
+        if(cfg->capture_channels == 1)
+            return setup_launch<G, 1>(h);
+        return fail(h, WF_HIP_ERR_RUNTIME, "fft_size %u: no launch plan", cfg->fft_size);
+    } else if constexpr(G::T >= 256)
+        return want_split ? setup_launch_split<G>(h) : (cfg->capture_channels > 1) ? setup_launch<G, 2>(h) : setup_launch<G, 1>(h);
+    else
+        return setup_launch<G, 2>(h);
+}
+
+} // namespace
+
+namespace wf::host {
+
+#define WF_CAT2(a, b) a##b
+#define WF_CAT(a, b) WF_CAT2(a, b)
+int WF_CAT(setup_tick_, WF_TU_GEOM)(wf_hip *h, bool want_split)
+{
+#if defined(WF_GEOM_ONLY) && (WF_GEOM_ONLY != WF_TU_GEOM)
+    (void)want_split; // development builds: one geometry only (tools/variant.sh)
+    return fail(h, WF_HIP_ERR_UNSUPPORTED, "development build: only the %d-sample geometry is compiled in", WF_GEOM_ONLY);
+#elif defined(WF_GEOM_ONLY)
+    if(h->blu) // development builds: no Bluestein instantiations
+        return fail(h, WF_HIP_ERR_UNSUPPORTED, "development build without the Bluestein kernels");
+    return setup_tick_geometry<WF_CAT(wf::G, WF_TU_GEOM)>(h, want_split);
+#else
+    return setup_tick_geometry<WF_CAT(wf::G, WF_TU_GEOM)>(h, want_split);
+#endif
+}
+
+} // namespace wf::host

@@ -226,6 +226,9 @@ WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 // Cache).  The smoothing state is read once and written once per tick: the hint on its stores alone +-0, on its loads
 // alone +-0, on both +3.7 % (0.701 -> 0.727; 16384 streams 0.69 -> 0.72-0.75) -- then only the rings, whose consecutive
 // windows overlap by 80 %, compete for the cache.  On the window loads themselves the hint costs 2 % (WF_NT_SMP).
+#ifndef WF_NT_ROWS
+#define WF_NT_ROWS true // m_decibels rows stored with the non-temporal hint
+#endif
 #ifndef WF_NT_STATE
 #define WF_NT_STATE 1
 #endif
