@@ -275,6 +275,31 @@ long wfemu_bar_lanes(const wf_config *cfg, int threads, int max_blocks, int whic
     return (long)v.size();
 }
 
+// the wave-private form (wf::bar_pieces).  which: 0 coef [blocks][threads][4], 1 base, 2 info, 3 bar_piece (ints as float),
+// 4 scalars {num_segs, blocks, num_slots}; -1000 if the form does not exist for this configuration
+long wfemu_bar_pieces(const wf_config *cfg, int threads, int points, int max_blocks, int which, float *out, long cap)
+{
+    wf::HostTables tab;
+    const int rc = wf::build_host_tables(*cfg, tab);
+    if(rc != 0)
+        return rc;
+    wf::BarPieceTables pc;
+    if(!wf::bar_pieces(tab, threads, points, max_blocks, pc))
+        return -1000;
+    std::vector<float> v;
+    switch(which) {
+    case 0: v = pc.coef; break;
+    case 1: v.assign(pc.base.begin(), pc.base.end()); break;
+    case 2: v.assign(pc.info.begin(), pc.info.end()); break;
+    case 3: v.assign(pc.bar_piece.begin(), pc.bar_piece.end()); break;
+    case 4: v = {(float)pc.num_segs, (float)pc.blocks, (float)pc.num_slots}; break;
+    default: return -1;
+    }
+    for(long i = 0; i < (long)v.size() && i < cap; ++i)
+        out[i] = v[(size_t)i];
+    return (long)v.size();
+}
+
 int wfemu_lds_bytes(uint32_t fft_size)
 {
     int r = -1;

@@ -184,6 +184,96 @@ def test_bar_segment_tables_are_a_permutation_of_the_flat_tables():
     assert emu.bar_lanes(many, 64, 3, 0) is None
 
 
+def test_slope_factors_formed_on_the_device_stay_next_to_the_reference_table():
+    """Policy<G>::SLOPE_LINEAR (wf_tick_phases.hpp): the geometries from 2048 samples form m_slope_modifiers[k] as
+    fma(k, 3 * slope / (M - 1), 1) instead of loading the reference's table log10f(10 * powf(1000, k * slope / (M - 1)))
+    (src/source.cpp:1283-1290; bit-identical in wf_host_tables.cpp).  The two differ by the table's own powf / log10f roundings:
+    pinned here at 5e-7 relative over the reference's slider range, 1/20 of the parity tolerance."""
+    worst = 0.0
+    for n in (2048, 4096, 8192, 16384, 32768):
+        for slope in (0.05, 0.3, 1.0, 2.25, 5.0):
+            cfg = scenarios.make_config(dict(fft_size=n, stereo=1, slope=slope))
+            tab = emu.host_table(cfg, 1).astype(np.float64)
+            M = n // 2
+            assert len(tab) == M
+            step = np.float32(3.0 * float(np.float32(slope)) / (M - 1))
+            k = np.arange(M, dtype=np.float32)
+            dev = (k.astype(np.float64) * np.float64(step) + 1.0).astype(np.float32).astype(np.float64)   # one fma: a single rounding
+            worst = max(worst, float(np.max(np.abs(dev - tab) / tab)))
+    assert worst <= 5e-7, worst
+
+
+def test_bar_piece_tables_replayed_lane_by_lane():
+    """wf::bar_pieces (the wave-private form of the bars tail: no barrier between parking the row and reading it, partial sums
+    added by a six-step DPP scan, the last wavefront to arrive adds the pieces).  Replays what the kernel does with the tables on
+    a random dB row -- per-thread dot products over 16-byte words, the segmented prefix scan step by step exactly as the DPP
+    controls move lanes (row_shr:1/2/4/8 inside rows of 16, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3), the
+    slots, the sum per bar -- against the flat table; and checks the property the missing barrier rests on: a thread reads
+    only bins its own wavefront has written."""
+    rng = np.random.default_rng(11)
+    geoms = {512: (64, 4), 1024: (64, 8), 2048: (64, 16), 4096: (128, 16), 8192: (256, 16), 16384: (512, 16), 32768: (512, 32)}
+    seen = 0
+    for n, (T, P) in geoms.items():
+        for mode, extra in ((1, {}), (2, dict(log_scale=0)), (0, dict(mirror_freq_axis=1, bar_width=10, bar_gap=2)), (1, dict(width=1200)), (0, dict(width=1000, bar_width=20, bar_gap=5, log_scale=0))):
+            cfg = scenarios.make_config(dict(fft_size=n, stereo=1, bars=1, interp_mode=mode, **extra))
+            coef = emu.host_table(cfg, 7).astype(np.float64)
+            bins = emu.host_table(cfg, 8).astype(np.int64)
+            off = emu.host_table(cfg, 9).astype(np.int64)
+            mb = P // 4 + 2
+            lc = emu.bar_pieces(cfg, T, P, mb, 0)
+            if lc is None:
+                # (at most 64 bars -- lane b of the last wavefront finishes bar b -- and at most 64 segments per wavefront: on a
+                # log axis most bars lie in the first 256 bins, i.e. in wavefront 0; bar_segments' layouts take the rest)
+                assert len(off) - 1 > 30, (n, mode, extra, "the form should exist")
+                continue
+            seen += 1
+            base = emu.bar_pieces(cfg, T, P, mb, 1).astype(np.int64)
+            info = emu.bar_pieces(cfg, T, P, mb, 2).astype(np.int64)
+            piece = emu.bar_pieces(cfg, T, P, mb, 3).astype(np.int64)
+            num_segs, blocks, num_slots = (int(v) for v in emu.bar_pieces(cfg, T, P, mb, 4))
+            M, wps = n // 2, T // 64
+            assert 1 <= blocks <= mb and len(base) == T and len(info) == T and len(piece) == len(off) and num_segs <= T
+            lc = lc.astype(np.float64).reshape(blocks, T, 4)
+            assert np.all(base % 4 == 0) and np.all(base >= 0) and np.all(base + 4 * blocks <= M)
+            # wave-private reads: bin k is parked by the wavefront that owns chunk k // 256, i.e. wave (k // 256) % wps
+            lb = base[None, :, None] + 4 * np.arange(blocks)[:, None, None] + np.arange(4)[None, None, :]   # [blocks][T][4]
+            owner = (lb // 256) % wps
+            wave = (np.arange(T) // 64)[None, :, None]
+            used = lc != 0
+            assert np.all(owner[used] == wave.repeat(blocks, 0).repeat(4, 2)[used]), (n, mode, "a thread weighs a bin another wavefront parks")
+            if wps > 1:  # stricter: the 16-byte words it READS lie in its own wavefront's chunks too (garbage times 0 would be NaN)
+                segs = (info != 0) | (np.abs(lc).sum(axis=(0, 2)) > 0)
+                assert np.all((owner == wave)[:, segs, :]), (n, mode, "a segment reads bins of another wavefront")
+            db = rng.uniform(-120.0, 0.0, M)
+            part = (lc * db[lb]).sum(axis=(0, 2))
+            # the scan, wavefront by wavefront
+            tot = part.copy()
+            for w in range(wps):
+                v = tot[64 * w:64 * w + 64].copy()
+                f = info[64 * w:64 * w + 64]
+                lane = np.arange(64)
+                for bit, d in enumerate((1, 2, 4, 8)):
+                    src = np.where((lane & 15) >= d, np.roll(v, d), 0.0)          # row_shr:d, bound_ctrl: 0 from outside the row
+                    v = v + np.where((f >> bit) & 1, src, 0.0)
+                src = np.where(((lane >> 4) & 1) == 1, v[np.maximum((lane & ~15) - 1, 0)], 0.0)   # row_bcast:15, rows 1 and 3
+                v = v + np.where((f >> 4) & 1, src, 0.0)
+                src = np.where(lane >= 32, v[31], 0.0)                                           # row_bcast:31, rows 2 and 3
+                v = v + np.where((f >> 5) & 1, src, 0.0)
+                tot[64 * w:64 * w + 64] = v
+            slots = np.full(max(num_slots, len(off)), np.nan)
+            ends = np.nonzero(info >> 8)[0]
+            slot_of = (info[ends] >> 8) - 1
+            assert len(set(slot_of.tolist())) == len(slot_of), "two lanes write one slot"
+            slots[slot_of] = tot[ends]
+            for b in range(len(off) - 1):
+                flat = float((coef[off[b]:off[b + 1]] * db[bins[off[b]:off[b + 1]]]).sum())
+                got = float(slots[b]) if wps == 1 else float(slots[piece[b]:piece[b + 1]].sum())
+                if off[b + 1] == off[b]:
+                    got = 0.0 if wps == 1 and np.isnan(got) else got
+                assert abs(flat - got) <= 1e-9 * max(1.0, abs(flat)), (n, mode, extra, b, flat, got)
+    assert seen >= 20
+
+
 def test_power_of_two_kernels_do_not_spill():
     """the fused kernels of the power-of-two sizes (the measured ones) must fit their register budget: a few bytes of scratch
     per lane cost N = 1024 ten percent in round 2 before anyone looked.  Compiles each geometry on its own (hipcc

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("WF_HIP_LIB", os.path.abspath("build/variants/lib_timing.so"))
+os.environ.setdefault("WF_HIP_LIB", os.path.abspath("variants/lib_timing.so"))
 import waveform_amd as wf
 from tools import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -14,9 +14,10 @@ if os.environ.get("WF_BENCH_CURVE"):
 cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=1.0, **extra)
 b = wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * (ticks + 2))
 b.push_synth(synth.DEFAULT_SEED, 0, hop * (ticks + 1))
-b.time_ticks(int(os.environ.get("WF_WARM_TICKS", "600")), hop, hop * (ticks - 1))  # settled clocks (profiles/r02j_warmup.txt)
+FLAGS = int(os.environ.get("WF_BENCH_FLAGS", "0"))  # 1: WF_HIP_TICK_NO_DECIBELS (bars-only ticks)
+b.time_ticks(int(os.environ.get("WF_WARM_TICKS", "600")), hop, hop * (ticks - 1), flags=FLAGS)  # settled clocks (profiles/r02j_warmup.txt)
 for i in range(ticks):
-    b.tick(delay_frames=hop * (ticks - 1 - i))
+    b.tick(delay_frames=hop * (ticks - 1 - i), flags=FLAGS)
 b.sync()
 nblk = streams * 2 // 2
 buf = np.zeros(nblk * 16, np.uint64)

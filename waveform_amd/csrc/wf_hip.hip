@@ -76,6 +76,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.lead_bar = h->d_lead_bar;
         a.bar.lead_end = h->d_lead_end;
         a.bar.wave_local = h->bar_wave_local ? 1 : 0;
+        a.bar.piece_mode = h->bar_piece_mode ? 1 : 0;
         a.bar.num_segs = h->bar_segs;
         a.bar.lane_blocks = h->bar_blocks;
         a.bar.cur_coef = h->d_cur_coef;
@@ -104,6 +105,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
     }
     a.half_coef = 0.5f * (2.0f / h->tab.window_sum); // mag_coefficient (reference src/source_generic.cpp:110), halved: the
                                                      // kernel produces 2X[k] from the real split
+    a.slope_step = h->tab.slope.empty() ? 0.0f : (float)(3.0 * (double)h->cfg.slope / (double)(h->M - 1));
     a.row_bins = h->M;
     if(h->blu) {
         a.blu_a = h->d_blu_a;

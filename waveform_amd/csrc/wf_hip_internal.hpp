@@ -156,6 +156,7 @@ struct wf_hip {
     float *d_lane_coef = nullptr;
     int *d_lane_base = nullptr, *d_bar_seg = nullptr, *d_seg_group = nullptr, *d_lead_bar = nullptr, *d_lead_end = nullptr;
     bool bar_wave_local = false;
+    bool bar_piece_mode = false;     // BarArgs::piece_mode (d_seg_group holds BarPieceTables::info, d_bar_seg its bar_piece)
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;

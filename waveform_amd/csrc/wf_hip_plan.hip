@@ -332,12 +332,49 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             wf::BarLaneTables lanes;
             // (wave-local layout: no workgroup barrier inside the reduction; not with the filter, whose inputs are staged by
             // bar index behind a barrier anyway.  WF_HIP_BARS_WAVE_LOCAL=0: the plain layout, development aid)
+            // wave-private pieces first (no barrier, DPP scan, last-arriver sum: wf_host_tables.hpp BarPieceTables); not with the
+            // filter (its inputs are staged by bar index behind a barrier anyway) nor on the zero-padded sizes
+            wf::BarPieceTables pieces;
+            bool want_pieces = h->tab.gauss_radius == 0 && h->N >= 512u;
+            if(h->blu) { // Bluestein proper keeps bar_segments' layouts (its instantiations are compiled without this one); the sizes
+                         // that will run as a mixed-radix transform (setup_launch_blu asks the same question) take it
+                int radix[4] = {0, 0, 0, 0};
+                bool direct = false;
+                wf::dispatch_geometry(h->geom_n, [&](auto g) {
+                    using G = decltype(g);
+                    if constexpr(G::N >= 32768)
+                        direct = wf::plan_mixed_radix(h->N / 2, (uint32_t)wf::GBig::T, radix, (uint64_t)wf::GBig::M) > 0;
+                    else
+                        direct = G::N >= 1024 && wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, radix, (uint64_t)G::M) > 0;
+                });
+#ifdef WF_DEV_OVERRIDES
+                if(const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX"))
+                    direct = direct && off[0] != '1';
+#endif
+                want_pieces = want_pieces && direct;
+            }
+#ifdef WF_DEV_OVERRIDES
+            if(const char *e = std::getenv("WF_HIP_BAR_PIECES"))
+                want_pieces = want_pieces && e[0] != '0';
+#endif
+            if(want_pieces && wf::bar_pieces(h->tab, threads, points, points / 4 + 2, pieces) &&
+               (size_t)h->M + (size_t)pieces.num_slots <= lds_floats) {
+                h->bar_piece_mode = true;
+                h->bar_segs = pieces.num_segs;
+                h->bar_blocks = pieces.blocks;
+                h->out_steps = 1;
+                WF_PLAN_TRY(upload(h, &h->d_lane_coef, pieces.coef));
+                WF_PLAN_TRY(upload(h, &h->d_lane_base, pieces.base));
+                WF_PLAN_TRY(upload(h, &h->d_seg_group, pieces.info));
+                WF_PLAN_TRY(upload(h, &h->d_bar_seg, pieces.bar_piece));
+                WF_PLAN_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
+            }
             bool local = h->tab.gauss_radius == 0;
 #ifdef WF_DEV_OVERRIDES
             if(const char *e = std::getenv("WF_HIP_BARS_WAVE_LOCAL"))
                 local = local && e[0] != '0';
 #endif
-            if(wf::bar_segments(h->tab, threads, points / 4 + 2, lanes, local)) {
+            if(!h->bar_piece_mode && wf::bar_segments(h->tab, threads, points / 4 + 2, lanes, local)) {
                 h->bar_wave_local = lanes.wave_local;
                 h->bar_segs = lanes.num_segs;
                 h->bar_blocks = lanes.blocks;
@@ -454,7 +491,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             h->d_cur_coef = nullptr; h->d_cur_base = nullptr; h->d_cur_x = nullptr; h->d_gauss = nullptr; h->d_gauss_wsum = nullptr;
             h->d_lane_coef = nullptr; h->d_lane_base = nullptr; h->d_bar_seg = nullptr; h->d_seg_group = nullptr;
             h->d_lead_bar = nullptr; h->d_lead_end = nullptr;
-            h->curve = h->curve_both = h->curve_catrom = h->stream_steps = h->bar_wave_local = false;
+            h->curve = h->curve_both = h->curve_catrom = h->stream_steps = h->bar_wave_local = h->bar_piece_mode = false;
             h->out_steps = h->bar_segs = h->bar_blocks = h->bar_chunks = h->bar_stage_off = 0;
             h->bar_lpb = 1;
             chunks.clear();

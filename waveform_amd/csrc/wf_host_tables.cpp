@@ -438,6 +438,96 @@ bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTable
     return true;
 }
 
+bool bar_pieces(const HostTables &t, int threads, int points, int max_blocks, BarPieceTables &out)
+{
+    out = BarPieceTables{};
+    if(t.num_bars <= 0 || t.num_bars > 64 || threads < 64 || threads % 64 || points < 4 || points % 4)
+        return false;
+    const int M = (int)t.bar_rows_bins, wps = threads / 64, groups = points / 4;
+    if(M < 256 * wps)
+        return false; // (rows shorter than one chunk per wavefront: the zero-padded sizes keep bar_segments' layout)
+    struct Piece { int bar, wave, lo, hi, cend; }; // bins [lo, hi) of one bar inside the chunk that ends at cend
+    std::vector<Piece> pieces;
+    out.bar_piece.assign((size_t)t.num_bars + 1, 0);
+    for(int b = 0; b < t.num_bars; ++b) {
+        out.bar_piece[(size_t)b] = (int)pieces.size();
+        const int o = t.bar_off[(size_t)b], len = t.bar_off[(size_t)b + 1] - o;
+        if(len <= 0)
+            continue; // (a bar without entries: no slot, the finalizer's sum is empty -- 0 / count, as the flat form gives)
+        const int lo = t.bar_bin[(size_t)o], hi = lo + len;
+        for(int e = 1; e < len; ++e)
+            if(t.bar_bin[(size_t)o + e] != lo + e)
+                return false; // (entries of a bar sit on consecutive bins: build_bars)
+        if(hi > 256 * wps * groups)
+            return false;
+        if(wps == 1)
+            pieces.push_back({b, 0, lo, hi, M});
+        else
+            for(int c = lo / 256; c * 256 < hi; ++c)
+                pieces.push_back({b, c % wps, std::max(lo, c * 256), std::min(hi, c * 256 + 256), c * 256 + 256});
+    }
+    out.bar_piece[(size_t)t.num_bars] = (int)pieces.size();
+    // the smallest segment length (a multiple of 4 bins) with which every wavefront's pieces fit its 64 lanes
+    int L = 0;
+    for(int l = 4; l <= 4 * max_blocks && L == 0; l += 4) {
+        std::vector<int> used((size_t)wps, 0);
+        bool ok = true;
+        for(const Piece &q : pieces) {
+            const int k = ((q.lo & 3) + (q.hi - q.lo) + l - 1) / l;
+            used[(size_t)q.wave] += k;
+            ok = ok && k <= 64 && used[(size_t)q.wave] <= 64;
+        }
+        if(ok)
+            L = l;
+    }
+    if(L == 0)
+        return false;
+    out.blocks = L / 4;
+    out.coef.assign((size_t)out.blocks * threads * 4, 0.0f);
+    out.base.assign((size_t)threads, 0);
+    out.info.assign((size_t)threads, 0);
+    for(int w = 0; w < wps; ++w) // lanes without a segment read (and multiply by zero) the first bins of their own wavefront
+        for(int l = 0; l < 64; ++l)
+            out.base[(size_t)(w * 64 + l)] = std::min(256 * w, M - L) & ~3;
+    std::vector<int> next((size_t)wps, 0);
+    for(size_t pi = 0; pi < pieces.size(); ++pi) {
+        const Piece &q = pieces[pi];
+        const int first = q.lo & ~3, k = ((q.lo - first) + (q.hi - q.lo) + L - 1) / L;
+        const int l0 = next[(size_t)q.wave];
+        next[(size_t)q.wave] += k;
+        const int b_off = t.bar_off[(size_t)q.bar], b_lo = t.bar_bin[(size_t)b_off];
+        for(int g = 0; g < k; ++g) {
+            const int lane = l0 + g, s = q.wave * 64 + lane;
+            // bins [bstart, bstart + L); a segment that would reach past its chunk (or the row) moves down, its coefficients with it
+            int bstart = first + g * L;
+            if(bstart + L > std::min(q.cend, M))
+                bstart = std::min(q.cend, M) - L;
+            out.base[(size_t)s] = bstart;
+            for(int j = 0; j < L; ++j) {
+                const int bin = bstart + j;
+                const bool mine = bin >= first + g * L && bin < first + (g + 1) * L && bin >= q.lo && bin < q.hi;
+                if(mine)
+                    out.coef[((size_t)(j / 4) * threads + s) * 4 + (size_t)(j % 4)] = t.bar_coef[(size_t)b_off + (bin - b_lo)];
+            }
+            // the segmented inclusive prefix over lanes [l0, l0 + k): which of the scan's six steps this lane takes
+            int flags = 0;
+            for(int d = 0; d < 4; ++d)
+                if(lane - (1 << d) >= l0 && (lane & 15) >= (1 << d))
+                    flags |= 1 << d;
+            if(lane >= 16 && ((lane >> 4) & 1) && l0 <= (lane & ~15) - 1)
+                flags |= 1 << 4; // rows 1 and 3 add the last lane of the row before them
+            if(lane >= 32 && l0 <= 31)
+                flags |= 1 << 5; // rows 2 and 3 add lane 31
+            out.info[(size_t)s] = flags | (g == k - 1 ? ((wps == 1 ? q.bar : (int)pi) + 1) << 8 : 0);
+        }
+    }
+    out.num_segs = 0;
+    for(int w = 0; w < wps; ++w)
+        out.num_segs += next[(size_t)w];
+    out.num_slots = (int)pieces.size();
+    return true;
+}
+
 bool curve_lanes(const HostTables &t, const wf_config &cfg, int threads, int max_steps, CurveLaneTables &out)
 {
     out = CurveLaneTables{};

@@ -77,6 +77,26 @@ struct BarLaneTables {
 // wave_local: try the layout above first (needs every bar to fit 64 segments and the padded total to fit the threads)
 bool bar_segments(const HostTables &t, int threads, int max_blocks, BarLaneTables &out, bool wave_local = false);
 
+// Wave-private form of the same tables (round 4).  Thread t of a spectrum of `threads` threads with `points` bins each holds
+// bins 4 (t + threads * u) .. + 3, u < points / 4, in registers when the row is finished, i.e. wavefront w = t / 64 owns the
+// 256-bin chunks c = w + (threads / 64) * u.  A bar is cut into PIECES where the owner of its bins changes (never, on one
+// wavefront); the segments of a piece are lanes of the wavefront that owns its bins and read only bins of that wavefront's
+// chunks -- so a wavefront parks its part of the row in LDS and reads it back without waiting for anyone.  The piece's
+// partial sums are added by a segmented prefix scan over the lanes (six DPP steps, flags in `info`), its last lane leaves the
+// total in slot `piece index` of an LDS array, and whichever wavefront arrives last adds the slots of every bar (bar b on
+// lane b: needs num_bars <= 64) in a fixed order.  false when it does not fit (more than 64 segments in one wavefront, more
+// than 64 bars): bar_segments' layouts remain.
+struct BarPieceTables {
+    std::vector<float> coef;    // [blocks][threads][4] lane-major, as BarLaneTables::coef
+    std::vector<int> base;      // [threads] first of the segment's 4 * blocks consecutive bins (inside one chunk of the thread's wavefront)
+    std::vector<int> info;      // [threads] bits 0..5: the scan's steps this lane takes (1, 2, 4, 8 lanes down inside its row of 16; the
+                                // last lane of the previous row; lane 31); bits 8..: 1 + slot when the lane is the last of a piece
+                                // (one wavefront per spectrum: slot = the bar itself)
+    std::vector<int> bar_piece; // [num_bars + 1] bar b owns slots [bar_piece[b], bar_piece[b + 1])
+    int num_slots = 0, blocks = 0, num_segs = 0;
+};
+bool bar_pieces(const HostTables &t, int threads, int points, int max_blocks, BarPieceTables &out);
+
 // Curve mode (one output per thread and step): output o = k * threads + s reads the 8 consecutive dB bins starting at
 // base[o] with coefficients coef[o][0..8) (its composite kernel shifted/zero-padded to 8 taps inside [0, M)); tables are
 // padded to whole steps with zero coefficients.

@@ -68,10 +68,6 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_DEFER_STATE
 #define WF_DEFER_STATE 0 // 1: smoothing-state stores issued behind the display's table requests (p4_split_smooth<.., DEFER>)
 #endif
-#ifndef WF_BAR_COEF_EARLY
-#define WF_BAR_COEF_EARLY 0 // (bar tables requested in front of the smoothing state instead of behind it, so that the dot products need
-                            // no wait of their own: up to 24 more registers across P4 -- 128 VGPRs and 20-36 B of scratch on every geometry from 4096)
-#endif
 #ifndef WF_WPS_SMALL
 #define WF_WPS_SMALL 4 // 8-point geometry (N = 1024): 5 waves per SIMD was +4 % in round 1 (84 VGPRs); with what the kernel has
                        // learned since (paused streams, underflow, bars-only tracking, lanes) it spilled 36 B per lane at the
@@ -414,14 +410,16 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
         }
     }
     WF_STAMP(8);
-#if WF_BAR_COEF_EARLY
-    // the bar tables of this thread, requested in front of the smoothing state: they are in when the state is (vector memory
-    // completes in order), so that the dot products at the end do not begin with a wait that also sits out the row stores
+    // the bar tables of this thread: requested here, in front of P4 and its state stores, where the geometry has the registers
+    // (Policy<G>::BAR_COEF_EARLY) -- else behind the dB math below
+    constexpr bool COEF_EARLY = Policy<G>::BAR_COEF_EARLY && !BLU && DEC == 0 && !BOTH;
     BarEntries<G> bar_entries;
-    bars_fetch_entries<G>(a.bar, t, bar_entries);
-    if(!process && a.bar.out != nullptr)
-        wait_vmem_all(); // (the rare path that skips P4 and its wait)
-#endif
+    bar_entries.base = 0;
+    if constexpr(COEF_EARLY) {
+        bars_fetch_entries<G>(a.bar, t, bar_entries);
+        if(!process && a.bar.out != nullptr)
+            wait_vmem_all(); // (the rare path that skips P4 and its wait)
+    }
     if(process) {
         if constexpr(BLU) {
             if constexpr(MR)
@@ -530,10 +528,8 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
             __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
-#if !WF_BAR_COEF_EARLY
-    BarEntries<G> bar_entries;
-    bars_fetch_entries<G>(a.bar, t, bar_entries);
-#endif
+    if constexpr(!COEF_EARLY)
+        bars_fetch_entries<G>(a.bar, t, bar_entries);
     if constexpr(WF_DEFER_STATE && !BLU && DEC == 0) {
         if(process && !mono_mix)
             p4_store_state<G>(a, t, ts, mag); // behind the table requests (p4_split_smooth<.., DEFER>)
@@ -602,6 +598,14 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
 #ifndef WF_EXP_NO_TAIL
 #define WF_EXP_NO_TAIL 0 // 1 (measurement only, the bars come out wrong): the display phase skipped -- what a tick would cost if the tail were free
 #endif
+#ifndef WF_EXP_TAIL_CUT
+#define WF_EXP_TAIL_CUT 0 // measurement only (wrong bars): 2 = the display phase ends behind the row's LDS copy, 3 = behind the dot products,
+                          // 4 = behind the piece totals' hand-over (no bar is finished); WF_EXP_NO_ARRIVAL_WAIT: the row is parked without
+                          // waiting for the other wavefronts' last reads of the exchange buffer
+#endif
+#ifndef WF_EXP_NO_ARRIVAL_WAIT
+#define WF_EXP_NO_ARRIVAL_WAIT 0
+#endif
     if(a.bar.out != nullptr && !WF_EXP_NO_TAIL) {
         // mono mixdown displays one row per stream: its curve points are shared by the threads of both spectra of the workgroup
         // (the plugin's default configuration: 800 points, 4 steps of 256 threads instead of 7 of 128)
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
                 spectrum_sync<G>();
         };
         // every thread of the spectrum is done reading its exchange buffer
-        if(count_arrivals) {
+        if(count_arrivals && !WF_EXP_NO_ARRIVAL_WAIT) {
             while(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
                 __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
@@ -624,7 +628,16 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
             store_row<RG, BLU>(dbl, t, d, NB);
         if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)
             dbl[MO] = dbl[MO + 1] = 0.0f;
-        row_sync();
+        if(WF_EXP_TAIL_CUT == 2) {
+#ifdef WF_EXP_KEEP_COEFS
+            for(int c = 0; c < BarEntries<G>::CMAX; ++c)
+                if(c < a.bar.lane_blocks)
+                    asm volatile("" ::"v"(bar_entries.coef[c].x), "v"(bar_entries.coef[c].y), "v"(bar_entries.coef[c].z), "v"(bar_entries.coef[c].w), "v"(bar_entries.base));
+#endif
+            return;
+        }
+        if((BLU && !MR) || !a.bar.piece_mode) // (wave-private bar layout: every wavefront reads back only what it has parked itself)
+            row_sync();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
         float *out1 = dup_row ? out0 + a.bar.num_bars : nullptr;
 #ifdef WF_PHASE_TIMING
@@ -661,9 +674,9 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
             else if(a.bar.curve)
                 curve_row<G>(bar_args, have_row, dbl, t, ov);
             else
-                pending = bars_reduce_row<G>(
-                    bar_args, (BLU && !MR) ? bars_preload<G>(a.bar, t) : bar_pre_early, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
-                    [](float v, int m) { return v + __shfl_xor(v, m, 64); });
+                pending = bars_reduce_row<G, !(BLU && !MR)>(
+                    bar_args, (BLU && !MR) ? bars_preload<G, false>(a.bar, t) : bar_pre_early, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
+                    [](float v, int m) { return v + __shfl_xor(v, m, 64); }, arrivals, count_arrivals ? 2 * WPS : WPS);
             if(pending)
                 outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
         }

@@ -76,6 +76,10 @@ struct BarArgs {
     const int *lead_bar;       // [T] the bar whose first segment this thread owns, or -1
     const int *lead_end;       // [T] one past that bar's last segment
     int wave_local;
+    // wave-private layout (BarPieceTables, wf_host_tables.hpp): seg_group = its `info` words, bar_seg = its `bar_piece`; the
+    // segments of a thread read bins its own wavefront parked -- no barrier between parking the row and reading it --, pieces
+    // are summed by a DPP prefix scan and the last wavefront to arrive adds the pieces of every bar
+    int piece_mode;
     int num_segs;
     int lane_blocks;
     // Curve display (render_curve, reference src/source.cpp:1360-1425): num_bars = m_width points per row, point
@@ -171,6 +175,7 @@ struct TickArgs {
     uint32_t *verdict_clear;   // the buffer the next tick ORs into
     // scalars
     float half_coef;           // 0.5f * (2.0f / m_window_sum)
+    float slope_step;          // 3 * m_slope / (M - 1): the slope factor of bin k is 1 + k * slope_step (0: slope off), Policy<G>::SLOPE_LINEAR
     float g, g2;               // get_gravity(seconds), 1 - g
     float vol_comp;            // min(m_volume_target - dbfs(m_input_rms), m_max_gain)
     const float *vol_comp_stream; // [n_streams] the same per stream (wf_hip_set_input_rms), or nullptr: vol_comp for all
@@ -226,6 +231,12 @@ WF_DEV void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 // Cache).  The smoothing state is read once and written once per tick: the hint on its stores alone +-0, on its loads
 // alone +-0, on both +3.7 % (0.701 -> 0.727; 16384 streams 0.69 -> 0.72-0.75) -- then only the rings, whose consecutive
 // windows overlap by 80 %, compete for the cache.  On the window loads themselves the hint costs 2 % (WF_NT_SMP).
+#ifndef WF_SLOPE_LINEAR
+#define WF_SLOPE_LINEAR 1 // Policy<G>::SLOPE_LINEAR
+#endif
+#ifndef WF_BAR_COEF_EARLY
+#define WF_BAR_COEF_EARLY 1 // Policy<G>::BAR_COEF_EARLY
+#endif
 #ifndef WF_NT_ROWS
 #define WF_NT_ROWS true // m_decibels rows stored with the non-temporal hint
 #endif
@@ -294,10 +305,44 @@ WF_DEV float meter_ema(float g, float old, float g2, float cur)
 WF_DEV void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); } // vmcnt(0), the other counters untouched (gfx9 encoding)
 WF_DEV void wave_fence() { __builtin_amdgcn_wave_barrier(); }
 WF_DEV float wave_shfl_down(float v, int d) { return __shfl_down(v, d, 64); } // lane l gets lane l + d's value (its own past the wavefront)
+// Segmented inclusive prefix sum over the lanes of a wavefront: lane l ends up with the sum of the lanes of its segment up to
+// and including itself.  `info` bits 0..5 say which of the six steps of a wave-wide scan this lane takes (BarPieceTables::info:
+// the lanes 1, 2, 4, 8 below it inside its row of 16, the last lane of the row before, lane 31).  Six DPP moves at VALU speed
+// instead of six ds_bpermute round trips; a step not taken adds an exact 0 (the moved value is masked, not multiplied: whatever
+// an unused lane holds stays out).
+WF_DEV float seg_prefix_scan(float v, uint32_t info)
+{
+#define WF_SCAN_STEP(CTRL, ROWS, BIT)                                                                                      \
+    {                                                                                                                      \
+        const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true);                            \
+        v += __int_as_float(o & __builtin_amdgcn_sbfe((int)info, BIT, 1));                                                 \
+    }
+    WF_SCAN_STEP(0x111, 0xf, 0) // row_shr:1
+    WF_SCAN_STEP(0x112, 0xf, 1) // row_shr:2
+    WF_SCAN_STEP(0x114, 0xf, 2) // row_shr:4
+    WF_SCAN_STEP(0x118, 0xf, 3) // row_shr:8
+    WF_SCAN_STEP(0x142, 0xa, 4) // row_bcast:15 into rows 1 and 3
+    WF_SCAN_STEP(0x143, 0xc, 5) // row_bcast:31 into rows 2 and 3
+#undef WF_SCAN_STEP
+    return v;
+}
+// a wavefront counts itself in (LDS atomic, workgroup scope); every lane gets the count before it
+WF_DEV int wave_arrive(int *counter, int lane)
+{
+    int old = 0;
+    asm volatile("" ::: "memory");
+    if(lane == 0)
+        old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    asm volatile("" ::: "memory");
+    return old;
+}
 #else
 WF_DEV void wait_vmem_all() {}
 WF_DEV void wave_fence() {}
 WF_DEV float wave_shfl_down(float v, int) { return v; } // (the emulator does not run the bar reduction)
+WF_DEV float seg_prefix_scan(float v, uint32_t) { return v; }
+WF_DEV int wave_arrive(int *counter, int) { return (*counter)++; }
 #endif
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
@@ -401,6 +446,16 @@ template<class G> struct Policy {
     static constexpr bool PREFETCH_SLOPE = (MODE == 1 || MODE == 3);
     static constexpr bool TOUCH_STATE = (MODE == 2);
     static constexpr bool PREFETCH_LATE = (MODE == 3); // 3: as 1, but requested behind pass 3's stores, under the barrier in front of P4
+    // The slope factors m_slope_modifiers[k] = log10f(10 * powf(1000, k * slope / (M - 1))) (src/source.cpp:1283-1290) are, but for
+    // the roundings of powf and log10f, 1 + 3 k slope / (M - 1): the geometries that request all of P4's operands first (MODE 0)
+    // form them with one fma per bin instead of loading them -- four of the twelve requests of P4's burst and 16 registers across
+    // the real split gone (N = 4096: 0.791 -> 0.803 of the HBM peak, interleaved, profiles/r04a_coef_early.txt); the factors
+    // differ from the reference's table by at most 4e-7 relative (tests/test_cpu_units.py pins it), DESIGN.md section 5.
+    static constexpr bool SLOPE_LINEAR = (WF_SLOPE_LINEAR != 0) && MODE == 0;
+    // The display's per-thread tables (BarEntries) requested in front of P4 instead of behind its state stores: a load at the end
+    // of the kernel waits out the whole loaded memory pipeline once more -- that wait, not the barrier or the shuffles, was the
+    // bars tail (profiles/r04a_tail_cuts.txt).  Needs the registers SLOPE_LINEAR frees (without them: 128 VGPRs + 36 B of scratch).
+    static constexpr bool BAR_COEF_EARLY = (WF_BAR_COEF_EARLY != 0) && SLOPE_LINEAR && G::T >= 128;
 };
 // Pass-1 twiddle rows W_M^(n' k1), k1 = 1..R1-1: only the rows whose k1 is a power of two come from the table; the others
 // are products of two of those (or of one and an earlier product): k1 = hi + lo with lo the lowest set bit.  At R1 = 8 that
@@ -1047,15 +1102,18 @@ template<class G> WF_DEV void p4_store_state(const TickArgs &a, int t, float *ts
         st_state(ts + 4 * (t + G::T * u), f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
 }
 
-template<class G, bool TS, bool FPK, bool DEFER = false>
+struct NoMid { WF_DEV void operator()() const {} };
+// mid(): called between the real split and the smoothing (whose state stores follow): where the kernel requests the display's
+// tables -- in front of the stores in the memory pipeline, behind the registers' peak
+template<class G, bool TS, bool FPK, bool DEFER = false, class Mid = NoMid>
 WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q,
-                                 float (&mag)[G::P])
+                                 float (&mag)[G::P], Mid mid = Mid{})
 {
     constexpr int M = G::M, T = G::T, P = G::P;
     // Threads that did not prefetch state/slope into registers earlier issue ALL of those loads now and consume them only
     // after the whole real split (two loops), so the split math covers their (L2) latency.
     constexpr bool LOAD_ALL_FIRST = !Policy<G>::PREFETCH_STATE;
-    float st_all[LOAD_ALL_FIRST ? P : 4], sl_all[LOAD_ALL_FIRST ? P : 4];
+    float st_all[LOAD_ALL_FIRST ? P : 4], sl_all[(LOAD_ALL_FIRST && !Policy<G>::SLOPE_LINEAR) ? P : 4];
     if(LOAD_ALL_FIRST) {
         WF_UNROLL
         for(int u = 0; u < P / 4; ++u) {
@@ -1064,8 +1122,11 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
                 const f4 o = ld_state(ts + k0);
                 st_all[4 * u] = o.x; st_all[4 * u + 1] = o.y; st_all[4 * u + 2] = o.z; st_all[4 * u + 3] = o.w;
             }
-            const f4 sv = ld4(a.slope + k0);
-            sl_all[4 * u] = sv.x; sl_all[4 * u + 1] = sv.y; sl_all[4 * u + 2] = sv.z; sl_all[4 * u + 3] = sv.w;
+            if(!Policy<G>::SLOPE_LINEAR) {
+                constexpr int S = Policy<G>::SLOPE_LINEAR ? 0 : 1;
+                const f4 sv = ld4(a.slope + k0);
+                sl_all[S * (4 * u)] = sv.x; sl_all[S * (4 * u + 1)] = sv.y; sl_all[S * (4 * u + 2)] = sv.z; sl_all[S * (4 * u + 3)] = sv.w;
+            }
         }
     }
     // this group's state / slope operands, from wherever the policy put them
@@ -1076,6 +1137,10 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
             WF_UNROLL
             for(int i = 0; i < 4; ++i)
                 sl4[i] = q.sl[(Policy<G>::PREFETCH_SLOPE ? 1 : 0) * (4 * u + i)];
+        } else if(LOAD_ALL_FIRST && Policy<G>::SLOPE_LINEAR) {
+            WF_UNROLL // (formed, not loaded: Policy<G>::SLOPE_LINEAR)
+            for(int i = 0; i < 4; ++i)
+                sl4[i] = fmaf((float)(k0 + i), a.slope_step, 1.0f);
         } else if(LOAD_ALL_FIRST) {
             WF_UNROLL
             for(int i = 0; i < 4; ++i)
@@ -1132,6 +1197,7 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
         if(!LOAD_ALL_FIRST)
             group(u);
     }
+    mid();
     // ---- loop 2: slope, temporal smoothing, state store ----------------------------------------------------------------
     if(LOAD_ALL_FIRST) {
         WF_UNROLL
@@ -1143,16 +1209,16 @@ WF_DEV void p4_split_smooth_impl(const TickArgs &a, int t, const cf *lds, float 
 // DEFER: the smoothing-state stores are left to the caller (p4_store_state), which issues them behind the requests for the
 // display's tables: vector memory completes in order, so tables requested behind the state stores are not in before the
 // stores' acknowledgement -- a round trip to HBM the dot products at the end of the kernel then sit out
-template<class G, bool DEFER = false>
-WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[G::P])
+template<class G, bool DEFER = false, class Mid = NoMid>
+WF_DEV void p4_split_smooth(const TickArgs &a, int t, const cf *lds, float *ts, const cf (&wb)[4], const P4Regs<G> &q, float (&mag)[G::P], Mid mid = Mid{})
 {
     if(a.mode & WF_MODE_TSMOOTH) {
         if(a.mode & WF_MODE_FAST_PEAKS)
-            p4_split_smooth_impl<G, true, true, DEFER>(a, t, lds, ts, wb, q, mag);
+            p4_split_smooth_impl<G, true, true, DEFER>(a, t, lds, ts, wb, q, mag, mid);
         else
-            p4_split_smooth_impl<G, true, false, DEFER>(a, t, lds, ts, wb, q, mag);
+            p4_split_smooth_impl<G, true, false, DEFER>(a, t, lds, ts, wb, q, mag, mid);
     } else
-        p4_split_smooth_impl<G, false, false, DEFER>(a, t, lds, ts, wb, q, mag);
+        p4_split_smooth_impl<G, false, false, DEFER>(a, t, lds, ts, wb, q, mag, mid);
 }
 
 // ---- decimated epilogue (DEC > 0): the N >> DEC point transform's bin o is bin o << DEC of the zero-padded one --------------
@@ -1384,11 +1450,25 @@ WF_DEV float lerp_std(float a, float b, float t)
 // the very start of the kernel with the audio window, so that the bars phase at the end does not begin with a chain of
 // dependent table loads.
 struct BarPre { int off, len, count; int s0, s1; int glen; int lead; };
-template<class G> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
+template<class G, bool PIECES = true> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 {
     BarPre p{0, 0, 1, 0, 0, 0, -1};
     if(b.out != nullptr) {
-        if(b.num_segs > 0 && b.wave_local) { // the bar this thread leads, if any
+        if(PIECES && b.num_segs > 0 && b.piece_mode) {
+            // glen: the scan flags and 1 + the slot this lane's piece total goes to.  One wavefront per spectrum: the slot is the
+            // bar itself (lead / count); several: lane l of whichever wavefront arrives last finishes bar l from slots [s0, s1)
+            p.glen = b.seg_group[t];
+            if(G::T == 64) {
+                p.lead = (int)((uint32_t)p.glen >> 8) - 1;
+                if(p.lead >= 0)
+                    p.count = b.count[p.lead];
+            } else if((t & 63) < b.num_bars) {
+                p.lead = t & 63;
+                p.s0 = b.bar_seg[p.lead];
+                p.s1 = b.bar_seg[p.lead + 1];
+                p.count = b.count[p.lead];
+            }
+        } else if(b.num_segs > 0 && b.wave_local) { // the bar this thread leads, if any
             p.lead = b.lead_bar[t];
             p.s0 = t;
             p.s1 = b.lead_end[t]; // one past the last segment of this thread's bar
@@ -1707,9 +1787,13 @@ WF_DEV void outputs_finish(const BarArgs &b, bool has_row, OutVals<G> &ov, float
 // Called by every thread of the workgroup (sync may be a block barrier); `has_row` says whether this spectrum produced one.
 // Returns true when the bars were left in `ov` for outputs_finish (one bar per thread, k = 0), false when they have already
 // been mapped and stored (chunked path; no filter there).
-template<class G, class Sync, class XorSum>
+// arrivals / arrive_last (piece mode, several wavefronts per spectrum): the spectrum's arrival counter in LDS and the value it
+// reads once every wavefront of the spectrum has counted itself in for the last time
+// PIECES == false: the instantiation never runs the wave-private layout (the Bluestein kernels, at their register cap: the host
+// does not build it for them)
+template<class G, bool PIECES = true, class Sync, class XorSum>
 WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntries<G> &be, bool has_row, float *db, float *prod, int t,
-                            float *out_row, float *dup_row, OutVals<G> &ov, Sync sync, XorSum xor_sum)
+                            float *out_row, float *dup_row, OutVals<G> &ov, Sync sync, XorSum xor_sum, int *arrivals = nullptr, int arrive_last = 0)
 {
     constexpr int T = G::T;
     auto emit = [&](int bar, float sum, int cnt) { emit_output(b, bar, sum / (float)cnt, out_row, dup_row); };
@@ -1732,6 +1816,40 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
                 }
             }
             part = (a0 + a1) + (a2 + a3);
+        }
+        if(PIECES && b.piece_mode) {
+            // Every segment read bins its own wavefront parked (LDS operations of a wave execute in order: no barrier in front
+            // of them).  The partials of a piece are added over the lanes; its last lane holds the total.
+            WF_BAR_STAMP(14);
+#if defined(WF_EXP_TAIL_CUT) && WF_EXP_TAIL_CUT == 3
+            asm volatile("" ::"v"(part));
+            return false;
+#endif
+            const uint32_t info = (uint32_t)pre.glen;
+            part = seg_prefix_scan(part, info);
+            const int slot = (int)(info >> 8) - 1;
+            WF_BAR_STAMP(15);
+            if constexpr(T == 64) {
+                if(has_row && slot >= 0)
+                    emit(slot, part, pre.count); // one wavefront: a bar is one piece
+            } else {
+                // the totals meet in LDS behind the row; a wavefront that has left its own counts itself in, and the one that
+                // finds everybody else's count adds the pieces of every bar in slot order -- nobody waits for anybody
+                if(has_row && slot >= 0)
+                    prod[slot] = part;
+                const int before = wave_arrive(arrivals, t & 63);
+#if defined(WF_EXP_TAIL_CUT) && WF_EXP_TAIL_CUT == 4
+                asm volatile("" ::"v"(before));
+                return false;
+#endif
+                if(before == arrive_last - 1 && has_row && pre.lead >= 0) {
+                    float sum = 0.0f;
+                    for(int k = pre.s0; k < pre.s1; ++k)
+                        sum += prod[k];
+                    emit(pre.lead, sum, pre.count);
+                }
+            }
+            return false;
         }
         if(b.wave_local) {
             // every bar lives inside one wavefront: its partials are added by a segmented reduction over the lanes (six
