@@ -21,10 +21,13 @@ torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous), capped at the de
 has -- the line says how many were measured.
 
 One JSON line on rank 0.  Extra objects:
-  roofline       algorithmic bytes per tick / average device time per tick (HIP events on the
-                 library's stream over the same timed region) vs 8 TB/s HBM peak
-  cpu_baseline   the reference's own AVX2 path (oracle/_ref/libwfref.so: verbatim TUs + vendored
-                 FFTW) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  roofline       algorithmic bytes per tick / the wall-clock time per step of the timed region vs 8 TB/s HBM peak
+                 (frac); frac_events (HIP events on the library's stream over the same region), frac_trace (the
+                 committed rocprofv3 kernel trace named in `profile`), cold (the same steps with no lead-in)
+  cpu_baseline   the reference's own classes (oracle/_ref/libwfref.so: verbatim TUs + vendored FFTW) timed on
+                 this box's host cores on a bounded sample (rank 0, N=1 only): WAVSourceAVX2 (value; 1 thread
+                 and all cores) and WAVSourceGeneric (the parity target); every other_configs shape carries
+                 the same at its own fft size
   other_configs  (N=1) the same measurement on the other shapes the north star names: working sets
                  past the 256 MB Infinity Cache (8192 / 16384 streams), BASELINE configs[3]
                  (N=16384 x 1024 streams, TV-EMA + Lanczos bars), configs[1], the configs[4] per-GPU
@@ -85,27 +88,50 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(fft: int, cores: int, budget_core_s: float):
-    """The reference's AVX2+FMA3 path on the host cores, bounded sample."""
+def cpu_baseline(fft: int, cores: int, budget_core_s: float, settings: dict | None = None, classes=("avx2", "generic")):
+    """The reference's own CPU classes on the host cores (oracle/_ref/libwfref.so: verbatim TUs + vendored FFTW), bounded sample:
+    WAVSourceAVX2 (the headline baseline: `value`) and WAVSourceGeneric (the parity target), each on 1 thread and on `cores`
+    threads.  budget_core_s: core-seconds of CPU work for the T-thread run of each class."""
     from oracle import wfref
     if not wfref.available():
         return None
-    settings = dict(fft_size=fft, enable_large_fft=True, channel_mode="stereo", slope=1.0, window="hann",
-                    temporal_smoothing="exp_moving_avg", gravity=0.65)
-    # calibrate on one core, then size the sample to the budget
-    v1, _ = wfref.bench("avx2", settings, 4, 1, 8, 64, hop=HOP, seed=SEED)
-    if v1 <= 0:
+    settings = dict(settings or dict(enable_large_fft=True, channel_mode="stereo", slope=1.0, window="hann",
+                                     temporal_smoothing="exp_moving_avg", gravity=0.65), fft_size=fft)
+    out, streams_per_thread = {}, 8
+    for isa in classes:
+        # calibrate on one core, then size the sample to the budget
+        v1, _ = wfref.bench(isa, settings, 4, 1, 8, 64, hop=HOP, seed=SEED)
+        if v1 <= 0:
+            continue
+        per_core = max(budget_core_s / max(cores, 1), 0.25)          # seconds of work per thread
+        ticks = int(max(32, min(16384, per_core * v1 / (2 * streams_per_thread))))
+        v1, el1 = wfref.bench(isa, settings, streams_per_thread, 1, 8, max(32, ticks // 4), hop=HOP, seed=SEED)
+        n_streams = streams_per_thread * cores
+        v, el = wfref.bench(isa, settings, n_streams, cores, 16, ticks, hop=HOP, seed=SEED)
+        out[isa] = {"value": v, "cores": cores, "value_1_thread": v1, "streams": n_streams, "ticks": ticks, "wall_s": el + el1}
+    if "avx2" not in out:
         return None
-    per_core = max(budget_core_s / max(cores, 1), 0.25)          # seconds of work per thread
-    streams_per_thread = 8
-    ticks = int(max(64, min(16384, per_core * v1 / (2 * streams_per_thread))))
-    n_streams = streams_per_thread * cores
-    v, el = wfref.bench("avx2", settings, n_streams, cores, 16, ticks, hop=HOP, seed=SEED)
-    return {
-        "value": v, "unit": "spectra/s", "cores": cores, "kind": "reference",
-        "sample": f"WAVSourceAVX2::tick_spectrum (verbatim reference + vendored FFTW 3.3.11), {n_streams} stereo streams x "
-                  f"{ticks} ticks, hop {HOP}, FFT {fft}, {cores} threads, {el:.2f} s wall; 1 thread: {v1:.0f} spectra/s",
+    a = out["avx2"]
+    res = {
+        "value": a["value"], "unit": "spectra/s", "cores": cores, "kind": "reference", "class": "WAVSourceAVX2",
+        "value_1_thread": a["value_1_thread"],
+        "sample": f"WAVSourceAVX2::tick_spectrum (verbatim reference + vendored FFTW 3.3.11), {a['streams']} stereo streams x "
+                  f"{a['ticks']} ticks, hop {HOP}, FFT {fft}, {cores} threads, {a['wall_s']:.2f} s wall; 1 thread: {a['value_1_thread']:.0f} spectra/s",
     }
+    if "generic" in out:
+        g = out["generic"]
+        res["generic"] = {"value": g["value"], "value_1_thread": g["value_1_thread"], "cores": cores, "class": "WAVSourceGeneric (the parity target)",
+                          "sample": f"{g['streams']} stereo streams x {g['ticks']} ticks, {g['wall_s']:.2f} s wall"}
+    return res
+
+
+def shape_settings(wf, cfg):
+    """the reference plugin's setting keys for a wf_config (what tests/helpers.ref_settings does; kept here so that bench.py imports
+    nothing from tests/)"""
+    win = {v: k for k, v in wf.WINDOW.items()}[int(cfg.window)]
+    ts = {0: "none", 1: "exp_moving_avg", 2: "tv_exp_moving_avg"}[int(cfg.tsmoothing)]
+    return dict(enable_large_fft=True, auto_fft_size=False, channel_mode="stereo" if cfg.stereo else "mono", window=win,
+                temporal_smoothing=ts, gravity=repr(float(cfg.gravity)), slope=repr(float(cfg.slope)), fast_peaks=bool(cfg.fast_peaks))
 
 
 def host_cores() -> int:
@@ -120,43 +146,55 @@ def host_cores() -> int:
     return n
 
 
-def pmc_profile(shape: str):
-    """The latest committed rocprofv3 summary of this shape (profiles/rNN*_<shape>_pmc.json), or None."""
+def pmc_profile(shape: str, kernel: str):
+    """The latest committed rocprofv3 summary of this shape (profiles/rNN*_<shape>_pmc.json) that was taken on the kernel this
+    run executes (its `kernel` string must equal wf_hip_kernel_name()), or None -- a summary of a kernel that no longer runs
+    is not replayed."""
     best = None
     for p in sorted((ROOT / "profiles").glob(f"r*_{shape}_pmc.json")):
         try:
             d = json.loads(p.read_text())
         except Exception:
             continue
-        if d.get("hbm_bytes_per_launch"):
+        if d.get("hbm_bytes_per_launch") and d.get("kernel") == kernel:
             best = (p.name, d)
     return best
 
 
-def roofline(batch, shape, kernel_ms, flags=0, wall_ms=None):
-    """frac: algorithmic bytes per tick / device time per tick (HIP events on the library's stream, no profiler attached).
-    frac_wall: the same bytes / the barrier-bracketed wall-clock time per step (host launch overhead and the final
-    synchronisation included) -- the figure the driver's own clock reproduces; it sits a few percent under frac.
+def roofline(batch, shape, kernel_ms, flags=0, wall_ms=None, cold_ms=None):
+    """frac: algorithmic bytes per tick / the barrier-bracketed WALL-CLOCK time per step of this run (host launch overhead and the
+    final synchronisation included) -- the figure the driver's own clock reproduces.
+    frac_events: the same bytes / device time per tick (HIP events on the library's stream around the same region): a few
+    percent above frac.
+    frac_trace: the same bytes / tick_span_ns of the committed rocprofv3 kernel trace named in `profile` (profiler attached).
     traffic is NOT measured in this run (PMC counters need rocprofv3 passes of their own): it is replayed from the committed
-    summary named in traffic_source."""
+    summary named in traffic_source, which must have been taken on the kernel this run executes."""
     algo = batch.algorithmic_bytes_per_tick(flags)
-    achieved = algo / (kernel_ms * 1e-3) / 1e9
-    prof = pmc_profile(shape) if shape else None
+    ev = algo / (kernel_ms * 1e-3) / 1e9
+    achieved = algo / (wall_ms * 1e-3) / 1e9 if wall_ms else ev
+    prof = pmc_profile(shape, batch.kernel_name()) if shape else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-           "frac_wall": (algo / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if wall_ms else None,
+           "timed_by": "wall clock per step (barrier + synchronize on both sides)" if wall_ms else "HIP events",
+           "frac_events": ev / HBM_PEAK_GBPS, "achieved_events": ev,
+           "frac_wall": (achieved / HBM_PEAK_GBPS) if wall_ms else None,
            "traffic": (prof[1].get("hbm_bytes_per_tick_all_kernels") or prof[1].get("hbm_bytes_per_tick") or prof[1]["hbm_bytes_per_launch"]) if prof else None,
-           "traffic_source": (f"profiles/{prof[0]} (committed rocprofv3 --pmc passes of this shape; not measured in this run)" if prof else None),
+           "traffic_source": (f"profiles/{prof[0]} (committed rocprofv3 --pmc passes of this shape and kernel; not measured in this run)" if prof else None),
            "kernel": batch.kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_tick": algo,
            "algorithmic_bytes_per_kernel_launch": algo // max(batch.launches_per_tick(), 1),
-           # achieved = algorithmic_bytes_per_tick / kernel_ms.  A tick goes out as kernel_launches_per_tick concurrent
-           # launches of the kernel (lanes on their own HIP streams), timed together by the events (kernel_ms).  rocprofv3's
-           # per-launch average is one slice (algorithmic_bytes_per_kernel_launch) sharing the chip with the others; what
-           # must agree with kernel_ms is the tick span of its kernel trace (profile.tick_span_ms)
+           # A tick goes out as kernel_launches_per_tick launches (lanes on their own HIP streams run concurrently), timed
+           # together by the events (kernel_ms).  rocprofv3's per-launch average is one slice
+           # (algorithmic_bytes_per_kernel_launch) sharing the chip with the others; what must agree with kernel_ms is the tick
+           # span of its kernel trace (profile.tick_span_ms)
            "kernel_launches_per_tick": batch.launches_per_tick()}
+    if cold_ms:
+        out["cold"] = {"ms_per_step": cold_ms, "frac": algo / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                       "what": "the same steps timed the same way as the first thing the process does on the device (no lead-in: the clocks are still ramping)"}
     if prof:
         tr, ks = prof[1].get("trace") or {}, prof[1].get("kernel_stats") or {}
-        out["profile"] = {"file": "profiles/" + prof[0], "tick_span_ms": (tr.get("tick_span_ns") or 0) * 1e-6 or None,
+        span = tr.get("tick_span_ns") or 0
+        out["profile"] = {"file": "profiles/" + prof[0], "tick_span_ms": span * 1e-6 or None,
                           "avg_launch_ms": (ks.get("avg_ns") or 0) * 1e-6 or None, "launches_per_tick": tr.get("launches_per_tick")}
+        out["frac_trace"] = (algo / (span * 1e-9) / 1e9 / HBM_PEAK_GBPS) if span else None
     return out
 
 
@@ -202,16 +240,28 @@ def shape_list(wf):
         ("fft_size 65536 (the reference's maximum, 'enable large FFT'): 256 stereo streams, EMA + slope; rows kernel with the column step and the "
          "real split folded in + epilogue", wf.Config.defaults(fft_size=65536, **ema), 256, 30, 0, "n65536"),
         ("fft_size 800 (the plugin's automatic size at 48 kHz / 60 fps; 400 complex points as mixed radix 25 x 16): 8192 stereo streams, EMA + slope",
-         wf.Config.defaults(fft_size=800, **ema), 8192, 60, 0, "blu800"),
+         wf.Config.defaults(fft_size=800, **ema), 8192, 60, 0, "n800_mixed_radix"),
     ]
     return shapes
 
 
-def other_configs(wf, device):
-    out = []
+def other_configs(wf, device, cpu_cores=0, cpu_core_s=4.0):
+    """cpu_cores > 0: every shape also carries the reference's CPU classes at ITS fft size and settings, a
+    few core-seconds each, once per distinct (fft size, smoothing) pair"""
+    out, cpu_seen = [], {}
     for name, cfg, streams, steps, flags, shape in shape_list(wf):
         try:
-            out.append(measure_shape(wf, name, cfg, streams, steps, 8, device, flags, shape))
+            r = measure_shape(wf, name, cfg, streams, steps, 8, device, flags, shape)
+            r["shape"] = shape
+            if cpu_cores > 0:
+                key = (int(cfg.fft_size), int(cfg.tsmoothing))
+                if key not in cpu_seen:
+                    try:
+                        cpu_seen[key] = cpu_baseline(int(cfg.fft_size), cpu_cores, cpu_core_s, shape_settings(wf, cfg))
+                    except Exception as e:
+                        cpu_seen[key] = {"error": str(e)}
+                r["cpu_baseline"] = cpu_seen[key]
+            out.append(r)
         except Exception as e:  # reported, never required
             out.append({"name": name, "error": str(e)})
     return out
@@ -328,7 +378,7 @@ def configs4_region(wf, torch, dist, rank, world, local_rank, steps, lead_in_ms=
             "gathered_bytes_per_rank_per_tick": int(streams * batch.display_channels * batch.num_bars * 4),
             "gathered_bytes_total_per_tick": int(total * batch.display_channels * batch.num_bars * 4),
             "verified": verified and finite,
-            "verification": "per-rank integer checksum of the float bit patterns of its own bars == checksum of its block in every rank's gathered copy; all values finite",
+            "verification": "per-rank position-weighted integer checksum of the float bit patterns of its own bars == checksum of its block in every rank's gathered copy; all values finite",
             "roofline": roofline(batch, "cfg5shape_8192streams_barsonly", max(dev_ms), flags, wall_ms=wall * 1e3 / steps),
         }
     finally:
@@ -463,6 +513,14 @@ def main():
     # Lead-in: the device's clocks settle after 15-20 ms of load (profiles/r02j_warmup.txt), whatever --warmup says -- a caller
     # that passes a handful of warm-up steps would otherwise time the ramp.  Untimed ticks of the same batch until
     # --lead-in-ms of device time have passed (0 disables); then the W warm-up steps the contract asks for.
+    # the cold figure: the same K steps, timed the same way, as the first thing this process does on the device
+    cold_ms = None
+    if args.lead_in_ms > 0 and gather is None:
+        barrier()
+        tc = time.perf_counter()
+        run(args.steps)
+        barrier()
+        cold_ms = (time.perf_counter() - tc) * 1e3 / args.steps
     lead_in_ticks = 0
     if args.lead_in_ms > 0:
         probe = run(16)
@@ -500,7 +558,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "warmup_total": args.warmup + lead_in_ticks,  # every untimed tick in front of the timed region: lead-in + the W requested
+            "warmup_total": args.warmup + lead_in_ticks + (args.steps if cold_ms else 0),  # every untimed tick in front of the timed region: the cold region, the lead-in, the W requested
             "lead_in": {"ms": args.lead_in_ms, "ticks": lead_in_ticks, "why": "untimed ticks until the device's clocks have settled (15-20 ms of load), in front of the warm-up steps"},
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
@@ -519,7 +577,7 @@ def main():
                                 else f"streams sharded over {world} GPU(s), no data-path collective"),
             },
             "roofline": roofline(batch, "cfg3_n4096" if (args.streams, args.fft, flags) == (STREAMS_PER_GPU, FFT_SIZE, 0) else None, kernel_ms, flags,
-                                 wall_ms=ms_per_step),
+                                 wall_ms=ms_per_step, cold_ms=cold_ms),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -558,7 +616,7 @@ def main():
         except Exception as e:
             print(f"bench.py: pcie_inclusive failed: {e}", file=sys.stderr)
         try:
-            out["other_configs"] = other_configs(wf, local_rank)
+            out["other_configs"] = other_configs(wf, local_rank, 0 if args.no_cpu_baseline else host_cores())
         except Exception as e:
             print(f"bench.py: other_configs failed: {e}", file=sys.stderr)
     if world == 1 and not args.no_other_configs and not args.bars_allgather:

@@ -92,3 +92,18 @@ def test_two_rank_gloo_allgather_matches_single_process(tmp_path, total):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == want.shape
         assert np.array_equal(got, want), f"rank {r}: gathered bars differ from the single-process result"
+
+
+def test_gather_checksum_sees_permutations():
+    """the verification's checksum weighs every bit pattern by its position: two streams swapped inside a rank's block, or
+    a compaction that landed one stream further on, must change it (a plain sum of the bit patterns would not)"""
+    import torch
+    from waveform_amd.dist import bars_checksum
+    g = torch.Generator().manual_seed(5)
+    bars = torch.rand((96, 2, 26), generator=g) * 400.0
+    ref = bars_checksum(bars)
+    swapped = bars.clone()
+    swapped[[3, 40]] = swapped[[40, 3]]
+    rolled = torch.roll(bars, 1, dims=0)
+    assert not torch.equal(bars_checksum(swapped), ref) and not torch.equal(bars_checksum(rolled), ref)
+    assert torch.equal(bars_checksum(bars.clone()), ref)

@@ -12,6 +12,7 @@ OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 CMD=${WF_PROFILE_CMD:-"python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-other-configs $EXTRA"}   # WF_PROFILE_CMD: profile another driver (e.g. tools/meter_bench.py)
+echo "$CMD" | sed "s#$R/##g" > $OUT/cmd.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
 if [ "${WF_PMC_SET:-full}" = "short" ]; then   # HBM bytes only
 for PMC in "FETCH_SIZE" "WRITE_SIZE"; do

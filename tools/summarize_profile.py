@@ -35,36 +35,66 @@ def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None,
         if match in r["Name"]:
             stats = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
             stats_all[r["Name"]] = dict(stats)
-    # launches of one tick may overlap (lanes: wf_hip_tick issues the batch as slices on several HIP streams), so the
-    # per-launch average above is not the time a tick takes: the trace gives that as the steady-state span per tick
+    # What the profiled command said about itself (its JSON line in stats.log): the library's kernel name -- bench.py replays a
+    # summary only for the kernel it was taken on -- and the launches one tick issues.
+    said = {}
+    log = src / "stats.log"
+    if log.exists():
+        for line in log.read_text(errors="replace").splitlines():
+            if line.startswith("{"):
+                try:
+                    d = json.loads(line)
+                except Exception:
+                    continue
+                r = d.get("roofline") or {}
+                said = {"kernel": r.get("kernel") or d.get("kernel"), "launches_per_tick": r.get("kernel_launches_per_tick"),
+                        "algorithmic_bytes_per_tick": r.get("algorithmic_bytes_per_tick")}
+    # The trace: which launches make a tick.  Launches of one tick may overlap (lanes: wf_hip_tick issues the batch as slices
+    # on several HIP streams) or follow each other (the transforms beyond a CU's LDS: rows kernel, then epilogue), and a
+    # command may run several batches one after the other, each on streams of its own (tools/wave_bench.py: three shapes).
+    # So: the batch = the HIP streams whose activity overlaps the last launch's stream in time (sequential batches do not
+    # overlap); a tick of it = one launch of every distinct kernel on every one of those streams; the tick span is
+    # (last end - first start) / ticks over the last 40 % of the batch's ticks (steady state: every profiled command spends
+    # at least half of its ticks on the lead-in its timed region follows), profiler attached.
     trace = {}
     tr = src / "stats" / "stats_kernel_trace.csv"
     if tr.exists():
-        rows = [r for r in csv.DictReader(open(tr)) if match in r["Kernel_Name"]]
-        lanes = len({r["Stream_Id"] for r in rows}) or 1
-        ticks = len(rows) // lanes
-        # steady state = the last 40 % of the ticks: every profiled command spends at least half of its ticks on the lead-in
-        # its timed region follows (the device's clocks settle after 15-20 ms of load)
-        skip = (ticks - max(1, ticks * 2 // 5)) * lanes
-        if ticks > 1:
-            body = rows[skip:]
-            span = max(int(r["End_Timestamp"]) for r in body) - min(int(r["Start_Timestamp"]) for r in body)
-            trace = {"launches": len(rows), "launches_per_tick": lanes, "ticks_in_span": len(body) // lanes,
-                     "tick_span_ns": span / (len(body) // lanes),
-                     "note": "launches of a tick run concurrently on %d HIP stream(s); tick_span_ns = (last end - first start) / ticks "
-                             "over the last 40 %% of the launches (steady state: behind the command's lead-in), profiler attached; "
-                             "kernel_stats averages every launch of the run, lead-in included" % lanes}
+        rows = sorted((r for r in csv.DictReader(open(tr)) if match in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+        if rows:
+            iv = {}
+            for r in rows:
+                a, b = iv.get(r["Stream_Id"], (1 << 62, 0))
+                iv[r["Stream_Id"]] = (min(a, int(r["Start_Timestamp"])), max(b, int(r["End_Timestamp"])))
+            last = rows[-1]["Stream_Id"]
+            la, lb = iv[last]
+            group = {sid for sid, (a, b) in iv.items() if min(b, lb) - max(a, la) > 0.5 * min(b - a, lb - la)}
+            rows = [r for r in rows if r["Stream_Id"] in group]
+            lanes = len(group)
+            names = sorted({r["Kernel_Name"] for r in rows})
+            per_tick = lanes * len(names)
+            if said.get("launches_per_tick") and len(names) == 1:  # (the same kernel twice in sequence: mono mixdown of split geometries)
+                per_tick = max(per_tick, int(said["launches_per_tick"]))
+            ticks = len(rows) // per_tick
+            if ticks > 1:
+                body = rows[(ticks - max(1, ticks * 2 // 5)) * per_tick:]
+                span = max(int(r["End_Timestamp"]) for r in body) - min(int(r["Start_Timestamp"]) for r in body)
+                trace = {"launches": len(rows), "launches_per_tick": per_tick, "concurrent_streams": lanes, "kernels_per_tick": names,
+                         "ticks_in_span": len(body) // per_tick, "tick_span_ns": span / (len(body) // per_tick),
+                         "note": "a tick = one launch of each of %d kernel(s) on each of %d concurrently used HIP stream(s); tick_span_ns = (last end - "
+                                 "first start) / ticks over the last 40 %% of the ticks (steady state: behind the command's lead-in), profiler "
+                                 "attached; kernel_stats averages every launch of the run, lead-in included" % (len(names), lanes)}
     fetch_b = tot.get("FETCH_SIZE", 0) * 1024 * 2
     write_b = tot.get("WRITE_SIZE", 0) * 1024
     cyc = tot.get("GRBM_GUI_ACTIVE", 0) / 8
     out = {
         "tag": tag, "command": command or "python bench.py --steps 30 --warmup 3 --no-cpu-baseline (tools/profile_gpu.sh)",
         "kernel_rocprof_name": kname, "streams": streams, "fft_size": fft,
-        "kernel": kernel or (f"spectrum_tick_kernel<N={fft},T=128,R=8x16x16,SPW=2>" if fft == 4096 else None),
+        "kernel": said.get("kernel") or kernel or (f"spectrum_tick_kernel<N={fft},T=128,R=8x16x16,SPW=2>" if fft == 4096 else None),
+        "algorithmic_bytes_per_tick": said.get("algorithmic_bytes_per_tick"),
         "kernel_stats": stats, "trace": trace, "dispatch": res,
         "hbm_bytes_per_launch": fetch_b + write_b,
         "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
-        "hbm_bytes_per_tick": (fetch_b + write_b) * (trace.get("launches_per_tick", 1) if trace else 1),
+        "hbm_bytes_per_tick": (fetch_b + write_b) * (trace.get("concurrent_streams", 1) if trace else 1),
         # a tick of several different kernels in sequence (the transforms beyond a CU's LDS): per kernel, and their sum
         "kernels": {kn: {"avg_ns": stats_all.get(kn, {}).get("avg_ns"), "calls": stats_all.get(kn, {}).get("calls"),
                          "hbm_bytes_per_launch": cs.get("FETCH_SIZE", 0) * 2048 + cs.get("WRITE_SIZE", 0) * 1024} for kn, cs in per_kernel.items()} if len(per_kernel) > 1 else None,

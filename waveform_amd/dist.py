@@ -60,9 +60,13 @@ def allgather_bars(local, shard: Shard, group=None):
 
 
 def bars_checksum(t):
-    """exact, order-independent checksum of a float32 tensor: the int64 sum of its bit patterns"""
+    """exact, position-dependent checksum of a float32 tensor (int64, wrapping)"""
     import torch
-    return t.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
+    # position-dependent: bit pattern i weighs (i mod 2^20) + 1, summed in wrapping int64 -- values permuted inside a block (streams
+    # in another order, a compaction that landed elsewhere) change it, which a plain sum of the bit patterns would not
+    bits = t.contiguous().view(torch.int32).to(torch.int64).reshape(-1)
+    w = (torch.arange(bits.numel(), dtype=torch.int64, device=bits.device) & 0xFFFFF) + 1
+    return (bits * w).sum().reshape(1)
 
 
 def verify_gathered(full, own, shard: Shard, group=None) -> bool:
