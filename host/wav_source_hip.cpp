@@ -45,6 +45,13 @@ struct HipApi {
     decltype(&wf_hip_set_stream_delay) set_stream_delay = nullptr;
     decltype(&wf_hip_set_stream_audio_ts) set_stream_audio_ts = nullptr;
     decltype(&wf_hip_output_channels) output_channels = nullptr;
+    decltype(&wf_hip_read_display_async) read_display_async = nullptr;
+    decltype(&wf_hip_read_bars) read_bars = nullptr;
+    decltype(&wf_hip_read_vertices) read_vertices = nullptr;
+    decltype(&wf_hip_read_vertex_counts) read_vertex_counts = nullptr;
+    decltype(&wf_hip_num_vertices) num_vertices = nullptr;
+    decltype(&wf_hip_num_bars) num_bars = nullptr;
+    decltype(&wf_hip_display_channels) display_channels = nullptr;
     bool ok = false;
 };
 
@@ -86,6 +93,13 @@ HipApi &api()
         WF_SYM(set_stream_delay)
         WF_SYM(set_stream_audio_ts)
         WF_SYM(output_channels)
+        WF_SYM(read_display_async)
+        WF_SYM(read_bars)
+        WF_SYM(read_vertices)
+        WF_SYM(read_vertex_counts)
+        WF_SYM(num_vertices)
+        WF_SYM(num_bars)
+        WF_SYM(display_channels)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
         auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
@@ -98,6 +112,13 @@ HipApi &api()
 
 std::atomic<uint64_t> g_fallback_ticks{0};
 std::atomic<uint64_t> g_host_rms_updates{0}; // update_input_rms calls that ran the reference's host loop
+std::atomic<uint64_t> g_device_renders{0}, g_host_renders{0}; // render() of HIP-configured spectrum sources: from the device / by the reference's loops
+
+bool device_render_mode()
+{
+    const char *e = std::getenv("WF_HIP_RENDER"); // 0: the reference's render() keeps interpolating and filling vertices on the host
+    return e == nullptr || e[0] != '0';
+}
 
 bool batched_mode()
 {
@@ -152,6 +173,13 @@ struct WFHipGroup {
     float seconds = 1.0f / 60.0f;
     bool failed = false;
     int device = 0;
+    // the display from the device (cfg.bars / cfg.curve with cfg.vertices): bar tops / curve points, vertices and vertex counts
+    // of every member come back with the rows
+    bool display = false;
+    uint32_t disp_ch = 0, points = 0, per_row = 0;
+    float *bars[2] = {nullptr, nullptr};      // page-locked [capacity][disp_ch][points]
+    float *verts[2] = {nullptr, nullptr};     // page-locked [capacity][disp_ch][per_row][4]
+    uint32_t *vcounts[2] = {nullptr, nullptr}; // page-locked [capacity][disp_ch]
 
     bool create(const wf_config &c, int dev)
     {
@@ -167,6 +195,19 @@ struct WFHipGroup {
         N = c.fft_size;
         M = c.fft_size / 2;
         out_ch = ((cap_ch > 1) || c.stereo) ? 2u : 1u; // src/source.cpp:1171
+        display = c.vertices != 0 && a.num_vertices(h) > 0;
+        if(display) {
+            disp_ch = a.display_channels(h);
+            points = a.num_bars(h);
+            per_row = a.num_vertices(h);
+            for(int i = 0; i < 2; ++i) {
+                bars[i] = static_cast<float *>(a.host_alloc((size_t)capacity * disp_ch * points * sizeof(float)));
+                verts[i] = static_cast<float *>(a.host_alloc((size_t)capacity * disp_ch * per_row * 4 * sizeof(float)));
+                vcounts[i] = static_cast<uint32_t *>(a.host_alloc((size_t)capacity * disp_ch * sizeof(uint32_t)));
+                if(bars[i] == nullptr || verts[i] == nullptr || vcounts[i] == nullptr)
+                    return false;
+            }
+        }
         member.assign(capacity, nullptr);
         submitted.assign(capacity, 0);
         frames.assign(capacity, 0);
@@ -206,6 +247,9 @@ struct WFHipGroup {
             if(silent[i]) a.host_free(silent[i]);
             if(sq_stage[i]) a.host_free(sq_stage[i]);
             if(rms_back[i]) a.host_free(rms_back[i]);
+            if(bars[i]) a.host_free(bars[i]);
+            if(verts[i]) a.host_free(verts[i]);
+            if(vcounts[i]) a.host_free(vcounts[i]);
         }
     }
 
@@ -238,6 +282,8 @@ struct WFHipGroup {
         ok = ok && a.read_rows_async(h, 0, capacity, rows[b], silent[b], b) == WF_HIP_OK;
         if(ok && rms_feed)
             ok = a.read_input_rms_async(h, 0, capacity, rms_back[b], b) == WF_HIP_OK;
+        if(ok && display)
+            ok = a.read_display_async(h, 0, capacity, bars[b], verts[b], vcounts[b], b) == WF_HIP_OK;
         rows_valid[b] = ok;
         ++batch;
         n_submitted = 0;
@@ -411,6 +457,8 @@ Registry &registry()
 
 uint64_t WAVSourceHIP::fallback_ticks() { return g_fallback_ticks.load(); }
 uint64_t WAVSourceHIP::host_rms_updates() { return g_host_rms_updates.load(); }
+uint64_t WAVSourceHIP::device_renders() { return g_device_renders.load(); }
+uint64_t WAVSourceHIP::host_renders() { return g_host_renders.load(); }
 
 bool WAVSourceHIP::available()
 {
@@ -491,7 +539,7 @@ bool WAVSourceHIP::hip_configure()
     c.normalize_volume = m_normalize_volume ? 1u : 0u;
     c.volume_target = m_volume_target;
     c.max_gain = m_max_gain;
-    c.bars = 0; // render_bars keeps running on the host from m_decibels in drop-in mode
+    c.bars = 0; // (hip_display_config below sets the display fields where render() is served from the device)
     c.interp_mode = (int32_t)m_interp_mode;
     c.log_scale = m_log_scale ? 1u : 0u;
     c.mirror_freq_axis = m_mirror_freq_axis ? 1u : 0u;
@@ -503,6 +551,18 @@ bool WAVSourceHIP::hip_configure()
     c.min_bar_height = m_min_bar_height;
     c.rounded_caps = m_rounded_caps ? 1u : 0u;
     m_hip_have_prev = false;
+    m_hip_display = m_hip_display_valid = false;
+    const wf_config rows_only = c;
+    if(!c.waveform && !c.meter && device_render_mode() && m_vbuf != nullptr)
+        hip_display_config(c);
+    for(int attempt = 0; attempt < 2; ++attempt) {
+    // (second attempt: the same configuration without the display -- e.g. a filtered curve whose staging the device refuses:
+    // the rows still come from the device, render() keeps interpolating on the host)
+    if(attempt == 1) {
+        if(c.vertices == 0)
+            break;
+        c = rows_only;
+    }
     if(!c.waveform && !c.meter && batched_mode()) {
         // spectrum display: join (or open) the batch of this configuration
         auto &r = registry();
@@ -527,6 +587,8 @@ bool WAVSourceHIP::hip_configure()
                 dev = std::min(std::max(std::atoi(e), 0), ndev - 1);
             auto fresh = std::make_unique<WFHipGroup>();
             if(!fresh->create(c, dev)) {
+                if(c.vertices != 0)
+                    continue; // once more without the display
                 LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
                 return false;
             }
@@ -556,6 +618,14 @@ bool WAVSourceHIP::hip_configure()
         m_slot = slot;
         m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
         m_hip_prev.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
+        m_hip_display = g->display;
+        if(m_hip_display) {
+            m_hip_points = g->points;
+            m_hip_per_row = g->per_row;
+            m_hip_bars.assign((size_t)g->disp_ch * g->points, 0.0f);
+            m_hip_verts.assign((size_t)g->disp_ch * g->per_row * 4, 0.0f);
+            m_hip_vcounts.assign(g->disp_ch, 0u);
+        }
         return true;
     }
     // level meter: join (or open) the batch of this meter configuration.  Meter buffers beyond 65536 samples (meter_buf above
@@ -625,10 +695,21 @@ bool WAVSourceHIP::hip_configure()
         dev = std::min(std::max(std::atoi(e), 0), std::max(api().device_count(), 1) - 1);
     const int rc = api().create(&c, dev, 1, 0, &m_hip);
     if(rc != WF_HIP_OK) {
-        // e.g. WF_HIP_ERR_UNSUPPORTED for a curve + filter combination whose staging does not fit the on-chip buffer
-        LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
         m_hip = nullptr;
+        if(c.vertices != 0)
+            continue; // once more without the display
+        // e.g. WF_HIP_ERR_UNSUPPORTED for a configuration the device refuses
+        LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
         return false;
+    }
+    m_hip_display = c.vertices != 0 && api().num_vertices(m_hip) > 0;
+    if(m_hip_display) {
+        const uint32_t dch = api().display_channels(m_hip);
+        m_hip_points = api().num_bars(m_hip);
+        m_hip_per_row = api().num_vertices(m_hip);
+        m_hip_bars.assign((size_t)dch * m_hip_points, 0.0f);
+        m_hip_verts.assign((size_t)dch * m_hip_per_row * 4, 0.0f);
+        m_hip_vcounts.assign(dch, 0u);
     }
     m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
     m_hip_out.assign((size_t)m_output_channels * (m_fft_size / 2), 0.0f);
@@ -637,6 +718,113 @@ bool WAVSourceHIP::hip_configure()
     m_hip_pushed = (m_display_mode == DisplayMode::WAVEFORM) ? m_fft_size : 0; // update() pre-fills m_fft_size zeros; so does the device
     m_hip_prev.assign((size_t)m_capture_channels * m_hip_pushed, 0.0f);          // ... and those zeros are what tick_waveform expects at the front
     return true;
+    } // (attempts)
+    return false;
+}
+
+// The display part of wf_config (include/wf_config.h) from the members get_settings / update() have set: which of render_bars /
+// render_curve runs (src/source.cpp:1354-1357), its interpolation, filter and geometry.
+void WAVSourceHIP::hip_display_config(wf_config &c) const
+{
+    const bool stepped = m_display_mode == DisplayMode::STEPPED_BAR;
+    if(m_display_mode == DisplayMode::BAR || stepped) {
+        c.bars = 1;
+        c.vertices = stepped ? 3u : 1u;
+    } else if(m_display_mode == DisplayMode::CURVE) {
+        c.curve = 1;
+        c.vertices = (m_render_mode == RenderMode::LINE) ? 2u : 1u;
+    } else
+        return;
+    c.filter_mode = (m_filter_mode != FilterMode::NONE) ? WF_FILTER_GAUSS : WF_FILTER_NONE;
+    c.filter_radius = m_filter_radius;
+    c.step_width = m_step_width;
+    c.step_gap = m_step_gap;
+    c.radial = m_radial ? 1u : 0u;
+}
+
+// a member's (or the synchronous handle's) display of the frame just read back -> the members render() draws from; the bar tops
+// also go where the reference keeps them (m_interp_bufs after render_bars / render_curve), for whoever looks there
+void WAVSourceHIP::hip_collect_display(const float *bars, const float *verts, const uint32_t *counts)
+{
+    std::memcpy(m_hip_bars.data(), bars, m_hip_bars.size() * sizeof(float));
+    std::memcpy(m_hip_verts.data(), verts, m_hip_verts.size() * sizeof(float));
+    std::memcpy(m_hip_vcounts.data(), counts, m_hip_vcounts.size() * sizeof(uint32_t));
+    const size_t channels = m_hip_vcounts.size();
+    for(size_t channel = 0; channel < channels; ++channel)
+        if(m_interp_bufs[channel].size() >= m_hip_points)
+            std::memcpy(m_interp_bufs[channel].data(), m_hip_bars.data() + channel * m_hip_points, (size_t)m_hip_points * sizeof(float));
+    m_hip_display_valid = true;
+}
+
+void WAVSourceHIP::render([[maybe_unused]] gs_effect_t *effect)
+{
+    std::lock_guard lock(m_mtx);
+    // the display modes the device does not draw (level meter: two values; waveform), sources on the CPU path, a frame before
+    // the first device result: the reference's own render
+    const bool spectrum = !m_meter_mode && m_display_mode != DisplayMode::WAVEFORM;
+    // the shader's gradient height / pulse colour follow the smallest y BEFORE the mirror image replaces the upper half
+    // (src/source.cpp:1548-1567); the device hands back the mirrored row, so those two render modes keep the host loops when the
+    // axis is mirrored
+    const bool miny_exact = !m_mirror_freq_axis || (m_render_mode != RenderMode::GRADIENT && m_render_mode != RenderMode::PULSE);
+    if(!spectrum || !using_hip() || !m_hip_display || !m_hip_display_valid || !miny_exact) {
+        if(spectrum && using_hip())
+            g_host_renders.fetch_add(1);
+        WAVSourceGeneric::render(effect);
+        return;
+    }
+    if(m_last_silent && m_hide_on_silent) // src/source.cpp:1349-1352
+        return;
+    if(m_vbuf == nullptr)
+        return;
+    g_device_renders.fetch_add(1);
+    const bool curve = m_display_mode == DisplayMode::CURVE;
+    auto tech = get_shader_tech();
+    // the constants render_bars / render_curve hand to set_shader_vars (src/source.cpp:1368-1373, :1480-1493)
+    const auto center = (float)m_height / 2;
+    const auto bottom = (float)m_height;
+    const auto cpos = m_stereo ? center : bottom;
+    const auto channel_offset = m_channel_spacing * 0.5f;
+    auto border_top = 0.0f, border_bottom = cpos - channel_offset;
+    if(!curve) {
+        border_top = (m_rounded_caps) ? m_cap_radius : 0.0f;
+        border_bottom = (m_rounded_caps && (!m_stereo || (m_channel_spacing > 0))) ? cpos - m_cap_radius : cpos;
+        if(m_channel_spacing > 0)
+            border_bottom -= channel_offset;
+        if(m_min_bar_height > 0)
+            border_bottom -= m_min_bar_height;
+        border_bottom = std::clamp(border_bottom, border_top, cpos);
+    }
+    const auto channels = m_stereo ? 2u : 1u;
+    auto miny = cpos;
+    auto minpos = 0u;
+    for(auto channel = 0u; channel < channels; ++channel)
+        for(auto i = 0u; i < m_hip_points; ++i) {
+            const auto val = m_hip_bars[(size_t)channel * m_hip_points + i];
+            if(val < miny) {
+                miny = val;
+                minpos = i;
+            }
+        }
+    set_shader_vars(cpos, miny, (float)minpos, channel_offset, border_top, border_bottom);
+
+    gs_technique_begin(tech);
+    gs_technique_begin_pass(tech, 0);
+    gs_load_vertexbuffer(m_vbuf);
+    gs_load_indexbuffer(nullptr);
+    auto vbdata = gs_vertexbuffer_get_data(m_vbuf);
+    static_assert(sizeof(vec3) == 4 * sizeof(float), "libobs' vec3 is four floats: what the device's vertex fill writes");
+    for(auto channel = 0u; channel < channels; ++channel) {
+        const auto count = std::min<size_t>(m_hip_vcounts[channel], std::min<size_t>(m_hip_per_row, vbdata->num));
+        std::memcpy(vbdata->points, m_hip_verts.data() + (size_t)channel * m_hip_per_row * 4, count * sizeof(vec3));
+        gs_vertexbuffer_flush(m_vbuf);
+        if(curve)
+            gs_draw((m_render_mode != RenderMode::LINE) ? GS_TRISTRIP : GS_LINESTRIP, 0, (uint32_t)vbdata->num);
+        else if(count > 0)
+            gs_draw(GS_TRIS, 0, (uint32_t)count);
+    }
+    gs_load_vertexbuffer(nullptr);
+    gs_technique_end_pass(tech);
+    gs_technique_end(tech);
 }
 
 void WAVSourceHIP::update(obs_data_t *settings)
@@ -693,6 +881,9 @@ void WAVSourceHIP::tick_spectrum_batched(float seconds)
             m_last_silent = g->silent[last][slot] != 0;
             if(g->rms_feed)
                 m_input_rms = g->rms_back[last][slot]; // as of that batch's tick (for observers; the device uses its own)
+            if(g->display && m_hip_display)
+                hip_collect_display(g->bars[last] + (size_t)slot * g->disp_ch * g->points, g->verts[last] + (size_t)slot * g->disp_ch * g->per_row * 4,
+                                    g->vcounts[last] + (size_t)slot * g->disp_ch);
         }
     }
     if(!ok) {
@@ -859,6 +1050,15 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     for(auto channel = 0u; channel < m_output_channels; ++channel)
         std::memcpy(m_decibels[channel].get(), m_hip_out.data() + (size_t)channel * outsz, outsz * sizeof(float));
     m_last_silent = silent != 0;
+    if(m_hip_display) {
+        std::vector<float> bars(m_hip_bars.size()), verts(m_hip_verts.size());
+        std::vector<uint32_t> counts(m_hip_vcounts.size());
+        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK && a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK &&
+           a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)
+            hip_collect_display(bars.data(), verts.data(), counts.data());
+        else
+            m_hip_display_valid = false; // render() goes back to the host loops over m_decibels
+    }
 }
 
 // Same observable behaviour as WAVSourceGeneric::tick_meter (src/source_generic.cpp:182-269): the audio that tick_meter
@@ -1163,4 +1363,13 @@ void WAVSourceHIP::tick_waveform(float seconds)
     for(auto channel = 0u; channel < m_output_channels; ++channel)
         std::memcpy(m_decibels[channel].get(), m_hip_out.data() + (size_t)channel * outsz, outsz * sizeof(float));
     m_last_silent = silent != 0;
+    if(m_hip_display) {
+        std::vector<float> bars(m_hip_bars.size()), verts(m_hip_verts.size());
+        std::vector<uint32_t> counts(m_hip_vcounts.size());
+        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK && a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK &&
+           a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)
+            hip_collect_display(bars.data(), verts.data(), counts.data());
+        else
+            m_hip_display_valid = false; // render() goes back to the host loops over m_decibels
+    }
 }

@@ -55,14 +55,32 @@ protected:
     size_t m_hip_pushed = 0;           // waveform: frames at the front of m_capturebufs that are already in the device ring
     int m_hip_state = 0;               // what the device was last told: WF_HIP_SHOWN / WF_HIP_HIDDEN / WF_HIP_HIDDEN_TIMEOUT
 
+    // The display from the device (render() override): what render_bars / render_curve would compute from m_decibels -- bar tops
+    // or curve points in pixels, and the vertices they write into the vertex buffer -- comes back with the rows (one frame late
+    // in batched mode); render() only hands it to libobs.  m_hip_display: the handle was created with cfg.bars / curve / vertices.
+    bool m_hip_display = false;
+    bool m_hip_display_valid = false;  // a device frame has been collected since the last update()
+    uint32_t m_hip_points = 0;         // outputs per displayed row (m_num_bars or m_width)
+    uint32_t m_hip_per_row = 0;        // vertices per displayed row (wf_hip_num_vertices)
+    std::vector<float> m_hip_bars;     // [display channels][m_hip_points] pixel y
+    std::vector<float> m_hip_verts;    // [display channels][m_hip_per_row][4]
+    std::vector<uint32_t> m_hip_vcounts; // [display channels] vertices of each channel's draw call
+
     void hip_release();
     bool hip_configure();              // (re)creates m_hip from the members update() has just set
+    void hip_display_config(struct wf_config &c) const; // the display fields of wf_config from the members update() has set
+    void hip_collect_display(const float *bars, const float *verts, const uint32_t *counts);
 
 public:
     using WAVSourceGeneric::WAVSourceGeneric;
     ~WAVSourceHIP() override;
 
     void update(obs_data_t *settings) override;
+    // WAVSource::render (src/source.cpp:1346-1358 -> render_bars :1473-1670 / render_curve :1360-1470) with the interpolation, the
+    // Gaussian filter, the dB -> pixel mapping, the mirror and the vertex loops taken from the device's results: what is left
+    // here is what needs libobs (shader parameters, the vertex buffer, gs_draw).  Falls back to the reference's render() where
+    // the device does not produce the display (level meter, waveform, a failed group, no frame collected yet).
+    void render(gs_effect_t *effect) override;
 
     // true when a gfx950 device and libwaveform_hip.so are available (callbacks::create asks this first)
     static bool available();
@@ -71,6 +89,10 @@ public:
     static uint64_t fallback_ticks();
     // update_input_rms calls served by the reference's host loop (0 for batched sources: the device keeps the RMS window)
     static uint64_t host_rms_updates();
+    // render() calls of HIP-configured spectrum sources: drawn from the device's vertices / handed to the reference's render()
+    // (whose apply_interp_filter*, apply_filter* and vertex loops then ran on the host)
+    static uint64_t device_renders();
+    static uint64_t host_renders();
 
 private:
     void tick_spectrum_batched(float seconds);

@@ -71,7 +71,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 9
+#define WF_HIP_ABI_VERSION 10
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -248,6 +248,14 @@ int wf_hip_readback_done(wf_hip *h, uint32_t slot);
  * wf_hip_readback_done(slot) blocks until both have landed.  The next wf_hip_tick waits (on the device, not the host) for a
  * copy still in flight before it overwrites the rows. */
 int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_rows, uint8_t *pinned_last_silent, uint32_t slot);
+/* What render_bars / render_curve would derive from those rows (src/source.cpp:1378-1425, :1500-1567) and write into the vertex
+ * buffer (:1436-1461, :1576-1659), as the ticks issued so far leave it for streams [first, first+count): the bar tops / curve
+ * points ([count][display_channels][num_bars], pixels), with cfg.vertices the vertices ([count][display_channels][num_vertices][4])
+ * and the vertex count of every row's draw call ([count][display_channels]) -- any of the three pointers may be NULL --, into
+ * page-locked memory behind the rows of the slot's wf_hip_read_rows_async (call that first; the plugin binding's render() override
+ * draws from them one frame later); lands with wf_hip_readback_done(slot) */
+int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_bars, float *pinned_vertices, uint32_t *pinned_counts,
+                              uint32_t slot);
 /* meter batches: m_meter_val ([count][capture_channels], dBFS) and m_last_silent (one byte per stream) as the ticks issued so
  * far leave them, copied into page-locked memory on the readback stream without waiting; wf_hip_readback_done(slot) blocks
  * until both have landed (the plugin's batched mode reads every source's level one video frame late) */

@@ -264,6 +264,8 @@ int wfref_using_hip(wfref_t *h)
 
 uint64_t wfref_hip_fallback_ticks(void) { return WAVSourceHIP::fallback_ticks(); }
 uint64_t wfref_hip_host_rms_updates(void) { return WAVSourceHIP::host_rms_updates(); }
+uint64_t wfref_hip_device_renders(void) { return WAVSourceHIP::device_renders(); }
+uint64_t wfref_hip_host_renders(void) { return WAVSourceHIP::host_renders(); }
 
 float wfref_noise(uint64_t seed, uint32_t stream, uint32_t channel, uint64_t index)
 {

@@ -73,6 +73,10 @@ const char *wfref_class_name(wfref_t *h);
 uint64_t wfref_hip_fallback_ticks(void);
 /* update_input_rms calls of WAVSourceHIP sources that ran on the host (the batched mode feeds the device instead) */
 uint64_t wfref_hip_host_rms_updates(void);
+/* render() calls of WAVSourceHIP spectrum sources that drew from the device's vertices / that ran the reference's own render
+ * (apply_interp_filter*, apply_filter*, the vertex loops) on the host */
+uint64_t wfref_hip_device_renders(void);
+uint64_t wfref_hip_host_renders(void);
 float wfref_gravity(wfref_t *h, float seconds);    /* get_gravity(), src/source.hpp:301-312 */
 float wfref_db_min(void);
 const float *wfref_decibels(wfref_t *h, int ch);   /* m_decibels[ch], fft_size/2 floats */

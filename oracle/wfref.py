@@ -59,6 +59,9 @@ def lib():
     L.wfref_hip_fallback_ticks.argtypes = []
     L.wfref_hip_host_rms_updates.restype = C.c_uint64
     L.wfref_hip_host_rms_updates.argtypes = []
+    for n in ("wfref_hip_device_renders", "wfref_hip_host_renders"):
+        getattr(L, n).restype = C.c_uint64
+        getattr(L, n).argtypes = []
     L.wfref_meter_mode.restype = C.c_int
     L.wfref_meter_mode.argtypes = [vp]
     for name in ("wfref_meter_val", "wfref_meter_buf"):
@@ -273,6 +276,16 @@ class RefSource:
             n = self.L.wfref_draw(self.h, i, C.byref(mode), C.byref(p))
             out.append((mode.value, _arr(p, n * 4).reshape(n, 4).copy() if n else np.zeros((0, 4), np.float32)))
         return out
+
+
+def hip_device_renders() -> int:
+    """render() calls of WAVSourceHIP spectrum sources drawn from the device's vertices"""
+    return int(lib().wfref_hip_device_renders())
+
+
+def hip_host_renders() -> int:
+    """render() calls of WAVSourceHIP spectrum sources that ran the reference's own interpolation and vertex loops"""
+    return int(lib().wfref_hip_host_renders())
 
 
 def hip_host_rms_updates() -> int:

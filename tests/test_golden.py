@@ -116,11 +116,24 @@ def test_reference_plugin_with_hip_tick(name):
     wfref = _hip_env(batched=False)
     cfg = scenarios.make_config(scenarios.SCENARIOS[name]["cfg"])
     before = wfref.hip_fallback_ticks()
+    drawn, on_host = wfref.hip_device_renders(), wfref.hip_host_renders()
     be = scenarios.RefBackend(cfg, isa="hip")
     assert be.src.using_hip, "WAVSourceHIP fell back to the CPU path: the HIP library did not load or no gfx950 device"
     _check(name, be)
     assert be.src.using_hip, "WAVSourceHIP released the device path during the scenario"
     assert wfref.hip_fallback_ticks() == before, "ticks were served by the reference's CPU class"
+    _check_renders(wfref, cfg, drawn, on_host)
+
+
+def _check_renders(wfref, cfg, drawn, on_host):
+    """WAVSourceHIP::render (host/wav_source_hip.cpp): every render() of a spectrum display must have been drawn from the device's
+    bar tops / curve points and vertices -- none handed to the reference's own render_bars / render_curve, i.e. no
+    apply_interp_filter*, apply_filter* or vertex loop on the host (the bars and vertex buffers the scenario compares are then
+    the device's)"""
+    if cfg.meter or cfg.waveform or not (cfg.bars or cfg.curve) or scenarios.no_vertex_buffer(cfg):
+        return
+    assert wfref.hip_host_renders() == on_host, "render() ran the reference's interpolation and vertex loops on the host"
+    assert wfref.hip_device_renders() > drawn, "no render() was served from the device's display"
 
 
 class _OneFrameLate:
@@ -162,12 +175,14 @@ def test_reference_plugin_with_batched_hip_tick(name):
     cfg = scenarios.make_config(sc["cfg"])
     z, meta = _load(name)
     before, rms_before = wfref.hip_fallback_ticks(), wfref.hip_host_rms_updates()
+    drawn, on_host = wfref.hip_device_renders(), wfref.hip_host_renders()
     late = _OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
     assert late.be.src.using_hip
     scenarios.play(late, sc)
     recs = late.finish()
     assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before
     assert wfref.hip_host_rms_updates() == rms_before, "update_input_rms ran on the host: the device RMS producer was not in use"
+    _check_renders(wfref, cfg, drawn, on_host)
     assert len(recs) == meta["n_ticks"]
     silent = np.array([r["silent"] for r in recs], np.uint8)
     assert np.array_equal(silent, z["silent"]), f"{name}: m_last_silent sequence {silent} != reference {z['silent']} (one frame late)"
@@ -181,6 +196,13 @@ def test_reference_plugin_with_batched_hip_tick(name):
         if f"bars_{t}" in z.files:
             err = np.abs(r["bars"].astype(np.float64) - z[f"bars_{t}"])
             assert np.all(err <= 1e-5 * np.abs(z[f"bars_{t}"]) + 2e-3), f"{name} tick {t} bars: max err {err.max():.3e} px"
+        c = 0
+        while f"verts_{t}_c{c}" in z.files:  # the vertex buffer at that channel's gs_draw, filled from the device's vertices one frame later
+            got, want = r["verts"][c], z[f"verts_{t}_c{c}"]
+            assert got.shape == want.shape and np.array_equal(got[..., 0], want[..., 0]), f"{name} tick {t} channel {c}: vertex count / x"
+            err = np.abs(got[..., 1].astype(np.float64) - want[..., 1])
+            assert np.all(err <= 1e-5 * np.abs(want[..., 1]) + 2e-3), f"{name} tick {t} channel {c} vertex y: max err {err.max():.3e} px"
+            c += 1
 
 
 METER_DROPIN = ["meter_rms_stereo", "meter_peak_mono_tv_fastpeaks", "meter_nosmooth_ragged", "meter_silence_cycle", "meter_half_silent",

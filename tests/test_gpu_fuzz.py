@@ -669,15 +669,18 @@ def run_dropin_case(seed, family):
         cfg_dict, steps, sync_ms = draw_wave(seed)
     else:
         cfg_dict, steps, sync_ms = draw(seed, family)
-    cfg_dict = dict(cfg_dict)
-    cfg_dict.pop("vertices", None)  # the plugin's render loop stays the reference's own
+    cfg_dict = dict(cfg_dict)   # (vertices stay: WAVSourceHIP::render draws the plugin's vertex buffer from the device's)
     cfg = scenarios.make_config(cfg_dict)
     sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
     before = wfref.hip_fallback_ticks()
+    drawn, on_host = wfref.hip_device_renders(), wfref.hip_host_renders()
     hip = scenarios.RefBackend(cfg, isa="hip")
     assert hip.src.using_hip, "WAVSourceHIP did not take the device path"
     got = scenarios.play(hip, sc)
     assert hip.src.using_hip and wfref.hip_fallback_ticks() == before, "fell back to the CPU class"
+    if family not in ("meter", "wave"):
+        import test_golden as tg
+        tg._check_renders(wfref, cfg, drawn, on_host)
     want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
     assert len(got) == len(want)
     undo = _undo_db(cfg) if family in ("pow2", "any", "huge") else None
@@ -692,10 +695,11 @@ def run_dropin_case(seed, family):
             assert_levels_close(g["db"], w["db"], x["db"], what + " levels")
             continue
         assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
-        if False:
-            pass
+        if family in ("pow2", "any", "huge"):
+            # rows, and what render() drew from the device's display: bar tops / curve points and the vertex buffer of every gs_draw
+            _compare([g], [w], undo, what, cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)
         else:
-            assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, **({"deep": True} if family in ("pow2", "any", "huge") else {"lin_eps": None}))
+            assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, lin_eps=None)
 
 
 def run_dropin_batched_case(seed, family):
@@ -711,22 +715,22 @@ def run_dropin_batched_case(seed, family):
     os.environ["WF_HIP_BATCHED"] = "1"
     cfg_dict, steps, sync_ms = draw(seed, family)
     cfg_dict = dict(cfg_dict)
-    cfg_dict.pop("vertices", None)
     cfg = scenarios.make_config(cfg_dict)
     sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
     before = wfref.hip_fallback_ticks()
+    drawn, on_host = wfref.hip_device_renders(), wfref.hip_host_renders()
     late = tg._OneFrameLate(scenarios.RefBackend(cfg, isa="hip"))
     assert late.be.src.using_hip
     scenarios.play(late, sc)
     got = late.finish()
     assert late.be.src.using_hip and wfref.hip_fallback_ticks() == before, "fell back to the CPU class"
+    tg._check_renders(wfref, cfg, drawn, on_host)
     want = scenarios.play(scenarios.RefBackend(cfg, isa="generic"), sc)
     assert len(got) == len(want), (len(got), len(want))
     undo = _undo_db(cfg)
     for t, (g, w) in enumerate(zip(got, want)):
         what = f"batched drop-in {family} case {seed} tick {t} ({cfg_dict}, sync {sync_ms} ms)"
-        assert g["silent"] == w["silent"], what + f": m_last_silent {g['silent']} != {w['silent']}"
-        assert_db_close(g["db"], w["db"], what + " rows", undo_db=undo, deep=True)
+        _compare([g], [w], undo, what, cfg_stepped=cfg_dict.get("vertices") == 3, cfg=cfg)  # rows, bars / curve, vertex buffers: one frame late
 
 
 

@@ -1269,6 +1269,37 @@ int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pin
     return WF_HIP_OK;
 }
 
+int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_bars, float *pinned_vertices, uint32_t *pinned_counts,
+                              uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(slot > 1)
+        return fail(h, WF_HIP_ERR_INVALID, "slot is not 0 / 1");
+    if(h->d_bars == nullptr || h->meter)
+        return fail(h, WF_HIP_ERR_INVALID, "the configuration displays neither bars nor a curve (cfg.bars == 0 and cfg.curve == 0)");
+    if((pinned_vertices != nullptr || pinned_counts != nullptr) && h->d_verts == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "configuration has no vertex fill (cfg.vertices == 0)");
+    if(!h->rows_in_flight[slot] || h->read_stream == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_display_async rides on the slot's wf_hip_read_rows_async: call that first");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    // behind the rows' copy on the readback stream (which already waits for the tick, its bars and its vertex fill on every lane);
+    // the next tick waits, on the device, for this slot's event before it overwrites any of them
+    const size_t per = (size_t)h->disp_ch * h->num_bars;
+    if(pinned_bars)
+        WF_HIP_TRY(h, hipMemcpyAsync(pinned_bars, h->d_bars + first * per, count * per * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
+    if(pinned_vertices) {
+        const size_t pv = (size_t)h->disp_ch * h->vtab.per_row;
+        WF_HIP_TRY(h, hipMemcpyAsync(pinned_vertices, h->d_verts + first * pv, count * pv * sizeof(wf::f4), hipMemcpyDeviceToHost, h->read_stream));
+    }
+    if(pinned_counts)
+        WF_HIP_TRY(h, hipMemcpyAsync(pinned_counts, h->d_vert_counts + (size_t)first * h->disp_ch, (size_t)count * h->disp_ch * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
+    return WF_HIP_OK;
+}
+
 int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_levels, uint8_t *pinned_last_silent, uint32_t slot)
 {
     int rc = check_range(h, first, count);
