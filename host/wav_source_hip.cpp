@@ -195,16 +195,20 @@ struct WFHipGroup {
         N = c.fft_size;
         M = c.fft_size / 2;
         out_ch = ((cap_ch > 1) || c.stereo) ? 2u : 1u; // src/source.cpp:1171
-        display = c.vertices != 0 && a.num_vertices(h) > 0;
+        display = (c.bars != 0 || c.curve != 0) && a.num_bars(h) > 0 && (c.curve != 0 || a.num_vertices(h) > 0);
         if(display) {
             disp_ch = a.display_channels(h);
             points = a.num_bars(h);
-            per_row = a.num_vertices(h);
+            per_row = a.num_vertices(h); // 0 for a curve: its points come back, the strip is written on the host
             for(int i = 0; i < 2; ++i) {
                 bars[i] = static_cast<float *>(a.host_alloc((size_t)capacity * disp_ch * points * sizeof(float)));
+                if(bars[i] == nullptr)
+                    return false;
+                if(per_row == 0)
+                    continue;
                 verts[i] = static_cast<float *>(a.host_alloc((size_t)capacity * disp_ch * per_row * 4 * sizeof(float)));
                 vcounts[i] = static_cast<uint32_t *>(a.host_alloc((size_t)capacity * disp_ch * sizeof(uint32_t)));
-                if(bars[i] == nullptr || verts[i] == nullptr || vcounts[i] == nullptr)
+                if(verts[i] == nullptr || vcounts[i] == nullptr)
                     return false;
             }
         }
@@ -283,7 +287,7 @@ struct WFHipGroup {
         if(ok && rms_feed)
             ok = a.read_input_rms_async(h, 0, capacity, rms_back[b], b) == WF_HIP_OK;
         if(ok && display)
-            ok = a.read_display_async(h, 0, capacity, bars[b], verts[b], vcounts[b], b) == WF_HIP_OK;
+            ok = a.read_display_async(h, 0, capacity, bars[b], per_row ? verts[b] : nullptr, per_row ? vcounts[b] : nullptr, b) == WF_HIP_OK;
         rows_valid[b] = ok;
         ++batch;
         n_submitted = 0;
@@ -555,11 +559,12 @@ bool WAVSourceHIP::hip_configure()
     const wf_config rows_only = c;
     if(!c.waveform && !c.meter && device_render_mode() && m_vbuf != nullptr)
         hip_display_config(c);
+    const auto has_display = [](const wf_config &k) { return k.bars != 0 || k.curve != 0; };
     for(int attempt = 0; attempt < 2; ++attempt) {
     // (second attempt: the same configuration without the display -- e.g. a filtered curve whose staging the device refuses:
     // the rows still come from the device, render() keeps interpolating on the host)
     if(attempt == 1) {
-        if(c.vertices == 0)
+        if(!has_display(c))
             break;
         c = rows_only;
     }
@@ -587,7 +592,7 @@ bool WAVSourceHIP::hip_configure()
                 dev = std::min(std::max(std::atoi(e), 0), ndev - 1);
             auto fresh = std::make_unique<WFHipGroup>();
             if(!fresh->create(c, dev)) {
-                if(c.vertices != 0)
+                if(has_display(c))
                     continue; // once more without the display
                 LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
                 return false;
@@ -624,7 +629,7 @@ bool WAVSourceHIP::hip_configure()
             m_hip_per_row = g->per_row;
             m_hip_bars.assign((size_t)g->disp_ch * g->points, 0.0f);
             m_hip_verts.assign((size_t)g->disp_ch * g->per_row * 4, 0.0f);
-            m_hip_vcounts.assign(g->disp_ch, 0u);
+            m_hip_vcounts.assign(g->per_row ? g->disp_ch : 0u, 0u);
         }
         return true;
     }
@@ -696,20 +701,20 @@ bool WAVSourceHIP::hip_configure()
     const int rc = api().create(&c, dev, 1, 0, &m_hip);
     if(rc != WF_HIP_OK) {
         m_hip = nullptr;
-        if(c.vertices != 0)
+        if(has_display(c))
             continue; // once more without the display
         // e.g. WF_HIP_ERR_UNSUPPORTED for a configuration the device refuses
         LogWarn << "HIP spectrum path unavailable for this configuration (" << api().last_error(nullptr) << "); using the CPU path";
         return false;
     }
-    m_hip_display = c.vertices != 0 && api().num_vertices(m_hip) > 0;
+    m_hip_display = has_display(c) && api().num_bars(m_hip) > 0 && (c.curve != 0 || api().num_vertices(m_hip) > 0);
     if(m_hip_display) {
         const uint32_t dch = api().display_channels(m_hip);
         m_hip_points = api().num_bars(m_hip);
         m_hip_per_row = api().num_vertices(m_hip);
         m_hip_bars.assign((size_t)dch * m_hip_points, 0.0f);
         m_hip_verts.assign((size_t)dch * m_hip_per_row * 4, 0.0f);
-        m_hip_vcounts.assign(dch, 0u);
+        m_hip_vcounts.assign(m_hip_per_row ? dch : 0u, 0u);
     }
     m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
     m_hip_out.assign((size_t)m_output_channels * (m_fft_size / 2), 0.0f);
@@ -731,8 +736,10 @@ void WAVSourceHIP::hip_display_config(wf_config &c) const
         c.bars = 1;
         c.vertices = stepped ? 3u : 1u;
     } else if(m_display_mode == DisplayMode::CURVE) {
+        // the points come from the device; render_curve's vertex loop only writes their y into a strip whose x never changes
+        // (src/source.cpp:1443-1460) and stays here: its vertices would be eight times the bytes of the points on the way back
         c.curve = 1;
-        c.vertices = (m_render_mode == RenderMode::LINE) ? 2u : 1u;
+        c.vertices = 0;
     } else
         return;
     c.filter_mode = (m_filter_mode != FilterMode::NONE) ? WF_FILTER_GAUSS : WF_FILTER_NONE;
@@ -747,9 +754,11 @@ void WAVSourceHIP::hip_display_config(wf_config &c) const
 void WAVSourceHIP::hip_collect_display(const float *bars, const float *verts, const uint32_t *counts)
 {
     std::memcpy(m_hip_bars.data(), bars, m_hip_bars.size() * sizeof(float));
-    std::memcpy(m_hip_verts.data(), verts, m_hip_verts.size() * sizeof(float));
-    std::memcpy(m_hip_vcounts.data(), counts, m_hip_vcounts.size() * sizeof(uint32_t));
-    const size_t channels = m_hip_vcounts.size();
+    if(m_hip_per_row) {
+        std::memcpy(m_hip_verts.data(), verts, m_hip_verts.size() * sizeof(float));
+        std::memcpy(m_hip_vcounts.data(), counts, m_hip_vcounts.size() * sizeof(uint32_t));
+    }
+    const size_t channels = m_hip_points ? m_hip_bars.size() / m_hip_points : 0;
     for(size_t channel = 0; channel < channels; ++channel)
         if(m_interp_bufs[channel].size() >= m_hip_points)
             std::memcpy(m_interp_bufs[channel].data(), m_hip_bars.data() + channel * m_hip_points, (size_t)m_hip_points * sizeof(float));
@@ -814,12 +823,31 @@ void WAVSourceHIP::render([[maybe_unused]] gs_effect_t *effect)
     auto vbdata = gs_vertexbuffer_get_data(m_vbuf);
     static_assert(sizeof(vec3) == 4 * sizeof(float), "libobs' vec3 is four floats: what the device's vertex fill writes");
     for(auto channel = 0u; channel < channels; ++channel) {
+        if(curve) {
+            // render_curve's own loop (src/source.cpp:1436-1461): the points' y into the strip
+            auto offset = channel_offset;
+            if(channel)
+                offset = -offset;
+            const auto bot = cpos - offset;
+            const float *pts = m_hip_bars.data() + (size_t)channel * m_hip_points;
+            const auto n = std::min<size_t>(m_hip_points, m_width);
+            for(size_t i = 0; i < n; ++i) {
+                const auto val = pts[i];
+                if(m_render_mode == RenderMode::LINE)
+                    vbdata->points[i].y = channel == 0 ? val : bottom - val;
+                else {
+                    vbdata->points[i * 2].y = channel == 0 ? val : bottom - val;
+                    vbdata->points[(i * 2) + 1].y = bot;
+                }
+            }
+            gs_vertexbuffer_flush(m_vbuf);
+            gs_draw((m_render_mode != RenderMode::LINE) ? GS_TRISTRIP : GS_LINESTRIP, 0, (uint32_t)vbdata->num);
+            continue;
+        }
         const auto count = std::min<size_t>(m_hip_vcounts[channel], std::min<size_t>(m_hip_per_row, vbdata->num));
         std::memcpy(vbdata->points, m_hip_verts.data() + (size_t)channel * m_hip_per_row * 4, count * sizeof(vec3));
         gs_vertexbuffer_flush(m_vbuf);
-        if(curve)
-            gs_draw((m_render_mode != RenderMode::LINE) ? GS_TRISTRIP : GS_LINESTRIP, 0, (uint32_t)vbdata->num);
-        else if(count > 0)
+        if(count > 0)
             gs_draw(GS_TRIS, 0, (uint32_t)count);
     }
     gs_load_vertexbuffer(nullptr);
@@ -882,8 +910,9 @@ void WAVSourceHIP::tick_spectrum_batched(float seconds)
             if(g->rms_feed)
                 m_input_rms = g->rms_back[last][slot]; // as of that batch's tick (for observers; the device uses its own)
             if(g->display && m_hip_display)
-                hip_collect_display(g->bars[last] + (size_t)slot * g->disp_ch * g->points, g->verts[last] + (size_t)slot * g->disp_ch * g->per_row * 4,
-                                    g->vcounts[last] + (size_t)slot * g->disp_ch);
+                hip_collect_display(g->bars[last] + (size_t)slot * g->disp_ch * g->points,
+                                    g->per_row ? g->verts[last] + (size_t)slot * g->disp_ch * g->per_row * 4 : nullptr,
+                                    g->per_row ? g->vcounts[last] + (size_t)slot * g->disp_ch : nullptr);
         }
     }
     if(!ok) {
@@ -1053,8 +1082,8 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     if(m_hip_display) {
         std::vector<float> bars(m_hip_bars.size()), verts(m_hip_verts.size());
         std::vector<uint32_t> counts(m_hip_vcounts.size());
-        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK && a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK &&
-           a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)
+        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK &&
+           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)))
             hip_collect_display(bars.data(), verts.data(), counts.data());
         else
             m_hip_display_valid = false; // render() goes back to the host loops over m_decibels
@@ -1366,8 +1395,8 @@ void WAVSourceHIP::tick_waveform(float seconds)
     if(m_hip_display) {
         std::vector<float> bars(m_hip_bars.size()), verts(m_hip_verts.size());
         std::vector<uint32_t> counts(m_hip_vcounts.size());
-        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK && a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK &&
-           a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)
+        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK &&
+           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)))
             hip_collect_display(bars.data(), verts.data(), counts.data());
         else
             m_hip_display_valid = false; // render() goes back to the host loops over m_decibels

@@ -229,6 +229,9 @@ int wf_hip_push_rms_ragged_async(wf_hip *h, uint32_t first, uint32_t count, cons
 int wf_hip_read_input_rms_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
 /* m_input_rms of streams [first, first+count) as of the last tick */
 int wf_hip_read_input_rms(wf_hip *h, uint32_t first, uint32_t count, float *out);
+/* waits for everything the handle has issued.  With WF_HIP_CANARY=1 in the environment of wf_hip_create every device block of the
+ * handle ends in guard bytes, which this call then reads back: a kernel that wrote past a buffer makes it return
+ * WF_HIP_ERR_RUNTIME with the block named in wf_hip_last_error (a debugging aid: one small copy per block and sync) */
 int wf_hip_sync(wf_hip *h);
 
 /* ---- results ----------------------------------------------------------------------------- */

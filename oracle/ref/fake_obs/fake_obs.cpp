@@ -86,6 +86,7 @@ void destroy_source(obs_source *src)
 void push_audio(obs_source *src, const audio_data *audio, bool muted)
 {
     // index loop: the plugin may add/remove callbacks re-entrantly
+    std::lock_guard lock(src->audio_cb_mtx);
     for(size_t i = 0; i < src->audio_cbs.size(); ++i) {
         auto cb = src->audio_cbs[i];
         cb.first(cb.second, src, audio, muted);
@@ -196,10 +197,12 @@ obs_source_t *obs_weak_source_get_source(obs_weak_source_t *weak) { return weak-
 void obs_weak_source_release(obs_weak_source_t *weak) { delete weak; }
 void obs_source_add_audio_capture_callback(obs_source_t *source, obs_source_audio_capture_t callback, void *param)
 {
+    std::lock_guard lock(source->audio_cb_mtx);
     source->audio_cbs.emplace_back(callback, param);
 }
 void obs_source_remove_audio_capture_callback(obs_source_t *source, obs_source_audio_capture_t callback, void *param)
 {
+    std::lock_guard lock(source->audio_cb_mtx);
     auto &v = source->audio_cbs;
     for(size_t i = 0; i < v.size(); ++i)
         if(v[i].first == callback && v[i].second == param) { v.erase(v.begin() + (long)i); break; }

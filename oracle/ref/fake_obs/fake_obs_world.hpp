@@ -7,6 +7,7 @@
 #pragma once
 #include "obs-module.h"
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -31,6 +32,11 @@ struct obs_source {
     uint32_t flags = 0;
     bool showing = true;
     std::vector<std::pair<obs_source_audio_capture_t, void *>> audio_cbs;
+    // libobs' obs_source::audio_cb_mutex (a recursive pthread mutex): held while the audio thread runs the capture callbacks
+    // (source_signal_audio_data) and by add / remove -- which is why the reference's m_mtx is recursive and its capture_audio only
+    // try_locks for 10 ms (src/source.hpp:98-101, src/source.cpp:1822-1824): update() removes the callback under m_mtx while the
+    // audio thread may be inside it, holding this one
+    std::recursive_mutex audio_cb_mtx;
 };
 
 namespace fakeobs {

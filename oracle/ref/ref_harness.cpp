@@ -21,6 +21,7 @@
 #include <memory>
 #include <mutex>
 #include <numbers>
+#include <shared_mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -272,6 +273,148 @@ float wfref_noise(uint64_t seed, uint32_t stream, uint32_t channel, uint64_t ind
     return wf_synth_noise(seed, stream, channel, index);
 }
 
+// ---- threads, as OBS runs a source (src/source.hpp:98-101) ---------------------------------------------------------------------
+// One "audio" thread per source pushes 10 ms packets through the capture callback (capture_audio try_locks m_mtx for 10 ms and
+// drops the packet otherwise, src/source.cpp:1822-1824), one "video" thread ticks and renders every source once per frame, one
+// "UI" thread calls update() on random sources -- with a new FFT size now and then, so that buffers, plans and (WAVSourceHIP)
+// the device group membership change under the other threads' feet -- and destroys / re-creates random sources (the harness
+// keeps a source alive while a thread is inside it, as libobs' reference counting does).  After `seconds` everything stops and
+// the sources are checked against fresh ones of the same class on a deterministic serial script: after the chaos a source
+// (and, for WAVSourceHIP, its group) must compute exactly what a new one computes.
+// Returns 0; 1..: that many sources differ from a fresh one; -1: a source could not be created.  stats[6] = ticks, packets,
+// updates, re-creations, render calls, sources compared.
+int wfref_thread_stress(const char *isa, const char *settings, int n_sources, double seconds, uint64_t seed, uint64_t *stats)
+{
+    struct Slot {
+        std::shared_mutex life; // shared: a thread is inside the source; exclusive: it is being destroyed / re-created
+        wfref_t *h = nullptr;
+    };
+    std::vector<Slot> slots((size_t)n_sources);
+    for(auto &sl : slots) {
+        sl.h = wfref_create(isa, settings, 48000, 2, 60, 1);
+        if(sl.h == nullptr)
+            return -1;
+    }
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> n_ticks{0}, n_packets{0}, n_updates{0}, n_recreate{0}, n_render{0};
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_ns = [&] { return 1000000000ull + (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::vector<std::thread> threads;
+    for(int i = 0; i < n_sources; ++i)
+        threads.emplace_back([&, i] { // audio thread of source i: 480 frames every millisecond (ten times real time)
+            std::vector<float> a(2 * 480);
+            const auto key0 = wf_synth_key(seed, (uint32_t)i, 0), key1 = wf_synth_key(seed, (uint32_t)i, 1);
+            uint64_t pos = 0;
+            while(!stop.load(std::memory_order_relaxed)) {
+                for(int k = 0; k < 480; ++k) {
+                    a[(size_t)k] = wf_synth_sample(key0, pos + (uint64_t)k);
+                    a[480 + (size_t)k] = wf_synth_sample(key1, pos + (uint64_t)k);
+                }
+                pos += 480;
+                {
+                    std::shared_lock alive(slots[(size_t)i].life);
+                    const uint64_t now = now_ns();
+                    fakeobs::set_clock_ns(now);
+                    wfref_push_audio(slots[(size_t)i].h, a.data(), a.data() + 480, 480, now - audio_frames_to_ns(48000, 480), 0);
+                }
+                n_packets.fetch_add(1, std::memory_order_relaxed);
+                std::this_thread::sleep_for(std::chrono::microseconds(1000));
+            }
+        });
+    threads.emplace_back([&] { // video thread: tick every source, then render every source
+        while(!stop.load(std::memory_order_relaxed)) {
+            for(auto &sl : slots) {
+                std::shared_lock alive(sl.life);
+                fakeobs::set_clock_ns(now_ns());
+                wfref_tick(sl.h, 1.0f / 60.0f);
+                n_ticks.fetch_add(1, std::memory_order_relaxed);
+            }
+            for(auto &sl : slots) {
+                std::shared_lock alive(sl.life);
+                wfref_render(sl.h);
+                n_render.fetch_add(1, std::memory_order_relaxed);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(1500));
+        }
+    });
+    threads.emplace_back([&] { // UI thread
+        uint64_t r = seed * 6364136223846793005ull + 1442695040888963407ull;
+        auto next = [&] { r = r * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(r >> 33); };
+        const char *sizes[] = {"fft_size=1024", "fft_size=2048", "fft_size=4096", "fft_size=4096", "fft_size=800"};
+        while(!stop.load(std::memory_order_relaxed)) {
+            auto &sl = slots[next() % (uint32_t)n_sources];
+            const uint32_t what = next() % 8u;
+            if(what == 0) { // destroy + create
+                std::unique_lock gone(sl.life);
+                wfref_destroy(sl.h);
+                sl.h = wfref_create(isa, settings, 48000, 2, 60, 1);
+                n_recreate.fetch_add(1, std::memory_order_relaxed);
+            } else {
+                std::shared_lock alive(sl.life);
+                fakeobs::set_clock_ns(now_ns());
+                if(what < 4)
+                    wfref_update(sl.h, sizes[next() % 5u]);
+                else if(what == 4)
+                    wfref_show(sl.h, (int)(next() & 1u));
+                else
+                    wfref_update(sl.h, "");
+                n_updates.fetch_add(1, std::memory_order_relaxed);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(2500));
+        }
+    });
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop.store(true);
+    for(auto &t : threads)
+        t.join();
+    // after the chaos: every survivor, reset by update(), against a fresh source of the same class on one serial script
+    int differ = 0;
+    const int hop = 800, script_ticks = 12;
+    std::vector<float> a(2 * (size_t)hop);
+    std::vector<wfref_t *> fresh((size_t)n_sources, nullptr);
+    for(int i = 0; i < n_sources; ++i) {
+        fresh[(size_t)i] = wfref_create(isa, settings, 48000, 2, 60, 1);
+        if(fresh[(size_t)i] == nullptr)
+            return -1;
+        wfref_show(slots[(size_t)i].h, 1);
+        wfref_update(slots[(size_t)i].h, "fft_size=2048");
+        wfref_update(fresh[(size_t)i], "fft_size=2048");
+    }
+    uint64_t now = now_ns() + 1000000000ull;
+    for(int t = 0; t < script_ticks; ++t) {
+        now += audio_frames_to_ns(48000, (uint64_t)hop);
+        for(int i = 0; i < n_sources; ++i) {
+            const auto key0 = wf_synth_key(seed ^ 0x55, (uint32_t)i, 0), key1 = wf_synth_key(seed ^ 0x55, (uint32_t)i, 1);
+            for(int k = 0; k < hop; ++k) {
+                a[(size_t)k] = wf_synth_sample(key0, (uint64_t)t * (uint64_t)hop + (uint64_t)k);
+                a[(size_t)hop + (size_t)k] = wf_synth_sample(key1, (uint64_t)t * (uint64_t)hop + (uint64_t)k);
+            }
+            wfref_feed_and_tick(slots[(size_t)i].h, a.data(), a.data() + hop, (uint32_t)hop, now, 1.0f / 60.0f);
+            wfref_feed_and_tick(fresh[(size_t)i], a.data(), a.data() + hop, (uint32_t)hop, now, 1.0f / 60.0f);
+        }
+    }
+    for(int i = 0; i < n_sources; ++i) {
+        const size_t n = wfref_fft_size(slots[(size_t)i].h) / 2;
+        bool same = wfref_fft_size(fresh[(size_t)i]) / 2 == n && wfref_last_silent(slots[(size_t)i].h) == wfref_last_silent(fresh[(size_t)i]);
+        for(int c = 0; c < 2 && same; ++c)
+            same = std::memcmp(wfref_decibels(slots[(size_t)i].h, c), wfref_decibels(fresh[(size_t)i], c), n * sizeof(float)) == 0;
+        differ += same ? 0 : 1;
+    }
+    if(stats) {
+        stats[0] = n_ticks.load(); stats[1] = n_packets.load(); stats[2] = n_updates.load(); stats[3] = n_recreate.load();
+        stats[4] = n_render.load(); stats[5] = (uint64_t)n_sources;
+    }
+    for(int i = 0; i < n_sources; ++i) {
+        wfref_destroy(fresh[(size_t)i]);
+        wfref_destroy(slots[(size_t)i].h);
+    }
+    return differ;
+}
+
+// wfref_bench with a video_render behind every frame's ticks (what OBS does: tick every source, then render every source)
+static std::atomic<int> g_bench_render{0};
+void wfref_bench_set_render(int on) { g_bench_render.store(on); }
+
 double wfref_bench(const char *isa, const char *settings, uint32_t sample_rate, int channels, int n_streams, int n_threads,
                    int warmup_ticks, int timed_ticks, int hop, uint64_t seed, double *elapsed_s)
 {
@@ -316,6 +459,9 @@ double wfref_bench(const char *isa, const char *settings, uint32_t sample_rate, 
                         wfref_feed_and_tick(streams[(size_t)s], noise[0].data() + off, (cap_ch > 1) ? noise[1].data() + off : nullptr,
                                             (uint32_t)hop, now, 1.0f / 60.0f);
                     }
+                    if(g_bench_render.load(std::memory_order_relaxed))
+                        for(int s = lo; s < hi; ++s)
+                            wfref_render(streams[(size_t)s]);
                 }
             };
             run(warmup_ticks, 0);

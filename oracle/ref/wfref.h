@@ -107,6 +107,16 @@ double wfref_bench(const char *isa, const char *settings, uint32_t sample_rate, 
                    int n_streams, int n_threads, int warmup_ticks, int timed_ticks, int hop,
                    uint64_t seed, double *elapsed_s);
 
+/* The source under OBS' threads (src/source.hpp:98-101): one audio thread per source pushing packets through the capture callback,
+ * a video thread ticking and rendering every source, a UI thread calling update() / show / hide / destroy + create on random
+ * ones, for `seconds`; then every source against a fresh one of the same class on a serial script.  Returns the number of
+ * sources that differ (0 = pass), -1 if a source could not be created.  stats[6]: ticks, packets, updates, re-creations,
+ * renders, sources compared. */
+int wfref_thread_stress(const char *isa, const char *settings, int n_sources, double seconds, uint64_t seed, uint64_t *stats);
+
+/* != 0: every frame of wfref_bench also renders every source (video_render behind the frame's ticks, as OBS does) */
+void wfref_bench_set_render(int on);
+
 /* counter-hash white noise shared by oracle, harness and device generator */
 float wfref_noise(uint64_t seed, uint32_t stream, uint32_t channel, uint64_t index);
 

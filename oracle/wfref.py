@@ -278,6 +278,16 @@ class RefSource:
         return out
 
 
+def thread_stress(isa: str, settings: dict | None, n_sources: int, seconds: float, seed: int = 7):
+    """(sources that differ from a fresh one after the run, stats dict) -- wfref_thread_stress (oracle/ref/wfref.h)"""
+    L = lib()
+    L.wfref_thread_stress.restype = C.c_int
+    L.wfref_thread_stress.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_uint64, C.POINTER(C.c_uint64)]
+    st = (C.c_uint64 * 6)()
+    rc = L.wfref_thread_stress(isa.encode(), settings_str(settings), n_sources, seconds, seed, st)
+    return rc, dict(zip(("ticks", "packets", "updates", "recreations", "renders", "sources"), (int(v) for v in st)))
+
+
 def hip_device_renders() -> int:
     """render() calls of WAVSourceHIP spectrum sources drawn from the device's vertices"""
     return int(lib().wfref_hip_device_renders())
@@ -303,9 +313,10 @@ def db_min() -> float:
 
 
 def bench(isa: str, settings: dict | None, n_streams: int, n_threads: int, warmup: int, ticks: int, hop: int = 800,
-          sample_rate: int = 48000, channels: int = 2, seed: int = 0x5741564546524D31):
-    """Returns (spectra_per_s, elapsed_s) for the reference CPU path."""
+          sample_rate: int = 48000, channels: int = 2, seed: int = 0x5741564546524D31, render: bool = False):
+    """Returns (spectra_per_s, elapsed_s) for the reference CPU path.  render: every frame also renders every source."""
     el = C.c_double(0.0)
+    lib().wfref_bench_set_render(1 if render else 0)
     v = lib().wfref_bench(isa.encode(), settings_str(settings), sample_rate, channels, n_streams, n_threads, warmup,
                           ticks, hop, seed, C.byref(el))
     return float(v), float(el.value)

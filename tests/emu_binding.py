@@ -8,7 +8,8 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
-LIB_PATH = ROOT / "build" / "libwfemu.so"
+import os
+LIB_PATH = Path(os.environ["WFEMU_LIBRARY"]) if os.environ.get("WFEMU_LIBRARY") else ROOT / "build" / "libwfemu.so"  # WFEMU_LIBRARY: the sanitizer build
 _lib = None
 
 

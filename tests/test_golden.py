@@ -433,3 +433,58 @@ def test_sixty_four_sources_share_one_batch():
     print(f"\nplugin mode, 64 sources x FFT 4096 stereo: batched HIP {us_hip:.1f} us per source and frame, reference AVX2 {us_avx:.1f} us")
     assert wfref.hip_fallback_ticks() == before
     assert us_hip < us_avx, f"the batched device path ({us_hip:.1f} us per source) does not beat the reference's AVX2 tick ({us_avx:.1f} us)"
+    # tick + render per source and frame: the reference's AVX2 class (FMA3 interpolation in render), WAVSourceHIP with the
+    # reference's render() on the host (WF_HIP_RENDER=0), and WAVSourceHIP drawing from the device's display
+    for disp, extra in (("26 Lanczos bars", dict(display_mode="bars", interp_mode="lanczos")), ("800-point Catmull-Rom curve", dict(display_mode="curve", interp_mode="catmull_rom"))):
+        st = dict(settings, **extra)
+        drawn, on_host = wfref.hip_device_renders(), wfref.hip_host_renders()
+        v_dev, _ = wfref.bench("hip", st, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED, render=True)
+        assert wfref.hip_device_renders() > drawn and wfref.hip_host_renders() - on_host <= 64, "the timed frames were not drawn from the device's display"
+        os.environ["WF_HIP_RENDER"] = "0"
+        try:
+            v_host, _ = wfref.bench("hip", st, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED, render=True)
+        finally:
+            del os.environ["WF_HIP_RENDER"]
+        v_ref, _ = wfref.bench("avx2", st, 64, 1, 20, 300, hop=hop, seed=scenarios.SEED, render=True)
+        print(f"plugin mode, 64 sources x FFT 4096 stereo, {disp}, tick + render per source and frame: display from the device "
+              f"{2e6 / v_dev:.1f} us, device rows + the reference's render on the host {2e6 / v_host:.1f} us, reference AVX2 {2e6 / v_ref:.1f} us")
+        assert v_dev > v_ref
+
+
+@pytest.mark.gpu
+def test_canary_guards_behind_every_device_block(monkeypatch):
+    """there is no compute-sanitizer on this stack, so with WF_HIP_CANARY=1 every device block of a handle
+    ends in 256 guard bytes that wf_hip_sync reads back.  Every golden scenario once more with the guards armed -- spectrum at
+    every kind of FFT size, bars, curves, filters, vertex fill, level meter, waveform display, volume normalisation -- and a sync
+    after every tick: no kernel writes past a buffer.  And the check itself: one word written behind m_decibels (through the
+    HIP runtime, from outside the library) turns the next sync into WF_HIP_ERR_RUNTIME naming the block."""
+    import ctypes as C
+    import waveform_amd as wf
+    monkeypatch.setenv("WF_HIP_CANARY", "1")
+    for name in NAMES:
+        sc = scenarios.SCENARIOS[name]
+        cfg = scenarios.make_config(sc["cfg"])
+        be = scenarios.HipBackend(cfg, streams=5, probe=2)
+        try:
+            real_tick = be.tick
+
+            def tick(seconds, _t=real_tick, _b=be):
+                _t(seconds)
+                _b.batch.sync()  # raises WfHipError if a guard was touched
+            be.tick = tick
+            scenarios.play(be, sc)
+            be.batch.sync()
+        finally:
+            be.close()
+    cfg = wf.Config.defaults(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+    with wf.SpectrumBatch(cfg, 3) as b:
+        b.push_synth(scenarios.SEED, 0, 800)
+        b.tick()
+        b.sync()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        end_of_rows = b.decibels_device_ptr() + 3 * b.output_channels * b.bins * 4
+        assert hip.hipMemset(C.c_void_p(end_of_rows + 8), 0, 4) == 0 and hip.hipDeviceSynchronize() == 0
+        with pytest.raises(wf.WfHipError) as e:
+            b.sync()
+        assert "WF_HIP_CANARY" in str(e.value) and "past its end" in str(e.value), str(e.value)

@@ -282,6 +282,8 @@ void dev_release(wf_hip *h, void *p)
             h->allocs.pop_back();
             break;
         }
+    // (its guard entry goes with it: the next block may get the same address with another size)
+    h->guards.erase(std::remove_if(h->guards.begin(), h->guards.end(), [p](const auto &g) { return g.first == p; }), h->guards.end());
     (void)hipFree(p);
 }
 
@@ -1109,6 +1111,11 @@ int wf_hip_sync(wf_hip *h)
     WF_HIP_TRY(h, hipSetDevice(h->device));
     WF_TRY_RC(join_lanes(h));
     WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if(h->canary) { // (everything that can write has drained: the side streams too)
+        if(h->copy_stream) WF_HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+        if(h->read_stream) WF_HIP_TRY(h, hipStreamSynchronize(h->read_stream));
+        return check_canaries(h);
+    }
     return WF_HIP_OK;
 }
 

@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "wf_hip.h"
@@ -163,6 +164,8 @@ struct wf_hip {
     float *d_stage = nullptr;
     size_t stage_floats = 0;
     std::vector<void *> allocs;
+    bool canary = false;                                  // WF_HIP_CANARY=1 at create: guard bytes behind every block, checked by wf_hip_sync
+    std::vector<std::pair<void *, size_t>> guards;        // (block, payload bytes) of every guarded block still alive
     std::string last_error;
     std::string kernel_name;
     // launch description, fixed at create
@@ -193,14 +196,25 @@ int fail(wf_hip *h, int code, const char *fmt, ...) __attribute__((format(printf
                         __LINE__);                                                                                \
     } while(0)
 
+// Every device block carries 256 bytes of slack behind its payload (some kernels read -- never write -- a few words past a row).
+// With WF_HIP_CANARY=1 in the environment of wf_hip_create the slack is a guard: filled with GUARD_BYTE when the block is made,
+// checked by wf_hip_sync (check_canaries): a kernel that wrote past its buffer turns the next sync into WF_HIP_ERR_RUNTIME
+// naming the block (there is no compute-sanitizer on this stack).
+constexpr size_t GUARD_BYTES = 256;
+constexpr int GUARD_BYTE = 0xA5;
+int guard_block(wf_hip *h, void *p, size_t payload_bytes); // wf_hip_plan.hip
+int check_canaries(wf_hip *h);                             // wf_hip_plan.hip
+
 template<class T> int dev_alloc(wf_hip *h, T **out, size_t count)
 {
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, count * sizeof(T) + 256);
+    hipError_t e = hipMalloc(&p, count * sizeof(T) + GUARD_BYTES);
     if(e != hipSuccess)
         return fail(h, WF_HIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
     h->allocs.push_back(p);
     *out = static_cast<T *>(p);
+    if(h->canary)
+        return guard_block(h, p, count * sizeof(T));
     return WF_HIP_OK;
 }
 

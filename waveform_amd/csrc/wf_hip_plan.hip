@@ -37,6 +37,34 @@ int fail(wf_hip *h, int code, const char *fmt, ...)
     return code;
 }
 
+int guard_block(wf_hip *h, void *p, size_t payload_bytes)
+{
+    hipError_t e = hipMemsetAsync(static_cast<char *>(p) + payload_bytes, GUARD_BYTE, GUARD_BYTES, h->stream);
+    if(e != hipSuccess)
+        return fail(h, WF_HIP_ERR_RUNTIME, "hipMemsetAsync of a guard failed: %s", hipGetErrorString(e));
+    h->guards.emplace_back(p, payload_bytes);
+    return WF_HIP_OK;
+}
+
+// the guard bytes of every live block, read back and compared (the caller has synchronised the handle's streams)
+int check_canaries(wf_hip *h)
+{
+    if(!h->canary)
+        return WF_HIP_OK;
+    unsigned char buf[GUARD_BYTES];
+    for(size_t i = 0; i < h->guards.size(); ++i) {
+        const auto &g = h->guards[i];
+        hipError_t e = hipMemcpy(buf, static_cast<char *>(g.first) + g.second, GUARD_BYTES, hipMemcpyDeviceToHost);
+        if(e != hipSuccess)
+            return fail(h, WF_HIP_ERR_RUNTIME, "reading a guard back failed: %s", hipGetErrorString(e));
+        for(size_t b = 0; b < GUARD_BYTES; ++b)
+            if(buf[b] != (unsigned char)GUARD_BYTE)
+                return fail(h, WF_HIP_ERR_RUNTIME, "WF_HIP_CANARY: device block %zu of %zu (%zu payload bytes) was written %zu bytes past its end",
+                            i, h->guards.size(), g.second, b + 1);
+    }
+    return WF_HIP_OK;
+}
+
 } // namespace wf::host
 
 namespace {
@@ -82,6 +110,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     h->cfg = *cfg;
     h->tab = std::move(tab);
     h->device = device;
+    if(const char *e = std::getenv("WF_HIP_CANARY")) // guard bytes behind every device block, checked by wf_hip_sync
+        h->canary = e[0] == '1';
     h->n_streams = max_streams;
     h->N = cfg->fft_size;
     h->M = cfg->fft_size / 2;
@@ -484,7 +514,9 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // give back what the first plan uploaded, forget what it decided, plan again for big_outputs_kernel
             WF_CREATE_HIP(hipStreamSynchronize(h->stream));
             while(h->allocs.size() > mark) {
-                (void)hipFree(h->allocs.back());
+                void *gone = h->allocs.back();
+                h->guards.erase(std::remove_if(h->guards.begin(), h->guards.end(), [gone](const auto &g) { return g.first == gone; }), h->guards.end());
+                (void)hipFree(gone);
                 h->allocs.pop_back();
             }
             h->d_bar_coef = nullptr; h->d_bar_bin = nullptr; h->d_bar_off = nullptr; h->d_band_widths = nullptr; h->d_bar_chunk = nullptr;
