@@ -561,12 +561,12 @@ def test_starved_tick_in_the_middle_of_a_mono_mixdown(n):
                 assert_db_close(got[0][:1], want, f"N={n} tick {t}", deep=True)
 
 
-@pytest.mark.parametrize("n,loud,quiet", [(4096, 2000.0, 1e-24), (65536, 200.0, 1e-24), (800, 2000.0, 1e-24), (30000, 8.0, 1e-16)])
+@pytest.mark.parametrize("n,loud,quiet", [(4096, 2000.0, 1e-24), (65536, 2000.0, 1e-24), (16384, 2000.0, 1e-24), (800, 2000.0, 1e-24), (30000, 8.0, 1e-16)])
 def test_magnitude_range_headroom_and_floor(n, loud, quiet):
-    """|X|^2 = re^2 + im^2 is the one place where the path squares.  The device's window tables carry 2^40 (2^24 on the
-    Bluestein path through device memory) so that the square neither underflows for very quiet frames -- the reference's
-    hypotf answers for the whole float range; here down to |X| ~ 1e-31 -- nor overflows below the documented amplitudes
-    (256 at N = 65536, 4000 at N = 4096).  Audio scaled by a power of two far outside [-1, 1] in both directions must give
+    """|X|^2 = re^2 + im^2 is the one place where the path squares.  The device's window tables carry 2^40 up to 4096 samples, a
+    power of two less per doubling beyond (2^24 on the Bluestein path through device memory) so that the square neither
+    underflows for very quiet frames -- the reference's hypotf answers for the whole float range; here down to |X| ~ 1e-30 -- nor
+    overflows below an amplitude of 4096 (+72 dBFS) at any size.  Audio scaled by a power of two far outside [-1, 1] in both directions must give
     the oracle's rows, shifted by exactly 20 log10 of the factor."""
     cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=0.0, tsmoothing=wf.TSMOOTH["none"])
     hop, ticks = 800, 3

@@ -271,6 +271,32 @@ int check_range(wf_hip *h, uint32_t first, uint32_t count)
     return join_lanes(h);
 }
 
+} // namespace
+
+int wf::host::upload_words(wf_hip *h, void *d_dst, const void *src, size_t bytes)
+{
+    const uint32_t k = h->words_next++ & 1u;
+    if(h->ev_words[k] == nullptr)
+        WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_words[k], hipEventDisableTiming));
+    else
+        WF_HIP_TRY(h, hipEventSynchronize(h->ev_words[k])); // the copy that used this block two calls ago (long done)
+    if(h->h_words_bytes[k] < bytes) {
+        if(h->h_words[k])
+            (void)hipHostFree(h->h_words[k]);
+        h->h_words[k] = nullptr;
+        h->h_words_bytes[k] = 0;
+        const size_t want = std::max<size_t>(bytes, 4096);
+        WF_HIP_TRY(h, hipHostMalloc(&h->h_words[k], want, hipHostMallocDefault));
+        h->h_words_bytes[k] = want;
+    }
+    std::memcpy(h->h_words[k], src, bytes);
+    WF_HIP_TRY(h, hipMemcpyAsync(d_dst, h->h_words[k], bytes, hipMemcpyHostToDevice, h->stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_words[k], h->stream));
+    return WF_HIP_OK;
+}
+
+namespace {
+
 // frees a block handed out by dev_alloc (the caller has made sure nothing enqueued still uses it)
 void dev_release(wf_hip *h, void *p)
 {
@@ -892,8 +918,7 @@ int wf_hip_set_stream_delay(wf_hip *h, uint32_t first, uint32_t count, const uin
             return rc;
         WF_HIP_TRY(h, hipMemsetAsync(h->d_delay, 0, (size_t)h->n_streams * sizeof(uint32_t), h->stream));
     }
-    WF_HIP_TRY(h, hipMemcpyAsync(h->d_delay + first, delay_frames, (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `delay_frames` is borrowed for the call only
+    WF_TRY_RC(upload_words(h, h->d_delay + first, delay_frames, (size_t)count * sizeof(uint32_t))); // (staged: `delay_frames` is borrowed for the call only, and the call does not wait)
     h->max_stream_delay = std::max(h->max_stream_delay, mx);
     h->stream_delays_aligned = h->stream_delays_aligned && al; // conservative: never switches back to the vector fetch
     return WF_HIP_OK;
@@ -916,8 +941,7 @@ int wf_hip_set_stream_audio_ts(wf_hip *h, uint32_t first, uint32_t count, const 
             return rc;
         WF_HIP_TRY(h, hipMemsetAsync(h->d_audio_ts, 0, (size_t)h->n_streams * sizeof(unsigned long long), h->stream));
     }
-    WF_HIP_TRY(h, hipMemcpyAsync(h->d_audio_ts + first, audio_ts_ns, (size_t)count * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-    WF_HIP_TRY(h, hipStreamSynchronize(h->stream)); // `audio_ts_ns` is borrowed for the call only
+    WF_TRY_RC(upload_words(h, h->d_audio_ts + first, audio_ts_ns, (size_t)count * sizeof(uint64_t))); // (staged, no wait: see upload_words)
     return WF_HIP_OK;
 }
 

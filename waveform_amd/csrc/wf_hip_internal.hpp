@@ -140,9 +140,10 @@ struct wf_hip {
     // coefficient its inverse: scaling by 2^k is exact, the transform is linear, and |X|^2 = re^2 + im^2 -- the one place where
     // the path squares -- then stays representable down to |X| ~ 1e-31 instead of ~1e-19 (hypotf in the reference answers for
     // the whole float range: the first ticks behind a reset through a narrow window, a few samples under sin^16 tails, give
-    // |X| ~ 1e-26).  Headroom: N * amplitude * 2^40 squared must stay below FLT_MAX -- amplitude < 256 at N = 65536, < 4000 at
-    // N = 4096 (+48 dBFS and more; the reference overflows 2^40 times later).  Bluestein through device memory squares values
-    // that still carry its factor L: 2^24 there.
+    // |X| ~ 1e-26).  Headroom: N * amplitude * in_scale squared must stay below FLT_MAX; the factor is 2^40 up to 4096 samples and
+    // halves with every doubling beyond (wf_hip_create), which keeps the overflow point at an amplitude of 4096 (+72 dBFS) from
+    // 4096 samples up (the reference's hypotf overflows far later still: a stated deviation).  Bluestein
+    // through device memory squares values that still carry its factor L: 2^24 there.
     float in_scale = 1.0f;
     bool ext_outputs = false;        // the outputs are derived from the stored rows by big_outputs_kernel behind the tick kernel
                                      // (displays whose staging does not fit the tick kernel's exchange buffer)
@@ -163,6 +164,12 @@ struct wf_hip {
     size_t mask_bytes = 0;
     float *d_stage = nullptr;
     size_t stage_floats = 0;
+    // per-stream words the host sets every video frame (wf_hip_set_stream_delay / _audio_ts): staged in page-locked memory of
+    // the handle's own, two blocks used alternately, so that the calls copy and return instead of draining the stream
+    void *h_words[2] = {nullptr, nullptr};
+    size_t h_words_bytes[2] = {0, 0};
+    hipEvent_t ev_words[2] = {nullptr, nullptr};
+    uint32_t words_next = 0;
     std::vector<void *> allocs;
     bool canary = false;                                  // WF_HIP_CANARY=1 at create: guard bytes behind every block, checked by wf_hip_sync
     std::vector<std::pair<void *, size_t>> guards;        // (block, payload bytes) of every guarded block still alive
@@ -237,6 +244,10 @@ inline uint32_t next_pow2(uint32_t v)
         p <<= 1;
     return p;
 }
+
+// `bytes` of per-stream words from a borrowed host array to `d_dst`, without waiting for the stream: through one of the handle's
+// two page-locked staging blocks (wf_hip.hip)
+int upload_words(wf_hip *h, void *d_dst, const void *src, size_t bytes);
 
 // ---- kernel dispatch -----------------------------------------------------------------------------------------------------
 // One object file per geometry (wf_tick_geom.hip compiled with -DWF_TU_GEOM=<N>): picks the spectrum_tick_kernel instantiation

@@ -276,7 +276,16 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     // the kernel always multiplies by the window and slope tables; a disabled feature is a table of ones (x * 1.0f == x)
     {
         const std::vector<float> ones_m(h->M, 1.0f);
-        h->in_scale = (h->big_l && h->blu) ? 0x1p24f : 0x1p40f;
+        // 2^40 up to 4096 samples, one power of two less per doubling beyond (2^36 at 65536): |X|^2 overflows only above an amplitude
+        // of 2^64 / (N * in_scale) = 4096 (+72 dBFS) at every size from 4096 up, and still answers down to |X| ~ 2e-30
+        {
+            int lg = 0;
+            while((1u << lg) < h->N)
+                ++lg;
+            h->in_scale = std::ldexp(1.0f, std::min(40, 52 - lg));
+        }
+        if(h->big_l && h->blu)
+            h->in_scale = 0x1p24f;
         std::vector<float> win_dev(h->N, h->in_scale);
         for(size_t i = 0; i < h->tab.window.size() && i < win_dev.size(); ++i)
             win_dev[i] = h->tab.window[i] * h->in_scale; // (exact)
@@ -730,6 +739,10 @@ void wf_hip_destroy(wf_hip *h)
     }
     for(auto e : h->ev_bars_lane)
         if(e) (void)hipEventDestroy(e);
+    for(int i = 0; i < 2; ++i) {
+        if(h->ev_words[i]) (void)hipEventDestroy(h->ev_words[i]);
+        if(h->h_words[i]) (void)hipHostFree(h->h_words[i]);
+    }
     if(h->ev0) (void)hipEventDestroy(h->ev0);
     if(h->ev1) (void)hipEventDestroy(h->ev1);
     if(h->stream) (void)hipStreamDestroy(h->stream);
