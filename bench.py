@@ -540,7 +540,18 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    per_rank_ms, ranks_seen = [elapsed * 1e3 / args.steps], 1
     if dist is not None:
+        # every rank's own time per step and device time per tick, and how many ranks the collective really reached
+        mine = torch.tensor([elapsed * 1e3 / args.steps, kernel_ms, 1.0], dtype=torch.float64, device="cuda")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        per_rank_ms = [float(x) for x in allr[:, 0]]
+        per_rank_kernel_ms = [float(x) for x in allr[:, 1]]
+        one = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -548,6 +559,9 @@ def main():
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
 
+    if dist is not None and ranks_seen != world:
+        print(f"bench.py: rank {rank}: the process group has {world} ranks but an all-reduce over it reached {ranks_seen}", file=sys.stderr, flush=True)
+        os._exit(4)
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = spectra_per_step * world * args.steps / elapsed
@@ -561,6 +575,10 @@ def main():
             "warmup_total": args.warmup + lead_in_ticks + (args.steps if cold_ms else 0),  # every untimed tick in front of the timed region: the cold region, the lead-in, the W requested
             "lead_in": {"ms": args.lead_in_ms, "ticks": lead_in_ticks, "why": "untimed ticks until the device's clocks have settled (15-20 ms of load), in front of the warm-up steps"},
             "ms_per_step": ms_per_step,
+            # one process per GPU: what every rank measured itself (ms_per_step above is the slowest), the backend of the process
+            # group and how many ranks an all-reduce over it reached -- a rank that silently dropped out shows here
+            "ranks": {"world": world, "seen_by_all_reduce": ranks_seen, "backend": (dist.get_backend() if dist is not None else "none (one process)"),
+                      "ms_per_step_per_rank": per_rank_ms, "device_ms_per_tick_per_rank": (per_rank_kernel_ms if dist is not None else [kernel_ms])},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

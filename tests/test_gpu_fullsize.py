@@ -234,6 +234,7 @@ def test_bench_multi_rank_path_with_the_collective():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["ranks"]["world"] == 2 and line["ranks"]["seen_by_all_reduce"] == 2 and len(line["ranks"]["ms_per_step_per_rank"]) == 2
     c4 = line["configs4"]
     assert "error" not in c4, c4
     assert c4["verified"] is True and c4["streams_total"] == 2 * 8192 and len(c4["device_ms_per_tick"]["per_rank"]) == 2

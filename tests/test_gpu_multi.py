@@ -268,3 +268,16 @@ def test_the_c_example_runs(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=f"{ROOT / 'waveform_amd'}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=600)
     assert run.returncode == 0 and "streams over" in run.stdout, (run.stdout, run.stderr[-2000:])
+
+
+def test_node_check_runs_and_verifies():
+    """tools/node_check.py -- what gets run first on a node nobody could rehearse on: every device, the default transport and the
+    forced peer copies, per-device times, the gather alone, the links; exit code 0 only if every device's gathered copy verified"""
+    import json
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "node_check.py"), "--streams-per-device", "1024", "--ticks", "40"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["devices_used"] == wf.device_count() and len(out["runs"]) == 2
+    for run in out["runs"]:
+        assert run["verified"] and run["gather_alone_us"] > 0 and len(run["ms_per_tick_with_gather"]["per_device"]) == len(run["devices"])
