@@ -214,9 +214,13 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     P1Regs<G> r1;
     bool nz = false;
     float mr_touch[2] = {0.0f, 0.0f};
+    MrOps<G> mr_ops;
+    constexpr bool MR_EARLY = BLU && MR && WF_MR_PREFETCH && G::T == 64; // the epilogue's operands requested behind the window (one-wavefront containers)
     if constexpr(BLU && MR) {
         if(active) // windowed sample pairs straight into the exchange buffer, natural order (wf_mixed.hpp)
             nz = mr_fetch<G>(a, t, x, start, lds) && !hidden;
+        if constexpr(MR_EARLY)
+            mr_ops_request<G, true, false>(a, t, ts, mr_ops);
         // one dword of every 64-byte line of the smoothing state and the slope table of this row, requested now and never
         // used: the epilogue's own loads (it keeps no operands across the passes) find the lines in the L2 (+2.5 ... 4 % from
         // 128 threads per spectrum; -2 % on the one-wavefront geometries, where it is left out)
@@ -243,6 +247,12 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     BarPre bar_pre_early{0, 0, 1, 0, 0, 0, -1};
     if constexpr(!(BLU && !MR))
         bar_pre_early = bars_preload<G>(a.bar, t);
+#if WF_EXP_COEF_AT_FETCH
+    BarEntries<G> bar_entries;
+    bar_entries.base = 0;
+    if constexpr(Policy<G>::BAR_COEF_EARLY && !BLU && DEC == 0 && !BOTH)
+        bars_fetch_entries<G>(a.bar, t, bar_entries);
+#endif
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
     bool wave_below = true;
@@ -413,18 +423,33 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     // the bar tables of this thread: requested here, in front of P4 and its state stores, where the geometry has the registers
     // (Policy<G>::BAR_COEF_EARLY) -- else behind the dB math below
     constexpr bool COEF_EARLY = Policy<G>::BAR_COEF_EARLY && !BLU && DEC == 0 && !BOTH;
+#ifndef WF_EXP_COEF_AT_FETCH
+#define WF_EXP_COEF_AT_FETCH 0 // (experiment) the bar tables requested right behind the window fetch instead of in front of P4
+#endif
+#if !WF_EXP_COEF_AT_FETCH
     BarEntries<G> bar_entries;
     bar_entries.base = 0;
-    if constexpr(COEF_EARLY) {
+#endif
+    if constexpr(COEF_EARLY && !WF_EXP_COEF_AT_FETCH) {
         bars_fetch_entries<G>(a.bar, t, bar_entries);
         if(!process && a.bar.out != nullptr)
             wait_vmem_all(); // (the rare path that skips P4 and its wait)
     }
     if(process) {
         if constexpr(BLU) {
-            if constexpr(MR)
+            if constexpr(MR) {
                 asm volatile("" ::"v"(mr_touch[0]), "v"(mr_touch[1])); // (waited for here at the latest; see the fetch)
-            p4_direct<G, MR>(a, t, lds, ts, mag);
+#if WF_MR_PREFETCH
+                if constexpr(MR_EARLY)
+                    mr_ops_request<G, false, true>(a, t, ts, mr_ops);
+                else
+                    mr_ops_request<G, true, true>(a, t, ts, mr_ops); // all of the epilogue's operands at once, from the lines touched above
+                p4_mr<G>(a, t, lds, ts, mr_ops, mag);
+#else
+                p4_direct<G, MR>(a, t, lds, ts, mag);
+#endif
+            } else
+                p4_direct<G, MR>(a, t, lds, ts, mag);
         } else if constexpr(DEC > 0) {
             if(row_thread)
                 p4_split_smooth_dec<G, DEC>(a, t, lds, ts, r1.wb, r4, mag);
@@ -530,8 +555,13 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
     if constexpr(!COEF_EARLY)
         bars_fetch_entries<G>(a.bar, t, bar_entries);
+#ifndef WF_EXP_STORES_AFTER_PARK
+#define WF_EXP_STORES_AFTER_PARK 0 // (experiment, needs WF_DEFER_STATE=1) bars displays: the state and row stores issued between the row's LDS copy and its
+                                   // read-back, so that the LDS round trip runs under their issue
+#endif
+    const bool stores_after_park = WF_EXP_STORES_AFTER_PARK && WF_DEFER_STATE && !BLU && DEC == 0 && a.bar.out != nullptr && a.bar.piece_mode && !mono_mix;
     if constexpr(WF_DEFER_STATE && !BLU && DEC == 0) {
-        if(process && !mono_mix)
+        if(process && !mono_mix && !stores_after_park)
             p4_store_state<G>(a, t, ts, mag); // behind the table requests (p4_split_smooth<.., DEFER>)
     }
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
@@ -552,7 +582,7 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
         // (Storing the rows behind the bars / curve points instead -- so that the wait for their table loads, vector memory
         // completing in order, is not a wait for these stores' acknowledgement -- measured +-0 for both, -10 % for bars at
         // N = 2048, and is no longer in the tree.)
-        if(!a.skip_decibels) {
+        if(!a.skip_decibels && !stores_after_park) {
             store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
             if(dup_row)
                 store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
@@ -628,6 +658,17 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
             store_row<RG, BLU>(dbl, t, d, NB);
         if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)
             dbl[MO] = dbl[MO + 1] = 0.0f;
+        if(stores_after_park) {
+            if constexpr(WF_DEFER_STATE && !BLU && DEC == 0) {
+                if(process)
+                    p4_store_state<G>(a, t, ts, mag);
+            }
+            if(have_row && row_thread && !a.skip_decibels) {
+                store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
+                if(dup_row)
+                    store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
+            }
+        }
         if(WF_EXP_TAIL_CUT == 2) {
 #ifdef WF_EXP_KEEP_COEFS
             for(int c = 0; c < BarEntries<G>::CMAX; ++c)

@@ -874,6 +874,81 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
         }
     }
 }
+// ---- the mixed-radix sizes' epilogue (wf_mixed.hpp): the same real split, with its operands requested ahead ------------------
+// n/2 <= M/2 bins (the transform works between the two halves of the container's exchange buffer): a thread owns at most P/8
+// groups of four bins.  Per group: the smoothing state (f4) and W_n^k of its four bins (2 x f4); the slope factors are formed
+// (1 + 3 k slope / (n/2 - 1), Policy<G>::SLOPE_LINEAR's reasoning).  One-wavefront containers request them right behind the
+// window fetch -- the state only: 8 registers at 16 points per thread; with the twiddles too the 2048-sample container spilled
+// 56 B per lane -- so that its trip to HBM runs under the transform instead of behind it (what the power-of-two one-wavefront
+// geometries do: Policy MODE 1); everything else at the start of the epilogue, all at once.
+#ifndef WF_MR_PREFETCH
+#define WF_MR_PREFETCH 1
+#endif
+template<class G> struct MrOps {
+    static constexpr int GR = (G::P / 8) > 0 ? G::P / 8 : 1;
+    f4 st[GR], wa[GR], wb[GR];
+};
+// STATE: the smoothing state (HBM: the long trip); TWIDDLES: W_n^k (a table every stream shares: L2)
+template<class G, bool STATE, bool TWIDDLES> WF_DEV void mr_ops_request(const TickArgs &a, int t, const float *ts, MrOps<G> &o)
+{
+    constexpr int T = G::T;
+    const int np = (int)a.row_bins;
+    WF_UNROLL
+    for(int u = 0; u < MrOps<G>::GR; ++u) {
+        const int k0 = 4 * (t + T * u);
+        const int at = k0 < np ? k0 : 0; // (threads beyond the row load bin 0's operands and never use them)
+        if(STATE)
+            o.st[u] = (a.mode & WF_MODE_TSMOOTH) ? ld_state(ts + at) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if(TWIDDLES) {
+            o.wa[u] = ld4(reinterpret_cast<const float *>(a.blu_w + at));
+            o.wb[u] = ld4(reinterpret_cast<const float *>(a.blu_w + at + 2));
+        }
+    }
+}
+template<class G, bool TS, bool FPK>
+WF_DEV void p4_split_mr_impl(const TickArgs &a, int t, const cf *lds, float *ts, const MrOps<G> &o, float (&mag)[G::P])
+{
+    constexpr int T = G::T;
+    const int np = (int)a.row_bins; // blu_n / 2
+    WF_UNROLL
+    for(int u = 0; u < MrOps<G>::GR; ++u) {
+        const int k0 = 4 * (t + T * u);
+        if(k0 < np) {
+            const cf W[4] = {cf{o.wa[u].x, o.wa[u].y}, cf{o.wa[u].z, o.wa[u].w}, cf{o.wb[u].x, o.wb[u].y}, cf{o.wb[u].z, o.wb[u].w}};
+            const float st4v[4] = {o.st[u].x, o.st[u].y, o.st[u].z, o.st[u].w};
+            WF_UNROLL
+            for(int i = 0; i < 4; ++i) {
+                const int k = k0 + i, km = (k == 0) ? 0 : np - k;
+                const cf A = lds_ld2(lds, ex3_addr<G>(k)), B = lds_ld2(lds, ex3_addr<G>(km));
+                const float er = A.x + B.x, ei = A.y - B.y;
+                const float dr = A.x - B.x, di = A.y + B.y;
+                const float pr = fmaf(W[i].x, dr, -(W[i].y * di)); // Re(W D)
+                const float pi = fmaf(W[i].x, di, W[i].y * dr);    // Im(W D)
+                float m = mag2(er + pi, ei - pr) * a.half_coef * fmaf((float)k, a.slope_step, 1.0f);
+                if(TS) {
+                    float old = st4v[i];
+                    if(FPK)
+                        old = fmaxf(m, old);
+                    m = fmaf(a.g, old, a.g2 * m);
+                }
+                mag[4 * u + i] = m;
+            }
+            if(TS)
+                st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
+        }
+    }
+}
+template<class G> WF_DEV void p4_mr(const TickArgs &a, int t, const cf *lds, float *ts, const MrOps<G> &o, float (&mag)[G::P])
+{
+    if(a.mode & WF_MODE_TSMOOTH) {
+        if(a.mode & WF_MODE_FAST_PEAKS)
+            p4_split_mr_impl<G, true, true>(a, t, lds, ts, o, mag);
+        else
+            p4_split_mr_impl<G, true, false>(a, t, lds, ts, o, mag);
+    } else
+        p4_split_mr_impl<G, false, false>(a, t, lds, ts, o, mag);
+}
+
 template<class G, bool MR = false> WF_DEV void p4_direct(const TickArgs &a, int t, const cf *lds, float *ts, float (&mag)[G::P])
 {
     if(a.mode & WF_MODE_TSMOOTH) {
