@@ -116,6 +116,7 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
     a.tsmooth = tsmooth;
     a.decibels = decibels;
     a.half_coef = 0.5f * (2.0f / tab.window_sum);
+    a.slope_step = tab.slope.empty() ? 0.0f : (float)(3.0 * (double)cfg.slope / (double)(cfg.fft_size / 2 - 1)); // Policy<G>::SLOPE_LINEAR (as make_args sets it)
     a.g = gravity_for(cfg, seconds);
     a.g2 = 1.0f - a.g;
     a.db_min = db_min();

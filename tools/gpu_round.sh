@@ -31,4 +31,5 @@ for J in "plugindefaults:python $R/tools/quick_case.py plugin_defaults" "n32768:
   WF_PMC_SET=short WF_PROFILE_CMD="$CMD" bash tools/profile_gpu.sh ${TAG}_$NAME > /dev/null 2>&1
 done
 bash tools/size_sweep.sh $TAG > /dev/null 2>&1
+python tools/node_check.py > $O/node_check_$TAG.json 2> $O/node_check_$TAG.err
 ls $O/prof   # then, back home: bash tools/summarize_round.sh $TAG
