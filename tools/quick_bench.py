@@ -37,7 +37,7 @@ def run(n, streams, ticks=30, hop=800, stereo=1, reps=3, **kw):
         nspec = streams * b.capture_channels
         byt = b.algorithmic_bytes_per_tick()
         print(json.dumps(dict(lib=os.path.basename(os.environ.get("WF_HIP_LIB", "default")), kernel=b.kernel_name(), streams=streams,
-                              ms=round(best, 4), Mspectra_s=round(nspec / best / 1e3, 2), GBps=round(byt / best / 1e6, 1),
+                              ms=round(best, 4), algorithmic_bytes_per_tick=int(byt), Mspectra_s=round(nspec / best / 1e3, 2), GBps=round(byt / best / 1e6, 1),
                               frac=round(byt / best / 1e6 / 8000, 4))), flush=True)
 
 if __name__ == "__main__":

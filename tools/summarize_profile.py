@@ -47,8 +47,11 @@ def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None,
                 except Exception:
                     continue
                 r = d.get("roofline") or {}
+                algo = r.get("algorithmic_bytes_per_tick") or d.get("algorithmic_bytes_per_tick")
+                if algo is None and d.get("GBps") and d.get("ms"):  # tools/quick_bench.py: GB/s of algorithmic bytes over ms per tick
+                    algo = round(d["GBps"] * d["ms"] * 1e6)
                 said = {"kernel": r.get("kernel") or d.get("kernel"), "launches_per_tick": r.get("kernel_launches_per_tick"),
-                        "algorithmic_bytes_per_tick": r.get("algorithmic_bytes_per_tick")}
+                        "algorithmic_bytes_per_tick": algo}
     # The trace: which launches make a tick.  Launches of one tick may overlap (lanes: wf_hip_tick issues the batch as slices
     # on several HIP streams) or follow each other (the transforms beyond a CU's LDS: rows kernel, then epilogue), and a
     # command may run several batches one after the other, each on streams of its own (tools/wave_bench.py: three shapes).
