@@ -18,8 +18,14 @@
 namespace emu {
 struct Access { int idx; int bytes; int is_write; };
 static thread_local std::vector<Access> *g_trace = nullptr;
+// bounds check of every exchange-buffer access ("a debug build that bounds-checks LDS indices"): idx counts
+// complex points (8 bytes); g_lds_cf = the spectrum's buffer in complex points (Geom::LDS_CF), 0 = not armed
+static thread_local int g_lds_cf = 0;
+static thread_local long g_lds_violations = 0;
 inline void trace(int idx, int bytes, int is_write)
 {
+    if(g_lds_cf > 0 && (idx < 0 || (long)idx * 8 + bytes > (long)g_lds_cf * 8))
+        ++g_lds_violations;
     if(g_trace)
         g_trace->push_back({idx, bytes, is_write});
 }
@@ -133,7 +139,8 @@ template<class G> int run_geometry(const wf_config &cfg, const wf::HostTables &t
 
     constexpr int T = G::T, P = G::P, M = G::M;
     ConflictStats st[2];
-    std::vector<cf> lds((size_t)G::LDS_CF);
+    std::vector<cf> lds((size_t)G::LDS_CF); // (exactly the kernel's buffer: the AddressSanitizer build of this file sees an access past it)
+    emu::g_lds_cf = G::LDS_CF;
     std::vector<std::vector<emu::Access>> traces((size_t)T);
     struct Regs { cf v[P]; float mag[P]; float d[P]; P1Regs<G> r1; P4Regs<G> r4; };
     std::vector<Regs> regs((size_t)T);
@@ -215,6 +222,10 @@ int wfemu_tick(const wf_config *cfg, uint32_t n_streams, uint32_t ring_cap, cons
         using G = decltype(g);
         ret = run_geometry<G>(*cfg, tab, n_streams, ring_cap, ring, wpos, delay, seconds, tsmooth, decibels, stats);
     });
+    if(ok && ret == 0 && emu::g_lds_violations != 0) {
+        emu::g_lds_violations = 0;
+        return -77; // an exchange-buffer access outside the spectrum's LDS buffer
+    }
     return ok ? ret : WF_HIP_ERR_UNSUPPORTED;
 }
 

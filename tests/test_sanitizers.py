@@ -104,6 +104,13 @@ for s in range(60):  # the reference's full slider ranges (some combinations hav
             emu.host_table(scenarios.make_config(cfg_dict), k)
         except ValueError:
             pass
+# the emulated tick of every geometry under the same build: the spectrum's exchange buffer is a heap block of exactly Geom::LDS_CF
+# complex points, so an LDS index past it is a report here (and a -77 from the emulator's own bounds check anywhere)
+from tools import synth
+for nfft in (512, 1024, 2048, 4096, 8192, 16384, 32768):
+    cfg = scenarios.make_config(dict(fft_size=nfft, stereo=1, slope=1.0))
+    ring = np.ascontiguousarray(synth.block(1, 0, 1, 2, 0, 2 * nfft)[0], np.float32)
+    emu.tick(cfg, ring, 2 * nfft, np.zeros((2, nfft // 2), np.float32))
 print("tables ok", n)
 """ % (str(ROOT), str(ROOT / "tests"), str(lib))
     out = _child(["-c", code], _runtime("libasan.so"))
