@@ -52,6 +52,8 @@ struct HipApi {
     decltype(&wf_hip_num_vertices) num_vertices = nullptr;
     decltype(&wf_hip_num_bars) num_bars = nullptr;
     decltype(&wf_hip_display_channels) display_channels = nullptr;
+    decltype(&wf_hip_ring_frames) ring_frames = nullptr;
+    decltype(&wf_hip_read_waveform_ts) read_waveform_ts = nullptr;
     bool ok = false;
 };
 
@@ -100,6 +102,8 @@ HipApi &api()
         WF_SYM(num_vertices)
         WF_SYM(num_bars)
         WF_SYM(display_channels)
+        WF_SYM(ring_frames)
+        WF_SYM(read_waveform_ts)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
         auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
@@ -308,7 +312,7 @@ struct WFHipMeterGroup {
     wf_config cfg{};
     wf_hip *h = nullptr;
     int device = 0;
-    uint32_t capacity = 0, cap_ch = 0;
+    uint32_t capacity = 0, cap_ch = 0, ring_cap = 0;
     std::vector<WAVSourceHIP *> member;
     uint32_t members = 0;
     uint64_t batch = 1;
@@ -343,6 +347,7 @@ struct WFHipMeterGroup {
             return false;
         }
         cap_ch = c.capture_channels;
+        ring_cap = a.ring_frames(h);
         wave = c.waveform != 0;
         member.assign(capacity, nullptr);
         submitted.assign(capacity, 0);
@@ -1248,6 +1253,23 @@ void WAVSourceHIP::tick_waveform_batched(float seconds)
         const int64_t dtaudio = get_audio_sync(m_tick_ts);
         const size_t reserve = (dtaudio > 0) ? size_t(ns_to_audio_frames(m_audio_info.samples_per_sec, (uint64_t)dtaudio)) : 0; // frames
         const size_t max_frames = m_waveform_samples + reserve;
+        if(max_frames > g->ring_cap) {
+            // wf_hip_set_stream_delay would reject the whole batch for this one stream (an A/V-sync reserve beyond what the
+            // device rings were sized for): only THIS source leaves -- nothing of it has been staged or popped yet, so the
+            // reference's tick_waveform takes the frame over from m_capturebufs as they are, with m_decibels as step 1 left
+            // them (the previous frame's rows) and the sweep position the device kept for it (one 8-byte read that waits for
+            // the last batch: this happens once) -- and the group's other members never notice
+            uint64_t wts = 0;
+            if(a.read_waveform_ts(g->h, slot, 1, &wts) == WF_HIP_OK)
+                m_waveform_ts = (size_t)wts; // (else 0: the reference catches up by itself, src/source_generic.cpp:318-321)
+            lock.unlock();
+            LogWarn << "HIP waveform batch: this source's A/V-sync reserve (" << reserve << " frames) does not fit the device ring ("
+                    << g->ring_cap << "); it continues on the CPU path";
+            hip_release();
+            g_fallback_ticks.fetch_add(1);
+            WAVSourceGeneric::tick_waveform(seconds);
+            return;
+        }
         bool enough = true;
         for(auto i = 0u; i < m_capture_channels; ++i)
             if(m_capturebufs[i].size() <= reserve * sizeof(float)) // :293-295: the reference returns before it touches anything

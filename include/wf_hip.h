@@ -71,7 +71,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 10
+#define WF_HIP_ABI_VERSION 11
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -282,6 +282,10 @@ int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out);
 int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in);
 /* m_last_silent per stream */
 int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *out);
+/* waveform batches: m_waveform_ts (src/source.hpp:135, the timestamp of the next point the sweep will draw, ns) per stream as
+ * the last enqueued tick leaves it; waits for that tick.  What a source needs to continue the sweep on the host
+ * (src/source_generic.cpp:318-353) when it leaves a batch. */
+int wf_hip_read_waveform_ts(wf_hip *h, uint32_t first, uint32_t count, uint64_t *out);
 /* device pointers for zero-copy consumers on the same device (e.g. an RCCL all-gather of
  * the bars, or a renderer): valid until wf_hip_destroy */
 float *wf_hip_decibels_device(wf_hip *h);

@@ -120,6 +120,12 @@ int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *
     std::memcpy(out, h->silent.data() + first, count);
     return WF_HIP_OK;
 }
+uint32_t wf_hip_ring_frames(const wf_hip *) { return 1u << 20; }
+int wf_hip_read_waveform_ts(wf_hip *, uint32_t, uint32_t count, uint64_t *out)
+{
+    std::memset(out, 0, (size_t)count * sizeof(uint64_t));
+    return WF_HIP_OK;
+}
 int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *rows, uint8_t *silent, uint32_t)
 {
     wf_hip_read_decibels(h, first, count, rows);

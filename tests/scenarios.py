@@ -523,7 +523,7 @@ class OracleBackend:
         if self.cfg.meter:
             return dict(db=self.src.levels()[None], bars=self.src.bars()[None], silent=self.src.last_silent)
         if self.cfg.waveform:
-            rec = dict(db=self.src.rows(), bars=None, silent=self.src.last_silent)
+            rec = dict(db=self.src.rows(), bars=None, silent=self.src.last_silent, wts=self.src.waveform_ts)
             if self.auto_rms:
                 rec["rms"] = np.float32(self.rms)
             return rec
@@ -604,6 +604,9 @@ class HipBackend:
         if self.cfg.waveform:
             assert all(np.array_equal(db[0], db[i]) for i in range(1, self.streams)), "streams of one batch disagree"
             rec = dict(db=db[self.probe][: self.disp], bars=None, silent=bool(self.batch.last_silent()[self.probe]))
+            wts = self.batch.waveform_ts()
+            assert (wts == wts[0]).all(), "streams of one batch disagree"
+            rec["wts"] = int(wts[self.probe])
             if self.auto_rms:
                 rec["rms"] = self.batch.input_rms()[self.probe]
             return rec

@@ -398,7 +398,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name)
     L.wf_hip_abi_version.restype = C.c_int
-    assert L.wf_hip_abi_version() == 10
+    assert L.wf_hip_abi_version() == 11
 
 
 def test_no_device_fails_loudly():

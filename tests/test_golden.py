@@ -325,6 +325,47 @@ def test_waveform_sources_share_one_batch():
 
 
 @pytest.mark.gpu
+def test_one_waveform_source_outgrowing_the_ring_leaves_the_batch_alone():
+    """Four waveform sources share a batch; one of them has an A/V-sync offset whose reserve + sweep does not fit the device ring
+    (300 ms + 150 ms at 48 kHz > 16384 frames).  The C-ABI would reject the whole batch for that one stream: the host checks
+    first and only that source moves to the reference's CPU class -- its rows are then the reference's of the SAME frame --
+    while the other three stay in the batch, one frame late as ever."""
+    import os
+    from tools import synth
+    wfref = _hip_env(batched=True)
+    os.environ["WF_HIP_BATCH_CAPACITY"] = "64"
+    cfg = scenarios.make_config(dict(waveform=1, stereo=1, width=800, meter_ms=150))
+    n_src, frames, odd = 4, 50, 2
+    before = wfref.hip_fallback_ticks()
+    srcs = [scenarios.RefBackend(cfg, isa="hip") for _ in range(n_src)]
+    refs = [scenarios.RefBackend(cfg, isa="generic") for _ in range(n_src)]
+    for b in (srcs[odd], refs[odd]):
+        b.set_sync_ms(300)
+    assert all(s.src.using_hip for s in srcs)
+    want_prev = [None] * n_src
+    left_at = None
+    for f in range(frames):
+        for i, (s, o) in enumerate(zip(srcs, refs)):
+            a = synth.block(scenarios.SEED, 700 + i, 1, 2, f * 800, 800)[0]
+            for b in (s, o):
+                b.push(a, muted=False)
+                b.tick(1.0 / 60.0)
+            got, want = s.observe(), o.observe()
+            if i == odd and not s.src.using_hip:
+                left_at = f if left_at is None else left_at
+                if f > left_at:  # (the frame of the switch still shows what the batch had delivered)
+                    assert got["silent"] == want["silent"]
+                    assert np.array_equal(got["db"], want["db"]), f"source {i} frame {f}: the reference's own class, same frame"
+            elif want_prev[i] is not None and i != odd:
+                assert got["silent"] == want_prev[i]["silent"], f"source {i} frame {f}: m_last_silent"
+                assert_db_close(got["db"], want_prev[i]["db"], f"source {i} frame {f}: rows of the previous frame", lin_eps=None)
+            want_prev[i] = want
+    assert left_at is not None and left_at < 30, "the reserve outgrows the ring once 300 ms of audio are behind the sync point"
+    assert [s.src.using_hip for s in srcs] == [i != odd for i in range(n_src)], "only the offender leaves"
+    assert wfref.hip_fallback_ticks() > before
+
+
+@pytest.mark.gpu
 def test_sixty_four_meter_sources_share_one_batch():
     """64 level-meter sources of one configuration: one handle, one ragged ingest + one meter_tick_kernel + one readback per
     video frame.  Every source has its own audio and amplitude, some hide, stall or lose their capture along the way; each

@@ -625,7 +625,10 @@ def test_waveform_batch_with_per_stream_timestamps_and_paused_streams():
                     singles[i].tick(seconds=1 / 60, delay_frames=delays[i], audio_ts_ns=ts[i])
                 assert np.array_equal(rows[i], singles[i].decibels()[0]), f"frame {f} stream {i}: rows differ from the single-stream handle"
                 assert silent[i] == singles[i].last_silent()[0], f"frame {f} stream {i}: m_last_silent"
+                assert b.waveform_ts(i, 1)[0] == singles[i].waveform_ts()[0], f"frame {f} stream {i}: m_waveform_ts"
     mcfg = wf.Config.defaults(meter=1)
     with wf.SpectrumBatch(mcfg, 2) as m:
         with pytest.raises(wf.WfHipError):
             m.set_stream_audio_ts(np.zeros(2, np.uint64))   # not a waveform batch
+        with pytest.raises(wf.WfHipError):
+            m.waveform_ts()

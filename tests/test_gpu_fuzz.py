@@ -648,6 +648,7 @@ def test_hip_waveform_matches_oracle_on_random_case(seed):
     for t, (g, w) in enumerate(zip(got, want)):
         assert g["silent"] == w["silent"], f"wave case {seed} tick {t}: m_last_silent {g['silent']} != {w['silent']} ({cfg_dict})"
         assert_db_close(g["db"], w["db"], f"wave case {seed} tick {t} rows ({cfg_dict}, sync {sync_ms} ms)", lin_eps=None)
+        assert g["wts"] == w["wts"], f"wave case {seed} tick {t}: m_waveform_ts {g['wts']} != {w['wts']} ({cfg_dict}, sync {sync_ms} ms)"
 
 
 # ---- the same scripts through the reference plugin with WAVSourceHIP plugged in (the drop-in binding) -------------------------

@@ -122,6 +122,7 @@ def lib():
     L.wf_hip_read_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_write_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
+    L.wf_hip_read_waveform_ts.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     for n in ("decibels_device", "bars_device", "stream"):
         f = getattr(L, "wf_hip_" + n)
         f.restype = vp
@@ -381,6 +382,13 @@ class SpectrumBatch:
         out = np.empty(count, np.uint8)
         self._ck(self.L.wf_hip_read_last_silent(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out.astype(bool)
+
+    def waveform_ts(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """m_waveform_ts per stream (ns) as the last enqueued tick leaves it (waveform batches)"""
+        count = self.streams - first if count is None else count
+        out = np.empty(count, np.uint64)
+        self._ck(self.L.wf_hip_read_waveform_ts(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def decibels_device_ptr(self) -> int:
         return int(self.L.wf_hip_decibels_device(self.h) or 0)

@@ -1511,6 +1511,19 @@ int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *
     return WF_HIP_OK;
 }
 
+int wf_hip_read_waveform_ts(wf_hip *h, uint32_t first, uint32_t count, uint64_t *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(!h->wave || h->d_wts == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "m_waveform_ts belongs to waveform batches");
+    if(out == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "out is NULL");
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t));
+    return read_back(h, h->d_wts + first, out, (size_t)count * sizeof(uint64_t));
+}
+
 float *wf_hip_decibels_device(wf_hip *h) { return h ? h->d_decibels : nullptr; }
 float *wf_hip_bars_device(wf_hip *h) { return h ? h->d_bars : nullptr; }
 void *wf_hip_stream(wf_hip *h)
