@@ -195,15 +195,6 @@ WF_DEV void p4_big_impl(const TickArgs &a, int t, int kbase, int nb, const cf *z
         f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if(TS)
             st = ld_state(ts + k0);
-        if constexpr(MODE == 3) {
-            // fft_size 65536: the rows kernel has done the real split; bins kk .. kk + 3 are k2 = kk / 2, kk / 2 + 1 of both rows
-            const float *mb = reinterpret_cast<const float *>(z); // (this spectrum's [2][16384] magnitudes)
-            const f2 m0 = ld2(mb + kk / 2), m1 = ld2(mb + BIG_L2 + kk / 2);
-            mag[4 * u] = m0.x; mag[4 * u + 1] = m1.x; mag[4 * u + 2] = m0.y; mag[4 * u + 3] = m1.y;
-            const float sl4[4] = {sv.x, sv.y, sv.z, sv.w}, st4v[4] = {st.x, st.y, st.z, st.w};
-            p4_slope_smooth_group<G, TS, FPK>(a, t, u, ts, st4v, sl4, mag);
-            continue;
-        }
         const f4 za = ld4(reinterpret_cast<const float *>(z + kk)), zb = ld4(reinterpret_cast<const float *>(z + kk + 2));
         const cf A[4] = {cf{za.x, za.y}, cf{za.z, za.w}, cf{zb.x, zb.y}, cf{zb.z, zb.w}};
         if constexpr(MODE == 1) {
@@ -238,18 +229,15 @@ template<int MODE> WF_DEV void p4_big(const TickArgs &a, int t, int kbase, int n
         p4_big_impl<MODE, false, false>(a, t, kbase, nb, z, ts, mag);
 }
 
-// grid (parts, spectra): workgroup (part, spec) finishes bins [part * 16384, +16384) of the spectrum's row
-template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_kernel(const TickArgs a)
+// What follows a spectrum's magnitudes (the end of spectrum_tick_kernel, on rows of RG::T * RG::P bins starting at bin kbase): the
+// silence state machine from the per-channel facts, slope / smoothing / state through fill_mag(ts, mag) when the channel is
+// processed, the reset branch, the mono mixdown, dB and the rows, the verdict words of the next tick's silence test.
+//   nz_ch0 / nz_ch1: the channel's window holds a non-zero sample (reference :63-72)
+template<class RG, class FillMag>
+WF_DEV void big_finish(const TickArgs &a, int t, int kbase, uint32_t spec, bool nz_ch0, bool nz_ch1, FillMag &&fill_mag)
 {
-    using G = GBig;
-    using RG = RowG<G::T, G::P>;
-    constexpr int RP = G::P;
-    const int t = (int)threadIdx.x;
+    constexpr int RP = RG::P;
     const int lane = t & 63;
-    const int kbase = (int)blockIdx.x * BIG_TP;
-    uint32_t spec = a.stream_base * a.cap_ch + blockIdx.y;
-    if(a.split_ch != 0xffffffffu) // mono mixdown: one channel of every stream per launch, channel 1 first
-        spec = 2u * (a.stream_base + blockIdx.y) + a.split_ch;
     const uint32_t cap_shift = a.cap_ch - 1;
     const uint32_t stream = spec >> cap_shift, ch = spec & cap_shift;
     const bool stereo = (a.mode & WF_MODE_STEREO) != 0;
@@ -266,8 +254,8 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
     // the facts of the silence state machine (reference :63-95), as in split mode
     const uint32_t s0 = stream * a.cap_ch;
     const uint32_t vin0 = a.verdict_in[s0], vin1 = a.cap_ch > 1 ? a.verdict_in[s0 + 1u] : 0u;
-    const bool nz0 = !hidden && a.big_nz[s0] != 0u;
-    const bool nz1 = a.cap_ch > 1 && !hidden && a.big_nz[s0 + 1u] != 0u;
+    const bool nz0 = !hidden && nz_ch0;
+    const bool nz1 = a.cap_ch > 1 && !hidden && nz_ch1;
     const bool below0 = vin0 == 0u;
     const bool below1 = stereo ? (vin1 == 0u) : (vin0 == 0u); // mono display: channel 1 inspects row 0 too (reference :81)
     StreamPlan plan = plan_stream(was_silent, a.cap_ch, stereo, nz0, nz1, below0, below1);
@@ -285,9 +273,20 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
     for(int i = 0; i < RP; ++i)
         mag[i] = 0.0f;
     if(process)
-        p4_big<MODE>(a, t, kbase, NB, MODE == 3 ? reinterpret_cast<const cf *>(a.big_mag + (size_t)spec * (2u * BIG_L2)) : a.big_z + (size_t)spec * a.big_l, ts, mag);
+        fill_mag(ts, mag);
     else if(do_db && (!(mono_mix && ch == 1) || underflow)) // skipped channel of a live stream: its stale row is re-dBFS'ed
         load_row<RG, true>(rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
+#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 4 // (development: stop behind slope / smoothing / state)
+    {
+        float sacc = 0.0f;
+#pragma unroll
+        for(int i = 0; i < RP; ++i)
+            sacc += mag[i];
+        if(sacc == 1234.5f)
+            a.decibels[t] = sacc;
+        return;
+    }
+#endif
 
     // hidden / capture timeout: reset branch (reference :34-48)
     if(hidden && !was_silent) {
@@ -323,7 +322,18 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
         p4_db<RG, true>(a, t, mag, d, a.vol_comp_stream ? a.vol_comp_stream[stream] : a.vol_comp, NB, kbase);
 #pragma unroll
         for(int i = 0; i < RP; ++i)
-            exceeds = exceeds || (4 * (t + G::T * (i / 4)) < NB && d[i] > a.silent_floor);
+            exceeds = exceeds || (4 * (t + RG::T * (i / 4)) < NB && d[i] > a.silent_floor);
+#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 5 // (... behind the dB arithmetic, in front of the row stores)
+        {
+            float sacc = 0.0f;
+#pragma unroll
+            for(int i = 0; i < RP; ++i)
+                sacc += d[i];
+            if(sacc == 1234.5f)
+                a.decibels[t] = sacc;
+            return;
+        }
+#endif
         store_row<RG, true, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
         if(dup_row)
             store_row<RG, true, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
@@ -340,19 +350,35 @@ template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_ke
         a.verdict_clear[spec] = 0u;
 }
 
-// ---- fft_size 65536: the column step folded into the rows kernel, the real split too -----------------------------------
+// grid (parts, spectra): workgroup (part, spec) finishes bins [part * 16384, +16384) of the spectrum's row
+template<int MODE> __global__ __launch_bounds__(GBig::T, 4) void big_epilogue_kernel(const TickArgs a)
+{
+    using G = GBig;
+    const int t = (int)threadIdx.x;
+    const int kbase = (int)blockIdx.x * BIG_TP;
+    uint32_t spec = a.stream_base * a.cap_ch + blockIdx.y;
+    if(a.split_ch != 0xffffffffu) // mono mixdown: one channel of every stream per launch, channel 1 first
+        spec = 2u * (a.stream_base + blockIdx.y) + a.split_ch;
+    const uint32_t s0 = (spec >> (a.cap_ch - 1u)) * a.cap_ch;
+    const int NB = (int)a.row_bins - kbase;
+    big_finish<RowG<G::T, G::P>>(a, t, kbase, spec, a.big_nz[s0] != 0u, a.cap_ch > 1 && a.big_nz[s0 + 1u] != 0u, [&](float *ts, float (&mag)[G::P]) {
+        p4_big<MODE>(a, t, kbase, NB, a.big_z + (size_t)spec * a.big_l, ts, mag);
+    });
+}
+
+// ---- fft_size 65536: one kernel ---------------------------------------------------------------------------------------------
 // The packed real transform of 65536 samples is L = 2 x 16384 complex points.  Decimation in frequency over n1 (two columns)
 // leaves two independent 16384-point rows, and row k1 delivers exactly the bins of parity k1: U[k1 + 2 k2].  The real split
-// pairs bin k with bin m - k (m = 32768) -- the SAME parity -- so a row needs nothing from the other one.
-// big_rows_kernel<2, FOLD> therefore (1) forms its input itself: windowed sample pairs straight from the ring, u0 +- u1, times
-// W_L^n2 for row 1 (what big_columns_kernel wrote to the scratch buffer and this kernel read back: 8 N bytes per transform
-// gone, and a launch), and (2) finishes with the real split and stores |2X| coef / 2 of its 16384 bins as floats, planar
-// ([row][k2], 2 N bytes per transform instead of 4 N of complex points); big_epilogue_kernel<3> picks the magnitudes up --
-// no mirrored reads -- and does the rest.  Device-memory traffic per transform: 26 N -> 18 N bytes; three kernels -> two.
+// pairs bin k with bin m - k (m = 32768) -- the SAME parity -- so a row needs nothing from the other one.  big_whole_kernel
+// therefore (1) forms the rows' inputs itself: windowed sample pairs straight from the ring, u0 + u1 for row 0 and
+// (u0 - u1) W_L^n2 for row 1 (what big_columns_kernel writes to a scratch buffer for the other sizes), (2) transforms row 0 and
+// then row 1 in the exchange buffer, each followed by its real split into registers, and (3) finishes the tick from those
+// registers.  Device-memory traffic per transform: 26 N bytes (columns, rows, epilogue: round 2) -> 18 N (round 3: rows with the
+// column step and the split folded in, magnitudes through memory, epilogue) -> 10 N, what the tick itself needs; three kernels ->
+// two -> one.
 
-// the 16 points of row K1 this thread feeds into pass 1: u0 +- u1 (times W_L^n2 for K1 = 1), u = windowed sample pairs.
-// Eight to ten registers per point are in flight until its sum is formed; all sixteen at once do not fit the 128 registers
-// a thread of a 1024-thread workgroup has, so the burst goes out in groups of BIG_FETCH_ROWS points.
+// the 16 points per row this thread feeds into pass 1: u0 +- u1 (times W_L^n2 for row 1), u = windowed sample pairs.
+// Eight to ten registers per point are in flight until its sums are formed, so the burst goes out in groups of rows.
 #ifndef BIG_FETCH_ROWS
 #define BIG_FETCH_ROWS 4
 #endif
@@ -377,13 +403,15 @@ WF_DEV f4 big_ring4(const float *x, uint32_t i) { return *reinterpret_cast<const
 using GFold = Geom<32768, WF_FOLD_T, 16, 32, 32>;
 static_assert(GFold::LDS_CF == GBig::LDS_CF && GFold::R2 == GBig::R2 && GFold::R3 == GBig::R3 && GFold::R1 == GBig::R1, "the fused rows use GBig's tables and LDS budget");
 
-template<class G, bool ALIGNED> WF_DEV uint32_t big_fused_fetch(const TickArgs &a, int t, int k1, const float *x, uint32_t start, P1Regs<G> &r, cf *lds)
+// Both rows from ONE pass over the window: row 0's sums u0 + u1 are parked in the exchange buffer, in the very slots this thread's
+// pass-1 outputs will take, and come back as r.smp (all sixteen in registers during the burst do not fit); row 1's
+// (u0 - u1) W_L^n2 stay in r1.smp -- 64 registers that wait while row 0 is transformed.
+template<class G, bool ALIGNED, int BURST = BIG_FETCH_ROWS> WF_DEV uint32_t big_fused_fetch2(const TickArgs &a, int t, const float *x, uint32_t start, P1Regs<G> &r, P1Regs<G> &r1, cf *lds)
 {
     constexpr int R1 = G::R1, M1 = G::M1, B1 = G::B1;
-    constexpr int ROWS = (ALIGNED ? BIG_FETCH_ROWS : BIG_FETCH_ROWS / 2) / B1 > 0 ? (ALIGNED ? BIG_FETCH_ROWS : BIG_FETCH_ROWS / 2) / B1 : 1;
+    constexpr int ROWS = (ALIGNED ? BURST : BURST / 2) / B1 > 0 ? (ALIGNED ? BURST : BURST / 2) / B1 : 1;
     uint32_t acc = 0;
-    const float sgn = k1 ? -1.0f : 1.0f; // row 0: u0 + u1; row 1: (u0 - u1) W_L^n2 (row 0 of the table is all ones)
-    const float *tw_row = reinterpret_cast<const float *>(a.big_tw + (size_t)k1 * BIG_L2);
+    const float *tw_row = reinterpret_cast<const float *>(a.big_tw + (size_t)BIG_L2); // row 1 of the table
 #pragma unroll
     for(int j0 = 0; j0 < R1; j0 += ROWS) {
         f2 s0[ROWS][B1], s1[ROWS][B1], w0[ROWS][B1], w1[ROWS][B1], tw[ROWS][B1];
@@ -431,7 +459,10 @@ template<class G, bool ALIGNED> WF_DEV uint32_t big_fused_fetch(const TickArgs &
                 const f2 p0 = s0[jj][b], p1 = s1[jj][b], v0 = w0[jj][b], v1 = w1[jj][b], q = tw[jj][b];
                 acc |= f32_bits(p0.x) | f32_bits(p0.y) | f32_bits(p1.x) | f32_bits(p1.y);
                 const cf u0 = cf{p0.x * v0.x, p0.y * v0.y}, u1 = cf{p1.x * v1.x, p1.y * v1.y};
-                pt[b] = cmul(cf{fmaf(sgn, u1.x, u0.x), fmaf(sgn, u1.y, u0.y)}, cf{q.x, q.y});
+                pt[b] = cf{u0.x + u1.x, u0.y + u1.y};
+                const cf d = cmul(cf{u0.x - u1.x, u0.y - u1.y}, cf{q.x, q.y});
+                r1.smp[j][2 * b] = d.x;
+                r1.smp[j][2 * b + 1] = d.y;
             }
             // parked in the exchange buffer, in the very slots this thread's pass-1 outputs will take (p1_store): the sixteen
             // sums of a thread would otherwise occupy 2 R1 B1 registers for the whole burst
@@ -460,25 +491,26 @@ template<class G, bool ALIGNED> WF_DEV uint32_t big_fused_fetch(const TickArgs &
         }
 #pragma unroll
         for(int b = 0; b < 2 * B1; ++b)
-            r.win[j][b] = 1.0f;
+            r.win[j][b] = r1.win[j][b] = 1.0f;
     }
     return acc;
 }
 
+
 // bins of parity K1 from row K1's transform (natural order in LDS): mag[4 u + 2 h + K1] = |2 X[k]| coef / 2 for
 // k = 4 (t + T u) + 2 h + K1, i.e. Z[k2] with k2 = 2 (t + T u) + h and its mirror image m - k, which is row K1's
 // k2' = (16384 - K1 - k2) mod 16384
-template<class G> WF_DEV void big_fused_split(const TickArgs &a, int t, int k1, const cf *lds, float (&out)[G::P])
+template<class G, int K1> WF_DEV void big_fused_split(const TickArgs &a, int t, const cf *lds, float (&out)[2 * G::P])
 {
     constexpr int T = G::T, P = G::P;
     constexpr int WSTEP = 32 / ((2 * 2 * (int)BIG_L2) / (4 * T)); // W_65536^(4 T u) = W_32^(WSTEP u)
     static_assert(WSTEP >= 1 && WSTEP * (P / 2) <= 16 && 4 * T * 32 == 2 * 2 * (int)BIG_L2 * WSTEP, "the bins of a thread are W_32 steps apart");
-    // W_65536^k for k = 4 t + 2 h + k1; the bins 4 T u further on are that times W_32^(WSTEP u) (compile-time constants),
-    // as p4_split_smooth forms its twiddles.  out[2 u + h] is bin 4 (t + T u) + 2 h + k1.
+    // W_65536^k for k = 4 t + 2 h + K1; the bins 4 T u further on are that times W_32^(WSTEP u) (compile-time constants),
+    // as p4_split_smooth forms its twiddles.  out[4 u + 2 h + K1] is bin 4 (t + T u) + 2 h + K1.
     cf wh[2];
 #pragma unroll
     for(int h = 0; h < 2; ++h) {
-        const f2 w = ld2(reinterpret_cast<const float *>(a.big_tws + 4 * t + 2 * h + k1));
+        const f2 w = ld2(reinterpret_cast<const float *>(a.big_tws + 4 * t + 2 * h + K1));
         wh[h] = cf{w.x, w.y};
     }
 #pragma unroll
@@ -486,58 +518,33 @@ template<class G> WF_DEV void big_fused_split(const TickArgs &a, int t, int k1, 
 #pragma unroll
         for(int h = 0; h < 2; ++h) {
             const int k2 = 2 * (t + T * u) + h;
-            const int km = ((int)BIG_L2 - k1 - k2) & ((int)BIG_L2 - 1);
+            const int km = ((int)BIG_L2 - K1 - k2) & ((int)BIG_L2 - 1);
             const cf A = lds_ld2(lds, ex3_addr<G>(k2)), B = lds_ld2(lds, ex3_addr<G>(km));
             const cf w = mul_w32(wh[h], WSTEP * u);
             const float er = A.x + B.x, ei = A.y - B.y;
             const float dr = A.x - B.x, di = A.y + B.y;
             const float pr = fmaf(w.x, dr, -(w.y * di));
             const float pi = fmaf(w.x, di, w.y * dr);
-            out[2 * u + h] = mag2(er + pi, ei - pr) * a.half_coef;
+            out[2 * (2 * u + h) + K1] = mag2(er + pi, ei - pr) * a.half_coef;
         }
     }
 }
 
-// one row of one spectrum per workgroup: fetch + column step, the three LDS passes of the 32768-sample
-// geometry, the real split, 16384 magnitudes out
-template<bool ALIGNED> __global__ __launch_bounds__(GFold::T, GFold::T / 256) void big_rows_fold_kernel(const TickArgs a)
+// One workgroup of GFold's 512 threads runs row 0 and then row 1 of its spectrum through the exchange buffer and keeps each row's
+// 16384 magnitudes in registers -- 32 per thread and row, and a thread's magnitudes of the two rows are exactly the four-bin
+// groups of the row layout the end of the tick works on: row k1's k2 = 2 (t + T u) + h is bin 4 (t + T u) + 2 h + k1.  State,
+// slope table, roll-off and the dB rows are then read and written as whole 16-byte groups, once.  The window is read once as
+// well (big_fused_fetch2); the silence facts come from the fetch itself as in spectrum_tick_kernel's split mode.
+// Against round 3's two kernels (magnitudes through device memory, 1.45 x the algorithmic bytes, profiles/r04f_n65536_pmc.json):
+// 256 stereo streams 0.336 -> 0.445 of the HBM peak on one lane, 0.557 on two (profiles/r04g_n65536_whole.txt).
+#ifndef WF_WHOLE_BURST
+#define WF_WHOLE_BURST 2 // (rows per burst of the joint fetch: 2 is +3 % over BIG_FETCH_ROWS' 4 here -- row 1's sums fill up the registers)
+#endif
+// the three LDS passes of the 32768-sample geometry on the row whose pass-1 inputs are in r, then its real split into mag
+template<class G, int K1>
+WF_DEV void big_whole_row(const TickArgs &a, int t, P1Regs<G> &r, cf *lds, const cf *tw2_lds, float (&mag)[2 * G::P])
 {
-    using G = GFold;
-    constexpr int T = G::T, P = G::P;
-    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
-    cf *lds = reinterpret_cast<cf *>(big_smem);
-    cf *tw2_lds = lds + G::LDS_CF;
-    const int t = (int)threadIdx.x;
-    // Both rows of a spectrum read the whole window.  Workgroups go to the eight XCDs round-robin by their linear index, and
-    // every XCD has its own L2: the two rows sit eight indices apart -- same XCD, dispatched back to back -- so that the
-    // second read of a window is an L2 hit instead of a second trip to device memory.
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const int k1 = (int)(slot & 1u);
-    const uint32_t rel = (slot >> 1) * 8u + xcd;
-    if(rel >= a.stream_count * a.cap_ch)
-        return;
-    const uint32_t spec = a.stream_base * a.cap_ch + rel;
-    const uint32_t stream = spec >> (a.cap_ch - 1u);
-    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
-    const uint32_t start = (a.wpos[stream] - delay - (uint32_t)(2 * G::N)) & a.ring_mask;
-    const float *x = a.ring + (size_t)spec * a.ring_stride;
-    P1Regs<G> r;
-    const uint32_t acc = big_fused_fetch<G, ALIGNED>(a, t, k1, x, start, r, lds);
-    {   // the pass-2 twiddles by LDS-DMA, as in spectrum_tick_kernel
-        constexpr int BYTES = G::R2 * G::R3 * (int)sizeof(cf), PER = 64 * 16;
-        const int wave = t >> 6, lane = t & 63;
-#pragma unroll
-        for(int c = 0; c < BYTES / PER; ++c)
-            if((c % (T / 64)) == wave) {
-                const char *g = reinterpret_cast<const char *>(a.tw2) + c * PER + lane * 16;
-                char *l = reinterpret_cast<char *>(tw2_lds) + c * PER;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16,
-                                                 0, 0);
-            }
-    }
-    // x != 0.0f for any sample of the window (reference :63-72): row 0 has seen all of it
-    if(k1 == 0 && __any((acc & 0x7fffffffu) != 0u) && (t & 63) == 0)
-        atomicOr(a.big_nz_out + spec, 1u);
+    constexpr int P = G::P;
     p1_window_pass1<G>(a, t, r, lds);
     __syncthreads();
     cf pts[P];
@@ -549,18 +556,142 @@ template<bool ALIGNED> __global__ __launch_bounds__(GFold::T, GFold::T / 256) vo
     __syncthreads();
     p3_pass3_write<G>(t, lds, pts);
     __syncthreads();
-    float out[P];
-    big_fused_split<G>(a, t, k1, lds, out);
-    float *mb = a.big_mag + (size_t)spec * (2u * BIG_L2) + (size_t)k1 * BIG_L2;
+    big_fused_split<G, K1>(a, t, lds, mag);
+}
+
+// slope, smoothing and the state store of the whole row.  The operands of WF_WHOLE_BATCH groups of four bins are requested
+// together and consumed behind them: written group by group (load, load, wait, store) the state stores fence the next group's
+// loads -- the compiler cannot tell the rows apart -- and a thread pays sixteen trips to device memory one after the other
+// (20 of a workgroup's 46 us, profiles/r04g_n65536_whole_cuts.txt).
+#ifndef WF_WHOLE_BATCH
+#define WF_WHOLE_BATCH 8
+#endif
+// (measured and dropped, profiles/r04g_n65536_whole.txt: the state row's lines touched ahead of the fetch -- 0.557 -> 0.452 with two
+// lanes --; the first batch requested in front of row 1's real split -- the fetch's register allocation falls over: 800 B of scratch)
+template<class RG, bool TS, bool FPK> WF_DEV void p4_whole_impl(const TickArgs &a, int t, float *ts, float (&mag)[RG::P])
+{
+    constexpr int NB = WF_WHOLE_BATCH;
+    static_assert((RG::P / 4) % NB == 0);
 #pragma unroll
-    for(int u = 0; u < P / 2; ++u) // out[2 u + h] is k2 = 2 (t + T u) + h
-        *reinterpret_cast<f2 *>(mb + 2 * (t + T * u)) = f2{out[2 * u], out[2 * u + 1]};
+    for(int u0 = 0; u0 < RG::P / 4; u0 += NB) {
+        f4 sv[NB], st[NB];
+#pragma unroll
+        for(int i = 0; i < NB; ++i) {
+            const int k0 = 4 * (t + RG::T * (u0 + i));
+            sv[i] = ld4(a.slope + k0);
+            st[i] = TS ? ld_state(ts + k0) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for(int i = 0; i < NB; ++i) {
+            const float sl4[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w}, st4v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+            p4_slope_smooth_group<RG, TS, FPK>(a, t, u0 + i, ts, st4v, sl4, mag);
+        }
+    }
+}
+
+// one spectrum per workgroup (grid: spectra; mono mixdown: one channel of every stream per launch, TickArgs::split_ch)
+template<bool ALIGNED> __global__ __launch_bounds__(GFold::T, GFold::T / 256) void big_whole_kernel(const TickArgs a)
+{
+    using G = GFold;
+    using RG = RowG<G::T, 2 * G::P>;
+    constexpr int T = G::T;
+    static_assert(RG::T * RG::P == 2 * (int)BIG_L2, "a workgroup finishes the whole row of 32768 bins");
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    cf *lds = reinterpret_cast<cf *>(big_smem);
+    cf *tw2_lds = lds + G::LDS_CF;
+    const int t = (int)threadIdx.x;
+    uint32_t spec = a.stream_base * a.cap_ch + blockIdx.x;
+    if(a.split_ch != 0xffffffffu)
+        spec = 2u * (a.stream_base + blockIdx.x) + a.split_ch;
+    const uint32_t cap_shift = a.cap_ch - 1u;
+    const uint32_t stream = spec >> cap_shift, ch = spec & cap_shift;
+    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const uint32_t start = (a.wpos[stream] - delay - (uint32_t)(2 * G::N)) & a.ring_mask;
+    const float *x = a.ring + (size_t)spec * a.ring_stride;
+    {   // the pass-2 twiddles by LDS-DMA, as in spectrum_tick_kernel (their own region: both rows use them)
+        constexpr int BYTES = G::R2 * G::R3 * (int)sizeof(cf), PER = 64 * 16;
+        const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+        for(int c = 0; c < BYTES / PER; ++c)
+            if((c % (T / 64)) == wave) {
+                const char *g = reinterpret_cast<const char *>(a.tw2) + c * PER + lane * 16;
+                char *l = reinterpret_cast<char *>(tw2_lds) + c * PER;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16,
+                                                 0, 0);
+            }
+    }
+    float mag[RG::P];
+    P1Regs<G> r0, r1;
+    const uint32_t acc = big_fused_fetch2<G, ALIGNED, WF_WHOLE_BURST>(a, t, x, start, r0, r1, lds);
+#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 1 // (development: where a workgroup's time goes -- stop behind the fetch)
+    {
+        float sacc = 0.0f;
+#pragma unroll
+        for(int j = 0; j < G::R1; ++j)
+            sacc += r0.smp[j][0] + r1.smp[j][1] + r0.smp[j][2] + r1.smp[j][3];
+        if(sacc == 1234.5f)
+            a.decibels[t] = sacc;
+        return;
+    }
+#endif
+    big_whole_row<G, 0>(a, t, r0, lds, tw2_lds, mag);
+#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 2 // (... behind row 0)
+    {
+        float sacc = 0.0f;
+#pragma unroll
+        for(int j = 0; j < G::R1; ++j)
+            sacc += r1.smp[j][0] + r1.smp[j][1] + r1.smp[j][2] + r1.smp[j][3] + mag[4 * j] + mag[4 * j + 2];
+        if(sacc == 1234.5f)
+            a.decibels[t] = sacc;
+        return;
+    }
+#endif
+#pragma unroll
+    for(int j = 1; j < G::R1; ++j) // (the pass-1 twiddles again: row 0's copies are not kept across its transform)
+        if(tw1_row_loaded(j))
+            p1_load_tw1<G>(a, t, j, r1.tw1[j]);
+    __syncthreads(); // row 1's pass 1 writes where row 0's transform has just been read
+    big_whole_row<G, 1>(a, t, r1, lds, tw2_lds, mag);
+#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 3 // (... behind both rows)
+    {
+        float sacc = 0.0f;
+#pragma unroll
+        for(int j = 0; j < RG::P; ++j)
+            sacc += mag[j];
+        if(sacc == 1234.5f)
+            a.decibels[t] = sacc;
+        return;
+    }
+#endif
+    // x != 0.0f for any sample of the window (reference :63-72): a row's fetch sees all of it; the partner channel's window is
+    // looked at only when this one is digital silence (workgroup-uniform and rare), as in spectrum_tick_kernel's split mode
+    const bool nz_own = __syncthreads_or((acc & 0x7fffffffu) != 0u) != 0;
+    bool nz_other = false;
+    if(a.cap_ch > 1 && !nz_own) {
+        const float *xo = a.ring + (size_t)(spec ^ 1u) * a.ring_stride;
+        uint32_t o = 0;
+        for(uint32_t i = (uint32_t)t; i < (uint32_t)(2 * G::N); i += (uint32_t)T)
+            o |= f32_bits(xo[(start + i) & a.ring_mask]);
+        nz_other = __syncthreads_or((o & 0x7fffffffu) != 0u) != 0;
+    }
+    big_finish<RG>(a, t, 0, spec, ch == 0 ? nz_own : nz_other, ch == 0 ? nz_other : nz_own, [&](float *ts, float (&m)[RG::P]) {
+#pragma unroll
+        for(int i = 0; i < RG::P; ++i)
+            m[i] = mag[i];
+        if(a.mode & WF_MODE_TSMOOTH) {
+            if(a.mode & WF_MODE_FAST_PEAKS)
+                p4_whole_impl<RG, true, true>(a, t, ts, m);
+            else
+                p4_whole_impl<RG, true, false>(a, t, ts, m);
+        } else
+            p4_whole_impl<RG, false, false>(a, t, ts, m);
+    });
 }
 
 // ---- fft sizes above 16384 with small prime factors: big_c rows of a mixed-radix transform ------------------------------------
 // n/2 = C R complex points, R <= 8192 with a mixed-radix plan (wf_mixed.hpp), C <= 8.  Decimation in frequency over the C
 // columns: row k1 transforms a[n2] = (sum_c z[n2 + R c] W_C^(c k1)) W_(n/2)^(n2 k1), n2 < R, and delivers the bins
-// Z[k1 + C k2].  As in big_rows_fold_kernel the column step is folded into the fetch -- every row reads the whole window, the
+// Z[k1 + C k2].  As in big_whole_kernel the column step is folded into the fetch -- every row reads the whole window, the
 // rows of a spectrum sit eight workgroup indices apart (same XCD, one trip to device memory) --, the R points go through the
 // passes between the two halves of the exchange buffer, and the last pass stores Z in natural order; big_epilogue_kernel<1>
 // does the real split (it pairs k with n/2 - k: another row) and everything behind it.  Replaces Bluestein through device

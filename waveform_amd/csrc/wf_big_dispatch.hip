@@ -12,26 +12,19 @@ namespace {
 
 using wf::host::fail;
 
-// fft_size 65536: rows kernel with the column step and the real split folded in, then the epilogue on magnitudes (wf_big.hpp)
-int launch_tick_big_fold(wf_hip *h, const wf::TickArgs &a0, bool aligned)
+// fft_size 65536, one kernel: both rows of a spectrum and the end of its tick in one workgroup (wf_big.hpp: big_whole_kernel)
+int launch_tick_big_whole(wf_hip *h, const wf::TickArgs &a0, bool aligned)
 {
-    const uint32_t n_spec = a0.stream_count * a0.cap_ch;
     hipStream_t st = h->launch_stream;
-    const uint32_t spec_base = a0.stream_base * a0.cap_ch;
-    WF_HIP_TRY(h, hipMemsetAsync(h->d_big_nz + spec_base, 0, (size_t)n_spec * sizeof(uint32_t), st));
-    const dim3 grow(2u * ((n_spec + 7u) & ~7u)); // (row, spectrum) by XCD: see big_rows_fold_kernel
-    const size_t rows_lds = wf::big_rows_lds_bytes<2>();
-    if(aligned)
-        hipLaunchKernelGGL(wf::big_rows_fold_kernel<true>, grow, dim3(wf::GFold::T), rows_lds, st, a0);
-    else
-        hipLaunchKernelGGL(wf::big_rows_fold_kernel<false>, grow, dim3(wf::GFold::T), rows_lds, st, a0);
-    const uint32_t parts = (h->M + (uint32_t)wf::BIG_TP - 1u) / (uint32_t)wf::BIG_TP;
-    // mono mixdown: channel 1 of every stream, then channel 0 (TickArgs::split_ch)
-    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
+    const size_t lds = wf::big_rows_lds_bytes<2>();
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) { // mono mixdown: channel 1 of every stream, then channel 0
         wf::TickArgs a = a0;
         a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
-        const dim3 grid(parts, h->split_mono ? a.stream_count : n_spec);
-        hipLaunchKernelGGL((wf::big_epilogue_kernel<3>), grid, dim3(wf::GBig::T), 0, st, a);
+        const dim3 grid(h->split_mono ? a.stream_count : a.stream_count * a.cap_ch);
+        if(aligned)
+            hipLaunchKernelGGL(wf::big_whole_kernel<true>, grid, dim3(wf::GFold::T), lds, st, a);
+        else
+            hipLaunchKernelGGL(wf::big_whole_kernel<false>, grid, dim3(wf::GFold::T), lds, st, a);
     }
     if(a0.bar.out != nullptr)
         hipLaunchKernelGGL(wf::big_outputs_kernel, dim3(a0.stream_count * a0.bar.disp_ch), dim3(wf::GBig::T), h->big_out_lds, st, a0);
@@ -129,8 +122,8 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
             h->launch_rc = launch_tick_big_mr(h, s);
             continue;
         }
-        if(h->big_fused) {
-            h->launch_rc = launch_tick_big_fold(h, s, aligned);
+        if(h->big_whole) {
+            h->launch_rc = launch_tick_big_whole(h, s, aligned);
             continue;
         }
         switch(h->big_rows) {
@@ -162,17 +155,17 @@ int setup_launch_big(wf_hip *h)
         rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
     if(rc)
         return rc;
-    // fft_size 65536 (the one power of two up here): everything in one kernel.  WF_HIP_BIG_FUSED=0 keeps the three-kernel path
-    // (development aid: A/B, and the path every Bluestein size above 16384 takes)
-    h->big_fused = !h->blu && !h->big_mr && h->big_rows == 2;
+    // fft_size 65536 (the one power of two up here): both rows and the end of the tick in one kernel, no scratch in device memory.
+    // WF_HIP_BIG_WHOLE=0 (development builds) sends it through the columns -> rows -> epilogue chain every other size up here takes
+    h->big_whole = !h->blu && !h->big_mr && h->big_rows == 2;
 #ifdef WF_DEV_OVERRIDES
-    if(const char *e = std::getenv("WF_HIP_BIG_FUSED"))
-        h->big_fused = h->big_fused && e[0] != '0';
+    if(const char *e = std::getenv("WF_HIP_BIG_WHOLE"))
+        h->big_whole = h->big_whole && e[0] != '0';
 #endif
-    if(h->big_fused) {
-        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_rows_fold_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if(h->big_whole) {
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_whole_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)wf::big_rows_lds_bytes<2>()));
-        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_rows_fold_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_whole_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)wf::big_rows_lds_bytes<2>()));
     }
     if(h->big_out_lds)
@@ -189,8 +182,8 @@ int setup_launch_big(wf_hip *h)
             o += snprintf(rad + o, sizeof(rad) - (size_t)o, "%s%d", i ? "x" : "", h->mr_radix[i]);
         snprintf(name, sizeof(name), "big_mr_rows_kernel + big_epilogue_kernel<N=%u: %u rows of %u complex points as mixed radix %s, column step folded into the fetch>",
                  h->N, h->big_rows, h->M / h->big_rows, rad);
-    } else if(h->big_fused)
-        snprintf(name, sizeof(name), "big_rows_fold_kernel + big_epilogue_kernel<N=%u: two rows of 16384 complex points, column step and real split folded into the rows>", h->N);
+    } else if(h->big_whole)
+        snprintf(name, sizeof(name), "big_whole_kernel<N=%u: both rows of 16384 complex points and the end of the tick in one workgroup>", h->N);
     else if(h->blu)
         snprintf(name, sizeof(name), "big_{columns,rows,epilogue}_kernel<N=%u by Bluestein over %u = %u x 16384 complex points through device memory>",
                  h->N, h->big_l, h->big_rows);

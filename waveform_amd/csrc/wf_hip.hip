@@ -140,7 +140,6 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.big_z = h->d_big_z;
         a.big_tws = h->d_big_tws;
         a.big_tw = h->d_big_tw;
-        a.big_mag = h->d_big_mag;
         a.big_nz_out = h->d_big_nz;
         a.big_nz = h->d_big_nz;
         a.big_m = h->blu ? 0u : h->N / 2;

@@ -88,8 +88,7 @@ struct wf_hip {
     uint32_t big_l = 0, big_rows = 0;
     bool big_mr = false;             // fft sizes above 16384 with small prime factors: big_rows rows of a mixed-radix transform (big_mr_rows_kernel)
     wf::cf *d_big_wc = nullptr;      // [8][8] W_big_rows^(c k1)
-    bool big_fused = false;          // fft_size 65536: column step and real split folded into the rows kernel (big_rows_fold_kernel)
-    float *d_big_mag = nullptr;      // [n_spec][2][16384] its output: magnitudes by bin parity
+    bool big_whole = false;          // fft_size 65536: both rows plus the end of the tick in ONE kernel (big_whole_kernel), nothing through device memory
     wf::cf *d_big_v = nullptr, *d_big_z = nullptr, *d_big_tw = nullptr, *d_big_tws = nullptr;
     uint32_t *d_big_nz = nullptr;
     size_t big_out_lds = 0;          // dynamic LDS of big_outputs_kernel

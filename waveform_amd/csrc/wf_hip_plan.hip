@@ -652,8 +652,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_big_tw, t1));
         WF_CREATE_TRY(upload(h, &h->d_big_tws, t2));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
-        if(h->big_fused) { // (no complex scratch: the rows kernel reads the ring and leaves magnitudes)
-            WF_CREATE_TRY(dev_alloc(h, &h->d_big_mag, n_spec * 2u * 16384u));
+        if(h->big_whole) { // (fft_size 65536: no scratch at all, the magnitudes stay in registers)
         } else if(h->big_mr) { // (the rows read the ring themselves: one scratch buffer, for Z)
             WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_l));
         } else {
@@ -675,13 +674,17 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         if(h->M <= 512 && !h->cfg.meter && !h->cfg.waveform && wgs >= 6u * round)
             lanes = 3; // the one-wavefront 8-point geometry in long launches: 0.714-0.717 against 0.682-0.683 of the HBM peak at
                        // 16384 streams (steady state, r02j); +-2 % on every other geometry
+        if(per_cu == 1 && wgs >= 2u * round)
+            lanes = 3; // one workgroup per CU (32768 samples): fetch, transform and the end of the tick take turns inside a CU, and the
+                       // launches of three slices drift apart: 256 streams 0.465 -> 0.513 (two) -> 0.533 (three), 2048 streams 0.472 -> 0.470 -> 0.495
+        if(h->big_l) // the transforms through device memory: launch chains of small kernels, nothing to overlap -- except fft_size 65536 in
+                     // its one kernel, a CU per workgroup again: 256 streams 0.445 -> 0.557 (two) / 0.49 (three), 64 streams (half a round) 0.259 -> 0.253
+            lanes = (h->big_whole && n_spec >= 2u * (uint32_t)std::max(prop.multiProcessorCount, 1)) ? 2 : 1;
 #ifdef WF_DEV_OVERRIDES
         if(const char *e = std::getenv("WF_HIP_LANES"))
             lanes = std::atoi(e);
 #endif
         lanes = std::max(1, std::min({lanes, (int)wf_hip::MAX_LANES, (int)h->n_streams}));
-        if(h->big_l)
-            lanes = 1; // a handful of workgroups of a whole CU each: nothing to overlap
 #ifdef WF_PHASE_TIMING
         lanes = 1;
 #endif

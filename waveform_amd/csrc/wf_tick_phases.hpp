@@ -213,9 +213,8 @@ struct TickArgs {
     // transforms beyond a CU's LDS (wf_big.hpp): the finished transform in device memory and what the epilogue needs with it
     const cf *big_z;           // [n_spec][big_l] rows' output, natural order
     const cf *big_tws;         // [big_m] W_(2 big_m)^k (real split of the 65536-sample transform)
-    const cf *big_tw;          // [L1][16384] W_L^(n2 k1): the column twiddles (big_rows_fold_kernel folds the column step into its fetch)
-    float *big_mag;            // [n_spec][2][16384] fft_size 65536: |2X| coef / 2 of the bins of parity 0 / 1 (big_rows_fold_kernel -> epilogue)
-    uint32_t *big_nz_out;      // big_nz, writable (row 0 of big_rows_fold_kernel ORs "the window has a non-zero sample" into it)
+    const cf *big_tw;          // [L1][16384] W_L^(n2 k1): the column twiddles (big_whole_kernel / big_mr_rows_kernel fold the column step into their fetch)
+    uint32_t *big_nz_out;      // big_nz, writable (row 0 of big_mr_rows_kernel ORs "the window has a non-zero sample" into it)
     const uint32_t *big_nz;    // [n_spec] != 0: the window has a non-zero sample
     uint32_t big_m, big_l;     // complex points of the packed real transform; complex points per transform (scratch stride)
     BarArgs bar;
