@@ -25,6 +25,13 @@ L = wf.lib()
 L.wf_hip_debug_phase_clock.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert L.wf_hip_debug_phase_clock(b.h, buf.ctypes.data, buf.size) == 0
 s = buf.reshape(nblk, 16).astype(np.int64)
+if os.environ.get("WF_PHASE_MR"):  # the mixed-radix / Bluestein paths stamp 0, 1, 2, 8, 9, 10 only
+    tot = s[:, 10] - s[:, 0]
+    print("block lifetime: mean %.0f  p10 %.0f  p90 %.0f ticks of s_memtime (100 MHz)" % (tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
+    for nm, a0, a1 in (("fetch+nz", 0, 1), ("facts xchg", 1, 2), ("transform", 2, 8), ("p4 split+smooth", 8, 9), ("dB+store", 9, 10)):
+        dd = s[:, a1] - s[:, a0]
+        print(f"{nm:18s} mean {dd.mean():9.1f}  ({100 * dd.mean() / tot.mean():5.1f} %)   p90 {np.percentile(dd, 90):9.1f}")
+    sys.exit(0)
 d = np.diff(s[:, :11], axis=1)
 names = ["fetch+nz", "facts xchg", "p1 win+pass1", "sync+p2 read", "p2 dft+write", "sync+p3 read", "p3 dft+write", "sync", "p4 split+smooth", "dB+store"]
 if os.environ.get("WF_HIP_KERNEL") == "pipe":

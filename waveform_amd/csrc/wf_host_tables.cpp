@@ -864,6 +864,9 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
     }
 }
 
+#ifndef WF_MR_PASS_COST
+#define WF_MR_PASS_COST 24.0
+#endif
 int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4], uint64_t bluestein_points)
 {
     static const int kRadices[] = {25, 23, 20, 19, 17, 16, 15, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -892,7 +895,73 @@ int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4], uint64_t blues
     const bool led = lead != 1;         // ... behind a prime first pass: at most three more, none above 16
     const int max_n = led ? 3 : 4, min_n = led ? 1 : 2;
     int best[4] = {0, 0, 0, 0}, best_n = 0, best_min = 0, cur[4];
-    auto consider = [&](int n) {
+    double best_cost = 0.0;
+    // Which factorisation, in which order?  Every pass is `for(j = t; j < np / R; j += threads)` over in-register DFTs of R points
+    // (wf_mixed.hpp): a wavefront pays for ceil((np / R) / threads) butterflies per pass whether its lanes are busy or not, so
+    // few passes of large radices -- round 3's rule -- leave most lanes idle once np / R drops below the thread count
+    // (np = 400 on 64 threads as 25 x 16: 16 and 25 lanes busy; as 5 x 8 x 10: 80 / 128, 50 / 64, 40 / 64 -- and less than half
+    // the arithmetic per lane).  The cost of an order = the instructions one thread issues: per pass, butterflies per thread x
+    // (the DFT's arithmetic + 4 per twiddle + its LDS reads and writes, weighted) + a barrier's worth.  Constraints as before: a
+    // radix above 16 only in front (it has no twiddled form) and none behind a prime first pass; the last pass one butterfly per
+    // thread (np / R <= threads), R <= 16; the first pass's stores go out with stride R cf: even strides conflict in the LDS banks.
+    auto dft_cost = [](int R) -> double { // VALU instructions of MrDft<R>::run, counted from its source
+        switch(R) {
+        case 2: return 4; case 3: return 14; case 4: return 16; case 5: return 40; case 6: return 48; case 7: return 60; case 8: return 58;
+        case 9: return 100; case 10: return 116; case 11: return 140; case 12: return 128; case 13: return 192; case 15: return 222;
+        case 16: return 160; case 17: return 320; case 19: return 396; case 20: return 288; case 23: return 572; default: return 464; // 25
+        }
+    };
+    auto order_cost = [&](const int *order, int n) -> double {
+        double c = 0.0;
+        for(int s = 0; s < n; ++s) {
+            const int R = order[s];
+            const uint32_t nb = np / (uint32_t)R;
+            const double iters = (double)((nb + threads - 1u) / threads);
+            double per = dft_cost(R) + 3.0 * (2.0 * R);             // an LDS access ~ three arithmetic instructions of issue + wait
+            if(s > 0 || led)
+                per += 4.0 * (R - 1) + 2.0 * (R - 1);               // twiddles: complex multiplications + their (cached) loads
+            if(s == 0 && !led) {
+                int g = 1;
+                while(g < 16 && R % (2 * g) == 0)
+                    g *= 2;
+                per += 1.5 * R * (g - 1);                           // first-pass stores, stride R: g-way bank conflicts
+            }
+            c += iters * per + WF_MR_PASS_COST;                      // + the pass's barrier and loop set-up
+        }
+        return c;
+    };
+    auto consider_by_cost = [&](int n) {
+        int big = 0;
+        for(int i = 0; i < n; ++i)
+            big += cur[i] > 16;
+        if(big > (led ? 0 : 1))
+            return;
+        int perm[4] = {0, 1, 2, 3};
+        std::sort(perm, perm + n);
+        do {
+            int order[4];
+            for(int i = 0; i < n; ++i)
+                order[i] = cur[perm[i]];
+            bool ok = order[n - 1] <= 16 && np / (uint32_t)order[n - 1] <= threads;
+            for(int i = 1; i < n && ok; ++i)
+                ok = order[i] <= 16;
+            if(!ok)
+                continue;
+            const double c = order_cost(order, n);
+            if(best_n == 0 || c < best_cost - 1e-9) {
+                best_n = n;
+                best_cost = c;
+                for(int i = 0; i < n; ++i)
+                    best[i] = order[i];
+            }
+        } while(std::next_permutation(perm, perm + n));
+    };
+    // Spectra of several wavefronts (threads > 64) keep round 3's rule -- the fewest passes, then the largest smallest radix: every
+    // pass ends in a workgroup barrier there, and measured on MI355X the cost model's plans are no better (N = 1536 / 1920 on 128
+    // threads: -6 % with a fourth pass, +-0 without) or worse (N = 6000 on 512 threads as 5 x 10 x 10 x 6 instead of 25 x 10 x 12:
+    // -5.5 %; 4160: -1.5 %).  One wavefront per spectrum (N <= 1024): N = 800 1210 -> 958 vector instructions per spectrum,
+    // +2.8 %; N = 960 +3 % (profiles/r04g_n800_phases.txt).
+    auto consider_few_passes = [&](int n) {
         // order: a radix above 16 must be first (at most one, none behind a prime first pass); the last one is the largest radix
         // <= 16 with np / R <= threads; the first one otherwise an odd radix (its stores go out with stride R: conflict-free when
         // R is odd)
@@ -938,6 +1007,12 @@ int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4], uint64_t blues
             for(int i = 0; i < n; ++i)
                 best[i] = order[i];
         }
+    };
+    auto consider = [&](int n) {
+        if(threads <= 64u)
+            consider_by_cost(n);
+        else
+            consider_few_passes(n);
     };
     auto rec = [&](auto &&self, uint32_t left, int depth, int max_idx) -> void {
         if(left == 1) {

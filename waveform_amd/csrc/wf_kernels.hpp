@@ -104,6 +104,13 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
             a.phase_clock[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20); \
         }                                                                                                        \
     } while(0)
+#elif defined(WF_EXP_CUT_AT) // development: the kernel ends at phase boundary WF_EXP_CUT_AT (what do the phases in front of it cost?)
+#define WF_STAMP(i)         \
+    do {                    \
+        if((i) == WF_EXP_CUT_AT) \
+            return;         \
+    } while(0)
+#define WF_STAMP_HWID()
 #else
 #define WF_STAMP(i)
 #define WF_STAMP_HWID()

@@ -259,10 +259,6 @@ int WF_CAT(setup_tick_, WF_TU_GEOM)(wf_hip *h, bool want_split)
 #if defined(WF_GEOM_ONLY) && (WF_GEOM_ONLY != WF_TU_GEOM)
     (void)want_split; // development builds: one geometry only (tools/variant.sh)
     return fail(h, WF_HIP_ERR_UNSUPPORTED, "development build: only the %d-sample geometry is compiled in", WF_GEOM_ONLY);
-#elif defined(WF_GEOM_ONLY)
-    if(h->blu) // development builds: no Bluestein instantiations
-        return fail(h, WF_HIP_ERR_UNSUPPORTED, "development build without the Bluestein kernels");
-    return setup_tick_geometry<WF_CAT(wf::G, WF_TU_GEOM)>(h, want_split);
 #else
     return setup_tick_geometry<WF_CAT(wf::G, WF_TU_GEOM)>(h, want_split);
 #endif
