@@ -198,6 +198,27 @@ def roofline(batch, shape, kernel_ms, flags=0, wall_ms=None, cold_ms=None):
     return out
 
 
+def copy_ceiling(torch, mib=1024, reps=20):
+    """What a plain device-to-device copy reaches on this GPU, in this process, right now (torch's elementwise copy kernel on `mib`
+    MiB, read + written bytes / time by events): the memory system's own efficiency.  /opt/skills/guides/MI355X_MICROARCH.md
+    quotes 6.29 TB/s (79 % of the 8 TB/s peak) for a float4 copy; `frac` everywhere in this line stays against the 8 TB/s peak."""
+    n = mib * (1 << 20) // 4
+    src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(5):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    gbps = 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    return {"achieved": gbps, "unit": "GB/s", "frac_of_peak": gbps / HBM_PEAK_GBPS, "what": f"torch copy_ of {mib} MiB, bytes read + written, {reps} repetitions by events"}
+
+
 WARM_MS, TIMED_MS = 40.0, 30.0  # other shapes: device time of the untimed lead-in (clocks settle in 15-20 ms) and of the timed region
 
 
@@ -597,6 +618,12 @@ def main():
             "roofline": roofline(batch, "cfg3_n4096" if (args.streams, args.fft, flags) == (STREAMS_PER_GPU, FFT_SIZE, 0) else None, kernel_ms, flags,
                                  wall_ms=ms_per_step, cold_ms=cold_ms),
         }
+        try:  # the memory system's own ceiling, measured here and now: the headline kernel against a plain copy
+            cc = copy_ceiling(torch)
+            cc["headline_vs_copy"] = out["roofline"]["achieved"] / cc["achieved"]
+            out["roofline"]["copy_ceiling"] = cc
+        except Exception as e:
+            print(f"bench.py: copy_ceiling failed: {e}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.fft, host_cores(), args.cpu_seconds)
