@@ -301,14 +301,18 @@ def test_power_of_two_kernels_do_not_spill():
 
     with cf.ThreadPoolExecutor(6) as ex:
         results = list(ex.map(usage, (512, 1024, 2048, 4096, 8192, 16384, 32768)))
-    seen = seen_mixed = 0
+    seen = seen_mixed = seen_small = 0
     for res in results:
         for name, scratch, vgprs in res:
-            m = re.search(r"ELb([01])ELb([01])ELb([01])EEEvNS_8TickArgsE$", name)  # <.., BLU, BOTH, MR>
+            m = re.search(r"ELb([01])ELb([01])ELb([01])ELb([01])EEEvNS_8TickArgsE$", name)  # <.., BLU, BOTH, MR, MRS>
             assert m, name
-            blu, mixed = m.group(1) == "1", m.group(3) == "1"
+            blu, mixed, small = m.group(1) == "1", m.group(3) == "1", m.group(4) == "1"
             if blu and not mixed:
                 continue  # Bluestein: the compatibility path, a few spills tolerated (bounded by the next test)
+            if small:     # the one-wavefront container's small-radix instantiation: five waves per SIMD, 96 registers, three words parked
+                seen_small += 1
+                assert scratch <= 16 and vgprs <= 96, f"{name}: {scratch} B of scratch per lane, {vgprs} VGPRs"
+                continue
             if mixed:     # the mixed-radix transform inside the same instantiation (wf_mixed.hpp): no scratch either
                 seen_mixed += 1
                 assert scratch == 0 and vgprs <= 128, f"{name}: {scratch} B of scratch per lane, {vgprs} VGPRs"
@@ -319,7 +323,7 @@ def test_power_of_two_kernels_do_not_spill():
             # (N = 32768: 512 threads of 32 points, one workgroup per CU by its LDS = two waves per SIMD with 256 registers each)
             limit = 256 if "GeomILi32768ELi512E" in name else 128
             assert vgprs <= limit, f"{name} needs {vgprs} VGPRs (limit {limit}): a wave per SIMD fewer"
-    assert seen >= 12 and seen_mixed >= 6
+    assert seen >= 12 and seen_mixed >= 6 and seen_small >= 1
 
 
 def test_compatibility_path_kernels_stay_near_their_register_budget(tmp_path):

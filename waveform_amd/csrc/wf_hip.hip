@@ -121,6 +121,9 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         }
         a.mr.tw = h->d_mr_tw;
         a.mr.wp = h->d_mr_wp;
+        a.mr.half = h->mr_half;
+        a.mr.s3 = h->mr_s3;
+        a.mr.lds_cf = h->mr_lds_cf;
         if(h->big_l) // direct form: |c_k| / L, times mag_coefficient (the packed form's tables carry the 1 / L, and its real split the 1 / 2)
             a.half_coef = (2.0f / h->tab.window_sum) / (float)h->big_l;
     }
@@ -132,6 +135,8 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         }
         a.mr.tw = h->d_mr_tw;
         a.mr.wp = h->d_mr_wp;
+        a.mr.half = (int)wf::GBig::M / 2; // (the rows kernel's two halves of the 132 KB buffer; its Z goes to device memory)
+        a.mr.s3 = a.mr.lds_cf = 0;
         a.big_c = h->big_rows;
         a.big_r = h->M / h->big_rows;
         a.big_wc = h->d_big_wc;

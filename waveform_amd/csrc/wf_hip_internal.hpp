@@ -78,6 +78,7 @@ struct wf_hip {
     bool split_mono = false;         // ... and, for mono mixdown, in different launches (TickArgs::split_ch)
     // FFT sizes that are not powers of two: Bluestein over the geometry of geom_n = 2 * L points (spectrum_tick_kernel<.., BLU>)
     bool blu = false;
+    int mr_half = 0, mr_s3 = 0, mr_lds_cf = 0; // MrPlan::half / s3 / lds_cf: the spectrum's exchange buffer sized by the transform
     int mr_passes = 0;               // > 0: fft_size = 2^a 3^b 5^c, the transform runs as mixed-radix passes inside the Bluestein instantiation (wf_mixed.hpp)
     int mr_radix[4] = {0, 0, 0, 0}, mr_tw_off[4] = {0, 0, 0, 0};
     wf::cf *d_mr_tw = nullptr;       // the passes' twiddle tables (wf::build_mixed_radix_tables)

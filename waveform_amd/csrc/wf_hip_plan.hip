@@ -313,6 +313,25 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         if(e_ != hipSuccess)                                                                             \
             return fail(h, WF_HIP_ERR_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e_));          \
     } while(0)
+    // will this size run as a mixed-radix transform inside the Bluestein instantiation?  (setup_launch_blu asks the same question)
+    auto mixed_radix_direct = [&]() -> bool {
+        if(!h->blu || h->big_l)
+            return false;
+        int radix[4] = {0, 0, 0, 0};
+        bool direct = false;
+        wf::dispatch_geometry(h->geom_n, [&](auto g) {
+            using G = decltype(g);
+            if constexpr(G::N >= 32768)
+                direct = wf::plan_mixed_radix(h->N / 2, (uint32_t)wf::GBig::T, radix, (uint64_t)wf::GBig::M) > 0;
+            else
+                direct = G::N >= 1024 && wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, radix, (uint64_t)G::M) > 0;
+        });
+#ifdef WF_DEV_OVERRIDES
+        if(const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX"))
+            direct = direct && off[0] != '1';
+#endif
+        return direct;
+    };
     auto plan_outputs = [&](bool ext) -> int {
         WF_PLAN_TRY(upload(h, &h->d_bar_coef, h->tab.bar_coef));
         WF_PLAN_TRY(upload(h, &h->d_bar_bin, h->tab.bar_bin));
@@ -334,6 +353,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             lds_floats = (size_t)wf::GBig::LDS_CF * 2;
             threads = wf::GBig::T;
         }
+        if(!own_kernel && mixed_radix_direct()) // the exchange buffer is sized by the transform there (MrPlan::lds_cf, setup_launch_blu)
+            lds_floats = 2u * (size_t)wf::mr_exchange_cf(h->N / 2, (uint32_t)(lds_floats / 2));
         int lpb = 1;
         while(lpb < 64 && (uint32_t)(threads / (lpb * 2)) >= h->num_bars)
             lpb *= 2;
@@ -375,23 +396,9 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // filter (its inputs are staged by bar index behind a barrier anyway) nor on the zero-padded sizes
             wf::BarPieceTables pieces;
             bool want_pieces = h->tab.gauss_radius == 0 && h->N >= 512u;
-            if(h->blu) { // Bluestein proper keeps bar_segments' layouts (its instantiations are compiled without this one); the sizes
-                         // that will run as a mixed-radix transform (setup_launch_blu asks the same question) take it
-                int radix[4] = {0, 0, 0, 0};
-                bool direct = false;
-                wf::dispatch_geometry(h->geom_n, [&](auto g) {
-                    using G = decltype(g);
-                    if constexpr(G::N >= 32768)
-                        direct = wf::plan_mixed_radix(h->N / 2, (uint32_t)wf::GBig::T, radix, (uint64_t)wf::GBig::M) > 0;
-                    else
-                        direct = G::N >= 1024 && wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, radix, (uint64_t)G::M) > 0;
-                });
-#ifdef WF_DEV_OVERRIDES
-                if(const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX"))
-                    direct = direct && off[0] != '1';
-#endif
-                want_pieces = want_pieces && direct;
-            }
+            if(h->blu) // Bluestein proper keeps bar_segments' layouts (its instantiations are compiled without this one); the sizes
+                       // that will run as a mixed-radix transform take it
+                want_pieces = want_pieces && mixed_radix_direct();
 #ifdef WF_DEV_OVERRIDES
             if(const char *e = std::getenv("WF_HIP_BAR_PIECES"))
                 want_pieces = want_pieces && e[0] != '0';

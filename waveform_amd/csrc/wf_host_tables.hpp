@@ -139,6 +139,26 @@ void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables 
 // factor or no ordering fits: radices above 16 only in the first pass (the twiddled passes hold 2 (R - 1) more registers), and
 // the last pass has one butterfly per thread at most (np / radix[last] <= threads).
 int plan_mixed_radix(uint32_t np, uint32_t threads, int radix[4], uint64_t bluestein_points = 0);
+// The exchange buffer of a mixed-radix spectrum of np complex points (MrPlan::half / s3 / lds_cf, wf_tick_phases.hpp): two halves of
+// `half` = np rounded up to 16 points; never less than 576 complex units (the display phase parks the dB row and stages its
+// inputs there: Geom::LDS_CF's floor) and never more than the container geometry's buffer (np <= M / 2).
+inline uint32_t mr_exchange_half(uint32_t np) { return (np + 15u) & ~15u; }
+inline uint32_t mr_exchange_cf(uint32_t np, uint32_t container_lds_cf)
+{
+    const uint32_t want = 2u * mr_exchange_half(np);
+    return want < 576u ? (576u < container_lds_cf ? 576u : container_lds_cf) : (want < container_lds_cf ? want : container_lds_cf);
+}
+// the radices the one-wavefront container's small instantiation carries (spectrum_tick_kernel<.., MRS>): without the in-register
+// DFTs of 7, 11, 13, 15, 16 and the first-pass radices its threads get by with 96 registers -- a fifth wave per SIMD
+inline bool mr_small_radices(const int *radix, int passes)
+{
+    for(int i = 0; i < passes; ++i)
+        switch(radix[i]) {
+        case 2: case 3: case 4: case 5: case 6: case 8: case 9: case 10: case 12: break;
+        default: return false;
+        }
+    return passes > 0;
+}
 // (bluestein_points: the length L of the transforms Bluestein would run instead, 0: no alternative worth weighing -- a prime first
 // pass is only planned where its p^2 work is expected to beat them)
 // radix[0] a prime of 29 .. 127 (the rest of np is then planned behind it, radices up to 16): wp[m] = W_p^m, padded with ones to

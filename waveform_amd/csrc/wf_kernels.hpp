@@ -76,6 +76,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_WPS_2048_BLU
 #define WF_WPS_2048_BLU 4 // (+3-4 % over three waves and no scratch, measured: 52 B of scratch per lane weigh less than a fourth wave) the Bluestein instantiation of the same geometry (fft sizes 528 ... 1008, the automatic size 800 among them)
 #endif
+#ifndef WF_WPS_2048_MRS
+#define WF_WPS_2048_MRS 5 // 96 registers, 12 B of scratch per lane
+#endif
 #ifndef WF_WPS_2048
 #define WF_WPS_2048 3
 #endif
@@ -143,9 +146,14 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // BOTH (SPW == 2, mono mixdown with a curve display): the stream's one displayed row is finished by the threads of both
 // spectra.  A template parameter, not a run-time flag: the extra code cost the 2048-point kernel a VGPR too many (129: three
 // waves per SIMD instead of four) and 5-15 % even on configurations that never take the path.
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false>
-__global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
+//
+// MRS (with MR, one-wavefront containers): the mixed-radix instantiation for plans of the radices 2, 3, 4, 5, 6, 8, 9, 10, 12 (N = 800
+// as 5 x 10 x 8, 960 as 5 x 12 x 8 ...).  Without the large in-register DFTs the kernel fits 96 registers -- five waves per SIMD instead
+// of four, and the tick of these sizes scales with the spectra in flight (profiles/r04g_n800_phases.txt).
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false>
+__global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
+    static_assert(!MRS || (MR && G::T == 64 && G::P > 8), "the small-radix instantiation belongs to the one-wavefront 16-point container");
     static_assert(!BOTH || (SPW == 2 && !SPLIT && DEC == 0 && !BLU), "shared curve row: two spectra per workgroup, power-of-two sizes");
     static_assert(!BLU || (DEC == 0 && !TLDS && !ALIGNED), "Bluestein path: scalar fetch, no decimation, no staged tables");
     static_assert(!MR || BLU, "the mixed-radix transform (wf_mixed.hpp) runs inside the Bluestein instantiation's fetch and epilogue");
@@ -195,8 +203,10 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
         vin1 = a.verdict_in[2u * stream + 1u];
     }
 
-    cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * G::LDS_CF;
-    cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * G::LDS_CF;
+    // a spectrum's exchange buffer: the geometry's, or -- mixed-radix sizes -- what the transform needs (MrPlan::lds_cf)
+    const int lds_cf = MR ? a.mr.lds_cf : (int)G::LDS_CF;
+    cf *lds = reinterpret_cast<cf *>(smem_raw) + (size_t)sub * lds_cf;
+    cf *tw2_lds = reinterpret_cast<cf *>(smem_raw) + (size_t)SPW * lds_cf;
     int *facts = reinterpret_cast<int *>(tw2_lds + G::R2 * G::R3);
     // bars / curve display, several wavefronts per spectrum: how many of them are done with the last reads of the exchange
     // buffer (see "arrivals" below).  In the spare words behind the facts.
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
     if constexpr(BLU && MR) {
         // FFT sizes with no prime factor above 5: the n/2-point transform itself, two to four mixed-radix passes between the two
         // halves of the exchange buffer (wf_mixed.hpp) instead of Bluestein's two power-of-two transforms
-        mr_transform<G>(a.mr, process, (int)a.row_bins, t, lds, tw2_lds, [] { spectrum_sync<G>(); }); // (tw2_lds: the prime pass's W_p^m, staged where the power-of-two kernels keep their pass-2 twiddles: TickArgs::tw2 points at it)
+        mr_transform<G, MRS>(a.mr, process, (int)a.row_bins, t, lds, tw2_lds, [] { spectrum_sync<G>(); }); // (tw2_lds: the prime pass's W_p^m, staged where the power-of-two kernels keep their pass-2 twiddles: TickArgs::tw2 points at it)
     } else {
         if constexpr(TLDS) {
             cf o1[G::R1][G::B1];
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(G::T *SPW, (BLU && G::P > 8 && G::T <= 64) ? WF_WPS
         }
         __syncthreads();
         if(do_db && ch == 0 && row_thread) {
-            const float *other = reinterpret_cast<const float *>(lds + G::LDS_CF);
+            const float *other = reinterpret_cast<const float *>(lds + lds_cf);
 #pragma unroll
             for(int u = 0; u < RP / 4; ++u) {
                 const f4 o = *reinterpret_cast<const f4 *>(other + 4 * (t + RG::T * u));

@@ -316,7 +316,7 @@ WF_DEV void mr_pass_prime(int p, const cf *src, cf *dst, const cf *wp, int np, i
         mr_pass_prime_jb<4>(p, src, dst, wp, np, t, T);
 }
 // first pass (ns == 1: no twiddles): every planned radix
-WF_DEV void mr_pass_first(int R, const cf *src, cf *dst, int np, int t, int T)
+template<bool SMALL = false> WF_DEV void mr_pass_first(int R, const cf *src, cf *dst, int np, int t, int T)
 {
     switch(R) {
     case 2: mr_pass_r<2, false>(src, dst, nullptr, np, 1, t, T); break;
@@ -324,24 +324,24 @@ WF_DEV void mr_pass_first(int R, const cf *src, cf *dst, int np, int t, int T)
     case 4: mr_pass_r<4, false>(src, dst, nullptr, np, 1, t, T); break;
     case 5: mr_pass_r<5, false>(src, dst, nullptr, np, 1, t, T); break;
     case 6: mr_pass_r<6, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 7: mr_pass_r<7, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 7: if constexpr(!SMALL) mr_pass_r<7, false>(src, dst, nullptr, np, 1, t, T); break;
     case 8: mr_pass_r<8, false>(src, dst, nullptr, np, 1, t, T); break;
     case 9: mr_pass_r<9, false>(src, dst, nullptr, np, 1, t, T); break;
     case 10: mr_pass_r<10, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 11: mr_pass_r<11, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 11: if constexpr(!SMALL) mr_pass_r<11, false>(src, dst, nullptr, np, 1, t, T); break;
     case 12: mr_pass_r<12, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 13: mr_pass_r<13, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 15: mr_pass_r<15, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 16: mr_pass_r<16, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 17: mr_pass_r<17, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 19: mr_pass_r<19, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 23: mr_pass_r<23, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 20: mr_pass_r<20, false>(src, dst, nullptr, np, 1, t, T); break;
-    default: mr_pass_r<25, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 13: if constexpr(!SMALL) mr_pass_r<13, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 15: if constexpr(!SMALL) mr_pass_r<15, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 16: if constexpr(!SMALL) mr_pass_r<16, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 17: if constexpr(!SMALL) mr_pass_r<17, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 19: if constexpr(!SMALL) mr_pass_r<19, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 23: if constexpr(!SMALL) mr_pass_r<23, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 20: if constexpr(!SMALL) mr_pass_r<20, false>(src, dst, nullptr, np, 1, t, T); break;
+    default: if constexpr(!SMALL) mr_pass_r<25, false>(src, dst, nullptr, np, 1, t, T); break;
     }
 }
 // middle passes: radices up to 16
-WF_DEV void mr_pass(int R, const cf *src, cf *dst, const cf *tw, int np, int ns, int t, int T)
+template<bool SMALL = false> WF_DEV void mr_pass(int R, const cf *src, cf *dst, const cf *tw, int np, int ns, int t, int T)
 {
     switch(R) {
     case 2: mr_pass_r<2, true>(src, dst, tw, np, ns, t, T); break;
@@ -349,15 +349,15 @@ WF_DEV void mr_pass(int R, const cf *src, cf *dst, const cf *tw, int np, int ns,
     case 4: mr_pass_r<4, true>(src, dst, tw, np, ns, t, T); break;
     case 5: mr_pass_r<5, true>(src, dst, tw, np, ns, t, T); break;
     case 6: mr_pass_r<6, true>(src, dst, tw, np, ns, t, T); break;
-    case 7: mr_pass_r<7, true>(src, dst, tw, np, ns, t, T); break;
+    case 7: if constexpr(!SMALL) mr_pass_r<7, true>(src, dst, tw, np, ns, t, T); break;
     case 8: mr_pass_r<8, true>(src, dst, tw, np, ns, t, T); break;
     case 9: mr_pass_r<9, true>(src, dst, tw, np, ns, t, T); break;
     case 10: mr_pass_r<10, true>(src, dst, tw, np, ns, t, T); break;
-    case 11: mr_pass_r<11, true>(src, dst, tw, np, ns, t, T); break;
+    case 11: if constexpr(!SMALL) mr_pass_r<11, true>(src, dst, tw, np, ns, t, T); break;
     case 12: mr_pass_r<12, true>(src, dst, tw, np, ns, t, T); break;
-    case 13: mr_pass_r<13, true>(src, dst, tw, np, ns, t, T); break;
-    case 15: mr_pass_r<15, true>(src, dst, tw, np, ns, t, T); break;
-    default: mr_pass_r<16, true>(src, dst, tw, np, ns, t, T); break;
+    case 13: if constexpr(!SMALL) mr_pass_r<13, true>(src, dst, tw, np, ns, t, T); break;
+    case 15: if constexpr(!SMALL) mr_pass_r<15, true>(src, dst, tw, np, ns, t, T); break;
+    default: if constexpr(!SMALL) mr_pass_r<16, true>(src, dst, tw, np, ns, t, T); break;
     }
 }
 // the last pass: ns R == np, at most one butterfly per thread (j = t < nb = ns); X[j + k ns] handed to `store` behind `sync`
@@ -375,7 +375,7 @@ template<int R, class Sync, class Store> WF_DEV void mr_last_r(bool process, con
             store(t + k * ns, v[k]);
     }
 }
-template<class Sync, class Store> WF_DEV void mr_last(int R, bool process, const cf *src, const cf *tw, int ns, int t, Sync sync, Store store)
+template<bool SMALL = false, class Sync, class Store> WF_DEV void mr_last(int R, bool process, const cf *src, const cf *tw, int ns, int t, Sync sync, Store store)
 {
     switch(R) {
     case 2: mr_last_r<2>(process, src, tw, ns, t, sync, store); break;
@@ -383,15 +383,15 @@ template<class Sync, class Store> WF_DEV void mr_last(int R, bool process, const
     case 4: mr_last_r<4>(process, src, tw, ns, t, sync, store); break;
     case 5: mr_last_r<5>(process, src, tw, ns, t, sync, store); break;
     case 6: mr_last_r<6>(process, src, tw, ns, t, sync, store); break;
-    case 7: mr_last_r<7>(process, src, tw, ns, t, sync, store); break;
+    case 7: if constexpr(!SMALL) mr_last_r<7>(process, src, tw, ns, t, sync, store); else sync(); break;
     case 8: mr_last_r<8>(process, src, tw, ns, t, sync, store); break;
     case 9: mr_last_r<9>(process, src, tw, ns, t, sync, store); break;
     case 10: mr_last_r<10>(process, src, tw, ns, t, sync, store); break;
-    case 11: mr_last_r<11>(process, src, tw, ns, t, sync, store); break;
+    case 11: if constexpr(!SMALL) mr_last_r<11>(process, src, tw, ns, t, sync, store); else sync(); break;
     case 12: mr_last_r<12>(process, src, tw, ns, t, sync, store); break;
-    case 13: mr_last_r<13>(process, src, tw, ns, t, sync, store); break;
-    case 15: mr_last_r<15>(process, src, tw, ns, t, sync, store); break;
-    default: mr_last_r<16>(process, src, tw, ns, t, sync, store); break;
+    case 13: if constexpr(!SMALL) mr_last_r<13>(process, src, tw, ns, t, sync, store); else sync(); break;
+    case 15: if constexpr(!SMALL) mr_last_r<15>(process, src, tw, ns, t, sync, store); else sync(); break;
+    default: if constexpr(!SMALL) mr_last_r<16>(process, src, tw, ns, t, sync, store); else sync(); break;
     }
 }
 
@@ -446,32 +446,35 @@ template<class G> WF_DEV bool mr_fetch(const TickArgs &a, int t, const float *x,
 
 // The whole transform.  On entry the np windowed points sit in lds[0 .. np) (natural order); Z[k] is handed to store(k, Z[k]) by
 // the thread that finishes it.  Called by ALL threads of the spectrum (sync is its barrier).
-template<class G, class Sync, class Store> WF_DEV void mr_transform_to(const MrPlan &p, bool process, int np, int t, cf *lds, const cf *wp_lds, Sync sync, Store store)
+// SMALL: the instantiation that carries the radices 2, 3, 4, 5, 6, 8, 9, 10 and 12 only (wf::mr_small_radices: the host picks it for
+// plans made of those) -- the register-hungry in-register DFTs compile to nothing
+template<class G, bool SMALL = false, class Sync, class Store> WF_DEV void mr_transform_to(const MrPlan &p, bool process, int np, int t, cf *lds, const cf *wp_lds, Sync sync, Store store)
 {
-    constexpr int H = G::M / 2; // second half of the exchange buffer (M >= 2 np)
+    const int H = p.half; // second half of the exchange buffer (MrPlan::half >= np)
     sync(); // the fetch has written the first half
     if(process) {
-        if(p.radix[0] > 25) // (uniform) a prime of 29 .. 127: by the definition, its twiddles in LDS at wp_lds
-            mr_pass_prime(p.radix[0], lds, lds + H, wp_lds, np, t, G::T);
-        else
-            mr_pass_first(p.radix[0], lds, lds + H, np, t, G::T);
+        if(!SMALL && p.radix[0] > 25) { // (uniform) a prime of 29 .. 127: by the definition, its twiddles in LDS at wp_lds
+            if constexpr(!SMALL)
+                mr_pass_prime(p.radix[0], lds, lds + H, wp_lds, np, t, G::T);
+        } else
+            mr_pass_first<SMALL>(p.radix[0], lds, lds + H, np, t, G::T);
     }
     int ns = p.radix[0], cur = 1;
     for(int s = 1; s + 1 < p.passes; ++s) {
         const int R = p.radix[s];
         sync();
         if(process)
-            mr_pass(R, lds + cur * H, lds + (1 - cur) * H, p.tw + p.tw_off[s], np, ns, t, G::T);
+            mr_pass<SMALL>(R, lds + cur * H, lds + (1 - cur) * H, p.tw + p.tw_off[s], np, ns, t, G::T);
         cur ^= 1;
         ns *= R;
     }
     sync();
-    mr_last(p.radix[p.passes - 1], process, lds + cur * H, p.tw + p.tw_off[p.passes - 1], ns, t, sync, store);
+    mr_last<SMALL>(p.radix[p.passes - 1], process, lds + cur * H, p.tw + p.tw_off[p.passes - 1], ns, t, sync, store);
 }
-// ... with Z[k] left at ex3_addr<G>(k) of the exchange buffer, visible to every thread of the spectrum on return
-template<class G, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool process, int np, int t, cf *lds, const cf *wp_lds, Sync sync)
+// ... with Z[k] left at mr_z_addr(p, k) of the exchange buffer, visible to every thread of the spectrum on return
+template<class G, bool SMALL = false, class Sync> WF_DEV void mr_transform(const MrPlan &p, bool process, int np, int t, cf *lds, const cf *wp_lds, Sync sync)
 {
-    mr_transform_to<G>(p, process, np, t, lds, wp_lds, sync, [lds](int k, cf v) { lds_st2(lds, ex3_addr<G>(k), v); });
+    mr_transform_to<G, SMALL>(p, process, np, t, lds, wp_lds, sync, [lds, &p](int k, cf v) { lds_st2(lds, mr_z_addr(p, k), v); });
     sync();
 }
 

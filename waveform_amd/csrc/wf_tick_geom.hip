@@ -80,21 +80,22 @@ template<class G, int DEC> int setup_launch_dec(wf_hip *h)
 }
 
 // Bluestein path (FFT sizes that are not powers of two): always the scalar fetch
-template<class G, int SPW, bool SPLIT, bool MR = false> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a0, bool)
+template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> void launch_tick_blu(wf_hip *h, const wf::TickArgs &a0, bool)
 {
     const uint32_t n_spec = a0.stream_count * a0.cap_ch;
     const dim3 block(G::T * SPW);
-    const size_t lds = wf::tick_lds_bytes<G, SPW>();
+    // (mixed radix: the exchange buffers by the transform's size, MrPlan::lds_cf)
+    const size_t lds = wf::tick_lds_bytes<G, SPW>() - (MR ? (size_t)SPW * ((size_t)G::LDS_CF - (size_t)h->mr_lds_cf) * sizeof(wf::cf) : 0);
     const bool two = SPLIT && h->split_mono; // mono mixdown in two launches (TickArgs::split_ch)
     for(int pass = 0; pass < (two ? 2 : 1); ++pass) {
         wf::TickArgs a = a0;
         a.split_ch = two ? (uint32_t)(1 - pass) : 0xffffffffu;
         const dim3 grid(two ? a.stream_count : (n_spec + SPW - 1) / SPW);
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR>), grid, block, lds, h->launch_stream, a);
+        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS>), grid, block, lds, h->launch_stream, a);
     }
 }
 
-template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_hip *h)
+template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> int setup_launch_blu(wf_hip *h)
 {
     if constexpr(!MR && G::N >= 1024) { // (the smallest container a size that is not a power of two ever gets: wf::bluestein_length)
         // sizes with small prime factors take the same instantiation's fetch and epilogue around a direct transform
@@ -130,13 +131,32 @@ template<class G, int SPW, bool SPLIT, bool MR = false> int setup_launch_blu(wf_
                 }
             }
 #endif
+            // one-wavefront containers: plans made of small radices take the instantiation that carries only those (five waves per SIMD)
+            if constexpr(G::T == 64 && G::P > 8 && !SPLIT) {
+                bool small = wf::mr_small_radices(h->mr_radix, h->mr_passes);
+#ifdef WF_DEV_OVERRIDES
+                if(const char *e = std::getenv("WF_HIP_MR_SMALL")) // 0: the instantiation with every radix (A/B)
+                    small = small && e[0] != '0';
+#endif
+                if(small)
+                    return setup_launch_blu<G, SPW, SPLIT, true, true>(h);
+            }
             return setup_launch_blu<G, SPW, SPLIT, true>(h);
         }
     }
-    const int lds = (int)wf::tick_lds_bytes<G, SPW>();
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR>),
+    int lds = (int)wf::tick_lds_bytes<G, SPW>();
+    // (the attribute belongs to the kernel, not to this handle: always the container's size -- another handle of another fft size
+    // on the same instantiation may need all of it)
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    h->launch = &launch_tick_blu<G, SPW, SPLIT, MR>;
+    if constexpr(MR) {
+        // the spectrum's exchange buffer by the transform's size, not the container's (MrPlan::lds_cf): room for more spectra per CU
+        h->mr_half = (int)wf::mr_exchange_half(h->N / 2);
+        h->mr_lds_cf = (int)wf::mr_exchange_cf(h->N / 2, (uint32_t)G::LDS_CF);
+        h->mr_s3 = h->mr_half / 4 + 4;
+        lds -= SPW * ((int)G::LDS_CF - h->mr_lds_cf) * (int)sizeof(wf::cf);
+    }
+    h->launch = &launch_tick_blu<G, SPW, SPLIT, MR, MRS>;
     h->wg_lds = (uint32_t)lds;
     h->wg_threads = (uint32_t)(G::T * SPW);
     h->split = SPLIT;

@@ -145,7 +145,13 @@ struct MrPlan {
     const cf *wp;               // radix[0] a prime above 25 (mr_pass_prime): [radix[0]] W_p^m in device memory (the tick kernel finds it in
                                 // its LDS twiddle area, staged with the other tables; the large-FFT rows kernel copies it there itself)
     const cf *tw;               // per pass [R][Ns]: W_(Ns R)^(k jm), Ns = product of the radices before it (coalesced across a wavefront's butterflies)
+    // The spectrum's exchange buffer, sized by the TRANSFORM rather than by the container geometry (wf::mr_exchange_cf): the passes
+    // work between its two halves of `half` >= n/2 points, the finished Z[k] sits at (k & 3) * s3 + (k >> 2) -- ex3_addr's
+    // four planes with a plane stride that fits n/2 points -- and spectrum s of a workgroup starts at s * lds_cf.  N = 800 on
+    // the 2048-sample container: 6.5 instead of 8.7 KB per spectrum.
+    int half, s3, lds_cf;
 };
+WF_DEV int mr_z_addr(const MrPlan &p, int k) { return (k & 3) * p.s3 + (k >> 2); }
 
 struct TickArgs {
     // audio rings: one per (stream, captured channel), ring_cap samples each (power of two)
@@ -853,7 +859,7 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
             WF_UNROLL
             for(int i = 0; i < 4; ++i) {
                 const int k = k0 + i, km = (k == 0) ? 0 : np - k;
-                const cf rk = lds_ld2(lds, ex3_addr<G>(k)), rm = lds_ld2(lds, ex3_addr<G>(km));
+                const cf rk = lds_ld2(lds, MR ? mr_z_addr(a.mr, k) : ex3_addr<G>(k)), rm = lds_ld2(lds, MR ? mr_z_addr(a.mr, km) : ex3_addr<G>(km));
                 const cf A = MR ? rk : cmul(cf{rk.x, -rk.y}, Q[i]), B = MR ? rm : cmul(cf{rm.x, -rm.y}, QR[i]);
                 const float er = A.x + B.x, ei = A.y - B.y;
                 const float dr = A.x - B.x, di = A.y + B.y;
@@ -918,7 +924,7 @@ WF_DEV void p4_split_mr_impl(const TickArgs &a, int t, const cf *lds, float *ts,
             WF_UNROLL
             for(int i = 0; i < 4; ++i) {
                 const int k = k0 + i, km = (k == 0) ? 0 : np - k;
-                const cf A = lds_ld2(lds, ex3_addr<G>(k)), B = lds_ld2(lds, ex3_addr<G>(km));
+                const cf A = lds_ld2(lds, mr_z_addr(a.mr, k)), B = lds_ld2(lds, mr_z_addr(a.mr, km));
                 const float er = A.x + B.x, ei = A.y - B.y;
                 const float dr = A.x - B.x, di = A.y + B.y;
                 const float pr = fmaf(W[i].x, dr, -(W[i].y * di)); // Re(W D)
