@@ -153,7 +153,7 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false>
 __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
-    static_assert(!MRS || (MR && G::T == 64 && G::P > 8), "the small-radix instantiation belongs to the one-wavefront 16-point container");
+    static_assert(!MRS || (MR && G::T <= 256 && G::P > 8), "the small-radix instantiation belongs to the containers of one, two and four wavefronts");
     static_assert(!BOTH || (SPW == 2 && !SPLIT && DEC == 0 && !BLU), "shared curve row: two spectra per workgroup, power-of-two sizes");
     static_assert(!BLU || (DEC == 0 && !TLDS && !ALIGNED), "Bluestein path: scalar fetch, no decimation, no staged tables");
     static_assert(!MR || BLU, "the mixed-radix transform (wf_mixed.hpp) runs inside the Bluestein instantiation's fetch and epilogue");

@@ -132,7 +132,7 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> int se
             }
 #endif
             // one-wavefront containers: plans made of small radices take the instantiation that carries only those (five waves per SIMD)
-            if constexpr(G::T == 64 && G::P > 8 && !SPLIT) {
+            if constexpr(G::T <= 256 && G::P > 8) {
                 bool small = wf::mr_small_radices(h->mr_radix, h->mr_passes);
 #ifdef WF_DEV_OVERRIDES
                 if(const char *e = std::getenv("WF_HIP_MR_SMALL")) // 0: the instantiation with every radix (A/B)
