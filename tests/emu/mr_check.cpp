@@ -49,7 +49,7 @@ int main()
 {
     check_dft<2>(); check_dft<3>(); check_dft<4>(); check_dft<5>(); check_dft<6>(); check_dft<8>(); check_dft<9>(); check_dft<10>();
     check_dft<12>(); check_dft<15>(); check_dft<16>(); check_dft<20>(); check_dft<25>(); check_dft<7>(); check_dft<11>(); check_dft<13>(); check_dft<17>(); check_dft<19>(); check_dft<23>();
-    int planned = 0;
+    int planned = 0, small_plans = 0;
     for(unsigned n = 128; n <= 16384; n += 16) {
         unsigned r = n;
         for(unsigned p : {2u, 3u, 5u, 7u, 11u, 13u})
@@ -89,7 +89,26 @@ int main()
         }
         CHECK(passes >= 2 && passes <= 4 && prod == np, "n = %u: %d passes, product %llu", n, passes, prod);
         CHECK(np / (unsigned)radix[passes - 1] <= T, "n = %u: last pass has %u butterflies for %u threads", n, np / radix[passes - 1], T);
+        // the exchange buffer sized by the transform (MrPlan::half / s3 / lds_cf as setup_launch_blu fills them): both halves hold the
+        // points, the four-plane layout of the finished Z fits, never beyond the container geometry's buffer (M + padding >= 2 np)
+        unsigned M = 512;
+        while(M < 2 * np)
+            M <<= 1;
+        const unsigned container = M + M / 16 + 64; // (a lower bound of every Geom<2 M, ..>::LDS_CF: EX1 / EX3 padding)
+        const unsigned half = mr_exchange_half(np), cfb = mr_exchange_cf(np, container), s3 = half / 4 + 4;
+        CHECK(half >= np && half % 16 == 0 && half <= M / 2 + 15, "n = %u: half %u", n, half);
+        CHECK(cfb >= 2 * half || cfb == container, "n = %u: buffer %u for two halves of %u", n, cfb, half);
+        CHECK(3 * s3 + (np - 1) / 4 < cfb, "n = %u: Z's last plane ends at %u of %u", n, 3 * s3 + (np - 1) / 4, cfb);
+        CHECK(cfb >= 576 || cfb == container, "n = %u: the display phase's floor (576), got %u", n, cfb);
+        // the small-radix instantiation is picked for plans made of its radices only
+        bool all_small = true;
+        for(int i = 0; i < passes; ++i)
+            all_small = all_small && (radix[i] == 2 || radix[i] == 3 || radix[i] == 4 || radix[i] == 5 || radix[i] == 6 || radix[i] == 8 || radix[i] == 9 || radix[i] == 10 || radix[i] == 12);
+        CHECK(mr_small_radices(radix, passes) == all_small, "n = %u: mr_small_radices", n);
+        small_plans += all_small && T <= 256;
     }
+    CHECK(small_plans >= 30, "only %d sizes on the small-radix instantiation", small_plans); // (34: the automatic sizes 640 ... 2400 among them)
+    std::printf("small-radix plans on one to four wavefronts: %d\n", small_plans);
     std::printf("planned %d sizes\n", planned);
     for(unsigned n : {800u, 1600u, 960u, 1920u, 2000u, 320u, 144u, 8000u, 1536u, 15552u, 12288u, 6000u, 4160u, 1760u, 1456u, 880u, 352u, 16016u, 224u, 1824u, 304u, 1088u, 1472u, 5888u, 14720u, 4144u, 2368u, 1856u, 8128u, 16256u, 592u, 7808u}) {
         int radix[4], off[4];
