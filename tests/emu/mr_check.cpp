@@ -103,7 +103,7 @@ int main()
         // the small-radix instantiation is picked for plans made of its radices only
         bool all_small = true;
         for(int i = 0; i < passes; ++i)
-            all_small = all_small && (radix[i] == 2 || radix[i] == 3 || radix[i] == 4 || radix[i] == 5 || radix[i] == 6 || radix[i] == 8 || radix[i] == 9 || radix[i] == 10 || radix[i] == 12);
+            all_small = all_small && (radix[i] == 2 || radix[i] == 3 || radix[i] == 4 || radix[i] == 5 || radix[i] == 6 || radix[i] == 7 || radix[i] == 8 || radix[i] == 9 || radix[i] == 10 || radix[i] == 11 || radix[i] == 12);
         CHECK(mr_small_radices(radix, passes) == all_small, "n = %u: mr_small_radices", n);
         small_plans += all_small && T <= 256;
     }

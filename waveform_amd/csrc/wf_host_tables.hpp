@@ -149,12 +149,12 @@ inline uint32_t mr_exchange_cf(uint32_t np, uint32_t container_lds_cf)
     return want < 576u ? (576u < container_lds_cf ? 576u : container_lds_cf) : (want < container_lds_cf ? want : container_lds_cf);
 }
 // the radices the one-wavefront container's small instantiation carries (spectrum_tick_kernel<.., MRS>): without the in-register
-// DFTs of 7, 11, 13, 15, 16 and the first-pass radices its threads get by with 96 registers -- a fifth wave per SIMD
+// DFTs of 13, 15, 16 and the first-pass radices its threads get by with 96 registers -- a fifth wave per SIMD
 inline bool mr_small_radices(const int *radix, int passes)
 {
     for(int i = 0; i < passes; ++i)
         switch(radix[i]) {
-        case 2: case 3: case 4: case 5: case 6: case 8: case 9: case 10: case 12: break;
+        case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: break;
         default: return false;
         }
     return passes > 0;

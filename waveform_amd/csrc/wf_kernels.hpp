@@ -147,7 +147,7 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // spectra.  A template parameter, not a run-time flag: the extra code cost the 2048-point kernel a VGPR too many (129: three
 // waves per SIMD instead of four) and 5-15 % even on configurations that never take the path.
 //
-// MRS (with MR, one-wavefront containers): the mixed-radix instantiation for plans of the radices 2, 3, 4, 5, 6, 8, 9, 10, 12 (N = 800
+// MRS (with MR; containers of one, two and four wavefronts): the mixed-radix instantiation for plans of the radices 2 ... 12 (N = 800
 // as 5 x 10 x 8, 960 as 5 x 12 x 8 ...).  Without the large in-register DFTs the kernel fits 96 registers -- five waves per SIMD instead
 // of four, and the tick of these sizes scales with the spectra in flight (profiles/r04g_n800_phases.txt).
 template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false>

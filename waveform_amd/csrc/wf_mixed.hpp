@@ -324,11 +324,11 @@ template<bool SMALL = false> WF_DEV void mr_pass_first(int R, const cf *src, cf 
     case 4: mr_pass_r<4, false>(src, dst, nullptr, np, 1, t, T); break;
     case 5: mr_pass_r<5, false>(src, dst, nullptr, np, 1, t, T); break;
     case 6: mr_pass_r<6, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 7: if constexpr(!SMALL) mr_pass_r<7, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 7: mr_pass_r<7, false>(src, dst, nullptr, np, 1, t, T); break;
     case 8: mr_pass_r<8, false>(src, dst, nullptr, np, 1, t, T); break;
     case 9: mr_pass_r<9, false>(src, dst, nullptr, np, 1, t, T); break;
     case 10: mr_pass_r<10, false>(src, dst, nullptr, np, 1, t, T); break;
-    case 11: if constexpr(!SMALL) mr_pass_r<11, false>(src, dst, nullptr, np, 1, t, T); break;
+    case 11: mr_pass_r<11, false>(src, dst, nullptr, np, 1, t, T); break;
     case 12: mr_pass_r<12, false>(src, dst, nullptr, np, 1, t, T); break;
     case 13: if constexpr(!SMALL) mr_pass_r<13, false>(src, dst, nullptr, np, 1, t, T); break;
     case 15: if constexpr(!SMALL) mr_pass_r<15, false>(src, dst, nullptr, np, 1, t, T); break;
@@ -349,11 +349,11 @@ template<bool SMALL = false> WF_DEV void mr_pass(int R, const cf *src, cf *dst, 
     case 4: mr_pass_r<4, true>(src, dst, tw, np, ns, t, T); break;
     case 5: mr_pass_r<5, true>(src, dst, tw, np, ns, t, T); break;
     case 6: mr_pass_r<6, true>(src, dst, tw, np, ns, t, T); break;
-    case 7: if constexpr(!SMALL) mr_pass_r<7, true>(src, dst, tw, np, ns, t, T); break;
+    case 7: mr_pass_r<7, true>(src, dst, tw, np, ns, t, T); break;
     case 8: mr_pass_r<8, true>(src, dst, tw, np, ns, t, T); break;
     case 9: mr_pass_r<9, true>(src, dst, tw, np, ns, t, T); break;
     case 10: mr_pass_r<10, true>(src, dst, tw, np, ns, t, T); break;
-    case 11: if constexpr(!SMALL) mr_pass_r<11, true>(src, dst, tw, np, ns, t, T); break;
+    case 11: mr_pass_r<11, true>(src, dst, tw, np, ns, t, T); break;
     case 12: mr_pass_r<12, true>(src, dst, tw, np, ns, t, T); break;
     case 13: if constexpr(!SMALL) mr_pass_r<13, true>(src, dst, tw, np, ns, t, T); break;
     case 15: if constexpr(!SMALL) mr_pass_r<15, true>(src, dst, tw, np, ns, t, T); break;
@@ -383,11 +383,11 @@ template<bool SMALL = false, class Sync, class Store> WF_DEV void mr_last(int R,
     case 4: mr_last_r<4>(process, src, tw, ns, t, sync, store); break;
     case 5: mr_last_r<5>(process, src, tw, ns, t, sync, store); break;
     case 6: mr_last_r<6>(process, src, tw, ns, t, sync, store); break;
-    case 7: if constexpr(!SMALL) mr_last_r<7>(process, src, tw, ns, t, sync, store); else sync(); break;
+    case 7: mr_last_r<7>(process, src, tw, ns, t, sync, store); break;
     case 8: mr_last_r<8>(process, src, tw, ns, t, sync, store); break;
     case 9: mr_last_r<9>(process, src, tw, ns, t, sync, store); break;
     case 10: mr_last_r<10>(process, src, tw, ns, t, sync, store); break;
-    case 11: if constexpr(!SMALL) mr_last_r<11>(process, src, tw, ns, t, sync, store); else sync(); break;
+    case 11: mr_last_r<11>(process, src, tw, ns, t, sync, store); break;
     case 12: mr_last_r<12>(process, src, tw, ns, t, sync, store); break;
     case 13: if constexpr(!SMALL) mr_last_r<13>(process, src, tw, ns, t, sync, store); else sync(); break;
     case 15: if constexpr(!SMALL) mr_last_r<15>(process, src, tw, ns, t, sync, store); else sync(); break;
@@ -446,7 +446,7 @@ template<class G> WF_DEV bool mr_fetch(const TickArgs &a, int t, const float *x,
 
 // The whole transform.  On entry the np windowed points sit in lds[0 .. np) (natural order); Z[k] is handed to store(k, Z[k]) by
 // the thread that finishes it.  Called by ALL threads of the spectrum (sync is its barrier).
-// SMALL: the instantiation that carries the radices 2, 3, 4, 5, 6, 8, 9, 10 and 12 only (wf::mr_small_radices: the host picks it for
+// SMALL: the instantiation that carries the radices 2 ... 12 only (wf::mr_small_radices: the host picks it for
 // plans made of those) -- the register-hungry in-register DFTs compile to nothing
 template<class G, bool SMALL = false, class Sync, class Store> WF_DEV void mr_transform_to(const MrPlan &p, bool process, int np, int t, cf *lds, const cf *wp_lds, Sync sync, Store store)
 {
