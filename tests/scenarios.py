@@ -623,4 +623,7 @@ class HipBackend:
         return rec
 
     def close(self):
+        import os
+        if os.environ.get("WF_HIP_CANARY"):  # the guard bytes behind every device block are compared in wf_hip_sync: a kernel that wrote past a buffer fails the case here
+            self.batch.sync()
         self.batch.close()
