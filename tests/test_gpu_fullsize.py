@@ -104,6 +104,36 @@ def test_cfg3_whole_batch_equals_small_handles():
             assert_db_close(rows, want, f"64-stream handle, streams {base}..{base + part - 1} vs oracle", deep=True)
 
 
+@pytest.mark.parametrize("n,streams,lanes", [(65536, 264, 2), (32768, 520, 3)])
+def test_lanes_on_the_one_workgroup_per_cu_kernels(n, streams, lanes):
+    """fft_size 65536 (big_whole_kernel) and 32768 take two / three lanes once the batch is two rounds of one-workgroup-per-CU
+    workgroups: the whole batch after a few ticks must equal, bit for bit, the same streams replayed through small one-lane handles
+    (every stream, across both lane boundaries), and one small block -- the one that straddles the first boundary -- the oracle."""
+    cfg = wf.Config.defaults(fft_size=n, stereo=1, slope=1.0)
+    ticks, hop, part = 5, 800, 24
+    with wf.SpectrumBatch(cfg, streams, ring_frames=n + hop * (ticks + 1)) as b:
+        assert b.launches_per_tick() == lanes, b.kernel_name()
+        b.push_synth(SEED, 0, hop * ticks)
+        for t in range(ticks):
+            b.tick(delay_frames=hop * (ticks - 1 - t))
+        full, full_state = b.decibels(), b.tsmooth()
+    boundary = streams // lanes
+    checked_base = boundary - part // 2
+    for base in list(range(0, streams, part)) + [checked_base]:
+        cnt = min(part, streams - base)
+        with wf.SpectrumBatch(cfg, cnt, ring_frames=n + hop * (ticks + 1)) as s:
+            assert s.launches_per_tick() == 1
+            s.push_synth(SEED, 0, hop * ticks, stream_id0=base)
+            for t in range(ticks):
+                s.tick(delay_frames=hop * (ticks - 1 - t))
+            rows, state = s.decibels(), s.tsmooth()
+        assert np.array_equal(rows, full[base:base + cnt]), f"N = {n}, streams {base}..{base + cnt - 1}: rows of the {streams}-stream batch differ from a {cnt}-stream handle"
+        assert np.array_equal(state, full_state[base:base + cnt]), f"N = {n}, streams {base}..{base + cnt - 1}: smoothing state differs"
+        if base == checked_base:
+            want, _ = _oracle_rows(cfg, range(base, base + 4), ticks, hop)
+            assert_db_close(rows[:4], want, f"N = {n}: {cnt}-stream handle, streams {base}..{base + 3} vs oracle", deep=True)
+
+
 def test_cfg2_256_consecutive_frames():
     """configs[1]: stereo, FFT 2048, Hann + magnitude + dB, no smoothing, "batch = 256 frames": 256 consecutive 60 fps frames
     of one stereo stream.  Every frame against the oracle; and the same 256 frames as ONE batch -- stream i analyses the
