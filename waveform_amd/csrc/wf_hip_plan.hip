@@ -526,6 +526,11 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(h->num_bars) {
         const size_t mark = h->allocs.size();
         int orc = plan_outputs(false);
+#ifdef WF_DEV_OVERRIDES
+        if(const char *e = std::getenv("WF_HIP_EXT_OUTPUTS")) // 1: the display from the stored rows by big_outputs_kernel even where the tick kernel could finish it (A/B)
+            if(e[0] == '1' && orc == WF_HIP_OK)
+                orc = WF_HIP_ERR_UNSUPPORTED;
+#endif
         if(orc == WF_HIP_ERR_UNSUPPORTED && h->big_l == 0) {
             // give back what the first plan uploaded, forget what it decided, plan again for big_outputs_kernel
             WF_CREATE_HIP(hipStreamSynchronize(h->stream));
