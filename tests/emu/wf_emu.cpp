@@ -312,6 +312,28 @@ long wfemu_bar_pieces(const wf_config *cfg, int threads, int points, int max_blo
     return (long)v.size();
 }
 
+// the prefix-sum form (wf::bar_ps).  which: 0 the lane table [blocks][5][64][4] (integers as bit patterns), 1 scalars
+// {num_lanes, num_subs}; -1000 if the form does not exist for this configuration
+long wfemu_bar_ps(const wf_config *cfg, int threads, int which, float *out, long cap)
+{
+    wf::HostTables tab;
+    const int rc = wf::build_host_tables(*cfg, tab);
+    if(rc != 0)
+        return rc;
+    wf::BarPsTables ps;
+    if(!wf::bar_ps(tab, threads, ps))
+        return -1000;
+    std::vector<float> v;
+    switch(which) {
+    case 0: v = ps.tab; break;
+    case 1: v = {(float)ps.num_lanes, (float)ps.num_subs}; break;
+    default: return -1;
+    }
+    for(long i = 0; i < (long)v.size() && i < cap; ++i)
+        out[i] = v[(size_t)i];
+    return (long)v.size();
+}
+
 int wfemu_lds_bytes(uint32_t fft_size)
 {
     int r = -1;

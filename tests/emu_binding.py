@@ -69,6 +69,21 @@ def bar_pieces(cfg, threads: int, points: int, max_blocks: int, which: int):
     return out[:n]
 
 
+def bar_ps(cfg, threads: int, which: int):
+    """prefix-sum form of the bar tables (wf::bar_ps); None if it does not exist for this configuration"""
+    L = lib()
+    L.wfemu_bar_ps.restype = C.c_long
+    L.wfemu_bar_ps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_long]
+    n = L.wfemu_bar_ps(C.cast(C.byref(cfg), C.c_void_p), threads, which, None, 0)
+    if n == -1000:
+        return None
+    if n < 0:
+        raise ValueError(f"wfemu_bar_ps failed: {n}")
+    out = np.zeros(max(n, 1), np.float32)
+    L.wfemu_bar_ps(C.cast(C.byref(cfg), C.c_void_p), threads, which, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+    return out[:n]
+
+
 def tick(cfg, ring: np.ndarray, wpos: int, tsmooth: np.ndarray, delay: int = 0, seconds: float = 1 / 60):
     """ring: float32 [spectra, ring_cap]; tsmooth: float32 [spectra, M] (updated in place).
     Returns (decibels [streams, out_ch, M], stats[6])"""

@@ -77,6 +77,8 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.lead_end = h->d_lead_end;
         a.bar.wave_local = h->bar_wave_local ? 1 : 0;
         a.bar.piece_mode = h->bar_piece_mode ? 1 : 0;
+        a.bar.ps_tab = h->d_ps_tab;
+        a.bar.ps_lanes = h->bar_ps_lanes;
         a.bar.num_segs = h->bar_segs;
         a.bar.lane_blocks = h->bar_blocks;
         a.bar.cur_coef = h->d_cur_coef;

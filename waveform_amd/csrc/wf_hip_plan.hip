@@ -403,6 +403,21 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             if(const char *e = std::getenv("WF_HIP_BAR_PIECES"))
                 want_pieces = want_pieces && e[0] != '0';
 #endif
+            // prefix-sum layout first (BarPsTables: float64 prefix sums of the row in registers, one lane per sub-band -- no
+            // per-thread coefficient table at all); power-of-two sizes from 512 samples, no Gaussian filter
+            wf::BarPsTables ps;
+            bool want_ps = h->tab.gauss_radius == 0 && points >= 8 && !h->blu; // (wf::BarEntries<G>::PS: not on the four-point geometry)
+#ifdef WF_DEV_OVERRIDES
+            if(const char *e = std::getenv("WF_HIP_BAR_PS"))
+                want_ps = want_ps && e[0] != '0';
+#endif
+            if(want_ps && wf::bar_ps(h->tab, threads, ps) && wf::ps_lds_floats(h->M) <= lds_floats) {
+                h->bar_ps_lanes = ps.num_lanes;
+                h->out_steps = 1;
+                WF_PLAN_TRY(upload(h, &h->d_ps_tab, ps.tab));
+                WF_PLAN_HIP(hipStreamSynchronize(h->stream)); // the staging vector dies here
+                want_pieces = false;
+            }
             if(want_pieces && wf::bar_pieces(h->tab, threads, points, points / 4 + 2, pieces) &&
                (size_t)h->M + (size_t)pieces.num_slots <= lds_floats) {
                 h->bar_piece_mode = true;
@@ -420,7 +435,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             if(const char *e = std::getenv("WF_HIP_BARS_WAVE_LOCAL"))
                 local = local && e[0] != '0';
 #endif
-            if(!h->bar_piece_mode && wf::bar_segments(h->tab, threads, points / 4 + 2, lanes, local)) {
+            if(!h->bar_piece_mode && h->bar_ps_lanes == 0 && wf::bar_segments(h->tab, threads, points / 4 + 2, lanes, local)) {
                 h->bar_wave_local = lanes.wave_local;
                 h->bar_segs = lanes.num_segs;
                 h->bar_blocks = lanes.blocks;
@@ -507,7 +522,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             WF_PLAN_TRY(upload(h, &h->d_gauss_wsum, h->tab.gauss_wsum));
             WF_PLAN_HIP(hipStreamSynchronize(h->stream));
         }
-        if(h->bar_segs == 0 && !h->curve && !own_kernel) { // chunked form: a chunk holds at least one whole bar
+        if(h->bar_segs == 0 && h->bar_ps_lanes == 0 && !h->curve && !own_kernel) { // chunked form: a chunk holds at least one whole bar
             int longest = 0;
             for(uint32_t b = 0; b < h->num_bars; ++b)
                 longest = std::max(longest, h->tab.bar_off[(size_t)b + 1] - h->tab.bar_off[(size_t)b]);
@@ -544,6 +559,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             h->d_cur_coef = nullptr; h->d_cur_base = nullptr; h->d_cur_x = nullptr; h->d_gauss = nullptr; h->d_gauss_wsum = nullptr;
             h->d_lane_coef = nullptr; h->d_lane_base = nullptr; h->d_bar_seg = nullptr; h->d_seg_group = nullptr;
             h->d_lead_bar = nullptr; h->d_lead_end = nullptr;
+            h->d_ps_tab = nullptr; h->bar_ps_lanes = 0;
             h->curve = h->curve_both = h->curve_catrom = h->stream_steps = h->bar_wave_local = h->bar_piece_mode = false;
             h->out_steps = h->bar_segs = h->bar_blocks = h->bar_chunks = h->bar_stage_off = 0;
             h->bar_lpb = 1;

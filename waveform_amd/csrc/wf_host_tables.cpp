@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <cstdint>
 #include <limits>
 #include <numbers>
@@ -525,6 +526,130 @@ bool bar_pieces(const HostTables &t, int threads, int points, int max_blocks, Ba
     for(int w = 0; w < wps; ++w)
         out.num_segs += next[(size_t)w];
     out.num_slots = (int)pieces.size();
+    return true;
+}
+
+bool bar_ps(const HostTables &t, int threads, BarPsTables &out)
+{
+    out = BarPsTables{};
+    const intmax_t M = t.bar_rows_bins;
+    if(t.num_bars <= 0 || t.num_bars > 254 || threads < 64 || threads % 64 || M < 256 || M % 256 || M > 32767)
+        return false;
+    if(t.gauss_radius > 0 || (int)t.band_widths.size() != t.num_bars)
+        return false;
+    const bool point = t.interp_taps == 0;
+    const int taps = t.interp_taps, radius = t.interp_radius;
+    if(!point && !((taps == 8 && radius == 4) || (taps == 4 && radius == 2)))
+        return false;
+    struct Sub { int bar; intmax_t lo, hi; float w[8]; };
+    std::vector<Sub> subs;
+    size_t k = 0;
+    for(int i = 0; i < t.num_bars; ++i) {
+        const intmax_t count = t.band_widths[(size_t)i];
+        if(count < 1 || count > 65535)
+            return false;
+        if(point) { // sum += m_decibels[(size_t)m_interp_indices[i] + j], src/source.cpp:1529-1530
+            Sub s{i, 0, 0, {0, 0, 0, 1.0f, 0, 0, 0, 0}};
+            s.lo = std::clamp<intmax_t>((intmax_t)t.interp_indices[(size_t)i], 0, M);
+            s.hi = std::clamp<intmax_t>(s.lo + count, 0, M);
+            subs.push_back(s);
+            continue;
+        }
+        if(k + (size_t)count > t.interp_indices.size() || (k + (size_t)count) * (size_t)taps > t.interp_weights.size())
+            return false;
+        for(intmax_t j = 0; j < count; ++j, ++k) {
+            const intmax_t ix = (intmax_t)t.interp_indices[k];
+            float w[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // tap j of the sample's row weighs bin ix - radius + 1 + j: slot j + 4 - radius of the 8
+            for(int q = 0; q < taps; ++q)
+                w[q + 4 - radius] = t.interp_weights[k * (size_t)taps + (size_t)q];
+            if(!subs.empty() && subs.back().bar == i && subs.back().hi == ix && std::memcmp(subs.back().w, w, sizeof w) == 0)
+                ++subs.back().hi;
+            else {
+                Sub s{i, ix, ix + 1, {}};
+                std::memcpy(s.w, w, sizeof w);
+                subs.push_back(s);
+            }
+        }
+    }
+    for(const Sub &s : subs)
+        if(s.lo < 0 || s.hi > M || s.hi < s.lo)
+            return false;
+    // lanes: the sub-bands of a bar are consecutive lanes of one block of 64
+    std::vector<int> lane_of(subs.size());
+    int lane = 0;
+    for(size_t a = 0; a < subs.size();) {
+        size_t b = a;
+        while(b < subs.size() && subs[b].bar == subs[a].bar)
+            ++b;
+        const int n = (int)(b - a);
+        if(n > 64)
+            return false;
+        if((lane % 64) + n > 64)
+            lane = (lane + 63) / 64 * 64;
+        for(size_t q = a; q < b; ++q)
+            lane_of[q] = lane++;
+        a = b;
+    }
+    const int blocks = (lane + 63) / 64;
+    if(blocks * 64 > threads)
+        return false;
+    out.num_lanes = blocks * 64;
+    out.num_subs = (int)subs.size();
+    out.tab.assign((size_t)blocks * 5 * 64 * 4, 0.0f);
+    auto word = [&](int ln, int c, int e) -> float & { return out.tab[(((size_t)(ln / 64) * 5 + (size_t)c) * 64 + (size_t)(ln % 64)) * 4 + (size_t)e]; };
+    auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    for(size_t a = 0; a < subs.size(); ++a) {
+        const Sub &s = subs[a];
+        const int ln = lane_of[a];
+        float clo[7], chi[7], sw = 0.0f;
+        if(s.hi - s.lo <= 7) {
+            // direct: the composite coefficient of bin m is the sum of the taps of every sample of the sub-band that land on it
+            auto coef = [&](intmax_t m) {
+                double c = 0.0;
+                for(intmax_t ix = s.lo; ix < s.hi; ++ix) {
+                    const intmax_t q = m - ix + 3;
+                    if(q >= 0 && q < 8)
+                        c += (double)s.w[q];
+                }
+                return (float)c;
+            };
+            for(int j = 0; j < 7; ++j) {
+                clo[j] = coef(s.lo - 3 + j);
+                chi[j] = (s.hi - 3 + j > s.lo + 3) ? coef(s.hi - 3 + j) : 0.0f;
+            }
+        } else {
+            double c = 0.0;
+            for(int j = 0; j < 7; ++j) {
+                c += (double)s.w[j];
+                clo[j] = (float)c;
+                chi[j] = -(float)c;
+            }
+            sw = (float)(c + (double)s.w[7]);
+        }
+        for(int j = 0; j < 4; ++j)
+            word(ln, 0, j) = clo[j];
+        word(ln, 1, 0) = clo[4]; word(ln, 1, 1) = clo[5]; word(ln, 1, 2) = clo[6]; word(ln, 1, 3) = chi[0];
+        for(int j = 0; j < 4; ++j)
+            word(ln, 2, j) = chi[1 + j];
+        word(ln, 3, 0) = chi[5]; word(ln, 3, 1) = chi[6]; word(ln, 3, 2) = sw;
+        // the segmented inclusive prefix over the bar's lanes [l0, l0 + n): which of seg_prefix_scan's six steps this lane takes
+        size_t first = a;
+        while(first > 0 && subs[first - 1].bar == s.bar)
+            --first;
+        const int l0 = lane_of[first] % 64, l = ln % 64;
+        const bool last = a + 1 == subs.size() || subs[a + 1].bar != s.bar;
+        uint32_t flags = 0;
+        for(int d = 0; d < 4; ++d)
+            if(l - (1 << d) >= l0 && (l & 15) >= (1 << d))
+                flags |= 1u << d;
+        if(l >= 16 && ((l >> 4) & 1) && l0 <= (l & ~15) - 1)
+            flags |= 1u << 4;
+        if(l >= 32 && l0 <= 31)
+            flags |= 1u << 5;
+        const uint32_t info = flags | (last ? (uint32_t)(s.bar + 1) << 8 : 0u) | (uint32_t)t.band_widths[(size_t)s.bar] << 16;
+        word(ln, 4, 0) = bits((uint32_t)s.lo | (uint32_t)s.hi << 16);
+        word(ln, 4, 1) = bits(info);
+    }
     return true;
 }
 

@@ -97,6 +97,30 @@ struct BarPieceTables {
 };
 bool bar_pieces(const HostTables &t, int threads, int points, int max_blocks, BarPieceTables &out);
 
+// Prefix-sum form of the bar reduction (round 5).  Inside a band every sample sits on the bin after its predecessor and -- as
+// init_interp forms the positions as idx[i] + j in float (src/source.cpp:876-884) -- the fractional part of the position, and
+// with it the sample's weight row, only changes where the sum crosses into the next binade.  A band is therefore a handful of
+// SUB-BANDS [lo, hi) of consecutive bins with ONE weight row W (8 taps at bins ix - 3 .. ix + 4; Catmull-Rom's four sit in the
+// middle), found here by comparing the reference's own rows bit for bit, and
+//     sum_{ix in [lo, hi)} sum_t W[t] dB[ix - 3 + t]  =  SW (PS[hi + 4] - PS[lo + 4]) + E(lo) - E(hi),
+//     PS[x] = sum_{m < x} dB[m],   SW = sum_t W[t],   E(q) = sum_{j < 7} C[j] dB[q - 3 + j],   C[j] = sum_{t <= j} W[t]
+// (bins outside the row count as 0, which is kernel_convolve's clipping, src/filter.hpp:160-169): two look-ups into a prefix
+// sum of the row, kept in float64, and two 7-tap edge corrections instead of count x 8 products -- no per-bin coefficient table
+// (46 KB at N = 4096, 186 KB at 16384), no per-thread table loads, no read-back of the whole row.  Sub-bands of at most 7 bins
+// are evaluated directly instead (SW = 0, the two windows carry the composite coefficients of the bins they cover): no
+// cancellation for the narrow bands at the bottom of a log axis.  One lane of a finishing wavefront per sub-band; the
+// sub-bands of a bar are consecutive lanes of one wavefront and are added by seg_prefix_scan (flags in `info`).
+// POINT mode (plain band means, src/source.cpp:1525-1532) is the same with W = a single 1.
+struct BarPsTables {
+    // [blocks of 64 lanes][5][64][4] floats, lane-major 16-byte words: {clo[0..3]} {clo[4..6], chi[0]} {chi[1..4]}
+    // {chi[5], chi[6], SW, 0} {lo | hi << 16, info, 0, 0} (the last word's integers stored as bit patterns).  chi already carries its sign.
+    // info: bits 0..5 seg_prefix_scan's steps; bits 8..15: 1 + bar when the lane is the last of its bar; bits 16..31: the bar's count
+    std::vector<float> tab;
+    int num_lanes = 0; // lanes used, padding included (a bar never straddles a block of 64)
+    int num_subs = 0;
+};
+bool bar_ps(const HostTables &t, int threads, BarPsTables &out);
+
 // Curve mode (one output per thread and step): output o = k * threads + s reads the 8 consecutive dB bins starting at
 // base[o] with coefficients coef[o][0..8) (its composite kernel shifted/zero-padded to 8 taps inside [0, M)); tables are
 // padded to whole steps with zero coefficients.

@@ -664,6 +664,14 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             else
                 spectrum_sync<G>();
         };
+        // prefix-sum layout (BarPsTables): the scans run in registers, before anybody is waited for
+        constexpr bool PS_OK = !BLU && DEC == 0 && !BOTH && BarEntries<G>::PS;
+        const bool ps_mode = PS_OK && a.bar.ps_lanes > 0;
+        PsScan<RG> ps_regs;
+        if constexpr(PS_OK) {
+            if(ps_mode && have_row)
+                ps_scan<RG>(d, ps_regs);
+        }
         // every thread of the spectrum is done reading its exchange buffer
         if(count_arrivals && !WF_EXP_NO_ARRIVAL_WAIT) {
             while(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
@@ -671,6 +679,31 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             asm volatile("" ::: "memory");
         } else if(!(mono_mix && !SPLIT))
             row_sync();
+        if constexpr(PS_OK) {
+            if(ps_mode) {
+                // Every wavefront leaves its part of the row and the prefix sums of its blocks, then counts itself in (release: its
+                // LDS stores are ordered in front of the count); the wavefronts that own sub-bands wait for the whole spectrum
+                // (acquire) and finish one sub-band per lane.  One wavefront per spectrum: program order is all it takes.
+                if(have_row)
+                    ps_park<RG>(dbl, MO, t, d, ps_regs);
+                if constexpr(T > 64) {
+                    if(lane == 0)
+                        __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if(t < a.bar.ps_lanes) {
+                        const int everybody = count_arrivals ? 2 * WPS : WPS;
+                        while(__hip_atomic_load(arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < everybody)
+                            __builtin_amdgcn_s_sleep(1);
+                    }
+                } else
+                    __builtin_amdgcn_wave_barrier();
+                if(have_row && t < a.bar.ps_lanes) {
+                    float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+                    ps_finish<G>(a.bar, bar_entries, dbl, MO, out0, dup_row ? out0 + a.bar.num_bars : nullptr);
+                }
+                WF_STAMP(13);
+                return;
+            }
+        }
         if(have_row && row_thread)
             store_row<RG, BLU>(dbl, t, d, NB);
         if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)

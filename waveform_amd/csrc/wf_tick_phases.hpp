@@ -80,6 +80,11 @@ struct BarArgs {
     // segments of a thread read bins its own wavefront parked -- no barrier between parking the row and reading it --, pieces
     // are summed by a DPP prefix scan and the last wavefront to arrive adds the pieces of every bar
     int piece_mode;
+    // prefix-sum layout (BarPsTables, wf_host_tables.hpp): every wavefront leaves a float64 prefix sum of its 256-bin blocks of the
+    // row next to the row itself; lane l of the finishing wavefront(s) evaluates sub-band l from two look-ups and two 7-tap
+    // edge windows.  ps_tab: [blocks][5][64][4]; ps_lanes: lanes used (a multiple of 64); 0: off
+    const float *ps_tab;
+    int ps_lanes;
     int num_segs;
     int lane_blocks;
     // Curve display (render_curve, reference src/source.cpp:1360-1425): num_bars = m_width points per row, point
@@ -342,7 +347,29 @@ WF_DEV int wave_arrive(int *counter, int lane)
     asm volatile("" ::: "memory");
     return old;
 }
+// Inclusive prefix sum of a double over the 64 lanes of a wavefront: the classic six DPP steps (row_shr 1, 2, 4, 8 inside rows of
+// 16, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) on the two halves of the value; a lane without a source
+// adds +0.0.  v_add_f64 runs at the rate of v_add_f32 on gfx950.
+WF_DEV double wave_scan_f64(double v)
+{
+#define WF_SCAN64_STEP(CTRL, ROWS)                                                                                         \
+    {                                                                                                                      \
+        const long long b = __double_as_longlong(v);                                                                       \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROWS, 0xf, true);                     \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWS, 0xf, true);                              \
+        v += __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);                                    \
+    }
+    WF_SCAN64_STEP(0x111, 0xf)
+    WF_SCAN64_STEP(0x112, 0xf)
+    WF_SCAN64_STEP(0x114, 0xf)
+    WF_SCAN64_STEP(0x118, 0xf)
+    WF_SCAN64_STEP(0x142, 0xa)
+    WF_SCAN64_STEP(0x143, 0xc)
+#undef WF_SCAN64_STEP
+    return v;
+}
 #else
+WF_DEV double wave_scan_f64(double v) { return v; } // (the emulator does not run the bar reduction)
 WF_DEV void wait_vmem_all() {}
 WF_DEV void wave_fence() {}
 WF_DEV float wave_shfl_down(float v, int) { return v; } // (the emulator does not run the bar reduction)
@@ -1533,7 +1560,7 @@ struct BarPre { int off, len, count; int s0, s1; int glen; int lead; };
 template<class G, bool PIECES = true> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 {
     BarPre p{0, 0, 1, 0, 0, 0, -1};
-    if(b.out != nullptr) {
+    if(b.out != nullptr && b.ps_lanes == 0) { // (the prefix-sum layout keeps everything in its lane table: bars_fetch_entries)
         if(PIECES && b.num_segs > 0 && b.piece_mode) {
             // glen: the scan flags and 1 + the slot this lane's piece total goes to.  One wavefront per spectrum: the slot is the
             // bar itself (lead / count); several: lane l of whichever wavefront arrives last finishes bar l from slots [s0, s1)
@@ -1576,7 +1603,8 @@ template<class G, bool PIECES = true> WF_DEV BarPre bars_preload(const BarArgs &
 // The (coefficient, bin) pairs of this thread's segment: 16-byte loads, coalesced across the threads, requested before
 // the dB math so that their L2 latency is off the critical path.
 template<class G> struct BarEntries {
-    static constexpr int CMAX = G::P / 4 + 2; // the host builds segments of at most 4 * CMAX entries
+    static constexpr bool PS = G::P >= 8; // the prefix-sum layout (not on the four-point geometry, N = 512: at its 80-register cap the two extra words spill)
+    static constexpr int CMAX = (PS && G::P / 4 + 2 < 5) ? 5 : G::P / 4 + 2; // the host builds segments of at most 4 * (P / 4 + 2) entries; the prefix-sum layout's lane table is five words
     f4 coef[CMAX];
     int base;
 };
@@ -1584,13 +1612,24 @@ template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEnt
 {
     constexpr int T = G::T;
     be.base = 0;
-    if(b.out == nullptr || b.num_segs == 0)
+    if(b.out == nullptr || (b.num_segs == 0 && b.ps_lanes == 0))
         return;
-    be.base = b.lane_base[t];
+    // One loop for both layouts (two loops writing the one array left half of it in scratch: ROCm 7.2's SROA gives up on the phi).
+    // Prefix-sum layout: the five 16-byte words of this lane's sub-band (BarPsTables), requested only by the wavefronts that
+    // finish sub-bands (t < ps_lanes is wave-uniform: ps_lanes is a multiple of 64).
+    const bool ps = BarEntries<G>::PS && b.ps_lanes > 0;
+    const float *p = ps ? b.ps_tab + ((size_t)(t >> 6) * 5 * 64 + (size_t)(t & 63)) * 4 : b.lane_coef + (size_t)t * 4;
+    const int stride = ps ? 256 : T * 4;
+    int n = ps ? (t < b.ps_lanes ? 5 : 0) : b.lane_blocks;
+#if defined(__HIPCC__)
+    n = __builtin_amdgcn_readfirstlane(n);
+#endif
+    if(!ps)
+        be.base = b.lane_base[t];
     WF_UNROLL
     for(int c = 0; c < BarEntries<G>::CMAX; ++c)
-        if(c < b.lane_blocks) // uniform
-            be.coef[c] = ld4(b.lane_coef + (c * T + t) * 4);
+        if(c < n) // uniform
+            be.coef[c] = ld4(p + c * stride);
 }
 
 // mean dB of output o -> pixel row (reference src/source.cpp:1548-1557 bars, :1411 curve):
@@ -1862,6 +1901,93 @@ WF_DEV void outputs_finish(const BarArgs &b, bool has_row, OutVals<G> &ov, float
             if(k < b.out_steps && k * T + t < n)
                 store_output(b, k * T + t, y[k], out_row, dup_row);
     }
+}
+
+// ---- bars, prefix-sum layout (BarPsTables, wf_host_tables.hpp) ---------------------------------------------------------------
+// A spectrum's LDS in this layout, as floats from `dbl`: [4 zeros | the row's M dB values | 4 zeros] (bins -4 .. M + 3: the taps
+// kernel_convolve drops read an exact 0), then M / 4 + 1 doubles scan[g] = the sum of the bins of g's 256-bin block in front of
+// group g = bin / 4 (the last entry, one past the row, is 0), then M / 256 doubles tot[c] = the sum of block c.  Thread t holds
+// bins 4 (t + T u) .. + 3, u < P / 4, i.e. wavefront w = t / 64 owns the blocks c = w + (T / 64) u, one per register group.
+WF_DEV double *ps_scan_area(float *dbl, int M) { return reinterpret_cast<double *>(dbl + 8 + M); }
+constexpr size_t ps_lds_floats(size_t M) { return 8 + M + 2 * (M / 4 + 2) + 2 * (M / 256); } // (constexpr: host and device)
+// registers only: the inclusive prefix over the wavefront of every group's four-bin sums (float64: what is subtracted later are
+// prefixes of up to 256 values each, and float32 prefixes of a row with 150 dB of dynamic range lose 1e-3 dB)
+template<class RG> struct PsScan { double inc[RG::P / 4]; float own[RG::P / 4]; };
+template<class RG> WF_DEV void ps_scan(const float (&d)[RG::P], PsScan<RG> &ps)
+{
+    WF_UNROLL
+    for(int u = 0; u < RG::P / 4; ++u)
+        ps.own[u] = (d[4 * u] + d[4 * u + 1]) + (d[4 * u + 2] + d[4 * u + 3]);
+    WF_UNROLL
+    for(int u = 0; u < RG::P / 4; ++u)
+        ps.inc[u] = wave_scan_f64((double)ps.own[u]);
+}
+template<class RG> WF_DEV void ps_park(float *dbl, int M, int t, const float (&d)[RG::P], const PsScan<RG> &ps)
+{
+    constexpr int T = RG::T;
+    store_row<RG>(dbl + 4, t, d);
+    double *scan = ps_scan_area(dbl, M), *tot = scan + M / 4 + 2;
+    WF_UNROLL
+    for(int u = 0; u < RG::P / 4; ++u)
+        scan[t + T * u] = ps.inc[u] - (double)ps.own[u];
+    if((t & 63) == 63) {
+        WF_UNROLL
+        for(int u = 0; u < RG::P / 4; ++u)
+            tot[(t >> 6) + (T / 64) * u] = ps.inc[u];
+    }
+    if(t == 0) {
+        st4(dbl, f4{0.0f, 0.0f, 0.0f, 0.0f});
+        st4(dbl + 4 + M, f4{0.0f, 0.0f, 0.0f, 0.0f});
+        scan[M / 4] = 0.0;
+    }
+}
+// lane t (< ps_lanes) finishes sub-band t; the last lane of a bar maps and stores it
+template<class G> WF_DEV void ps_finish(const BarArgs &b, const BarEntries<G> &be, float *dbl, int M, float *out_row, float *dup_row)
+{
+    const uint32_t lohi = f32_bits(be.coef[4].x), info = f32_bits(be.coef[4].y);
+    const int lo = (int)(lohi & 0xffffu), hi = (int)(lohi >> 16);
+    const double *scan = ps_scan_area(dbl, M), *tot = scan + M / 4 + 2;
+    const float *pl = dbl + lo + 1, *ph = dbl + hi + 1; // bins q - 3 .. q + 3 of the row parked from dbl + 4
+    float l[7], h[7];
+    WF_UNROLL
+    for(int j = 0; j < 7; ++j) {
+        l[j] = pl[j];
+        h[j] = ph[j];
+    }
+    // PS[min(q + 4, M)] within its block: the group's entry + the bins of the group in front of the position (the top three of the
+    // window; a clamped position is a multiple of 4)
+    auto local = [&](int q, const float (&w)[7], int &blk) {
+        const int x = q + 4 < M ? q + 4 : M;
+        const int g = x >> 2, i = x & 3;
+        blk = g >> 6;
+        float part = i >= 1 ? w[6] : 0.0f;
+        part += i >= 2 ? w[5] : 0.0f;
+        part += i >= 3 ? w[4] : 0.0f;
+        return scan[g] + (double)part;
+    };
+    int bl, bh;
+    const double p_lo = local(lo, l, bl), p_hi = local(hi, h, bh);
+    double dp = p_hi - p_lo;
+    for(int c = bl; c < bh; ++c)
+        dp += tot[c];
+    float e0 = l[0] * be.coef[0].x, e1 = h[0] * be.coef[1].w;
+    e0 = fmaf(l[1], be.coef[0].y, e0);
+    e1 = fmaf(h[1], be.coef[2].x, e1);
+    e0 = fmaf(l[2], be.coef[0].z, e0);
+    e1 = fmaf(h[2], be.coef[2].y, e1);
+    e0 = fmaf(l[3], be.coef[0].w, e0);
+    e1 = fmaf(h[3], be.coef[2].z, e1);
+    e0 = fmaf(l[4], be.coef[1].x, e0);
+    e1 = fmaf(h[4], be.coef[2].w, e1);
+    e0 = fmaf(l[5], be.coef[1].y, e0);
+    e1 = fmaf(h[5], be.coef[3].x, e1);
+    e0 = fmaf(l[6], be.coef[1].z, e0);
+    e1 = fmaf(h[6], be.coef[3].y, e1);
+    float sub = fmaf(be.coef[3].z, (float)dp, e0 + e1);
+    sub = seg_prefix_scan(sub, info);
+    const int bar = (int)((info >> 8) & 0xffu) - 1;
+    if(bar >= 0)
+        emit_output(b, bar, sub / (float)(info >> 16), out_row, dup_row);
 }
 
 // Called by every thread of the workgroup (sync may be a block barrier); `has_row` says whether this spectrum produced one.
