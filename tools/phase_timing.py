@@ -46,7 +46,10 @@ for i, nm in enumerate(names):
 print("after stamp 10 (flags store, bars if any) until the end of the kernel: mean %.0f ticks" % (s[:, 13] - s[:, 10]).mean())
 if os.environ.get("WF_BENCH_CURVE"):
     print("curve: row->LDS+syncs %.0f | points + mapping + stores %.0f" % ((s[:, 12] - s[:, 10]).mean(), (s[:, 13] - s[:, 12]).mean()))
-if os.environ.get("WF_BENCH_BARS"):
+if os.environ.get("WF_BENCH_BARS") and os.environ.get("WF_HIP_BAR_PS", "1") != "0":
+    print("bars (prefix-sum layout, first wavefront of the workgroup): wait for the last reads %.0f | park row + group sums %.0f | count in + wait for everybody %.0f | prefix, sub-bands, stores %.0f" %
+          ((s[:, 12] - s[:, 10]).mean(), (s[:, 14] - s[:, 12]).mean(), (s[:, 15] - s[:, 14]).mean(), (s[:, 13] - s[:, 15]).mean()))
+elif os.environ.get("WF_BENCH_BARS"):
     print("bars: row->LDS+syncs %.0f | A products+sync %.0f | B1 segment sums+sync %.0f | B2 bar sums+stores %.0f" %
           ((s[:, 12] - s[:, 10]).mean(), (s[:, 14] - s[:, 12]).mean(), (s[:, 15] - s[:, 14]).mean(), (s[:, 13] - s[:, 15]).mean()))
 # ---- where and when: per-CU residency from HW_ID (slot 11) / XCC_ID (slot 12) ------------------------------

@@ -590,17 +590,18 @@ bool bar_ps(const HostTables &t, int threads, BarPsTables &out)
             lane_of[q] = lane++;
         a = b;
     }
-    const int blocks = (lane + 63) / 64;
-    if(blocks * 64 > threads)
-        return false;
-    out.num_lanes = blocks * 64;
+    if(lane > 64)
+        return false; // (one finishing wavefront: at most 64 sub-bands; the other layouts take the displays with more)
+    out.num_lanes = 64;
     out.num_subs = (int)subs.size();
-    out.tab.assign((size_t)blocks * 5 * 64 * 4, 0.0f);
-    auto word = [&](int ln, int c, int e) -> float & { return out.tab[(((size_t)(ln / 64) * 5 + (size_t)c) * 64 + (size_t)(ln % 64)) * 4 + (size_t)e]; };
+    out.merge = lane <= 32; // the table repeats in lanes 32 ..: one wavefront finishes two spectra
+    out.tab.assign((size_t)5 * 64 * 4, 0.0f);
+    auto word = [&](int ln, int c, int e) -> float & { return out.tab[((size_t)c * 64 + (size_t)ln) * 4 + (size_t)e]; };
     auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    for(int rep = 0; rep < (out.merge ? 2 : 1); ++rep)
     for(size_t a = 0; a < subs.size(); ++a) {
         const Sub &s = subs[a];
-        const int ln = lane_of[a];
+        const int ln = lane_of[a] + 32 * rep;
         float clo[7], chi[7], sw = 0.0f;
         if(s.hi - s.lo <= 7) {
             // direct: the composite coefficient of bin m is the sum of the taps of every sample of the sub-band that land on it
@@ -636,7 +637,7 @@ bool bar_ps(const HostTables &t, int threads, BarPsTables &out)
         size_t first = a;
         while(first > 0 && subs[first - 1].bar == s.bar)
             --first;
-        const int l0 = lane_of[first] % 64, l = ln % 64;
+        const int l0 = lane_of[first] + 32 * rep, l = ln;
         const bool last = a + 1 == subs.size() || subs[a + 1].bar != s.bar;
         uint32_t flags = 0;
         for(int d = 0; d < 4; ++d)

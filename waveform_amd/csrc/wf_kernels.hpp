@@ -173,6 +173,12 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     const int t = tid % T;            // thread within the spectrum
     const int lane = tid & 63;
     const int wave_in_block = tid >> 6;
+    // bars in the prefix-sum layout (BarPsTables): the wavefront that finishes the sub-bands -- the first of the workgroup for
+    // both of its spectra where their sub-bands fit 32 lanes each, else the first of every spectrum
+    constexpr bool PS_OK = !BLU && DEC == 0 && !BOTH && BarEntries<G>::PS;
+    const bool ps_mode = PS_OK && a.bar.out != nullptr && a.bar.ps_lanes > 0;
+    const bool ps_merged = SPW == 2 && a.bar.ps_merge != 0;
+    const bool ps_finisher = ps_mode && (ps_merged ? wave_in_block == 0 : (t >> 6) == 0);
     // Prologue: nothing here may wait for memory before the window fetch is in flight.  The spectrum index is clamped
     // (no branch), stream/channel come from a shift (cap_ch is 1 or 2), and the two per-stream words (write position,
     // flags) are scalar loads issued together.
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     BarEntries<G> bar_entries;
     bar_entries.base = 0;
     if constexpr(Policy<G>::BAR_COEF_EARLY && !BLU && DEC == 0 && !BOTH)
-        bars_fetch_entries<G>(a.bar, t, bar_entries);
+        bars_fetch_entries<G>(a.bar, t, bar_entries, ps_finisher);
 #endif
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
@@ -285,6 +291,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         facts[wave_in_block] = (wave_nz ? 1 : 0) | (wave_below ? 2 : 0);
     if(T > 64 && t == 0)
         *arrivals = 0;
+    if(PS_OK && tid < 2)
+        facts[2 * SPW * WPS + 2 + tid] = 0; // (prefix-sum layout: the counters of the wavefronts that have parked their part of the row)
     __syncthreads(); // facts + the LDS twiddle table are visible to the whole workgroup
     if constexpr(SPLIT) {
         int orf = 0;
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     bar_entries.base = 0;
 #endif
     if constexpr(COEF_EARLY && !WF_EXP_COEF_AT_FETCH) {
-        bars_fetch_entries<G>(a.bar, t, bar_entries);
+        bars_fetch_entries<G>(a.bar, t, bar_entries, ps_finisher);
         if(!process && a.bar.out != nullptr)
             wait_vmem_all(); // (the rare path that skips P4 and its wait)
     }
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     }
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
     if constexpr(!COEF_EARLY)
-        bars_fetch_entries<G>(a.bar, t, bar_entries);
+        bars_fetch_entries<G>(a.bar, t, bar_entries, ps_finisher);
 #ifndef WF_EXP_STORES_AFTER_PARK
 #define WF_EXP_STORES_AFTER_PARK 0 // (experiment, needs WF_DEFER_STATE=1) bars displays: the state and row stores issued between the row's LDS copy and its
                                    // read-back, so that the LDS round trip runs under their issue
@@ -664,13 +672,20 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             else
                 spectrum_sync<G>();
         };
-        // prefix-sum layout (BarPsTables): the scans run in registers, before anybody is waited for
-        constexpr bool PS_OK = !BLU && DEC == 0 && !BOTH && BarEntries<G>::PS;
-        const bool ps_mode = PS_OK && a.bar.ps_lanes > 0;
-        PsScan<RG> ps_regs;
-        if constexpr(PS_OK) {
-            if(ps_mode && have_row)
-                ps_scan<RG>(d, ps_regs);
+#ifndef WF_EXP_PS_CUT
+#define WF_EXP_PS_CUT 0 // measurement only (wrong bars): 2 = the display phase ends behind the parking (nobody finishes a bar), 5 = the dB math
+                        // alone, 6 = 5 + the wait for the other wavefronts' last reads of the exchange buffer, 7 = the finisher ends behind its wait,
+                        // 8 = ... behind the prefix, 9 = everything but the stores of the bars
+#endif
+        if(WF_EXP_PS_CUT == 5 || WF_EXP_PS_CUT == 6) {
+            if(WF_EXP_PS_CUT == 6 && count_arrivals) {
+                while(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for(int i = 0; i < RP; ++i)
+                asm volatile("" ::"v"(d[i]));
+            return;
         }
         // every thread of the spectrum is done reading its exchange buffer
         if(count_arrivals && !WF_EXP_NO_ARRIVAL_WAIT) {
@@ -681,24 +696,48 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             row_sync();
         if constexpr(PS_OK) {
             if(ps_mode) {
-                // Every wavefront leaves its part of the row and the prefix sums of its blocks, then counts itself in (release: its
-                // LDS stores are ordered in front of the count); the wavefronts that own sub-bands wait for the whole spectrum
-                // (acquire) and finish one sub-band per lane.  One wavefront per spectrum: program order is all it takes.
+                // Every wavefront leaves its part of the row and its group sums, then counts itself in (release: its LDS stores are
+                // ordered in front of the count; the first wavefront of a spectrum also says whether the spectrum has a row); the
+                // finishing wavefront waits for everybody it serves (acquire).  One wavefront per spectrum and no sharing: program
+                // order is all it takes.
+                WF_STAMP(12);
                 if(have_row)
-                    ps_park<RG>(dbl, MO, t, d, ps_regs);
-                if constexpr(T > 64) {
+                    ps_park<RG>(dbl, MO, t, d);
+                WF_STAMP(14);
+                if(WF_EXP_PS_CUT == 2)
+                    return;
+                int *parked = facts + 2 * SPW * WPS + 2 + (ps_merged ? 0 : sub);
+                const int everybody = ps_merged ? SPW * WPS : WPS;
+                uint32_t word = have_row ? 0x100u << sub : 0u;
+                if(T > 64 || ps_merged) {
                     if(lane == 0)
-                        __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if(t < a.bar.ps_lanes) {
-                        const int everybody = count_arrivals ? 2 * WPS : WPS;
-                        while(__hip_atomic_load(arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < everybody)
+                        __hip_atomic_fetch_add(parked, 1 + (int)((t >> 6) == 0 ? word : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if(ps_finisher) {
+                        while(((word = (uint32_t)__hip_atomic_load(parked, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) & 0xffu) < (uint32_t)everybody)
                             __builtin_amdgcn_s_sleep(1);
                     }
                 } else
                     __builtin_amdgcn_wave_barrier();
-                if(have_row && t < a.bar.ps_lanes) {
-                    float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
-                    ps_finish<G>(a.bar, bar_entries, dbl, MO, out0, dup_row ? out0 + a.bar.num_bars : nullptr);
+                WF_STAMP(15);
+                if(ps_finisher && WF_EXP_PS_CUT == 7) { // (the finisher ends behind its wait: what do the table request and the wait cost?)
+#pragma unroll
+                    for(int c = 0; c < 5; ++c)
+                        asm volatile("" ::"v"(bar_entries.coef[c].x), "v"(bar_entries.coef[c].y), "v"(bar_entries.coef[c].z), "v"(bar_entries.coef[c].w));
+                    return;
+                }
+                if(ps_finisher) {
+                    const bool dup = a.out_ch > a.cap_ch;
+                    if(ps_merged) {
+                        // lanes 0 .. 31: the first spectrum of the workgroup, 32 .. 63: the second
+                        const int seg = lane >> 5;
+                        const uint32_t spec_s = a.stream_base * a.cap_ch + blockIdx.x * SPW + (uint32_t)seg;
+                        float *dbl_s = reinterpret_cast<float *>(reinterpret_cast<cf *>(smem_raw) + (size_t)seg * lds_cf);
+                        float *out_s = a.bar.out + ((size_t)(spec_s >> cap_shift) * a.bar.disp_ch + (spec_s & cap_shift)) * a.bar.num_bars;
+                        ps_finish<G, RG, 32>(a.bar, bar_entries, dbl_s, MO, lane & 31, ((word >> (8 + seg)) & 1u) != 0, out_s, dup ? out_s + a.bar.num_bars : nullptr);
+                    } else {
+                        float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+                        ps_finish<G, RG, 64>(a.bar, bar_entries, dbl, MO, lane, have_row && (a.bar.ps_merge == 0 || lane < 32), out0, dup ? out0 + a.bar.num_bars : nullptr);
+                    }
                 }
                 WF_STAMP(13);
                 return;

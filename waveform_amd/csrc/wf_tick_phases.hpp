@@ -80,11 +80,12 @@ struct BarArgs {
     // segments of a thread read bins its own wavefront parked -- no barrier between parking the row and reading it --, pieces
     // are summed by a DPP prefix scan and the last wavefront to arrive adds the pieces of every bar
     int piece_mode;
-    // prefix-sum layout (BarPsTables, wf_host_tables.hpp): every wavefront leaves a float64 prefix sum of its 256-bin blocks of the
-    // row next to the row itself; lane l of the finishing wavefront(s) evaluates sub-band l from two look-ups and two 7-tap
-    // edge windows.  ps_tab: [blocks][5][64][4]; ps_lanes: lanes used (a multiple of 64); 0: off
+    // prefix-sum layout (BarPsTables, wf_host_tables.hpp): every wavefront leaves its part of the row and its four-bin group sums;
+    // lane l of the finishing wavefront evaluates sub-band l from two look-ups into a float64 prefix sum it forms itself and two
+    // 7-tap edge windows.  ps_tab: [5][64][4]; ps_lanes: 64, or 0: off
     const float *ps_tab;
     int ps_lanes;
+    int ps_merge;              // != 0 (two spectra per workgroup, at most 32 sub-bands): the first wavefront of the workgroup finishes both spectra, 32 lanes each (the table repeats in lanes 32 ..)
     int num_segs;
     int lane_blocks;
     // Curve display (render_curve, reference src/source.cpp:1360-1425): num_bars = m_width points per row, point
@@ -347,29 +348,7 @@ WF_DEV int wave_arrive(int *counter, int lane)
     asm volatile("" ::: "memory");
     return old;
 }
-// Inclusive prefix sum of a double over the 64 lanes of a wavefront: the classic six DPP steps (row_shr 1, 2, 4, 8 inside rows of
-// 16, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) on the two halves of the value; a lane without a source
-// adds +0.0.  v_add_f64 runs at the rate of v_add_f32 on gfx950.
-WF_DEV double wave_scan_f64(double v)
-{
-#define WF_SCAN64_STEP(CTRL, ROWS)                                                                                         \
-    {                                                                                                                      \
-        const long long b = __double_as_longlong(v);                                                                       \
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROWS, 0xf, true);                     \
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWS, 0xf, true);                              \
-        v += __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);                                    \
-    }
-    WF_SCAN64_STEP(0x111, 0xf)
-    WF_SCAN64_STEP(0x112, 0xf)
-    WF_SCAN64_STEP(0x114, 0xf)
-    WF_SCAN64_STEP(0x118, 0xf)
-    WF_SCAN64_STEP(0x142, 0xa)
-    WF_SCAN64_STEP(0x143, 0xc)
-#undef WF_SCAN64_STEP
-    return v;
-}
 #else
-WF_DEV double wave_scan_f64(double v) { return v; } // (the emulator does not run the bar reduction)
 WF_DEV void wait_vmem_all() {}
 WF_DEV void wave_fence() {}
 WF_DEV float wave_shfl_down(float v, int) { return v; } // (the emulator does not run the bar reduction)
@@ -1608,19 +1587,19 @@ template<class G> struct BarEntries {
     f4 coef[CMAX];
     int base;
 };
-template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be)
+template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be, bool finisher = false)
 {
     constexpr int T = G::T;
     be.base = 0;
     if(b.out == nullptr || (b.num_segs == 0 && b.ps_lanes == 0))
         return;
     // One loop for both layouts (two loops writing the one array left half of it in scratch: ROCm 7.2's SROA gives up on the phi).
-    // Prefix-sum layout: the five 16-byte words of this lane's sub-band (BarPsTables), requested only by the wavefronts that
-    // finish sub-bands (t < ps_lanes is wave-uniform: ps_lanes is a multiple of 64).
+    // Prefix-sum layout: the five 16-byte words of this lane's sub-band (BarPsTables), requested only by the wavefront that
+    // finishes sub-bands (`finisher`, wave-uniform).
     const bool ps = BarEntries<G>::PS && b.ps_lanes > 0;
-    const float *p = ps ? b.ps_tab + ((size_t)(t >> 6) * 5 * 64 + (size_t)(t & 63)) * 4 : b.lane_coef + (size_t)t * 4;
+    const float *p = ps ? b.ps_tab + (size_t)(t & 63) * 4 : b.lane_coef + (size_t)t * 4;
     const int stride = ps ? 256 : T * 4;
-    int n = ps ? (t < b.ps_lanes ? 5 : 0) : b.lane_blocks;
+    int n = ps ? (finisher ? 5 : 0) : b.lane_blocks;
 #if defined(__HIPCC__)
     n = __builtin_amdgcn_readfirstlane(n);
 #endif
@@ -1904,49 +1883,102 @@ WF_DEV void outputs_finish(const BarArgs &b, bool has_row, OutVals<G> &ov, float
 }
 
 // ---- bars, prefix-sum layout (BarPsTables, wf_host_tables.hpp) ---------------------------------------------------------------
+// The tick of a bars display is as much bound by the vector units as by memory (cut-point builds, profiles/r05b_ps_cuts*.txt: 100
+// more instructions per wavefront in the tail cost what they add to its ~1200, 8 %), so the layout is built around instruction
+// count: every wavefront only parks its part of the row and the sums of its four-bin groups (12 additions, five 16-byte LDS
+// stores); ONE wavefront finishes -- for both spectra of a workgroup where the sub-bands fit 32 lanes each -- and it alone forms
+// the prefix sum, over 16-bin quads, in float64.
 // A spectrum's LDS in this layout, as floats from `dbl`: [4 zeros | the row's M dB values | 4 zeros] (bins -4 .. M + 3: the taps
-// kernel_convolve drops read an exact 0), then M / 4 + 1 doubles scan[g] = the sum of the bins of g's 256-bin block in front of
-// group g = bin / 4 (the last entry, one past the row, is 0), then M / 256 doubles tot[c] = the sum of block c.  Thread t holds
-// bins 4 (t + T u) .. + 3, u < P / 4, i.e. wavefront w = t / 64 owns the blocks c = w + (T / 64) u, one per register group.
-WF_DEV double *ps_scan_area(float *dbl, int M) { return reinterpret_cast<double *>(dbl + 8 + M); }
-constexpr size_t ps_lds_floats(size_t M) { return 8 + M + 2 * (M / 4 + 2) + 2 * (M / 256); } // (constexpr: host and device)
-// registers only: the inclusive prefix over the wavefront of every group's four-bin sums (float64: what is subtracted later are
-// prefixes of up to 256 values each, and float32 prefixes of a row with 150 dB of dynamic range lose 1e-3 dB)
-template<class RG> struct PsScan { double inc[RG::P / 4]; float own[RG::P / 4]; };
-template<class RG> WF_DEV void ps_scan(const float (&d)[RG::P], PsScan<RG> &ps)
+// kernel_convolve drops read an exact 0), then gs[M / 4] = the four-bin group sums, thread-major (group g = bin / 4 = t + T u of
+// thread t, register group u, sits at t (P / 4) + u: one 16-byte store per thread), then qp[M / 16 + 1] doubles: the sum of all
+// quads in front of quad Q (the last entry: the row's total).
+constexpr size_t ps_lds_floats(size_t M) { return 8 + M + M / 4 + 2 * (M / 16 + 2); } // (constexpr: host and device)
+WF_DEV float *ps_gs_area(float *dbl, int M) { return dbl + 8 + M; }
+WF_DEV double *ps_qp_area(float *dbl, int M) { return reinterpret_cast<double *>(dbl + 8 + M + M / 4); }
+template<class RG> WF_DEV void ps_park(float *dbl, int M, int t, const float (&d)[RG::P])
 {
-    WF_UNROLL
-    for(int u = 0; u < RG::P / 4; ++u)
-        ps.own[u] = (d[4 * u] + d[4 * u + 1]) + (d[4 * u + 2] + d[4 * u + 3]);
-    WF_UNROLL
-    for(int u = 0; u < RG::P / 4; ++u)
-        ps.inc[u] = wave_scan_f64((double)ps.own[u]);
-}
-template<class RG> WF_DEV void ps_park(float *dbl, int M, int t, const float (&d)[RG::P], const PsScan<RG> &ps)
-{
-    constexpr int T = RG::T;
+    constexpr int NG = RG::P / 4;
+    static_assert(NG == 2 || NG % 4 == 0, "group sums are stored as 8- or 16-byte words");
     store_row<RG>(dbl + 4, t, d);
-    double *scan = ps_scan_area(dbl, M), *tot = scan + M / 4 + 2;
+    float *gs = ps_gs_area(dbl, M) + t * NG;
+    float s[NG];
     WF_UNROLL
-    for(int u = 0; u < RG::P / 4; ++u)
-        scan[t + T * u] = ps.inc[u] - (double)ps.own[u];
-    if((t & 63) == 63) {
+    for(int u = 0; u < NG; ++u)
+        s[u] = (d[4 * u] + d[4 * u + 1]) + (d[4 * u + 2] + d[4 * u + 3]);
+    if constexpr(NG == 2)
+        *reinterpret_cast<f2 *>(gs) = f2{s[0], s[1]};
+    else {
         WF_UNROLL
-        for(int u = 0; u < RG::P / 4; ++u)
-            tot[(t >> 6) + (T / 64) * u] = ps.inc[u];
+        for(int u = 0; u < NG; u += 4)
+            st4(gs + u, f4{s[u], s[u + 1], s[u + 2], s[u + 3]});
     }
     if(t == 0) {
         st4(dbl, f4{0.0f, 0.0f, 0.0f, 0.0f});
         st4(dbl + 4 + M, f4{0.0f, 0.0f, 0.0f, 0.0f});
-        scan[M / 4] = 0.0;
     }
 }
-// lane t (< ps_lanes) finishes sub-band t; the last lane of a bar maps and stores it
-template<class G> WF_DEV void ps_finish(const BarArgs &b, const BarEntries<G> &be, float *dbl, int M, float *out_row, float *dup_row)
+// Inclusive prefix over segments of L = 32 or 64 lanes (32: the halves of the wavefront separately -- the last step is left out)
+template<int L> WF_DEV double seg_scan_f64(double v)
 {
+    static_assert(L == 32 || L == 64, "");
+#if defined(__HIPCC__)
+#define WF_SCAN64_STEP(CTRL, ROWS)                                                                                         \
+    {                                                                                                                      \
+        const long long b = __double_as_longlong(v);                                                                       \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROWS, 0xf, true);                     \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWS, 0xf, true);                              \
+        v += __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);                                    \
+    }
+    WF_SCAN64_STEP(0x111, 0xf)
+    WF_SCAN64_STEP(0x112, 0xf)
+    WF_SCAN64_STEP(0x114, 0xf)
+    WF_SCAN64_STEP(0x118, 0xf)
+    WF_SCAN64_STEP(0x142, 0xa)
+    if constexpr(L == 64)
+        WF_SCAN64_STEP(0x143, 0xc)
+#undef WF_SCAN64_STEP
+#endif
+    return v;
+}
+// The finishing wavefront: lane `ll` of the L lanes that serve this spectrum (i) adds the group sums of its share of the quads,
+// leaves their float64 prefix in LDS, (ii) evaluates sub-band `ll` of the lane table; the last lane of a bar maps and stores it
+// (`emit` false: the spectrum produced no row -- everything is computed on whatever the buffer holds and nothing is stored; the
+// DPP steps must not sit under a divergent branch).
+template<class G, class RG, int L> WF_DEV void ps_finish(const BarArgs &b, const BarEntries<G> &be, float *dbl, int M, int ll, bool emit, float *out_row, float *dup_row)
+{
+    constexpr int T = RG::T, NG = RG::P / 4;
+    const float *gs = ps_gs_area(dbl, M);
+    double *qp = ps_qp_area(dbl, M);
+    // group g = t + T u is stored at t NG + u; the four groups of quad Q are four consecutive threads of one register group
+    auto quad_groups = [&](int Q) { const int g0 = 4 * Q; return gs + (g0 & (T - 1)) * NG + g0 / T; };
+    constexpr int QUADS = G::M / 16, NQ = (QUADS + L - 1) / L;
+    double run = 0.0, ex[NQ];
+    WF_UNROLL
+    for(int k = 0; k < NQ; ++k) {
+        const int Q = ll * NQ + k;
+        const float *p = quad_groups(Q < QUADS ? Q : 0);
+        const float qt = (p[0] + p[NG]) + (p[2 * NG] + p[3 * NG]);
+        ex[k] = run;
+        run += (double)(Q < QUADS ? qt : 0.0f);
+    }
+    const double inc = seg_scan_f64<L>(run), base = inc - run;
+    WF_UNROLL
+    for(int k = 0; k < NQ; ++k) {
+        const int Q = ll * NQ + k;
+        if(Q < QUADS)
+            qp[Q] = base + ex[k];
+    }
+    if(ll == L - 1)
+        qp[QUADS] = inc;
+    wave_fence(); // (LDS operations of a wavefront execute in order: the look-ups below see the prefix)
+#if defined(WF_EXP_PS_CUT) && WF_EXP_PS_CUT == 8
+    WF_UNROLL
+    for(int c = 0; c < 5; ++c)
+        asm volatile("" ::"v"(be.coef[c].x), "v"(be.coef[c].y), "v"(be.coef[c].z), "v"(be.coef[c].w));
+    return;
+#endif
     const uint32_t lohi = f32_bits(be.coef[4].x), info = f32_bits(be.coef[4].y);
     const int lo = (int)(lohi & 0xffffu), hi = (int)(lohi >> 16);
-    const double *scan = ps_scan_area(dbl, M), *tot = scan + M / 4 + 2;
     const float *pl = dbl + lo + 1, *ph = dbl + hi + 1; // bins q - 3 .. q + 3 of the row parked from dbl + 4
     float l[7], h[7];
     WF_UNROLL
@@ -1954,22 +1986,22 @@ template<class G> WF_DEV void ps_finish(const BarArgs &b, const BarEntries<G> &b
         l[j] = pl[j];
         h[j] = ph[j];
     }
-    // PS[min(q + 4, M)] within its block: the group's entry + the bins of the group in front of the position (the top three of the
-    // window; a clamped position is a multiple of 4)
-    auto local = [&](int q, const float (&w)[7], int &blk) {
+    // PS[min(q + 4, M)]: the quads in front (float64), the groups of the quad in front, the bins of the group in front (the top
+    // three of the window; a clamped position is a multiple of 16)
+    auto prefix = [&](int q, const float (&w)[7]) {
         const int x = q + 4 < M ? q + 4 : M;
-        const int g = x >> 2, i = x & 3;
-        blk = g >> 6;
-        float part = i >= 1 ? w[6] : 0.0f;
-        part += i >= 2 ? w[5] : 0.0f;
-        part += i >= 3 ? w[4] : 0.0f;
-        return scan[g] + (double)part;
+        const int ng = (x >> 2) & 3, nb = x & 3;
+        const float *p = quad_groups(x >> 4);
+        double v = qp[x >> 4];
+        v += (double)(ng >= 1 ? p[0] : 0.0f);
+        v += (double)(ng >= 2 ? p[NG] : 0.0f);
+        v += (double)(ng >= 3 ? p[2 * NG] : 0.0f);
+        v += (double)(nb >= 1 ? w[6] : 0.0f);
+        v += (double)(nb >= 2 ? w[5] : 0.0f);
+        v += (double)(nb >= 3 ? w[4] : 0.0f);
+        return v;
     };
-    int bl, bh;
-    const double p_lo = local(lo, l, bl), p_hi = local(hi, h, bh);
-    double dp = p_hi - p_lo;
-    for(int c = bl; c < bh; ++c)
-        dp += tot[c];
+    const double dp = prefix(hi, h) - prefix(lo, l);
     float e0 = l[0] * be.coef[0].x, e1 = h[0] * be.coef[1].w;
     e0 = fmaf(l[1], be.coef[0].y, e0);
     e1 = fmaf(h[1], be.coef[2].x, e1);
@@ -1986,7 +2018,11 @@ template<class G> WF_DEV void ps_finish(const BarArgs &b, const BarEntries<G> &b
     float sub = fmaf(be.coef[3].z, (float)dp, e0 + e1);
     sub = seg_prefix_scan(sub, info);
     const int bar = (int)((info >> 8) & 0xffu) - 1;
-    if(bar >= 0)
+#if defined(WF_EXP_PS_CUT) && WF_EXP_PS_CUT == 9
+    asm volatile("" ::"v"(sub), "v"(bar));
+    return;
+#endif
+    if(emit && bar >= 0)
         emit_output(b, bar, sub / (float)(info >> 16), out_row, dup_row);
 }
 
