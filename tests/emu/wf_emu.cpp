@@ -312,8 +312,8 @@ long wfemu_bar_pieces(const wf_config *cfg, int threads, int points, int max_blo
     return (long)v.size();
 }
 
-// the prefix-sum form (wf::bar_ps).  which: 0 the lane table [5][64][4] (integers as bit patterns), 1 scalars
-// {num_lanes, num_subs, merge}; -1000 if the form does not exist for this configuration
+// the prefix-sum form (wf::bar_ps).  which: 0 the lane table [3][64][4] (integers as bit patterns), 1 scalars
+// {num_lanes, num_subs}; -1000 if the form does not exist for this configuration
 long wfemu_bar_ps(const wf_config *cfg, int threads, int which, float *out, long cap)
 {
     wf::HostTables tab;
@@ -326,7 +326,7 @@ long wfemu_bar_ps(const wf_config *cfg, int threads, int which, float *out, long
     std::vector<float> v;
     switch(which) {
     case 0: v = ps.tab; break;
-    case 1: v = {(float)ps.num_lanes, (float)ps.num_subs, ps.merge ? 1.0f : 0.0f}; break;
+    case 1: v = {(float)ps.num_lanes, (float)ps.num_subs}; break;
     default: return -1;
     }
     for(long i = 0; i < (long)v.size() && i < cap; ++i)

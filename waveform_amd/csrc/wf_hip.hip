@@ -79,7 +79,6 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.piece_mode = h->bar_piece_mode ? 1 : 0;
         a.bar.ps_tab = h->d_ps_tab;
         a.bar.ps_lanes = h->bar_ps_lanes;
-        a.bar.ps_merge = h->bar_ps_merge ? 1 : 0;
         a.bar.num_segs = h->bar_segs;
         a.bar.lane_blocks = h->bar_blocks;
         a.bar.cur_coef = h->d_cur_coef;

@@ -161,7 +161,6 @@ struct wf_hip {
     bool bar_piece_mode = false;     // BarArgs::piece_mode (d_seg_group holds BarPieceTables::info, d_bar_seg its bar_piece)
     float *d_ps_tab = nullptr;       // BarArgs::ps_tab (BarPsTables::tab), prefix-sum layout of the bar reduction
     int bar_ps_lanes = 0;            // BarArgs::ps_lanes; 0: the layout is not used
-    bool bar_ps_merge = false;       // BarArgs::ps_merge
     unsigned long long *d_phase_clock = nullptr; // only allocated by WF_PHASE_TIMING builds
     uint8_t *d_mask = nullptr;
     size_t mask_bytes = 0;

@@ -406,14 +406,13 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // prefix-sum layout first (BarPsTables: float64 prefix sums of the row in registers, one lane per sub-band -- no
             // per-thread coefficient table at all); power-of-two sizes from 512 samples, no Gaussian filter
             wf::BarPsTables ps;
-            bool want_ps = h->tab.gauss_radius == 0 && points >= 8 && !h->blu; // (wf::BarEntries<G>::PS: not on the four-point geometry)
+            bool want_ps = h->tab.gauss_radius == 0 && h->N >= 512u && !h->blu;
 #ifdef WF_DEV_OVERRIDES
             if(const char *e = std::getenv("WF_HIP_BAR_PS"))
                 want_ps = want_ps && e[0] != '0';
 #endif
             if(want_ps && wf::bar_ps(h->tab, threads, ps) && wf::ps_lds_floats(h->M) <= lds_floats) {
                 h->bar_ps_lanes = ps.num_lanes;
-                h->bar_ps_merge = ps.merge;
                 h->out_steps = 1;
                 WF_PLAN_TRY(upload(h, &h->d_ps_tab, ps.tab));
                 WF_PLAN_HIP(hipStreamSynchronize(h->stream)); // the staging vector dies here
@@ -560,7 +559,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             h->d_cur_coef = nullptr; h->d_cur_base = nullptr; h->d_cur_x = nullptr; h->d_gauss = nullptr; h->d_gauss_wsum = nullptr;
             h->d_lane_coef = nullptr; h->d_lane_base = nullptr; h->d_bar_seg = nullptr; h->d_seg_group = nullptr;
             h->d_lead_bar = nullptr; h->d_lead_end = nullptr;
-            h->d_ps_tab = nullptr; h->bar_ps_lanes = 0; h->bar_ps_merge = false;
+            h->d_ps_tab = nullptr; h->bar_ps_lanes = 0;
             h->curve = h->curve_both = h->curve_catrom = h->stream_steps = h->bar_wave_local = h->bar_piece_mode = false;
             h->out_steps = h->bar_segs = h->bar_blocks = h->bar_chunks = h->bar_stage_off = 0;
             h->bar_lpb = 1;

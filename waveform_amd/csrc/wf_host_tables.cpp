@@ -574,34 +574,16 @@ bool bar_ps(const HostTables &t, int threads, BarPsTables &out)
     for(const Sub &s : subs)
         if(s.lo < 0 || s.hi > M || s.hi < s.lo)
             return false;
-    // lanes: the sub-bands of a bar are consecutive lanes of one block of 64
-    std::vector<int> lane_of(subs.size());
-    int lane = 0;
-    for(size_t a = 0; a < subs.size();) {
-        size_t b = a;
-        while(b < subs.size() && subs[b].bar == subs[a].bar)
-            ++b;
-        const int n = (int)(b - a);
-        if(n > 64)
-            return false;
-        if((lane % 64) + n > 64)
-            lane = (lane + 63) / 64 * 64;
-        for(size_t q = a; q < b; ++q)
-            lane_of[q] = lane++;
-        a = b;
-    }
-    if(lane > 64)
-        return false; // (one finishing wavefront: at most 64 sub-bands; the other layouts take the displays with more)
+    // two lanes per sub-band: lane 2 j its low edge, lane 2 j + 1 its high edge
+    if(subs.size() > 32)
+        return false; // (one finishing wavefront per spectrum; the other layouts take the displays with more)
     out.num_lanes = 64;
     out.num_subs = (int)subs.size();
-    out.merge = lane <= 32; // the table repeats in lanes 32 ..: one wavefront finishes two spectra
-    out.tab.assign((size_t)5 * 64 * 4, 0.0f);
+    out.tab.assign((size_t)3 * 64 * 4, 0.0f);
     auto word = [&](int ln, int c, int e) -> float & { return out.tab[((size_t)c * 64 + (size_t)ln) * 4 + (size_t)e]; };
     auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    for(int rep = 0; rep < (out.merge ? 2 : 1); ++rep)
     for(size_t a = 0; a < subs.size(); ++a) {
         const Sub &s = subs[a];
-        const int ln = lane_of[a] + 32 * rep;
         float clo[7], chi[7], sw = 0.0f;
         if(s.hi - s.lo <= 7) {
             // direct: the composite coefficient of bin m is the sum of the taps of every sample of the sub-band that land on it
@@ -627,29 +609,33 @@ bool bar_ps(const HostTables &t, int threads, BarPsTables &out)
             }
             sw = (float)(c + (double)s.w[7]);
         }
-        for(int j = 0; j < 4; ++j)
-            word(ln, 0, j) = clo[j];
-        word(ln, 1, 0) = clo[4]; word(ln, 1, 1) = clo[5]; word(ln, 1, 2) = clo[6]; word(ln, 1, 3) = chi[0];
-        for(int j = 0; j < 4; ++j)
-            word(ln, 2, j) = chi[1 + j];
-        word(ln, 3, 0) = chi[5]; word(ln, 3, 1) = chi[6]; word(ln, 3, 2) = sw;
-        // the segmented inclusive prefix over the bar's lanes [l0, l0 + n): which of seg_prefix_scan's six steps this lane takes
-        size_t first = a;
+        // the segmented inclusive prefix over the bar's lanes [l0, l1]: which of seg_prefix_scan's six steps a lane takes
+        size_t first = a, last = a;
         while(first > 0 && subs[first - 1].bar == s.bar)
             --first;
-        const int l0 = lane_of[first] + 32 * rep, l = ln;
-        const bool last = a + 1 == subs.size() || subs[a + 1].bar != s.bar;
-        uint32_t flags = 0;
-        for(int d = 0; d < 4; ++d)
-            if(l - (1 << d) >= l0 && (l & 15) >= (1 << d))
-                flags |= 1u << d;
-        if(l >= 16 && ((l >> 4) & 1) && l0 <= (l & ~15) - 1)
-            flags |= 1u << 4;
-        if(l >= 32 && l0 <= 31)
-            flags |= 1u << 5;
-        const uint32_t info = flags | (last ? (uint32_t)(s.bar + 1) << 8 : 0u) | (uint32_t)t.band_widths[(size_t)s.bar] << 16;
-        word(ln, 4, 0) = bits((uint32_t)s.lo | (uint32_t)s.hi << 16);
-        word(ln, 4, 1) = bits(info);
+        while(last + 1 < subs.size() && subs[last + 1].bar == s.bar)
+            ++last;
+        const int l0 = 2 * (int)first;
+        for(int side = 0; side < 2; ++side) {
+            const int l = 2 * (int)a + side;
+            const float *c = side ? chi : clo;
+            for(int j = 0; j < 4; ++j)
+                word(l, 0, j) = c[j];
+            word(l, 1, 0) = c[4]; word(l, 1, 1) = c[5]; word(l, 1, 2) = c[6]; word(l, 1, 3) = sw;
+            uint32_t flags = 0;
+            for(int d = 0; d < 4; ++d)
+                if(l - (1 << d) >= l0 && (l & 15) >= (1 << d))
+                    flags |= 1u << d;
+            if(l >= 16 && ((l >> 4) & 1) && l0 <= (l & ~15) - 1)
+                flags |= 1u << 4;
+            if(l >= 32 && l0 <= 31)
+                flags |= 1u << 5;
+            // the bar is finished by the low-edge lane of its last sub-band (the sums meet on even lanes)
+            const bool finishes = a == last && side == 0;
+            const uint32_t info = flags | (finishes ? (uint32_t)(s.bar + 1) << 8 : 0u) | (uint32_t)t.band_widths[(size_t)s.bar] << 16;
+            word(l, 2, 0) = bits((uint32_t)(side ? s.hi : s.lo));
+            word(l, 2, 1) = bits(info);
+        }
     }
     return true;
 }

@@ -108,17 +108,17 @@ bool bar_pieces(const HostTables &t, int threads, int points, int max_blocks, Ba
 // sum of the row, kept in float64, and two 7-tap edge corrections instead of count x 8 products -- no per-bin coefficient table
 // (46 KB at N = 4096, 186 KB at 16384), no per-thread table loads, no read-back of the whole row.  Sub-bands of at most 7 bins
 // are evaluated directly instead (SW = 0, the two windows carry the composite coefficients of the bins they cover): no
-// cancellation for the narrow bands at the bottom of a log axis.  One lane of the finishing wavefront per sub-band (at most 64);
-// the sub-bands of a bar are consecutive lanes and are added by seg_prefix_scan (flags in `info`).
+// cancellation for the narrow bands at the bottom of a log axis.  The first wavefront of a spectrum finishes: TWO lanes per sub-band
+// (at most 32 sub-bands) -- lane 2 j its low edge (window coefficients clo, position lo), lane 2 j + 1 its high edge (chi, hi) --,
+// one look-up and one window each; the halves meet on the even lane, the sub-bands of a bar by seg_prefix_scan (flags in `info`).
 // POINT mode (plain band means, src/source.cpp:1525-1532) is the same with W = a single 1.
 struct BarPsTables {
-    // [5][64][4] floats, lane-major 16-byte words: {clo[0..3]} {clo[4..6], chi[0]} {chi[1..4]}
-    // {chi[5], chi[6], SW, 0} {lo | hi << 16, info, 0, 0} (the last word's integers stored as bit patterns).  chi already carries its sign.
-    // info: bits 0..5 seg_prefix_scan's steps; bits 8..15: 1 + bar when the lane is the last of its bar; bits 16..31: the bar's count
+    // [3][64][4] floats, lane-major 16-byte words: {c[0..3]} {c[4..6], SW} {position, info, 0, 0} (the integers stored as bit
+    // patterns; chi carries its sign).  info: bits 0..5 seg_prefix_scan's steps; bits 8..15: 1 + bar on the lane that finishes
+    // the bar (the low-edge lane of its last sub-band); bits 16..31: the bar's count
     std::vector<float> tab;
     int num_lanes = 0; // 64
     int num_subs = 0;
-    bool merge = false; // at most 32 lanes used: the table repeats in lanes 32 .. 63, so that one wavefront can finish two spectra
 };
 bool bar_ps(const HostTables &t, int threads, BarPsTables &out);
 

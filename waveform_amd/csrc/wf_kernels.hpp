@@ -173,12 +173,12 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     const int t = tid % T;            // thread within the spectrum
     const int lane = tid & 63;
     const int wave_in_block = tid >> 6;
-    // bars in the prefix-sum layout (BarPsTables): the wavefront that finishes the sub-bands -- the first of the workgroup for
-    // both of its spectra where their sub-bands fit 32 lanes each, else the first of every spectrum
-    constexpr bool PS_OK = !BLU && DEC == 0 && !BOTH && BarEntries<G>::PS;
-    const bool ps_mode = PS_OK && a.bar.out != nullptr && a.bar.ps_lanes > 0;
-    const bool ps_merged = SPW == 2 && a.bar.ps_merge != 0;
-    const bool ps_finisher = ps_mode && (ps_merged ? wave_in_block == 0 : (t >> 6) == 0);
+    // bars in the prefix-sum layout (BarPsTables): the first wavefront of every spectrum finishes its sub-bands
+    // (formed where they are used, not held from here: two lane masks across the whole kernel were four scalar registers too many
+    // for the 2048-sample kernel, whose spill slot then took it over 128 vector registers)
+    constexpr bool PS_OK = !BLU && DEC == 0 && !BOTH;
+#define WF_PS_MODE (PS_OK && a.bar.out != nullptr && a.bar.ps_lanes > 0)
+#define WF_PS_FINISHER (WF_PS_MODE && (t >> 6) == 0)
     // Prologue: nothing here may wait for memory before the window fetch is in flight.  The spectrum index is clamped
     // (no branch), stream/channel come from a shift (cap_ch is 1 or 2), and the two per-stream words (write position,
     // flags) are scalar loads issued together.
@@ -269,12 +269,12 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     // few words where they are used instead of holding them from here)
     BarPre bar_pre_early{0, 0, 1, 0, 0, 0, -1};
     if constexpr(!(BLU && !MR))
-        bar_pre_early = bars_preload<G>(a.bar, t);
+        bar_pre_early = bars_preload<G, true, PS_OK>(a.bar, t);
 #if WF_EXP_COEF_AT_FETCH
     BarEntries<G> bar_entries;
     bar_entries.base = 0;
     if constexpr(Policy<G>::BAR_COEF_EARLY && !BLU && DEC == 0 && !BOTH)
-        bars_fetch_entries<G>(a.bar, t, bar_entries, ps_finisher);
+        bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
 #endif
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     bar_entries.base = 0;
 #endif
     if constexpr(COEF_EARLY && !WF_EXP_COEF_AT_FETCH) {
-        bars_fetch_entries<G>(a.bar, t, bar_entries, ps_finisher);
+        bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
         if(!process && a.bar.out != nullptr)
             wait_vmem_all(); // (the rare path that skips P4 and its wait)
     }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     }
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
     if constexpr(!COEF_EARLY)
-        bars_fetch_entries<G>(a.bar, t, bar_entries, ps_finisher);
+        bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
 #ifndef WF_EXP_STORES_AFTER_PARK
 #define WF_EXP_STORES_AFTER_PARK 0 // (experiment, needs WF_DEFER_STATE=1) bars displays: the state and row stores issued between the row's LDS copy and its
                                    // read-back, so that the LDS round trip runs under their issue
@@ -661,7 +661,15 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
 #ifndef WF_EXP_NO_ARRIVAL_WAIT
 #define WF_EXP_NO_ARRIVAL_WAIT 0
 #endif
+#ifndef WF_TAIL_PRIO
+#define WF_TAIL_PRIO 0
+#endif
     if(a.bar.out != nullptr && !WF_EXP_NO_TAIL) {
+        // The display phase runs with raised issue priority: what is left of the workgroup's life is a short serial stretch (one
+        // wavefront per spectrum at the end) that holds the workgroup's LDS, and on a SIMD shared with three wavefronts in their
+        // transform passes every instruction of it otherwise waits its turn
+        if(WF_TAIL_PRIO > 0)
+            __builtin_amdgcn_s_setprio(WF_TAIL_PRIO);
         // mono mixdown displays one row per stream: its curve points are shared by the threads of both spectra of the workgroup
         // (the plugin's default configuration: 800 points, 4 steps of 256 threads instead of 7 of 128)
         constexpr bool both = BOTH;
@@ -695,25 +703,23 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         } else if(!(mono_mix && !SPLIT))
             row_sync();
         if constexpr(PS_OK) {
-            if(ps_mode) {
+            if(WF_PS_MODE) {
+                const bool ps_finisher = (t >> 6) == 0;
                 // Every wavefront leaves its part of the row and its group sums, then counts itself in (release: its LDS stores are
-                // ordered in front of the count; the first wavefront of a spectrum also says whether the spectrum has a row); the
-                // finishing wavefront waits for everybody it serves (acquire).  One wavefront per spectrum and no sharing: program
-                // order is all it takes.
+                // ordered in front of the count); the spectrum's first wavefront waits for the others (acquire) and finishes.  One
+                // wavefront per spectrum: program order is all it takes.
                 WF_STAMP(12);
                 if(have_row)
                     ps_park<RG>(dbl, MO, t, d);
                 WF_STAMP(14);
                 if(WF_EXP_PS_CUT == 2)
                     return;
-                int *parked = facts + 2 * SPW * WPS + 2 + (ps_merged ? 0 : sub);
-                const int everybody = ps_merged ? SPW * WPS : WPS;
-                uint32_t word = have_row ? 0x100u << sub : 0u;
-                if(T > 64 || ps_merged) {
+                int *parked = facts + 2 * SPW * WPS + 2 + sub;
+                if constexpr(T > 64) {
                     if(lane == 0)
-                        __hip_atomic_fetch_add(parked, 1 + (int)((t >> 6) == 0 ? word : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(parked, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if(ps_finisher) {
-                        while(((word = (uint32_t)__hip_atomic_load(parked, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) & 0xffu) < (uint32_t)everybody)
+                        while(__hip_atomic_load(parked, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
                             __builtin_amdgcn_s_sleep(1);
                     }
                 } else
@@ -721,23 +727,13 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 WF_STAMP(15);
                 if(ps_finisher && WF_EXP_PS_CUT == 7) { // (the finisher ends behind its wait: what do the table request and the wait cost?)
 #pragma unroll
-                    for(int c = 0; c < 5; ++c)
+                    for(int c = 0; c < 3; ++c)
                         asm volatile("" ::"v"(bar_entries.coef[c].x), "v"(bar_entries.coef[c].y), "v"(bar_entries.coef[c].z), "v"(bar_entries.coef[c].w));
                     return;
                 }
                 if(ps_finisher) {
-                    const bool dup = a.out_ch > a.cap_ch;
-                    if(ps_merged) {
-                        // lanes 0 .. 31: the first spectrum of the workgroup, 32 .. 63: the second
-                        const int seg = lane >> 5;
-                        const uint32_t spec_s = a.stream_base * a.cap_ch + blockIdx.x * SPW + (uint32_t)seg;
-                        float *dbl_s = reinterpret_cast<float *>(reinterpret_cast<cf *>(smem_raw) + (size_t)seg * lds_cf);
-                        float *out_s = a.bar.out + ((size_t)(spec_s >> cap_shift) * a.bar.disp_ch + (spec_s & cap_shift)) * a.bar.num_bars;
-                        ps_finish<G, RG, 32>(a.bar, bar_entries, dbl_s, MO, lane & 31, ((word >> (8 + seg)) & 1u) != 0, out_s, dup ? out_s + a.bar.num_bars : nullptr);
-                    } else {
-                        float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
-                        ps_finish<G, RG, 64>(a.bar, bar_entries, dbl, MO, lane, have_row && (a.bar.ps_merge == 0 || lane < 32), out0, dup ? out0 + a.bar.num_bars : nullptr);
-                    }
+                    float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+                    ps_finish<G, RG>(a.bar, bar_entries, dbl, MO, lane, have_row, out0, dup_row ? out0 + a.bar.num_bars : nullptr);
                 }
                 WF_STAMP(13);
                 return;
@@ -805,13 +801,15 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 curve_row<G>(bar_args, have_row, dbl, t, ov);
             else
                 pending = bars_reduce_row<G, !(BLU && !MR)>(
-                    bar_args, (BLU && !MR) ? bars_preload<G, false>(a.bar, t) : bar_pre_early, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
+                    bar_args, (BLU && !MR) ? bars_preload<G, false, false>(a.bar, t) : bar_pre_early, bar_entries, have_row, dbl, dbl + MO, t, out0, out1, ov, [] { spectrum_sync<G>(); },
                     [](float v, int m) { return v + __shfl_xor(v, m, 64); }, arrivals, count_arrivals ? 2 * WPS : WPS);
             if(pending)
                 outputs_finish<G>(bar_args, have_row, ov, dbl, t, out0, out1, [] { spectrum_sync<G>(); });
         }
     }
     WF_STAMP(13);
+#undef WF_PS_MODE
+#undef WF_PS_FINISHER
 }
 
 } // namespace wf

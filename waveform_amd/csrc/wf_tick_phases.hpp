@@ -81,11 +81,10 @@ struct BarArgs {
     // are summed by a DPP prefix scan and the last wavefront to arrive adds the pieces of every bar
     int piece_mode;
     // prefix-sum layout (BarPsTables, wf_host_tables.hpp): every wavefront leaves its part of the row and its four-bin group sums;
-    // lane l of the finishing wavefront evaluates sub-band l from two look-ups into a float64 prefix sum it forms itself and two
-    // 7-tap edge windows.  ps_tab: [5][64][4]; ps_lanes: 64, or 0: off
+    // the first wavefront of the spectrum forms a float64 prefix sum over 16-bin quads and evaluates the sub-bands, two lanes each
+    // (one look-up and one 7-tap edge window per lane).  ps_tab: [3][64][4]; ps_lanes: 64, or 0: off
     const float *ps_tab;
     int ps_lanes;
-    int ps_merge;              // != 0 (two spectra per workgroup, at most 32 sub-bands): the first wavefront of the workgroup finishes both spectra, 32 lanes each (the table repeats in lanes 32 ..)
     int num_segs;
     int lane_blocks;
     // Curve display (render_curve, reference src/source.cpp:1360-1425): num_bars = m_width points per row, point
@@ -1536,10 +1535,10 @@ WF_DEV float lerp_std(float a, float b, float t)
 // the very start of the kernel with the audio window, so that the bars phase at the end does not begin with a chain of
 // dependent table loads.
 struct BarPre { int off, len, count; int s0, s1; int glen; int lead; };
-template<class G, bool PIECES = true> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
+template<class G, bool PIECES = true, bool PS_OK = true> WF_DEV BarPre bars_preload(const BarArgs &b, int t)
 {
     BarPre p{0, 0, 1, 0, 0, 0, -1};
-    if(b.out != nullptr && b.ps_lanes == 0) { // (the prefix-sum layout keeps everything in its lane table: bars_fetch_entries)
+    if(b.out != nullptr && !(PS_OK && b.ps_lanes > 0)) { // (the prefix-sum layout keeps everything in its lane table: bars_fetch_entries)
         if(PIECES && b.num_segs > 0 && b.piece_mode) {
             // glen: the scan flags and 1 + the slot this lane's piece total goes to.  One wavefront per spectrum: the slot is the
             // bar itself (lead / count); several: lane l of whichever wavefront arrives last finishes bar l from slots [s0, s1)
@@ -1582,24 +1581,33 @@ template<class G, bool PIECES = true> WF_DEV BarPre bars_preload(const BarArgs &
 // The (coefficient, bin) pairs of this thread's segment: 16-byte loads, coalesced across the threads, requested before
 // the dB math so that their L2 latency is off the critical path.
 template<class G> struct BarEntries {
-    static constexpr bool PS = G::P >= 8; // the prefix-sum layout (not on the four-point geometry, N = 512: at its 80-register cap the two extra words spill)
-    static constexpr int CMAX = (PS && G::P / 4 + 2 < 5) ? 5 : G::P / 4 + 2; // the host builds segments of at most 4 * (P / 4 + 2) entries; the prefix-sum layout's lane table is five words
+    static constexpr int CMAX = G::P / 4 + 2; // the host builds segments of at most 4 * CMAX entries; the prefix-sum layout's lane table is three words
     f4 coef[CMAX];
     int base;
 };
-template<class G> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be, bool finisher = false)
+template<class G, bool PS_OK = true> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be, bool finisher = false)
 {
     constexpr int T = G::T;
     be.base = 0;
+    if constexpr(!PS_OK) { // (the instantiation never runs the prefix-sum layout -- the Bluestein / mixed-radix kernels at their register caps)
+        if(b.out == nullptr || b.num_segs == 0)
+            return;
+        be.base = b.lane_base[t];
+        WF_UNROLL
+        for(int c = 0; c < BarEntries<G>::CMAX; ++c)
+            if(c < b.lane_blocks) // uniform
+                be.coef[c] = ld4(b.lane_coef + (c * T + t) * 4);
+        return;
+    }
     if(b.out == nullptr || (b.num_segs == 0 && b.ps_lanes == 0))
         return;
     // One loop for both layouts (two loops writing the one array left half of it in scratch: ROCm 7.2's SROA gives up on the phi).
-    // Prefix-sum layout: the five 16-byte words of this lane's sub-band (BarPsTables), requested only by the wavefront that
+    // Prefix-sum layout: the three 16-byte words of this lane's sub-band edge (BarPsTables), requested only by the wavefront that
     // finishes sub-bands (`finisher`, wave-uniform).
-    const bool ps = BarEntries<G>::PS && b.ps_lanes > 0;
+    const bool ps = b.ps_lanes > 0;
     const float *p = ps ? b.ps_tab + (size_t)(t & 63) * 4 : b.lane_coef + (size_t)t * 4;
     const int stride = ps ? 256 : T * 4;
-    int n = ps ? (finisher ? 5 : 0) : b.lane_blocks;
+    int n = ps ? (finisher ? 3 : 0) : b.lane_blocks;
 #if defined(__HIPCC__)
     n = __builtin_amdgcn_readfirstlane(n);
 #endif
@@ -1898,14 +1906,16 @@ WF_DEV double *ps_qp_area(float *dbl, int M) { return reinterpret_cast<double *>
 template<class RG> WF_DEV void ps_park(float *dbl, int M, int t, const float (&d)[RG::P])
 {
     constexpr int NG = RG::P / 4;
-    static_assert(NG == 2 || NG % 4 == 0, "group sums are stored as 8- or 16-byte words");
+    static_assert(NG == 1 || NG == 2 || NG % 4 == 0, "group sums are stored as 4-, 8- or 16-byte words");
     store_row<RG>(dbl + 4, t, d);
     float *gs = ps_gs_area(dbl, M) + t * NG;
     float s[NG];
     WF_UNROLL
     for(int u = 0; u < NG; ++u)
         s[u] = (d[4 * u] + d[4 * u + 1]) + (d[4 * u + 2] + d[4 * u + 3]);
-    if constexpr(NG == 2)
+    if constexpr(NG == 1)
+        gs[0] = s[0];
+    else if constexpr(NG == 2)
         *reinterpret_cast<f2 *>(gs) = f2{s[0], s[1]};
     else {
         WF_UNROLL
@@ -1917,10 +1927,10 @@ template<class RG> WF_DEV void ps_park(float *dbl, int M, int t, const float (&d
         st4(dbl + 4 + M, f4{0.0f, 0.0f, 0.0f, 0.0f});
     }
 }
-// Inclusive prefix over segments of L = 32 or 64 lanes (32: the halves of the wavefront separately -- the last step is left out)
-template<int L> WF_DEV double seg_scan_f64(double v)
+// Inclusive prefix of a double over the 64 lanes of a wavefront: the classic six DPP steps (row_shr 1, 2, 4, 8 inside rows of 16,
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) on the two halves of the value; a lane without a source adds +0.0
+WF_DEV double wave_scan_f64(double v)
 {
-    static_assert(L == 32 || L == 64, "");
 #if defined(__HIPCC__)
 #define WF_SCAN64_STEP(CTRL, ROWS)                                                                                         \
     {                                                                                                                      \
@@ -1934,24 +1944,33 @@ template<int L> WF_DEV double seg_scan_f64(double v)
     WF_SCAN64_STEP(0x114, 0xf)
     WF_SCAN64_STEP(0x118, 0xf)
     WF_SCAN64_STEP(0x142, 0xa)
-    if constexpr(L == 64)
-        WF_SCAN64_STEP(0x143, 0xc)
+    WF_SCAN64_STEP(0x143, 0xc)
 #undef WF_SCAN64_STEP
 #endif
     return v;
 }
-// The finishing wavefront: lane `ll` of the L lanes that serve this spectrum (i) adds the group sums of its share of the quads,
-// leaves their float64 prefix in LDS, (ii) evaluates sub-band `ll` of the lane table; the last lane of a bar maps and stores it
-// (`emit` false: the spectrum produced no row -- everything is computed on whatever the buffer holds and nothing is stored; the
-// DPP steps must not sit under a divergent branch).
-template<class G, class RG, int L> WF_DEV void ps_finish(const BarArgs &b, const BarEntries<G> &be, float *dbl, int M, int ll, bool emit, float *out_row, float *dup_row)
+// the value of lane l ^ 1 (quad_perm:[1,0,3,2])
+WF_DEV int lane_swap1(int v)
+{
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+#else
+    return v;
+#endif
+}
+// The finishing wavefront of a spectrum: lane `ll` (i) adds the group sums of its share of the quads and leaves their float64
+// prefix in LDS, (ii) evaluates one edge of sub-band ll / 2 -- the look-up at its position and the dot product of its window --;
+// the edges meet on the even lane, the sub-bands of a bar by the segmented scan, and the lane that finishes a bar maps and stores
+// it.  (`emit` false: the spectrum produced no row -- everything is computed on whatever the buffer holds and nothing is stored;
+// the DPP steps must not sit under a divergent branch.)
+template<class G, class RG> WF_DEV void ps_finish(const BarArgs &b, const BarEntries<G> &be, float *dbl, int M, int ll, bool emit, float *out_row, float *dup_row)
 {
     constexpr int T = RG::T, NG = RG::P / 4;
     const float *gs = ps_gs_area(dbl, M);
     double *qp = ps_qp_area(dbl, M);
     // group g = t + T u is stored at t NG + u; the four groups of quad Q are four consecutive threads of one register group
     auto quad_groups = [&](int Q) { const int g0 = 4 * Q; return gs + (g0 & (T - 1)) * NG + g0 / T; };
-    constexpr int QUADS = G::M / 16, NQ = (QUADS + L - 1) / L;
+    constexpr int QUADS = G::M / 16, NQ = (QUADS + 63) / 64;
     double run = 0.0, ex[NQ];
     WF_UNROLL
     for(int k = 0; k < NQ; ++k) {
@@ -1959,63 +1978,56 @@ template<class G, class RG, int L> WF_DEV void ps_finish(const BarArgs &b, const
         const float *p = quad_groups(Q < QUADS ? Q : 0);
         const float qt = (p[0] + p[NG]) + (p[2 * NG] + p[3 * NG]);
         ex[k] = run;
-        run += (double)(Q < QUADS ? qt : 0.0f);
+        run += (double)((QUADS % 64 == 0 || Q < QUADS) ? qt : 0.0f);
     }
-    const double inc = seg_scan_f64<L>(run), base = inc - run;
+    const double inc = wave_scan_f64(run), base = inc - run;
     WF_UNROLL
     for(int k = 0; k < NQ; ++k) {
         const int Q = ll * NQ + k;
-        if(Q < QUADS)
+        if(QUADS % 64 == 0 || Q < QUADS)
             qp[Q] = base + ex[k];
     }
-    if(ll == L - 1)
+    if(ll == 63)
         qp[QUADS] = inc;
     wave_fence(); // (LDS operations of a wavefront execute in order: the look-ups below see the prefix)
 #if defined(WF_EXP_PS_CUT) && WF_EXP_PS_CUT == 8
     WF_UNROLL
-    for(int c = 0; c < 5; ++c)
+    for(int c = 0; c < 3; ++c)
         asm volatile("" ::"v"(be.coef[c].x), "v"(be.coef[c].y), "v"(be.coef[c].z), "v"(be.coef[c].w));
     return;
 #endif
-    const uint32_t lohi = f32_bits(be.coef[4].x), info = f32_bits(be.coef[4].y);
-    const int lo = (int)(lohi & 0xffffu), hi = (int)(lohi >> 16);
-    const float *pl = dbl + lo + 1, *ph = dbl + hi + 1; // bins q - 3 .. q + 3 of the row parked from dbl + 4
-    float l[7], h[7];
+    const int q = (int)f32_bits(be.coef[2].x);
+    const uint32_t info = f32_bits(be.coef[2].y);
+    const float *pw = dbl + q + 1; // bins q - 3 .. q + 3 of the row parked from dbl + 4
+    float w[7];
     WF_UNROLL
-    for(int j = 0; j < 7; ++j) {
-        l[j] = pl[j];
-        h[j] = ph[j];
-    }
+    for(int j = 0; j < 7; ++j)
+        w[j] = pw[j];
     // PS[min(q + 4, M)]: the quads in front (float64), the groups of the quad in front, the bins of the group in front (the top
     // three of the window; a clamped position is a multiple of 16)
-    auto prefix = [&](int q, const float (&w)[7]) {
-        const int x = q + 4 < M ? q + 4 : M;
-        const int ng = (x >> 2) & 3, nb = x & 3;
-        const float *p = quad_groups(x >> 4);
-        double v = qp[x >> 4];
-        v += (double)(ng >= 1 ? p[0] : 0.0f);
-        v += (double)(ng >= 2 ? p[NG] : 0.0f);
-        v += (double)(ng >= 3 ? p[2 * NG] : 0.0f);
-        v += (double)(nb >= 1 ? w[6] : 0.0f);
-        v += (double)(nb >= 2 ? w[5] : 0.0f);
-        v += (double)(nb >= 3 ? w[4] : 0.0f);
-        return v;
-    };
-    const double dp = prefix(hi, h) - prefix(lo, l);
-    float e0 = l[0] * be.coef[0].x, e1 = h[0] * be.coef[1].w;
-    e0 = fmaf(l[1], be.coef[0].y, e0);
-    e1 = fmaf(h[1], be.coef[2].x, e1);
-    e0 = fmaf(l[2], be.coef[0].z, e0);
-    e1 = fmaf(h[2], be.coef[2].y, e1);
-    e0 = fmaf(l[3], be.coef[0].w, e0);
-    e1 = fmaf(h[3], be.coef[2].z, e1);
-    e0 = fmaf(l[4], be.coef[1].x, e0);
-    e1 = fmaf(h[4], be.coef[2].w, e1);
-    e0 = fmaf(l[5], be.coef[1].y, e0);
-    e1 = fmaf(h[5], be.coef[3].x, e1);
-    e0 = fmaf(l[6], be.coef[1].z, e0);
-    e1 = fmaf(h[6], be.coef[3].y, e1);
-    float sub = fmaf(be.coef[3].z, (float)dp, e0 + e1);
+    const int x = q + 4 < M ? q + 4 : M;
+    const int ng = (x >> 2) & 3, nb = x & 3;
+    const float *pg = quad_groups(x >> 4);
+    double f = qp[x >> 4];
+    f += (double)(ng >= 1 ? pg[0] : 0.0f);
+    f += (double)(ng >= 2 ? pg[NG] : 0.0f);
+    f += (double)(ng >= 3 ? pg[2 * NG] : 0.0f);
+    f += (double)(nb >= 1 ? w[6] : 0.0f);
+    f += (double)(nb >= 2 ? w[5] : 0.0f);
+    f += (double)(nb >= 3 ? w[4] : 0.0f);
+    float e0 = w[0] * be.coef[0].x, e1 = w[1] * be.coef[0].y;
+    e0 = fmaf(w[2], be.coef[0].z, e0);
+    e1 = fmaf(w[3], be.coef[0].w, e1);
+    e0 = fmaf(w[4], be.coef[1].x, e0);
+    e1 = fmaf(w[5], be.coef[1].y, e1);
+    e0 = fmaf(w[6], be.coef[1].z, e0);
+    const float e = e0 + e1;
+    // the high edge's prefix and window sum come over from the odd lane
+    const long long fb = __builtin_bit_cast(long long, f);
+    const long long ob = ((long long)lane_swap1((int)(fb >> 32)) << 32) | (long long)(unsigned int)lane_swap1((int)(fb & 0xffffffffll));
+    const float oe = __builtin_bit_cast(float, lane_swap1(__builtin_bit_cast(int, e)));
+    const double dp = __builtin_bit_cast(double, ob) - f;
+    float sub = (ll & 1) ? 0.0f : fmaf(be.coef[1].w, (float)dp, e + oe);
     sub = seg_prefix_scan(sub, info);
     const int bar = (int)((info >> 8) & 0xffu) - 1;
 #if defined(WF_EXP_PS_CUT) && WF_EXP_PS_CUT == 9
