@@ -71,7 +71,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 11
+#define WF_HIP_ABI_VERSION 12
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -271,6 +271,19 @@ int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_o
  * the stream its RCCL all-gather runs on) is made to wait for it; the handle goes on with the next tick meanwhile.  The
  * caller keeps `d_out` untouched by anything else until its consumer has run (wf_hip_wait_event orders a reuse). */
 int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, void *d_out, void *consumer_stream);
+/* Zero-copy form of the above (ABI 12): from the next tick on, every tick ALSO leaves the bars of the whole batch -- the ones it
+ * finishes and, copied over, the ones it leaves as they are (paused, hidden, silent streams) -- in caller-owned device memory of
+ * the same shape ([num_streams][display_channels][num_bars] floats), alternating between the two buffers from tick to tick: the
+ * send buffer of an all-gather is written by the tick kernel itself, nothing is enqueued behind the tick.  NULL, NULL turns it
+ * off.  WF_HIP_ERR_UNSUPPORTED for fft sizes that are not powers of two and for the batches whose display comes from a kernel of
+ * its own (fft sizes beyond a CU's LDS, filtered displays that do not fit the tick kernel's staging): those keep
+ * wf_hip_copy_bars_device_async.  WF_HIP_ERR_INVALID for level-meter and waveform batches. */
+int wf_hip_set_bars_mirror(wf_hip *h, void *d_out0, void *d_out1);
+/* `consumer_stream` is made to wait for the newest tick (every lane); *d_out = the buffer that tick wrote (NULL before the
+ * first tick).  Nothing is copied, nothing waits on the host.  A buffer is written again by the tick after next: the caller
+ * issues that tick only when the consumer of the buffer has run (an event of its own behind the consumer, two ticks old by then:
+ * hipEventSynchronize returns at once -- a device-side wait in front of every tick instead cost 4 % of the tick rate). */
+int wf_hip_bars_mirror_ready(wf_hip *h, void *consumer_stream, void **d_out);
 /* everything the handle issues after this call (on all of its internal streams) waits, on the device, for `event` (a
  * hipEvent_t of the caller, recorded before the call) -- e.g. "the gather that read the buffer the next
  * wf_hip_copy_bars_device_async overwrites has run".  Does not wait on the host. */

@@ -46,6 +46,9 @@ struct wf_hip {
     uint32_t id0 = 0;   // global id of stream 0 (wf_hip_push_synth's stream_id0)
     uint32_t ticks = 0;
     std::vector<uint8_t> hidden;
+    float *mirror[2] = {nullptr, nullptr}; // wf_hip_set_bars_mirror: every tick also writes its bars there, alternately
+    uint32_t mirror_next = 0;
+    float *mirror_last = nullptr;
     std::string err;
 };
 static thread_local std::string g_err;
@@ -92,7 +95,28 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
     return WF_HIP_OK;
 }
 int wf_hip_reset(wf_hip *h, uint32_t, uint32_t) { h->ticks = 0; return WF_HIP_OK; }
-int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *) { ++h->ticks; return WF_HIP_OK; }
+static void fill_bars(const wf_hip *h, uint32_t first, uint32_t count, float *out);
+int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *)
+{
+    ++h->ticks;
+    if(h->mirror[0]) {
+        h->mirror_last = h->mirror[h->mirror_next];
+        fill_bars(h, 0, h->streams, h->mirror_last);
+        h->mirror_next ^= 1u;
+    }
+    return WF_HIP_OK;
+}
+int wf_hip_set_bars_mirror(wf_hip *h, void *a, void *b)
+{
+    if(getenv("WF_MOCK_NO_MIRROR"))
+        return WF_HIP_ERR_UNSUPPORTED;
+    h->mirror[0] = static_cast<float *>(a);
+    h->mirror[1] = static_cast<float *>(b);
+    h->mirror_next = 0;
+    h->mirror_last = nullptr;
+    return WF_HIP_OK;
+}
+int wf_hip_bars_mirror_ready(wf_hip *h, void *, void **out) { *out = h->mirror_last; return WF_HIP_OK; }
 int wf_hip_sync(wf_hip *) { return WF_HIP_OK; }
 int wf_hip_wait_event(wf_hip *, void *) { return WF_HIP_OK; }
 int wf_hip_time_begin(wf_hip *) { return WF_HIP_OK; }

@@ -121,6 +121,8 @@ int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *
     return WF_HIP_OK;
 }
 uint32_t wf_hip_ring_frames(const wf_hip *) { return 1u << 20; }
+int wf_hip_set_bars_mirror(wf_hip *, void *, void *) { return WF_HIP_ERR_UNSUPPORTED; }
+int wf_hip_bars_mirror_ready(wf_hip *, void *, void **) { return WF_HIP_ERR_INVALID; }
 int wf_hip_read_waveform_ts(wf_hip *, uint32_t, uint32_t count, uint64_t *out)
 {
     std::memset(out, 0, (size_t)count * sizeof(uint64_t));

@@ -506,7 +506,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name)
     L.wf_hip_abi_version.restype = C.c_int
-    assert L.wf_hip_abi_version() == 11
+    assert L.wf_hip_abi_version() == 12
 
 
 def test_no_device_fails_loudly():

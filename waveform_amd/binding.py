@@ -148,6 +148,8 @@ def lib():
     L.wf_hip_launches_per_tick.argtypes = [vp]
     L.wf_hip_algorithmic_bytes_per_tick.restype = u64
     L.wf_hip_algorithmic_bytes_per_tick.argtypes = [vp, u32]
+    L.wf_hip_set_bars_mirror.argtypes = [vp, vp, vp]
+    L.wf_hip_bars_mirror_ready.argtypes = [vp, vp, C.POINTER(vp)]
     # one batch over several devices (wf_hip_multi_*)
     L.wf_hip_multi_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), u32, u32, u32, C.POINTER(vp)]
     L.wf_hip_multi_destroy.argtypes = [vp]
@@ -350,6 +352,18 @@ class SpectrumBatch:
         to wait for the copy; the handle goes on with its next tick"""
         count = self.streams - first if count is None else count
         self._ck(self.L.wf_hip_copy_bars_device_async(self.h, first, count, C.c_void_p(dev_ptr), C.c_void_p(consumer_stream)))
+
+    def set_bars_mirror(self, dev_ptr0: int | None, dev_ptr1: int | None):
+        """from the next tick on every tick also leaves the whole batch's bars in dev_ptr0 / dev_ptr1, alternately (device
+        buffers of [streams][display_channels][num_bars] floats owned by the caller); None, None turns it off.  Raises
+        WfHipError (code -2, WF_HIP_ERR_UNSUPPORTED) for batches whose display comes from a kernel of its own."""
+        self._ck(self.L.wf_hip_set_bars_mirror(self.h, C.c_void_p(dev_ptr0), C.c_void_p(dev_ptr1)))
+
+    def bars_mirror_ready(self, consumer_stream: int) -> int | None:
+        """`consumer_stream` waits for the newest tick; returns the device pointer of the buffer it wrote (None before any tick)"""
+        out = C.c_void_p(0)
+        self._ck(self.L.wf_hip_bars_mirror_ready(self.h, C.c_void_p(consumer_stream), C.byref(out)))
+        return out.value
 
     def time_begin(self):
         self._ck(self.L.wf_hip_time_begin(self.h))

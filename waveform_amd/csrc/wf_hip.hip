@@ -95,6 +95,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.entries = (int)h->tab.bar_coef.size();
         a.bar.lanes_per_bar = h->bar_lpb;
         a.bar.out = h->d_bars;
+        a.bar.out2_delta = h->bars_mirror[0] ? (long long)(h->bars_mirror[h->mirror_next] - h->d_bars) : 0;
         a.bar.num_bars = (int)h->num_bars;
         a.bar.mirror = h->cfg.mirror_freq_axis ? 1 : 0;
         a.bar.border_top = h->tab.border_top;
@@ -872,6 +873,10 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
     }
     if(h->split)
         h->flag_cur = (h->flag_cur + 1) % 3; // what the kernel wrote is what the next tick (and the readers) see
+    if(h->bars_mirror[0]) {
+        h->mirror_last = h->bars_mirror[h->mirror_next];
+        h->mirror_next ^= 1u;
+    }
     return WF_HIP_OK;
 }
 
@@ -1447,6 +1452,50 @@ int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, voi
             WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_bars_lane[l], hipEventDisableTiming));
         WF_HIP_TRY(h, hipMemcpyAsync(static_cast<float *>(d_out) + (size_t)(a - first) * per, h->d_bars + (size_t)a * per,
                                      (size_t)(b - a) * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+        WF_HIP_TRY(h, hipEventRecord(h->ev_bars_lane[l], st));
+        WF_HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_bars_lane[l], 0));
+    }
+    return WF_HIP_OK;
+}
+
+int wf_hip_set_bars_mirror(wf_hip *h, void *d_out0, void *d_out1)
+{
+    if(h == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if((d_out0 == nullptr) != (d_out1 == nullptr) || (d_out0 != nullptr && d_out0 == d_out1))
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirror: two different buffers, or NULL and NULL");
+    if(d_out0 != nullptr) {
+        if(h->d_bars == nullptr || h->meter || h->wave)
+            return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0 and cfg.curve == 0, or a level-meter / waveform batch)");
+        if(h->ext_outputs || h->big_l != 0 || h->blu)
+            return fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: only the power-of-two sizes up to 32768 whose display the tick kernel finishes itself write a second bars buffer; copy the bars with wf_hip_copy_bars_device_async", h->N);
+        if(d_out0 == (void *)h->d_bars || d_out1 == (void *)h->d_bars)
+            return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirror: the handle's own buffer");
+    }
+    h->bars_mirror[0] = static_cast<float *>(d_out0);
+    h->bars_mirror[1] = static_cast<float *>(d_out1);
+    h->mirror_next = 0;
+    h->mirror_last = nullptr;
+    return WF_HIP_OK;
+}
+
+int wf_hip_bars_mirror_ready(wf_hip *h, void *consumer_stream, void **d_out)
+{
+    if(h == nullptr || d_out == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if(h->bars_mirror[0] == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "no mirror buffers set (wf_hip_set_bars_mirror)");
+    if(consumer_stream == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "consumer stream is NULL");
+    *d_out = h->mirror_last;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t cs = static_cast<hipStream_t>(consumer_stream);
+    // as wf_hip_copy_bars_device_async: the lanes are not joined -- the consumer waits for each of them
+    const int lanes = h->lanes_pending ? h->n_lanes : 1;
+    for(int l = 0; l < lanes; ++l) {
+        hipStream_t st = l == 0 ? h->stream : h->lane_stream[l];
+        if(h->ev_bars_lane[l] == nullptr)
+            WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_bars_lane[l], hipEventDisableTiming));
         WF_HIP_TRY(h, hipEventRecord(h->ev_bars_lane[l], st));
         WF_HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_bars_lane[l], 0));
     }

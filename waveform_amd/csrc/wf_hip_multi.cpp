@@ -147,6 +147,10 @@ struct Shard {
     hipEvent_t ev_sent[2] = {nullptr, nullptr}; // peer transport: this shard's copies into every device's buffer have run
     hipEvent_t ev_done[2] = {nullptr, nullptr}; // the gathered result of the slot is complete on this device
     bool slot_used[2] = {false, false};
+    // zero-copy gathers (wf_hip_set_bars_mirror): the handle's tick kernel writes its bars into the slot's send buffer itself
+    // (LOCAL: into the result), alternating with the ticks -- the slot of a gather is then the buffer the newest tick wrote
+    bool mirror = false;
+    uint32_t cur_slot = 0; // the slot of the gather in flight / issued last on this shard
     ncclComm_t comm = nullptr;
     Worker worker;
     std::string err;
@@ -162,7 +166,8 @@ struct wf_hip_multi {
     std::vector<std::unique_ptr<Shard>> shard;
     Transport transport = Transport::LOCAL;
     std::string transport_note;
-    uint32_t gathers = 0; // slot of the next gather = gathers & 1
+    uint32_t gathers = 0; // gathers issued so far; without the mirror the slot of the next one = gathers & 1
+    int last_slot = -1;   // the slot that holds the newest complete result; -1: none (no gather yet, or the last timed run failed half way)
     // A gather that failed on one shard leaves the others with a collective nobody answers (RCCL) or with copies that never
     // come (peer): the group then aborts its communicators (ncclCommAbort ends the kernels already enqueued, so the gather
     // streams drain), refuses every later gather and goes on ticking, reading and destroying normally.
@@ -252,15 +257,33 @@ int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
         s.err = "injected failure (wf_hip_multi_debug_fail_next_gather)";
         return WF_HIP_ERR_RUNTIME;
     }
-    if(s.slot_used[k]) { // the gather that read this send buffer two gathers ago must have run before the buffer is rewritten
-        const int rc = wf_hip_wait_event(s.h, s.ev_done[k]);
+    int rc;
+    if(s.mirror) {
+        // the newest tick wrote the bars into one of the two buffers itself: the gather stream waits for that tick, nothing is copied
+        void *buf = nullptr;
+        rc = wf_hip_bars_mirror_ready(s.h, s.gstream, &buf);
+        if(rc)
+            return rc;
+        float *const *tgt = (m->transport == Transport::LOCAL) ? s.gathered : s.send;
+        if(buf == nullptr) { // no tick since the mirror was set: the handle's own buffer is the only copy
+            k = 0;
+            rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, tgt[0], s.gstream);
+            if(rc)
+                return rc;
+        } else
+            k = buf == (void *)tgt[1] ? 1u : 0u;
+    } else {
+        if(s.slot_used[k]) { // the gather that read this send buffer two gathers ago must have run before the buffer is rewritten
+            rc = wf_hip_wait_event(s.h, s.ev_done[k]);
+            if(rc)
+                return rc;
+        }
+        float *dst = (m->transport == Transport::LOCAL) ? s.gathered[k] : s.send[k];
+        rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, dst, s.gstream);
         if(rc)
             return rc;
     }
-    float *dst = (m->transport == Transport::LOCAL) ? s.gathered[k] : s.send[k];
-    int rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, dst, s.gstream);
-    if(rc)
-        return rc;
+    s.cur_slot = k;
     const size_t per = m->per;
     switch(m->transport) {
     case Transport::LOCAL: break;
@@ -296,12 +319,16 @@ int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
 int gather_complete(wf_hip_multi *m, uint32_t i, uint32_t k)
 {
     Shard &s = *m->shard[i];
+    if(s.mirror)
+        k = s.cur_slot; // (every shard's handle has run the same number of ticks: the same slot on all of them)
     if(m->transport == Transport::PEER)
         for(uint32_t j = 0; j < m->n; ++j)
             if(j != i)
                 WF_MHIP(s, hipStreamWaitEvent(s.gstream, m->shard[j]->ev_sent[k], 0));
     WF_MHIP(s, hipEventRecord(s.ev_done[k], s.gstream));
     s.slot_used[k] = true;
+    if(s.mirror && s.slot_used[k ^ 1u]) // the next tick writes the other slot's buffer: the gather that read it, a tick old, must have run
+        WF_MHIP(s, hipEventSynchronize(s.ev_done[k ^ 1u])); // (returns at once; a device-side wait in front of every tick cost 4 % of the tick rate)
     return WF_HIP_OK;
 }
 
@@ -511,6 +538,19 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
                 if(m->transport == Transport::RCCL && m->ragged)
                     WF_MHIP(s, hipMalloc((void **)&s.recv_pad[k], (size_t)m->n * m->largest * per * sizeof(float)));
             }
+            // zero-copy gathers: the tick kernel writes the slot's send buffer (LOCAL: the result) itself; the batches whose display
+            // comes from a kernel of its own keep the copy behind the tick (WF_HIP_MULTI_MIRROR=0: the copy for everybody, A/B aid)
+            {
+                const char *e = std::getenv("WF_HIP_MULTI_MIRROR");
+                float *const *tgt = (m->transport == Transport::LOCAL) ? s.gathered : s.send;
+                const int mrc = (e && e[0] == '0') ? (int)WF_HIP_ERR_UNSUPPORTED : wf_hip_set_bars_mirror(s.h, tgt[0], tgt[1]);
+                if(mrc == WF_HIP_OK)
+                    s.mirror = true;
+                else if(mrc != WF_HIP_ERR_UNSUPPORTED) {
+                    s.err = wf_hip_last_error(s.h);
+                    return mrc;
+                }
+            }
             if(m->transport == Transport::PEER) // direct xGMI stores where the link allows; hipMemcpyPeerAsync stages otherwise
                 for(uint32_t j = 0; j < m->n; ++j) {
                     const int other = m->shard[j]->device;
@@ -694,14 +734,15 @@ int wf_hip_multi_allgather_bars(wf_hip_multi *m)
         return rc;
     }
     ++m->gathers;
+    m->last_slot = (int)m->shard[0]->cur_slot;
     return WF_HIP_OK;
 }
 
 const float *wf_hip_multi_gathered_device(wf_hip_multi *m, uint32_t i)
 {
-    if(m == nullptr || i >= m->n || m->gathers == 0)
+    if(m == nullptr || i >= m->n || m->last_slot < 0)
         return nullptr;
-    return m->shard[i]->gathered[(m->gathers - 1) & 1u];
+    return m->shard[i]->gathered[m->last_slot];
 }
 
 // Test aid: shard `shard`'s next gather reports a failure before it enqueues anything -- what a failed wait or copy on one
@@ -723,9 +764,9 @@ int wf_hip_multi_read_gathered(wf_hip_multi *m, uint32_t i, float *out)
         return rc;
     if(i >= m->n || out == nullptr)
         return mfail(m, WF_HIP_ERR_INVALID, "device index %u outside 0..%u, or out is NULL", i, m->n);
-    if(m->gathers == 0)
-        return mfail(m, WF_HIP_ERR_INVALID, "no gather has been issued yet");
-    const uint32_t k = (m->gathers - 1) & 1u;
+    if(m->last_slot < 0)
+        return mfail(m, WF_HIP_ERR_INVALID, "no complete gather to read (none issued yet, or the last timed run failed half way)");
+    const uint32_t k = (uint32_t)m->last_slot;
     Shard &s = *m->shard[i];
     s.worker.post([m, &s, k, out] {
         WF_MHIP(s, hipMemcpyAsync(out, s.gathered[k], (size_t)m->total * m->per * sizeof(float), hipMemcpyDeviceToHost, s.gstream));
@@ -794,9 +835,20 @@ int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32
             st = WF_HIP_ERR_RUNTIME;
         return st;
     });
-    if(gather && !(rc && any_failed.load()))
-        m->gathers = k0 + ticks;
+    if(gather) {
+        if(rc == WF_HIP_OK && !any_failed.load()) {
+            m->gathers = k0 + ticks;
+            m->last_slot = (int)m->shard[0]->cur_slot;
+        } else {
+            // some gathers of the run completed on some shards and overwrote the slots: no slot holds a result every device agrees
+            // on -- wf_hip_multi_gathered_device / _read_gathered say so until the next complete gather
+            m->last_slot = -1;
+        }
+    }
     if(rc) {
+        // A shard that stopped in a tick (nothing to do with the exchange) left the others with a collective it never joined as
+        // well -- from that tick on; the communicators are aborted in both cases, but only because peers are stuck, and the text
+        // kept is the failing call's
         if(gather && any_failed.load())
             gather_fail(m);
         return rc;

@@ -112,6 +112,10 @@ struct BarArgs {
     unsigned long long *clk;   // development aid: this workgroup's stamp slots
 #endif
     float *out;                // [n_streams][disp_ch][num_bars]
+    // != 0 (wf_hip_set_bars_mirror): every tick also leaves the batch's bars -- the ones it finishes and, copied over, the ones it
+    // does not touch (paused, hidden or silent streams) -- in a second buffer of the same shape that starts out2_delta floats
+    // behind `out`: the send buffer of the all-gather of BASELINE configs[4], written by the kernel instead of a copy behind it
+    long long out2_delta;
     int num_bars;
     int num_chunks;
     int entries;               // total number of entries (= off[num_bars])
@@ -1635,11 +1639,17 @@ WF_DEV float map_output(const BarArgs &b, float v)
     return lerp_std(b.border_top, b.border_bottom, q);
 }
 // stores incl. the mirrored image (:1559-1564, :1419-1424): outputs above the middle repeat the lower ones
+WF_DEV void put_output(const BarArgs &b, float *row, int o, float y)
+{
+    row[o] = y;
+    if(b.out2_delta != 0) // uniform
+        row[(long long)o + b.out2_delta] = y;
+}
 WF_DEV void store_output(const BarArgs &b, int o, float y, float *out_row, float *dup_row)
 {
     if(!b.mirror) {
-        out_row[o] = y;
-        if(dup_row) dup_row[o] = y;
+        put_output(b, out_row, o, y);
+        if(dup_row) put_output(b, dup_row, o, y);
         return;
     }
     const int half = b.num_bars / 2;
@@ -1647,12 +1657,12 @@ WF_DEV void store_output(const BarArgs &b, int o, float y, float *out_row, float
     const bool own = o <= half;
     const bool image = o < half && img > half && img < b.num_bars;
     if(own) {
-        out_row[o] = y;
-        if(dup_row) dup_row[o] = y;
+        put_output(b, out_row, o, y);
+        if(dup_row) put_output(b, dup_row, o, y);
     }
     if(image) {
-        out_row[img] = y;
-        if(dup_row) dup_row[img] = y;
+        put_output(b, out_row, img, y);
+        if(dup_row) put_output(b, dup_row, img, y);
     }
 }
 WF_DEV void emit_output(const BarArgs &b, int o, float v, float *out_row, float *dup_row)

@@ -90,14 +90,17 @@ def verify_gathered(full, own, shard: Shard, group=None) -> bool:
 
 
 class BarsGather:
-    """The per-tick exchange of BASELINE configs[4], overlapped: after tick i the handle copies its bars into one of two
-    send buffers on its own stream (wf_hip_copy_bars_device_async) and goes on with tick i+1; the all-gather of tick i runs
-    on a side stream that waits only for that copy (11 us of xGMI wire time per peer against ~140 us of compute per tick,
-    SURVEY.md section 8(e)).  Nothing blocks the host: a send buffer is reused two ticks later, after an event says its gather
-    has run.  world 1: the "gather" is the local copy -- the same device path, no collective."""
+    """The per-tick exchange of BASELINE configs[4], overlapped and without a copy: the handle's tick kernel writes the batch's
+    bars straight into one of two send buffers (wf_hip_set_bars_mirror) and goes on with tick i+1; the all-gather of tick i
+    runs on a side stream that waits only for that tick (11 us of xGMI wire time per peer against ~140 us of compute per
+    tick).  A send buffer is rewritten two ticks later; before that tick is issued the host checks the
+    event behind the gather that read it (a tick old by then).  world 1: the "gathered" bars ARE
+    the send buffer -- no collective, no copy.  Batches whose display comes from a kernel of its own (fft sizes beyond a CU's
+    LDS) keep the copy behind the tick (wf_hip_copy_bars_device_async)."""
 
     def __init__(self, batch, shard: Shard, group=None):
         import torch
+        from . import binding
         self.batch, self.shard, self.group = batch, shard, group
         shape = (shard.count, batch.display_channels, batch.num_bars)
         self.send = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -105,22 +108,50 @@ class BarsGather:
         self.done = [None, None]
         self.side = torch.cuda.Stream()
         self.i = 0
+        self.newest = None
+        try:
+            import os
+            if os.environ.get("WF_BARS_GATHER_COPY"):  # A/B aid (tools/ab_gather.py): the copy behind the tick for everybody
+                raise binding.WfHipError(-2, "WF_BARS_GATHER_COPY")
+            batch.set_bars_mirror(self.send[0].data_ptr(), self.send[1].data_ptr())
+            self.zero_copy = True
+        except binding.WfHipError as e:
+            if e.code != -2:  # WF_HIP_ERR_UNSUPPORTED: the display comes from a kernel of its own -> the copy behind the tick
+                raise
+            self.zero_copy = False
+
+    def close(self):
+        if self.zero_copy:
+            self.side.synchronize()
+            self.batch.set_bars_mirror(None, None)
+            self.zero_copy = False
 
     def launch(self):
+        """call after every tick: the gather of that tick's bars is enqueued on the side stream"""
         import torch
-        k = self.i & 1
+        if self.zero_copy:
+            ptr = self.batch.bars_mirror_ready(self.side.cuda_stream)
+            k = 0 if ptr == self.send[0].data_ptr() else 1
+        else:
+            k = self.i & 1
+            if self.done[k] is not None:
+                self.done[k].synchronize()  # the gather that read this send buffer two ticks ago (long finished)
+            self.batch.copy_bars_to_device_async(self.send[k].data_ptr(), self.side.cuda_stream)
         self.i += 1
-        if self.done[k] is not None:
-            self.done[k].synchronize()  # the gather that read this send buffer two ticks ago (long finished)
-        self.batch.copy_bars_to_device_async(self.send[k].data_ptr(), self.side.cuda_stream)
         with torch.cuda.stream(self.side):
-            self.result[k] = allgather_bars(self.send[k], self.shard, self.group)
+            self.result[k] = self.send[k] if (self.zero_copy and self.shard.world == 1) else allgather_bars(self.send[k], self.shard, self.group)
             ev = torch.cuda.Event()
             ev.record(self.side)
             self.done[k] = ev
+        if self.zero_copy and self.done[k ^ 1] is not None:
+            # the next tick writes the other buffer: the gather that read it (enqueued a tick ago) must have run.  A host wait
+            # that returns at once -- a device-side wait in front of every tick cost 4 % of the tick rate
+            self.done[k ^ 1].synchronize()
+        self.newest = k
         return k
 
     def wait(self):
-        """blocks until every launched gather has run; returns the newest combined bars [total, display_channels, num_bars]"""
+        """blocks until every launched gather has run; returns the newest combined bars [total, display_channels, num_bars]
+        (zero-copy at world 1: the send buffer itself -- valid until the tick after next rewrites it)"""
         self.side.synchronize()
-        return self.result[(self.i - 1) & 1] if self.i else None
+        return self.result[self.newest] if self.newest is not None else None
