@@ -618,6 +618,13 @@ def main():
             "roofline": roofline(batch, "cfg3_n4096" if (args.streams, args.fft, flags) == (STREAMS_PER_GPU, FFT_SIZE, 0) else None, kernel_ms, flags,
                                  wall_ms=ms_per_step, cold_ms=cold_ms),
         }
+        # every rank's own fraction of its GPU's HBM peak -- by its wall clock per step and by its device time per tick -- next to the
+        # job's (the slowest rank's): a GPU that lags the others on a node shows here
+        algo_per_tick = out["roofline"]["algorithmic_bytes_per_tick"]
+        peak = out["roofline"]["peak"]
+        dev_ms_per_rank = per_rank_kernel_ms if dist is not None else [kernel_ms]
+        out["roofline"]["frac_per_rank"] = [algo_per_tick / (ms * 1e-3) / 1e9 / peak for ms in per_rank_ms]
+        out["roofline"]["frac_events_per_rank"] = [algo_per_tick / (ms * 1e-3) / 1e9 / peak for ms in dev_ms_per_rank]
         try:  # the memory system's own ceiling, measured here and now: the headline kernel against a plain copy
             cc = copy_ceiling(torch)
             cc["headline_vs_copy"] = out["roofline"]["achieved"] / cc["achieved"]

@@ -279,6 +279,11 @@ int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, voi
  * its own (fft sizes beyond a CU's LDS, filtered displays that do not fit the tick kernel's staging): those keep
  * wf_hip_copy_bars_device_async.  WF_HIP_ERR_INVALID for level-meter and waveform batches. */
 int wf_hip_set_bars_mirror(wf_hip *h, void *d_out0, void *d_out1);
+/* the same with n <= 8 buffers per set: tick k writes every buffer of set k & 1.  The buffers may be memory of peer devices this
+ * device can address (hipDeviceEnablePeerAccess): a shard then leaves its slice in every device's gathered result itself, and the
+ * exchange of BASELINE configs[4] needs no copy and no collective kernel at all (the C ABI's multi-device group, peer transport).
+ * n = 0 turns it off.  wf_hip_bars_mirror_ready reports buffer 0 of the set. */
+int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *d_out0, void *const *d_out1);
 /* `consumer_stream` is made to wait for the newest tick (every lane); *d_out = the buffer that tick wrote (NULL before the
  * first tick).  Nothing is copied, nothing waits on the host.  A buffer is written again by the tick after next: the caller
  * issues that tick only when the consumer of the buffer has run (an event of its own behind the consumer, two ticks old by then:

@@ -22,6 +22,9 @@ extern "C" void mock_set_device_count(int n) { g_devices = n; }
 extern "C" {
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = reinterpret_cast<hipStream_t>(std::malloc(8)); return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = reinterpret_cast<hipStream_t>(std::malloc(8)); return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
@@ -47,6 +50,7 @@ struct wf_hip {
     uint32_t ticks = 0;
     std::vector<uint8_t> hidden;
     float *mirror[2] = {nullptr, nullptr}; // wf_hip_set_bars_mirror: every tick also writes its bars there, alternately
+    std::vector<std::vector<float *>> mirrors; // wf_hip_set_bars_mirrors: all buffers of the two sets
     uint32_t mirror_next = 0;
     float *mirror_last = nullptr;
     std::string err;
@@ -102,6 +106,9 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *)
     if(h->mirror[0]) {
         h->mirror_last = h->mirror[h->mirror_next];
         fill_bars(h, 0, h->streams, h->mirror_last);
+        if(!h->mirrors.empty())
+            for(float *p : h->mirrors[h->mirror_next])
+                fill_bars(h, 0, h->streams, p);
         h->mirror_next ^= 1u;
     }
     return WF_HIP_OK;
@@ -110,8 +117,24 @@ int wf_hip_set_bars_mirror(wf_hip *h, void *a, void *b)
 {
     if(getenv("WF_MOCK_NO_MIRROR"))
         return WF_HIP_ERR_UNSUPPORTED;
+    h->mirrors.clear();
     h->mirror[0] = static_cast<float *>(a);
     h->mirror[1] = static_cast<float *>(b);
+    h->mirror_next = 0;
+    h->mirror_last = nullptr;
+    return WF_HIP_OK;
+}
+int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *a, void *const *b)
+{
+    if(getenv("WF_MOCK_NO_MIRROR"))
+        return WF_HIP_ERR_UNSUPPORTED;
+    h->mirrors.assign(2, std::vector<float *>());
+    for(uint32_t j = 0; j < n; ++j) {
+        h->mirrors[0].push_back(static_cast<float *>(a[j]));
+        h->mirrors[1].push_back(static_cast<float *>(b[j]));
+    }
+    h->mirror[0] = n ? h->mirrors[0][0] : nullptr;
+    h->mirror[1] = n ? h->mirrors[1][0] : nullptr;
     h->mirror_next = 0;
     h->mirror_last = nullptr;
     return WF_HIP_OK;

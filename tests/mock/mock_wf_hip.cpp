@@ -122,6 +122,7 @@ int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *
 }
 uint32_t wf_hip_ring_frames(const wf_hip *) { return 1u << 20; }
 int wf_hip_set_bars_mirror(wf_hip *, void *, void *) { return WF_HIP_ERR_UNSUPPORTED; }
+int wf_hip_set_bars_mirrors(wf_hip *, uint32_t, void *const *, void *const *) { return WF_HIP_ERR_UNSUPPORTED; }
 int wf_hip_bars_mirror_ready(wf_hip *, void *, void **) { return WF_HIP_ERR_INVALID; }
 int wf_hip_read_waveform_ts(wf_hip *, uint32_t, uint32_t count, uint64_t *out)
 {

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """tools/node_check.py -- first thing to run on a multi-GPU node nobody could rehearse on: enumerates the
 devices and the links between them, runs BASELINE configs[4]'s shape through the C ABI's multi-device group (wf_hip_multi_*) over
-every device -- first with the default transport (ncclAllGather of the dlopen()ed librccl.so where the devices are distinct),
-then with the peer copies forced -- and prints ONE JSON object: per-device tick times with and without the gather, the gather's
-own time on its side stream, the link type / hop count of every device pair, and whether every device's gathered copy equals
-the shards' own bars.  Exit code 0 only if everything verified; otherwise one line on stderr says which transport and which
+every device, one leg per process -- the default transport (ncclAllGather of the dlopen()ed librccl.so where the devices are
+distinct); RCCL with its channel count capped at one and at two (how many CUs the collective's kernels take from a tick that
+fills them in whole rounds); RCCL with the gather stream on a hardware queue of its own; the peer transport with the tick
+kernels storing their slice into every device's result (no kernel, no copy in the exchange) and with copies behind the tick --
+and prints ONE JSON object: per-device tick times with and without the gather and their difference per leg, the gather's own
+time, the link type / hop count of every device pair, and whether every device's gathered copy equals the shards' own bars.  Exit code 0 only if everything verified; otherwise one line on stderr says which transport and which
 device failed.
 
     python tools/node_check.py [--devices N] [--streams-per-device 8192] [--ticks 200]
@@ -82,11 +84,23 @@ def run(wf, np, devices, transport, streams_per_device, ticks):
             os.environ["WF_HIP_MULTI_TRANSPORT"] = old
 
 
+LEGS = [
+    # (name, transport asked for, extra environment): every leg in a process of its own -- RCCL reads its environment once
+    ("default", None, {}),
+    ("rccl, one channel", "rccl", {"NCCL_MAX_NCHANNELS": "1"}),
+    ("rccl, two channels", "rccl", {"NCCL_MAX_NCHANNELS": "2"}),
+    ("rccl, gather stream on a hardware queue of its own", "rccl", {"WF_HIP_MULTI_GATHER_PRIORITY": "high"}),
+    ("peer, the tick kernels store into every device's result", "peer", {}),
+    ("peer, copies behind the tick", "peer", {"WF_HIP_MULTI_MIRROR": "send"}),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--devices", type=int, default=0, help="0: every visible device")
     ap.add_argument("--streams-per-device", type=int, default=8192)
     ap.add_argument("--ticks", type=int, default=200)
+    ap.add_argument("--leg", type=int, default=-1, help="(internal) run one leg of LEGS in this process and print its object")
     args = ap.parse_args()
     import numpy as np
     import waveform_amd as wf
@@ -96,18 +110,37 @@ def main():
         print("node_check: no usable gfx950 device", file=sys.stderr)
         return 3
     devices = list(range(n))
-    runs = [run(wf, np, devices, None, args.streams_per_device, args.ticks)]
-    if n > 1:
-        runs.append(run(wf, np, devices, "peer", args.streams_per_device, args.ticks))
-    else:  # one device: the peer path with two shards on it (the shard arithmetic, the threads, the double buffering)
-        runs.append(run(wf, np, [0, 0], "peer", args.streams_per_device // 2, args.ticks))
+    if args.leg >= 0:
+        name, transport, _ = LEGS[args.leg]
+        if n == 1 and transport == "peer":  # one device: the peer path with two shards on it (the shard arithmetic, the threads, the double buffering)
+            r = run(wf, np, [0, 0], "peer", args.streams_per_device // 2, args.ticks)
+        else:
+            r = run(wf, np, devices, transport, args.streams_per_device, args.ticks)
+        r["leg"] = name
+        print(json.dumps(r), flush=True)
+        return 0
+    import subprocess
+    runs = []
+    for i, (name, transport, env) in enumerate(LEGS):
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", str(i), "--devices", str(n), "--streams-per-device", str(args.streams_per_device),
+               "--ticks", str(args.ticks)]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+            lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+            r = json.loads(lines[-1]) if lines else {"leg": name, "error": f"rc {p.returncode}: {p.stderr.strip()[-300:]}", "verified": False}
+        except subprocess.TimeoutExpired:
+            r = {"leg": name, "error": "timed out after 300 s (a collective nobody answered?)", "verified": False}
+        r["environment"] = env
+        if "ms_per_tick_with_gather" in r and "ms_per_tick_without_gather" in r:
+            r["gather_costs_per_tick_us"] = round((r["ms_per_tick_with_gather"]["max"] - r["ms_per_tick_without_gather"]["max"]) * 1e3, 2)
+        runs.append(r)
     out = {"devices_visible": have, "devices_used": n, "links": links(n), "runs": runs}
     print(json.dumps(out), flush=True)
     rc = 0
     for r in runs:
         if not r.get("verified"):
             rc = 1
-            print(f"node_check: transport {r.get('transport', r['transport_asked'])} over devices {r['devices']}: "
+            print(f"node_check: leg '{r.get('leg')}' (transport {r.get('transport', r.get('transport_asked'))}) over devices {r.get('devices')}: "
                   + (r.get("error") or f"device indices {r.get('devices_with_a_wrong_copy')} hold a gathered copy that differs from the shards' bars"), file=sys.stderr)
     return rc
 

@@ -95,7 +95,9 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.entries = (int)h->tab.bar_coef.size();
         a.bar.lanes_per_bar = h->bar_lpb;
         a.bar.out = h->d_bars;
-        a.bar.out2_delta = h->bars_mirror[0] ? (long long)(h->bars_mirror[h->mirror_next] - h->d_bars) : 0;
+        a.bar.out2_n = (int)h->mirror_n;
+        for(uint32_t j = 0; j < h->mirror_n; ++j)
+            a.bar.out2_delta[j] = (long long)(h->bars_mirror[h->mirror_next][j] - h->d_bars);
         a.bar.num_bars = (int)h->num_bars;
         a.bar.mirror = h->cfg.mirror_freq_axis ? 1 : 0;
         a.bar.border_top = h->tab.border_top;
@@ -873,8 +875,8 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
     }
     if(h->split)
         h->flag_cur = (h->flag_cur + 1) % 3; // what the kernel wrote is what the next tick (and the readers) see
-    if(h->bars_mirror[0]) {
-        h->mirror_last = h->bars_mirror[h->mirror_next];
+    if(h->mirror_n) {
+        h->mirror_last = h->bars_mirror[h->mirror_next][0];
         h->mirror_next ^= 1u;
     }
     return WF_HIP_OK;
@@ -1458,32 +1460,45 @@ int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, voi
     return WF_HIP_OK;
 }
 
+int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *d_out0, void *const *d_out1)
+{
+    if(h == nullptr)
+        return WF_HIP_ERR_INVALID;
+    if(n > 8 || (n > 0 && (d_out0 == nullptr || d_out1 == nullptr)))
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirrors: at most 8 buffers per set, both sets given");
+    if(n > 0) {
+        if(h->d_bars == nullptr || h->meter || h->wave)
+            return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0 and cfg.curve == 0, or a level-meter / waveform batch)");
+        if(h->ext_outputs || h->big_l != 0 || h->blu)
+            return fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: only the power-of-two sizes up to 32768 whose display the tick kernel finishes itself write further bars buffers; copy the bars with wf_hip_copy_bars_device_async", h->N);
+        for(uint32_t j = 0; j < n; ++j)
+            if(d_out0[j] == nullptr || d_out1[j] == nullptr || d_out0[j] == d_out1[j] || d_out0[j] == (void *)h->d_bars || d_out1[j] == (void *)h->d_bars)
+                return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirrors: buffer %u of a set is NULL, the same in both sets or the handle's own", j);
+    }
+    for(uint32_t j = 0; j < 8; ++j) {
+        h->bars_mirror[0][j] = j < n ? static_cast<float *>(d_out0[j]) : nullptr;
+        h->bars_mirror[1][j] = j < n ? static_cast<float *>(d_out1[j]) : nullptr;
+    }
+    h->mirror_n = n;
+    h->mirror_next = 0;
+    h->mirror_last = nullptr;
+    return WF_HIP_OK;
+}
+
 int wf_hip_set_bars_mirror(wf_hip *h, void *d_out0, void *d_out1)
 {
     if(h == nullptr)
         return WF_HIP_ERR_INVALID;
-    if((d_out0 == nullptr) != (d_out1 == nullptr) || (d_out0 != nullptr && d_out0 == d_out1))
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirror: two different buffers, or NULL and NULL");
-    if(d_out0 != nullptr) {
-        if(h->d_bars == nullptr || h->meter || h->wave)
-            return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0 and cfg.curve == 0, or a level-meter / waveform batch)");
-        if(h->ext_outputs || h->big_l != 0 || h->blu)
-            return fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: only the power-of-two sizes up to 32768 whose display the tick kernel finishes itself write a second bars buffer; copy the bars with wf_hip_copy_bars_device_async", h->N);
-        if(d_out0 == (void *)h->d_bars || d_out1 == (void *)h->d_bars)
-            return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirror: the handle's own buffer");
-    }
-    h->bars_mirror[0] = static_cast<float *>(d_out0);
-    h->bars_mirror[1] = static_cast<float *>(d_out1);
-    h->mirror_next = 0;
-    h->mirror_last = nullptr;
-    return WF_HIP_OK;
+    if((d_out0 == nullptr) != (d_out1 == nullptr))
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirror: two buffers, or NULL and NULL");
+    return wf_hip_set_bars_mirrors(h, d_out0 ? 1u : 0u, &d_out0, &d_out1);
 }
 
 int wf_hip_bars_mirror_ready(wf_hip *h, void *consumer_stream, void **d_out)
 {
     if(h == nullptr || d_out == nullptr)
         return WF_HIP_ERR_INVALID;
-    if(h->bars_mirror[0] == nullptr)
+    if(h->mirror_n == 0)
         return fail(h, WF_HIP_ERR_INVALID, "no mirror buffers set (wf_hip_set_bars_mirror)");
     if(consumer_stream == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "consumer stream is NULL");

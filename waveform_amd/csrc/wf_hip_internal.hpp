@@ -96,8 +96,10 @@ struct wf_hip {
     int *d_big_task = nullptr, *d_big_bar_task = nullptr; // BarArgs::big_task / big_bar_task
     int big_num_tasks = 0;
     float *d_bars = nullptr;
-    // wf_hip_set_bars_mirror: the two caller-owned buffers the ticks also write their bars into, alternately
-    float *bars_mirror[2] = {nullptr, nullptr};
+    // wf_hip_set_bars_mirror(s): the caller-owned buffers the ticks also write their bars into -- mirror_n of them per tick, the
+    // two sets alternately
+    float *bars_mirror[2][8] = {};
+    uint32_t mirror_n = 0;
     uint32_t mirror_next = 0;       // the buffer the next tick writes
     float *mirror_last = nullptr;   // the buffer the newest tick wrote
     wf::VertexTables vtab;           // cfg.vertices: the vertex fill behind every tick

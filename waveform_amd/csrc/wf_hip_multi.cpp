@@ -150,6 +150,7 @@ struct Shard {
     // zero-copy gathers (wf_hip_set_bars_mirror): the handle's tick kernel writes its bars into the slot's send buffer itself
     // (LOCAL: into the result), alternating with the ticks -- the slot of a gather is then the buffer the newest tick wrote
     bool mirror = false;
+    bool direct = false; // peer transport with peer access everywhere: the tick kernel stores this shard's slice into every device's result itself
     uint32_t cur_slot = 0; // the slot of the gather in flight / issued last on this shard
     ncclComm_t comm = nullptr;
     Worker worker;
@@ -265,11 +266,25 @@ int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
         if(rc)
             return rc;
         float *const *tgt = (m->transport == Transport::LOCAL) ? s.gathered : s.send;
+        float *direct_tgt[2] = {nullptr, nullptr};
+        if(s.direct) { // buffer 0 of a set: this shard's slice of device 0's result
+            direct_tgt[0] = m->shard[0]->gathered[0] + (size_t)s.first * m->per;
+            direct_tgt[1] = m->shard[0]->gathered[1] + (size_t)s.first * m->per;
+            tgt = direct_tgt;
+        }
         if(buf == nullptr) { // no tick since the mirror was set: the handle's own buffer is the only copy
             k = 0;
-            rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, tgt[0], s.gstream);
-            if(rc)
-                return rc;
+            if(s.direct) {
+                for(uint32_t j = 0; j < m->n; ++j) {
+                    rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, m->shard[j]->gathered[0] + (size_t)s.first * m->per, s.gstream);
+                    if(rc)
+                        return rc;
+                }
+            } else {
+                rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, tgt[0], s.gstream);
+                if(rc)
+                    return rc;
+            }
         } else
             k = buf == (void *)tgt[1] ? 1u : 0u;
     } else {
@@ -303,7 +318,7 @@ int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
         break;
     }
     case Transport::PEER:
-        for(uint32_t j = 0; j < m->n; ++j) {
+        for(uint32_t j = 0; j < m->n && !s.direct; ++j) { // (direct: the tick kernel has stored the slice everywhere already)
             Shard &o = *m->shard[j];
             WF_MHIP(s, hipMemcpyPeerAsync(o.gathered[k] + (size_t)s.first * per, o.device, s.send[k], s.device,
                                           (size_t)s.count * per * sizeof(float), s.gstream));
@@ -525,7 +540,21 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
     if(m->per != 0) {
         rc = run_all(m, [m](uint32_t i) {
             Shard &s = *m->shard[i];
-            WF_MHIP(s, hipStreamCreateWithFlags(&s.gstream, hipStreamNonBlocking));
+            // HIP multiplexes a process's streams of one priority onto four hardware queues per device, which a handle's lanes fill: a
+            // gather stream that shares an in-order hardware queue with a lane puts that lane's next tick behind whatever the exchange
+            // of the last one enqueued (two shards on one device, peer copies: +36 us per tick), and one with a queue of its own
+            // (another priority) runs its kernels INTO the tick, which fills the CUs in whole rounds (+77 us; both traced:
+            // profiles/r05h_peer_trace*.txt).  The exchange therefore enqueues no kernel where it can avoid it (mirrors above); RCCL's
+            // own kernels remain -- WF_HIP_MULTI_GATHER_PRIORITY=high lets a node check try them on a queue of their own.
+            {
+                const char *pe = std::getenv("WF_HIP_MULTI_GATHER_PRIORITY");
+                if(pe && std::strcmp(pe, "high") == 0) {
+                    int least = 0, greatest = 0;
+                    WF_MHIP(s, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    WF_MHIP(s, hipStreamCreateWithPriority(&s.gstream, hipStreamNonBlocking, greatest));
+                } else
+                    WF_MHIP(s, hipStreamCreateWithFlags(&s.gstream, hipStreamNonBlocking));
+            }
             const size_t per = m->per;
             for(int k = 0; k < 2; ++k) {
                 WF_MHIP(s, hipEventCreateWithFlags(&s.ev_sent[k], hipEventDisableTiming));
@@ -538,19 +567,6 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
                 if(m->transport == Transport::RCCL && m->ragged)
                     WF_MHIP(s, hipMalloc((void **)&s.recv_pad[k], (size_t)m->n * m->largest * per * sizeof(float)));
             }
-            // zero-copy gathers: the tick kernel writes the slot's send buffer (LOCAL: the result) itself; the batches whose display
-            // comes from a kernel of its own keep the copy behind the tick (WF_HIP_MULTI_MIRROR=0: the copy for everybody, A/B aid)
-            {
-                const char *e = std::getenv("WF_HIP_MULTI_MIRROR");
-                float *const *tgt = (m->transport == Transport::LOCAL) ? s.gathered : s.send;
-                const int mrc = (e && e[0] == '0') ? (int)WF_HIP_ERR_UNSUPPORTED : wf_hip_set_bars_mirror(s.h, tgt[0], tgt[1]);
-                if(mrc == WF_HIP_OK)
-                    s.mirror = true;
-                else if(mrc != WF_HIP_ERR_UNSUPPORTED) {
-                    s.err = wf_hip_last_error(s.h);
-                    return mrc;
-                }
-            }
             if(m->transport == Transport::PEER) // direct xGMI stores where the link allows; hipMemcpyPeerAsync stages otherwise
                 for(uint32_t j = 0; j < m->n; ++j) {
                     const int other = m->shard[j]->device;
@@ -562,6 +578,47 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
                 }
             return (int)WF_HIP_OK;
         });
+        // zero-copy gathers, once every device's buffers exist: the tick kernel writes the slot's send buffer (LOCAL: the result)
+        // itself -- or, peer transport on devices that can all address each other, this shard's slice of EVERY device's result:
+        // no copy, no kernel on the gather streams at all.  The batches whose display comes from a kernel of its own keep the copy
+        // behind the tick (WF_HIP_MULTI_MIRROR=0: the copy for everybody, =send: no direct peer stores; A/B aids)
+        if(rc == WF_HIP_OK) {
+            const char *e = std::getenv("WF_HIP_MULTI_MIRROR");
+            bool all_peer = m->transport == Transport::PEER && m->n <= 8 && !(e && std::strcmp(e, "send") == 0);
+            for(uint32_t i = 0; i < m->n && all_peer; ++i)
+                for(uint32_t j = 0; j < m->n && all_peer; ++j) {
+                    const int a = m->shard[i]->device, b = m->shard[j]->device;
+                    int can = a == b ? 1 : 0;
+                    if(a != b && (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can))
+                        all_peer = false;
+                }
+            (void)hipGetLastError();
+            rc = run_all(m, [m, e, all_peer](uint32_t i) {
+                Shard &s = *m->shard[i];
+                if(e && e[0] == '0')
+                    return (int)WF_HIP_OK;
+                int mrc;
+                if(all_peer) {
+                    void *set0[8], *set1[8];
+                    for(uint32_t j = 0; j < m->n; ++j) {
+                        set0[j] = m->shard[j]->gathered[0] + (size_t)s.first * m->per;
+                        set1[j] = m->shard[j]->gathered[1] + (size_t)s.first * m->per;
+                    }
+                    mrc = wf_hip_set_bars_mirrors(s.h, m->n, set0, set1);
+                } else {
+                    float *const *tgt = (m->transport == Transport::LOCAL) ? s.gathered : s.send;
+                    mrc = wf_hip_set_bars_mirror(s.h, tgt[0], tgt[1]);
+                }
+                if(mrc == WF_HIP_OK) {
+                    s.mirror = true;
+                    s.direct = all_peer;
+                } else if(mrc != WF_HIP_ERR_UNSUPPORTED) {
+                    s.err = wf_hip_last_error(s.h);
+                    return mrc;
+                }
+                return (int)WF_HIP_OK;
+            });
+        }
         if(rc) {
             g_multi_create_error = m->last_error;
             destroy_impl(m);

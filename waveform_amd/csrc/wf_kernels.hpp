@@ -526,8 +526,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 for(int i = t; i < a.bar.num_bars * (dup ? 2 : 1); i += T) {
                     bo[i] = a.bar.border_bottom;
                     if constexpr(!BLU) // (the Bluestein / mixed-radix instantiations, at their register caps, do not serve wf_hip_set_bars_mirror)
-                        if(a.bar.out2_delta != 0)
-                            bo[(long long)i + a.bar.out2_delta] = a.bar.border_bottom;
+                        for(int j = 0; j < a.bar.out2_n; ++j)
+                            bo[(long long)i + a.bar.out2_delta[j]] = a.bar.border_bottom;
                 }
             }
         }
@@ -668,15 +668,18 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
 #ifndef WF_TAIL_PRIO
 #define WF_TAIL_PRIO 0
 #endif
-    // the second bars buffer (BarArgs::out2_delta) of a spectrum whose displayed row(s) this tick leaves as they are: copied over
-    if(!BLU && a.bar.out != nullptr && a.bar.out2_delta != 0 && active && ch < a.bar.disp_ch) {
+    // the further bars buffers (BarArgs::out2_delta) of a spectrum whose displayed row(s) this tick leaves as they are: copied over
+    if(!BLU && a.bar.out != nullptr && a.bar.out2_n > 0 && active && ch < a.bar.disp_ch) {
         const bool have_row_ = do_db && !(mono_mix && ch == 1);
         const bool reset_ = hidden && !was_silent && ch < (stereo ? 2u : 1u);
         if(!have_row_ && !reset_) { // (uniform over the spectrum)
             const float *bo = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
             const int n = a.bar.num_bars * ((a.out_ch > a.cap_ch) ? 2 : 1);
-            for(int i = t; i < n; i += T)
-                const_cast<float *>(bo)[(long long)i + a.bar.out2_delta] = bo[i];
+            for(int i = t; i < n; i += T) {
+                const float v = bo[i];
+                for(int j = 0; j < a.bar.out2_n; ++j)
+                    const_cast<float *>(bo)[(long long)i + a.bar.out2_delta[j]] = v;
+            }
         }
     }
     if(a.bar.out != nullptr && !WF_EXP_NO_TAIL) {
@@ -787,8 +790,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         WF_STAMP(12);
 #else
         // (the Bluestein / mixed-radix instantiations do not serve wf_hip_set_bars_mirror -- the host refuses it for their sizes --:
-        // with the offset a constant 0 the second stores fold away; the 96-register instantiation spilled on them)
-        const BarArgs bar_blu = [&] { BarArgs b = a.bar; if(BLU) b.out2_delta = 0; return b; }();
+        // with the count a constant 0 the further stores fold away; the 96-register instantiation spilled on them)
+        const BarArgs bar_blu = [&] { BarArgs b = a.bar; if(BLU) b.out2_n = 0; return b; }();
         const BarArgs &bar_args = BLU ? bar_blu : a.bar;
 #endif
         OutVals<G> ov;

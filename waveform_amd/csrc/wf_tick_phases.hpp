@@ -112,10 +112,12 @@ struct BarArgs {
     unsigned long long *clk;   // development aid: this workgroup's stamp slots
 #endif
     float *out;                // [n_streams][disp_ch][num_bars]
-    // != 0 (wf_hip_set_bars_mirror): every tick also leaves the batch's bars -- the ones it finishes and, copied over, the ones it
-    // does not touch (paused, hidden or silent streams) -- in a second buffer of the same shape that starts out2_delta floats
-    // behind `out`: the send buffer of the all-gather of BASELINE configs[4], written by the kernel instead of a copy behind it
-    long long out2_delta;
+    // > 0 (wf_hip_set_bars_mirror / _mirrors): every tick also leaves the batch's bars -- the ones it finishes and, copied over, the
+    // ones it does not touch (paused, hidden or silent streams) -- in out2_n more buffers of the same shape, buffer j starting
+    // out2_delta[j] floats behind `out`: the send buffer of the all-gather of BASELINE configs[4] (or, with peer access, this shard's
+    // slice of every device's gathered result) written by the kernel instead of by copies behind it
+    int out2_n;
+    long long out2_delta[8];
     int num_bars;
     int num_chunks;
     int entries;               // total number of entries (= off[num_bars])
@@ -1642,8 +1644,8 @@ WF_DEV float map_output(const BarArgs &b, float v)
 WF_DEV void put_output(const BarArgs &b, float *row, int o, float y)
 {
     row[o] = y;
-    if(b.out2_delta != 0) // uniform
-        row[(long long)o + b.out2_delta] = y;
+    for(int j = 0; j < b.out2_n; ++j) // uniform
+        row[(long long)o + b.out2_delta[j]] = y;
 }
 WF_DEV void store_output(const BarArgs &b, int o, float y, float *out_row, float *dup_row)
 {

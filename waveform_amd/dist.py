@@ -106,7 +106,10 @@ class BarsGather:
         self.send = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(2)]
         self.result = [None, None]
         self.done = [None, None]
-        self.side = torch.cuda.Stream()
+        # (WF_BARS_GATHER_PRIORITY=high: the collective on a hardware queue of its own instead of one shared with a lane of the handle --
+        # for the first run on a real node to try; see the note at the gather streams of wf_hip_multi.cpp)
+        import os
+        self.side = torch.cuda.Stream(priority=-1) if os.environ.get("WF_BARS_GATHER_PRIORITY") == "high" else torch.cuda.Stream()
         self.i = 0
         self.newest = None
         try:
