@@ -342,8 +342,11 @@ int gather_complete(wf_hip_multi *m, uint32_t i, uint32_t k)
                 WF_MHIP(s, hipStreamWaitEvent(s.gstream, m->shard[j]->ev_sent[k], 0));
     WF_MHIP(s, hipEventRecord(s.ev_done[k], s.gstream));
     s.slot_used[k] = true;
-    if(s.mirror && s.slot_used[k ^ 1u]) // the next tick writes the other slot's buffer: the gather that read it, a tick old, must have run
-        WF_MHIP(s, hipEventSynchronize(s.ev_done[k ^ 1u])); // (returns at once; a device-side wait in front of every tick cost 4 % of the tick rate)
+    // The next tick writes the other slot's buffer.  Where that is a SEND buffer (RCCL; peer copies), the exchange that read it -- a tick
+    // old -- must have run: a host wait that returns at once (a device-side wait in front of every tick cost 4 % of the tick rate).
+    // Where the kernels store into the results themselves (local, direct peer stores) nothing inside the group reads the buffer.
+    if(s.mirror && !s.direct && m->transport != Transport::LOCAL && s.slot_used[k ^ 1u])
+        WF_MHIP(s, hipEventSynchronize(s.ev_done[k ^ 1u]));
     return WF_HIP_OK;
 }
 
