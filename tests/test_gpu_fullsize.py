@@ -44,6 +44,31 @@ def _oracle_ticks(cfg, stream_ids, ticks, hop, keep, bars=False):
     return np.stack(rows), (np.stack(bar_rows) if bars else None)
 
 
+def _reference_ticks(cfg, stream_ids, ticks, hop, keep, bars=False):
+    """the same, played through the REFERENCE ITSELF -- oracle/_ref/libwfref.so: the reference's own translation units and FFTW,
+    its generic class, update() / capture_audio / tick / render_bars -- instead of the C restatement: [stream][tick][...]"""
+    import scenarios
+    from oracle import wfref
+    if not wfref.available():
+        pytest.skip("oracle/_ref/libwfref.so not built")
+    rows, bar_rows = [], []
+    for s in stream_ids:
+        be = scenarios.RefBackend(cfg, isa="generic")
+        r, br = [], []
+        for t in range(ticks):
+            be.push(synth.block(SEED, s, 1, cfg.capture_channels, t * hop, hop)[0], muted=False)
+            be.tick(1.0 / 60.0)
+            if t >= ticks - keep:
+                rec = be.observe()
+                r.append(rec["db"])
+                if bars:
+                    br.append(rec["bars"])
+        rows.append(np.stack(r))
+        if bars:
+            bar_rows.append(np.stack(br))
+    return np.stack(rows), (np.stack(bar_rows) if bars else None)
+
+
 # cfg3's checked streams: the first and last 32 of the batch (SURVEY.md section 8(d)), the 32 around the boundary between the
 # two concurrent launches wf_hip_tick issues ("lanes": streams [0, 2048) and [2048, 4096)), and one block in the middle of each
 CFG3_BLOCKS = ((0, 32), (1008, 32), (2032, 32), (3056, 32), (4064, 32))
@@ -76,6 +101,11 @@ def test_cfg3_full_batch_spot_checks_and_determinism():
     for k in range(checked):
         assert_db_close(res[0][0][:, k], want[:, k], f"cfg3 full batch vs oracle, tick {warm + k} (first/last 32 streams, lane boundary, mid-lane)", deep=True)
     assert np.all(np.isfinite(res[0][1]))
+    # one block -- the 32 streams across the lane boundary -- against the reference itself (libwfref.so, generic class), not its restatement
+    blk = [i for i, sid in enumerate(ids) if 2032 <= sid < 2064]
+    ref, _ = _reference_ticks(cfg, [ids[i] for i in blk], ticks, hop, checked)
+    for k in range(checked):
+        assert_db_close(res[0][0][blk, k], ref[:, k], f"cfg3 full batch vs libwfref.so, tick {warm + k} (streams 2032-2063)", deep=True)
 
 
 def test_cfg3_whole_batch_equals_small_handles():
@@ -217,6 +247,11 @@ def test_cfg5_full_size_65536_streams_in_eight_shards():
     _, want = _oracle_ticks(cfg, ids, ticks, hop, checked, bars=True)
     err = np.abs(got.astype(np.float64) - want)
     assert np.all(err <= 1e-5 * np.abs(want) + 2e-3), f"cfg5 full size, bars of the first / last 32 streams of every shard: max err {err.max():.3e} px"
+    # the first 32 streams of the LAST shard against the reference itself (libwfref.so, generic class)
+    at = ids.index((shards - 1) * per)
+    _, refb = _reference_ticks(cfg, ids[at:at + 32], ticks, hop, checked, bars=True)
+    err = np.abs(got[at:at + 32].astype(np.float64) - refb)
+    assert np.all(err <= 1e-5 * np.abs(refb) + 2e-3), f"cfg5 full size vs libwfref.so, streams {ids[at]}..{ids[at + 31]}: max err {err.max():.3e} px"
 
 
 def test_bars_gather_world1_and_self_launching_bench():
@@ -333,6 +368,12 @@ def test_cfg4_full_batch_bars():
         assert_db_close(res[0][0][:, k], want[:, k], f"cfg4 full batch rows vs oracle, tick {warm + k} (first/last 32 streams)", deep=True)
         err = np.abs(res[0][1][:, k].astype(np.float64) - wantb[:, k])
         assert np.all(err <= 1e-5 * np.abs(wantb[:, k]) + 2e-3), f"cfg4 bars, tick {warm + k}: max err {err.max():.3e} px"
+    # the last 32 streams of the batch against the reference itself (libwfref.so, generic class), rows and bars
+    ref, refb = _reference_ticks(cfg, ids[32:], ticks, hop, checked, bars=True)
+    for k in range(checked):
+        assert_db_close(res[0][0][32:, k], ref[:, k], f"cfg4 full batch rows vs libwfref.so, tick {warm + k} (last 32 streams)", deep=True)
+        err = np.abs(res[0][1][32:, k].astype(np.float64) - refb[:, k])
+        assert np.all(err <= 1e-5 * np.abs(refb[:, k]) + 2e-3), f"cfg4 bars vs libwfref.so, tick {warm + k}: max err {err.max():.3e} px"
 
 
 def test_bars_only_mode_matches_full_mode():

@@ -526,8 +526,10 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 for(int i = t; i < a.bar.num_bars * (dup ? 2 : 1); i += T) {
                     bo[i] = a.bar.border_bottom;
                     if constexpr(!BLU) // (the Bluestein / mixed-radix instantiations, at their register caps, do not serve wf_hip_set_bars_mirror)
-                        for(int j = 0; j < a.bar.out2_n; ++j)
-                            bo[(long long)i + a.bar.out2_delta[j]] = a.bar.border_bottom;
+#pragma unroll
+                        for(int j = 0; j < 8; ++j)
+                            if(j < a.bar.out2_n)
+                                bo[(long long)i + a.bar.out2_delta[j]] = a.bar.border_bottom;
                 }
             }
         }
@@ -677,8 +679,10 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             const int n = a.bar.num_bars * ((a.out_ch > a.cap_ch) ? 2 : 1);
             for(int i = t; i < n; i += T) {
                 const float v = bo[i];
-                for(int j = 0; j < a.bar.out2_n; ++j)
-                    const_cast<float *>(bo)[(long long)i + a.bar.out2_delta[j]] = v;
+#pragma unroll
+                for(int j = 0; j < 8; ++j)
+                    if(j < a.bar.out2_n)
+                        const_cast<float *>(bo)[(long long)i + a.bar.out2_delta[j]] = v;
             }
         }
     }

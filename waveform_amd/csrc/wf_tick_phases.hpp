@@ -316,6 +316,21 @@ WF_DEV float meter_ema(float g, float old, float g2, float cur)
     return x + y;
 }
 
+// The spectrum's temporal smoothing, mag = g * old + (1 - g) * mag (reference src/source_generic.cpp:124-132).  WF_EMA_GENERIC = 1: the
+// generic class's three roundings (two products, one sum); 0: fma(g, old, g2 * mag), two roundings, as the reference's own AVX2 class
+// contracts it (src/source_avx2.cpp:154)
+#ifndef WF_EMA_GENERIC
+#define WF_EMA_GENERIC 1
+#endif
+WF_DEV float spectrum_ema(float g, float old, float g2, float cur)
+{
+#if WF_EMA_GENERIC
+    return meter_ema(g, old, g2, cur);
+#else
+    return fmaf(g, old, g2 * cur);
+#endif
+}
+
 // ordering point between LDS operations of one wavefront (they execute in program order: a scheduling fence suffices)
 #if defined(__HIPCC__)
 WF_DEV void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); } // vmcnt(0), the other counters untouched (gfx9 encoding)
@@ -881,7 +896,7 @@ WF_DEV void p4_split_blu_impl(const TickArgs &a, int t, const cf *lds, float *ts
                     float old = st4v[i];
                     if(FPK)
                         old = fmaxf(m, old);
-                    m = fmaf(a.g, old, a.g2 * m);
+                    m = spectrum_ema(a.g, old, a.g2, m);
                 }
                 mag[4 * u + i] = m;
             }
@@ -945,7 +960,7 @@ WF_DEV void p4_split_mr_impl(const TickArgs &a, int t, const cf *lds, float *ts,
                     float old = st4v[i];
                     if(FPK)
                         old = fmaxf(m, old);
-                    m = fmaf(a.g, old, a.g2 * m);
+                    m = spectrum_ema(a.g, old, a.g2, m);
                 }
                 mag[4 * u + i] = m;
             }
@@ -1177,7 +1192,7 @@ WF_DEV void p4_slope_smooth_group(const TickArgs &a, int t, int u, float *ts, co
                 old = fmaxf(mag[4 * u + i], old);
             // (g * oldval) + (g2 * mag) (reference :130); evaluated as fma(g, old, g2*mag) like the reference's own
             // AVX2 path (src/source_avx2.cpp:154) -- within 1 ulp of the generic path's separately rounded sum
-            mag[4 * u + i] = fmaf(a.g, old, a.g2 * mag[4 * u + i]);
+            mag[4 * u + i] = spectrum_ema(a.g, old, a.g2, mag[4 * u + i]);
         }
         if(!DEFER)
             st_state(ts + k0, f4{mag[4 * u], mag[4 * u + 1], mag[4 * u + 2], mag[4 * u + 3]});
@@ -1354,7 +1369,7 @@ WF_DEV f4 p4_split_smooth_dec_impl(const TickArgs &a, int t, const cf *lds, floa
             float old = q.st[i];
             if(FPK)
                 old = fmaxf(m, old);
-            m = fmaf(a.g, old, a.g2 * m);
+            m = spectrum_ema(a.g, old, a.g2, m);
         }
         mag[i] = m;
     }
@@ -1644,8 +1659,10 @@ WF_DEV float map_output(const BarArgs &b, float v)
 WF_DEV void put_output(const BarArgs &b, float *row, int o, float y)
 {
     row[o] = y;
-    for(int j = 0; j < b.out2_n; ++j) // uniform
-        row[(long long)o + b.out2_delta[j]] = y;
+    WF_UNROLL
+    for(int j = 0; j < 8; ++j) // (constant indices: indexed by a run-time j the kernel's argument block went to scratch, 784 B per lane)
+        if(j < b.out2_n) // uniform
+            row[(long long)o + b.out2_delta[j]] = y;
 }
 WF_DEV void store_output(const BarArgs &b, int o, float y, float *out_row, float *dup_row)
 {
