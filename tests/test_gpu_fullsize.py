@@ -306,6 +306,34 @@ def test_bench_multi_rank_path_with_the_collective():
     assert "all_gather" in c4["collective"]
 
 
+def test_roctx_ranges_are_opt_in_and_change_nothing():
+    """WF_HIP_ROCTX=1: wf_hip_tick pushes / pops a roctx range around itself, resolved at run time from the profiler's marker library
+    ("Tracing"); the rows are the same bits, and without a marker library on the box the tick simply runs"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r)
+import waveform_amd as wf
+from tools import synth
+cfg = wf.Config.defaults(fft_size=2048, stereo=1, slope=1.0, bars=1, interp_mode=wf.INTERP["lanczos"])
+with wf.SpectrumBatch(cfg, 16) as b:
+    for t in range(4):
+        b.push_synth(synth.DEFAULT_SEED, t * 800, 800)
+        b.tick()
+    print("rows", hashlib.sha256(b.decibels().tobytes() + b.bars().tobytes()).hexdigest())
+''' % str(root)
+    import os
+    outs = []
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, WF_HIP_ROCTX=v))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("rows")][-1])
+    assert outs[0] == outs[1]
+
+
 def test_cfg3_gain_invariance_full_batch():
     """linearity of the path up to the dB stage: doubling every sample adds exactly 20*log10(2) dB
     (float scaling by 2 is exact through window, FFT, |X|, slope and the EMA)."""

@@ -11,9 +11,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
+export WF_HIP_ROCTX=1   # roctx ranges around every wf_hip_tick (resolved from the profiler's marker library at run time)
 CMD=${WF_PROFILE_CMD:-"python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-other-configs $EXTRA"}   # WF_PROFILE_CMD: profile another driver (e.g. tools/meter_bench.py)
 echo "$CMD" | sed "s#$R/##g" > $OUT/cmd.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1   # (--marker-trace: the roctx range around every wf_hip_tick)
 if [ "${WF_PMC_SET:-full}" = "short" ]; then   # HBM bytes only
 for PMC in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc_$PMC -o pmc -- $CMD > $OUT/pmc_$PMC.log 2>&1

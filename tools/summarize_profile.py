@@ -78,14 +78,26 @@ def main(tag, name, streams=4096, fft=4096, match="spectrum_tick", command=None,
             if said.get("launches_per_tick") and len(names) == 1:  # (the same kernel twice in sequence: mono mixdown of split geometries)
                 per_tick = max(per_tick, int(said["launches_per_tick"]))
             ticks = len(rows) // per_tick
-            if ticks > 1:
-                body = rows[(ticks - max(1, ticks * 2 // 5)) * per_tick:]
+            if ticks > 2:
+                # tick k = launches [k * per_tick, (k + 1) * per_tick) in start order; its period = first start of tick k + 1 - first start
+                # of tick k.  The figure is the MEDIAN period over the last 40 % of the ticks: (last end - first start) / ticks, the
+                # round-4 form, let one host stall inside the window (the profiler's own buffer flushes) stretch every tick of it
+                # (profiles/r04i_cfg3_8192streams: 141.6 us where the launches average 107.6).  Both are kept; a window whose
+                # mean exceeds the median by more than 15 % says so.
+                first = (ticks - max(2, ticks * 2 // 5))
+                starts = [min(int(r["Start_Timestamp"]) for r in rows[k * per_tick:(k + 1) * per_tick]) for k in range(first, ticks)]
+                periods = sorted(b - a for a, b in zip(starts, starts[1:]))
+                median = periods[len(periods) // 2] if len(periods) % 2 else 0.5 * (periods[len(periods) // 2 - 1] + periods[len(periods) // 2])
+                body = rows[first * per_tick:]
                 span = max(int(r["End_Timestamp"]) for r in body) - min(int(r["Start_Timestamp"]) for r in body)
+                mean = span / (len(body) // per_tick)
                 trace = {"launches": len(rows), "launches_per_tick": per_tick, "concurrent_streams": lanes, "kernels_per_tick": names,
-                         "ticks_in_span": len(body) // per_tick, "tick_span_ns": span / (len(body) // per_tick),
-                         "note": "a tick = one launch of each of %d kernel(s) on each of %d concurrently used HIP stream(s); tick_span_ns = (last end - "
-                                 "first start) / ticks over the last 40 %% of the ticks (steady state: behind the command's lead-in), profiler "
-                                 "attached; kernel_stats averages every launch of the run, lead-in included" % (len(names), lanes)}
+                         "ticks_in_span": len(body) // per_tick, "tick_span_ns": median, "tick_span_mean_ns": mean,
+                         "stalled_window": bool(mean > 1.15 * median),
+                         "note": "a tick = one launch of each of %d kernel(s) on each of %d concurrently used HIP stream(s); tick_span_ns = the median "
+                                 "distance between the first launches of consecutive ticks over the last 40 %% of the ticks (steady state: behind the "
+                                 "command's lead-in), profiler attached; tick_span_mean_ns = (last end - first start) / ticks of the same window "
+                                 "(one host stall stretches it: stalled_window); kernel_stats averages every launch of the run, lead-in included" % (len(names), lanes)}
     fetch_b = tot.get("FETCH_SIZE", 0) * 1024 * 2
     write_b = tot.get("WRITE_SIZE", 0) * 1024
     cyc = tot.get("GRBM_GUI_ACTIVE", 0) / 8

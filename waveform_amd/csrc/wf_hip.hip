@@ -4,6 +4,7 @@
 // (wf_tick_geom.hip, wf_big_dispatch.hip).  gfx950 only.  There is no CPU fallback: every entry point either drives the
 // device or fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -720,7 +721,52 @@ int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, 
     return WF_HIP_OK;
 }
 
+// roctx ranges around the tick ("Tracing": the reference has none either; the timeline of a profiled process
+// then shows the host's part of every tick next to the kernels).  Opt-in -- WF_HIP_ROCTX=1 in the environment -- and resolved at
+// run time from the profiler's own marker library (librocprofiler-sdk-roctx.so, else libroctx64.so): the product links neither.
+extern "C++" {
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = std::getenv("WF_HIP_ROCTX");
+        if(e == nullptr || e[0] == '0')
+            return;
+        for(const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if(void *lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+                if(push && pop)
+                    return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx()
+{
+    static const Roctx r; // (thread-safe initialisation)
+    return r;
+}
+} // namespace
+} // extern "C++"
+
+static int wf_hip_tick_impl(wf_hip *h, const wf_hip_tick_params *p);
 int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *p)
+{
+    const Roctx &rx = roctx();
+    if(rx.push == nullptr)
+        return wf_hip_tick_impl(h, p);
+    rx.push("wf_hip_tick");
+    const int rc = wf_hip_tick_impl(h, p);
+    rx.pop();
+    return rc;
+}
+
+static int wf_hip_tick_impl(wf_hip *h, const wf_hip_tick_params *p)
 {
     if(h == nullptr || p == nullptr)
         return WF_HIP_ERR_INVALID;
