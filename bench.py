@@ -260,7 +260,7 @@ def shape_list(wf):
         # the ends of the reference's FFT range (not BASELINE configs; reported so that the driver's line carries them too)
         ("fft_size 65536 (the reference's maximum, 'enable large FFT'): 256 stereo streams, EMA + slope; both rows of 16384 complex points and "
          "the end of the tick in one workgroup", wf.Config.defaults(fft_size=65536, **ema), 256, 30, 0, "n65536"),
-        ("fft_size 800 (the plugin's automatic size at 48 kHz / 60 fps; 400 complex points as mixed radix 25 x 16): 8192 stereo streams, EMA + slope",
+        ("fft_size 800 (the plugin's automatic size at 48 kHz / 60 fps; 400 complex points by a mixed-radix plan -- the radices are in the kernel name): 8192 stereo streams, EMA + slope",
          wf.Config.defaults(fft_size=800, **ema), 8192, 60, 0, "n800_mixed_radix"),
     ]
     return shapes

@@ -763,6 +763,13 @@ void WAVSourceHIP::hip_collect_display(const float *bars, const float *verts, co
         std::memcpy(m_hip_verts.data(), verts, m_hip_verts.size() * sizeof(float));
         std::memcpy(m_hip_vcounts.data(), counts, m_hip_vcounts.size() * sizeof(uint32_t));
     }
+    hip_publish_display();
+}
+
+// m_hip_bars / m_hip_verts / m_hip_vcounts hold this frame's display: the bar tops (curve points) also go where render() and the
+// reference's own members expect them
+void WAVSourceHIP::hip_publish_display()
+{
     const size_t channels = m_hip_points ? m_hip_bars.size() / m_hip_points : 0;
     for(size_t channel = 0; channel < channels; ++channel)
         if(m_interp_bufs[channel].size() >= m_hip_points)
@@ -1085,11 +1092,10 @@ void WAVSourceHIP::tick_spectrum(float seconds)
         std::memcpy(m_decibels[channel].get(), m_hip_out.data() + (size_t)channel * outsz, outsz * sizeof(float));
     m_last_silent = silent != 0;
     if(m_hip_display) {
-        std::vector<float> bars(m_hip_bars.size()), verts(m_hip_verts.size());
-        std::vector<uint32_t> counts(m_hip_vcounts.size());
-        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK &&
-           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)))
-            hip_collect_display(bars.data(), verts.data(), counts.data());
+        // straight into the members render() draws from (no per-tick allocations, no staging copy)
+        if(a.read_bars(m_hip, 0, 1, m_hip_bars.data()) == WF_HIP_OK &&
+           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, m_hip_verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, m_hip_vcounts.data()) == WF_HIP_OK)))
+            hip_publish_display();
         else
             m_hip_display_valid = false; // render() goes back to the host loops over m_decibels
     }
@@ -1413,14 +1419,5 @@ void WAVSourceHIP::tick_waveform(float seconds)
     }
     for(auto channel = 0u; channel < m_output_channels; ++channel)
         std::memcpy(m_decibels[channel].get(), m_hip_out.data() + (size_t)channel * outsz, outsz * sizeof(float));
-    m_last_silent = silent != 0;
-    if(m_hip_display) {
-        std::vector<float> bars(m_hip_bars.size()), verts(m_hip_verts.size());
-        std::vector<uint32_t> counts(m_hip_vcounts.size());
-        if(a.read_bars(m_hip, 0, 1, bars.data()) == WF_HIP_OK &&
-           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, counts.data()) == WF_HIP_OK)))
-            hip_collect_display(bars.data(), verts.data(), counts.data());
-        else
-            m_hip_display_valid = false; // render() goes back to the host loops over m_decibels
-    }
+    m_last_silent = silent != 0; // (no device display here: hip_configure builds one for spectrum displays only, the waveform's points are the rows)
 }

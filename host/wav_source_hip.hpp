@@ -70,6 +70,7 @@ protected:
     bool hip_configure();              // (re)creates m_hip from the members update() has just set
     void hip_display_config(struct wf_config &c) const; // the display fields of wf_config from the members update() has set
     void hip_collect_display(const float *bars, const float *verts, const uint32_t *counts);
+    void hip_publish_display();
 
 public:
     using WAVSourceGeneric::WAVSourceGeneric;

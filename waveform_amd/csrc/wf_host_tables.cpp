@@ -454,7 +454,7 @@ bool bar_pieces(const HostTables &t, int threads, int points, int max_blocks, Ba
         out.bar_piece[(size_t)b] = (int)pieces.size();
         const int o = t.bar_off[(size_t)b], len = t.bar_off[(size_t)b + 1] - o;
         if(len <= 0)
-            continue; // (a bar without entries: no slot, the finalizer's sum is empty -- 0 / count, as the flat form gives)
+            return false; // (a bar without entries has no last lane to emit it on one wavefront per spectrum: bar_segments' layouts take the display)
         const int lo = t.bar_bin[(size_t)o], hi = lo + len;
         for(int e = 1; e < len; ++e)
             if(t.bar_bin[(size_t)o + e] != lo + e)

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     if(count_arrivals) {
         asm volatile("" ::: "memory");
         if(lane == 0)
-            __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(arrivals, 1, WF_ARRIVE_ORDER_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
     if constexpr(!COEF_EARLY)
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
 #endif
         if(WF_EXP_PS_CUT == 5 || WF_EXP_PS_CUT == 6) {
             if(WF_EXP_PS_CUT == 6 && count_arrivals) {
-                while(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
+                while(__hip_atomic_load(arrivals, WF_ARRIVE_ORDER_ACQ, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
                     __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         }
         // every thread of the spectrum is done reading its exchange buffer
         if(count_arrivals && !WF_EXP_NO_ARRIVAL_WAIT) {
-            while(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
+            while(__hip_atomic_load(arrivals, WF_ARRIVE_ORDER_ACQ, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
                 __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
         } else if(!(mono_mix && !SPLIT))

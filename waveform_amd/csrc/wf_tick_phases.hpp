@@ -357,13 +357,22 @@ WF_DEV float seg_prefix_scan(float v, uint32_t info)
 #undef WF_SCAN_STEP
     return v;
 }
+// The arrival counters of the display phase (a wavefront has made its last reads of the exchange buffer / has left its part of the
+// row): release on the count, acquire on the wait, at workgroup scope -- what the memory model asks for.  (Until round 5: relaxed
+// operations between compiler barriers, leaning on gfx9 executing a wavefront's LDS operations in order; on LDS the ordered forms cost
+// one s_waitcnt lgkmcnt(0) in front of the count.  -DWF_ARRIVE_RELAXED=1 builds the old form for an A/B.)
+#ifndef WF_ARRIVE_RELAXED
+#define WF_ARRIVE_RELAXED 0
+#endif
+#define WF_ARRIVE_ORDER_REL (WF_ARRIVE_RELAXED ? __ATOMIC_RELAXED : __ATOMIC_RELEASE)
+#define WF_ARRIVE_ORDER_ACQ (WF_ARRIVE_RELAXED ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE)
 // a wavefront counts itself in (LDS atomic, workgroup scope); every lane gets the count before it
 WF_DEV int wave_arrive(int *counter, int lane)
 {
     int old = 0;
     asm volatile("" ::: "memory");
     if(lane == 0)
-        old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __hip_atomic_fetch_add(counter, 1, WF_ARRIVE_RELAXED ? __ATOMIC_RELAXED : __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
     asm volatile("" ::: "memory");
     return old;
@@ -373,7 +382,7 @@ WF_DEV void wait_vmem_all() {}
 WF_DEV void wave_fence() {}
 WF_DEV float wave_shfl_down(float v, int) { return v; } // (the emulator does not run the bar reduction)
 WF_DEV float seg_prefix_scan(float v, uint32_t) { return v; }
-WF_DEV int wave_arrive(int *counter, int) { return (*counter)++; }
+WF_DEV int wave_arrive(int *counter, int) { return __atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL); }
 #endif
 
 // All LDS traffic goes through these four helpers (ds_read_b64/b128, ds_write_b64/b128).
@@ -1936,12 +1945,22 @@ template<class RG> WF_DEV void ps_park(float *dbl, int M, int t, const float (&d
 {
     constexpr int NG = RG::P / 4;
     static_assert(NG == 1 || NG == 2 || NG % 4 == 0, "group sums are stored as 4-, 8- or 16-byte words");
-    store_row<RG>(dbl + 4, t, d);
+#ifndef WF_EXP_PARK
+#define WF_EXP_PARK 0 // measurement only (wrong bars): 1 = the group sums alone are parked, 2 = the row alone, 3 = nothing (the sums are formed)
+#endif
+    if(WF_EXP_PARK == 0 || WF_EXP_PARK == 2)
+        store_row<RG>(dbl + 4, t, d);
     float *gs = ps_gs_area(dbl, M) + t * NG;
     float s[NG];
     WF_UNROLL
     for(int u = 0; u < NG; ++u)
         s[u] = (d[4 * u] + d[4 * u + 1]) + (d[4 * u + 2] + d[4 * u + 3]);
+    if(WF_EXP_PARK >= 2) {
+        WF_UNROLL
+        for(int u = 0; u < NG; ++u)
+            asm volatile("" ::"v"(s[u]));
+        return;
+    }
     if constexpr(NG == 1)
         gs[0] = s[0];
     else if constexpr(NG == 2)
