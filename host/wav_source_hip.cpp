@@ -46,6 +46,8 @@ struct HipApi {
     decltype(&wf_hip_set_stream_audio_ts) set_stream_audio_ts = nullptr;
     decltype(&wf_hip_output_channels) output_channels = nullptr;
     decltype(&wf_hip_read_display_async) read_display_async = nullptr;
+    decltype(&wf_hip_read_premirror) read_premirror = nullptr;
+    decltype(&wf_hip_read_premirror_async) read_premirror_async = nullptr;
     decltype(&wf_hip_read_bars) read_bars = nullptr;
     decltype(&wf_hip_read_vertices) read_vertices = nullptr;
     decltype(&wf_hip_read_vertex_counts) read_vertex_counts = nullptr;
@@ -96,6 +98,8 @@ HipApi &api()
         WF_SYM(set_stream_audio_ts)
         WF_SYM(output_channels)
         WF_SYM(read_display_async)
+        WF_SYM(read_premirror)
+        WF_SYM(read_premirror_async)
         WF_SYM(read_bars)
         WF_SYM(read_vertices)
         WF_SYM(read_vertex_counts)
@@ -184,6 +188,7 @@ struct WFHipGroup {
     float *bars[2] = {nullptr, nullptr};      // page-locked [capacity][disp_ch][points]
     float *verts[2] = {nullptr, nullptr};     // page-locked [capacity][disp_ch][per_row][4]
     uint32_t *vcounts[2] = {nullptr, nullptr}; // page-locked [capacity][disp_ch]
+    float *pre[2] = {nullptr, nullptr};       // page-locked [capacity][disp_ch]: mirrored axis, the value above the middle before the mirror (wf_hip_read_premirror)
 
     bool create(const wf_config &c, int dev)
     {
@@ -208,6 +213,11 @@ struct WFHipGroup {
                 bars[i] = static_cast<float *>(a.host_alloc((size_t)capacity * disp_ch * points * sizeof(float)));
                 if(bars[i] == nullptr)
                     return false;
+                if(c.mirror_freq_axis) {
+                    pre[i] = static_cast<float *>(a.host_alloc((size_t)capacity * disp_ch * sizeof(float)));
+                    if(pre[i] == nullptr)
+                        return false;
+                }
                 if(per_row == 0)
                     continue;
                 verts[i] = static_cast<float *>(a.host_alloc((size_t)capacity * disp_ch * per_row * 4 * sizeof(float)));
@@ -292,6 +302,8 @@ struct WFHipGroup {
             ok = a.read_input_rms_async(h, 0, capacity, rms_back[b], b) == WF_HIP_OK;
         if(ok && display)
             ok = a.read_display_async(h, 0, capacity, bars[b], per_row ? verts[b] : nullptr, per_row ? vcounts[b] : nullptr, b) == WF_HIP_OK;
+        if(ok && display && pre[b])
+            ok = a.read_premirror_async(h, 0, capacity, pre[b], b) == WF_HIP_OK;
         rows_valid[b] = ok;
         ++batch;
         n_submitted = 0;
@@ -635,6 +647,7 @@ bool WAVSourceHIP::hip_configure()
             m_hip_bars.assign((size_t)g->disp_ch * g->points, 0.0f);
             m_hip_verts.assign((size_t)g->disp_ch * g->per_row * 4, 0.0f);
             m_hip_vcounts.assign(g->per_row ? g->disp_ch : 0u, 0u);
+            m_hip_pre.assign(g->disp_ch, 0.0f);
         }
         return true;
     }
@@ -720,6 +733,7 @@ bool WAVSourceHIP::hip_configure()
         m_hip_bars.assign((size_t)dch * m_hip_points, 0.0f);
         m_hip_verts.assign((size_t)dch * m_hip_per_row * 4, 0.0f);
         m_hip_vcounts.assign(m_hip_per_row ? dch : 0u, 0u);
+        m_hip_pre.assign(dch, 0.0f);
     }
     m_hip_window.assign((size_t)m_capture_channels * m_fft_size, 0.0f);
     m_hip_out.assign((size_t)m_output_channels * (m_fft_size / 2), 0.0f);
@@ -783,11 +797,7 @@ void WAVSourceHIP::render([[maybe_unused]] gs_effect_t *effect)
     // the display modes the device does not draw (level meter: two values; waveform), sources on the CPU path, a frame before
     // the first device result: the reference's own render
     const bool spectrum = !m_meter_mode && m_display_mode != DisplayMode::WAVEFORM;
-    // the shader's gradient height / pulse colour follow the smallest y BEFORE the mirror image replaces the upper half
-    // (src/source.cpp:1548-1567); the device hands back the mirrored row, so those two render modes keep the host loops when the
-    // axis is mirrored
-    const bool miny_exact = !m_mirror_freq_axis || (m_render_mode != RenderMode::GRADIENT && m_render_mode != RenderMode::PULSE);
-    if(!spectrum || !using_hip() || !m_hip_display || !m_hip_display_valid || !miny_exact) {
+    if(!spectrum || !using_hip() || !m_hip_display || !m_hip_display_valid) {
         if(spectrum && using_hip())
             g_host_renders.fetch_add(1);
         WAVSourceGeneric::render(effect);
@@ -818,14 +828,25 @@ void WAVSourceHIP::render([[maybe_unused]] gs_effect_t *effect)
     const auto channels = m_stereo ? 2u : 1u;
     auto miny = cpos;
     auto minpos = 0u;
-    for(auto channel = 0u; channel < channels; ++channel)
-        for(auto i = 0u; i < m_hip_points; ++i) {
+    // The shader's gradient height / pulse colour follow the smallest y of the rows BEFORE the mirror image replaces their upper
+    // halves (src/source.cpp:1548-1567, :1411-1424).  The device hands back the mirrored rows -- whose upper halves repeat lower
+    // values: a strict "<" never picks them -- and, per row, the one value every output above the middle had before the mirror
+    // (wf_hip_read_premirror): first seen at output num_bars / 2 + 1.
+    const auto half = m_hip_points / 2u;
+    for(auto channel = 0u; channel < channels; ++channel) {
+        const auto upto = m_mirror_freq_axis ? std::min(half + 1u, m_hip_points) : m_hip_points;
+        for(auto i = 0u; i < upto; ++i) {
             const auto val = m_hip_bars[(size_t)channel * m_hip_points + i];
             if(val < miny) {
                 miny = val;
                 minpos = i;
             }
         }
+        if(m_mirror_freq_axis && half + 1u < m_hip_points && channel < m_hip_pre.size() && m_hip_pre[channel] < miny) {
+            miny = m_hip_pre[channel];
+            minpos = half + 1u;
+        }
+    }
     set_shader_vars(cpos, miny, (float)minpos, channel_offset, border_top, border_bottom);
 
     gs_technique_begin(tech);
@@ -921,6 +942,8 @@ void WAVSourceHIP::tick_spectrum_batched(float seconds)
             m_last_silent = g->silent[last][slot] != 0;
             if(g->rms_feed)
                 m_input_rms = g->rms_back[last][slot]; // as of that batch's tick (for observers; the device uses its own)
+            if(g->display && m_hip_display && g->pre[last])
+                m_hip_pre.assign(g->pre[last] + (size_t)slot * g->disp_ch, g->pre[last] + (size_t)(slot + 1) * g->disp_ch);
             if(g->display && m_hip_display)
                 hip_collect_display(g->bars[last] + (size_t)slot * g->disp_ch * g->points,
                                     g->per_row ? g->verts[last] + (size_t)slot * g->disp_ch * g->per_row * 4 : nullptr,
@@ -1094,7 +1117,8 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     if(m_hip_display) {
         // straight into the members render() draws from (no per-tick allocations, no staging copy)
         if(a.read_bars(m_hip, 0, 1, m_hip_bars.data()) == WF_HIP_OK &&
-           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, m_hip_verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, m_hip_vcounts.data()) == WF_HIP_OK)))
+           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, m_hip_verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, m_hip_vcounts.data()) == WF_HIP_OK)) &&
+           (!m_mirror_freq_axis || a.read_premirror(m_hip, 0, 1, m_hip_pre.data()) == WF_HIP_OK))
             hip_publish_display();
         else
             m_hip_display_valid = false; // render() goes back to the host loops over m_decibels

@@ -65,6 +65,7 @@ protected:
     std::vector<float> m_hip_bars;     // [display channels][m_hip_points] pixel y
     std::vector<float> m_hip_verts;    // [display channels][m_hip_per_row][4]
     std::vector<uint32_t> m_hip_vcounts; // [display channels] vertices of each channel's draw call
+    std::vector<float> m_hip_pre;        // [display channels] mirrored axis: the value the outputs above the middle had before the mirror
 
     void hip_release();
     bool hip_configure();              // (re)creates m_hip from the members update() has just set

@@ -263,6 +263,15 @@ int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *
  * far leave them, copied into page-locked memory on the readback stream without waiting; wf_hip_readback_done(slot) blocks
  * until both have landed (the plugin's batched mode reads every source's level one video frame late) */
 int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_levels, uint8_t *pinned_last_silent, uint32_t slot);
+/* Displays with cfg.mirror_freq_axis: render_bars / render_curve take the row's smallest y for the shader (miny / minpos, gradient
+ * and pulse render modes) BEFORE the outputs above the middle are replaced by images of the lower ones (src/source.cpp:1548-1567,
+ * :1411-1424).  Above the middle every output sits on the clamped top position and has one and the same value; that value --
+ * output num_bars / 2 + 1 of the row before the mirror -- per displayed row: [count][display_channels].  With it and the rows
+ * wf_hip_read_bars returns the host finds the reference's miny / minpos without interpolating the row itself.
+ * WF_HIP_ERR_INVALID for configurations without a mirrored display.  The _async form rides on a slot's wf_hip_read_rows_async
+ * like wf_hip_read_display_async (wf_hip_readback_done(slot) says when it has landed). */
+int wf_hip_read_premirror(wf_hip *h, uint32_t first, uint32_t count, float *out);
+int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
 /* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
  * all-gather); ordered on the handle's stream and synchronised before returning */
 int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);

@@ -25,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <array>
 #include <vector>
 
 namespace fakeobs {
@@ -145,6 +146,10 @@ static thread_local gs_vertex_buffer *g_loaded_vb = nullptr;
 static thread_local std::vector<fakeobs::Draw> g_draws;
 std::vector<fakeobs::Draw> &fakeobs::draws() { return g_draws; }
 void fakeobs::clear_draws() { g_draws.clear(); }
+// shader parameters by name: what set_shader_vars hands the effect during a render (thread-local, like the draws) -- the last value
+// of each, four floats (a float parameter in [0], a bool as 0 / 1)
+static thread_local std::map<std::string, std::array<float, 4>> g_shader_vals;
+std::map<std::string, std::array<float, 4>> &fakeobs::shader_values() { return g_shader_vals; }
 
 extern "C" {
 
@@ -276,9 +281,9 @@ void obs_property_int_set_limits(obs_property_t *, int, int, int) {}
 struct gs_vertex_buffer { gs_vb_data *data; };
 struct gs_effect { int dummy; };
 struct gs_effect_technique { int dummy; };
-struct gs_effect_param { int dummy; };
+struct gs_effect_param { std::string name; };
 static gs_effect_technique g_tech;
-static gs_effect_param g_param;
+static thread_local std::map<std::string, gs_effect_param> g_params;
 void obs_enter_graphics(void) {}
 void obs_leave_graphics(void) {}
 gs_vb_data *gs_vbdata_create(void) { return (gs_vb_data *)bzalloc(sizeof(gs_vb_data)); }
@@ -310,15 +315,20 @@ void gs_draw(gs_draw_mode mode, uint32_t start, uint32_t num)
 gs_effect_t *gs_effect_create_from_file(const char *, char **) { return new gs_effect{0}; }
 void gs_effect_destroy(gs_effect_t *effect) { delete effect; }
 gs_technique_t *gs_effect_get_technique(const gs_effect_t *, const char *) { return &g_tech; }
-gs_eparam_t *gs_effect_get_param_by_name(const gs_effect_t *, const char *) { return &g_param; }
+gs_eparam_t *gs_effect_get_param_by_name(const gs_effect_t *, const char *name)
+{
+    auto &p = g_params[name ? name : ""];
+    p.name = name ? name : "";
+    return &p;
+}
 size_t gs_technique_begin(gs_technique_t *) { return 1; }
 void gs_technique_end(gs_technique_t *) {}
 bool gs_technique_begin_pass(gs_technique_t *, size_t) { return true; }
 void gs_technique_end_pass(gs_technique_t *) {}
-void gs_effect_set_bool(gs_eparam_t *, bool) {}
-void gs_effect_set_float(gs_eparam_t *, float) {}
-void gs_effect_set_vec2(gs_eparam_t *, const vec2 *) {}
-void gs_effect_set_vec4(gs_eparam_t *, const vec4 *) {}
+void gs_effect_set_bool(gs_eparam_t *p, bool v) { if(p) g_shader_vals[p->name] = {v ? 1.0f : 0.0f, 0, 0, 0}; }
+void gs_effect_set_float(gs_eparam_t *p, float v) { if(p) g_shader_vals[p->name] = {v, 0, 0, 0}; }
+void gs_effect_set_vec2(gs_eparam_t *p, const vec2 *v) { if(p && v) g_shader_vals[p->name] = {v->x, v->y, 0, 0}; }
+void gs_effect_set_vec4(gs_eparam_t *p, const vec4 *v) { if(p && v) g_shader_vals[p->name] = {v->x, v->y, v->z, v->w}; }
 
 /* ---- memory / log / clock / module ------------------------------------------------ */
 void *bmalloc(size_t size) { return malloc(size ? size : 1); }

@@ -10,6 +10,7 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <array>
 #include <vector>
 
 namespace fakeobs {
@@ -57,6 +58,7 @@ void push_audio(obs_source *src, const audio_data *audio, bool muted);
 // channel of stepped bars has no vertices at all, src/source.cpp:1661-1664)
 struct Draw { int mode; uint32_t start, num; std::vector<float> points; };
 std::vector<Draw> &draws(); // thread-local
+std::map<std::string, std::array<float, 4>> &shader_values(); // thread-local: the last value every shader parameter was set to
 void clear_draws();
 
 obs_data *data_create();

@@ -189,6 +189,17 @@ size_t wfref_draw(wfref_t *, int i, int *mode, const float **points)
     if(points) *points = d[(size_t)i].points.data();
     return d[(size_t)i].num; /* vertices drawn; points holds 4 floats per vertex */
 }
+/* the last value a shader parameter was set to (set_shader_vars, src/source.cpp:1693-1770): returns 0 if it never was */
+int wfref_shader_value(wfref_t *, const char *name, float out[4])
+{
+    auto &m = fakeobs::shader_values();
+    auto it = m.find(name ? name : "");
+    if(it == m.end())
+        return 0;
+    for(int i = 0; i < 4; ++i)
+        out[i] = it->second[(size_t)i];
+    return 1;
+}
 void wfref_show(wfref_t *h, int show)
 {
     h->self->showing = (show != 0);

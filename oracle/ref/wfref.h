@@ -54,6 +54,7 @@ void wfref_render(wfref_t *h);
 /* what the last wfref_render() handed to gs_draw (src/source.cpp:1463-1465, :1661-1664): one call per displayed channel;
  * returns the number of vertices drawn, *points = 4 floats (x, y, z, w) per vertex of the vertex buffer at that moment */
 int wfref_draw_count(wfref_t *h);
+int wfref_shader_value(wfref_t *h, const char *name, float out[4]); /* the last value set_shader_vars gave the parameter; 0: never set */
 size_t wfref_draw(wfref_t *h, int i, int *mode, const float **points);
 void wfref_show(wfref_t *h, int show);
 

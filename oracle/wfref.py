@@ -264,6 +264,16 @@ class RefSource:
         n = self.L.wfref_bars(self.h, ch, C.byref(p))
         return _arr(p, n)
 
+    def shader_value(self, name: str):
+        """the last value set_shader_vars (src/source.cpp:1693-1770) gave shader parameter `name` on this thread: float32[4]
+        (a float parameter in [0]), or None if it was never set"""
+        self.L.wfref_shader_value.restype = C.c_int
+        self.L.wfref_shader_value.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]
+        out = (C.c_float * 4)()
+        if not self.L.wfref_shader_value(self.h, name.encode(), out):
+            return None
+        return np.array(list(out), np.float32)
+
     def draws(self):
         """the gs_draw calls of the last render(): [(mode, vertices [n, 4])], one per displayed channel"""
         self.L.wfref_draw_count.restype = C.c_int

@@ -121,6 +121,8 @@ int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *
     return WF_HIP_OK;
 }
 uint32_t wf_hip_ring_frames(const wf_hip *) { return 1u << 20; }
+int wf_hip_read_premirror(wf_hip *h, uint32_t, uint32_t count, float *out) { for(uint32_t i = 0; i < count * h->disp; ++i) out[i] = 0.0f; return WF_HIP_OK; }
+int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float *out, uint32_t) { return wf_hip_read_premirror(h, first, count, out); }
 int wf_hip_set_bars_mirror(wf_hip *, void *, void *) { return WF_HIP_ERR_UNSUPPORTED; }
 int wf_hip_set_bars_mirrors(wf_hip *, uint32_t, void *const *, void *const *) { return WF_HIP_ERR_UNSUPPORTED; }
 int wf_hip_bars_mirror_ready(wf_hip *, void *, void **) { return WF_HIP_ERR_INVALID; }

@@ -368,7 +368,7 @@ def recorded(records, record):
 
 # ---- backends --------------------------------------------------------------------------------------
 class RefBackend:
-    def __init__(self, cfg, isa="generic"):
+    def __init__(self, cfg, isa="generic", extra_settings=None):
         from helpers import ref_settings
         from oracle import wfref
         self.cfg = cfg
@@ -376,7 +376,7 @@ class RefBackend:
         # before the first packet is not a capture timeout of the harness's making
         wfref.lib().wfref_set_clock_ns(1_000_000_000)
         self.sr = int(cfg.sample_rate)
-        self.src = wfref.RefSource(ref_settings(cfg), isa=isa, sample_rate=self.sr, channels=int(cfg.capture_channels))
+        self.src = wfref.RefSource(ref_settings(cfg, **(extra_settings or {})), isa=isa, sample_rate=self.sr, channels=int(cfg.capture_channels))
         assert self.src.capture_channels == cfg.capture_channels
         self.capture_channels = int(cfg.capture_channels)
         self.disp = 2 if cfg.stereo else 1

@@ -136,6 +136,63 @@ def _check_renders(wfref, cfg, drawn, on_host):
     assert wfref.hip_device_renders() > drawn, "no render() was served from the device's display"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("shader", ["gradient", "pulse:peak_magnitude", "pulse:peak_frequency"])
+def test_mirrored_axis_shader_constants_come_from_the_device(shader, batched):
+    """render modes whose shader constants follow the row's smallest y -- gradient (grad_height) and pulse (color_base, by
+    magnitude or by position) -- on a MIRRORED frequency axis: the reference takes miny / minpos before the mirror image
+    replaces the upper half of the row (src/source.cpp:1548-1567, :1411-1424).  WAVSourceHIP::render finds them from the
+    device's mirrored row plus the one value the outputs above the middle had before (wf_hip_read_premirror): every render must
+    be served from the device (host_renders unchanged) and hand set_shader_vars what the plugin's own CPU class hands it --
+    bars with an odd and an even count, stereo and mono, and a curve."""
+    wfref = _hip_env(batched=batched)
+    mode, _, pulse = shader.partition(":")
+    extra = dict(render_mode=mode, grad_ratio=repr(0.75), color_base=0xFF102030, color_crest=0xFFE0D0C0)
+    if pulse:
+        extra["pulse_mode"] = pulse
+    names = {"gradient": ["grad_height", "grad_center", "grad_offset"], "pulse": ["color_base"]}[mode]
+    layouts = [dict(fft_size=2048, stereo=1, bars=1, interp_mode=1, mirror_freq_axis=1, vertices=1),                        # 26 bars
+               dict(fft_size=4096, stereo=0, bars=1, interp_mode=2, mirror_freq_axis=1, vertices=1, width=810, slope=1.0),  # 27 bars
+               dict(fft_size=1024, stereo=1, bars=1, interp_mode=0, mirror_freq_axis=1, vertices=1, width=640, bar_width=9, bar_gap=2, log_scale=0),
+               dict(fft_size=2048, stereo=1, curve=1, interp_mode=2, mirror_freq_axis=1, vertices=1, width=801)]
+    steps = [("noise", 800), ("tick",)] * 3 + [("noise_amp", 800, 0.02), ("tick",)] * 3 + [("noise_ch0_only", 800), ("tick",)] * 2
+    for cfg_dict in layouts:
+        cfg = scenarios.make_config(cfg_dict)
+        sc = dict(cfg=cfg_dict, steps=steps, record="all")
+
+        class Shaded:
+            """a RefBackend whose observe() also records the shader constants of that frame's render"""
+            def __init__(self, isa):
+                self.be = scenarios.RefBackend(cfg, isa=isa, extra_settings=extra)
+                self.capture_channels = self.be.capture_channels
+            def __getattr__(self, k):
+                return getattr(self.be, k)
+            def observe(self):
+                rec = self.be.observe()
+                rec["shader"] = {n: self.be.src.shader_value(n) for n in names}
+                return rec
+        before, drawn, on_host = wfref.hip_fallback_ticks(), wfref.hip_device_renders(), wfref.hip_host_renders()
+        hip = Shaded("hip")
+        assert hip.be.src.using_hip
+        if batched:
+            late = _OneFrameLate(hip)
+            scenarios.play(late, sc)
+            got = late.finish()
+        else:
+            got = scenarios.play(hip, sc)
+        assert hip.be.src.using_hip and wfref.hip_fallback_ticks() == before
+        assert wfref.hip_host_renders() == on_host, f"{cfg_dict}: render() went back to the host loops for a mirrored axis with {shader}"
+        assert wfref.hip_device_renders() > drawn
+        want = scenarios.play(Shaded("generic"), sc)
+        assert len(got) == len(want)
+        for t, (g, w) in enumerate(zip(got, want)):
+            for n in names:
+                assert w["shader"][n] is not None and g["shader"][n] is not None, (cfg_dict, shader, n)
+                d = np.abs(g["shader"][n].astype(np.float64) - w["shader"][n])
+                assert np.all(d <= 1e-5 * np.abs(w["shader"][n]) + 2e-3), f"{cfg_dict} {shader} tick {t}: shader constant {n} {g['shader'][n]} != {w['shader'][n]}"
+
+
 class _OneFrameLate:
     """plays a scenario on a backend whose outputs lag one video frame (the batched plugin mode): every tick's record is
     taken at the following tick; one extra tick at the end collects the last frame"""

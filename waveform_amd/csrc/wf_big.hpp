@@ -782,8 +782,9 @@ __global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
     float *dbl = reinterpret_cast<float *>(big_smem);
     const int t = (int)threadIdx.x;
-    const BarArgs &b = a.bar;
-    const uint32_t stream = a.stream_base + blockIdx.x / b.disp_ch, r = blockIdx.x % b.disp_ch;
+    const uint32_t stream = a.stream_base + blockIdx.x / a.bar.disp_ch, r = blockIdx.x % a.bar.disp_ch;
+    // (BarArgs::pre_out points at the entry of the row being finished)
+    const BarArgs b = [&] { BarArgs c = a.bar; if(c.pre_out) c.pre_out += (size_t)stream * a.bar.disp_ch + r; return c; }();
     const int MO = (int)a.row_bins;
     const float *row = a.decibels + ((size_t)stream * a.out_ch + r) * MO;
     float *out_row = b.out + ((size_t)stream * b.disp_ch + r) * b.num_bars;

@@ -96,6 +96,7 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.bar.entries = (int)h->tab.bar_coef.size();
         a.bar.lanes_per_bar = h->bar_lpb;
         a.bar.out = h->d_bars;
+        a.bar.pre_out = h->d_bars_pre;
         a.bar.out2_n = (int)h->mirror_n;
         for(uint32_t j = 0; j < h->mirror_n; ++j)
             a.bar.out2_delta[j] = (long long)(h->bars_mirror[h->mirror_next][j] - h->d_bars);
@@ -478,6 +479,9 @@ int wf_hip_reset(wf_hip *h, uint32_t first, uint32_t count)
         const size_t nb = (size_t)count * h->disp_ch * h->num_bars;
         hipLaunchKernelGGL(wf::fill_f32_kernel, dim3((unsigned)std::min<size_t>((nb + 255) / 256, 4096)), dim3(256), 0, h->stream,
                            h->d_bars + (size_t)first * h->disp_ch * h->num_bars, nb, h->tab.border_bottom);
+        if(h->d_bars_pre)
+            hipLaunchKernelGGL(wf::fill_f32_kernel, dim3(((size_t)count * h->disp_ch + 255) / 256), dim3(256), 0, h->stream,
+                               h->d_bars_pre + (size_t)first * h->disp_ch, (size_t)count * h->disp_ch, h->tab.border_bottom);
     }
     WF_HIP_TRY(h, hipGetLastError());
     int rrc = reset_rms_producer(h, first, count);
@@ -1356,6 +1360,36 @@ int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pin
     WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
     h->read_used[slot] = true;
     h->rows_in_flight[slot] = true;
+    return WF_HIP_OK;
+}
+
+int wf_hip_read_premirror(wf_hip *h, uint32_t first, uint32_t count, float *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(h->d_bars_pre == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "the configuration has no mirrored display (cfg.mirror_freq_axis == 0, or no bars / curve)");
+    if(out == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL");
+    return read_back(h, h->d_bars_pre + (size_t)first * h->disp_ch, out, (size_t)count * h->disp_ch * sizeof(float));
+}
+
+int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(slot > 1 || pinned_out == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL or slot is not 0 / 1");
+    if(h->d_bars_pre == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "the configuration has no mirrored display (cfg.mirror_freq_axis == 0, or no bars / curve)");
+    if(!h->rows_in_flight[slot] || h->read_stream == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_premirror_async rides on the slot's wf_hip_read_rows_async: call that first");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_out, h->d_bars_pre + (size_t)first * h->disp_ch, (size_t)count * h->disp_ch * sizeof(float), hipMemcpyDeviceToHost,
+                                 h->read_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
     return WF_HIP_OK;
 }
 

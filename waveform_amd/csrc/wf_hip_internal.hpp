@@ -96,6 +96,7 @@ struct wf_hip {
     int *d_big_task = nullptr, *d_big_bar_task = nullptr; // BarArgs::big_task / big_bar_task
     int big_num_tasks = 0;
     float *d_bars = nullptr;
+    float *d_bars_pre = nullptr;    // BarArgs::pre_out: [n_streams][disp_ch], mirrored displays only
     // wf_hip_set_bars_mirror(s): the caller-owned buffers the ticks also write their bars into -- mirror_n of them per tick, the
     // two sets alternately
     float *bars_mirror[2][8] = {};

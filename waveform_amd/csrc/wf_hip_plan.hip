@@ -252,6 +252,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(dev_alloc(h, &h->d_verdict, 3 * n_spec));
     if(h->num_bars)
         WF_CREATE_TRY(dev_alloc(h, &h->d_bars, (size_t)h->n_streams * h->disp_ch * h->num_bars));
+    if(h->num_bars && cfg->mirror_freq_axis && !cfg->meter && !cfg->waveform) // the value render_bars / render_curve see above the middle before the mirror (BarArgs::pre_out)
+        WF_CREATE_TRY(dev_alloc(h, &h->d_bars_pre, (size_t)h->n_streams * h->disp_ch));
     if(cfg->vertices) {
         if(cfg->vertices > 3u || (cfg->vertices == 3u && (!cfg->bars || cfg->step_width < 1 || cfg->step_gap < 0)) || (cfg->vertices == 2u && cfg->bars) ||
            (!cfg->bars && !cfg->curve))

@@ -523,6 +523,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             if(a.bar.out != nullptr) {
                 // what render_bars makes of rows of DB_MIN: every bar at border_bottom
                 float *bo = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
+                if(a.bar.pre_out != nullptr && t < (dup ? 2 : 1))
+                    a.bar.pre_out[(size_t)stream * a.bar.disp_ch + ch + t] = a.bar.border_bottom;
                 for(int i = t; i < a.bar.num_bars * (dup ? 2 : 1); i += T) {
                     bo[i] = a.bar.border_bottom;
                     if constexpr(!BLU) // (the Bluestein / mixed-radix instantiations, at their register caps, do not serve wf_hip_set_bars_mirror)
@@ -755,7 +757,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 }
                 if(ps_finisher) {
                     float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
-                    ps_finish<G, RG>(a.bar, bar_entries, dbl, MO, lane, have_row, out0, dup_row ? out0 + a.bar.num_bars : nullptr);
+                    const BarArgs bar_row = [&] { BarArgs b = a.bar; if(b.pre_out) b.pre_out += (size_t)stream * a.bar.disp_ch + ch; return b; }();
+                    ps_finish<G, RG>(bar_row, bar_entries, dbl, MO, lane, have_row, out0, dup_row ? out0 + a.bar.num_bars : nullptr);
                 }
                 WF_STAMP(13);
                 return;
@@ -790,13 +793,23 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         float *out1 = dup_row ? out0 + a.bar.num_bars : nullptr;
 #ifdef WF_PHASE_TIMING
         BarArgs bar_args = a.bar;
+        if(bar_args.pre_out)
+            bar_args.pre_out += (size_t)stream * a.bar.disp_ch + (BOTH ? 0u : ch);
         bar_args.clk = (a.phase_clock && threadIdx.x == 0) ? a.phase_clock + (size_t)blockIdx.x * 16 : nullptr;
         WF_STAMP(12);
 #else
         // (the Bluestein / mixed-radix instantiations do not serve wf_hip_set_bars_mirror -- the host refuses it for their sizes --:
         // with the count a constant 0 the further stores fold away; the 96-register instantiation spilled on them)
-        const BarArgs bar_blu = [&] { BarArgs b = a.bar; if(BLU) b.out2_n = 0; return b; }();
-        const BarArgs &bar_args = BLU ? bar_blu : a.bar;
+        // (and BarArgs::pre_out points at the entry of the row being finished: the stream's only row when the threads of both spectra share it)
+        const BarArgs bar_row = [&] {
+            BarArgs b = a.bar;
+            if(BLU)
+                b.out2_n = 0;
+            if(b.pre_out)
+                b.pre_out += (size_t)stream * a.bar.disp_ch + (BOTH ? 0u : ch);
+            return b;
+        }();
+        const BarArgs &bar_args = bar_row;
 #endif
         OutVals<G> ov;
         bool pending = true;

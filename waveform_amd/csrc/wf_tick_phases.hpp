@@ -112,6 +112,11 @@ struct BarArgs {
     unsigned long long *clk;   // development aid: this workgroup's stamp slots
 #endif
     float *out;                // [n_streams][disp_ch][num_bars]
+    // mirrored frequency axis (reference src/source.cpp:1559-1564): outputs above the middle are replaced by images of the lower ones
+    // AFTER render_bars / render_curve have taken the row's smallest y for the shader (miny / minpos, :1548-1557).  Above the middle
+    // every output sits on the clamped top position and has the same value: output num_bars / 2 + 1's goes here, one float per
+    // displayed row, so that the host finds the reference's miny without drawing the row itself.  nullptr: not kept
+    float *pre_out;            // [n_streams][disp_ch]; inside the kernel's display phase: the entry of the row being finished
     // > 0 (wf_hip_set_bars_mirror / _mirrors): every tick also leaves the batch's bars -- the ones it finishes and, copied over, the
     // ones it does not touch (paused, hidden or silent streams) -- in out2_n more buffers of the same shape, buffer j starting
     // out2_delta[j] floats behind `out`: the send buffer of the all-gather of BASELINE configs[4] (or, with peer access, this shard's
@@ -1684,6 +1689,10 @@ WF_DEV void store_output(const BarArgs &b, int o, float y, float *out_row, float
     const int img = 2 * half - o;
     const bool own = o <= half;
     const bool image = o < half && img > half && img < b.num_bars;
+    if(o == half + 1 && b.pre_out != nullptr) { // (one lane per row; the caller has pointed pre_out at this row's entry: BarArgs::pre_out)
+        b.pre_out[0] = y;
+        if(dup_row) b.pre_out[1] = y; // (the second row of a single captured channel shown as stereo: the next entry)
+    }
     if(own) {
         put_output(b, out_row, o, y);
         if(dup_row) put_output(b, dup_row, o, y);
