@@ -334,6 +334,22 @@ long wfemu_bar_ps(const wf_config *cfg, int threads, int which, float *out, long
     return (long)v.size();
 }
 
+// the tables of the rows-by-Bluestein form of the sizes above 16384 (wf::build_bluestein_rows).  which: 0 column twiddle x opening chirp
+// [C][R], 1 FFT_L(chirp) [L], 2 closing chirp / L [R]; interleaved re, im.  Returns the floats of the table (L with out == nullptr && which < 0)
+long wfemu_bluestein_rows(uint32_t np, uint32_t c, int which, float *out, long cap)
+{
+    std::vector<wf::cfloat> rowtw, bhat, q;
+    const uint32_t L = wf::build_bluestein_rows(np, c, rowtw, bhat, q);
+    if(which < 0)
+        return (long)L;
+    const std::vector<wf::cfloat> &v = which == 0 ? rowtw : which == 1 ? bhat : q;
+    for(long i = 0; i < (long)v.size() && 2 * i + 1 < cap; ++i) {
+        out[2 * i] = v[(size_t)i].re;
+        out[2 * i + 1] = v[(size_t)i].im;
+    }
+    return 2 * (long)v.size();
+}
+
 int wfemu_lds_bytes(uint32_t fft_size)
 {
     int r = -1;

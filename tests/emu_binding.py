@@ -16,8 +16,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists():
-            subprocess.run(["make", "-C", str(ROOT / "tests" / "emu")], check=True, capture_output=True)
+        if not os.environ.get("WFEMU_LIBRARY"):  # (make: a no-op when the library is newer than its sources)
+            subprocess.run(["make", "-C", str(ROOT / "tests" / "emu"), str(Path("..") / ".." / "build" / "libwfemu.so")], check=True, capture_output=True)
         L = C.CDLL(str(LIB_PATH))
         fp = C.POINTER(C.c_float)
         L.wfemu_tick.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, fp, C.POINTER(C.c_uint32), C.c_uint32, C.c_float, fp, fp,
@@ -82,6 +82,21 @@ def bar_ps(cfg, threads: int, which: int):
     out = np.zeros(max(n, 1), np.float32)
     L.wfemu_bar_ps(C.cast(C.byref(cfg), C.c_void_p), threads, which, out.ctypes.data_as(C.POINTER(C.c_float)), n)
     return out[:n]
+
+
+def bluestein_rows(np_points: int, c: int):
+    """wf::build_bluestein_rows: (L, rowtw [C, R], bhat [L], q [R]) as complex64"""
+    L = lib()
+    L.wfemu_bluestein_rows.restype = C.c_long
+    L.wfemu_bluestein_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.c_long]
+    length = L.wfemu_bluestein_rows(np_points, c, -1, None, 0)
+    tabs = []
+    for which in range(3):
+        n = L.wfemu_bluestein_rows(np_points, c, which, None, 0)
+        out = np.zeros(n, np.float32)
+        L.wfemu_bluestein_rows(np_points, c, which, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+        tabs.append(out.view(np.complex64))
+    return int(length), tabs[0].reshape(c, np_points // c), tabs[1], tabs[2]
 
 
 def tick(cfg, ring: np.ndarray, wpos: int, tsmooth: np.ndarray, delay: int = 0, seconds: float = 1 / 60):

@@ -340,6 +340,35 @@ def _replay_bar_ps(tab, M, T, P, db):
     return out
 
 
+@pytest.mark.parametrize("n,c", [(48016, 8), (17488, 8), (65424, 8), (33824, 8), (32760, 4)])
+def test_bluestein_rows_tables_replayed(n, c):
+    """The sizes above 16384 whose n/2 has a large prime factor: n/2 = C R, the column step and C rows of R points by chirp-z over
+    L >= 2 R - 1 points (big_br_columns_kernel / big_br_rows_kernel, wf_big.hpp).  The host tables (wf::build_bluestein_rows)
+    replayed with numpy's FFT as the container transform must deliver the n/2-point DFT -- the packed real transform the
+    reference's fftwf_plan_dft_r2c_1d computes (src/source.cpp:423-431) -- row k1 holding Z[k1 + C k2]."""
+    from tests import emu_binding as emu
+    points = n // 2
+    R = points // c
+    L, rowtw, bhat, q = emu.bluestein_rows(points, c)
+    assert L >= 2 * R - 1 and L & (L - 1) == 0 and L in (4096, 8192)
+    rng = np.random.default_rng(n)
+    z = (rng.standard_normal(points) + 1j * rng.standard_normal(points)).astype(np.complex64)
+    want = np.fft.fft(z.astype(np.complex128))
+    cols = z.reshape(c, R)                                   # cols[cc, n2] = z[n2 + R cc]
+    wc = np.exp(-2j * np.pi * np.outer(np.arange(c), np.arange(c)) / c)
+    a = (wc @ cols.astype(np.complex128)) * rowtw            # a[k1, n2], chirp and column twiddle folded in
+    y = np.zeros((c, L), np.complex128)
+    y[:, :R] = a
+    # the kernel's form: R = FFT(conj(FFT(y) bhat)) (= L conj(y (*) chirp)), Z_row = q conj(R)
+    r2 = np.fft.fft(np.conj(np.fft.fft(y, axis=1) * bhat), axis=1)[:, :R]
+    rows = q * np.conj(r2)
+    got = np.empty(points, np.complex128)
+    for k1 in range(c):
+        got[k1::c] = rows[k1]
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < 2e-6, err
+
+
 def test_bar_prefix_sum_tables_replayed_lane_by_lane():
     """wf::bar_ps (round 5: the bar reduction as two look-ups into a float64 prefix sum of the row + two 7-tap edge windows per
     sub-band of identical weight rows, reference src/filter.hpp:194-211 / src/source.cpp:876-884) against the flat per-bin

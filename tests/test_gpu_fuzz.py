@@ -398,10 +398,15 @@ def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
             name = b.kernel_name()
             assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)
-    for n, big_mr in ((48000, True), (32000, True), (65520, True), (20480, True), (16400, True), (48016, False), (33824, False)):
+    # above 16384: rows of a mixed-radix transform where n/2 = C R has a plan, else (n a multiple of 16 -- every position of the
+    # reference's slider is one of 64) rows by Bluestein inside LDS, else Bluestein through device memory
+    for n, kernel in ((48000, "big_mr_rows_kernel"), (32000, "big_mr_rows_kernel"), (65520, "big_mr_rows_kernel"), (20480, "big_mr_rows_kernel"),
+                      (16400, "big_mr_rows_kernel"), (48016, "big_br_{columns,rows}_kernel"), (33824, "big_br_{columns,rows}_kernel"),
+                      (65424, "big_br_{columns,rows}_kernel"), (17488, "big_br_{columns,rows}_kernel"), (33832, "big_{columns,rows,epilogue}_kernel")):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 1) as b:
             name = b.kernel_name()
-            assert ("big_mr_rows_kernel" in name) == big_mr and ("Bluestein" in name) != big_mr, (n, name)
+            assert name.startswith(kernel + " ") or name.startswith(kernel + "<"), (n, name)
+            assert ("Bluestein" in name) == (kernel != "big_mr_rows_kernel"), (n, name)
 
 
 @pytest.mark.gpu

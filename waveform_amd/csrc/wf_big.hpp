@@ -195,14 +195,27 @@ WF_DEV void p4_big_impl(const TickArgs &a, int t, int kbase, int nb, const cf *z
         f4 st = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if(TS)
             st = ld_state(ts + k0);
-        const f4 za = ld4(reinterpret_cast<const float *>(z + kk)), zb = ld4(reinterpret_cast<const float *>(z + kk + 2));
-        const cf A[4] = {cf{za.x, za.y}, cf{za.z, za.w}, cf{zb.x, zb.y}, cf{zb.z, zb.w}};
-        if constexpr(MODE == 1) {
+        cf A[4];
+        // MODE 3: MODE 1 on rows that lie where big_br_rows_kernel left them: Z[k] at z[(k % big_c) big_rs + k / big_c], big_c a power of two
+        const uint32_t cs = (uint32_t)__builtin_ctz(a.big_c), cm = a.big_c - 1u;
+        auto zt = [&](int k) { return z + (size_t)((uint32_t)k & cm) * a.big_rs + ((uint32_t)k >> cs); };
+        if constexpr(MODE == 3) {
+#pragma unroll
+            for(int i = 0; i < 4; ++i) {
+                const f2 q = ld2(reinterpret_cast<const float *>(zt(kk + i)));
+                A[i] = cf{q.x, q.y};
+            }
+        } else {
+            const f4 za = ld4(reinterpret_cast<const float *>(z + kk)), zb = ld4(reinterpret_cast<const float *>(z + kk + 2));
+            A[0] = cf{za.x, za.y}; A[1] = cf{za.z, za.w}; A[2] = cf{zb.x, zb.y}; A[3] = cf{zb.z, zb.w};
+        }
+        if constexpr(MODE == 1 || MODE == 3) {
             const f4 wa = ld4(reinterpret_cast<const float *>(a.big_tws + kk)), wb = ld4(reinterpret_cast<const float *>(a.big_tws + kk + 2));
             const cf W[4] = {cf{wa.x, wa.y}, cf{wa.z, wa.w}, cf{wb.x, wb.y}, cf{wb.z, wb.w}};
 #pragma unroll
             for(int i = 0; i < 4; ++i) {
-                const f2 bq = ld2(reinterpret_cast<const float *>(z + ((kk + i) == 0 ? 0 : m - kk - i))); // Z[m] is Z[0]; m need not be a power of two
+                const int km = (kk + i) == 0 ? 0 : m - kk - i; // Z[m] is Z[0]; m need not be a power of two
+                const f2 bq = ld2(reinterpret_cast<const float *>(MODE == 3 ? zt(km) : z + km));
                 const float er = A[i].x + bq.x, ei = A[i].y - bq.y;
                 const float dr = A[i].x - bq.x, di = A[i].y + bq.y;
                 const float pr = fmaf(W[i].x, dr, -(W[i].y * di));
@@ -769,6 +782,125 @@ __global__ __launch_bounds__(GBig::T, 4) void big_mr_rows_kernel(const TickArgs 
     mr_transform_to<G>(a.mr, true, (int)R, t, lds, wp_lds, [] { __syncthreads(); }, [=](int k2, cf v) {
         *reinterpret_cast<f2 *>(z + (size_t)k2 * C + k1) = f2{v.x, v.y};
     });
+}
+
+// ---- fft sizes above 16384 whose n/2 has a prime factor no mixed-radix plan takes: big_c rows, each by Bluestein INSIDE LDS ---------
+// (round 5; until then these sizes -- about 300 of the 768 positions of the reference's FFT-size slider above 16384,
+// src/source.cpp:359-363 -- ran Bluestein over 3n/2 .. points through device memory: five kernels, 0.01-0.03 of the roofline.)
+// n/2 = C R, C = 8 (or 4): decimation in frequency over the C columns,
+//   a[k1][n2] = (sum_c z[n2 + R c] W_C^(c k1)) W_(n/2)^(n2 k1) conj(w_n2)      (big_br_columns_kernel; w_m = exp(i pi m^2 / R):
+//                                                                             column twiddle and opening chirp are ONE table, big_tw)
+// and the R-point DFT of row k1 -- it delivers Z[k1 + C k2], k2 < R -- by Bluestein over the container geometry G of L = G::M >= 2 R - 1
+// complex points (big_br_rows_kernel: the phase functions of the fused kernel's Bluestein instantiation): FFT_L, times FFT_L(chirp)
+// (blu_b), conjugate, FFT_L again, Z_row[k2] = blu_q[k2] conj(R_k2), written over the row's input.  The epilogue of the packed real
+// transform (big_epilogue_kernel<3>: <1> reading the rows where they lie) takes it from there.
+// Scratch: [n_spec][C][big_rs] complex, big_rs = R rounded up to even (16-byte rows); a.big_l = C big_rs, the spectrum's stride.
+// First form (one kernel: every row summing the columns in its own fetch, as big_mr_rows_kernel does): every row workgroup reads the
+// WHOLE window -- C x the requests, 2 C x 16 dependent round trips in front of two transforms: 425 us of 494 at 48016 x 256 streams.
+template<int C> __global__ __launch_bounds__(256) void big_br_columns_kernel(const TickArgs a)
+{
+    const uint32_t R = a.big_r;
+    const uint32_t spec = a.stream_base * a.cap_ch + blockIdx.y;
+    const uint32_t stream = spec >> (a.cap_ch - 1u);
+    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const uint32_t start = (a.wpos[stream] - delay - a.blu_n) & a.ring_mask;
+    const float *x = a.ring + (size_t)spec * a.ring_stride;
+    const uint32_t n2 = blockIdx.x * 256u + threadIdx.x;
+    const bool in = n2 < R;
+    const uint32_t n2c = in ? n2 : 0u;
+    cf v[C];
+    uint32_t acc = 0;
+#pragma unroll
+    for(int c = 0; c < C; ++c) {
+        const uint32_t i = n2c + R * (uint32_t)c, si = start + 2u * i;
+        const float x0 = x[si & a.ring_mask], x1 = x[(si + 1u) & a.ring_mask];
+        const f2 w = ld2(a.window + 2u * i);
+        acc |= f32_bits(x0) | f32_bits(x1);
+        v[c] = cf{x0 * w.x, x1 * w.y};
+    }
+    dft_dif<C>(v); // X[k1] in v[brev(k1)]
+    if(in) {
+        cf *out = const_cast<cf *>(a.big_z) + (size_t)spec * a.big_l + n2;
+#pragma unroll
+        for(int k1 = 0; k1 < C; ++k1) {
+            const f2 q = ld2(reinterpret_cast<const float *>(a.big_tw + (size_t)k1 * R + n2));
+            const cf o = cmul(v[brev(k1, ilog2(C))], cf{q.x, q.y});
+            *reinterpret_cast<f2 *>(out + (size_t)k1 * a.big_rs) = f2{o.x, o.y};
+        }
+    }
+    // x != 0.0f for any sample of the window (reference :63-72)
+    if(__any(in && (acc & 0x7fffffffu) != 0u) && (threadIdx.x & 63u) == 0u)
+        atomicOr(a.big_nz_out + spec, 1u);
+}
+
+template<class G> constexpr size_t big_br_lds_bytes() { return (size_t)G::LDS_CF * sizeof(cf) + (size_t)G::R2 * G::R3 * sizeof(cf) + 16; }
+template<class G> __global__ __launch_bounds__(G::T, 4) void big_br_rows_kernel(const TickArgs a)
+{
+    constexpr int T = G::T, P = G::P, R1 = G::R1, B1 = G::B1, M1 = G::M1;
+    static_assert(B1 == 2, "two points -- one 16-byte request -- per thread and pass-1 row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    cf *lds = reinterpret_cast<cf *>(big_smem);
+    cf *tw2_lds = lds + G::LDS_CF;
+    const int t = (int)threadIdx.x;
+    const uint32_t C = a.big_c, R = a.big_r;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3; // (the rows of a spectrum on one XCD: the epilogue reads them together)
+    const uint32_t k1 = slot % C, rel = (slot / C) * 8u + xcd;
+    if(rel >= a.stream_count * a.cap_ch)
+        return;
+    const uint32_t spec = a.stream_base * a.cap_ch + rel;
+    cf *row = const_cast<cf *>(a.big_z) + (size_t)spec * a.big_l + (size_t)k1 * a.big_rs; // (in: the columns' output; out: Z of this row)
+    P1Regs<G> r;
+#pragma unroll
+    for(int j = 0; j < R1; ++j) {
+        const uint32_t idx = (uint32_t)(j * M1 + B1 * t);
+        const bool in0 = idx < R, in1 = idx + 1u < R;
+        const f4 q = ld4(reinterpret_cast<const float *>(row + (in0 ? idx : 0u)));
+        r.smp[j][0] = in0 ? q.x : 0.0f;
+        r.smp[j][1] = in0 ? q.y : 0.0f;
+        r.smp[j][2] = in1 ? q.z : 0.0f;
+        r.smp[j][3] = in1 ? q.w : 0.0f;
+#pragma unroll
+        for(int e = 0; e < 4; ++e)
+            r.win[j][e] = 1.0f;
+        if(j >= 1 && tw1_row_loaded(j))
+            p1_load_tw1<G>(a, t, j, r.tw1[j]);
+    }
+    { // the pass-2 twiddles by LDS-DMA, as in spectrum_tick_kernel
+        constexpr int BYTES = G::R2 * G::R3 * (int)sizeof(cf), PER = 64 * 16;
+        static_assert(BYTES % PER == 0, "pass-2 twiddle table in whole wave-wide requests");
+        const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+        for(int c = 0; c < BYTES / PER; ++c)
+            if((c % (T / 64)) == wave) {
+                const char *g = reinterpret_cast<const char *>(a.tw2) + c * PER + lane * 16;
+                char *l = reinterpret_cast<char *>(tw2_lds) + c * PER;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16,
+                                                 0, 0);
+            }
+    }
+    cf pts[P];
+    auto transform = [&] {
+        p1_window_pass1<G>(a, t, r, lds);
+        __syncthreads();
+        p2_read<G>(t, lds, pts);
+        __syncthreads();
+        p2_pass2_write<G>(tw2_lds, t, lds, pts);
+        __syncthreads();
+        p3_read<G>(t, lds, pts);
+        __syncthreads();
+        p3_pass3_write<G>(t, lds, pts);
+        __syncthreads();
+    };
+    transform();
+    blu_mid<G>(a, t, lds, r); // conj(FFT(y) . FFT(chirp)) back into the fetch registers
+    __syncthreads();          // every thread has read its points: pass 1 may overwrite the buffer
+    transform();
+    for(uint32_t k2 = (uint32_t)t; k2 < R; k2 += (uint32_t)T) {
+        const cf v = lds_ld2(lds, ex3_addr<G>((int)k2));
+        const f2 q = ld2(reinterpret_cast<const float *>(a.blu_q + k2));
+        const cf o = cmul(cf{v.x, -v.y}, cf{q.x, q.y});
+        *reinterpret_cast<f2 *>(row + k2) = f2{o.x, o.y};
+    }
 }
 
 // ---- render-time outputs from the finished rows --------------------------------------------------------------------

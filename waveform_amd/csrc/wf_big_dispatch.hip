@@ -108,6 +108,30 @@ int launch_tick_big_mr(wf_hip *h, const wf::TickArgs &a0)
     return WF_HIP_OK;
 }
 
+// fft sizes above 16384 with a large prime factor: the column step, the rows by Bluestein inside LDS (in place), the epilogue on the
+// rows where they lie (wf_big.hpp)
+template<class G, int C> int launch_tick_big_br(wf_hip *h, const wf::TickArgs &a0)
+{
+    const uint32_t n_spec = a0.stream_count * a0.cap_ch;
+    hipStream_t st = h->launch_stream;
+    const uint32_t spec_base = a0.stream_base * a0.cap_ch;
+    WF_HIP_TRY(h, hipMemsetAsync(h->d_big_nz + spec_base, 0, (size_t)n_spec * sizeof(uint32_t), st));
+    hipLaunchKernelGGL((wf::big_br_columns_kernel<C>), dim3((a0.big_r + 255u) / 256u, n_spec), dim3(256), 0, st, a0);
+    const dim3 grow(h->big_rows * ((n_spec + 7u) & ~7u));
+    hipLaunchKernelGGL((wf::big_br_rows_kernel<G>), grow, dim3(G::T), wf::big_br_lds_bytes<G>(), st, a0);
+    const uint32_t parts = (h->M + (uint32_t)wf::BIG_TP - 1u) / (uint32_t)wf::BIG_TP;
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) {
+        wf::TickArgs a = a0;
+        a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(parts, h->split_mono ? a.stream_count : n_spec);
+        hipLaunchKernelGGL((wf::big_epilogue_kernel<3>), grid, dim3(wf::GBig::T), 0, st, a);
+    }
+    if(a0.bar.out != nullptr)
+        hipLaunchKernelGGL(wf::big_outputs_kernel, dim3(a0.stream_count * a0.bar.disp_ch), dim3(wf::GBig::T), h->big_out_lds, st, a0);
+    WF_HIP_TRY(h, hipGetLastError());
+    return WF_HIP_OK;
+}
+
 void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     // (a failure leaves its text in last_error and its HIP error sticky: wf_hip_tick's hipGetLastError() behind the launches
@@ -120,6 +144,11 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
         s.stream_count = std::min(part, a.stream_count - off);
         if(h->big_mr) {
             h->launch_rc = launch_tick_big_mr(h, s);
+            continue;
+        }
+        if(h->big_br) {
+            h->launch_rc = h->br_l == 4096u ? launch_tick_big_br<wf::G8192, 8>(h, s)
+                            : h->big_rows == 8 ? launch_tick_big_br<wf::G16384, 8>(h, s) : launch_tick_big_br<wf::G16384, 4>(h, s);
             continue;
         }
         if(h->big_whole) {
@@ -151,13 +180,18 @@ int setup_launch_big(wf_hip *h)
     if(h->big_mr)
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_mr_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)((size_t)(wf::GBig::LDS_CF + 128) * sizeof(wf::cf))));
-    else
+    else if(h->big_br) {
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G8192>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)wf::big_br_lds_bytes<wf::G8192>()));
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G16384>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)wf::big_br_lds_bytes<wf::G16384>()));
+    } else
         rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
     if(rc)
         return rc;
     // fft_size 65536 (the one power of two up here): both rows and the end of the tick in one kernel, no scratch in device memory.
     // WF_HIP_BIG_WHOLE=0 (development builds) sends it through the columns -> rows -> epilogue chain every other size up here takes
-    h->big_whole = !h->blu && !h->big_mr && h->big_rows == 2;
+    h->big_whole = !h->blu && !h->big_mr && !h->big_br && h->big_rows == 2;
 #ifdef WF_DEV_OVERRIDES
     if(const char *e = std::getenv("WF_HIP_BIG_WHOLE"))
         h->big_whole = h->big_whole && e[0] != '0';
@@ -174,7 +208,7 @@ int setup_launch_big(wf_hip *h)
     h->launch = &launch_tick_big;
     h->split = true;
     h->flag_bufs = 3;
-    char name[200];
+    char name[256];
     if(h->big_mr) {
         char rad[48];
         int o = 0;
@@ -182,7 +216,10 @@ int setup_launch_big(wf_hip *h)
             o += snprintf(rad + o, sizeof(rad) - (size_t)o, "%s%d", i ? "x" : "", h->mr_radix[i]);
         snprintf(name, sizeof(name), "big_mr_rows_kernel + big_epilogue_kernel<N=%u: %u rows of %u complex points as mixed radix %s, column step folded into the fetch>",
                  h->N, h->big_rows, h->M / h->big_rows, rad);
-    } else if(h->big_whole)
+    } else if(h->big_br)
+        snprintf(name, sizeof(name), "big_br_{columns,rows}_kernel + big_epilogue_kernel<N=%u: %u rows of %u complex points by Bluestein over %u points inside LDS>",
+                 h->N, h->big_rows, h->M / h->big_rows, h->br_l);
+    else if(h->big_whole)
         snprintf(name, sizeof(name), "big_whole_kernel<N=%u: both rows of 16384 complex points and the end of the tick in one workgroup>", h->N);
     else if(h->blu)
         snprintf(name, sizeof(name), "big_{columns,rows,epilogue}_kernel<N=%u by Bluestein over %u = %u x 16384 complex points through device memory>",

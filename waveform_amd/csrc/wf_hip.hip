@@ -148,6 +148,15 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.big_r = h->M / h->big_rows;
         a.big_wc = h->d_big_wc;
     }
+    if(h->big_br) { // rows by Bluestein inside LDS: the container geometry's tables in place of the batch geometry's
+        a.tw1 = h->d_br_tw1;
+        a.tw2 = h->d_br_tw2;
+        a.blu_b = h->d_br_bhat;
+        a.blu_q = h->d_br_q;
+        a.big_c = h->big_rows;
+        a.big_r = h->M / h->big_rows;
+        a.big_wc = h->d_big_wc;
+    }
     if(h->big_l) {
         a.big_z = h->d_big_z;
         a.big_tws = h->d_big_tws;
@@ -155,7 +164,8 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.big_nz_out = h->d_big_nz;
         a.big_nz = h->d_big_nz;
         a.big_m = h->blu ? 0u : h->N / 2;
-        a.big_l = h->big_l;
+        a.big_l = h->big_br ? h->big_rows * h->br_rs : h->big_l;
+        a.big_rs = h->br_rs;
         a.blu_n = h->N; // the window length the underflow test compares with
     }
     a.half_coef *= 1.0f / h->in_scale; // the window tables on the device carry in_scale

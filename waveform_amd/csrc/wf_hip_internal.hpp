@@ -88,6 +88,11 @@ struct wf_hip {
     // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
     uint32_t big_l = 0, big_rows = 0;
     bool big_mr = false;             // fft sizes above 16384 with small prime factors: big_rows rows of a mixed-radix transform (big_mr_rows_kernel)
+    bool big_br = false;             // fft sizes above 16384 with a prime factor no plan takes: big_rows (= 8) rows, each by Bluestein inside LDS (big_br_rows_kernel)
+    uint32_t br_rs = 0;              // ... a row's stride in the scratch buffer: M / big_rows rounded up to even
+    uint32_t br_l = 0;               // ... over br_l complex points (4096 / 8192: the 8192- / 16384-sample geometry as container)
+    wf::cf *d_br_tw1 = nullptr, *d_br_tw2 = nullptr; // the container's pass-1 / pass-2 twiddles
+    wf::cf *d_br_rowtw = nullptr, *d_br_bhat = nullptr, *d_br_q = nullptr; // build_bluestein_rows
     wf::cf *d_big_wc = nullptr;      // [8][8] W_big_rows^(c k1)
     bool big_whole = false;          // fft_size 65536: both rows plus the end of the tick in ONE kernel (big_whole_kernel), nothing through device memory
     wf::cf *d_big_v = nullptr, *d_big_z = nullptr, *d_big_tw = nullptr, *d_big_tws = nullptr;

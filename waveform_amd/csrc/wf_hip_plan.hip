@@ -147,6 +147,22 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                     h->big_rows = c;
                 }
             }
+            // ... and where n/2 has a prime factor no plan takes: n/2 = C R, C = 8 or 4, R <= 4096 points by Bluestein over the
+            // 8192- / 16384-sample geometry INSIDE LDS (big_br_rows_kernel) -- about 300 of the slider's 768 positions up here
+            bool rows_ok = true;
+#ifdef WF_DEV_OVERRIDES
+            if(const char *no_br = std::getenv("WF_HIP_NO_BLUESTEIN_ROWS")) // (development: A/B against Bluestein through device memory)
+                rows_ok = no_br[0] != '1';
+#endif
+            for(uint32_t c = 8; c >= 4 && !h->big_mr && !h->big_br && rows_ok; c >>= 1)
+                if(np % c == 0 && np / c <= 4096u && np / c >= 1024u) {
+                    h->big_br = true;
+                    h->blu = false; // (as above: the plain packed real transform, its rows by chirp-z)
+                    h->big_l = np;
+                    h->big_rows = c;
+                    h->br_l = 2u * (np / c) - 1u > 4096u ? 8192u : 4096u; // (build_bluestein_rows' container length)
+                    h->br_rs = (np / c + 1u) & ~1u;
+                }
         }
     }
     if(cfg->waveform) {
@@ -656,6 +672,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_blu_w, tw));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
+    std::vector<wf::cfloat> br_rowtw;
     if(h->big_mr) {
         // the rows' passes (a transform of R = n / 2 / C points) and the column step's W_C^(c k1)
         std::vector<wf::cfloat> twf, unused;
@@ -672,9 +689,40 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_big_wc, wc));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
+    if(h->big_br) {
+        // the container transform's twiddles, FFT(chirp), the closing chirp and the column step's W_C^(c k1); the table of column
+        // twiddle x opening chirp goes where the other paths keep their column twiddles (d_big_tw, below)
+        std::vector<wf::cfloat> bhat, q, t1f, t2f, unused;
+        if(wf::build_bluestein_rows(h->big_l, h->big_rows, br_rowtw, bhat, q) != h->br_l)
+            return bail(fail(h, WF_HIP_ERR_RUNTIME, "Bluestein rows: container length"));
+        wf::dispatch_geometry(2u * h->br_l, [&](auto g) {
+            using G = decltype(g);
+            wf::build_twiddles(G::M, G::R1, G::R2, G::R3, t1f, t2f, unused);
+        });
+        auto as_cf = [](const std::vector<wf::cfloat> &v) {
+            std::vector<wf::cf> o(v.size());
+            std::memcpy(o.data(), v.data(), v.size() * sizeof(wf::cf));
+            return o;
+        };
+        std::vector<wf::cf> wc(64, wf::cf{1.0f, 0.0f});
+        const double two_pi = 6.283185307179586476925286766559;
+        for(uint32_t k1 = 0; k1 < h->big_rows; ++k1)
+            for(uint32_t c = 0; c < h->big_rows; ++c) {
+                const double ang = -two_pi * (double)((c * k1) % h->big_rows) / (double)h->big_rows;
+                wc[k1 * 8u + c] = wf::cf{(float)std::cos(ang), (float)std::sin(ang)};
+            }
+        WF_CREATE_TRY(upload(h, &h->d_br_tw1, as_cf(t1f)));
+        WF_CREATE_TRY(upload(h, &h->d_br_tw2, as_cf(t2f)));
+        WF_CREATE_TRY(upload(h, &h->d_br_bhat, as_cf(bhat)));
+        WF_CREATE_TRY(upload(h, &h->d_br_q, as_cf(q)));
+        WF_CREATE_TRY(upload(h, &h->d_big_wc, wc));
+        WF_CREATE_HIP(hipStreamSynchronize(h->stream));
+    }
     if(h->big_l) {
         std::vector<wf::cfloat> twb, twsb;
         wf::build_big_twiddles(h->big_l, h->big_rows, h->blu ? 0u : h->N, twb, twsb);
+        if(h->big_br)
+            twb = br_rowtw;
         std::vector<wf::cf> t1(twb.size()), t2(twsb.size());
         std::memcpy(t1.data(), twb.data(), t1.size() * sizeof(wf::cf));
         if(!t2.empty())
@@ -683,6 +731,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_big_tws, t2));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
         if(h->big_whole) { // (fft_size 65536: no scratch at all, the magnitudes stay in registers)
+        } else if(h->big_br) { // (columns -> rows in place -> epilogue)
+            WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_rows * h->br_rs));
         } else if(h->big_mr) { // (the rows read the ring themselves: one scratch buffer, for Z)
             WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_l));
         } else {

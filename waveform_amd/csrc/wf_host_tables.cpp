@@ -912,6 +912,47 @@ void fft_double(std::vector<double> &re, std::vector<double> &im)
 }
 } // namespace
 
+uint32_t build_bluestein_rows(uint32_t np, uint32_t C, std::vector<cfloat> &rowtw, std::vector<cfloat> &bhat, std::vector<cfloat> &q)
+{
+    const uint32_t R = np / C;
+    uint32_t L = 4096;
+    while(L < 2u * R - 1u)
+        L <<= 1;
+    const double pi = 3.14159265358979323846264338327950288;
+    auto chirp = [&](uint64_t m, double &cr, double &ci) { // w_m = exp(i pi m^2 / R), the phase reduced exactly
+        const uint64_t ph = (m * m) % (2ull * R);
+        const double a = pi * (double)ph / (double)R;
+        cr = std::cos(a);
+        ci = std::sin(a);
+    };
+    rowtw.resize((size_t)np);
+    for(uint32_t k1 = 0; k1 < C; ++k1)
+        for(uint32_t n2 = 0; n2 < R; ++n2) {
+            double cr, ci;
+            chirp(n2, cr, ci);
+            const double a = -2.0 * pi * (double)(((uint64_t)n2 * k1) % np) / (double)np;
+            const double tr = std::cos(a), ti = std::sin(a);
+            // W_np^(n2 k1) * conj(w_n2)
+            rowtw[(size_t)k1 * R + n2] = cfloat{(float)(tr * cr + ti * ci), (float)(ti * cr - tr * ci)};
+        }
+    std::vector<double> br(L, 0.0), bi(L, 0.0);
+    for(uint32_t m = 0; m < R; ++m)
+        chirp(m, br[m], bi[m]);
+    for(uint32_t m = 1; m < R; ++m) // negative lags, wrapped
+        chirp(m, br[L - m], bi[L - m]);
+    fft_double(br, bi);
+    bhat.resize(L);
+    for(uint32_t k = 0; k < L; ++k)
+        bhat[k] = cfloat{(float)br[k], (float)bi[k]};
+    q.resize(R);
+    for(uint32_t k = 0; k < R; ++k) {
+        double cr, ci;
+        chirp(k, cr, ci);
+        q[k] = cfloat{(float)(cr / (double)L), (float)(-ci / (double)L)};
+    }
+    return L;
+}
+
 void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out)
 {
     const uint32_t n = cfg.fft_size;

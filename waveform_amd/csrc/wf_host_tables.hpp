@@ -158,6 +158,12 @@ uint32_t bluestein_length(uint32_t n);
 // W_real_n^k, the real-split twiddles of a packed real_n-sample transform (real_n == 0: not built)
 void build_big_twiddles(uint32_t L, uint32_t rows, uint32_t real_n, std::vector<cfloat> &tw_big, std::vector<cfloat> &tws_big);
 void build_bluestein(const wf_config &cfg, const HostTables &t, BluesteinTables &out);
+// FFT sizes above 16384 whose n/2 has a prime factor no mixed-radix plan takes: n/2 = C R points as C rows of R (decimation in
+// frequency over the C columns, folded into the rows' fetch like big_mr_rows_kernel's), every row transformed by Bluestein INSIDE a
+// workgroup's LDS (wf_big.hpp: big_br_rows_kernel) -- convolution length L = the power of two >= 2 R - 1 (returned; >= 4096).
+// rowtw[k1][n2] = W_(n/2)^(n2 k1) conj(w_n2), the column twiddle and the chirp of row k1's point n2 in one factor;
+// bhat = FFT_L of the chirp w_m = exp(i pi m^2 / R) (lags -(R-1) .. R-1, wrapped); q[k] = conj(w_k) / L: Z_row[k] = q[k] conj(R_k).
+uint32_t build_bluestein_rows(uint32_t np, uint32_t C, std::vector<cfloat> &rowtw, std::vector<cfloat> &bhat, std::vector<cfloat> &q);
 
 // FFT sizes with no prime factor above 23 and at most one of 17, 19, 23, 20, 25 (wf_mixed.hpp): the n/2-point transform as two to four mixed-radix passes instead of
 // Bluestein.  plan_mixed_radix fills radix[] in pass order and returns the number of passes, 0 when np has another prime

@@ -227,6 +227,7 @@ struct TickArgs {
     const cf *blu_w;           // [blu_n / 2] W_blu_n^k, the real-split twiddles
     MrPlan mr;                 // blu_n = 2^a 3^b 5^c: the transform is computed directly (blu_a, blu_b, blu_q, blu_qr unused)
     uint32_t big_c, big_r;     // big_mr_rows_kernel (wf_big.hpp): the n/2 points as big_c rows of big_r (mr plans a row)
+    uint32_t big_rs;           // big_br_*_kernel: the stride of a row in the scratch buffer (big_r rounded up to even)
     const cf *big_wc;          // [8][8] W_big_c^(c k1): the column step of row k1
     const cf *blu_a;           // [2 M] the factors of x_2j and x_2j+1 in point j of the chirped, windowed, packed input; zero from point blu_n / 2 on
     const cf *blu_b;           // [M] FFT_M of the chirp
