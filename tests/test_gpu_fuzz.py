@@ -50,7 +50,7 @@ SMOOTH_SIZES = [n for n in range(128, 16384 + 1, 16) if _five_smooth(n) and n & 
 HUGE_SMOOTH_SIZES = [n for n in range(16384 + 16, 65536, 16) if _five_smooth(n) and n & (n - 1)]
 
 
-def draw(seed: int, family: str = "pow2"):
+def draw(seed: int, family: str = "pow2", fft_size: int | None = None):
     r = np.random.default_rng({"pow2": 1000, "any": 77000, "huge": 555000, "smooth": 880000}[family] + seed)
     if family == "huge":
         # 65536 itself a quarter of the time, else ANY multiple of 16 in (10912, 65536) -- awkward prime factors included: that
@@ -84,6 +84,8 @@ def draw(seed: int, family: str = "pow2"):
         n = 16 * int(r.integers(8, int(hi) // 16 + 1))
         if n & (n - 1) == 0:
             n += 16
+    if fft_size is not None:  # (tests/sizes_large_sweep.py: everything else as drawn)
+        n = int(fft_size)
     layout = int(r.integers(0, 4))  # 0 mono capture, 1 mono mixdown of 2, 2 stereo, 3 one captured channel shown twice
     cfg = dict(fft_size=n,
                capture_channels=1 if layout in (0, 3) else 2,
@@ -318,10 +320,10 @@ def _compare(got, want, undo, what, cfg_stepped=False, cfg=None):
             assert abs(float(g["rms"]) - float(w["rms"])) <= 1e-5 * abs(float(w["rms"])) + 1e-9, f"{what} tick {t} m_input_rms"
 
 
-def run_spectrum_case(seed, family):
+def run_spectrum_case(seed, family, fft_size=None):
     import waveform_amd as wf
     from oracle import wfref
-    cfg_dict, steps, sync_ms = draw_wide(seed) if family == "wide" else draw(seed, family)
+    cfg_dict, steps, sync_ms = draw_wide(seed) if family == "wide" else draw(seed, family, fft_size)
     cfg = scenarios.make_config(cfg_dict)
     sc = dict(cfg=cfg_dict, steps=steps, record="all", sync_ms=sync_ms)
     what = f"{family} case {seed} ({cfg_dict}, sync {sync_ms} ms)"
@@ -398,11 +400,12 @@ def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
             name = b.kernel_name()
             assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)
-    # above 16384: rows of a mixed-radix transform where n/2 = C R has a plan, else (n a multiple of 16 -- every position of the
-    # reference's slider is one of 64) rows by Bluestein inside LDS, else Bluestein through device memory
+    # above 16384: rows of a mixed-radix transform where n/2 = C R has a plan without a prime pass, else (n a multiple of 16 -- every
+    # position of the reference's slider is one of 64) rows by Bluestein inside LDS (16400 = 2 x 41 x 10 x 10 included).  Every legal size
+    # takes one of the two: Bluestein through device memory is left to the development builds' WF_HIP_NO_BLUESTEIN_ROWS=1
     for n, kernel in ((48000, "big_mr_rows_kernel"), (32000, "big_mr_rows_kernel"), (65520, "big_mr_rows_kernel"), (20480, "big_mr_rows_kernel"),
-                      (16400, "big_mr_rows_kernel"), (48016, "big_br_{columns,rows}_kernel"), (33824, "big_br_{columns,rows}_kernel"),
-                      (65424, "big_br_{columns,rows}_kernel"), (17488, "big_br_{columns,rows}_kernel"), (33832, "big_{columns,rows,epilogue}_kernel")):
+                      (16400, "big_br_{columns,rows}_kernel"), (48016, "big_br_{columns,rows}_kernel"), (33824, "big_br_{columns,rows}_kernel"),
+                      (65424, "big_br_{columns,rows}_kernel"), (17488, "big_br_{columns,rows}_kernel")):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 1) as b:
             name = b.kernel_name()
             assert name.startswith(kernel + " ") or name.startswith(kernel + "<"), (n, name)

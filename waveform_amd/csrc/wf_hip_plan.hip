@@ -135,34 +135,42 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
 #endif
         if(h->blu && h->big_l && big_direct) {
             const uint32_t np = h->N / 2;
-            for(uint32_t c = 2; c <= 8 && !h->big_mr; ++c) {
-                if(np % c || np / c > 8192u)
-                    continue;
-                const int passes = wf::plan_mixed_radix(np / c, 1024u, h->mr_radix);
-                if(passes > 0) {
-                    h->big_mr = true;
-                    h->mr_passes = passes;
-                    h->blu = false;      // no chirp tables, no chirped window: the plain packed real transform
-                    h->big_l = np;       // (complex points per spectrum in the scratch buffer)
-                    h->big_rows = c;
-                }
-            }
-            // ... and where n/2 has a prime factor no plan takes: n/2 = C R, C = 8 or 4, R <= 4096 points by Bluestein over the
-            // 8192- / 16384-sample geometry INSIDE LDS (big_br_rows_kernel) -- about 300 of the slider's 768 positions up here
+            // ... and where n/2 = C R with C = 8 or 4 and R <= 4096: the rows by Bluestein over the 8192- / 16384-sample geometry INSIDE
+            // LDS (big_br_*_kernel) -- every multiple of 16 up here, the slider's 768 positions among them
             bool rows_ok = true;
 #ifdef WF_DEV_OVERRIDES
             if(const char *no_br = std::getenv("WF_HIP_NO_BLUESTEIN_ROWS")) // (development: A/B against Bluestein through device memory)
                 rows_ok = no_br[0] != '1';
 #endif
-            for(uint32_t c = 8; c >= 4 && !h->big_mr && !h->big_br && rows_ok; c >>= 1)
-                if(np % c == 0 && np / c <= 4096u && np / c >= 1024u) {
-                    h->big_br = true;
-                    h->blu = false; // (as above: the plain packed real transform, its rows by chirp-z)
-                    h->big_l = np;
+            uint32_t br_c = 0;
+            for(uint32_t c = 8; c >= 4 && !br_c && rows_ok; c >>= 1)
+                if(np % c == 0 && np / c <= 4096u && np / c >= 1024u)
+                    br_c = c;
+            for(uint32_t c = 2; c <= 8 && !h->big_mr; ++c) {
+                if(np % c || np / c > 8192u)
+                    continue;
+                int radix[4] = {0, 0, 0, 0};
+                const int passes = wf::plan_mixed_radix(np / c, 1024u, radix);
+                // A plan that opens with a prime pass (29 ... 127: wf::mr_pass_prime, p products per point) loses to the Bluestein rows:
+                // of the slider's 251 such positions 215 are faster there, by up to 40 % (113x8x9: 0.53 -> 0.31 ms at 256 streams), the
+                // other 36 slower by 6 % on average (profiles/r05_sizes_large_before.jsonl)
+                if(passes > 0 && !(br_c && radix[0] > 25)) {
+                    h->big_mr = true;
+                    h->mr_passes = passes;
+                    std::copy(radix, radix + 4, h->mr_radix);
+                    h->blu = false;      // no chirp tables, no chirped window: the plain packed real transform
+                    h->big_l = np;       // (complex points per spectrum in the scratch buffer)
                     h->big_rows = c;
-                    h->br_l = 2u * (np / c) - 1u > 4096u ? 8192u : 4096u; // (build_bluestein_rows' container length)
-                    h->br_rs = (np / c + 1u) & ~1u;
                 }
+            }
+            if(!h->big_mr && br_c) {
+                h->big_br = true;
+                h->blu = false; // (as above: the plain packed real transform, its rows by chirp-z)
+                h->big_l = np;
+                h->big_rows = br_c;
+                h->br_l = 2u * (np / br_c) - 1u > 4096u ? 8192u : 4096u; // (build_bluestein_rows' container length)
+                h->br_rs = (np / br_c + 1u) & ~1u;
+            }
         }
     }
     if(cfg->waveform) {
@@ -759,7 +767,10 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                        // launches of three slices drift apart: 256 streams 0.465 -> 0.513 (two) -> 0.533 (three), 2048 streams 0.472 -> 0.470 -> 0.495
         if(h->big_l) // the transforms through device memory: launch chains of small kernels, nothing to overlap -- except fft_size 65536 in
                      // its one kernel, a CU per workgroup again: 256 streams 0.445 -> 0.557 (two) / 0.49 (three), 64 streams (half a round) 0.259 -> 0.253
-            lanes = (h->big_whole && n_spec >= 2u * (uint32_t)std::max(prop.multiProcessorCount, 1)) ? 2 : 1;
+            // (the rows of the other sizes up here -- mixed radix, Bluestein in LDS -- likewise from two spectra per CU on: their column /
+            // rows / epilogue kernels are bound by different things and two slices' chains overlap: 48016 x 256 streams 0.266 -> 0.250 ms,
+            // 48000 x 256 0.170 -> 0.160, 17488 x 512 0.164 -> 0.158, 48016 x 1024 1.07 -> 1.02; three lanes +-2 % around two)
+            lanes = ((h->big_whole || h->big_mr || h->big_br) && n_spec >= 2u * (uint32_t)std::max(prop.multiProcessorCount, 1)) ? 2 : 1;
 #ifdef WF_DEV_OVERRIDES
         if(const char *e = std::getenv("WF_HIP_LANES"))
             lanes = std::atoi(e);
