@@ -340,7 +340,7 @@ def _replay_bar_ps(tab, M, T, P, db):
     return out
 
 
-@pytest.mark.parametrize("n,c", [(48016, 8), (17488, 8), (65424, 8), (33824, 8), (32760, 4)])
+@pytest.mark.parametrize("n,c", [(48016, 8), (17488, 8), (65424, 8), (33824, 8), (48064, 32), (48064, 16), (17728, 32), (65344, 32), (33472, 16)])
 def test_bluestein_rows_tables_replayed(n, c):
     """The sizes above 16384 whose n/2 has a large prime factor: n/2 = C R, the column step and C rows of R points by chirp-z over
     L >= 2 R - 1 points (big_br_columns_kernel / big_br_rows_kernel, wf_big.hpp).  The host tables (wf::build_bluestein_rows)
@@ -350,7 +350,7 @@ def test_bluestein_rows_tables_replayed(n, c):
     points = n // 2
     R = points // c
     L, rowtw, bhat, q = emu.bluestein_rows(points, c)
-    assert L >= 2 * R - 1 and L & (L - 1) == 0 and L in (4096, 8192)
+    assert L >= 2 * R - 1 and L & (L - 1) == 0 and (L < 4 * R or L == 1024) and L in (1024, 2048, 4096, 8192)
     rng = np.random.default_rng(n)
     z = (rng.standard_normal(points) + 1j * rng.standard_normal(points)).astype(np.complex64)
     want = np.fft.fft(z.astype(np.complex128))

@@ -410,6 +410,10 @@ def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
             name = b.kernel_name()
             assert name.startswith(kernel + " ") or name.startswith(kernel + "<"), (n, name)
             assert ("Bluestein" in name) == (kernel != "big_mr_rows_kernel"), (n, name)
+    # 16 rows where n/2 is a multiple of 16 (every slider position), 8 for the other multiples of 16; the container: >= 2 R - 1 points
+    for n, rows, r, container in ((48064, 16, 1502, 4096), (65472, 16, 2046, 4096), (32704, 16, 1022, 2048), (17488, 8, 1093, 4096), (48016, 8, 3001, 8192)):
+        with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 1) as b:
+            assert f"{rows} rows of {r} complex points by Bluestein over {container} points" in b.kernel_name(), (n, b.kernel_name())
 
 
 @pytest.mark.gpu

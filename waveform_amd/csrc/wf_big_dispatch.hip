@@ -132,6 +132,20 @@ template<class G, int C> int launch_tick_big_br(wf_hip *h, const wf::TickArgs &a
     return WF_HIP_OK;
 }
 
+template<int C> int launch_tick_big_br_g(wf_hip *h, const wf::TickArgs &a)
+{
+    switch(h->br_l) {
+    case 1024u: return launch_tick_big_br<wf::G2048, C>(h, a);
+    case 2048u: return launch_tick_big_br<wf::G4096, C>(h, a);
+    case 4096u: return launch_tick_big_br<wf::G8192, C>(h, a);
+    default: return launch_tick_big_br<wf::G16384, C>(h, a);
+    }
+}
+int launch_tick_big_br_c(wf_hip *h, const wf::TickArgs &a)
+{
+    return h->big_rows == 32u ? launch_tick_big_br_g<32>(h, a) : h->big_rows == 16u ? launch_tick_big_br_g<16>(h, a) : launch_tick_big_br_g<8>(h, a);
+}
+
 void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
 {
     // (a failure leaves its text in last_error and its HIP error sticky: wf_hip_tick's hipGetLastError() behind the launches
@@ -147,8 +161,7 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
             continue;
         }
         if(h->big_br) {
-            h->launch_rc = h->br_l == 4096u ? launch_tick_big_br<wf::G8192, 8>(h, s)
-                            : h->big_rows == 8 ? launch_tick_big_br<wf::G16384, 8>(h, s) : launch_tick_big_br<wf::G16384, 4>(h, s);
+            h->launch_rc = launch_tick_big_br_c(h, s);
             continue;
         }
         if(h->big_whole) {
@@ -181,6 +194,10 @@ int setup_launch_big(wf_hip *h)
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_mr_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)((size_t)(wf::GBig::LDS_CF + 128) * sizeof(wf::cf))));
     else if(h->big_br) {
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G2048>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)wf::big_br_lds_bytes<wf::G2048>()));
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G4096>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)wf::big_br_lds_bytes<wf::G4096>()));
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G8192>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)wf::big_br_lds_bytes<wf::G8192>()));
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G16384>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -155,7 +155,6 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.blu_q = h->d_br_q;
         a.big_c = h->big_rows;
         a.big_r = h->M / h->big_rows;
-        a.big_wc = h->d_big_wc;
     }
     if(h->big_l) {
         a.big_z = h->d_big_z;

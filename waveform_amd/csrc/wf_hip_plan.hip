@@ -142,9 +142,15 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             if(const char *no_br = std::getenv("WF_HIP_NO_BLUESTEIN_ROWS")) // (development: A/B against Bluestein through device memory)
                 rows_ok = no_br[0] != '1';
 #endif
-            uint32_t br_c = 0;
-            for(uint32_t c = 8; c >= 4 && !br_c && rows_ok; c >>= 1)
-                if(np % c == 0 && np / c <= 4096u && np / c >= 1024u)
+            // C = 16 where it divides n/2 (every multiple of 32), else 8: the smaller the container the more workgroups a CU holds --
+            // 48064 x 256 streams 0.254 ms with 8 rows over 8192 points, 0.194 with 16 over 4096, 0.209 with 32 over 2048
+            uint32_t br_c = 0, br_first = 16u;
+#ifdef WF_DEV_OVERRIDES
+            if(const char *e = std::getenv("WF_HIP_BR_ROWS"))
+                br_first = (uint32_t)std::atoi(e);
+#endif
+            for(uint32_t c = br_first; c >= 8u && !br_c && rows_ok; c >>= 1)
+                if(np % c == 0 && np / c <= 4096u && np / c >= 256u)
                     br_c = c;
             for(uint32_t c = 2; c <= 8 && !h->big_mr; ++c) {
                 if(np % c || np / c > 8192u)
@@ -168,7 +174,9 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 h->blu = false; // (as above: the plain packed real transform, its rows by chirp-z)
                 h->big_l = np;
                 h->big_rows = br_c;
-                h->br_l = 2u * (np / br_c) - 1u > 4096u ? 8192u : 4096u; // (build_bluestein_rows' container length)
+                h->br_l = 1024u; // (build_bluestein_rows' container length)
+                while(h->br_l < 2u * (np / br_c) - 1u)
+                    h->br_l <<= 1;
                 h->br_rs = (np / br_c + 1u) & ~1u;
             }
         }
@@ -698,7 +706,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
     if(h->big_br) {
-        // the container transform's twiddles, FFT(chirp), the closing chirp and the column step's W_C^(c k1); the table of column
+        // the container transform's twiddles, FFT(chirp), the closing chirp (the column step is a radix-C butterfly in registers); the table of column
         // twiddle x opening chirp goes where the other paths keep their column twiddles (d_big_tw, below)
         std::vector<wf::cfloat> bhat, q, t1f, t2f, unused;
         if(wf::build_bluestein_rows(h->big_l, h->big_rows, br_rowtw, bhat, q) != h->br_l)
@@ -712,18 +720,11 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             std::memcpy(o.data(), v.data(), v.size() * sizeof(wf::cf));
             return o;
         };
-        std::vector<wf::cf> wc(64, wf::cf{1.0f, 0.0f});
-        const double two_pi = 6.283185307179586476925286766559;
-        for(uint32_t k1 = 0; k1 < h->big_rows; ++k1)
-            for(uint32_t c = 0; c < h->big_rows; ++c) {
-                const double ang = -two_pi * (double)((c * k1) % h->big_rows) / (double)h->big_rows;
-                wc[k1 * 8u + c] = wf::cf{(float)std::cos(ang), (float)std::sin(ang)};
-            }
-        WF_CREATE_TRY(upload(h, &h->d_br_tw1, as_cf(t1f)));
-        WF_CREATE_TRY(upload(h, &h->d_br_tw2, as_cf(t2f)));
-        WF_CREATE_TRY(upload(h, &h->d_br_bhat, as_cf(bhat)));
-        WF_CREATE_TRY(upload(h, &h->d_br_q, as_cf(q)));
-        WF_CREATE_TRY(upload(h, &h->d_big_wc, wc));
+        const std::vector<wf::cf> s1 = as_cf(t1f), s2 = as_cf(t2f), s3 = as_cf(bhat), s4 = as_cf(q); // (alive until the copies are through)
+        WF_CREATE_TRY(upload(h, &h->d_br_tw1, s1));
+        WF_CREATE_TRY(upload(h, &h->d_br_tw2, s2));
+        WF_CREATE_TRY(upload(h, &h->d_br_bhat, s3));
+        WF_CREATE_TRY(upload(h, &h->d_br_q, s4));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
     }
     if(h->big_l) {

@@ -915,7 +915,7 @@ void fft_double(std::vector<double> &re, std::vector<double> &im)
 uint32_t build_bluestein_rows(uint32_t np, uint32_t C, std::vector<cfloat> &rowtw, std::vector<cfloat> &bhat, std::vector<cfloat> &q)
 {
     const uint32_t R = np / C;
-    uint32_t L = 4096;
+    uint32_t L = 1024; // (the smallest container: the 2048-sample geometry)
     while(L < 2u * R - 1u)
         L <<= 1;
     const double pi = 3.14159265358979323846264338327950288;
