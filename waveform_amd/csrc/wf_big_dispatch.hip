@@ -32,6 +32,11 @@ int launch_tick_big_whole(wf_hip *h, const wf::TickArgs &a0, bool aligned)
     return WF_HIP_OK;
 }
 
+#ifdef WF_DEV_OVERRIDES
+// The chain through device memory: columns -> rows (twice, with a pointwise product in between, for Bluestein's direct form) ->
+// epilogue.  Rounds 2-4 ran the sizes above 16384 on it; since round 5 every legal size has a faster path (big_whole_kernel, mixed-radix
+// rows, Bluestein rows inside LDS), and the chain is compiled into the development builds only, as the A/B baseline
+// (WF_HIP_BIG_WHOLE=0, WF_HIP_NO_MIXED_RADIX=1 + WF_HIP_NO_BLUESTEIN_ROWS=1).
 template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
 {
     const uint32_t n_spec = a0.stream_count * a0.cap_ch;
@@ -84,6 +89,8 @@ template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
     WF_HIP_TRY(h, hipGetLastError());
     return WF_HIP_OK;
 }
+
+#endif // WF_DEV_OVERRIDES
 
 // fft sizes above 16384 with small prime factors: rows of a mixed-radix transform (column step folded into the fetch), then the
 // epilogue of the packed real transform (wf_big.hpp)
@@ -168,20 +175,26 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
             h->launch_rc = launch_tick_big_whole(h, s, aligned);
             continue;
         }
+#ifdef WF_DEV_OVERRIDES
         switch(h->big_rows) {
         case 2: h->launch_rc = launch_tick_big_l<2>(h, s); break;
         case 4: h->launch_rc = launch_tick_big_l<4>(h, s); break;
         default: h->launch_rc = launch_tick_big_l<8>(h, s); break;
         }
+#else
+        h->launch_rc = fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: no kernel for this size in this build", h->N); // (unreachable: setup_launch_big refuses)
+#endif
     }
 }
 
+#ifdef WF_DEV_OVERRIDES
 template<int L1> int setup_big_rows(wf_hip *h)
 {
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_rows_kernel<L1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)wf::big_rows_lds_bytes<L1>()));
     return WF_HIP_OK;
 }
+#endif
 
 } // namespace
 
@@ -202,8 +215,14 @@ int setup_launch_big(wf_hip *h)
                                           (int)wf::big_br_lds_bytes<wf::G8192>()));
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G16384>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)wf::big_br_lds_bytes<wf::G16384>()));
-    } else
+    } else {
+#ifdef WF_DEV_OVERRIDES
         rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
+#else
+        if(h->blu || h->big_rows != 2) // (no legal size gets here: every multiple of 16 above 16384 has rows of one kind or the other)
+            return fail(h, WF_HIP_ERR_UNSUPPORTED, "fft_size %u: neither a power of two nor a length with a row decomposition (a multiple of 16 has one)", h->N);
+#endif
+    }
     if(rc)
         return rc;
     // fft_size 65536 (the one power of two up here): both rows and the end of the tick in one kernel, no scratch in device memory.
