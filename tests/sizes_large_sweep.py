@@ -2,7 +2,7 @@
 positions from 16448 to 65536), each one (1) played through a drawn fuzz scenario (tests/test_gpu_fuzz.py's "huge" family with the
 size forced) against the reference itself, oracle/_ref/libwfref.so, and (2) timed: 256 stereo streams, back-to-back ticks, steady
 state (tools/quick_bench.py's method with shorter regions).  One JSON line per position:
-    python tests/sizes_large_sweep.py [OUT.jsonl [LO [HI [STEP [parity]]]]]   (development aid / evidence: profiles/r05_sizes_large.jsonl)
+    python tests/sizes_large_sweep.py [OUT.jsonl [LO [HI [STEP [parity | STREAMS]]]]]   (development aid / evidence: profiles/r05_sizes_large.jsonl)
 With "parity" as the fifth argument the timing is left out and the lines are short -- the form used for EVERY legal size, the 4089
 multiples of 16 from 128 to 65536 (profiles/r05_sizes_all_parity.jsonl: python tests/sizes_large_sweep.py OUT 128 65536 16 parity).
 """
@@ -23,6 +23,8 @@ hi = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 step = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 parity_only = len(sys.argv) > 5 and sys.argv[5] == "parity"
 STREAMS, HOP, TICKS = 256, 800, 12
+if len(sys.argv) > 5 and sys.argv[5].isdigit():  # (another batch size: the sizes up to 16384 want more streams to fill the chip)
+    STREAMS = int(sys.argv[5])
 quick_bench.WARM_MS, quick_bench.TIMED_MS = 12.0, 8.0
 
 
