@@ -111,6 +111,10 @@ for nfft in (512, 1024, 2048, 4096, 8192, 16384, 32768):
     cfg = scenarios.make_config(dict(fft_size=nfft, stereo=1, slope=1.0))
     ring = np.ascontiguousarray(synth.block(1, 0, 1, 2, 0, 2 * nfft)[0], np.float32)
     emu.tick(cfg, ring, 2 * nfft, np.zeros((2, nfft // 2), np.float32))
+# the tables of the rows-by-Bluestein form of the sizes above 16384 (wf::build_bluestein_rows): the row counts and lengths the plan picks
+for nfft, c in ((16400, 8), (17728, 16), (32704, 16), (33472, 16), (48016, 8), (48064, 16), (65344, 16), (65424, 8), (65472, 16)):
+    L, rowtw, bhat, q = emu.bluestein_rows(nfft // 2, c)
+    assert L >= 2 * (nfft // 2 // c) - 1 and rowtw.shape == (c, nfft // 2 // c) and bhat.size == L and q.size == nfft // 2 // c
 print("tables ok", n)
 """ % (str(ROOT), str(ROOT / "tests"), str(lib))
     out = _child(["-c", code], _runtime("libasan.so"))
