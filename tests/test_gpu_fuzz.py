@@ -394,6 +394,15 @@ def test_hip_matches_oracle_on_random_smooth_size(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [800, 960, 720, 880, 1600, 1920, 2000, 1760])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_automatic_sizes_with_compile_time_plans(n, seed):
+    """The sizes the plugin picks by itself (sample_rate / fps & -16; reference src/source.cpp:1161-1166) run their mixed-radix plan as
+    compile-time constants (mr_transform_fixed, wf_mixed.hpp): each of them through drawn scenarios of the smooth family"""
+    run_spectrum_case(7000 + 10 * seed + n, "smooth", fft_size=n)
+
+
+@pytest.mark.gpu
 def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
     import waveform_amd as wf
     for n, mixed in ((800, True), (1600, True), (960, True), (8000, True), (16320, True), (16336, False), (4160, True), (1760, True), (1456, True), (1824, True), (1088, True), (1472, True), (464, True), (4144, True), (7808, True), (8128, False), (2096, False), (13456, False), (144, True), (15552, True)):

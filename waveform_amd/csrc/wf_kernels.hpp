@@ -76,6 +76,9 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 #ifndef WF_WPS_2048_BLU
 #define WF_WPS_2048_BLU 4 // (+3-4 % over three waves and no scratch, measured: 52 B of scratch per lane weigh less than a fourth wave) the Bluestein instantiation of the same geometry (fft sizes 528 ... 1008, the automatic size 800 among them)
 #endif
+#ifndef WF_MR_FIXED_PLANS
+#define WF_MR_FIXED_PLANS 1 // 0: every mixed-radix size through the run-time plan (A/B)
+#endif
 #ifndef WF_WPS_2048_MRS
 #define WF_WPS_2048_MRS 5 // 96 registers, 12 B of scratch per lane
 #endif
@@ -361,7 +364,28 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     if constexpr(BLU && MR) {
         // FFT sizes with no prime factor above 5: the n/2-point transform itself, two to four mixed-radix passes between the two
         // halves of the exchange buffer (wf_mixed.hpp) instead of Bluestein's two power-of-two transforms
-        mr_transform<G, MRS>(a.mr, process, (int)a.row_bins, t, lds, tw2_lds, [] { spectrum_sync<G>(); }); // (tw2_lds: the prime pass's W_p^m, staged where the power-of-two kernels keep their pass-2 twiddles: TickArgs::tw2 points at it)
+        // The sizes the plugin picks by itself (sample_rate / fps & -16 at 48 and 44.1 kHz, 60 / 50 / 30 / 25 / 24 fps) run their plan as
+        // compile-time constants (mr_transform_fixed): N = 800 0.430 -> 0.462 of the HBM peak at 8192 streams, 0.316 -> 0.358 at 2048.
+        auto plan_is = [&](int r0, int r1, int r2) { return a.mr.passes == 3 && a.mr.radix[0] == r0 && a.mr.radix[1] == r1 && a.mr.radix[2] == r2; };
+        auto sp_sync = [] { spectrum_sync<G>(); };
+        if(MRS && WF_MR_FIXED_PLANS && G::N == 2048 && plan_is(5, 10, 8)) // 800
+            mr_transform_fixed<G, 5, 10, 8>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 2048 && plan_is(5, 12, 8)) // 960
+            mr_transform_fixed<G, 5, 12, 8>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 2048 && plan_is(10, 6, 6)) // 720
+            mr_transform_fixed<G, 10, 6, 6>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 2048 && plan_is(11, 5, 8)) // 880
+            mr_transform_fixed<G, 11, 5, 8>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 4096 && plan_is(10, 8, 10)) // 1600
+            mr_transform_fixed<G, 10, 8, 10>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 4096 && plan_is(10, 8, 12)) // 1920
+            mr_transform_fixed<G, 10, 8, 12>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 4096 && plan_is(10, 10, 10)) // 2000
+            mr_transform_fixed<G, 10, 10, 10>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 4096 && plan_is(10, 8, 11)) // 1760
+            mr_transform_fixed<G, 10, 8, 11>(a.mr, process, t, lds, sp_sync);
+        else
+            mr_transform<G, MRS>(a.mr, process, (int)a.row_bins, t, lds, tw2_lds, [] { spectrum_sync<G>(); }); // (tw2_lds: the prime pass's W_p^m, staged where the power-of-two kernels keep their pass-2 twiddles: TickArgs::tw2 points at it)
     } else {
         if constexpr(TLDS) {
             cf o1[G::R1][G::B1];

@@ -478,4 +478,22 @@ template<class G, bool SMALL = false, class Sync> WF_DEV void mr_transform(const
     sync();
 }
 
+// A plan known at compile time (three passes R0 x R1 x R2): the same pass functions with every length, stride and trip count a
+// constant -- the divisions by the stride become multiplications, the loops over a thread's butterflies unroll, no dispatch on the
+// radix.  For the sizes the plugin picks by itself (sample_rate / fps & -16).
+template<class G, int R0, int R1, int R2, class Sync> WF_DEV void mr_transform_fixed(const MrPlan &p, bool process, int t, cf *lds, Sync sync)
+{
+    constexpr int np = R0 * R1 * R2;
+    constexpr int H = (np + 15) & ~15; // wf::mr_exchange_half
+    sync();
+    if(process)
+        mr_pass_r<R0, false>(lds, lds + H, nullptr, np, 1, t, G::T);
+    sync();
+    if(process)
+        mr_pass_r<R1, true>(lds + H, lds, p.tw, np, R0, t, G::T);
+    sync();
+    mr_last_r<R2>(process, lds, p.tw + R1 * R0, R0 * R1, t, sync, [lds, &p](int k, cf v) { lds_st2(lds, mr_z_addr(p, k), v); });
+    sync();
+}
+
 } // namespace wf
