@@ -141,8 +141,7 @@ template<class G, int C> int launch_tick_big_br(wf_hip *h, const wf::TickArgs &a
 
 template<int C> int launch_tick_big_br_g(wf_hip *h, const wf::TickArgs &a)
 {
-    switch(h->br_l) {
-    case 1024u: return launch_tick_big_br<wf::G2048, C>(h, a);
+    switch(h->br_l) { // (16 rows: 2048 points up to n = 32768, 4096 above; 8 rows: 4096 / 8192)
     case 2048u: return launch_tick_big_br<wf::G4096, C>(h, a);
     case 4096u: return launch_tick_big_br<wf::G8192, C>(h, a);
     default: return launch_tick_big_br<wf::G16384, C>(h, a);
@@ -150,7 +149,7 @@ template<int C> int launch_tick_big_br_g(wf_hip *h, const wf::TickArgs &a)
 }
 int launch_tick_big_br_c(wf_hip *h, const wf::TickArgs &a)
 {
-    return h->big_rows == 32u ? launch_tick_big_br_g<32>(h, a) : h->big_rows == 16u ? launch_tick_big_br_g<16>(h, a) : launch_tick_big_br_g<8>(h, a);
+    return h->big_rows == 16u ? launch_tick_big_br_g<16>(h, a) : launch_tick_big_br_g<8>(h, a);
 }
 
 void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
@@ -207,8 +206,6 @@ int setup_launch_big(wf_hip *h)
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_mr_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)((size_t)(wf::GBig::LDS_CF + 128) * sizeof(wf::cf))));
     else if(h->big_br) {
-        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G2048>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)wf::big_br_lds_bytes<wf::G2048>()));
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G4096>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)wf::big_br_lds_bytes<wf::G4096>()));
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G8192>), hipFuncAttributeMaxDynamicSharedMemorySize,

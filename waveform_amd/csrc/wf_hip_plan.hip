@@ -144,13 +144,14 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
 #endif
             // C = 16 where it divides n/2 (every multiple of 32), else 8: the smaller the container the more workgroups a CU holds --
             // 48064 x 256 streams 0.254 ms with 8 rows over 8192 points, 0.194 with 16 over 4096, 0.209 with 32 over 2048
+            // (32 rows over 1024 / 2048 points: 0.209 -- profiles/r05m_bluestein_rows_ab.txt; not compiled in any more)
             uint32_t br_c = 0, br_first = 16u;
 #ifdef WF_DEV_OVERRIDES
-            if(const char *e = std::getenv("WF_HIP_BR_ROWS"))
-                br_first = (uint32_t)std::atoi(e);
+            if(const char *e = std::getenv("WF_HIP_BR_ROWS")) // 8: every size on 8 rows (A/B)
+                br_first = std::atoi(e) == 8 ? 8u : 16u;
 #endif
             for(uint32_t c = br_first; c >= 8u && !br_c && rows_ok; c >>= 1)
-                if(np % c == 0 && np / c <= 4096u && np / c >= 256u)
+                if(np % c == 0 && np / c <= 4096u && np / c >= 512u)
                     br_c = c;
             for(uint32_t c = 2; c <= 8 && !h->big_mr; ++c) {
                 if(np % c || np / c > 8192u)
@@ -174,7 +175,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 h->blu = false; // (as above: the plain packed real transform, its rows by chirp-z)
                 h->big_l = np;
                 h->big_rows = br_c;
-                h->br_l = 1024u; // (build_bluestein_rows' container length)
+                h->br_l = 2048u; // (build_bluestein_rows' container length for rows of more than 512 points)
                 while(h->br_l < 2u * (np / br_c) - 1u)
                     h->br_l <<= 1;
                 h->br_rs = (np / br_c + 1u) & ~1u;
