@@ -32,8 +32,9 @@
  * FFT sizes: every multiple of 16 from 128 to 65536, the reference's own range with "enable large FFT" (src/source.cpp:349,
  * :359-363, :562-565).  Powers of two up to 32768 and the other sizes up to 16384 -- as a mixed-radix transform where the
  * size has small prime factors and at most one prime factor of up to 127 (the automatic sizes, 114 of the slider's 120
- * positions that are not powers of two), by Bluestein's algorithm otherwise -- run inside one fused kernel; 65536 and the other
- * sizes above 16384 take their transform through device memory in two steps (wf_big.hpp: 1-33 % of the HBM roofline).
+ * positions that are not powers of two), by Bluestein's algorithm otherwise -- run inside one fused kernel; 65536 runs in one
+ * kernel of its own; the other sizes above 16384 as rows of n/2 = C R points with one complex scratch buffer in device memory
+ * (wf_big.hpp: rows of a mixed-radix transform, or rows by Bluestein inside LDS; 12-21 % of the HBM roofline).
  * Anything else -> WF_HIP_ERR_UNSUPPORTED.
  *
  * Waveform display.  A handle created from a configuration with cfg.waveform != 0 is a *waveform batch*: wf_hip_tick runs
@@ -76,7 +77,7 @@ extern "C" {
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
     WF_HIP_ERR_INVALID = -1,     /* bad argument / configuration */
-    WF_HIP_ERR_UNSUPPORTED = -2, /* legal for the reference, not implemented here (e.g. non power-of-two FFT size) */
+    WF_HIP_ERR_UNSUPPORTED = -2, /* legal for the reference, not implemented here (e.g. a waveform display wider than 8192 points) */
     WF_HIP_ERR_NO_DEVICE = -3,   /* no usable HIP device */
     WF_HIP_ERR_RUNTIME = -4,     /* a HIP call failed; see wf_hip_last_error */
     WF_HIP_ERR_NOMEM = -5
