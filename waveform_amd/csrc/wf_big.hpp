@@ -949,10 +949,39 @@ __global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
     const int wave = t >> 6, lane = t & 63;
     float *part = filtered ? wl + size : dbl; // [num_tasks] partial sums, behind the filter's staging
     for(int task = wave; task < b.big_num_tasks; task += T / 64) {
-        const int e0 = b.big_task[3 * task + 1], e1 = b.big_task[3 * task + 2];
-        // eight of a lane's (index, coefficient, bin) triples in flight at a time instead of one dependent chain per entry
+        const int e0 = b.big_task[4 * task + 1], e1 = b.big_task[4 * task + 2], bin0 = b.big_task[4 * task + 3];
         float acc = 0.0f;
         int e = e0 + lane;
+        if(bin0 >= 0) {
+            // (wave-uniform) consecutive bins: coefficient and bin of an entry are requested together -- one trip to the L2 per batch
+            // instead of two, sixteen entries of a lane in flight; the sums are formed in the same order as below
+            const float *rw = row + (bin0 - e0);
+            for(; e + 15 * 64 < e1; e += 16 * 64) {
+                float cv[16], rv[16];
+#pragma unroll
+                for(int i = 0; i < 16; ++i) {
+                    cv[i] = b.coef[e + 64 * i];
+                    rv[i] = rw[e + 64 * i];
+                }
+#pragma unroll
+                for(int i = 0; i < 16; ++i)
+                    acc = fmaf(rv[i], cv[i], acc);
+            }
+            for(; e + 3 * 64 < e1; e += 4 * 64) {
+                float cv[4], rv[4];
+#pragma unroll
+                for(int i = 0; i < 4; ++i) {
+                    cv[i] = b.coef[e + 64 * i];
+                    rv[i] = rw[e + 64 * i];
+                }
+#pragma unroll
+                for(int i = 0; i < 4; ++i)
+                    acc = fmaf(rv[i], cv[i], acc);
+            }
+            for(; e < e1; e += 64)
+                acc = fmaf(rw[e], b.coef[e], acc);
+        }
+        // (else) eight of a lane's (index, coefficient, bin) triples in flight at a time instead of one dependent chain per entry
         for(; e + 7 * 64 < e1; e += 8 * 64) {
             int bi[8];
             float cv[8], rv[8];

@@ -495,22 +495,33 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             h->big_num_tasks = 0;
             if(!h->curve && !h->tab.bar_off.empty()) {
                 std::vector<int> task, bar_task(h->tab.bar_off.size(), 0);
+                int cap = 2048;
+#ifdef WF_DEV_OVERRIDES
+                if(const char *e = std::getenv("WF_HIP_BIG_TASK")) // (development: the task size, a multiple of 64)
+                    cap = std::max(64, std::atoi(e) & ~63);
+#endif
                 for(size_t bq = 0; bq + 1 < h->tab.bar_off.size(); ++bq) {
-                    bar_task[bq] = (int)(task.size() / 3);
+                    bar_task[bq] = (int)(task.size() / 4);
                     const int e0 = h->tab.bar_off[bq], e1 = h->tab.bar_off[bq + 1];
-                    const int parts = std::max(1, (e1 - e0 + 2047) / 2048);
+                    const int parts = std::max(1, (e1 - e0 + cap - 1) / cap);
                     const int per = (((e1 - e0 + parts - 1) / parts) + 63) & ~63;
                     for(int q = 0; q < parts; ++q) {
                         const int lo = std::min(e0 + q * per, e1), hi = std::min(lo + per, e1);
                         if(q == 0 || lo < hi) {
+                            // a task whose entries walk consecutive bins (every bar of an interpolated display does: a band and its
+                            // taps) says where it starts: the kernel then forms the bins' addresses instead of loading them first
+                            bool run = lo < hi;
+                            for(int e = lo + 1; e < hi && run; ++e)
+                                run = h->tab.bar_bin[(size_t)e] == h->tab.bar_bin[(size_t)lo] + (e - lo);
                             task.push_back((int)bq);
                             task.push_back(lo);
                             task.push_back(hi);
+                            task.push_back(run ? h->tab.bar_bin[(size_t)lo] : -1);
                         }
                     }
                 }
-                bar_task.back() = (int)(task.size() / 3);
-                h->big_num_tasks = (int)(task.size() / 3);
+                bar_task.back() = (int)(task.size() / 4);
+                h->big_num_tasks = (int)(task.size() / 4);
                 WF_PLAN_TRY(upload(h, &h->d_big_task, task));
                 WF_PLAN_TRY(upload(h, &h->d_big_bar_task, bar_task));
                 WF_PLAN_HIP(hipStreamSynchronize(h->stream));

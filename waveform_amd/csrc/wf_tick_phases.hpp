@@ -59,7 +59,7 @@ struct BarArgs {
     const int *chunk;          // [num_chunks + 1] bar ranges whose entries fit the LDS scratch together
     // big_outputs_kernel (wf_big.hpp): the entries cut into tasks of at most 2048, one wavefront each -- a bar at the top of a log
     // axis owns half the row, and one wavefront walking it alone was the kernel's whole duration
-    const int *big_task;       // [num_tasks][3] bar, first entry, one past the last entry
+    const int *big_task;       // [num_tasks][4] bar, first entry, one past the last entry, the first entry's bin where the entries walk consecutive bins (else -1)
     const int *big_bar_task;   // [num_bars + 1] the tasks of bar b: [big_bar_task[b], big_bar_task[b + 1])
     int big_num_tasks;
     // Usual case (bars <= threads per spectrum): every thread owns one segment of the entries -- near-equal lengths,
