@@ -784,10 +784,11 @@ __global__ __launch_bounds__(GBig::T, 4) void big_mr_rows_kernel(const TickArgs 
     });
 }
 
-// ---- fft sizes above 16384 whose n/2 has a prime factor no mixed-radix plan takes: big_c rows, each by Bluestein INSIDE LDS ---------
-// (round 5; until then these sizes -- about 300 of the 768 positions of the reference's FFT-size slider above 16384,
+// ---- fft sizes above 16384 with no mixed-radix plan (or one that opens with a prime pass): big_c rows, each by Bluestein INSIDE LDS ---
+// (round 5; until then the sizes without a plan -- about 300 of the 768 positions of the reference's FFT-size slider above 16384,
 // src/source.cpp:359-363 -- ran Bluestein over 3n/2 .. points through device memory: five kernels, 0.01-0.03 of the roofline.)
-// n/2 = C R, C = 8 (or 4): decimation in frequency over the C columns,
+// n/2 = C R, C = 16 for the multiples of 32 (every slider position), 8 for the other multiples of 16: decimation in frequency over
+// the C columns,
 //   a[k1][n2] = (sum_c z[n2 + R c] W_C^(c k1)) W_(n/2)^(n2 k1) conj(w_n2)      (big_br_columns_kernel; w_m = exp(i pi m^2 / R):
 //                                                                             column twiddle and opening chirp are ONE table, big_tw)
 // and the R-point DFT of row k1 -- it delivers Z[k1 + C k2], k2 < R -- by Bluestein over the container geometry G of L = G::M >= 2 R - 1
