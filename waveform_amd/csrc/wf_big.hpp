@@ -956,13 +956,13 @@ __global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
         if(bin0 >= 0) {
             // (wave-uniform) consecutive bins: coefficient and bin of an entry are requested together -- one trip to the L2 per batch
             // instead of two, sixteen entries of a lane in flight; the sums are formed in the same order as below
-            const float *rw = row + (bin0 - e0);
+            const int shift = bin0 - e0; // entry e multiplies bin e + shift
             for(; e + 15 * 64 < e1; e += 16 * 64) {
                 float cv[16], rv[16];
 #pragma unroll
                 for(int i = 0; i < 16; ++i) {
                     cv[i] = b.coef[e + 64 * i];
-                    rv[i] = rw[e + 64 * i];
+                    rv[i] = row[e + shift + 64 * i];
                 }
 #pragma unroll
                 for(int i = 0; i < 16; ++i)
@@ -973,14 +973,14 @@ __global__ __launch_bounds__(GBig::T) void big_outputs_kernel(const TickArgs a)
 #pragma unroll
                 for(int i = 0; i < 4; ++i) {
                     cv[i] = b.coef[e + 64 * i];
-                    rv[i] = rw[e + 64 * i];
+                    rv[i] = row[e + shift + 64 * i];
                 }
 #pragma unroll
                 for(int i = 0; i < 4; ++i)
                     acc = fmaf(rv[i], cv[i], acc);
             }
             for(; e < e1; e += 64)
-                acc = fmaf(rw[e], b.coef[e], acc);
+                acc = fmaf(row[e + shift], b.coef[e], acc);
         }
         // (else) eight of a lane's (index, coefficient, bin) triples in flight at a time instead of one dependent chain per entry
         for(; e + 7 * 64 < e1; e += 8 * 64) {
