@@ -34,7 +34,8 @@
  * size has small prime factors and at most one prime factor of up to 127 (the automatic sizes, 114 of the slider's 120
  * positions that are not powers of two), by Bluestein's algorithm otherwise -- run inside one fused kernel; 65536 runs in one
  * kernel of its own; the other sizes above 16384 as rows of n/2 = C R points with one complex scratch buffer in device memory
- * (wf_big.hpp: rows of a mixed-radix transform, or rows by Bluestein inside LDS; 12-21 % of the HBM roofline).
+ * (wf_big.hpp: rows of a mixed-radix transform -- two rows: in one kernel without scratch --, or rows by Bluestein inside LDS; 12-28 % of
+ * the HBM roofline).
  * Anything else -> WF_HIP_ERR_UNSUPPORTED.
  *
  * Waveform display.  A handle created from a configuration with cfg.waveform != 0 is a *waveform batch*: wf_hip_tick runs

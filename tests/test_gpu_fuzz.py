@@ -409,16 +409,17 @@ def test_smooth_sizes_take_the_mixed_radix_kernel_and_the_others_bluestein():
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 2) as b:
             name = b.kernel_name()
             assert ("mixed radix" in name) == mixed and ("Bluestein" in name) != mixed, (n, name)
-    # above 16384: rows of a mixed-radix transform where n/2 = C R has a plan without a prime pass, else (n a multiple of 16 -- every
+    # above 16384: rows of a mixed-radix transform where n/2 = C R has a plan without a prime pass (two rows: both and the end of the
+    # tick in one kernel), else (n a multiple of 16 -- every
     # position of the reference's slider is one of 64) rows by Bluestein inside LDS (16400 = 2 x 41 x 10 x 10 included).  Every legal size
     # takes one of the two: Bluestein through device memory is left to the development builds' WF_HIP_NO_BLUESTEIN_ROWS=1
-    for n, kernel in ((48000, "big_mr_rows_kernel"), (32000, "big_mr_rows_kernel"), (65520, "big_mr_rows_kernel"), (20480, "big_mr_rows_kernel"),
+    for n, kernel in ((48000, "big_mr_rows_kernel"), (32000, "big_mr_whole_kernel"), (65520, "big_mr_rows_kernel"), (20480, "big_mr_whole_kernel"), (30000, "big_mr_whole_kernel"),
                       (16400, "big_br_{columns,rows}_kernel"), (48016, "big_br_{columns,rows}_kernel"), (33824, "big_br_{columns,rows}_kernel"),
                       (65424, "big_br_{columns,rows}_kernel"), (17488, "big_br_{columns,rows}_kernel")):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 1) as b:
             name = b.kernel_name()
             assert name.startswith(kernel + " ") or name.startswith(kernel + "<"), (n, name)
-            assert ("Bluestein" in name) == (kernel != "big_mr_rows_kernel"), (n, name)
+            assert ("Bluestein" in name) == (not kernel.startswith("big_mr_")), (n, name)
     # 16 rows where n/2 is a multiple of 16 (every slider position), 8 for the other multiples of 16; the container: >= 2 R - 1 points
     for n, rows, r, container in ((48064, 16, 1502, 4096), (65472, 16, 2046, 4096), (32704, 16, 1022, 2048), (17488, 8, 1093, 4096), (48016, 8, 3001, 8192)):
         with wf.SpectrumBatch(wf.Config.defaults(fft_size=n), 1) as b:

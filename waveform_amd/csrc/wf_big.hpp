@@ -784,6 +784,131 @@ __global__ __launch_bounds__(GBig::T, 4) void big_mr_rows_kernel(const TickArgs 
     });
 }
 
+// ---- fft sizes above 16384 whose n/2 is TWO rows of a mixed-radix transform: one kernel, as for 65536 --------------------------------
+// n/2 = 2 R, R <= 8192 with a plan on 512 threads.  What big_whole_kernel does with two 16384-point power-of-two rows, with the rows
+// transformed by wf_mixed.hpp's passes: ONE pass over the window forms row 0's inputs u0 + u1 (into the exchange buffer, natural
+// order) and row 1's (u0 - u1) W_(n/2)^n2 (16 complex per thread, in registers while row 0 is transformed); row k1 delivers the bins
+// of parity k1 and the real split pairs bin k with bin n/2 - k -- the same parity --, so each row is split right behind its transform
+// into the four-bin groups of the row layout (row k1's k2 = 2 (t + T u) + h is bin 4 (t + T u) + 2 h + k1); big_finish ends the
+// tick from those registers.  No scratch in device memory, one kernel instead of rows + epilogue (85 of the slider's positions:
+// 16448 ... 32704).
+template<class RG, bool TS, bool FPK> WF_DEV void p4_part_impl(const TickArgs &a, int t, float *ts, int nb, float (&mag)[RG::P])
+{
+    constexpr int NBT = WF_WHOLE_BATCH; // (as p4_whole_impl, on a row that need not fill the layout: groups at or beyond nb sit out)
+    static_assert((RG::P / 4) % NBT == 0);
+#pragma unroll
+    for(int u0 = 0; u0 < RG::P / 4; u0 += NBT) {
+        f4 sv[NBT], st[NBT];
+#pragma unroll
+        for(int i = 0; i < NBT; ++i) {
+            const int k0 = 4 * (t + RG::T * (u0 + i)), at = k0 < nb ? k0 : 0;
+            sv[i] = ld4(a.slope + at);
+            st[i] = TS ? ld_state(ts + at) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for(int i = 0; i < NBT; ++i) {
+            const float sl4[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w}, st4v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+            if(4 * (t + RG::T * (u0 + i)) < nb)
+                p4_slope_smooth_group<RG, TS, FPK>(a, t, u0 + i, ts, st4v, sl4, mag);
+        }
+    }
+}
+// bins of parity K1 from row K1's transform (Z_row[k2] at mr_z_addr): out[4 u + 2 h + K1] for k2 = 2 (t + T u) + h < R
+template<int T, int K1, int RP> WF_DEV void big_mrw_split(const TickArgs &a, int t, int R, const cf *lds, float (&out)[RP])
+{
+#pragma unroll
+    for(int u = 0; u < RP / 4; ++u) {
+#pragma unroll
+        for(int h = 0; h < 2; ++h) {
+            const int k2 = 2 * (t + T * u) + h;
+            if(k2 < R) {
+                const int k = 2 * k2 + K1;
+                const int km = K1 ? R - 1 - k2 : (k2 == 0 ? 0 : R - k2); // (n/2 - k) / 2 within the row; Z[n/2] is Z[0]
+                const cf A = lds_ld2(lds, mr_z_addr(a.mr, k2)), B = lds_ld2(lds, mr_z_addr(a.mr, km));
+                const f2 w = ld2(reinterpret_cast<const float *>(a.big_tws + k));
+                const float er = A.x + B.x, ei = A.y - B.y;
+                const float dr = A.x - B.x, di = A.y + B.y;
+                const float pr = fmaf(w.x, dr, -(w.y * di));
+                const float pi = fmaf(w.x, di, w.y * dr);
+                out[4 * u + 2 * h + K1] = mag2(er + pi, ei - pr) * a.half_coef;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(GFold::T, GFold::T / 256) void big_mr_whole_kernel(const TickArgs a)
+{
+    using G = GFold;                 // (1024 threads of 8 points: 46 registers spilled at the 128 four waves per SIMD leave, 0.074 -> 0.090 ms at 32000)
+    constexpr int T = G::T, PT = 16; // 16 points per thread and row: R <= 8192
+    using RG = RowG<T, 32>;          // 16384 bins: n / 2 <= 16384
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    cf *lds = reinterpret_cast<cf *>(big_smem);
+    const int t = (int)threadIdx.x;
+    uint32_t spec = a.stream_base * a.cap_ch + blockIdx.x;
+    if(a.split_ch != 0xffffffffu)
+        spec = 2u * (a.stream_base + blockIdx.x) + a.split_ch;
+    const uint32_t cap_shift = a.cap_ch - 1u;
+    const uint32_t stream = spec >> cap_shift, ch = spec & cap_shift;
+    const uint32_t delay = a.delay + (a.delay_stream ? a.delay_stream[stream] : 0u);
+    const uint32_t start = (a.wpos[stream] - delay - a.blu_n) & a.ring_mask;
+    const float *x = a.ring + (size_t)spec * a.ring_stride;
+    const int R = (int)a.big_r;
+    cf *wp_lds = lds + 2 * a.mr.half; // behind the exchange buffer: the prime pass's W_p^m
+    if(a.mr.radix[0] > 25 && t < a.mr.radix[0])
+        wp_lds[t] = a.mr.wp[t];
+    cf r1[PT];
+    uint32_t acc = 0;
+#pragma unroll
+    for(int i = 0; i < PT; ++i) {
+        const int n2 = t + T * i;
+        const bool in = n2 < R;
+        const uint32_t j0 = in ? (uint32_t)n2 : 0u, j1 = j0 + (uint32_t)R, s0 = start + 2u * j0, s1 = start + 2u * j1;
+        const float x00 = x[s0 & a.ring_mask], x01 = x[(s0 + 1u) & a.ring_mask], x10 = x[s1 & a.ring_mask], x11 = x[(s1 + 1u) & a.ring_mask];
+        const f2 w0 = ld2(a.window + 2u * j0), w1 = ld2(a.window + 2u * j1);
+        const f2 q = ld2(reinterpret_cast<const float *>(a.big_tw + (size_t)R + j0)); // W_(n/2)^n2: row 1 of the column twiddles
+        acc |= f32_bits(x00) | f32_bits(x01) | f32_bits(x10) | f32_bits(x11);
+        const cf u0 = cf{x00 * w0.x, x01 * w0.y}, u1 = cf{x10 * w1.x, x11 * w1.y};
+        r1[i] = cmul(csub(u0, u1), cf{q.x, q.y});
+        if(in)
+            lds_st2(lds, n2, cadd(u0, u1));
+    }
+    float mag[RG::P];
+#pragma unroll
+    for(int i = 0; i < RG::P; ++i)
+        mag[i] = 0.0f;
+    mr_transform<G>(a.mr, true, R, t, lds, wp_lds, [] { __syncthreads(); });
+    big_mrw_split<T, 0>(a, t, R, lds, mag);
+    __syncthreads(); // every thread has read row 0's Z: row 1's inputs may go in
+#pragma unroll
+    for(int i = 0; i < PT; ++i)
+        if(t + T * i < R)
+            lds_st2(lds, t + T * i, r1[i]);
+    mr_transform<G>(a.mr, true, R, t, lds, wp_lds, [] { __syncthreads(); });
+    big_mrw_split<T, 1>(a, t, R, lds, mag);
+    // x != 0.0f for any sample of the window (reference :63-72), the partner channel as in big_whole_kernel
+    const bool nz_own = __syncthreads_or((acc & 0x7fffffffu) != 0u) != 0;
+    bool nz_other = false;
+    if(a.cap_ch > 1 && !nz_own) {
+        const float *xo = a.ring + (size_t)(spec ^ 1u) * a.ring_stride;
+        uint32_t o = 0;
+        for(uint32_t i = (uint32_t)t; i < a.blu_n; i += (uint32_t)T)
+            o |= f32_bits(xo[(start + i) & a.ring_mask]);
+        nz_other = __syncthreads_or((o & 0x7fffffffu) != 0u) != 0;
+    }
+    const int nb = (int)a.row_bins;
+    big_finish<RG>(a, t, 0, spec, ch == 0 ? nz_own : nz_other, ch == 0 ? nz_other : nz_own, [&](float *ts, float (&m)[RG::P]) {
+#pragma unroll
+        for(int i = 0; i < RG::P; ++i)
+            m[i] = mag[i];
+        if(a.mode & WF_MODE_TSMOOTH) {
+            if(a.mode & WF_MODE_FAST_PEAKS)
+                p4_part_impl<RG, true, true>(a, t, ts, nb, m);
+            else
+                p4_part_impl<RG, true, false>(a, t, ts, nb, m);
+        } else
+            p4_part_impl<RG, false, false>(a, t, ts, nb, m);
+    });
+}
+
 // ---- fft sizes above 16384 with no mixed-radix plan (or one that opens with a prime pass): big_c rows, each by Bluestein INSIDE LDS ---
 // (round 5; until then the sizes without a plan -- about 300 of the 768 positions of the reference's FFT-size slider above 16384,
 // src/source.cpp:359-363 -- ran Bluestein over 3n/2 .. points through device memory: five kernels, 0.01-0.03 of the roofline.)

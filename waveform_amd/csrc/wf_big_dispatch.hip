@@ -92,6 +92,24 @@ template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
 
 #endif // WF_DEV_OVERRIDES
 
+// fft sizes above 16384 whose n/2 is two rows of a mixed-radix transform: both rows and the end of the tick in one workgroup
+// (wf_big.hpp: big_mr_whole_kernel)
+int launch_tick_big_mrw(wf_hip *h, const wf::TickArgs &a0)
+{
+    hipStream_t st = h->launch_stream;
+    const size_t lds = (size_t)(2 * a0.mr.half + 128) * sizeof(wf::cf);
+    for(int pass = 0; pass < (h->split_mono ? 2 : 1); ++pass) { // mono mixdown: channel 1 of every stream, then channel 0
+        wf::TickArgs a = a0;
+        a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
+        const dim3 grid(h->split_mono ? a.stream_count : a.stream_count * a.cap_ch);
+        hipLaunchKernelGGL(wf::big_mr_whole_kernel, grid, dim3(wf::GFold::T), lds, st, a);
+    }
+    if(a0.bar.out != nullptr)
+        hipLaunchKernelGGL(wf::big_outputs_kernel, dim3(a0.stream_count * a0.bar.disp_ch), dim3(wf::GBig::T), h->big_out_lds, st, a0);
+    WF_HIP_TRY(h, hipGetLastError());
+    return WF_HIP_OK;
+}
+
 // fft sizes above 16384 with small prime factors: rows of a mixed-radix transform (column step folded into the fetch), then the
 // epilogue of the packed real transform (wf_big.hpp)
 int launch_tick_big_mr(wf_hip *h, const wf::TickArgs &a0)
@@ -163,7 +181,7 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
         s.stream_base = a.stream_base + off;
         s.stream_count = std::min(part, a.stream_count - off);
         if(h->big_mr) {
-            h->launch_rc = launch_tick_big_mr(h, s);
+            h->launch_rc = h->big_mrw ? launch_tick_big_mrw(h, s) : launch_tick_big_mr(h, s);
             continue;
         }
         if(h->big_br) {
@@ -202,9 +220,12 @@ namespace wf::host {
 int setup_launch_big(wf_hip *h)
 {
     int rc = WF_HIP_OK;
-    if(h->big_mr)
+    if(h->big_mr) {
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_mr_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)((size_t)(wf::GBig::LDS_CF + 128) * sizeof(wf::cf))));
+        WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_mr_whole_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)((size_t)(wf::GBig::M + 128) * sizeof(wf::cf))));
+    }
     else if(h->big_br) {
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G4096>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)wf::big_br_lds_bytes<wf::G4096>()));
@@ -244,11 +265,12 @@ int setup_launch_big(wf_hip *h)
     char name[256];
     if(h->big_mr) {
         char rad[48];
+        const char *form = h->big_mrw ? "big_mr_whole_kernel<N=%u: both of its %u rows of %u complex points as mixed radix %s and the end of the tick in one workgroup>"
+                                      : "big_mr_rows_kernel + big_epilogue_kernel<N=%u: %u rows of %u complex points as mixed radix %s, column step folded into the fetch>";
         int o = 0;
         for(int i = 0; i < h->mr_passes; ++i)
             o += snprintf(rad + o, sizeof(rad) - (size_t)o, "%s%d", i ? "x" : "", h->mr_radix[i]);
-        snprintf(name, sizeof(name), "big_mr_rows_kernel + big_epilogue_kernel<N=%u: %u rows of %u complex points as mixed radix %s, column step folded into the fetch>",
-                 h->N, h->big_rows, h->M / h->big_rows, rad);
+        snprintf(name, sizeof(name), form, h->N, h->big_rows, h->M / h->big_rows, rad);
     } else if(h->big_br)
         snprintf(name, sizeof(name), "big_br_{columns,rows}_kernel + big_epilogue_kernel<N=%u: %u rows of %u complex points by Bluestein over %u points inside LDS>",
                  h->N, h->big_rows, h->M / h->big_rows, h->br_l);

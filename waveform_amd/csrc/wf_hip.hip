@@ -143,7 +143,8 @@ wf::TickArgs make_args(wf_hip *h, const wf_hip_tick_params *p)
         a.mr.tw = h->d_mr_tw;
         a.mr.wp = h->d_mr_wp;
         a.mr.half = (int)wf::GBig::M / 2; // (the rows kernel's two halves of the 132 KB buffer; its Z goes to device memory)
-        a.mr.s3 = a.mr.lds_cf = 0;
+        a.mr.s3 = h->big_mrw ? a.mr.half / 4 + 4 : 0; // (big_mr_whole_kernel leaves a row's Z in the buffer: mr_z_addr's four planes)
+        a.mr.lds_cf = 0;
         a.big_c = h->big_rows;
         a.big_r = h->M / h->big_rows;
         a.big_wc = h->d_big_wc;

@@ -88,6 +88,7 @@ struct wf_hip {
     // transforms beyond a CU's LDS (wf_big.hpp): big_l = big_rows * 16384 complex points in two steps through device memory
     uint32_t big_l = 0, big_rows = 0;
     bool big_mr = false;             // fft sizes above 16384 with small prime factors: big_rows rows of a mixed-radix transform (big_mr_rows_kernel)
+    bool big_mrw = false;            // ... two rows on 512 threads: both rows and the end of the tick in one kernel (big_mr_whole_kernel), no scratch
     bool big_br = false;             // fft sizes above 16384 with a prime factor no plan takes: big_rows (= 8) rows, each by Bluestein inside LDS (big_br_rows_kernel)
     uint32_t br_rs = 0;              // ... a row's stride in the scratch buffer: M / big_rows rounded up to even
     uint32_t br_l = 0;               // ... over br_l complex points (4096 / 8192: the 8192- / 16384-sample geometry as container)

@@ -153,16 +153,29 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             for(uint32_t c = br_first; c >= 8u && !br_c && rows_ok; c >>= 1)
                 if(np % c == 0 && np / c <= 4096u && np / c >= 512u)
                     br_c = c;
+            bool mrw_ok = true;
+#ifdef WF_DEV_OVERRIDES
+            if(const char *e = std::getenv("WF_HIP_MR_WHOLE")) // 0: two rows through rows + epilogue like the others (A/B)
+                mrw_ok = e[0] != '0';
+#endif
             for(uint32_t c = 2; c <= 8 && !h->big_mr; ++c) {
                 if(np % c || np / c > 8192u)
                     continue;
                 int radix[4] = {0, 0, 0, 0};
-                const int passes = wf::plan_mixed_radix(np / c, 1024u, radix);
+                int passes = 0;
+                bool whole = false;
+                if(c == 2u && mrw_ok) { // two rows: on 512 threads where a plan exists -- one kernel (big_mr_whole_kernel)
+                    passes = wf::plan_mixed_radix(np / c, 512u, radix);
+                    whole = passes > 0;
+                }
+                if(passes <= 0)
+                    passes = wf::plan_mixed_radix(np / c, 1024u, radix);
                 // A plan that opens with a prime pass (29 ... 127: wf::mr_pass_prime, p products per point) loses to the Bluestein rows:
                 // of the slider's 251 such positions 215 are faster there, by up to 40 % (113x8x9: 0.53 -> 0.31 ms at 256 streams), the
                 // other 36 slower by 6 % on average (profiles/r05_sizes_large_before.jsonl)
                 if(passes > 0 && !(br_c && radix[0] > 25)) {
                     h->big_mr = true;
+                    h->big_mrw = whole;
                     h->mr_passes = passes;
                     std::copy(radix, radix + 4, h->mr_radix);
                     h->blu = false;      // no chirp tables, no chirped window: the plain packed real transform
@@ -751,7 +764,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         WF_CREATE_TRY(upload(h, &h->d_big_tw, t1));
         WF_CREATE_TRY(upload(h, &h->d_big_tws, t2));
         WF_CREATE_HIP(hipStreamSynchronize(h->stream));
-        if(h->big_whole) { // (fft_size 65536: no scratch at all, the magnitudes stay in registers)
+        if(h->big_whole || h->big_mrw) { // (fft_size 65536 and the two-row mixed-radix sizes: no scratch at all, the magnitudes stay in registers)
         } else if(h->big_br) { // (columns -> rows in place -> epilogue)
             WF_CREATE_TRY(dev_alloc(h, &h->d_big_z, n_spec * h->big_rows * h->br_rs));
         } else if(h->big_mr) { // (the rows read the ring themselves: one scratch buffer, for Z)
