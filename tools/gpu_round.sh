@@ -26,7 +26,7 @@ WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 4" bash tools/pr
 for J in "plugindefaults:python $R/tools/quick_case.py plugin_defaults" "n32768:python $R/tools/quick_bench.py 32768:512" \
          "n800:python $R/tools/quick_bench.py 800:8192" "n4160:python $R/tools/quick_bench.py 4160:2048" \
          "n65536:python $R/tools/quick_bench.py 65536:256" \
-         "n16400:python $R/tools/quick_bench.py 16400:512" "n48000:python $R/tools/quick_bench.py 48000:256" "n48016:python $R/tools/quick_bench.py 48016:256" \
+         "n16400:python $R/tools/quick_bench.py 16400:512" "n48000:python $R/tools/quick_bench.py 48000:256" "n48016:python $R/tools/quick_bench.py 48016:256" "n32000:python $R/tools/quick_bench.py 32000:256" \
          "meter:python $R/tools/meter_bench.py" "wave:python $R/tools/wave_bench.py"; do
   NAME=${J%%:*}; CMD=${J#*:}
   WF_PMC_SET=short WF_PROFILE_CMD="$CMD" bash tools/profile_gpu.sh ${TAG}_$NAME > /dev/null 2>&1

@@ -23,5 +23,6 @@ S n65536 n65536 big_ 256 65536
 S n16400 n16400 big_ 512 16400
 S n48000 n48000 big_ 256 48000
 S n48016 n48016_bluestein_rows big_ 256 48016
+S n32000 n32000_mixed_radix_whole big_ 256 32000
 S meter meter meter_tick 16384 7200
 S wave wave waveform_tick 65536 800
