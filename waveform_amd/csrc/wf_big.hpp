@@ -862,6 +862,7 @@ __global__ __launch_bounds__(GFold::T, GFold::T / 256) void big_mr_whole_kernel(
         const int n2 = t + T * i;
         const bool in = n2 < R;
         const uint32_t j0 = in ? (uint32_t)n2 : 0u, j1 = j0 + (uint32_t)R, s0 = start + 2u * j0, s1 = start + 2u * j1;
+        // (the pairs as 8-byte requests where the window starts on an even sample: 0.074 -> 0.077 ms at 32000 -- measured, left out)
         const float x00 = x[s0 & a.ring_mask], x01 = x[(s0 + 1u) & a.ring_mask], x10 = x[s1 & a.ring_mask], x11 = x[(s1 + 1u) & a.ring_mask];
         const f2 w0 = ld2(a.window + 2u * j0), w1 = ld2(a.window + 2u * j1);
         const f2 q = ld2(reinterpret_cast<const float *>(a.big_tw + (size_t)R + j0)); // W_(n/2)^n2: row 1 of the column twiddles
@@ -936,13 +937,23 @@ template<int C> __global__ __launch_bounds__(256) void big_br_columns_kernel(con
     const uint32_t n2c = in ? n2 : 0u;
     cf v[C];
     uint32_t acc = 0;
+    if((start & 1u) == 0u) { // (uniform) the window starts on an even sample: a pair is one aligned 8-byte request (it cannot straddle the ring's wrap)
 #pragma unroll
-    for(int c = 0; c < C; ++c) {
-        const uint32_t i = n2c + R * (uint32_t)c, si = start + 2u * i;
-        const float x0 = x[si & a.ring_mask], x1 = x[(si + 1u) & a.ring_mask];
-        const f2 w = ld2(a.window + 2u * i);
-        acc |= f32_bits(x0) | f32_bits(x1);
-        v[c] = cf{x0 * w.x, x1 * w.y};
+        for(int c = 0; c < C; ++c) {
+            const uint32_t i = n2c + R * (uint32_t)c;
+            const f2 xs = ld2(x + ((start + 2u * i) & a.ring_mask)), w = ld2(a.window + 2u * i);
+            acc |= f32_bits(xs.x) | f32_bits(xs.y);
+            v[c] = cf{xs.x * w.x, xs.y * w.y};
+        }
+    } else {
+#pragma unroll
+        for(int c = 0; c < C; ++c) {
+            const uint32_t i = n2c + R * (uint32_t)c, si = start + 2u * i;
+            const float x0 = x[si & a.ring_mask], x1 = x[(si + 1u) & a.ring_mask];
+            const f2 w = ld2(a.window + 2u * i);
+            acc |= f32_bits(x0) | f32_bits(x1);
+            v[c] = cf{x0 * w.x, x1 * w.y};
+        }
     }
     dft_dif<C>(v); // X[k1] in v[brev(k1)]
     if(in) {
