@@ -29,7 +29,7 @@ quick_bench.WARM_MS, quick_bench.TIMED_MS = 12.0, 8.0
 
 
 def family(name: str) -> str:
-    for key, fam in (("big_mr_rows", "mixed-radix rows"), ("big_br_", "Bluestein rows in LDS"), ("big_whole", "one kernel (65536)"),
+    for key, fam in (("big_mr_whole", "mixed radix: two rows in one kernel"), ("big_mr_rows", "mixed-radix rows"), ("big_br_", "Bluestein rows in LDS"), ("big_whole", "one kernel (65536)"),
                      ("big_{columns", "through device memory"), ("spectrum_tick_kernel", "fused tick kernel")):
         if key in name:
             return fam
