@@ -43,7 +43,7 @@ int main(void)
             rc = wf_hip_tick(h, &p);                        /* tick_spectrum + the bar reduction, one kernel launch */
     }
     if(rc == WF_HIP_OK)
-        rc = wf_hip_read_bars(h, 0, STREAMS, tops);
+        rc = wf_hip_read(h, WF_HIP_OUT_BARS, 0, STREAMS, tops);
     if(rc != WF_HIP_OK)
         fprintf(stderr, "wf_hip: %d (%s)\n", rc, wf_hip_last_error(h));
     else

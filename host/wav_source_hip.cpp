@@ -26,36 +26,25 @@ struct HipApi {
     decltype(&wf_hip_push_audio) push_audio = nullptr;
     decltype(&wf_hip_tick) tick = nullptr;
     decltype(&wf_hip_set_hidden) set_hidden = nullptr;
-    decltype(&wf_hip_read_decibels) read_decibels = nullptr;
-    decltype(&wf_hip_read_last_silent) read_last_silent = nullptr;
-    decltype(&wf_hip_read_meter) read_meter = nullptr;
+    decltype(&wf_hip_read) read = nullptr;
+    decltype(&wf_hip_read_async) read_async = nullptr;
+    decltype(&wf_hip_enable_input_rms) enable_input_rms = nullptr;
     decltype(&wf_hip_last_error) last_error = nullptr;
     decltype(&wf_hip_reset) reset = nullptr;
     decltype(&wf_hip_push_audio_ragged_async) push_audio_ragged_async = nullptr;
     decltype(&wf_hip_ingest_done) ingest_done = nullptr;
-    decltype(&wf_hip_read_rows_async) read_rows_async = nullptr;
     decltype(&wf_hip_readback_done) readback_done = nullptr;
     decltype(&wf_hip_set_input_rms) set_input_rms = nullptr;
     decltype(&wf_hip_host_alloc) host_alloc = nullptr;
     decltype(&wf_hip_host_free) host_free = nullptr;
-    decltype(&wf_hip_enable_input_rms_feed) enable_input_rms_feed = nullptr;
     decltype(&wf_hip_push_rms_ragged_async) push_rms_ragged_async = nullptr;
-    decltype(&wf_hip_read_input_rms_async) read_input_rms_async = nullptr;
-    decltype(&wf_hip_read_meter_async) read_meter_async = nullptr;
     decltype(&wf_hip_set_stream_delay) set_stream_delay = nullptr;
     decltype(&wf_hip_set_stream_audio_ts) set_stream_audio_ts = nullptr;
     decltype(&wf_hip_output_channels) output_channels = nullptr;
-    decltype(&wf_hip_read_display_async) read_display_async = nullptr;
-    decltype(&wf_hip_read_premirror) read_premirror = nullptr;
-    decltype(&wf_hip_read_premirror_async) read_premirror_async = nullptr;
-    decltype(&wf_hip_read_bars) read_bars = nullptr;
-    decltype(&wf_hip_read_vertices) read_vertices = nullptr;
-    decltype(&wf_hip_read_vertex_counts) read_vertex_counts = nullptr;
     decltype(&wf_hip_num_vertices) num_vertices = nullptr;
     decltype(&wf_hip_num_bars) num_bars = nullptr;
     decltype(&wf_hip_display_channels) display_channels = nullptr;
     decltype(&wf_hip_ring_frames) ring_frames = nullptr;
-    decltype(&wf_hip_read_waveform_ts) read_waveform_ts = nullptr;
     bool ok = false;
 };
 
@@ -78,36 +67,25 @@ HipApi &api()
         WF_SYM(push_audio)
         WF_SYM(tick)
         WF_SYM(set_hidden)
-        WF_SYM(read_decibels)
-        WF_SYM(read_last_silent)
-        WF_SYM(read_meter)
+        WF_SYM(read)
+        WF_SYM(read_async)
+        WF_SYM(enable_input_rms)
         WF_SYM(last_error)
         WF_SYM(reset)
         WF_SYM(push_audio_ragged_async)
         WF_SYM(ingest_done)
-        WF_SYM(read_rows_async)
         WF_SYM(readback_done)
         WF_SYM(set_input_rms)
         WF_SYM(host_alloc)
         WF_SYM(host_free)
-        WF_SYM(enable_input_rms_feed)
         WF_SYM(push_rms_ragged_async)
-        WF_SYM(read_input_rms_async)
-        WF_SYM(read_meter_async)
         WF_SYM(set_stream_delay)
         WF_SYM(set_stream_audio_ts)
         WF_SYM(output_channels)
-        WF_SYM(read_display_async)
-        WF_SYM(read_premirror)
-        WF_SYM(read_premirror_async)
-        WF_SYM(read_bars)
-        WF_SYM(read_vertices)
-        WF_SYM(read_vertex_counts)
         WF_SYM(num_vertices)
         WF_SYM(num_bars)
         WF_SYM(display_channels)
         WF_SYM(ring_frames)
-        WF_SYM(read_waveform_ts)
 #undef WF_SYM
         // struct wf_config and the entry points above must be the ones this file was compiled against
         auto abi = reinterpret_cast<decltype(&wf_hip_abi_version)>(dlsym(a.lib, "wf_hip_abi_version"));
@@ -153,7 +131,7 @@ uint32_t group_capacity()
 //      being assembled, with its show / hide / timeout state and its m_input_rms.
 // The member that completes the frame -- or one that comes round again while an incomplete batch is waiting -- flushes:
 // state masks and RMS values that changed, ONE ragged ingest (wf_hip_push_audio_ragged_async), ONE wf_hip_tick, ONE
-// readback (wf_hip_read_rows_async); members that did not show up are paused for that tick.  Nothing in a flush waits for
+// readback (wf_hip_read_async); members that did not show up are paused for that tick.  Nothing in a flush waits for
 // the device.
 struct WFHipGroup {
     wf_config cfg{};
@@ -188,7 +166,7 @@ struct WFHipGroup {
     float *bars[2] = {nullptr, nullptr};      // page-locked [capacity][disp_ch][points]
     float *verts[2] = {nullptr, nullptr};     // page-locked [capacity][disp_ch][per_row][4]
     uint32_t *vcounts[2] = {nullptr, nullptr}; // page-locked [capacity][disp_ch]
-    float *pre[2] = {nullptr, nullptr};       // page-locked [capacity][disp_ch]: mirrored axis, the value above the middle before the mirror (wf_hip_read_premirror)
+    float *pre[2] = {nullptr, nullptr};       // page-locked [capacity][disp_ch]: mirrored axis, the value above the middle before the mirror (WF_HIP_OUT_PREMIRROR)
 
     bool create(const wf_config &c, int dev)
     {
@@ -234,7 +212,7 @@ struct WFHipGroup {
         rms.assign(capacity, 0.0f);
         rms_dev.assign(capacity, -1.0f);
         sq_frames.assign(capacity, 0);
-        if(c.normalize_volume && std::getenv("WF_HIP_HOST_RMS") == nullptr && a.enable_input_rms_feed(h) == WF_HIP_OK) {
+        if(c.normalize_volume && std::getenv("WF_HIP_HOST_RMS") == nullptr && a.enable_input_rms(h, 1) == WF_HIP_OK) {
             rms_feed = true;
             sq_max = c.sample_rate & ~15u; // m_input_rms_size: more than a window's worth per frame is never needed
             for(int i = 0; i < 2; ++i) {
@@ -297,13 +275,20 @@ struct WFHipGroup {
         wf_hip_tick_params p{};
         p.seconds = seconds;
         ok = ok && a.tick(h, &p) == WF_HIP_OK;
-        ok = ok && a.read_rows_async(h, 0, capacity, rows[b], silent[b], b) == WF_HIP_OK;
-        if(ok && rms_feed)
-            ok = a.read_input_rms_async(h, 0, capacity, rms_back[b], b) == WF_HIP_OK;
-        if(ok && display)
-            ok = a.read_display_async(h, 0, capacity, bars[b], per_row ? verts[b] : nullptr, per_row ? vcounts[b] : nullptr, b) == WF_HIP_OK;
-        if(ok && display && pre[b])
-            ok = a.read_premirror_async(h, 0, capacity, pre[b], b) == WF_HIP_OK;
+        if(ok) { // the frame: rows + m_last_silent, and behind them what the members draw from one frame later
+            wf_hip_readback dst{};
+            dst.rows = rows[b];
+            dst.last_silent = silent[b];
+            if(rms_feed)
+                dst.input_rms = rms_back[b];
+            if(display) {
+                dst.bars = bars[b];
+                dst.vertices = per_row ? verts[b] : nullptr;
+                dst.vertex_counts = per_row ? vcounts[b] : nullptr;
+                dst.premirror = pre[b];
+            }
+            ok = a.read_async(h, 0, capacity, &dst, b) == WF_HIP_OK;
+        }
         rows_valid[b] = ok;
         ++batch;
         n_submitted = 0;
@@ -445,10 +430,15 @@ struct WFHipMeterGroup {
         wf_hip_tick_params p{};
         p.seconds = seconds;
         ok = ok && a.tick(h, &p) == WF_HIP_OK;
-        if(wave)
-            ok = ok && a.read_rows_async(h, 0, capacity, rows[b], silent[b], b) == WF_HIP_OK;
-        else
-            ok = ok && a.read_meter_async(h, 0, capacity, levels[b], silent[b], b) == WF_HIP_OK;
+        if(ok) {
+            wf_hip_readback dst{};
+            dst.last_silent = silent[b];
+            if(wave)
+                dst.rows = rows[b];
+            else
+                dst.meter = levels[b];
+            ok = a.read_async(h, 0, capacity, &dst, b) == WF_HIP_OK;
+        }
         valid[b] = ok;
         ++batch;
         n_submitted = 0;
@@ -797,7 +787,15 @@ void WAVSourceHIP::render([[maybe_unused]] gs_effect_t *effect)
     // the display modes the device does not draw (level meter: two values; waveform), sources on the CPU path, a frame before
     // the first device result: the reference's own render
     const bool spectrum = !m_meter_mode && m_display_mode != DisplayMode::WAVEFORM;
-    if(!spectrum || !using_hip() || !m_hip_display || !m_hip_display_valid) {
+    // The shader's gradient height / pulse colour follow the smallest y BEFORE the mirror image replaces the upper half
+    // (src/source.cpp:1548-1567, :1411-1424).  Without the Gaussian filter every output above the middle has ONE pre-mirror value
+    // (init_interp clamps their positions to the highest bin, src/source.cpp:857-862), which the device keeps
+    // (WF_HIP_OUT_PREMIRROR).  With the filter on (apply_filter runs before that loop, :1541-1547) outputs half+1 ... half+radius
+    // blend that constant with lower bars and the minimum may sit at any of them: those two render modes then keep the
+    // reference's own loops over m_decibels.
+    const bool miny_on_device = !m_mirror_freq_axis || m_filter_mode == FilterMode::NONE ||
+                                (m_render_mode != RenderMode::GRADIENT && m_render_mode != RenderMode::PULSE);
+    if(!spectrum || !using_hip() || !m_hip_display || !m_hip_display_valid || !miny_on_device) {
         if(spectrum && using_hip())
             g_host_renders.fetch_add(1);
         WAVSourceGeneric::render(effect);
@@ -831,7 +829,7 @@ void WAVSourceHIP::render([[maybe_unused]] gs_effect_t *effect)
     // The shader's gradient height / pulse colour follow the smallest y of the rows BEFORE the mirror image replaces their upper
     // halves (src/source.cpp:1548-1567, :1411-1424).  The device hands back the mirrored rows -- whose upper halves repeat lower
     // values: a strict "<" never picks them -- and, per row, the one value every output above the middle had before the mirror
-    // (wf_hip_read_premirror): first seen at output num_bars / 2 + 1.
+    // (WF_HIP_OUT_PREMIRROR): first seen at output num_bars / 2 + 1.
     const auto half = m_hip_points / 2u;
     for(auto channel = 0u; channel < channels; ++channel) {
         const auto upto = m_mirror_freq_axis ? std::min(half + 1u, m_hip_points) : m_hip_points;
@@ -1103,8 +1101,8 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     p.input_rms = m_input_rms;
     p.flags = 0;
     uint8_t silent = 0;
-    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read_decibels(m_hip, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
-       a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
+    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read(m_hip, WF_HIP_OUT_DECIBELS, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
+       a.read(m_hip, WF_HIP_OUT_LAST_SILENT, 0, 1, &silent) != WF_HIP_OK) {
         LogWarn << "HIP tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
         hip_release();
         g_fallback_ticks.fetch_add(1);
@@ -1116,9 +1114,10 @@ void WAVSourceHIP::tick_spectrum(float seconds)
     m_last_silent = silent != 0;
     if(m_hip_display) {
         // straight into the members render() draws from (no per-tick allocations, no staging copy)
-        if(a.read_bars(m_hip, 0, 1, m_hip_bars.data()) == WF_HIP_OK &&
-           (m_hip_per_row == 0 || (a.read_vertices(m_hip, 0, 1, m_hip_verts.data()) == WF_HIP_OK && a.read_vertex_counts(m_hip, 0, 1, m_hip_vcounts.data()) == WF_HIP_OK)) &&
-           (!m_mirror_freq_axis || a.read_premirror(m_hip, 0, 1, m_hip_pre.data()) == WF_HIP_OK))
+        if(a.read(m_hip, WF_HIP_OUT_BARS, 0, 1, m_hip_bars.data()) == WF_HIP_OK &&
+           (m_hip_per_row == 0 || (a.read(m_hip, WF_HIP_OUT_VERTICES, 0, 1, m_hip_verts.data()) == WF_HIP_OK &&
+                                   a.read(m_hip, WF_HIP_OUT_VERTEX_COUNTS, 0, 1, m_hip_vcounts.data()) == WF_HIP_OK)) &&
+           (!m_mirror_freq_axis || a.read(m_hip, WF_HIP_OUT_PREMIRROR, 0, 1, m_hip_pre.data()) == WF_HIP_OK))
             hip_publish_display();
         else
             m_hip_display_valid = false; // render() goes back to the host loops over m_decibels
@@ -1229,8 +1228,8 @@ void WAVSourceHIP::tick_meter(float seconds)
     p.seconds = seconds;
     float levels[2] = {DB_MIN, DB_MIN};
     uint8_t silent = 0;
-    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read_meter(m_hip, 0, 1, levels) != WF_HIP_OK ||
-       a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
+    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read(m_hip, WF_HIP_OUT_METER, 0, 1, levels) != WF_HIP_OK ||
+       a.read(m_hip, WF_HIP_OUT_LAST_SILENT, 0, 1, &silent) != WF_HIP_OK) {
         LogWarn << "HIP meter tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
         hip_release();
         g_fallback_ticks.fetch_add(1);
@@ -1290,7 +1289,7 @@ void WAVSourceHIP::tick_waveform_batched(float seconds)
             // them (the previous frame's rows) and the sweep position the device kept for it (one 8-byte read that waits for
             // the last batch: this happens once) -- and the group's other members never notice
             uint64_t wts = 0;
-            if(a.read_waveform_ts(g->h, slot, 1, &wts) == WF_HIP_OK)
+            if(a.read(g->h, WF_HIP_OUT_WAVEFORM_TS, slot, 1, &wts) == WF_HIP_OK)
                 m_waveform_ts = (size_t)wts; // (else 0: the reference catches up by itself, src/source_generic.cpp:318-321)
             lock.unlock();
             LogWarn << "HIP waveform batch: this source's A/V-sync reserve (" << reserve << " frames) does not fit the device ring ("
@@ -1434,8 +1433,8 @@ void WAVSourceHIP::tick_waveform(float seconds)
     }
     m_hip_out.resize((size_t)m_output_channels * outsz);
     uint8_t silent = 0;
-    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read_decibels(m_hip, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
-       a.read_last_silent(m_hip, 0, 1, &silent) != WF_HIP_OK) {
+    if(!ok || a.tick(m_hip, &p) != WF_HIP_OK || a.read(m_hip, WF_HIP_OUT_DECIBELS, 0, 1, m_hip_out.data()) != WF_HIP_OK ||
+       a.read(m_hip, WF_HIP_OUT_LAST_SILENT, 0, 1, &silent) != WF_HIP_OK) {
         LogWarn << "HIP waveform tick failed (" << a.last_error(m_hip) << "); falling back to the CPU path";
         hip_release();
         g_fallback_ticks.fetch_add(1);

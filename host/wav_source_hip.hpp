@@ -24,7 +24,7 @@ class WAVSourceHIP : public WAVSourceGeneric
 protected:
     // update_input_rms (src/source.hpp:273; WAVSourceGeneric src/source_generic.cpp:392-403): in batched mode with volume
     // normalisation the squared peaks sync_rms_buffer would consume go to the device, which keeps the one-second window
-    // and its sum per stream (wf_hip_enable_input_rms_feed); otherwise the reference's host loop runs
+    // and its sum per stream (wf_hip_enable_input_rms with feed = 1); otherwise the reference's host loop runs
     void update_input_rms() override;
     void tick_spectrum(float seconds) override;
     void tick_meter(float seconds) override;   // level meter: src/source_generic.cpp:182-269 on the device

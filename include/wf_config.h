@@ -81,11 +81,11 @@ typedef struct wf_config {
     uint32_t waveform;          /* m_display_mode == DisplayMode::WAVEFORM */
     /* vertex fill (the loops of render_bars / render_curve that write the vertex buffer, src/source.cpp:1576-1659, :1436-1461):
      * with vertices != 0 (and bars or curve) every tick also leaves, per displayed channel, the vertices the reference
-     * hands to gs_draw -- wf_hip_read_vertices.  1: filled geometry (bars: two triangles per bar, plus the cap fans with
+     * hands to gs_draw -- WF_HIP_OUT_VERTICES.  1: filled geometry (bars: two triangles per bar, plus the cap fans with
      * rounded_caps; curve: a triangle strip of 2 * width vertices, RenderMode SOLID / GRADIENT / ...); 2: the curve as a
      * line strip of width vertices (RenderMode::LINE); 3: stepped bars (display_mode STEPPED_BAR, :1583-1607): per bar as
      * many step quads of step_width pixels, step_width + step_gap apart, as fit under its height -- the number of
-     * vertices then changes from tick to tick (wf_hip_read_vertex_counts). */
+     * vertices then changes from tick to tick (WF_HIP_OUT_VERTEX_COUNTS). */
     uint32_t vertices;
     int32_t step_width;         /* m_step_width (vertices == 3) */
     int32_t step_gap;           /* m_step_gap */

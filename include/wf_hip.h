@@ -25,8 +25,8 @@
  *                        src/source_avx.cpp:29-200, src/source_avx2.cpp:24-209), plus, when
  *                        the configuration displays bars, the bar reduction of render_bars
  *                        (src/source.cpp:1500-1557; src/filter.hpp:160-211)
- *   wf_hip_read_*        reading m_decibels / m_interp_bufs / m_tsmooth_buf
- *   wf_hip_enable_input_rms / wf_hip_read_input_rms
+ *   wf_hip_read[_async]  reading m_decibels / m_interp_bufs / m_tsmooth_buf / m_meter_val ... (wf_hip_output)
+ *   wf_hip_enable_input_rms
  *                        capture_audio's RMS part + sync_rms_buffer + update_input_rms
  *                        (src/source.cpp:1842-1871, :810-835; src/source_generic.cpp:392-403)
  * FFT sizes: every multiple of 16 from 128 to 65536, the reference's own range with "enable large FFT" (src/source.cpp:349,
@@ -40,16 +40,16 @@
  *
  * Waveform display.  A handle created from a configuration with cfg.waveform != 0 is a *waveform batch*: wf_hip_tick runs
  * WAVSource*::tick_waveform (src/source_generic.cpp:271-390) for every stream -- a history of cfg.width dBFS points per
- * channel, extended by one point per meter_ms / width of newly consumed audio -- and wf_hip_read_decibels returns the rows
+ * channel, extended by one point per meter_ms / width of newly consumed audio -- and WF_HIP_OUT_DECIBELS holds the rows
  * ([count][output_channels][width]; wf_hip_fft_size() == width as m_fft_size does in this mode).  The tick needs
  * wf_hip_tick_params::audio_ts_ns.  Widths up to 8192 points.
  *
  * Level meter.  A handle created from a configuration with cfg.meter != 0 is a *meter batch*: wf_hip_tick runs
  * WAVSource*::tick_meter (src/source_generic.cpp:182-269; AVX src/source_avx.cpp:202-322) for every stream -- the
  * meter buffer is the last wf_hip_fft_size() samples consumed from the device ring, RMS or peak over it, temporal
- * smoothing, dBFS, m_last_silent -- and wf_hip_read_meter / wf_hip_read_bars return m_meter_val and the bars
+ * smoothing, dBFS, m_last_silent -- and WF_HIP_OUT_METER / WF_HIP_OUT_BARS hold m_meter_val and the bars
  * render_bars draws from it (src/source.cpp:1505-1509, :1548-1557).  Spectrum-only entry points
- * (read_decibels, read/write_tsmooth, the table getters) fail with WF_HIP_ERR_INVALID on a meter batch.
+ * (WF_HIP_OUT_DECIBELS, WF_HIP_OUT_TSMOOTH / wf_hip_write_tsmooth, wf_hip_table) fail with WF_HIP_ERR_INVALID on a meter batch.
  *
  * Conventions: plain C types only; every function returns WF_HIP_OK (0) or a negative
  * wf_hip_status, never throws, never aborts; wf_hip_last_error() gives the text.  A handle
@@ -73,7 +73,7 @@
 extern "C" {
 #endif
 
-#define WF_HIP_ABI_VERSION 12
+#define WF_HIP_ABI_VERSION 13
 
 typedef enum wf_hip_status {
     WF_HIP_OK = 0,
@@ -142,11 +142,11 @@ int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const fl
  * stream s, channel c receives wf_synth_noise(seed, stream_id0 + s, c, index0 + i), i < frames. */
 int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, uint32_t stream_id0,
                       uint64_t index0, uint32_t frames);
-/* muted / silent packet: CircularBuffer::push_back_zero (src/source.cpp:1879-1880) */
-int wf_hip_push_silence(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames);
-/* muted packet that still carries samples (muted && !m_ignore_mute): the rings receive zeros, but capture_audio takes the
- * volume-normalisation RMS from the packet itself (src/source.cpp:1842-1871), so the device RMS producer receives
- * `samples`.  Without wf_hip_enable_input_rms this is wf_hip_push_silence. */
+/* muted / silent packet: the rings receive `frames` zeros, CircularBuffer::push_back_zero (src/source.cpp:1879-1880).  `samples`
+ * (layout of wf_hip_push_audio) may be NULL: a packet without data.  A muted packet that still carries samples (muted &&
+ * !m_ignore_mute) passes them: capture_audio takes the volume-normalisation RMS from the packet itself
+ * (src/source.cpp:1842-1871), so the device RMS producer (wf_hip_enable_input_rms) receives them; without the producer they are
+ * not read. */
 int wf_hip_push_audio_muted(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames);
 
 /* ---- the tick ------------------------------------------------------------------------- */
@@ -163,7 +163,7 @@ typedef struct wf_hip_tick_params {
 } wf_hip_tick_params;
 /* bars/curve-only batch mode: skip the m_decibels store (cfg.bars or cfg.curve must be set).  The silence state machine
  * (src/source_generic.cpp:74-95) keeps working: the kernel leaves a one-word verdict per row ("a value > floor - 10") for the
- * next tick's test instead.  After the first such tick, wf_hip_read_decibels returns rows only as fresh as the last tick
+ * next tick's test instead.  After the first such tick, WF_HIP_OUT_DECIBELS holds rows only as fresh as the last tick
  * without the flag that rewrote them.  Mono mixdown of two captured channels stores its (single) row regardless, and so do
  * the batches whose outputs are derived from the stored rows by a kernel of their own (fft sizes beyond a CU's LDS; displays
  * whose Gaussian-filter staging does not fit the tick kernel's on-chip buffer): there the flag is accepted and changes nothing. */
@@ -206,115 +206,124 @@ int wf_hip_set_stream_audio_ts(wf_hip *h, uint32_t first, uint32_t count, const 
  * min(volume_target - dbfs(rms), max_gain) (src/source_generic.cpp:163) is evaluated here, on the host, in float. */
 int wf_hip_set_input_rms(wf_hip *h, uint32_t first, uint32_t count, const float *rms);
 /* Volume normalisation produced on the device: update_input_rms for every stream (src/source_generic.cpp:392-403 with
- * sync_rms_buffer, src/source.cpp:810-835, fed by the RMS part of capture_audio, :1842-1871).  After this call every
+ * sync_rms_buffer, src/source.cpp:810-835, fed by the RMS part of capture_audio, :1842-1871).  feed == 0: after this call every
  * wf_hip_push_* also appends the squared per-frame peak of the captured channels to a per-stream RMS ring, and every
  * wf_hip_tick first recomputes m_input_rms over the m_input_rms_size (= sample_rate & -16) frames that end at the
  * A/V-sync point, as WAVSource::tick does (src/source.cpp:1330-1331); wf_hip_tick_params::input_rms is then ignored and
  * wf_hip_set_input_rms fails.  Needs cfg.normalize_volume (spectrum or waveform batches).  Audio pushed before the call
- * counts as silence. */
-int wf_hip_enable_input_rms(wf_hip *h);
-/* The same producer for hosts that already hold capture_audio's per-frame squared peaks -- the plugin binding: the
+ * counts as silence.
+ * feed != 0: the same producer for hosts that already hold capture_audio's per-frame squared peaks -- the plugin binding: the
  * reference's own capture_audio fills m_rms_sync_buf (src/source.cpp:1842-1871, from the packet even when it is muted),
  * and WAVSourceHIP::update_input_rms (the override of src/source.hpp:273, src/source_generic.cpp:392-403) hands what
  * sync_rms_buffer would move into m_input_rms_buf this tick (src/source.cpp:810-835) to
  * wf_hip_push_rms_ragged_async instead of adding up 48000 floats per source and frame on the host.  The squared-peak
  * ring is then independent of the audio rings' positions; wf_hip_tick recomputes every stream's m_input_rms as above.
- * Mutually exclusive with wf_hip_enable_input_rms. */
-int wf_hip_enable_input_rms_feed(wf_hip *h);
+ * The two forms are mutually exclusive on a handle. */
+int wf_hip_enable_input_rms(wf_hip *h, int feed);
 /* sq: page-locked [count][max_frames] squared peaks, oldest first; frames[count] values are valid per stream (0: that
  * stream's sync_rms_buffer had nothing to consume).  max_frames <= sample_rate & -16.  Shares the ingest slots of
  * wf_hip_push_audio*_async: wf_hip_ingest_done(slot) says when `sq` may be written again. */
 int wf_hip_push_rms_ragged_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_sq, const uint32_t *frames,
                                  uint32_t max_frames, uint32_t slot);
-/* m_input_rms of streams [first, first+count) as of the last tick, copied behind the rows of the slot's
- * wf_hip_read_rows_async (call that first); lands with wf_hip_readback_done(slot) */
-int wf_hip_read_input_rms_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
-/* m_input_rms of streams [first, first+count) as of the last tick */
-int wf_hip_read_input_rms(wf_hip *h, uint32_t first, uint32_t count, float *out);
 /* waits for everything the handle has issued.  With WF_HIP_CANARY=1 in the environment of wf_hip_create every device block of the
  * handle ends in guard bytes, which this call then reads back: a kernel that wrote past a buffer makes it return
  * WF_HIP_ERR_RUNTIME with the block named in wf_hip_last_error (a debugging aid: one small copy per block and sync) */
 int wf_hip_sync(wf_hip *h);
 
 /* ---- results ----------------------------------------------------------------------------- */
-/* m_decibels of streams [first, first+count): [count][output_channels][fft_size/2] */
-int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out);
-/* bar tops / curve points in pixels (m_interp_bufs after the optional Gaussian filter, the dB->y mapping and the mirror of
- * render_bars, src/source.cpp:1535-1564, or render_curve, :1396-1424): [count][display_channels][num_bars] */
-int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out);
-/* Pipelined readback: the bars of the tick(s) enqueued so far are copied into page-locked memory (wf_hip_host_alloc) on the
- * handle's readback stream, without waiting; the following ticks run meanwhile.  `slot` (0 or 1) names the copy for
- * wf_hip_readback_done, which blocks until it has landed.  The device keeps one snapshot per slot, so a later tick does not
- * disturb a copy in flight. */
-int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
+/* What a tick leaves per stream.  One synchronous reader and one pipelined one serve all of them (ABI 13; ABI 12 had a function
+ * per output and per form).  Shapes per stream, in the order the reference's members hold them: */
+typedef enum wf_hip_output {
+    WF_HIP_OUT_DECIBELS = 0,   /* float [output_channels][fft_size/2]        m_decibels (dBFS); not on meter batches */
+    WF_HIP_OUT_BARS,           /* float [display_channels][num_bars]         bar tops / curve points in pixels: m_interp_bufs after the optional
+                                  Gaussian filter, the dB->y mapping and the mirror of render_bars (src/source.cpp:1535-1564) or
+                                  render_curve (:1396-1424) */
+    WF_HIP_OUT_PREMIRROR,      /* float [display_channels]                   cfg.mirror_freq_axis displays: render_bars / render_curve take the
+                                  row's smallest y for the shader (miny / minpos; gradient and pulse render modes) BEFORE the outputs
+                                  above the middle are replaced by images of the lower ones (src/source.cpp:1548-1567, :1411-1424).
+                                  Without the Gaussian filter every output above the middle sits on the clamped top position and has one
+                                  and the same value: that value (output num_bars / 2 + 1 before the mirror).  With it and the BARS rows
+                                  the host finds the reference's miny / minpos without interpolating the row itself.  (With the filter on
+                                  the outputs next to the middle are blends and the value is not enough: the plugin binding keeps the
+                                  reference's own loops for that combination.) */
+    WF_HIP_OUT_VERTICES,       /* float [display_channels][num_vertices][4]  cfg.vertices: x, y, z, w as libobs' vec3 holds them (z = w = 0), the
+                                  vertices render_bars / render_curve write into their vertex buffer (src/source.cpp:1576-1659,
+                                  :1436-1461), produced by every tick from the bars / curve points of that tick */
+    WF_HIP_OUT_VERTEX_COUNTS,  /* uint32 [display_channels]                  stepped bars (cfg.vertices == 3): num_vertices is the buffer's capacity
+                                  per channel (num_bars * 6 * max_steps, create_vbuf src/source.cpp:988-1000); how many of them a tick's
+                                  draw call uses -- gs_draw(GS_TRIS, 0, vertpos), :1663; vertices beyond it are whatever earlier ticks
+                                  left, as in the reference's buffer */
+    WF_HIP_OUT_LAST_SILENT,    /* uint8                                      m_last_silent */
+    WF_HIP_OUT_TSMOOTH,        /* float [capture_channels][fft_size/2]       m_tsmooth_buf (spectrum batches) */
+    WF_HIP_OUT_METER,          /* float [capture_channels]                   meter batches: m_meter_val (dBFS) */
+    WF_HIP_OUT_INPUT_RMS,      /* float                                      m_input_rms as of the last tick (wf_hip_enable_input_rms) */
+    WF_HIP_OUT_WAVEFORM_TS     /* uint64                                     waveform batches: m_waveform_ts (src/source.hpp:135, the timestamp of
+                                  the next point the sweep will draw, ns) -- what a source needs to continue the sweep on the host
+                                  (src/source_generic.cpp:318-353) when it leaves a batch */
+} wf_hip_output;
+/* bytes per stream of an output of this batch (0: the batch has no such output) */
+size_t wf_hip_output_bytes(const wf_hip *h, wf_hip_output what);
+/* `what` of streams [first, first+count) as the ticks issued so far leave it, into `out` ([count] x the shape above); waits for
+ * those ticks.  WF_HIP_ERR_INVALID when the batch has no such output (wf_hip_last_error says why). */
+int wf_hip_read(wf_hip *h, wf_hip_output what, uint32_t first, uint32_t count, void *out);
+/* m_tsmooth_buf written back (state restore; layout of WF_HIP_OUT_TSMOOTH) */
+int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in);
+/* Pipelined readback: what the ticks issued so far leave for streams [first, first+count) is copied into page-locked memory
+ * (wf_hip_host_alloc) on the handle's readback stream, without waiting; the following ticks run meanwhile.  `slot` (0 or 1) names
+ * the copy for wf_hip_readback_done, which blocks until everything of it has landed.  Every destination is [count] x the shape
+ * of the output of that name; a NULL pointer leaves that output out.  Three combinations:
+ *  - rows (+ last_silent, both required) and any of bars / premirror / vertices / vertex_counts / input_rms behind them: the
+ *    plugin binding's frame (its render() override draws from them one frame later).  The copies read the handle's own
+ *    buffers: the next wf_hip_tick waits (on the device, not the host) for a copy still in flight before it overwrites them.
+ *  - bars alone: the device keeps one snapshot per slot (a device copy of a few MB at most behind the ticks), so a later tick
+ *    neither waits for nor disturbs a copy in flight (bench.py's host-fed leg).
+ *  - meter + last_silent (meter batches; both required): snapshots as well -- the plugin's batched mode reads every source's
+ *    level one video frame late. */
+typedef struct wf_hip_readback {
+    float *rows;             /* WF_HIP_OUT_DECIBELS */
+    uint8_t *last_silent;    /* WF_HIP_OUT_LAST_SILENT */
+    float *bars;             /* WF_HIP_OUT_BARS */
+    float *premirror;        /* WF_HIP_OUT_PREMIRROR */
+    float *vertices;         /* WF_HIP_OUT_VERTICES */
+    uint32_t *vertex_counts; /* WF_HIP_OUT_VERTEX_COUNTS */
+    float *input_rms;        /* WF_HIP_OUT_INPUT_RMS */
+    float *meter;            /* WF_HIP_OUT_METER */
+} wf_hip_readback;
+int wf_hip_read_async(wf_hip *h, uint32_t first, uint32_t count, const wf_hip_readback *dst, uint32_t slot);
 int wf_hip_readback_done(wf_hip *h, uint32_t slot);
-/* Pipelined readback of what the ticks issued so far leave in m_decibels and m_last_silent of streams [first, first+count):
- * rows [count][output_channels][fft_size/2] and one byte per stream into page-locked memory, on the readback stream;
- * wf_hip_readback_done(slot) blocks until both have landed.  The next wf_hip_tick waits (on the device, not the host) for a
- * copy still in flight before it overwrites the rows. */
-int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_rows, uint8_t *pinned_last_silent, uint32_t slot);
-/* What render_bars / render_curve would derive from those rows (src/source.cpp:1378-1425, :1500-1567) and write into the vertex
- * buffer (:1436-1461, :1576-1659), as the ticks issued so far leave it for streams [first, first+count): the bar tops / curve
- * points ([count][display_channels][num_bars], pixels), with cfg.vertices the vertices ([count][display_channels][num_vertices][4])
- * and the vertex count of every row's draw call ([count][display_channels]) -- any of the three pointers may be NULL --, into
- * page-locked memory behind the rows of the slot's wf_hip_read_rows_async (call that first; the plugin binding's render() override
- * draws from them one frame later); lands with wf_hip_readback_done(slot) */
-int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_bars, float *pinned_vertices, uint32_t *pinned_counts,
-                              uint32_t slot);
-/* meter batches: m_meter_val ([count][capture_channels], dBFS) and m_last_silent (one byte per stream) as the ticks issued so
- * far leave them, copied into page-locked memory on the readback stream without waiting; wf_hip_readback_done(slot) blocks
- * until both have landed (the plugin's batched mode reads every source's level one video frame late) */
-int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_levels, uint8_t *pinned_last_silent, uint32_t slot);
-/* Displays with cfg.mirror_freq_axis: render_bars / render_curve take the row's smallest y for the shader (miny / minpos, gradient
- * and pulse render modes) BEFORE the outputs above the middle are replaced by images of the lower ones (src/source.cpp:1548-1567,
- * :1411-1424).  Above the middle every output sits on the clamped top position and has one and the same value; that value --
- * output num_bars / 2 + 1 of the row before the mirror -- per displayed row: [count][display_channels].  With it and the rows
- * wf_hip_read_bars returns the host finds the reference's miny / minpos without interpolating the row itself.
- * WF_HIP_ERR_INVALID for configurations without a mirrored display.  The _async form rides on a slot's wf_hip_read_rows_async
- * like wf_hip_read_display_async (wf_hip_readback_done(slot) says when it has landed). */
-int wf_hip_read_premirror(wf_hip *h, uint32_t first, uint32_t count, float *out);
-int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot);
-/* the same bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL
- * all-gather); ordered on the handle's stream and synchronised before returning */
-int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out);
-/* the same without waiting: the copy is enqueued behind the ticks issued so far (every lane of a large batch copies the bars
+/* The bars copied device-to-device into `d_out` (a buffer on the handle's device, e.g. the send buffer of an RCCL all-gather;
+ * [count][display_channels][num_bars]) without waiting: the copy is enqueued behind the ticks issued so far (every lane of a large batch copies the bars
  * of its own slice: the tick's concurrent launches are not joined) and `consumer_stream` (a hipStream_t of the caller, e.g.
  * the stream its RCCL all-gather runs on) is made to wait for it; the handle goes on with the next tick meanwhile.  The
  * caller keeps `d_out` untouched by anything else until its consumer has run (wf_hip_wait_event orders a reuse). */
 int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, void *d_out, void *consumer_stream);
-/* Zero-copy form of the above (ABI 12): from the next tick on, every tick ALSO leaves the bars of the whole batch -- the ones it
+/* Zero-copy form of the above (ABI 13): from the next tick on, every tick ALSO leaves the bars of the whole batch -- the ones it
  * finishes and, copied over, the ones it leaves as they are (paused, hidden, silent streams) -- in caller-owned device memory of
- * the same shape ([num_streams][display_channels][num_bars] floats), alternating between the two buffers from tick to tick: the
- * send buffer of an all-gather is written by the tick kernel itself, nothing is enqueued behind the tick.  NULL, NULL turns it
- * off.  WF_HIP_ERR_UNSUPPORTED for fft sizes that are not powers of two and for the batches whose display comes from a kernel of
- * its own (fft sizes beyond a CU's LDS, filtered displays that do not fit the tick kernel's staging): those keep
- * wf_hip_copy_bars_device_async.  WF_HIP_ERR_INVALID for level-meter and waveform batches. */
-int wf_hip_set_bars_mirror(wf_hip *h, void *d_out0, void *d_out1);
-/* the same with n <= 8 buffers per set: tick k writes every buffer of set k & 1.  The buffers may be memory of peer devices this
- * device can address (hipDeviceEnablePeerAccess): a shard then leaves its slice in every device's gathered result itself, and the
- * exchange of BASELINE configs[4] needs no copy and no collective kernel at all (the C ABI's multi-device group, peer transport).
- * n = 0 turns it off.  wf_hip_bars_mirror_ready reports buffer 0 of the set. */
-int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *d_out0, void *const *d_out1);
-/* `consumer_stream` is made to wait for the newest tick (every lane); *d_out = the buffer that tick wrote (NULL before the
- * first tick).  Nothing is copied, nothing waits on the host.  A buffer is written again by the tick after next: the caller
- * issues that tick only when the consumer of the buffer has run (an event of its own behind the consumer, two ticks old by then:
- * hipEventSynchronize returns at once -- a device-side wait in front of every tick instead cost 4 % of the tick rate). */
+ * the same shape ([num_streams][display_channels][num_bars] floats): the send buffer of an all-gather is written by the tick
+ * kernel itself, nothing is enqueued behind the tick.  Two SETS of n <= 8 buffers each; every tick writes every buffer of the
+ * current write set.  The buffers may be memory of peer devices this device can address (hipDeviceEnablePeerAccess must have
+ * SUCCEEDED for the pair: a kernel store to an unmapped peer address faults): a shard then leaves its slice in every device's
+ * gathered result itself, and the exchange of BASELINE configs[4] needs no copy and no collective kernel at all (the C ABI's
+ * multi-device group, peer transport).  n = 0 turns it off.  The call waits for the ticks in flight (they write the old
+ * buffers) before it replaces the sets: the caller may free the old buffers when it returns.
+ * Power-of-two fft sizes up to 32768 whose display the tick kernel finishes itself ONLY: WF_HIP_ERR_UNSUPPORTED for the sizes that
+ * are not powers of two (Bluestein / mixed-radix instantiations run at their register caps), for the sizes beyond a CU's LDS and
+ * for filtered displays that do not fit the tick kernel's staging -- those keep wf_hip_copy_bars_device_async (wf_hip_multi_* and
+ * waveform_amd.dist.BarsGather pick the path per handle).  WF_HIP_ERR_INVALID for level-meter and waveform batches. */
+int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *set0, void *const *set1);
+/* Hand-over: `consumer_stream` is made to wait for the newest tick (every lane); *d_out = buffer 0 of the set that tick wrote,
+ * and the OTHER set becomes the write set -- ticks issued after this call leave the handed-over set alone until the next
+ * hand-over makes it the write set again.  (The write set changes here and only here: ticks between two hand-overs rewrite the
+ * same set, a tick that fails changes nothing.)  If no tick has written the set since it became the write set, the call fills it
+ * from the handle's own bars first (a device copy per buffer, behind the ticks issued so far).  Nothing waits on the host.
+ * The caller's side of the protocol: whatever still reads the set that now becomes the write set (the consumer of the hand-over
+ * before last) must have run before the next tick is issued -- an event of its own behind that consumer, a tick old by then:
+ * hipEventSynchronize returns at once (a device-side wait in front of every tick instead cost 4 % of the tick rate). */
 int wf_hip_bars_mirror_ready(wf_hip *h, void *consumer_stream, void **d_out);
 /* everything the handle issues after this call (on all of its internal streams) waits, on the device, for `event` (a
  * hipEvent_t of the caller, recorded before the call) -- e.g. "the gather that read the buffer the next
  * wf_hip_copy_bars_device_async overwrites has run".  Does not wait on the host. */
 int wf_hip_wait_event(wf_hip *h, void *event);
-/* meter batches: m_meter_val (dBFS) of streams [first, first+count): [count][capture_channels] */
-int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out);
-/* m_tsmooth_buf: [count][capture_channels][fft_size/2] */
-int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out);
-int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in);
-/* m_last_silent per stream */
-int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *out);
-/* waveform batches: m_waveform_ts (src/source.hpp:135, the timestamp of the next point the sweep will draw, ns) per stream as
- * the last enqueued tick leaves it; waits for that tick.  What a source needs to continue the sweep on the host
- * (src/source_generic.cpp:318-353) when it leaves a batch. */
-int wf_hip_read_waveform_ts(wf_hip *h, uint32_t first, uint32_t count, uint64_t *out);
 /* device pointers for zero-copy consumers on the same device (e.g. an RCCL all-gather of
  * the bars, or a renderer): valid until wf_hip_destroy */
 float *wf_hip_decibels_device(wf_hip *h);
@@ -322,24 +331,21 @@ float *wf_hip_bars_device(wf_hip *h);
 void *wf_hip_stream(wf_hip *h); /* hipStream_t */
 
 /* ---- host tables (what update() precomputes), for tests and for hosts that render themselves */
-size_t wf_hip_table_window(const wf_hip *h, const float **out, float *window_sum);
-size_t wf_hip_table_slope(const wf_hip *h, const float **out);
-size_t wf_hip_table_rolloff(const wf_hip *h, const float **out);
-size_t wf_hip_table_interp_indices(const wf_hip *h, const float **out);
-size_t wf_hip_table_band_widths(const wf_hip *h, const int **out);
-size_t wf_hip_table_interp_weights(const wf_hip *h, const float **out, int *radius, int *taps);
+typedef enum wf_hip_table_id {
+    WF_HIP_TABLE_WINDOW = 0,     /* float [fft_size]   m_window_coefficients (src/source.cpp:1190-1226) */
+    WF_HIP_TABLE_WINDOW_SUM,     /* float [1]          m_window_sum (:1228-1234) */
+    WF_HIP_TABLE_SLOPE,          /* float [fft_size/2] m_slope_modifiers (:1283-1290); empty when cfg.slope <= 0 */
+    WF_HIP_TABLE_ROLLOFF,        /* float [fft_size/2] m_rolloff_modifiers (:898-918) */
+    WF_HIP_TABLE_INTERP_INDICES, /* float []           m_interp_indices (init_interp, :837-896) */
+    WF_HIP_TABLE_BAND_WIDTHS,    /* int   [num_bars]   m_band_widths */
+    WF_HIP_TABLE_INTERP_WEIGHTS, /* float [][taps]     m_interp_kernel's weights, one row per sample position */
+    WF_HIP_TABLE_INTERP_SHAPE    /* int   [2]          {radius, taps} of the interpolation kernel */
+} wf_hip_table_id;
+/* number of elements; *out (may be NULL) = the table, owned by the handle, NULL when empty */
+size_t wf_hip_table(const wf_hip *h, wf_hip_table_id which, const void **out);
 float wf_hip_gravity(const wf_hip *h, float seconds); /* get_gravity(), src/source.hpp:301-312 */
-/* Vertex fill (cfg.vertices): the vertices render_bars / render_curve write into their vertex buffer for one displayed
- * channel (src/source.cpp:1576-1659, :1436-1461), produced by every tick from the bars / curve points of that tick.
- * wf_hip_num_vertices: vertices per displayed channel (0 when cfg.vertices is off).  wf_hip_read_vertices: out is
- * [count][display_channels][num_vertices][4] floats -- x, y, z, w as libobs' vec3 holds them (z = w = 0).
- * Stepped bars (cfg.vertices == 3): num_vertices is the buffer's capacity per channel (num_bars * 6 * max_steps, create_vbuf
- * src/source.cpp:988-1000); how many of them a tick's draw call uses -- gs_draw(GS_TRIS, 0, vertpos), :1663 -- comes from
- * wf_hip_read_vertex_counts ([count][display_channels]); vertices beyond it are whatever earlier ticks left, as in the
- * reference's buffer. */
+/* vertex fill (cfg.vertices; WF_HIP_OUT_VERTICES / WF_HIP_OUT_VERTEX_COUNTS): vertices per displayed channel, 0 when cfg.vertices is off */
 uint32_t wf_hip_num_vertices(const wf_hip *h);
-int wf_hip_read_vertices(wf_hip *h, uint32_t first, uint32_t count, float *out);
-int wf_hip_read_vertex_counts(wf_hip *h, uint32_t first, uint32_t count, uint32_t *out);
 const float *wf_hip_vertices_device(wf_hip *h); /* [n_streams][display_channels][num_vertices][4], device pointer */
 
 float wf_hip_db_min(void);                            /* DB_MIN, src/source.cpp:43 */
@@ -376,7 +382,12 @@ uint64_t wf_hip_algorithmic_bytes_per_tick(const wf_hip *h, uint32_t flags);
  * absent or refuses the device list (e.g. the same device named twice, which this library allows), by direct peer copies
  * (hipMemcpyPeerAsync, transport "peer"); WF_HIP_MULTI_TRANSPORT=rccl|peer forces one.  The gather is asynchronous and
  * double-buffered: it is enqueued on a side stream of every device behind the ticks issued so far, the next tick runs
- * meanwhile, and a result stays valid until the second-next gather.
+ * meanwhile, and a result stays valid until the FIRST TICK AFTER THE NEXT GATHER (where the tick kernels write the send
+ * buffers -- or, one device / peer access everywhere, the results -- themselves, that tick's kernels rewrite the buffer; the
+ * copying paths keep it until the second-next gather, but no caller should count on which path a size takes).  Ticks between
+ * two gathers, on the group or on a shard handle, and ticks that fail on one shard do not move the buffers: the pair is
+ * switched by the gather, on every shard together.  wf_hip_set_bars_mirrors / wf_hip_bars_mirror_ready must not be called on a
+ * shard handle (the group owns its shards' mirror buffers; a gather that finds the shards disagreeing fails).
  * A gather that fails on one device (the others may have their half in flight) takes the exchange out of service for the
  * group: the failing call returns the error, the RCCL communicators are aborted (ncclCommAbort -- no device keeps waiting for
  * a rank that never joined), every later gather returns WF_HIP_ERR_RUNTIME, and everything else -- ticks, reads,
@@ -406,13 +417,11 @@ int wf_hip_multi_reset(wf_hip_multi *m, uint32_t first, uint32_t count);
  * devices' host threads) */
 int wf_hip_multi_tick(wf_hip_multi *m, const wf_hip_tick_params *p);
 int wf_hip_multi_sync(wf_hip_multi *m); /* every device's streams, the gather streams included */
-/* results with global stream indices, as wf_hip_read_decibels / _bars / _last_silent */
-int wf_hip_multi_read_decibels(wf_hip_multi *m, uint32_t first, uint32_t count, float *out);
-int wf_hip_multi_read_bars(wf_hip_multi *m, uint32_t first, uint32_t count, float *out);
-int wf_hip_multi_read_last_silent(wf_hip_multi *m, uint32_t first, uint32_t count, uint8_t *out);
+/* results with global stream indices, as wf_hip_read (any output of the batch) */
+int wf_hip_multi_read(wf_hip_multi *m, wf_hip_output what, uint32_t first, uint32_t count, void *out);
 /* the exchange (see above); needs cfg.bars or cfg.curve */
 int wf_hip_multi_allgather_bars(wf_hip_multi *m);
-/* device i's copy of the newest gathered result: a pointer on that device (valid until the second-next gather; ordered behind
+/* device i's copy of the newest gathered result: a pointer on that device (valid until the first tick after the next gather; ordered behind
  * the gather on wf_hip_multi_gather_stream(m, i)), or copied to the host after waiting for it */
 const float *wf_hip_multi_gathered_device(wf_hip_multi *m, uint32_t i);
 void *wf_hip_multi_gather_stream(wf_hip_multi *m, uint32_t i); /* hipStream_t */
@@ -424,7 +433,8 @@ int wf_hip_multi_time_ticks(wf_hip_multi *m, const wf_hip_tick_params *p, uint32
                             float *per_device_ms);
 
 
-/* ---- test aid ------------------------------------------------------------------------------- */
+/* ---- test aids (development builds only: -DWF_DEV_BUILD, libwaveform_hip_dev.so; the release library exports neither) ---- */
+#ifdef WF_DEV_BUILD
 /* Moves the 32-bit sample counters of streams [first, first+count) on by `frames` (a multiple of the ring capacity), as
  * if that much audio had been captured before what the rings hold: tests reach the 2^32-sample wrap-around (a day at
  * 48 kHz; the reference's deques have no such counter) without feeding a day of audio. */
@@ -434,6 +444,7 @@ int wf_hip_debug_age(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
  * which have their collective / copies in flight by then.  Tests use it to check that the group survives: the call returns
  * the error, the communicators are aborted, later gathers are refused, ticks, reads, sync and destroy go on working. */
 int wf_hip_multi_debug_fail_next_gather(wf_hip_multi *m, uint32_t shard);
+#endif
 
 #ifdef __cplusplus
 }

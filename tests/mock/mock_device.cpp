@@ -49,10 +49,9 @@ struct wf_hip {
     uint32_t id0 = 0;   // global id of stream 0 (wf_hip_push_synth's stream_id0)
     uint32_t ticks = 0;
     std::vector<uint8_t> hidden;
-    float *mirror[2] = {nullptr, nullptr}; // wf_hip_set_bars_mirror: every tick also writes its bars there, alternately
-    std::vector<std::vector<float *>> mirrors; // wf_hip_set_bars_mirrors: all buffers of the two sets
-    uint32_t mirror_next = 0;
-    float *mirror_last = nullptr;
+    std::vector<std::vector<float *>> mirrors; // wf_hip_set_bars_mirrors: all buffers of the two sets; every tick writes set mirror_next,
+    uint32_t mirror_next = 0;                  // wf_hip_bars_mirror_ready hands it over and switches (as the library does: ABI 13)
+    bool mirror_fresh = false;
     std::string err;
 };
 static thread_local std::string g_err;
@@ -103,25 +102,11 @@ static void fill_bars(const wf_hip *h, uint32_t first, uint32_t count, float *ou
 int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *)
 {
     ++h->ticks;
-    if(h->mirror[0]) {
-        h->mirror_last = h->mirror[h->mirror_next];
-        fill_bars(h, 0, h->streams, h->mirror_last);
-        if(!h->mirrors.empty())
-            for(float *p : h->mirrors[h->mirror_next])
-                fill_bars(h, 0, h->streams, p);
-        h->mirror_next ^= 1u;
+    if(!h->mirrors.empty() && !h->mirrors[0].empty()) {
+        for(float *p : h->mirrors[h->mirror_next])
+            fill_bars(h, 0, h->streams, p);
+        h->mirror_fresh = true;
     }
-    return WF_HIP_OK;
-}
-int wf_hip_set_bars_mirror(wf_hip *h, void *a, void *b)
-{
-    if(getenv("WF_MOCK_NO_MIRROR"))
-        return WF_HIP_ERR_UNSUPPORTED;
-    h->mirrors.clear();
-    h->mirror[0] = static_cast<float *>(a);
-    h->mirror[1] = static_cast<float *>(b);
-    h->mirror_next = 0;
-    h->mirror_last = nullptr;
     return WF_HIP_OK;
 }
 int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *a, void *const *b)
@@ -133,13 +118,22 @@ int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *a, void *const *
         h->mirrors[0].push_back(static_cast<float *>(a[j]));
         h->mirrors[1].push_back(static_cast<float *>(b[j]));
     }
-    h->mirror[0] = n ? h->mirrors[0][0] : nullptr;
-    h->mirror[1] = n ? h->mirrors[1][0] : nullptr;
     h->mirror_next = 0;
-    h->mirror_last = nullptr;
+    h->mirror_fresh = false;
     return WF_HIP_OK;
 }
-int wf_hip_bars_mirror_ready(wf_hip *h, void *, void **out) { *out = h->mirror_last; return WF_HIP_OK; }
+int wf_hip_bars_mirror_ready(wf_hip *h, void *, void **out)
+{
+    if(h->mirrors.empty() || h->mirrors[0].empty())
+        return WF_HIP_ERR_INVALID;
+    if(!h->mirror_fresh) // no tick has written the set: filled from the handle's own bars
+        for(float *p : h->mirrors[h->mirror_next])
+            fill_bars(h, 0, h->streams, p);
+    *out = h->mirrors[h->mirror_next][0];
+    h->mirror_next ^= 1u;
+    h->mirror_fresh = false;
+    return WF_HIP_OK;
+}
 int wf_hip_sync(wf_hip *) { return WF_HIP_OK; }
 int wf_hip_wait_event(wf_hip *, void *) { return WF_HIP_OK; }
 int wf_hip_time_begin(wf_hip *) { return WF_HIP_OK; }
@@ -151,23 +145,39 @@ static void fill_bars(const wf_hip *h, uint32_t first, uint32_t count, float *ou
             for(uint32_t b = 0; b < h->bars; ++b)
                 out[((size_t)s * h->disp + c) * h->bars + b] = mock_bar_value(h->id0 + first + s, c, b, h->ticks);
 }
-int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out) { fill_bars(h, first, count, out); return WF_HIP_OK; }
 int wf_hip_copy_bars_device_async(wf_hip *h, uint32_t first, uint32_t count, void *d_out, void *)
 {
     fill_bars(h, first, count, static_cast<float *>(d_out));
     return WF_HIP_OK;
 }
-int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out)
+size_t wf_hip_output_bytes(const wf_hip *h, wf_hip_output what)
 {
-    const size_t per = 2u * (h->cfg.fft_size / 2u);
-    for(size_t i = 0; i < (size_t)count * per; ++i)
-        out[i] = (float)(h->id0 + first) + (float)(i / per);
-    return WF_HIP_OK;
+    switch(what) {
+    case WF_HIP_OUT_BARS: return (size_t)h->disp * h->bars * sizeof(float);
+    case WF_HIP_OUT_DECIBELS: return 2u * (h->cfg.fft_size / 2u) * sizeof(float);
+    case WF_HIP_OUT_LAST_SILENT: return 1;
+    default: return 0;
+    }
 }
-int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *out)
+int wf_hip_read(wf_hip *h, wf_hip_output what, uint32_t first, uint32_t count, void *out_)
 {
-    for(uint32_t i = 0; i < count; ++i)
-        out[i] = h->hidden[first + i] ? 1 : 0;
-    return WF_HIP_OK;
+    if(what == WF_HIP_OUT_BARS) {
+        fill_bars(h, first, count, static_cast<float *>(out_));
+        return WF_HIP_OK;
+    }
+    if(what == WF_HIP_OUT_DECIBELS) {
+        float *out = static_cast<float *>(out_);
+        const size_t per = 2u * (h->cfg.fft_size / 2u);
+        for(size_t i = 0; i < (size_t)count * per; ++i)
+            out[i] = (float)(h->id0 + first) + (float)(i / per);
+        return WF_HIP_OK;
+    }
+    if(what == WF_HIP_OUT_LAST_SILENT) {
+        uint8_t *out = static_cast<uint8_t *>(out_);
+        for(uint32_t i = 0; i < count; ++i)
+            out[i] = h->hidden[first + i] ? 1 : 0;
+        return WF_HIP_OK;
+    }
+    return WF_HIP_ERR_INVALID;
 }
 }

@@ -93,7 +93,7 @@ int wf_hip_set_hidden(wf_hip *h, uint32_t first, uint32_t count, const uint8_t *
     return WF_HIP_OK;
 }
 int wf_hip_set_input_rms(wf_hip *, uint32_t, uint32_t, const float *) { return WF_HIP_OK; }
-int wf_hip_enable_input_rms_feed(wf_hip *h) { h->err = "mock: no device RMS producer"; return WF_HIP_ERR_UNSUPPORTED; }
+int wf_hip_enable_input_rms(wf_hip *h, int) { h->err = "mock: no device RMS producer"; return WF_HIP_ERR_UNSUPPORTED; }
 int wf_hip_push_rms_ragged_async(wf_hip *, uint32_t, uint32_t, const float *, const uint32_t *, uint32_t, uint32_t) { return WF_HIP_OK; }
 int wf_hip_set_stream_delay(wf_hip *, uint32_t, uint32_t, const uint32_t *) { return WF_HIP_OK; }
 int wf_hip_set_stream_audio_ts(wf_hip *, uint32_t, uint32_t, const uint64_t *) { return WF_HIP_OK; }
@@ -110,70 +110,63 @@ int wf_hip_tick(wf_hip *h, const wf_hip_tick_params *)
     }
     return WF_HIP_OK;
 }
-int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    std::memcpy(out, h->rows.data() + (size_t)first * h->out * h->M, (size_t)count * h->out * h->M * sizeof(float));
-    return WF_HIP_OK;
-}
-int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *out)
-{
-    std::memcpy(out, h->silent.data() + first, count);
-    return WF_HIP_OK;
-}
 uint32_t wf_hip_ring_frames(const wf_hip *) { return 1u << 20; }
-int wf_hip_read_premirror(wf_hip *h, uint32_t, uint32_t count, float *out) { for(uint32_t i = 0; i < count * h->disp; ++i) out[i] = 0.0f; return WF_HIP_OK; }
-int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float *out, uint32_t) { return wf_hip_read_premirror(h, first, count, out); }
-int wf_hip_set_bars_mirror(wf_hip *, void *, void *) { return WF_HIP_ERR_UNSUPPORTED; }
 int wf_hip_set_bars_mirrors(wf_hip *, uint32_t, void *const *, void *const *) { return WF_HIP_ERR_UNSUPPORTED; }
 int wf_hip_bars_mirror_ready(wf_hip *, void *, void **) { return WF_HIP_ERR_INVALID; }
-int wf_hip_read_waveform_ts(wf_hip *, uint32_t, uint32_t count, uint64_t *out)
+// the one reader (wf_hip_read): every output a deterministic function of what the stream has received
+int wf_hip_read(wf_hip *h, wf_hip_output what, uint32_t first, uint32_t count, void *out_)
 {
-    std::memset(out, 0, (size_t)count * sizeof(uint64_t));
-    return WF_HIP_OK;
+    switch(what) {
+    case WF_HIP_OUT_DECIBELS:
+        std::memcpy(out_, h->rows.data() + (size_t)first * h->out * h->M, (size_t)count * h->out * h->M * sizeof(float));
+        return WF_HIP_OK;
+    case WF_HIP_OUT_LAST_SILENT:
+        std::memcpy(out_, h->silent.data() + first, count);
+        return WF_HIP_OK;
+    case WF_HIP_OUT_PREMIRROR:
+    case WF_HIP_OUT_INPUT_RMS: {
+        const size_t n = what == WF_HIP_OUT_PREMIRROR ? (size_t)count * h->disp : count;
+        std::memset(out_, 0, n * sizeof(float));
+        return WF_HIP_OK;
+    }
+    case WF_HIP_OUT_WAVEFORM_TS:
+        std::memset(out_, 0, (size_t)count * sizeof(uint64_t));
+        return WF_HIP_OK;
+    case WF_HIP_OUT_METER: {
+        float *out = static_cast<float *>(out_);
+        for(uint32_t i = 0; i < count * h->cap; ++i)
+            out[i] = -20.0f - (float)(h->sum[first + i / h->cap] % 31u);
+        return WF_HIP_OK;
+    }
+    case WF_HIP_OUT_BARS: {
+        float *out = static_cast<float *>(out_);
+        for(size_t i = 0; i < (size_t)count * h->disp * h->bars; ++i)
+            out[i] = 10.0f + (float)((h->sum[first + i / ((size_t)h->disp * h->bars)] + i) % 200u);
+        return WF_HIP_OK;
+    }
+    case WF_HIP_OUT_VERTICES:
+        std::memset(out_, 0, (size_t)count * h->disp * wf_hip_num_vertices(h) * 4 * sizeof(float));
+        return WF_HIP_OK;
+    case WF_HIP_OUT_VERTEX_COUNTS: {
+        uint32_t *out = static_cast<uint32_t *>(out_);
+        for(uint32_t i = 0; i < count * h->disp; ++i)
+            out[i] = wf_hip_num_vertices(h);
+        return WF_HIP_OK;
+    }
+    default: return WF_HIP_ERR_INVALID;
+    }
 }
-int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *rows, uint8_t *silent, uint32_t)
+// the pipelined reader: the mock copies at once
+int wf_hip_read_async(wf_hip *h, uint32_t first, uint32_t count, const wf_hip_readback *d, uint32_t)
 {
-    wf_hip_read_decibels(h, first, count, rows);
-    return wf_hip_read_last_silent(h, first, count, silent);
-}
-int wf_hip_read_input_rms_async(wf_hip *, uint32_t, uint32_t count, float *out, uint32_t)
-{
-    std::memset(out, 0, count * sizeof(float));
-    return WF_HIP_OK;
-}
-int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    for(uint32_t i = 0; i < count * h->cap; ++i)
-        out[i] = -20.0f - (float)(h->sum[first + i / h->cap] % 31u);
-    return WF_HIP_OK;
-}
-int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *levels, uint8_t *silent, uint32_t)
-{
-    wf_hip_read_meter(h, first, count, levels);
-    return wf_hip_read_last_silent(h, first, count, silent);
-}
-int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    for(size_t i = 0; i < (size_t)count * h->disp * h->bars; ++i)
-        out[i] = 10.0f + (float)((h->sum[first + i / ((size_t)h->disp * h->bars)] + i) % 200u);
-    return WF_HIP_OK;
-}
-int wf_hip_read_vertices(wf_hip *h, uint32_t, uint32_t count, float *out)
-{
-    std::memset(out, 0, (size_t)count * h->disp * wf_hip_num_vertices(h) * 4 * sizeof(float));
-    return WF_HIP_OK;
-}
-int wf_hip_read_vertex_counts(wf_hip *h, uint32_t, uint32_t count, uint32_t *out)
-{
-    for(uint32_t i = 0; i < count * h->disp; ++i)
-        out[i] = wf_hip_num_vertices(h);
-    return WF_HIP_OK;
-}
-int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *bars, float *verts, uint32_t *counts, uint32_t)
-{
-    if(bars) wf_hip_read_bars(h, first, count, bars);
-    if(verts) wf_hip_read_vertices(h, first, count, verts);
-    if(counts) wf_hip_read_vertex_counts(h, first, count, counts);
+    if(d->rows) wf_hip_read(h, WF_HIP_OUT_DECIBELS, first, count, d->rows);
+    if(d->last_silent) wf_hip_read(h, WF_HIP_OUT_LAST_SILENT, first, count, d->last_silent);
+    if(d->bars) wf_hip_read(h, WF_HIP_OUT_BARS, first, count, d->bars);
+    if(d->premirror) wf_hip_read(h, WF_HIP_OUT_PREMIRROR, first, count, d->premirror);
+    if(d->vertices) wf_hip_read(h, WF_HIP_OUT_VERTICES, first, count, d->vertices);
+    if(d->vertex_counts) wf_hip_read(h, WF_HIP_OUT_VERTEX_COUNTS, first, count, d->vertex_counts);
+    if(d->input_rms) wf_hip_read(h, WF_HIP_OUT_INPUT_RMS, first, count, d->input_rms);
+    if(d->meter) wf_hip_read(h, WF_HIP_OUT_METER, first, count, d->meter);
     return WF_HIP_OK;
 }
 }

@@ -24,9 +24,9 @@ L.wf_hip_multi_tick.argtypes = [vp, C.POINTER(TickParams)]
 L.wf_hip_multi_sync.argtypes = [vp]
 L.wf_hip_multi_allgather_bars.argtypes = [vp]
 L.wf_hip_multi_read_gathered.argtypes = [vp, u32, fp]
-L.wf_hip_multi_read_bars.argtypes = [vp, u32, u32, fp]
+L.wf_hip_multi_read.argtypes = [vp, C.c_int, u32, u32, vp]
+OUT_BARS, OUT_LAST_SILENT = 1, 5  # wf_hip_output
 L.wf_hip_multi_set_hidden.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
-L.wf_hip_multi_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
 L.wf_hip_multi_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, C.c_int, fp, fp]
 L.wf_hip_multi_debug_fail_next_gather.argtypes = [vp, u32]
 L.wf_hip_multi_shard.restype = vp
@@ -76,7 +76,7 @@ def scenario(devices, streams, rounds=6):
         mask[1::3] = 1
         assert L.wf_hip_multi_set_hidden(m, 0, streams, mask.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
         back = np.empty(streams, np.uint8)
-        assert L.wf_hip_multi_read_last_silent(m, 0, streams, back.ctypes.data_as(C.POINTER(C.c_uint8))) == 0 and np.array_equal(back, mask)
+        assert L.wf_hip_multi_read(m, OUT_LAST_SILENT, 0, streams, back.ctypes.data_as(vp)) == 0 and np.array_equal(back, mask)
         if len(devices) > 1:
             # one shard fails inside a gather: reported, later gathers refused, everything else goes on, destroy returns
             assert L.wf_hip_multi_debug_fail_next_gather(m, len(devices) - 1) == 0
@@ -85,7 +85,7 @@ def scenario(devices, streams, rounds=6):
             assert L.wf_hip_multi_allgather_bars(m) != 0 and b"out of service" in L.wf_hip_multi_last_error(m)
             assert L.wf_hip_multi_time_ticks(m, C.byref(p), 5, 0, 1, C.byref(ms), per) != 0
             assert L.wf_hip_multi_tick(m, C.byref(p)) == 0 and L.wf_hip_multi_sync(m) == 0
-            assert L.wf_hip_multi_read_bars(m, 0, streams, out.ctypes.data_as(fp)) == 0
+            assert L.wf_hip_multi_read(m, OUT_BARS, 0, streams, out.ctypes.data_as(vp)) == 0
         m2 = group(devices, streams)   # a failure inside the timed loop (the workers' barrier path)
         try:
             if len(devices) > 1:

@@ -516,6 +516,7 @@ def test_mixed_radix_plans_and_transforms(tmp_path):
 def _declared_functions(header: Path):
     text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
     text = re.sub(r"//.*", "", text)
+    text = re.sub(r"#ifdef WF_DEV_BUILD.*?#endif", "", text, flags=re.S)  # the test aids: development builds only (checked below)
     names = set()
     for m in re.finditer(r"\b(wf_[a-z0-9_]+)\s*\(", text):
         names.add(m.group(1))
@@ -535,7 +536,43 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name)
     L.wf_hip_abi_version.restype = C.c_int
-    assert L.wf_hip_abi_version() == 12
+    assert L.wf_hip_abi_version() == 13
+
+
+def test_release_library_carries_no_laboratory():
+    """The release library exports no test aid and at most 75 entry points (the boundary is a thin C ABI: the reference's operator
+    interface is four virtuals, src/source.hpp:273-277); the development build (same kernel objects, -DWF_DEV_BUILD on the two
+    host-side translation units) has the two hooks the tests need.  Every measurement switch in the kernels (WF_EXP_*: kernels that
+    end early or skip a phase, with WRONG results) defaults to 0 and is refused by wf_dev_guard.hpp outside development builds."""
+    def exported(path):
+        nm = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+        return {line.split()[-1] for line in nm.splitlines() if " T " in line and line.split()[-1].startswith("wf_hip_")}
+    rel = exported(ROOT / "waveform_amd" / "libwaveform_hip.so")
+    dev = exported(ROOT / "waveform_amd" / "libwaveform_hip_dev.so")
+    assert not [n for n in rel if "debug" in n], [n for n in rel if "debug" in n]
+    assert len(rel) <= 75, (len(rel), sorted(rel))
+    assert dev - rel == {"wf_hip_debug_age", "wf_hip_multi_debug_fail_next_gather"}, sorted(dev - rel)
+    csrc = ROOT / "waveform_amd" / "csrc"
+    guard = (csrc / "wf_dev_guard.hpp").read_text()
+    seen = set()
+    for p in list(csrc.glob("*.hpp")) + list(csrc.glob("*.hip")) + list(csrc.glob("*.cpp")):
+        if p.name == "wf_dev_guard.hpp":
+            continue
+        txt = p.read_text()
+        seen |= set(re.findall(r"\bWF_EXP_[A-Z0-9_]+\b", txt))
+        for name, val in re.findall(r"#define\s+(WF_EXP_[A-Z0-9_]+)\s+(\S+)", txt):
+            assert val == "0", f"{p.name}: {name} defaults to {val}"
+        if "WF_PHASE_TIMING" in txt or "WF_EXP_" in txt:
+            assert "wf_dev_guard.hpp" in txt or p.name in ("wf_tick_phases.hpp", "wf_big.hpp", "wf_hip.hip", "wf_hip_plan.hip"), p.name  # (those include it through wf_hip_internal.hpp / wf_kernels.hpp)
+    assert seen <= {"WF_EXP_NO_TAIL", "WF_EXP_CUT_AT"}, f"measurement switches in the product kernels: {sorted(seen)}"
+    for name in seen:
+        assert name in guard, f"{name} is not refused by wf_dev_guard.hpp outside development builds"
+    # and the guard works: a release compile with a stray -D stops
+    src = "#define WF_EXP_NO_TAIL 1\n#include \"wf_dev_guard.hpp\"\nint x;\n"
+    r = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-I", str(csrc), "-"], input=src, capture_output=True, text=True)
+    assert r.returncode != 0 and "WF_DEV_BUILD" in r.stderr
+    r = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-DWF_DEV_BUILD", "-I", str(csrc), "-"], input=src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 def test_no_device_fails_loudly():

@@ -143,7 +143,7 @@ def test_mirrored_axis_shader_constants_come_from_the_device(shader, batched):
     """render modes whose shader constants follow the row's smallest y -- gradient (grad_height) and pulse (color_base, by
     magnitude or by position) -- on a MIRRORED frequency axis: the reference takes miny / minpos before the mirror image
     replaces the upper half of the row (src/source.cpp:1548-1567, :1411-1424).  WAVSourceHIP::render finds them from the
-    device's mirrored row plus the one value the outputs above the middle had before (wf_hip_read_premirror): every render must
+    device's mirrored row plus the one value the outputs above the middle had before (WF_HIP_OUT_PREMIRROR): every render must
     be served from the device (host_renders unchanged) and hand set_shader_vars what the plugin's own CPU class hands it --
     bars with an odd and an even count, stereo and mono, and a curve."""
     wfref = _hip_env(batched=batched)
@@ -189,6 +189,58 @@ def test_mirrored_axis_shader_constants_come_from_the_device(shader, batched):
         for t, (g, w) in enumerate(zip(got, want)):
             for n in names:
                 assert w["shader"][n] is not None and g["shader"][n] is not None, (cfg_dict, shader, n)
+                d = np.abs(g["shader"][n].astype(np.float64) - w["shader"][n])
+                assert np.all(d <= 1e-5 * np.abs(w["shader"][n]) + 2e-3), f"{cfg_dict} {shader} tick {t}: shader constant {n} {g['shader'][n]} != {w['shader'][n]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("shader", ["gradient", "pulse:peak_frequency"])
+def test_mirrored_filtered_axis_keeps_the_reference_loops_for_miny(shader, batched):
+    """The same render modes with the Gaussian filter ON (apply_filter runs before the miny / minpos loop,
+    src/source.cpp:1541-1547): the pre-mirror outputs next to the middle are blends of the clamped top value with lower bars, the
+    minimum may sit at any of them, and one kept value cannot stand for them -- WAVSourceHIP::render hands those frames to the
+    reference's own loops (host renders counted) and the shader constants equal the plugin's CPU class.  Without gradient / pulse
+    the same filtered, mirrored display is drawn from the device."""
+    wfref = _hip_env(batched=batched)
+    mode, _, pulse = shader.partition(":")
+    extra = dict(render_mode=mode, grad_ratio=repr(0.75), color_base=0xFF102030, color_crest=0xFFE0D0C0)
+    if pulse:
+        extra["pulse_mode"] = pulse
+    names = {"gradient": ["grad_height", "grad_center", "grad_offset"], "pulse": ["color_base"]}[mode]
+    layouts = [dict(fft_size=2048, stereo=1, bars=1, interp_mode=1, mirror_freq_axis=1, vertices=1, filter_mode=1, filter_radius=2.5),
+               dict(fft_size=2048, stereo=0, curve=1, interp_mode=2, mirror_freq_axis=1, vertices=1, width=401, filter_mode=1, filter_radius=4.0)]
+    # loud low end, quiet top: the smallest y of the filtered row sits right above the middle, among the blended outputs
+    steps = [("noise", 800), ("tick",)] * 3 + [("noise_amp", 800, 0.02), ("tick",)] * 3
+    for cfg_dict in layouts:
+        cfg = scenarios.make_config(cfg_dict)
+        sc = dict(cfg=cfg_dict, steps=steps, record="all")
+
+        class Shaded:
+            def __init__(self, isa, extra_settings):
+                self.be = scenarios.RefBackend(cfg, isa=isa, extra_settings=extra_settings)
+                self.capture_channels = self.be.capture_channels
+            def __getattr__(self, k):
+                return getattr(self.be, k)
+            def observe(self):
+                rec = self.be.observe()
+                rec["shader"] = {n: self.be.src.shader_value(n) for n in names}
+                return rec
+        on_host = wfref.hip_host_renders()
+        hip = Shaded("hip", extra)
+        assert hip.be.src.using_hip
+        if batched:
+            late = _OneFrameLate(hip)
+            scenarios.play(late, sc)
+            got = late.finish()
+        else:
+            got = scenarios.play(hip, sc)
+        assert hip.be.src.using_hip
+        assert wfref.hip_host_renders() > on_host, f"{cfg_dict} {shader}: a filtered, mirrored row's miny was taken from the device's single pre-mirror value"
+        want = scenarios.play(Shaded("generic", extra), sc)
+        assert len(got) == len(want)
+        for t, (g, w) in enumerate(zip(got, want)):
+            for n in names:
                 d = np.abs(g["shader"][n].astype(np.float64) - w["shader"][n])
                 assert np.all(d <= 1e-5 * np.abs(w["shader"][n]) + 2e-3), f"{cfg_dict} {shader} tick {t}: shader constant {n} {g['shader'][n]} != {w['shader'][n]}"
 

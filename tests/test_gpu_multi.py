@@ -236,7 +236,9 @@ with wf.SpectrumBatch(cfg, streams, ring_frames=2048 + 40 * hop) as plain, wf.Mu
     assert ms > 0
 print("survived")
 ''' % (str(ROOT), shards, int(timed), transport, transport)
-    env = dict(os.environ, WF_HIP_MULTI_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # (the test aid lives in the development build of the library only: libwaveform_hip_dev.so, the same kernel objects)
+    env = dict(os.environ, WF_HIP_MULTI_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               WF_HIP_LIB=str(ROOT / "waveform_amd" / "libwaveform_hip_dev.so"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "survived" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 

@@ -1,5 +1,5 @@
 """Interleaved A/B of the bars tail's layouts on the shapes that display bars (development aid; needs a library built with
--DWF_DEV_OVERRIDES, e.g. tools/variant.sh dev, selected by WF_HIP_LIB): WF_HIP_BAR_PIECES=0 (bar_segments' wave-local layout:
+-DWF_DEV_BUILD, e.g. tools/variant.sh dev, selected by WF_HIP_LIB): WF_HIP_BAR_PIECES=0 (bar_segments' wave-local layout:
 row parked, barrier, six ds_bpermute steps) against 1 (wave-private pieces: no barrier, DPP scan, last-arriver sum).
 usage: WF_HIP_LIB=variants/lib_dev.so python tools/ab_bars.py [reps]"""
 import json, os, sys

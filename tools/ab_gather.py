@@ -1,6 +1,6 @@
 """Interleaved A/B of the per-tick exchange of BASELINE configs[4] at world 1 (development aid): the cfg5 per-GPU shape (8192
 stereo streams, FFT 4096, 26 Lanczos bars, bars-only ticks) without any gather, with waveform_amd.dist.BarsGather writing the
-send buffers from the tick kernel (wf_hip_set_bars_mirror) and with the copy behind the tick (WF_BARS_GATHER_COPY=1); then the
+send buffers from the tick kernel (wf_hip_set_bars_mirrors) and with the copy behind the tick (WF_BARS_GATHER_COPY=1); then the
 C ABI's multi-device group both ways (WF_HIP_MULTI_MIRROR).  Every measurement in a process of its own, round-robin.
 usage: python tools/ab_gather.py [reps]"""
 import json, os, subprocess, sys

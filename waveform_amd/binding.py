@@ -57,6 +57,18 @@ class TickParams(C.Structure):
 TICK_NO_DECIBELS = 1
 
 
+# wf_hip_output / wf_hip_table_id (include/wf_hip.h)
+OUT_DECIBELS, OUT_BARS, OUT_PREMIRROR, OUT_VERTICES, OUT_VERTEX_COUNTS, OUT_LAST_SILENT, OUT_TSMOOTH, OUT_METER, OUT_INPUT_RMS, OUT_WAVEFORM_TS = range(10)
+(TABLE_WINDOW, TABLE_WINDOW_SUM, TABLE_SLOPE, TABLE_ROLLOFF, TABLE_INTERP_INDICES, TABLE_BAND_WIDTHS, TABLE_INTERP_WEIGHTS,
+ TABLE_INTERP_SHAPE) = range(8)
+
+
+class Readback(C.Structure):
+    """wf_hip_readback: the page-locked destinations of one wf_hip_read_async (NULL leaves an output out)"""
+    _fields_ = [("rows", C.c_void_p), ("last_silent", C.c_void_p), ("bars", C.c_void_p), ("premirror", C.c_void_p), ("vertices", C.c_void_p),
+                ("vertex_counts", C.c_void_p), ("input_rms", C.c_void_p), ("meter", C.c_void_p)]
+
+
 def library_path() -> Path:
     # WF_HIP_LIB: development aid for A/B-ing kernel builds; the default is the in-tree library
     import os
@@ -91,64 +103,49 @@ def lib():
     L.wf_hip_push_audio_device.argtypes = [vp, u32, u32, vp, u32]
     L.wf_hip_push_audio_async.argtypes = [vp, u32, u32, vp, u32, u32]
     L.wf_hip_ingest_done.argtypes = [vp, u32]
-    L.wf_hip_read_bars_async.argtypes = [vp, u32, u32, vp, u32]
+    L.wf_hip_read_async.argtypes = [vp, u32, u32, C.POINTER(Readback), u32]
     L.wf_hip_readback_done.argtypes = [vp, u32]
     L.wf_hip_host_alloc.restype = vp
     L.wf_hip_host_alloc.argtypes = [C.c_size_t]
     L.wf_hip_host_free.argtypes = [vp]
     L.wf_hip_push_synth.argtypes = [vp, u32, u32, u64, u32, u64, u32]
-    L.wf_hip_push_silence.argtypes = [vp, u32, u32, u32]
     L.wf_hip_push_audio_muted.argtypes = [vp, u32, u32, fp, u32]
-    L.wf_hip_enable_input_rms.argtypes = [vp]
-    L.wf_hip_read_input_rms.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_enable_input_rms.argtypes = [vp, C.c_int]
     L.wf_hip_tick.argtypes = [vp, C.POINTER(TickParams)]
     L.wf_hip_set_hidden.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
     L.wf_hip_set_input_rms.argtypes = [vp, u32, u32, fp]
     L.wf_hip_set_stream_delay.argtypes = [vp, u32, u32, C.POINTER(C.c_uint32)]
     L.wf_hip_set_stream_audio_ts.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     L.wf_hip_sync.argtypes = [vp]
-    L.wf_hip_read_decibels.argtypes = [vp, u32, u32, fp]
-    L.wf_hip_read_bars.argtypes = [vp, u32, u32, fp]
+    L.wf_hip_read.argtypes = [vp, C.c_int, u32, u32, vp]
+    L.wf_hip_output_bytes.restype = C.c_size_t
+    L.wf_hip_output_bytes.argtypes = [vp, C.c_int]
     L.wf_hip_num_vertices.restype = u32
     L.wf_hip_num_vertices.argtypes = [vp]
-    L.wf_hip_read_vertices.argtypes = [vp, u32, u32, fp]
-    L.wf_hip_read_vertex_counts.argtypes = [vp, u32, u32, C.POINTER(C.c_uint32)]
-    L.wf_hip_copy_bars_device.argtypes = [vp, u32, u32, vp]
     L.wf_hip_copy_bars_device_async.argtypes = [vp, u32, u32, vp, vp]
     L.wf_hip_wait_event.argtypes = [vp, vp]
     L.wf_hip_time_begin.argtypes = [vp]
     L.wf_hip_time_end.argtypes = [vp, fp]
-    L.wf_hip_read_meter.argtypes = [vp, u32, u32, fp]
-    L.wf_hip_read_tsmooth.argtypes = [vp, u32, u32, fp]
     L.wf_hip_write_tsmooth.argtypes = [vp, u32, u32, fp]
-    L.wf_hip_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
-    L.wf_hip_read_waveform_ts.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     for n in ("decibels_device", "bars_device", "stream"):
         f = getattr(L, "wf_hip_" + n)
         f.restype = vp
         f.argtypes = [vp]
-    L.wf_hip_table_window.restype = C.c_size_t
-    L.wf_hip_table_window.argtypes = [vp, C.POINTER(fp), fp]
-    for n in ("slope", "rolloff", "interp_indices"):
-        f = getattr(L, "wf_hip_table_" + n)
-        f.restype = C.c_size_t
-        f.argtypes = [vp, C.POINTER(fp)]
-    L.wf_hip_table_band_widths.restype = C.c_size_t
-    L.wf_hip_table_band_widths.argtypes = [vp, C.POINTER(C.POINTER(C.c_int))]
-    L.wf_hip_table_interp_weights.restype = C.c_size_t
-    L.wf_hip_table_interp_weights.argtypes = [vp, C.POINTER(fp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.wf_hip_table.restype = C.c_size_t
+    L.wf_hip_table.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.wf_hip_gravity.restype = C.c_float
     L.wf_hip_gravity.argtypes = [vp, C.c_float]
     L.wf_hip_db_min.restype = C.c_float
     L.wf_hip_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, fp]
     L.wf_hip_kernel_name.restype = C.c_char_p
     L.wf_hip_kernel_name.argtypes = [vp]
-    L.wf_hip_debug_age.argtypes = [vp, u32, u32, u32]
+    if hasattr(L, "wf_hip_debug_age"):  # development builds only (libwaveform_hip_dev.so, -DWF_DEV_BUILD)
+        L.wf_hip_debug_age.argtypes = [vp, u32, u32, u32]
     L.wf_hip_launches_per_tick.restype = u32
     L.wf_hip_launches_per_tick.argtypes = [vp]
     L.wf_hip_algorithmic_bytes_per_tick.restype = u64
     L.wf_hip_algorithmic_bytes_per_tick.argtypes = [vp, u32]
-    L.wf_hip_set_bars_mirror.argtypes = [vp, vp, vp]
+    L.wf_hip_set_bars_mirrors.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp)]
     L.wf_hip_bars_mirror_ready.argtypes = [vp, vp, C.POINTER(vp)]
     # one batch over several devices (wf_hip_multi_*)
     L.wf_hip_multi_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), u32, u32, u32, C.POINTER(vp)]
@@ -169,9 +166,7 @@ def lib():
     L.wf_hip_multi_reset.argtypes = [vp, u32, u32]
     L.wf_hip_multi_tick.argtypes = [vp, C.POINTER(TickParams)]
     L.wf_hip_multi_sync.argtypes = [vp]
-    L.wf_hip_multi_read_decibels.argtypes = [vp, u32, u32, fp]
-    L.wf_hip_multi_read_bars.argtypes = [vp, u32, u32, fp]
-    L.wf_hip_multi_read_last_silent.argtypes = [vp, u32, u32, C.POINTER(C.c_uint8)]
+    L.wf_hip_multi_read.argtypes = [vp, C.c_int, u32, u32, vp]
     L.wf_hip_multi_allgather_bars.argtypes = [vp]
     L.wf_hip_multi_gathered_device.restype = vp
     L.wf_hip_multi_gathered_device.argtypes = [vp, u32]
@@ -179,7 +174,8 @@ def lib():
     L.wf_hip_multi_gather_stream.argtypes = [vp, u32]
     L.wf_hip_multi_read_gathered.argtypes = [vp, u32, fp]
     L.wf_hip_multi_time_ticks.argtypes = [vp, C.POINTER(TickParams), u32, u32, C.c_int, fp, fp]
-    L.wf_hip_multi_debug_fail_next_gather.argtypes = [vp, u32]
+    if hasattr(L, "wf_hip_multi_debug_fail_next_gather"):  # development builds only
+        L.wf_hip_multi_debug_fail_next_gather.argtypes = [vp, u32]
     _LIB = L
     return L
 
@@ -255,22 +251,21 @@ class SpectrumBatch:
 
     def enable_input_rms(self):
         """update_input_rms on the device from now on (cfg.normalize_volume)"""
-        self._ck(self.L.wf_hip_enable_input_rms(self.h))
+        self._ck(self.L.wf_hip_enable_input_rms(self.h, 0))
 
     def input_rms(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.streams - first if count is None else count
-        out = np.empty(count, np.float32)
-        self._ck(self.L.wf_hip_read_input_rms(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
-        return out
+        return self._read(OUT_INPUT_RMS, first, count, (), np.float32)
 
     def push_audio_async(self, pinned: "PinnedBuffer", count: int, frames: int, slot: int, first: int = 0):
         """pipelined ingest from page-locked memory (see wf_hip_push_audio_async); does not wait"""
         self._ck(self.L.wf_hip_push_audio_async(self.h, first, count, C.c_void_p(pinned.ptr), frames, slot))
 
     def read_bars_async(self, pinned: "PinnedBuffer", slot: int, first: int = 0, count: int | None = None):
-        """bars of the ticks enqueued so far -> page-locked memory, without waiting (wf_hip_read_bars_async)"""
+        """bars of the ticks enqueued so far -> page-locked memory, without waiting (wf_hip_read_async, the bars alone)"""
         count = self.streams - first if count is None else count
-        self._ck(self.L.wf_hip_read_bars_async(self.h, first, count, C.c_void_p(pinned.ptr), slot))
+        dst = Readback(bars=pinned.ptr)
+        self._ck(self.L.wf_hip_read_async(self.h, first, count, C.byref(dst), slot))
 
     def readback_done(self, slot: int):
         self._ck(self.L.wf_hip_readback_done(self.h, slot))
@@ -287,7 +282,7 @@ class SpectrumBatch:
 
     def push_silence(self, frames: int, first: int = 0, count: int | None = None):
         count = self.streams - first if count is None else count
-        self._ck(self.L.wf_hip_push_silence(self.h, first, count, frames))
+        self._ck(self.L.wf_hip_push_audio_muted(self.h, first, count, None, frames))  # a packet without data: zeros
 
     def reset(self, first: int = 0, count: int | None = None):
         count = self.streams - first if count is None else count
@@ -332,20 +327,23 @@ class SpectrumBatch:
     # -- results ------------------------------------------------------------------------
     def decibels(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.streams - first if count is None else count
-        out = np.empty((count, self.output_channels, self.bins), np.float32)
-        self._ck(self.L.wf_hip_read_decibels(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return self._read(OUT_DECIBELS, first, count, (self.output_channels, self.bins), np.float32)
+
+    def _read(self, what: int, first: int, count: int | None, shape, dtype) -> np.ndarray:
+        """wf_hip_read: output `what` of streams [first, first+count) as [count, *shape]"""
+        count = self.streams - first if count is None else count
+        out = np.empty((count,) + tuple(shape), dtype)
+        per = int(self.L.wf_hip_output_bytes(self.h, what))
+        assert per == 0 or per * count == out.nbytes, (what, per, out.shape)  # (0: the call below reports why the batch has none)
+        self._ck(self.L.wf_hip_read(self.h, what, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def bars(self, first: int = 0, count: int | None = None) -> np.ndarray:
-        count = self.streams - first if count is None else count
-        out = np.empty((count, self.display_channels, self.num_bars), np.float32)
-        self._ck(self.L.wf_hip_read_bars(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
-        return out
+        return self._read(OUT_BARS, first, count, (self.display_channels, self.num_bars), np.float32)
 
-    def copy_bars_to_device(self, dev_ptr: int, first: int = 0, count: int | None = None):
-        """device-to-device copy of the bar tops into a caller-owned buffer (e.g. a torch tensor's data_ptr())"""
-        count = self.streams - first if count is None else count
-        self._ck(self.L.wf_hip_copy_bars_device(self.h, first, count, C.c_void_p(dev_ptr)))
+    def premirror(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """mirrored displays: the one value the outputs above the middle had before the mirror, [count, display_channels]"""
+        return self._read(OUT_PREMIRROR, first, count, (self.display_channels,), np.float32)
 
     def copy_bars_to_device_async(self, dev_ptr: int, consumer_stream: int, first: int = 0, count: int | None = None):
         """the same without waiting: `consumer_stream` (a hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream) is made
@@ -353,14 +351,22 @@ class SpectrumBatch:
         count = self.streams - first if count is None else count
         self._ck(self.L.wf_hip_copy_bars_device_async(self.h, first, count, C.c_void_p(dev_ptr), C.c_void_p(consumer_stream)))
 
-    def set_bars_mirror(self, dev_ptr0: int | None, dev_ptr1: int | None):
-        """from the next tick on every tick also leaves the whole batch's bars in dev_ptr0 / dev_ptr1, alternately (device
-        buffers of [streams][display_channels][num_bars] floats owned by the caller); None, None turns it off.  Raises
-        WfHipError (code -2, WF_HIP_ERR_UNSUPPORTED) for batches whose display comes from a kernel of its own."""
-        self._ck(self.L.wf_hip_set_bars_mirror(self.h, C.c_void_p(dev_ptr0), C.c_void_p(dev_ptr1)))
+    def set_bars_mirrors(self, set0, set1):
+        """from the next tick on every tick also leaves the whole batch's bars in every buffer of the current write set (set0 /
+        set1: sequences of up to 8 device pointers each -- buffers of [streams][display_channels][num_bars] floats owned by the
+        caller); bars_mirror_ready() hands the write set over and switches to the other.  Empty sequences turn it off (the call
+        waits for the ticks in flight: the old buffers may be freed afterwards).  Raises WfHipError (code -2,
+        WF_HIP_ERR_UNSUPPORTED) for fft sizes that are not powers of two and for batches whose display comes from a kernel of
+        its own."""
+        n = len(set0)
+        assert n == len(set1) and n <= 8
+        a0 = (C.c_void_p * max(n, 1))(*set0)
+        a1 = (C.c_void_p * max(n, 1))(*set1)
+        self._ck(self.L.wf_hip_set_bars_mirrors(self.h, n, a0, a1))
 
-    def bars_mirror_ready(self, consumer_stream: int) -> int | None:
-        """`consumer_stream` waits for the newest tick; returns the device pointer of the buffer it wrote (None before any tick)"""
+    def bars_mirror_ready(self, consumer_stream: int) -> int:
+        """hand-over: `consumer_stream` waits for the newest tick; returns the device pointer of buffer 0 of the set the ticks
+        have written (filled from the handle's own bars if no tick has); the other set becomes the ticks' target"""
         out = C.c_void_p(0)
         self._ck(self.L.wf_hip_bars_mirror_ready(self.h, C.c_void_p(consumer_stream), C.byref(out)))
         return out.value
@@ -377,50 +383,33 @@ class SpectrumBatch:
     def meter(self, first: int = 0, count: int | None = None) -> np.ndarray:
         """meter batches: m_meter_val in dBFS, [count, capture_channels]"""
         count = self.streams - first if count is None else count
-        out = np.empty((count, self.capture_channels), np.float32)
-        self._ck(self.L.wf_hip_read_meter(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
-        return out
+        return self._read(OUT_METER, first, count, (self.capture_channels,), np.float32)
 
     def tsmooth(self, first: int = 0, count: int | None = None) -> np.ndarray:
-        count = self.streams - first if count is None else count
-        out = np.empty((count, self.capture_channels, self.bins), np.float32)
-        self._ck(self.L.wf_hip_read_tsmooth(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
-        return out
+        return self._read(OUT_TSMOOTH, first, count, (self.capture_channels, self.bins), np.float32)
 
     def set_tsmooth(self, state: np.ndarray, first: int = 0):
         s = np.ascontiguousarray(state, dtype=np.float32)
         self._ck(self.L.wf_hip_write_tsmooth(self.h, first, s.shape[0], s.ctypes.data_as(C.POINTER(C.c_float))))
 
     def last_silent(self, first: int = 0, count: int | None = None) -> np.ndarray:
-        count = self.streams - first if count is None else count
-        out = np.empty(count, np.uint8)
-        self._ck(self.L.wf_hip_read_last_silent(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_uint8))))
-        return out.astype(bool)
+        return self._read(OUT_LAST_SILENT, first, count, (), np.uint8).astype(bool)
 
     def waveform_ts(self, first: int = 0, count: int | None = None) -> np.ndarray:
         """m_waveform_ts per stream (ns) as the last enqueued tick leaves it (waveform batches)"""
-        count = self.streams - first if count is None else count
-        out = np.empty(count, np.uint64)
-        self._ck(self.L.wf_hip_read_waveform_ts(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_uint64))))
-        return out
+        return self._read(OUT_WAVEFORM_TS, first, count, (), np.uint64)
 
     def decibels_device_ptr(self) -> int:
         return int(self.L.wf_hip_decibels_device(self.h) or 0)
 
     def vertices(self, first: int = 0, count: int | None = None) -> np.ndarray:
         """[count, display_channels, num_vertices, 4]: what render_bars / render_curve hand to gs_draw (cfg.vertices)"""
-        count = self.streams - first if count is None else count
         n = int(self.L.wf_hip_num_vertices(self.h))
-        out = np.empty((count, self.display_channels, n, 4), np.float32)
-        self._ck(self.L.wf_hip_read_vertices(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
-        return out
+        return self._read(OUT_VERTICES, first, count, (self.display_channels, n, 4), np.float32)
 
     def vertex_counts(self, first: int = 0, count: int | None = None) -> np.ndarray:
         """[count, display_channels]: vertices each row's draw call uses (constant unless the bars are stepped)"""
-        count = self.streams - first if count is None else count
-        out = np.empty((count, self.display_channels), np.uint32)
-        self._ck(self.L.wf_hip_read_vertex_counts(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_uint32))))
-        return out
+        return self._read(OUT_VERTEX_COUNTS, first, count, (self.display_channels,), np.uint32)
 
     def bars_device_ptr(self) -> int:
         return int(self.L.wf_hip_bars_device(self.h) or 0)
@@ -429,23 +418,22 @@ class SpectrumBatch:
         return int(self.L.wf_hip_stream(self.h) or 0)
 
     # -- tables / measurement ---------------------------------------------------------------
+    def _table(self, which: int, ctype, dtype):
+        p = C.c_void_p()
+        n = int(self.L.wf_hip_table(self.h, which, C.byref(p)))
+        return _copy(C.cast(p, C.POINTER(ctype)), n, dtype) if p.value else None
+
     def table_window(self):
-        p, s = C.POINTER(C.c_float)(), C.c_float(0)
-        n = self.L.wf_hip_table_window(self.h, C.byref(p), C.byref(s))
-        return _copy(p, n), float(s.value)
+        return self._table(TABLE_WINDOW, C.c_float, np.float32), float(self._table(TABLE_WINDOW_SUM, C.c_float, np.float32)[0])
 
     def table(self, name: str):
         if name == "band_widths":
-            p = C.POINTER(C.c_int)()
-            n = self.L.wf_hip_table_band_widths(self.h, C.byref(p))
-            return _copy(p, n, np.int32)
+            return self._table(TABLE_BAND_WIDTHS, C.c_int, np.int32)
         if name == "interp_weights":
-            p, r, t = C.POINTER(C.c_float)(), C.c_int(0), C.c_int(0)
-            n = self.L.wf_hip_table_interp_weights(self.h, C.byref(p), C.byref(r), C.byref(t))
-            return _copy(p, n), r.value, t.value
-        p = C.POINTER(C.c_float)()
-        n = getattr(self.L, "wf_hip_table_" + name)(self.h, C.byref(p))
-        return _copy(p, n)
+            r, t = self._table(TABLE_INTERP_SHAPE, C.c_int, np.int32)
+            return self._table(TABLE_INTERP_WEIGHTS, C.c_float, np.float32), int(r), int(t)
+        which = {"slope": TABLE_SLOPE, "rolloff": TABLE_ROLLOFF, "interp_indices": TABLE_INTERP_INDICES}[name]
+        return self._table(which, C.c_float, np.float32)
 
     def gravity(self, seconds: float) -> float:
         return float(self.L.wf_hip_gravity(self.h, seconds))
@@ -561,19 +549,19 @@ class MultiBatch:
     def decibels(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.streams - first if count is None else count
         out = np.empty((count, self.output_channels, self.bins), np.float32)
-        self._ck(self.L.wf_hip_multi_read_decibels(self.m, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        self._ck(self.L.wf_hip_multi_read(self.m, OUT_DECIBELS, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def bars(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.streams - first if count is None else count
         out = np.empty((count, self.display_channels, self.num_bars), np.float32)
-        self._ck(self.L.wf_hip_multi_read_bars(self.m, first, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        self._ck(self.L.wf_hip_multi_read(self.m, OUT_BARS, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def last_silent(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.streams - first if count is None else count
         out = np.empty(count, np.uint8)
-        self._ck(self.L.wf_hip_multi_read_last_silent(self.m, first, count, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._ck(self.L.wf_hip_multi_read(self.m, OUT_LAST_SILENT, first, count, out.ctypes.data_as(C.c_void_p)))
         return out.astype(bool)
 
     def allgather_bars(self):

@@ -289,17 +289,6 @@ WF_DEV void big_finish(const TickArgs &a, int t, int kbase, uint32_t spec, bool 
         fill_mag(ts, mag);
     else if(do_db && (!(mono_mix && ch == 1) || underflow)) // skipped channel of a live stream: its stale row is re-dBFS'ed
         load_row<RG, true>(rows + (size_t)(mono_mix ? 0u : ch) * MO, t, mag, NB);
-#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 4 // (development: stop behind slope / smoothing / state)
-    {
-        float sacc = 0.0f;
-#pragma unroll
-        for(int i = 0; i < RP; ++i)
-            sacc += mag[i];
-        if(sacc == 1234.5f)
-            a.decibels[t] = sacc;
-        return;
-    }
-#endif
 
     // hidden / capture timeout: reset branch (reference :34-48)
     if(hidden && !was_silent) {
@@ -336,17 +325,6 @@ WF_DEV void big_finish(const TickArgs &a, int t, int kbase, uint32_t spec, bool 
 #pragma unroll
         for(int i = 0; i < RP; ++i)
             exceeds = exceeds || (4 * (t + RG::T * (i / 4)) < NB && d[i] > a.silent_floor);
-#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 5 // (... behind the dB arithmetic, in front of the row stores)
-        {
-            float sacc = 0.0f;
-#pragma unroll
-            for(int i = 0; i < RP; ++i)
-                sacc += d[i];
-            if(sacc == 1234.5f)
-                a.decibels[t] = sacc;
-            return;
-        }
-#endif
         store_row<RG, true, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
         if(dup_row)
             store_row<RG, true, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
@@ -636,46 +614,13 @@ template<bool ALIGNED> __global__ __launch_bounds__(GFold::T, GFold::T / 256) vo
     float mag[RG::P];
     P1Regs<G> r0, r1;
     const uint32_t acc = big_fused_fetch2<G, ALIGNED, WF_WHOLE_BURST>(a, t, x, start, r0, r1, lds);
-#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 1 // (development: where a workgroup's time goes -- stop behind the fetch)
-    {
-        float sacc = 0.0f;
-#pragma unroll
-        for(int j = 0; j < G::R1; ++j)
-            sacc += r0.smp[j][0] + r1.smp[j][1] + r0.smp[j][2] + r1.smp[j][3];
-        if(sacc == 1234.5f)
-            a.decibels[t] = sacc;
-        return;
-    }
-#endif
     big_whole_row<G, 0>(a, t, r0, lds, tw2_lds, mag);
-#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 2 // (... behind row 0)
-    {
-        float sacc = 0.0f;
-#pragma unroll
-        for(int j = 0; j < G::R1; ++j)
-            sacc += r1.smp[j][0] + r1.smp[j][1] + r1.smp[j][2] + r1.smp[j][3] + mag[4 * j] + mag[4 * j + 2];
-        if(sacc == 1234.5f)
-            a.decibels[t] = sacc;
-        return;
-    }
-#endif
 #pragma unroll
     for(int j = 1; j < G::R1; ++j) // (the pass-1 twiddles again: row 0's copies are not kept across its transform)
         if(tw1_row_loaded(j))
             p1_load_tw1<G>(a, t, j, r1.tw1[j]);
     __syncthreads(); // row 1's pass 1 writes where row 0's transform has just been read
     big_whole_row<G, 1>(a, t, r1, lds, tw2_lds, mag);
-#if defined(WF_EXP_WHOLE_CUT) && WF_EXP_WHOLE_CUT == 3 // (... behind both rows)
-    {
-        float sacc = 0.0f;
-#pragma unroll
-        for(int j = 0; j < RG::P; ++j)
-            sacc += mag[j];
-        if(sacc == 1234.5f)
-            a.decibels[t] = sacc;
-        return;
-    }
-#endif
     // x != 0.0f for any sample of the window (reference :63-72): a row's fetch sees all of it; the partner channel's window is
     // looked at only when this one is digital silence (workgroup-uniform and rare), as in spectrum_tick_kernel's split mode
     const bool nz_own = __syncthreads_or((acc & 0x7fffffffu) != 0u) != 0;

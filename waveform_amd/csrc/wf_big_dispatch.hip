@@ -32,7 +32,7 @@ int launch_tick_big_whole(wf_hip *h, const wf::TickArgs &a0, bool aligned)
     return WF_HIP_OK;
 }
 
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
 // The chain through device memory: columns -> rows (twice, with a pointwise product in between, for Bluestein's direct form) ->
 // epilogue.  Rounds 2-4 ran the sizes above 16384 on it; since round 5 every legal size has a faster path (big_whole_kernel, mixed-radix
 // rows, Bluestein rows inside LDS), and the chain is compiled into the development builds only, as the A/B baseline
@@ -90,7 +90,7 @@ template<int L1> int launch_tick_big_l(wf_hip *h, const wf::TickArgs &a0)
     return WF_HIP_OK;
 }
 
-#endif // WF_DEV_OVERRIDES
+#endif // WF_DEV_BUILD
 
 // fft sizes above 16384 whose n/2 is two rows of a mixed-radix transform: both rows and the end of the tick in one workgroup
 // (wf_big.hpp: big_mr_whole_kernel)
@@ -192,7 +192,7 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
             h->launch_rc = launch_tick_big_whole(h, s, aligned);
             continue;
         }
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         switch(h->big_rows) {
         case 2: h->launch_rc = launch_tick_big_l<2>(h, s); break;
         case 4: h->launch_rc = launch_tick_big_l<4>(h, s); break;
@@ -204,7 +204,7 @@ void launch_tick_big(wf_hip *h, const wf::TickArgs &a, bool aligned)
     }
 }
 
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
 template<int L1> int setup_big_rows(wf_hip *h)
 {
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_rows_kernel<L1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -234,7 +234,7 @@ int setup_launch_big(wf_hip *h)
         WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::big_br_rows_kernel<wf::G16384>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)wf::big_br_lds_bytes<wf::G16384>()));
     } else {
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         rc = h->big_rows == 2 ? setup_big_rows<2>(h) : h->big_rows == 4 ? setup_big_rows<4>(h) : setup_big_rows<8>(h);
 #else
         if(h->blu || h->big_rows != 2) // (no legal size gets here: every multiple of 16 above 16384 has rows of one kind or the other)
@@ -246,7 +246,7 @@ int setup_launch_big(wf_hip *h)
     // fft_size 65536 (the one power of two up here): both rows and the end of the tick in one kernel, no scratch in device memory.
     // WF_HIP_BIG_WHOLE=0 (development builds) sends it through the columns -> rows -> epilogue chain every other size up here takes
     h->big_whole = !h->blu && !h->big_mr && !h->big_br && h->big_rows == 2;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
     if(const char *e = std::getenv("WF_HIP_BIG_WHOLE"))
         h->big_whole = h->big_whole && e[0] != '0';
 #endif

@@ -540,7 +540,14 @@ int wf_hip_push_audio(wf_hip *h, uint32_t first, uint32_t count, const float *sa
 
 int wf_hip_push_audio_muted(wf_hip *h, uint32_t first, uint32_t count, const float *samples, uint32_t frames)
 {
-    return push_host(h, first, count, samples, frames, true);
+    if(samples != nullptr && h != nullptr && h->d_rms_ring != nullptr && !h->rms_feed)
+        return push_host(h, first, count, samples, frames, true); // the RMS producer takes the packet's samples
+    // a packet without data, or nobody to read it: CircularBuffer::push_back_zero
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    return push_common(h, first, count, nullptr, nullptr, frames);
 }
 
 int wf_hip_push_audio_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_samples, uint32_t frames, uint32_t slot)
@@ -694,15 +701,6 @@ int wf_hip_push_audio_device(wf_hip *h, uint32_t first, uint32_t count, const fl
         return fail(h, WF_HIP_ERR_INVALID, "d_samples is NULL");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     return push_common(h, first, count, d_samples, d_samples, frames);
-}
-
-int wf_hip_push_silence(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    WF_HIP_TRY(h, hipSetDevice(h->device));
-    return push_common(h, first, count, nullptr, nullptr, frames);
 }
 
 int wf_hip_push_synth(wf_hip *h, uint32_t first, uint32_t count, uint64_t seed, uint32_t stream_id0, uint64_t index0,
@@ -935,10 +933,8 @@ static int wf_hip_tick_impl(wf_hip *h, const wf_hip_tick_params *p)
     }
     if(h->split)
         h->flag_cur = (h->flag_cur + 1) % 3; // what the kernel wrote is what the next tick (and the readers) see
-    if(h->mirror_n) {
-        h->mirror_last = h->bars_mirror[h->mirror_next][0];
-        h->mirror_next ^= 1u;
-    }
+    if(h->mirror_n)
+        h->mirror_fresh = true;
     return WF_HIP_OK;
 }
 
@@ -1090,8 +1086,7 @@ static int enable_rms_producer(wf_hip *h, bool feed)
     return WF_HIP_OK;
 }
 
-int wf_hip_enable_input_rms(wf_hip *h) { return enable_rms_producer(h, false); }
-int wf_hip_enable_input_rms_feed(wf_hip *h) { return enable_rms_producer(h, true); }
+int wf_hip_enable_input_rms(wf_hip *h, int feed) { return enable_rms_producer(h, feed != 0); }
 
 int wf_hip_push_rms_ragged_async(wf_hip *h, uint32_t first, uint32_t count, const float *pinned_sq, const uint32_t *frames, uint32_t max_frames,
                                  uint32_t slot)
@@ -1102,7 +1097,7 @@ int wf_hip_push_rms_ragged_async(wf_hip *h, uint32_t first, uint32_t count, cons
     if(pinned_sq == nullptr || frames == nullptr || slot > 1 || max_frames == 0)
         return fail(h, WF_HIP_ERR_INVALID, "values or frames is NULL, max_frames is 0 or slot is not 0 / 1");
     if(!h->rms_feed)
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_push_rms_ragged_async needs wf_hip_enable_input_rms_feed");
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_push_rms_ragged_async needs wf_hip_enable_input_rms(h, 1)");
     if(max_frames > h->rms_size)
         return fail(h, WF_HIP_ERR_INVALID, "a feed of %u values per stream exceeds the RMS window (%u)", max_frames, h->rms_size);
     WF_HIP_TRY(h, hipSetDevice(h->device));
@@ -1173,34 +1168,6 @@ int wf_hip_push_rms_ragged_async(wf_hip *h, uint32_t first, uint32_t count, cons
     return WF_HIP_OK;
 }
 
-int wf_hip_read_input_rms_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(pinned_out == nullptr || slot > 1)
-        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL or slot is not 0 / 1");
-    if(h->d_input_rms == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "the device RMS producer is not enabled");
-    if(!h->rows_in_flight[slot] || h->read_stream == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_input_rms_async rides on the slot's wf_hip_read_rows_async: call that first");
-    WF_HIP_TRY(h, hipSetDevice(h->device));
-    // behind the rows' copy on the readback stream (which already waits for the tick); completes with wf_hip_readback_done(slot)
-    WF_HIP_TRY(h, hipMemcpyAsync(pinned_out, h->d_input_rms + first, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
-    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
-    return WF_HIP_OK;
-}
-
-int wf_hip_read_input_rms(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->d_input_rms == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "the device RMS producer is not enabled (wf_hip_enable_input_rms)");
-    return read_back(h, h->d_input_rms + first, out, (size_t)count * sizeof(float));
-}
-
 int wf_hip_sync(wf_hip *h)
 {
     if(h == nullptr)
@@ -1226,50 +1193,7 @@ static int read_back(wf_hip *h, const void *d, void *out, size_t bytes)
     return WF_HIP_OK;
 }
 
-int wf_hip_read_decibels(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->meter)
-        return fail(h, WF_HIP_ERR_INVALID, "meter batch: there is no m_decibels; read the levels with wf_hip_read_meter");
-    const size_t per = (size_t)h->out_ch * h->M;
-    return read_back(h, h->d_decibels + first * per, out, count * per * sizeof(float));
-}
-
-int wf_hip_read_bars(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->d_bars == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
-    const size_t per = (size_t)h->disp_ch * h->num_bars;
-    return read_back(h, h->d_bars + first * per, out, count * per * sizeof(float));
-}
-
 uint32_t wf_hip_num_vertices(const wf_hip *h) { return (h && h->d_verts) ? (uint32_t)h->vtab.per_row : 0u; }
-
-int wf_hip_read_vertices(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->d_verts == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "configuration has no vertex fill (cfg.vertices == 0)");
-    const size_t per = (size_t)h->disp_ch * h->vtab.per_row;
-    return read_back(h, h->d_verts + first * per, out, count * per * sizeof(wf::f4));
-}
-
-int wf_hip_read_vertex_counts(wf_hip *h, uint32_t first, uint32_t count, uint32_t *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->d_vert_counts == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "configuration has no vertex fill (cfg.vertices == 0)");
-    return read_back(h, h->d_vert_counts + (size_t)first * h->disp_ch, out, (size_t)count * h->disp_ch * sizeof(uint32_t));
-}
 
 const float *wf_hip_vertices_device(wf_hip *h)
 {
@@ -1279,7 +1203,7 @@ const float *wf_hip_vertices_device(wf_hip *h)
     return reinterpret_cast<const float *>(h->d_verts);
 }
 
-int wf_hip_read_bars_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
+static int read_bars_snapshot_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
 {
     int rc = check_range(h, first, count);
     if(rc)
@@ -1330,7 +1254,7 @@ __global__ void silent_bytes_kernel(const uint32_t *flags, uint32_t first, uint3
         out[i] = (flags[first + i] & wf::WF_STREAM_LAST_SILENT) ? 1 : 0;
 }
 
-int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_rows, uint8_t *pinned_last_silent, uint32_t slot)
+static int read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_rows, uint8_t *pinned_last_silent, uint32_t slot)
 {
     int rc = check_range(h, first, count);
     if(rc)
@@ -1373,19 +1297,7 @@ int wf_hip_read_rows_async(wf_hip *h, uint32_t first, uint32_t count, float *pin
     return WF_HIP_OK;
 }
 
-int wf_hip_read_premirror(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->d_bars_pre == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "the configuration has no mirrored display (cfg.mirror_freq_axis == 0, or no bars / curve)");
-    if(out == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL");
-    return read_back(h, h->d_bars_pre + (size_t)first * h->disp_ch, out, (size_t)count * h->disp_ch * sizeof(float));
-}
-
-int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
+static int read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
 {
     int rc = check_range(h, first, count);
     if(rc)
@@ -1395,7 +1307,7 @@ int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float
     if(h->d_bars_pre == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "the configuration has no mirrored display (cfg.mirror_freq_axis == 0, or no bars / curve)");
     if(!h->rows_in_flight[slot] || h->read_stream == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_premirror_async rides on the slot's wf_hip_read_rows_async: call that first");
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_async: premirror rides behind rows");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     WF_HIP_TRY(h, hipMemcpyAsync(pinned_out, h->d_bars_pre + (size_t)first * h->disp_ch, (size_t)count * h->disp_ch * sizeof(float), hipMemcpyDeviceToHost,
                                  h->read_stream));
@@ -1403,7 +1315,7 @@ int wf_hip_read_premirror_async(wf_hip *h, uint32_t first, uint32_t count, float
     return WF_HIP_OK;
 }
 
-int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_bars, float *pinned_vertices, uint32_t *pinned_counts,
+static int read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_bars, float *pinned_vertices, uint32_t *pinned_counts,
                               uint32_t slot)
 {
     int rc = check_range(h, first, count);
@@ -1416,7 +1328,7 @@ int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *
     if((pinned_vertices != nullptr || pinned_counts != nullptr) && h->d_verts == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "configuration has no vertex fill (cfg.vertices == 0)");
     if(!h->rows_in_flight[slot] || h->read_stream == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_display_async rides on the slot's wf_hip_read_rows_async: call that first");
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_async: bars / vertices ride behind rows");
     WF_HIP_TRY(h, hipSetDevice(h->device));
     // behind the rows' copy on the readback stream (which already waits for the tick, its bars and its vertex fill on every lane);
     // the next tick waits, on the device, for this slot's event before it overwrites any of them
@@ -1434,7 +1346,7 @@ int wf_hip_read_display_async(wf_hip *h, uint32_t first, uint32_t count, float *
     return WF_HIP_OK;
 }
 
-int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_levels, uint8_t *pinned_last_silent, uint32_t slot)
+static int read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_levels, uint8_t *pinned_last_silent, uint32_t slot)
 {
     int rc = check_range(h, first, count);
     if(rc)
@@ -1489,6 +1401,131 @@ int wf_hip_read_meter_async(wf_hip *h, uint32_t first, uint32_t count, float *pi
     return WF_HIP_OK;
 }
 
+// m_input_rms behind the rows' copy on the readback stream (which already waits for the tick)
+static int read_input_rms_async(wf_hip *h, uint32_t first, uint32_t count, float *pinned_out, uint32_t slot)
+{
+    if(h->d_input_rms == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "the device RMS producer is not enabled (wf_hip_enable_input_rms)");
+    WF_HIP_TRY(h, hipSetDevice(h->device));
+    WF_HIP_TRY(h, hipMemcpyAsync(pinned_out, h->d_input_rms + first, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->read_stream));
+    WF_HIP_TRY(h, hipEventRecord(h->ev_read[slot], h->read_stream));
+    return WF_HIP_OK;
+}
+
+int wf_hip_read_async(wf_hip *h, uint32_t first, uint32_t count, const wf_hip_readback *dst, uint32_t slot)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    if(dst == nullptr || slot > 1)
+        return fail(h, WF_HIP_ERR_INVALID, "destination set is NULL or slot is not 0 / 1");
+    const bool riders = dst->premirror || dst->vertices || dst->vertex_counts || dst->input_rms;
+    if(dst->meter) { // meter batches: level + m_last_silent, from snapshots
+        if(dst->last_silent == nullptr || dst->rows || dst->bars || riders)
+            return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_async: meter goes with last_silent and nothing else");
+        return read_meter_async(h, first, count, dst->meter, dst->last_silent, slot);
+    }
+    if(dst->rows == nullptr) { // the bars alone: from a snapshot per slot
+        if(dst->bars == nullptr || dst->last_silent || riders)
+            return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_async: without rows only the bars can be read (rows + last_silent lead every other combination)");
+        return read_bars_snapshot_async(h, first, count, dst->bars, slot);
+    }
+    if(dst->last_silent == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_read_async: rows go with last_silent");
+    rc = read_rows_async(h, first, count, dst->rows, dst->last_silent, slot);
+    if(rc == WF_HIP_OK && dst->input_rms)
+        rc = read_input_rms_async(h, first, count, dst->input_rms, slot);
+    if(rc == WF_HIP_OK && (dst->bars || dst->vertices || dst->vertex_counts))
+        rc = read_display_async(h, first, count, dst->bars, dst->vertices, dst->vertex_counts, slot);
+    if(rc == WF_HIP_OK && dst->premirror)
+        rc = read_premirror_async(h, first, count, dst->premirror, slot);
+    return rc;
+}
+
+// where an output lives on the device and how large it is per stream; nullptr + a text when the batch has none
+static const void *output_source(const wf_hip *h, wf_hip_output what, size_t *per_stream, const char **why)
+{
+    *per_stream = 0;
+    *why = "";
+    switch(what) {
+    case WF_HIP_OUT_DECIBELS:
+        if(h->meter) { *why = "meter batch: there is no m_decibels; read the levels (WF_HIP_OUT_METER)"; return nullptr; }
+        *per_stream = (size_t)h->out_ch * h->M * sizeof(float);
+        return h->d_decibels;
+    case WF_HIP_OUT_BARS:
+        if(h->d_bars == nullptr) { *why = "configuration has no bars (cfg.bars == 0 and cfg.curve == 0)"; return nullptr; }
+        *per_stream = (size_t)h->disp_ch * h->num_bars * sizeof(float);
+        return h->d_bars;
+    case WF_HIP_OUT_PREMIRROR:
+        if(h->d_bars_pre == nullptr) { *why = "the configuration has no mirrored display (cfg.mirror_freq_axis == 0, or no bars / curve)"; return nullptr; }
+        *per_stream = (size_t)h->disp_ch * sizeof(float);
+        return h->d_bars_pre;
+    case WF_HIP_OUT_VERTICES:
+        if(h->d_verts == nullptr) { *why = "configuration has no vertex fill (cfg.vertices == 0)"; return nullptr; }
+        *per_stream = (size_t)h->disp_ch * h->vtab.per_row * sizeof(wf::f4);
+        return h->d_verts;
+    case WF_HIP_OUT_VERTEX_COUNTS:
+        if(h->d_vert_counts == nullptr) { *why = "configuration has no vertex fill (cfg.vertices == 0)"; return nullptr; }
+        *per_stream = (size_t)h->disp_ch * sizeof(uint32_t);
+        return h->d_vert_counts;
+    case WF_HIP_OUT_LAST_SILENT:
+        *per_stream = sizeof(uint8_t); // (read as flag words, narrowed on the host)
+        return h->d_flags;
+    case WF_HIP_OUT_TSMOOTH:
+        if(h->meter || h->wave) { *why = "meter / waveform batch: there is no m_tsmooth_buf"; return nullptr; }
+        *per_stream = (size_t)h->cap_ch * h->M * sizeof(float);
+        return h->d_tsmooth;
+    case WF_HIP_OUT_METER:
+        if(!h->meter) { *why = "not a meter batch (cfg.meter == 0)"; return nullptr; }
+        *per_stream = (size_t)h->cap_ch * sizeof(float);
+        return h->d_meter_val;
+    case WF_HIP_OUT_INPUT_RMS:
+        if(h->d_input_rms == nullptr) { *why = "the device RMS producer is not enabled (wf_hip_enable_input_rms)"; return nullptr; }
+        *per_stream = sizeof(float);
+        return h->d_input_rms;
+    case WF_HIP_OUT_WAVEFORM_TS:
+        if(!h->wave || h->d_wts == nullptr) { *why = "m_waveform_ts belongs to waveform batches"; return nullptr; }
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t));
+        *per_stream = sizeof(uint64_t);
+        return h->d_wts;
+    }
+    *why = "unknown output";
+    return nullptr;
+}
+
+size_t wf_hip_output_bytes(const wf_hip *h, wf_hip_output what)
+{
+    if(h == nullptr)
+        return 0;
+    size_t per = 0;
+    const char *why = nullptr;
+    return output_source(h, what, &per, &why) ? per : 0;
+}
+
+int wf_hip_read(wf_hip *h, wf_hip_output what, uint32_t first, uint32_t count, void *out)
+{
+    int rc = check_range(h, first, count);
+    if(rc)
+        return rc;
+    size_t per = 0;
+    const char *why = nullptr;
+    const void *src = output_source(h, what, &per, &why);
+    if(src == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "%s", why);
+    if(out == nullptr)
+        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL");
+    if(what == WF_HIP_OUT_LAST_SILENT) { // the flag words of the buffer the newest tick wrote, narrowed to one byte per stream
+        std::vector<uint32_t> tmp(count);
+        rc = read_back(h, h->d_flags + (size_t)h->flag_cur * h->n_streams + first, tmp.data(), count * sizeof(uint32_t));
+        if(rc)
+            return rc;
+        for(uint32_t i = 0; i < count; ++i)
+            static_cast<uint8_t *>(out)[i] = (tmp[i] & wf::WF_STREAM_LAST_SILENT) ? 1 : 0;
+        return WF_HIP_OK;
+    }
+    return read_back(h, static_cast<const char *>(src) + (size_t)first * per, out, (size_t)count * per);
+}
+
 int wf_hip_readback_done(wf_hip *h, uint32_t slot)
 {
     if(h == nullptr || slot > 1)
@@ -1497,22 +1534,6 @@ int wf_hip_readback_done(wf_hip *h, uint32_t slot)
         return WF_HIP_OK;
     WF_HIP_TRY(h, hipSetDevice(h->device));
     WF_HIP_TRY(h, hipEventSynchronize(h->ev_read[slot]));
-    return WF_HIP_OK;
-}
-
-int wf_hip_copy_bars_device(wf_hip *h, uint32_t first, uint32_t count, void *d_out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->d_bars == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "configuration has no bars (cfg.bars == 0)");
-    if(d_out == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "output pointer is NULL");
-    const size_t per = (size_t)h->disp_ch * h->num_bars;
-    WF_HIP_TRY(h, hipSetDevice(h->device));
-    WF_HIP_TRY(h, hipMemcpyAsync(d_out, h->d_bars + first * per, count * per * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
     return WF_HIP_OK;
 }
 
@@ -1565,23 +1586,22 @@ int wf_hip_set_bars_mirrors(wf_hip *h, uint32_t n, void *const *d_out0, void *co
             if(d_out0[j] == nullptr || d_out1[j] == nullptr || d_out0[j] == d_out1[j] || d_out0[j] == (void *)h->d_bars || d_out1[j] == (void *)h->d_bars)
                 return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirrors: buffer %u of a set is NULL, the same in both sets or the handle's own", j);
     }
+    // ticks still in flight write the old buffers: they must have run before the sets are replaced (and the caller frees them)
+    if(h->mirror_n) {
+        WF_HIP_TRY(h, hipSetDevice(h->device));
+        WF_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for(int l = 1; l < h->n_lanes; ++l)
+            if(h->lane_stream[l])
+                WF_HIP_TRY(h, hipStreamSynchronize(h->lane_stream[l]));
+    }
     for(uint32_t j = 0; j < 8; ++j) {
         h->bars_mirror[0][j] = j < n ? static_cast<float *>(d_out0[j]) : nullptr;
         h->bars_mirror[1][j] = j < n ? static_cast<float *>(d_out1[j]) : nullptr;
     }
     h->mirror_n = n;
     h->mirror_next = 0;
-    h->mirror_last = nullptr;
+    h->mirror_fresh = false;
     return WF_HIP_OK;
-}
-
-int wf_hip_set_bars_mirror(wf_hip *h, void *d_out0, void *d_out1)
-{
-    if(h == nullptr)
-        return WF_HIP_ERR_INVALID;
-    if((d_out0 == nullptr) != (d_out1 == nullptr))
-        return fail(h, WF_HIP_ERR_INVALID, "wf_hip_set_bars_mirror: two buffers, or NULL and NULL");
-    return wf_hip_set_bars_mirrors(h, d_out0 ? 1u : 0u, &d_out0, &d_out1);
 }
 
 int wf_hip_bars_mirror_ready(wf_hip *h, void *consumer_stream, void **d_out)
@@ -1589,21 +1609,32 @@ int wf_hip_bars_mirror_ready(wf_hip *h, void *consumer_stream, void **d_out)
     if(h == nullptr || d_out == nullptr)
         return WF_HIP_ERR_INVALID;
     if(h->mirror_n == 0)
-        return fail(h, WF_HIP_ERR_INVALID, "no mirror buffers set (wf_hip_set_bars_mirror)");
+        return fail(h, WF_HIP_ERR_INVALID, "no mirror buffers set (wf_hip_set_bars_mirrors)");
     if(consumer_stream == nullptr)
         return fail(h, WF_HIP_ERR_INVALID, "consumer stream is NULL");
-    *d_out = h->mirror_last;
+    float *const *set = h->bars_mirror[h->mirror_next];
     WF_HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t cs = static_cast<hipStream_t>(consumer_stream);
+    const size_t per = (size_t)h->disp_ch * h->num_bars;
     // as wf_hip_copy_bars_device_async: the lanes are not joined -- the consumer waits for each of them
     const int lanes = h->lanes_pending ? h->n_lanes : 1;
     for(int l = 0; l < lanes; ++l) {
         hipStream_t st = l == 0 ? h->stream : h->lane_stream[l];
         if(h->ev_bars_lane[l] == nullptr)
             WF_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_bars_lane[l], hipEventDisableTiming));
+        if(!h->mirror_fresh) {
+            // no tick has written this set: the handle's own bars stand in (each lane copies the slice its ticks write)
+            const uint32_t lo = lanes == 1 ? 0u : (uint32_t)((uint64_t)h->n_streams * l / lanes);
+            const uint32_t hi = lanes == 1 ? h->n_streams : (uint32_t)((uint64_t)h->n_streams * (l + 1) / lanes);
+            for(uint32_t j = 0; j < h->mirror_n && hi > lo; ++j)
+                WF_HIP_TRY(h, hipMemcpyAsync(set[j] + (size_t)lo * per, h->d_bars + (size_t)lo * per, (size_t)(hi - lo) * per * sizeof(float), hipMemcpyDefault, st));
+        }
         WF_HIP_TRY(h, hipEventRecord(h->ev_bars_lane[l], st));
         WF_HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_bars_lane[l], 0));
     }
+    *d_out = set[0];
+    h->mirror_next ^= 1u;
+    h->mirror_fresh = false;
     return WF_HIP_OK;
 }
 
@@ -1618,27 +1649,6 @@ int wf_hip_wait_event(wf_hip *h, void *event)
         if(h->lane_stream[l])
             WF_HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], ev, 0));
     return WF_HIP_OK;
-}
-
-int wf_hip_read_meter(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(!h->meter)
-        return fail(h, WF_HIP_ERR_INVALID, "not a meter batch (cfg.meter == 0)");
-    return read_back(h, h->d_meter_val + (size_t)first * h->cap_ch, out, (size_t)count * h->cap_ch * sizeof(float));
-}
-
-int wf_hip_read_tsmooth(wf_hip *h, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(h->meter || h->wave)
-        return fail(h, WF_HIP_ERR_INVALID, "meter / waveform batch: there is no m_tsmooth_buf");
-    const size_t per = (size_t)h->cap_ch * h->M;
-    return read_back(h, h->d_tsmooth + first * per, out, count * per * sizeof(float));
 }
 
 int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float *in)
@@ -1657,33 +1667,6 @@ int wf_hip_write_tsmooth(wf_hip *h, uint32_t first, uint32_t count, const float 
     return WF_HIP_OK;
 }
 
-int wf_hip_read_last_silent(wf_hip *h, uint32_t first, uint32_t count, uint8_t *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    std::vector<uint32_t> tmp(count);
-    rc = read_back(h, h->d_flags + (size_t)h->flag_cur * h->n_streams + first, tmp.data(), count * sizeof(uint32_t));
-    if(rc)
-        return rc;
-    for(uint32_t i = 0; i < count; ++i)
-        out[i] = (tmp[i] & wf::WF_STREAM_LAST_SILENT) ? 1 : 0;
-    return WF_HIP_OK;
-}
-
-int wf_hip_read_waveform_ts(wf_hip *h, uint32_t first, uint32_t count, uint64_t *out)
-{
-    int rc = check_range(h, first, count);
-    if(rc)
-        return rc;
-    if(!h->wave || h->d_wts == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "m_waveform_ts belongs to waveform batches");
-    if(out == nullptr)
-        return fail(h, WF_HIP_ERR_INVALID, "out is NULL");
-    static_assert(sizeof(unsigned long long) == sizeof(uint64_t));
-    return read_back(h, h->d_wts + first, out, (size_t)count * sizeof(uint64_t));
-}
-
 float *wf_hip_decibels_device(wf_hip *h) { return h ? h->d_decibels : nullptr; }
 float *wf_hip_bars_device(wf_hip *h) { return h ? h->d_bars : nullptr; }
 void *wf_hip_stream(wf_hip *h)
@@ -1694,38 +1677,34 @@ void *wf_hip_stream(wf_hip *h)
     return (void *)h->stream;
 }
 
-size_t wf_hip_table_window(const wf_hip *h, const float **out, float *window_sum)
+size_t wf_hip_table(const wf_hip *h, wf_hip_table_id which, const void **out)
 {
-    if(window_sum) *window_sum = h->tab.window_sum;
-    if(out) *out = h->tab.window.empty() ? nullptr : h->tab.window.data();
-    return h->tab.window.size();
-}
-size_t wf_hip_table_slope(const wf_hip *h, const float **out)
-{
-    if(out) *out = h->tab.slope.empty() ? nullptr : h->tab.slope.data();
-    return h->tab.slope.size();
-}
-size_t wf_hip_table_rolloff(const wf_hip *h, const float **out)
-{
-    if(out) *out = h->tab.rolloff.empty() ? nullptr : h->tab.rolloff.data();
-    return h->tab.rolloff.size();
-}
-size_t wf_hip_table_interp_indices(const wf_hip *h, const float **out)
-{
-    if(out) *out = h->tab.interp_indices.empty() ? nullptr : h->tab.interp_indices.data();
-    return h->tab.interp_indices.size();
-}
-size_t wf_hip_table_band_widths(const wf_hip *h, const int **out)
-{
-    if(out) *out = h->tab.band_widths.empty() ? nullptr : h->tab.band_widths.data();
-    return h->tab.band_widths.size();
-}
-size_t wf_hip_table_interp_weights(const wf_hip *h, const float **out, int *radius, int *taps)
-{
-    if(radius) *radius = h->tab.interp_radius;
-    if(taps) *taps = h->tab.interp_taps;
-    if(out) *out = h->tab.interp_weights.empty() ? nullptr : h->tab.interp_weights.data();
-    return h->tab.interp_weights.size();
+    if(out)
+        *out = nullptr;
+    if(h == nullptr)
+        return 0;
+    auto give = [&](const auto &v) -> size_t {
+        if(out)
+            *out = v.empty() ? nullptr : static_cast<const void *>(v.data());
+        return v.size();
+    };
+    switch(which) {
+    case WF_HIP_TABLE_WINDOW: return give(h->tab.window);
+    case WF_HIP_TABLE_WINDOW_SUM:
+        if(out)
+            *out = &h->tab.window_sum;
+        return 1;
+    case WF_HIP_TABLE_SLOPE: return give(h->tab.slope);
+    case WF_HIP_TABLE_ROLLOFF: return give(h->tab.rolloff);
+    case WF_HIP_TABLE_INTERP_INDICES: return give(h->tab.interp_indices);
+    case WF_HIP_TABLE_BAND_WIDTHS: return give(h->tab.band_widths);
+    case WF_HIP_TABLE_INTERP_WEIGHTS: return give(h->tab.interp_weights);
+    case WF_HIP_TABLE_INTERP_SHAPE:
+        if(out)
+            *out = h->interp_shape;
+        return 2;
+    }
+    return 0;
 }
 float wf_hip_gravity(const wf_hip *h, float seconds) { return wf::gravity_for(h->cfg, seconds); }
 float wf_hip_db_min(void) { return wf::db_min(); }
@@ -1783,6 +1762,7 @@ int wf_hip_time_ticks(wf_hip *h, const wf_hip_tick_params *p, uint32_t ticks, ui
 // if that much more audio had been captured before what the rings hold now -- `frames` must be a multiple of every ring
 // capacity, so that positions keep addressing the same ring cells.  Lets a test reach the 2^32-sample wrap-around (a day
 // of audio at 48 kHz) without pushing a day of audio.
+#ifdef WF_DEV_BUILD
 extern "C" int wf_hip_debug_age(wf_hip *h, uint32_t first, uint32_t count, uint32_t frames)
 {
     int rc = check_range(h, first, count);
@@ -1798,6 +1778,7 @@ extern "C" int wf_hip_debug_age(wf_hip *h, uint32_t first, uint32_t count, uint3
     h->main_dirty = true;
     return WF_HIP_OK;
 }
+#endif
 
 #ifdef WF_PHASE_TIMING
 // development aid: copies the per-workgroup s_memtime stamps of the last tick (16 per workgroup)

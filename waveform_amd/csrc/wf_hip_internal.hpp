@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "wf_hip.h"
+#include "wf_dev_guard.hpp"
 #include "wf_host_tables.hpp"
 #include "wf_tick_phases.hpp" // TickArgs, BarsOnlyState (plain structs: no kernel is instantiated by including it)
 
@@ -101,14 +102,15 @@ struct wf_hip {
     size_t big_out_lds = 0;          // dynamic LDS of big_outputs_kernel
     int *d_big_task = nullptr, *d_big_bar_task = nullptr; // BarArgs::big_task / big_bar_task
     int big_num_tasks = 0;
+    int interp_shape[2] = {0, 0};    // {tab.interp_radius, tab.interp_taps} (WF_HIP_TABLE_INTERP_SHAPE)
     float *d_bars = nullptr;
     float *d_bars_pre = nullptr;    // BarArgs::pre_out: [n_streams][disp_ch], mirrored displays only
-    // wf_hip_set_bars_mirror(s): the caller-owned buffers the ticks also write their bars into -- mirror_n of them per tick, the
-    // two sets alternately
+    // wf_hip_set_bars_mirrors: the caller-owned buffers the ticks also write their bars into -- the mirror_n buffers of the write
+    // set; wf_hip_bars_mirror_ready hands the write set over and makes the other one the write set
     float *bars_mirror[2][8] = {};
     uint32_t mirror_n = 0;
-    uint32_t mirror_next = 0;       // the buffer the next tick writes
-    float *mirror_last = nullptr;   // the buffer the newest tick wrote
+    uint32_t mirror_next = 0;       // the set the ticks write
+    bool mirror_fresh = false;      // a tick has written set mirror_next since it became the write set
     wf::VertexTables vtab;           // cfg.vertices: the vertex fill behind every tick
     wf::f4 *d_verts = nullptr;
     uint32_t *d_vert_counts = nullptr; // [n_streams][disp_ch] vertices of each row's draw call

@@ -152,6 +152,7 @@ struct Shard {
     bool mirror = false;
     bool direct = false; // peer transport with peer access everywhere: the tick kernel stores this shard's slice into every device's result itself
     uint32_t cur_slot = 0; // the slot of the gather in flight / issued last on this shard
+    bool peer_ok[64] = {}; // [j]: this device may address device j's memory (peer access enabled, or the same device)
     ncclComm_t comm = nullptr;
     Worker worker;
     std::string err;
@@ -254,39 +255,25 @@ int check_range(wf_hip_multi *m, uint32_t first, uint32_t count)
 int gather_issue(wf_hip_multi *m, uint32_t i, uint32_t k)
 {
     Shard &s = *m->shard[i];
+#ifdef WF_DEV_BUILD
     if(m->debug_fail_shard == (int)i) { // (test aid: fails before anything is enqueued, as a failed wait or copy would)
         s.err = "injected failure (wf_hip_multi_debug_fail_next_gather)";
         return WF_HIP_ERR_RUNTIME;
     }
+#endif
     int rc;
     if(s.mirror) {
-        // the newest tick wrote the bars into one of the two buffers itself: the gather stream waits for that tick, nothing is copied
+        // the handle's ticks have written the bars into one of the two sets themselves (wf_hip_bars_mirror_ready: the gather stream
+        // waits for the newest tick, the other set becomes the ticks' target; a set no tick has written is filled from the
+        // handle's own bars): nothing is copied here
         void *buf = nullptr;
         rc = wf_hip_bars_mirror_ready(s.h, s.gstream, &buf);
         if(rc)
             return rc;
-        float *const *tgt = (m->transport == Transport::LOCAL) ? s.gathered : s.send;
-        float *direct_tgt[2] = {nullptr, nullptr};
-        if(s.direct) { // buffer 0 of a set: this shard's slice of device 0's result
-            direct_tgt[0] = m->shard[0]->gathered[0] + (size_t)s.first * m->per;
-            direct_tgt[1] = m->shard[0]->gathered[1] + (size_t)s.first * m->per;
-            tgt = direct_tgt;
-        }
-        if(buf == nullptr) { // no tick since the mirror was set: the handle's own buffer is the only copy
-            k = 0;
-            if(s.direct) {
-                for(uint32_t j = 0; j < m->n; ++j) {
-                    rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, m->shard[j]->gathered[0] + (size_t)s.first * m->per, s.gstream);
-                    if(rc)
-                        return rc;
-                }
-            } else {
-                rc = wf_hip_copy_bars_device_async(s.h, 0, s.count, tgt[0], s.gstream);
-                if(rc)
-                    return rc;
-            }
-        } else
-            k = buf == (void *)tgt[1] ? 1u : 0u;
+        // buffer 0 of a set: the send buffer (RCCL, peer copies), the result itself (one device), or -- direct peer stores -- this
+        // shard's slice of device 0's result
+        const float *b1 = s.direct ? m->shard[0]->gathered[1] + (size_t)s.first * m->per : (m->transport == Transport::LOCAL) ? s.gathered[1] : s.send[1];
+        k = buf == (const void *)b1 ? 1u : 0u;
     } else {
         if(s.slot_used[k]) { // the gather that read this send buffer two gathers ago must have run before the buffer is rewritten
             rc = wf_hip_wait_event(s.h, s.ev_done[k]);
@@ -335,18 +322,32 @@ int gather_complete(wf_hip_multi *m, uint32_t i, uint32_t k)
 {
     Shard &s = *m->shard[i];
     if(s.mirror)
-        k = s.cur_slot; // (every shard's handle has run the same number of ticks: the same slot on all of them)
+        k = s.cur_slot; // (the group has handed over every shard's set the same number of times: the same slot on all of them -- checked by the callers)
     if(m->transport == Transport::PEER)
         for(uint32_t j = 0; j < m->n; ++j)
             if(j != i)
                 WF_MHIP(s, hipStreamWaitEvent(s.gstream, m->shard[j]->ev_sent[k], 0));
     WF_MHIP(s, hipEventRecord(s.ev_done[k], s.gstream));
     s.slot_used[k] = true;
-    // The next tick writes the other slot's buffer.  Where that is a SEND buffer (RCCL; peer copies), the exchange that read it -- a tick
-    // old -- must have run: a host wait that returns at once (a device-side wait in front of every tick cost 4 % of the tick rate).
-    // Where the kernels store into the results themselves (local, direct peer stores) nothing inside the group reads the buffer.
+    // The ticks issued from here on write the other slot's buffers (the hand-over in gather_issue made them the write set).  Where
+    // that is a SEND buffer (RCCL; peer copies), the exchange that read it -- a gather old -- must have run: a host wait that returns
+    // at once (a device-side wait in front of every tick cost 4 % of the tick rate).  Where the kernels store into the results
+    // themselves (local, direct peer stores) nothing inside the group reads the buffer: it is the result of the gather before this
+    // one, which the header's contract gives up with the first tick after this gather.
     if(s.mirror && !s.direct && m->transport != Transport::LOCAL && s.slot_used[k ^ 1u])
         WF_MHIP(s, hipEventSynchronize(s.ev_done[k ^ 1u]));
+    return WF_HIP_OK;
+}
+
+// Zero-copy gathers: the slot is the set each shard's handle has just handed over.  The group hands over all of them together, so
+// they agree -- unless somebody called wf_hip_bars_mirror_ready / wf_hip_set_bars_mirrors on a shard handle behind the group's back
+// (the header forbids it): the pieces of the result would then lie in different buffers.
+int slots_agree(wf_hip_multi *m)
+{
+    for(uint32_t i = 1; i < m->n; ++i)
+        if(m->shard[i]->mirror && m->shard[0]->mirror && m->shard[i]->cur_slot != m->shard[0]->cur_slot)
+            return mfail(m, WF_HIP_ERR_RUNTIME, "shard %u handed over bars buffer %u, shard 0 buffer %u: the shards' mirror buffers were handed over or replaced outside the group",
+                         i, m->shard[i]->cur_slot, m->shard[0]->cur_slot);
     return WF_HIP_OK;
 }
 
@@ -574,10 +575,15 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
                 for(uint32_t j = 0; j < m->n; ++j) {
                     const int other = m->shard[j]->device;
                     int can = 0;
-                    if(other != s.device && hipDeviceCanAccessPeer(&can, s.device, other) == hipSuccess && can) {
-                        (void)hipDeviceEnablePeerAccess(other, 0); // (already enabled / refused: not fatal, the copies still work, staged)
+                    bool ok = other == s.device;
+                    if(!ok && hipDeviceCanAccessPeer(&can, s.device, other) == hipSuccess && can) {
+                        // (refused: not fatal for the copies, which are then staged -- but kernel stores to that device's memory would
+                        // fault: direct peer stores need the mapping to exist, for every ordered pair)
+                        const hipError_t pe = hipDeviceEnablePeerAccess(other, 0);
+                        ok = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
                         (void)hipGetLastError();
                     }
+                    s.peer_ok[j] = ok;
                 }
             return (int)WF_HIP_OK;
         });
@@ -588,14 +594,11 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
         if(rc == WF_HIP_OK) {
             const char *e = std::getenv("WF_HIP_MULTI_MIRROR");
             bool all_peer = m->transport == Transport::PEER && m->n <= 8 && !(e && std::strcmp(e, "send") == 0);
-            for(uint32_t i = 0; i < m->n && all_peer; ++i)
-                for(uint32_t j = 0; j < m->n && all_peer; ++j) {
-                    const int a = m->shard[i]->device, b = m->shard[j]->device;
-                    int can = a == b ? 1 : 0;
-                    if(a != b && (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can))
-                        all_peer = false;
-                }
-            (void)hipGetLastError();
+            for(uint32_t i = 0; i < m->n && all_peer; ++i) // hipDeviceEnablePeerAccess succeeded (or had before) on device i for device j
+                for(uint32_t j = 0; j < m->n && all_peer; ++j)
+                    all_peer = m->shard[i]->peer_ok[j];
+            if(m->transport == Transport::PEER && !all_peer && m->transport_note.empty())
+                m->transport_note = "peer access is not enabled between every pair of devices: the bars travel by hipMemcpyPeerAsync";
             rc = run_all(m, [m, e, all_peer](uint32_t i) {
                 Shard &s = *m->shard[i];
                 if(e && e[0] == '0')
@@ -610,7 +613,8 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
                     mrc = wf_hip_set_bars_mirrors(s.h, m->n, set0, set1);
                 } else {
                     float *const *tgt = (m->transport == Transport::LOCAL) ? s.gathered : s.send;
-                    mrc = wf_hip_set_bars_mirror(s.h, tgt[0], tgt[1]);
+                    void *b0 = tgt[0], *b1 = tgt[1];
+                    mrc = wf_hip_set_bars_mirrors(s.h, 1, &b0, &b1);
                 }
                 if(mrc == WF_HIP_OK) {
                     s.mirror = true;
@@ -729,53 +733,22 @@ int wf_hip_multi_sync(wf_hip_multi *m)
     });
 }
 
-int wf_hip_multi_read_decibels(wf_hip_multi *m, uint32_t first, uint32_t count, float *out)
+int wf_hip_multi_read(wf_hip_multi *m, wf_hip_output what, uint32_t first, uint32_t count, void *out)
 {
     int rc = check_range(m, first, count);
     if(rc)
         return rc;
     if(out == nullptr)
         return mfail(m, WF_HIP_ERR_INVALID, "out is NULL");
-    const size_t per_stream = (size_t)wf_hip_output_channels(m->shard[0]->h) * (wf_hip_fft_size(m->shard[0]->h) / 2);
+    const size_t per_stream = wf_hip_output_bytes(m->shard[0]->h, what);
+    if(per_stream == 0) // (the shard's own error text: why the batch has no such output)
+        return run_all(m, [=](uint32_t i) { return i == 0 ? wf_hip_read(m->shard[0]->h, what, 0, 1, out) : (int)WF_HIP_OK; });
     return run_all(m, [=](uint32_t i) {
         Shard &s = *m->shard[i];
         uint32_t lf, lc, off;
         if(!overlap(s, first, count, &lf, &lc, &off))
             return (int)WF_HIP_OK;
-        return wf_hip_read_decibels(s.h, lf, lc, out + (size_t)off * per_stream);
-    });
-}
-
-int wf_hip_multi_read_bars(wf_hip_multi *m, uint32_t first, uint32_t count, float *out)
-{
-    int rc = check_range(m, first, count);
-    if(rc)
-        return rc;
-    if(out == nullptr)
-        return mfail(m, WF_HIP_ERR_INVALID, "out is NULL");
-    const size_t per = m->per;
-    return run_all(m, [=](uint32_t i) {
-        Shard &s = *m->shard[i];
-        uint32_t lf, lc, off;
-        if(!overlap(s, first, count, &lf, &lc, &off))
-            return (int)WF_HIP_OK;
-        return wf_hip_read_bars(s.h, lf, lc, out + (size_t)off * per);
-    });
-}
-
-int wf_hip_multi_read_last_silent(wf_hip_multi *m, uint32_t first, uint32_t count, uint8_t *out)
-{
-    int rc = check_range(m, first, count);
-    if(rc)
-        return rc;
-    if(out == nullptr)
-        return mfail(m, WF_HIP_ERR_INVALID, "out is NULL");
-    return run_all(m, [=](uint32_t i) {
-        Shard &s = *m->shard[i];
-        uint32_t lf, lc, off;
-        if(!overlap(s, first, count, &lf, &lc, &off))
-            return (int)WF_HIP_OK;
-        return wf_hip_read_last_silent(s.h, lf, lc, out + off);
+        return wf_hip_read(s.h, what, lf, lc, static_cast<char *>(out) + (size_t)off * per_stream);
     });
 }
 
@@ -787,6 +760,8 @@ int wf_hip_multi_allgather_bars(wf_hip_multi *m)
     const uint32_t k = m->gathers & 1u;
     rc = run_all(m, [m, k](uint32_t i) { return gather_issue(m, i, k); });
     // (run_all returning is the host barrier between the halves: every ev_sent of this slot has been recorded)
+    if(rc == WF_HIP_OK)
+        rc = slots_agree(m);
     if(rc == WF_HIP_OK)
         rc = run_all(m, [m, k](uint32_t i) { return gather_complete(m, i, k); });
     if(rc) { // some shards have enqueued their half: see gather_fail
@@ -805,6 +780,7 @@ const float *wf_hip_multi_gathered_device(wf_hip_multi *m, uint32_t i)
     return m->shard[i]->gathered[m->last_slot];
 }
 
+#ifdef WF_DEV_BUILD
 // Test aid: shard `shard`'s next gather reports a failure before it enqueues anything -- what a failed wait or copy on one
 // device looks like to the others, which have their half of the exchange in flight by then.
 int wf_hip_multi_debug_fail_next_gather(wf_hip_multi *m, uint32_t shard)
@@ -814,6 +790,7 @@ int wf_hip_multi_debug_fail_next_gather(wf_hip_multi *m, uint32_t shard)
     m->debug_fail_shard = (int)shard;
     return WF_HIP_OK;
 }
+#endif
 
 void *wf_hip_multi_gather_stream(wf_hip_multi *m, uint32_t i) { return (m && i < m->n) ? m->shard[i]->gstream : nullptr; }
 

@@ -109,6 +109,8 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         return fail(nullptr, WF_HIP_ERR_NOMEM, "out of host memory");
     h->cfg = *cfg;
     h->tab = std::move(tab);
+    h->interp_shape[0] = h->tab.interp_radius;
+    h->interp_shape[1] = h->tab.interp_taps;
     h->device = device;
     if(const char *e = std::getenv("WF_HIP_CANARY")) // guard bytes behind every device block, checked by wf_hip_sync
         h->canary = e[0] == '1';
@@ -129,7 +131,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         // above 16384 samples and not a power of two: where n/2 = C R with R <= 8192 a length that has a mixed-radix plan, C <= 8
         // rows of that transform (big_mr_rows_kernel) instead of Bluestein through device memory
         bool big_direct = true;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         if(const char *no_mr = std::getenv("WF_HIP_NO_MIXED_RADIX")) // (development: A/B against Bluestein)
             big_direct = no_mr[0] != '1';
 #endif
@@ -138,7 +140,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // ... and where n/2 = C R with C = 8 or 4 and R <= 4096: the rows by Bluestein over the 8192- / 16384-sample geometry INSIDE
             // LDS (big_br_*_kernel) -- every multiple of 16 up here, the slider's 768 positions among them
             bool rows_ok = true;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             if(const char *no_br = std::getenv("WF_HIP_NO_BLUESTEIN_ROWS")) // (development: A/B against Bluestein through device memory)
                 rows_ok = no_br[0] != '1';
 #endif
@@ -146,7 +148,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // 48064 x 256 streams 0.254 ms with 8 rows over 8192 points, 0.194 with 16 over 4096, 0.209 with 32 over 2048
             // (32 rows over 1024 / 2048 points: 0.209 -- profiles/r05m_bluestein_rows_ab.txt; not compiled in any more)
             uint32_t br_c = 0, br_first = 16u;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             if(const char *e = std::getenv("WF_HIP_BR_ROWS")) // 8: every size on 8 rows (A/B)
                 br_first = std::atoi(e) == 8 ? 8u : 16u;
 #endif
@@ -154,7 +156,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 if(np % c == 0 && np / c <= 4096u && np / c >= 512u)
                     br_c = c;
             bool mrw_ok = true;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             if(const char *e = std::getenv("WF_HIP_MR_WHOLE")) // 0: two rows through rows + epilogue like the others (A/B)
                 mrw_ok = e[0] != '0';
 #endif
@@ -208,7 +210,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         // channels: +2.5-4 % on the 1 MB rows of bench.py (60.0-60.3 -> 61.7-63.2 % of peak, three interleaved runs), nothing
         // to gain on shallow rings.  WF_HIP_RING_PAD=<floats> overrides (development aid).
         uint32_t pad = h->ring_cap >= 65536u ? 16448u : 0u;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         if(const char *e = std::getenv("WF_HIP_RING_PAD"))
             pad = (uint32_t)std::strtoul(e, nullptr, 10) & ~3u;
 #endif
@@ -280,7 +282,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     // peak (two workgroups per CU instead of one), N = 8192 57.2 -> 58.5 % (four instead of two), N = 32768 cannot run a
     // pair any other way.  WF_HIP_SPLIT=0/1 overrides (development aid; mono mixdown and single-channel captures never split).
     bool want_split = h->geom_n >= 8192;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
     if(const char *e = std::getenv("WF_HIP_SPLIT"))
         want_split = (e[0] == '1') && h->geom_n >= 8192;
 #endif
@@ -374,7 +376,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             else
                 direct = G::N >= 1024 && wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, radix, (uint64_t)G::M) > 0;
         });
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         if(const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX"))
             direct = direct && off[0] != '1';
 #endif
@@ -420,7 +422,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // of both spectra (spectrum_tick_kernel, BarArgs::both_subs)
             h->curve_both = !cfg->stereo && cfg->capture_channels == 2 && !own_kernel && !want_split && !h->blu && h->N >= 1024u &&
                             true; // (the kernels that exist with BOTH: wf_tick_geom.hip, setup_launch)
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             h->curve_both = h->curve_both && std::getenv("WF_HIP_TLDS") == nullptr;
             if(const char *e = std::getenv("WF_HIP_CURVE_BOTH"))
                 h->curve_both = h->curve_both && e[0] != '0';
@@ -447,7 +449,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             if(h->blu) // Bluestein proper keeps bar_segments' layouts (its instantiations are compiled without this one); the sizes
                        // that will run as a mixed-radix transform take it
                 want_pieces = want_pieces && mixed_radix_direct();
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             if(const char *e = std::getenv("WF_HIP_BAR_PIECES"))
                 want_pieces = want_pieces && e[0] != '0';
 #endif
@@ -455,7 +457,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // per-thread coefficient table at all); power-of-two sizes from 512 samples, no Gaussian filter
             wf::BarPsTables ps;
             bool want_ps = h->tab.gauss_radius == 0 && h->N >= 512u && !h->blu;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             if(const char *e = std::getenv("WF_HIP_BAR_PS"))
                 want_ps = want_ps && e[0] != '0';
 #endif
@@ -479,7 +481,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                 WF_PLAN_HIP(hipStreamSynchronize(h->stream)); // the staging vectors die here
             }
             bool local = h->tab.gauss_radius == 0;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             if(const char *e = std::getenv("WF_HIP_BARS_WAVE_LOCAL"))
                 local = local && e[0] != '0';
 #endif
@@ -509,7 +511,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             if(!h->curve && !h->tab.bar_off.empty()) {
                 std::vector<int> task, bar_task(h->tab.bar_off.size(), 0);
                 int cap = 2048;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
                 if(const char *e = std::getenv("WF_HIP_BIG_TASK")) // (development: the task size, a multiple of 64)
                     cap = std::max(64, std::atoi(e) & ~63);
 #endif
@@ -600,7 +602,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
     if(h->num_bars) {
         const size_t mark = h->allocs.size();
         int orc = plan_outputs(false);
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         if(const char *e = std::getenv("WF_HIP_EXT_OUTPUTS")) // 1: the display from the stored rows by big_outputs_kernel even where the tick kernel could finish it (A/B)
             if(e[0] == '1' && orc == WF_HIP_OK)
                 orc = WF_HIP_ERR_UNSUPPORTED;
@@ -797,7 +799,7 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
             // rows / epilogue kernels are bound by different things and two slices' chains overlap: 48016 x 256 streams 0.266 -> 0.250 ms,
             // 48000 x 256 0.170 -> 0.160, 17488 x 512 0.164 -> 0.158, 48016 x 1024 1.07 -> 1.02; three lanes +-2 % around two)
             lanes = ((h->big_whole || h->big_mr || h->big_br) && n_spec >= 2u * (uint32_t)std::max(prop.multiProcessorCount, 1)) ? 2 : 1;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         if(const char *e = std::getenv("WF_HIP_LANES"))
             lanes = std::atoi(e);
 #endif

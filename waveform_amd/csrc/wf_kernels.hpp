@@ -16,6 +16,10 @@
 #include "wf_tick_phases.hpp"
 #include "wf_mixed.hpp"
 #include "wf_hip.h"
+#ifndef WF_EXP_NO_TAIL
+#define WF_EXP_NO_TAIL 0 // 1 (development builds, measurement only: the bars come out wrong): the display phase skipped -- what a tick would cost if the tail were free
+#endif
+#include "wf_dev_guard.hpp"
 
 namespace wf {
 
@@ -273,12 +277,6 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     BarPre bar_pre_early{0, 0, 1, 0, 0, 0, -1};
     if constexpr(!(BLU && !MR))
         bar_pre_early = bars_preload<G, true, PS_OK>(a.bar, t);
-#if WF_EXP_COEF_AT_FETCH
-    BarEntries<G> bar_entries;
-    bar_entries.base = 0;
-    if constexpr(Policy<G>::BAR_COEF_EARLY && !BLU && DEC == 0 && !BOTH)
-        bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
-#endif
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
     bool wave_below = true;
@@ -472,14 +470,9 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     // the bar tables of this thread: requested here, in front of P4 and its state stores, where the geometry has the registers
     // (Policy<G>::BAR_COEF_EARLY) -- else behind the dB math below
     constexpr bool COEF_EARLY = Policy<G>::BAR_COEF_EARLY && !BLU && DEC == 0 && !BOTH;
-#ifndef WF_EXP_COEF_AT_FETCH
-#define WF_EXP_COEF_AT_FETCH 0 // (experiment) the bar tables requested right behind the window fetch instead of in front of P4
-#endif
-#if !WF_EXP_COEF_AT_FETCH
     BarEntries<G> bar_entries;
     bar_entries.base = 0;
-#endif
-    if constexpr(COEF_EARLY && !WF_EXP_COEF_AT_FETCH) {
+    if constexpr(COEF_EARLY) {
         bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
         if(!process && a.bar.out != nullptr)
             wait_vmem_all(); // (the rare path that skips P4 and its wait)
@@ -612,13 +605,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
     if constexpr(!COEF_EARLY)
         bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
-#ifndef WF_EXP_STORES_AFTER_PARK
-#define WF_EXP_STORES_AFTER_PARK 0 // (experiment, needs WF_DEFER_STATE=1) bars displays: the state and row stores issued between the row's LDS copy and its
-                                   // read-back, so that the LDS round trip runs under their issue
-#endif
-    const bool stores_after_park = WF_EXP_STORES_AFTER_PARK && WF_DEFER_STATE && !BLU && DEC == 0 && a.bar.out != nullptr && a.bar.piece_mode && !mono_mix;
     if constexpr(WF_DEFER_STATE && !BLU && DEC == 0) {
-        if(process && !mono_mix && !stores_after_park)
+        if(process && !mono_mix)
             p4_store_state<G>(a, t, ts, mag); // behind the table requests (p4_split_smooth<.., DEFER>)
     }
     const bool have_row = do_db && !(mono_mix && ch == 1); // this subgroup produces row `ch` (and row 1 too when one
@@ -639,7 +627,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         // (Storing the rows behind the bars / curve points instead -- so that the wait for their table loads, vector memory
         // completing in order, is not a wait for these stores' acknowledgement -- measured +-0 for both, -10 % for bars at
         // N = 2048, and is no longer in the tree.)
-        if(!a.skip_decibels && !stores_after_park) {
+        if(!a.skip_decibels) {
             store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
             if(dup_row)
                 store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
@@ -682,17 +670,6 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     }
 
     // ---- bars: what render_bars derives from the rows just written (reference src/source.cpp:1500-1557) ---------------
-#ifndef WF_EXP_NO_TAIL
-#define WF_EXP_NO_TAIL 0 // 1 (measurement only, the bars come out wrong): the display phase skipped -- what a tick would cost if the tail were free
-#endif
-#ifndef WF_EXP_TAIL_CUT
-#define WF_EXP_TAIL_CUT 0 // measurement only (wrong bars): 2 = the display phase ends behind the row's LDS copy, 3 = behind the dot products,
-                          // 4 = behind the piece totals' hand-over (no bar is finished); WF_EXP_NO_ARRIVAL_WAIT: the row is parked without
-                          // waiting for the other wavefronts' last reads of the exchange buffer
-#endif
-#ifndef WF_EXP_NO_ARRIVAL_WAIT
-#define WF_EXP_NO_ARRIVAL_WAIT 0
-#endif
 #ifndef WF_TAIL_PRIO
 #define WF_TAIL_PRIO 0
 #endif
@@ -728,23 +705,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             else
                 spectrum_sync<G>();
         };
-#ifndef WF_EXP_PS_CUT
-#define WF_EXP_PS_CUT 0 // measurement only (wrong bars): 2 = the display phase ends behind the parking (nobody finishes a bar), 5 = the dB math
-                        // alone, 6 = 5 + the wait for the other wavefronts' last reads of the exchange buffer, 7 = the finisher ends behind its wait,
-                        // 8 = ... behind the prefix, 9 = everything but the stores of the bars
-#endif
-        if(WF_EXP_PS_CUT == 5 || WF_EXP_PS_CUT == 6) {
-            if(WF_EXP_PS_CUT == 6 && count_arrivals) {
-                while(__hip_atomic_load(arrivals, WF_ARRIVE_ORDER_ACQ, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
-                    __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for(int i = 0; i < RP; ++i)
-                asm volatile("" ::"v"(d[i]));
-            return;
-        }
         // every thread of the spectrum is done reading its exchange buffer
-        if(count_arrivals && !WF_EXP_NO_ARRIVAL_WAIT) {
+        if(count_arrivals) {
             while(__hip_atomic_load(arrivals, WF_ARRIVE_ORDER_ACQ, __HIP_MEMORY_SCOPE_WORKGROUP) < WPS)
                 __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
@@ -760,8 +722,6 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 if(have_row)
                     ps_park<RG>(dbl, MO, t, d);
                 WF_STAMP(14);
-                if(WF_EXP_PS_CUT == 2)
-                    return;
                 int *parked = facts + 2 * SPW * WPS + 2 + sub;
                 if constexpr(T > 64) {
                     if(lane == 0)
@@ -773,12 +733,6 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 } else
                     __builtin_amdgcn_wave_barrier();
                 WF_STAMP(15);
-                if(ps_finisher && WF_EXP_PS_CUT == 7) { // (the finisher ends behind its wait: what do the table request and the wait cost?)
-#pragma unroll
-                    for(int c = 0; c < 3; ++c)
-                        asm volatile("" ::"v"(bar_entries.coef[c].x), "v"(bar_entries.coef[c].y), "v"(bar_entries.coef[c].z), "v"(bar_entries.coef[c].w));
-                    return;
-                }
                 if(ps_finisher) {
                     float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
                     const BarArgs bar_row = [&] { BarArgs b = a.bar; if(b.pre_out) b.pre_out += (size_t)stream * a.bar.disp_ch + ch; return b; }();
@@ -792,25 +746,6 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             store_row<RG, BLU>(dbl, t, d, NB);
         if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)
             dbl[MO] = dbl[MO + 1] = 0.0f;
-        if(stores_after_park) {
-            if constexpr(WF_DEFER_STATE && !BLU && DEC == 0) {
-                if(process)
-                    p4_store_state<G>(a, t, ts, mag);
-            }
-            if(have_row && row_thread && !a.skip_decibels) {
-                store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)ch * MO, t, d, NB);
-                if(dup_row)
-                    store_row<RG, BLU, WF_NT_ROWS>(rows + (size_t)MO, t, d, NB);
-            }
-        }
-        if(WF_EXP_TAIL_CUT == 2) {
-#ifdef WF_EXP_KEEP_COEFS
-            for(int c = 0; c < BarEntries<G>::CMAX; ++c)
-                if(c < a.bar.lane_blocks)
-                    asm volatile("" ::"v"(bar_entries.coef[c].x), "v"(bar_entries.coef[c].y), "v"(bar_entries.coef[c].z), "v"(bar_entries.coef[c].w), "v"(bar_entries.base));
-#endif
-            return;
-        }
         if((BLU && !MR) || !a.bar.piece_mode) // (wave-private bar layout: every wavefront reads back only what it has parked itself)
             row_sync();
         float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;

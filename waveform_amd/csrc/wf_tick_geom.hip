@@ -100,14 +100,14 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> int se
     if constexpr(!MR && G::N >= 1024) { // (the smallest container a size that is not a power of two ever gets: wf::bluestein_length)
         // sizes with small prime factors take the same instantiation's fetch and epilogue around a direct transform
         bool direct = true;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         if(const char *off = std::getenv("WF_HIP_NO_MIXED_RADIX")) // (development: A/B against Bluestein)
             direct = off[0] != '1';
 #endif
         const int passes = direct ? wf::plan_mixed_radix(h->N / 2, (uint32_t)G::T, h->mr_radix, (uint64_t)G::M) : 0;
         if(passes > 0) {
             h->mr_passes = passes;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
             if(const char *e = std::getenv("WF_HIP_MR_PLAN")) { // (development: "25,16" -- another order or split of the same product)
                 int r[4] = {0, 0, 0, 0}, n = 0;
                 uint64_t prod = 1;
@@ -134,7 +134,7 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> int se
             // one-wavefront containers: plans made of small radices take the instantiation that carries only those (five waves per SIMD)
             if constexpr(G::T <= 256 && G::P > 8) {
                 bool small = wf::mr_small_radices(h->mr_radix, h->mr_passes);
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
                 if(const char *e = std::getenv("WF_HIP_MR_SMALL")) // 0: the instantiation with every radix (A/B)
                     small = small && e[0] != '0';
 #endif
@@ -211,7 +211,7 @@ template<class G, int SPW> int setup_launch(wf_hip *h)
 {
     if constexpr(SPW == 2) {
         bool tlds = G::P <= 8;
-#ifdef WF_DEV_OVERRIDES
+#ifdef WF_DEV_BUILD
         if(const char *e = std::getenv("WF_HIP_TLDS"))
             tlds = e[0] == '1';
 #endif

@@ -1955,22 +1955,12 @@ template<class RG> WF_DEV void ps_park(float *dbl, int M, int t, const float (&d
 {
     constexpr int NG = RG::P / 4;
     static_assert(NG == 1 || NG == 2 || NG % 4 == 0, "group sums are stored as 4-, 8- or 16-byte words");
-#ifndef WF_EXP_PARK
-#define WF_EXP_PARK 0 // measurement only (wrong bars): 1 = the group sums alone are parked, 2 = the row alone, 3 = nothing (the sums are formed)
-#endif
-    if(WF_EXP_PARK == 0 || WF_EXP_PARK == 2)
-        store_row<RG>(dbl + 4, t, d);
+    store_row<RG>(dbl + 4, t, d);
     float *gs = ps_gs_area(dbl, M) + t * NG;
     float s[NG];
     WF_UNROLL
     for(int u = 0; u < NG; ++u)
         s[u] = (d[4 * u] + d[4 * u + 1]) + (d[4 * u + 2] + d[4 * u + 3]);
-    if(WF_EXP_PARK >= 2) {
-        WF_UNROLL
-        for(int u = 0; u < NG; ++u)
-            asm volatile("" ::"v"(s[u]));
-        return;
-    }
     if constexpr(NG == 1)
         gs[0] = s[0];
     else if constexpr(NG == 2)
@@ -2048,12 +2038,6 @@ template<class G, class RG> WF_DEV void ps_finish(const BarArgs &b, const BarEnt
     if(ll == 63)
         qp[QUADS] = inc;
     wave_fence(); // (LDS operations of a wavefront execute in order: the look-ups below see the prefix)
-#if defined(WF_EXP_PS_CUT) && WF_EXP_PS_CUT == 8
-    WF_UNROLL
-    for(int c = 0; c < 3; ++c)
-        asm volatile("" ::"v"(be.coef[c].x), "v"(be.coef[c].y), "v"(be.coef[c].z), "v"(be.coef[c].w));
-    return;
-#endif
     const int q = (int)f32_bits(be.coef[2].x);
     const uint32_t info = f32_bits(be.coef[2].y);
     const float *pw = dbl + q + 1; // bins q - 3 .. q + 3 of the row parked from dbl + 4
@@ -2088,10 +2072,6 @@ template<class G, class RG> WF_DEV void ps_finish(const BarArgs &b, const BarEnt
     float sub = (ll & 1) ? 0.0f : fmaf(be.coef[1].w, (float)dp, e + oe);
     sub = seg_prefix_scan(sub, info);
     const int bar = (int)((info >> 8) & 0xffu) - 1;
-#if defined(WF_EXP_PS_CUT) && WF_EXP_PS_CUT == 9
-    asm volatile("" ::"v"(sub), "v"(bar));
-    return;
-#endif
     if(emit && bar >= 0)
         emit_output(b, bar, sub / (float)(info >> 16), out_row, dup_row);
 }
@@ -2133,10 +2113,6 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
             // Every segment read bins its own wavefront parked (LDS operations of a wave execute in order: no barrier in front
             // of them).  The partials of a piece are added over the lanes; its last lane holds the total.
             WF_BAR_STAMP(14);
-#if defined(WF_EXP_TAIL_CUT) && WF_EXP_TAIL_CUT == 3
-            asm volatile("" ::"v"(part));
-            return false;
-#endif
             const uint32_t info = (uint32_t)pre.glen;
             part = seg_prefix_scan(part, info);
             const int slot = (int)(info >> 8) - 1;
@@ -2150,10 +2126,6 @@ WF_DEV bool bars_reduce_row(const BarArgs &b, const BarPre &pre, const BarEntrie
                 if(has_row && slot >= 0)
                     prod[slot] = part;
                 const int before = wave_arrive(arrivals, t & 63);
-#if defined(WF_EXP_TAIL_CUT) && WF_EXP_TAIL_CUT == 4
-                asm volatile("" ::"v"(before));
-                return false;
-#endif
                 if(before == arrive_last - 1 && has_row && pre.lead >= 0) {
                     float sum = 0.0f;
                     for(int k = pre.s0; k < pre.s1; ++k)

@@ -91,54 +91,71 @@ def verify_gathered(full, own, shard: Shard, group=None) -> bool:
 
 class BarsGather:
     """The per-tick exchange of BASELINE configs[4], overlapped and without a copy: the handle's tick kernel writes the batch's
-    bars straight into one of two send buffers (wf_hip_set_bars_mirror) and goes on with tick i+1; the all-gather of tick i
+    bars straight into one of two send buffers (wf_hip_set_bars_mirrors) and goes on with tick i+1; the all-gather of tick i
     runs on a side stream that waits only for that tick (11 us of xGMI wire time per peer against ~140 us of compute per
-    tick).  A send buffer is rewritten two ticks later; before that tick is issued the host checks the
-    event behind the gather that read it (a tick old by then).  world 1: the "gathered" bars ARE
-    the send buffer -- no collective, no copy.  Batches whose display comes from a kernel of its own (fft sizes beyond a CU's
-    LDS) keep the copy behind the tick (wf_hip_copy_bars_device_async)."""
+    tick).  launch() hands the written buffer over (wf_hip_bars_mirror_ready) and makes the other one
+    the ticks' target; before the next tick is issued the host checks the event behind the gather that read THAT buffer (a
+    launch old by then).  world 1: the "gathered" bars ARE the send buffer -- no collective, no copy.  FFT sizes that are not
+    powers of two and batches whose display comes from a kernel of its own (fft sizes beyond a CU's LDS) keep the copy behind
+    the tick (wf_hip_copy_bars_device_async): the path is picked per handle, by what wf_hip_set_bars_mirrors answers.
+    A context manager: the send buffers are torch tensors the tick kernels write into, so close() (or leaving the `with` block,
+    or the object being dropped) takes them away from the handle -- waiting for the ticks in flight -- before torch may reuse
+    the memory."""
 
     def __init__(self, batch, shard: Shard, group=None):
+        import os
         import torch
         from . import binding
         self.batch, self.shard, self.group = batch, shard, group
+        self.zero_copy = False
         shape = (shard.count, batch.display_channels, batch.num_bars)
         self.send = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(2)]
         self.result = [None, None]
         self.done = [None, None]
         # (WF_BARS_GATHER_PRIORITY=high: the collective on a hardware queue of its own instead of one shared with a lane of the handle --
         # for the first run on a real node to try; see the note at the gather streams of wf_hip_multi.cpp)
-        import os
         self.side = torch.cuda.Stream(priority=-1) if os.environ.get("WF_BARS_GATHER_PRIORITY") == "high" else torch.cuda.Stream()
         self.i = 0
         self.newest = None
         try:
-            import os
             if os.environ.get("WF_BARS_GATHER_COPY"):  # A/B aid (tools/ab_gather.py): the copy behind the tick for everybody
                 raise binding.WfHipError(-2, "WF_BARS_GATHER_COPY")
-            batch.set_bars_mirror(self.send[0].data_ptr(), self.send[1].data_ptr())
+            batch.set_bars_mirrors([self.send[0].data_ptr()], [self.send[1].data_ptr()])
             self.zero_copy = True
         except binding.WfHipError as e:
-            if e.code != -2:  # WF_HIP_ERR_UNSUPPORTED: the display comes from a kernel of its own -> the copy behind the tick
+            if e.code != -2:  # WF_HIP_ERR_UNSUPPORTED: not a power of two, or the display comes from a kernel of its own -> the copy behind the tick
                 raise
-            self.zero_copy = False
 
     def close(self):
         if self.zero_copy:
-            self.side.synchronize()
-            self.batch.set_bars_mirror(None, None)
             self.zero_copy = False
+            self.side.synchronize()
+            if getattr(self.batch, "h", None):  # (the handle may be gone already: nothing writes the buffers then)
+                self.batch.set_bars_mirrors([], [])  # waits for the ticks in flight
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def launch(self):
-        """call after every tick: the gather of that tick's bars is enqueued on the side stream"""
+        """call after every tick (or every few: ticks between two launches rewrite the same buffer): the gather of the newest
+        tick's bars is enqueued on the side stream"""
         import torch
         if self.zero_copy:
-            ptr = self.batch.bars_mirror_ready(self.side.cuda_stream)
+            ptr = self.batch.bars_mirror_ready(self.side.cuda_stream)  # (a buffer no tick has written is filled from the handle's own bars)
             k = 0 if ptr == self.send[0].data_ptr() else 1
         else:
             k = self.i & 1
             if self.done[k] is not None:
-                self.done[k].synchronize()  # the gather that read this send buffer two ticks ago (long finished)
+                self.done[k].synchronize()  # the gather that read this send buffer two launches ago (long finished)
             self.batch.copy_bars_to_device_async(self.send[k].data_ptr(), self.side.cuda_stream)
         self.i += 1
         with torch.cuda.stream(self.side):
@@ -147,14 +164,14 @@ class BarsGather:
             ev.record(self.side)
             self.done[k] = ev
         if self.zero_copy and self.done[k ^ 1] is not None:
-            # the next tick writes the other buffer: the gather that read it (enqueued a tick ago) must have run.  A host wait
-            # that returns at once -- a device-side wait in front of every tick cost 4 % of the tick rate
+            # the ticks issued from here on write the other buffer: the gather that read it (enqueued a launch ago) must have run.
+            # A host wait that returns at once -- a device-side wait in front of every tick cost 4 % of the tick rate
             self.done[k ^ 1].synchronize()
         self.newest = k
         return k
 
     def wait(self):
         """blocks until every launched gather has run; returns the newest combined bars [total, display_channels, num_bars]
-        (zero-copy at world 1: the send buffer itself -- valid until the tick after next rewrites it)"""
+        (zero-copy at world 1: the send buffer itself -- valid until the first tick after the next launch rewrites it)"""
         self.side.synchronize()
         return self.result[self.newest] if self.newest is not None else None
