@@ -374,8 +374,9 @@ def configs4_region(wf, torch, dist, rank, world, local_rank, steps, lead_in_ms=
         # verification: the gathered result of the last tick, block by block, against what each rank holds itself
         full = gather.wait()                                             # [total][2][26] on this rank
         own = torch.empty((streams, batch.display_channels, batch.num_bars), dtype=torch.float32, device="cuda")
-        batch.copy_bars_to_device_async(own.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.current_stream().synchronize()
+        side = torch.cuda.Stream()  # (the default stream's handle is 0: the library takes a real hipStream_t)
+        batch.copy_bars_to_device_async(own.data_ptr(), side.cuda_stream)
+        side.synchronize()
         from waveform_amd.dist import verify_gathered
         verified = verify_gathered(full, own, shard)   # (collective when world > 1: every rank checks the copy it received)
         times = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")

@@ -398,7 +398,9 @@ typedef struct wf_hip_multi wf_hip_multi;
 int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_devices, uint32_t streams_total, uint32_t ring_frames,
                         wf_hip_multi **out);
 void wf_hip_multi_destroy(wf_hip_multi *m);
-/* text of the last error on this group (or of the last failed wf_hip_multi_create when m == NULL) */
+/* text of the last error on this group (or of the last failed wf_hip_multi_create when m == NULL).  Right after a successful
+ * wf_hip_multi_create: why the group did not get the transport it would have picked by itself ("ncclCommInitAll failed: ...",
+ * "peer access is not enabled between every pair of devices ..."), or "" */
 const char *wf_hip_multi_last_error(const wf_hip_multi *m);
 uint32_t wf_hip_multi_num_devices(const wf_hip_multi *m);
 uint32_t wf_hip_multi_num_streams(const wf_hip_multi *m);

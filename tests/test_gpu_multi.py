@@ -123,6 +123,78 @@ def test_gather_runs_under_the_next_tick_and_is_double_buffered():
         assert all(np.array_equal(x, last[0]) for x in last) and np.array_equal(last[0], m.bars())
 
 
+@pytest.mark.parametrize("n_fft,devices", [(4096, [0]), (4096, [0, 0, 0]), (800, [0, 0, 0]), (800, [0]), (48000, [0, 0])])
+def test_ticks_between_gathers_leave_the_gathered_result_alone(n_fft, devices):
+    """The contract of include/wf_hip.h: a gathered result stays valid until the FIRST tick after the NEXT gather -- whatever the
+    number of ticks between two gathers, and whichever path the size takes: where the tick kernels write the send buffers / the
+    results themselves (power-of-two sizes; round 5 switched buffers with every TICK, so the second tick after a gather overwrote
+    the result being read) and where the bars are copied behind the tick (sizes that are not powers of two -- N = 800, the
+    plugin's automatic size, mixed radix -- and sizes beyond a CU's LDS: wf_hip_set_bars_mirrors answers UNSUPPORTED and the group
+    picks the copy for that handle)."""
+    have = wf.device_count()
+    devices = [(i % have) for i in range(len(devices))]
+    cfg = _cfg(fft_size=n_fft)
+    streams, hop = (24 if n_fft < 16384 else 6), 800
+    pattern = [1, 2, 3, 1, 0, 2, 1]          # ticks in front of each gather (0: two gathers of the same tick)
+    total = sum(pattern) + 4
+    ring = n_fft + hop * (total + 2)
+    with wf.SpectrumBatch(cfg, streams, ring_frames=ring) as plain, wf.MultiBatch(cfg, streams, devices, ring_frames=ring) as m:
+        for b in (plain, m):
+            b.push_synth(SEED, 0, hop * (total + 1))
+        t = 0
+
+        def tick():
+            nonlocal t
+            plain.tick(delay_frames=hop * (total - t)); m.tick(delay_frames=hop * (total - t))
+            t += 1
+        tick()  # (a first tick: nothing gathered yet)
+        for k, n_ticks in enumerate(pattern):
+            for _ in range(n_ticks):
+                tick()
+            want = plain.bars()
+            m.allgather_bars()
+            for i in range(m.n_devices):
+                assert np.array_equal(m.gathered(i), want), f"gather {k} (after {n_ticks} ticks) on device index {i}"
+            # ticks after the gather -- none of them may touch the result until another gather has been issued
+            if k + 1 < len(pattern):
+                for _ in range(pattern[k + 1]):
+                    tick()
+                    for i in range(m.n_devices):
+                        assert np.array_equal(m.gathered(i), want), f"a tick behind gather {k} changed the gathered result on device index {i}"
+                pattern[k + 1] = 0  # (already ticked)
+        assert np.array_equal(m.bars(), plain.bars())
+
+
+def test_a_gather_before_any_tick_and_shard_handles_ticked_directly():
+    """a gather with no tick since the buffers were set hands over the handles' own bars (the reset state); shard handles ticked
+    directly (the header allows it), one of them more often than the others, do not desynchronise the shards' buffers: the next
+    gather is still every shard's newest bars, complete and the same on every device (round 5 derived the buffer from the
+    shard's own tick count)"""
+    import ctypes as C
+    from waveform_amd import binding
+    have = wf.device_count()
+    devices = [(i % have) for i in range(3)]
+    cfg = _cfg(fft_size=2048)
+    streams, hop = 9, 800
+    with wf.SpectrumBatch(cfg, streams) as plain, wf.MultiBatch(cfg, streams, devices) as m:
+        m.allgather_bars()
+        assert np.array_equal(m.gathered(0), plain.bars()) and np.array_equal(m.gathered(2), plain.bars())
+        for t in range(5):
+            a = synth.block(SEED, 0, streams, 2, t * hop, hop)
+            m.push_audio(a)
+            if t == 2:  # this frame every shard's handle is ticked by hand, shard 1 twice (a second tick of the same audio)
+                p = binding.TickParams(1.0 / 60.0, 0, 0.0, 0, 0)
+                for i, (h, dev, first, count) in enumerate(m.shards):
+                    for _ in range(2 if i == 1 else 1):
+                        assert m.L.wf_hip_tick(h, C.byref(p)) == 0
+            else:
+                m.tick()
+            m.allgather_bars()
+            got = [m.gathered(i) for i in range(m.n_devices)]
+            assert all(np.array_equal(g, got[0]) for g in got), f"frame {t}: the devices hold different gathered results"
+            assert np.array_equal(got[0], m.bars()), f"frame {t}: the gathered result is not the shards' newest bars"
+
+
 def test_rccl_transport_in_a_fresh_process():
     """ncclAllGather through the dlopen()ed librccl.so: one rank per visible device (one on a 1-GPU box), equal and ragged
     shards; in a child process so that a broken RCCL cannot take the test session with it"""

@@ -488,6 +488,7 @@ class MultiBatch:
         self.streams = streams
         self.n_devices = int(self.L.wf_hip_multi_num_devices(m))
         self.transport = self.L.wf_hip_multi_transport(m).decode()
+        self.transport_note = self.L.wf_hip_multi_last_error(m).decode()  # why not the transport it would have picked ("" if it did)
         self.shards = []
         for i in range(self.n_devices):
             dev, first, count = C.c_int(0), C.c_uint32(0), C.c_uint32(0)

@@ -632,6 +632,9 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
             return rc;
         }
     }
+    // not an error, but what a node check wants to see: why the group did not get the transport it would have picked
+    // (wf_hip_multi_last_error(m) right after create; the next failing call overwrites it)
+    m->last_error = m->transport_note;
     *out = m;
     return WF_HIP_OK;
 }
