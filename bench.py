@@ -245,18 +245,19 @@ def measure_shape(wf, name, cfg, streams, steps, warmup, device, flags=0, shape=
 
 def shape_list(wf):
     ema = dict(stereo=1, slope=1.0, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)
+    # BASELINE shapes first (the driver keeps the head of the line's standard keys and the last 8 KB of stdout), the reference-range extras last
     shapes = [
+        ("configs[3]: 1024 stereo streams, FFT 16384, TV-EMA (gravity) + 26 Lanczos bars per channel",
+         wf.Config.defaults(fft_size=16384, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["tvexponential"], gravity=0.65,
+                            bars=1, interp_mode=wf.INTERP["lanczos"]), 1024, 60, 0, "cfg4_n16384_bars"),
+        ("configs[4] per-GPU shape: 8192 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars only (no m_decibels store)",
+         wf.Config.defaults(fft_size=4096, bars=1, interp_mode=wf.INTERP["lanczos"], **ema), 8192, 60, wf.TICK_NO_DECIBELS, "cfg5shape_8192streams_barsonly"),
+        ("configs[1] as a batch: 256 stereo streams, FFT 2048, Hann + magnitude + dB, no smoothing",
+         wf.Config.defaults(fft_size=2048, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["none"]), 256, 60, 0, "cfg2_batch"),
         ("configs[2] x2: 8192 stereo streams, FFT 4096, EMA + slope (536 MB working set, past the 256 MB Infinity Cache)",
          wf.Config.defaults(fft_size=4096, **ema), 8192, 60, 0, "cfg3_8192streams"),
         ("configs[2] x4: 16384 stereo streams, FFT 4096, EMA + slope (1.07 GB working set)",
          wf.Config.defaults(fft_size=4096, **ema), 16384, 40, 0, "cfg3_16384streams"),
-        ("configs[3]: 1024 stereo streams, FFT 16384, TV-EMA (gravity) + 26 Lanczos bars per channel",
-         wf.Config.defaults(fft_size=16384, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["tvexponential"], gravity=0.65,
-                            bars=1, interp_mode=wf.INTERP["lanczos"]), 1024, 60, 0, "cfg4_n16384_bars"),
-        ("configs[1] as a batch: 256 stereo streams, FFT 2048, Hann + magnitude + dB, no smoothing",
-         wf.Config.defaults(fft_size=2048, stereo=1, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["none"]), 256, 60, 0, "cfg2_batch"),
-        ("configs[4] per-GPU shape: 8192 stereo streams, FFT 4096, EMA + slope, 26 Lanczos bars per channel, bars only (no m_decibels store)",
-         wf.Config.defaults(fft_size=4096, bars=1, interp_mode=wf.INTERP["lanczos"], **ema), 8192, 60, wf.TICK_NO_DECIBELS, "cfg5shape_8192streams_barsonly"),
         # the ends of the reference's FFT range (not BASELINE configs; reported so that the driver's line carries them too)
         ("fft_size 65536 (the reference's maximum, 'enable large FFT'): 256 stereo streams, EMA + slope; both rows of 16384 complex points and "
          "the end of the tick in one workgroup", wf.Config.defaults(fft_size=65536, **ema), 256, 30, 0, "n65536"),
@@ -564,6 +565,17 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     per_rank_ms, ranks_seen = [elapsed * 1e3 / args.steps], 1
+    # The scaling curve's N = 1 point, taken in THIS run: rank 0 alone over the same K steps while the other ranks wait at a
+    # barrier (their GPUs idle) -- the driver computes efficiency itself from its own N = 1 run; this is the same ratio from one
+    # process group, one box, one minute, and it travels in the line (config.scaling_point, and again at the line's very end).
+    solo_rate = None
+    if dist is not None and gather is None:
+        if rank == 0:
+            ts = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize()
+            solo_rate = spectra_per_step * args.steps / (time.perf_counter() - ts)
+        barrier()
     if dist is not None:
         # every rank's own time per step and device time per tick, and how many ranks the collective really reached
         mine = torch.tensor([elapsed * 1e3 / args.steps, kernel_ms, 1.0], dtype=torch.float64, device="cuda")
@@ -620,6 +632,11 @@ def main():
             "roofline": roofline(batch, "cfg3_n4096" if (args.streams, args.fft, flags) == (STREAMS_PER_GPU, FFT_SIZE, 0) else None, kernel_ms, flags,
                                  wall_ms=ms_per_step, cold_ms=cold_ms),
         }
+        n1 = solo_rate if solo_rate else value
+        out["config"]["scaling_point"] = {"n": world, "spectra_per_s": value, "per_gpu_spectra_per_s": value / world, "n1_spectra_per_s": n1,
+                                          "efficiency_vs_n1": value / (world * n1),
+                                          "n1_how": ("rank 0 alone over the same steps, the other ranks idle at a barrier, same process group" if solo_rate
+                                                     else "this run IS the N = 1 point")}
         # every rank's own fraction of its GPU's HBM peak -- by its wall clock per step and by its device time per tick -- next to the
         # job's (the slowest rank's): a GPU that lags the others on a node shows here
         algo_per_tick = out["roofline"]["algorithmic_bytes_per_tick"]
@@ -684,6 +701,28 @@ def main():
             out["configs4"] = cfg4
         if world == 1 and not args.no_other_configs and not args.bars_allgather:
             out["c_abi_multi"] = c_abi_multi()
+        # One compact object with every figure that matters, twice: inside `roofline` (a standard key: the driver keeps those whole)
+        # and as the LAST key of the line (the driver keeps the last 8 KB of stdout) -- the long per-shape objects in between may
+        # be cut, the figures are not.
+        def brief(r):
+            rf = (r or {}).get("roofline") or {}
+            return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in
+                    (("frac", rf.get("frac")), ("frac_events", rf.get("frac_events")), ("frac_trace", rf.get("frac_trace")),
+                     ("traffic_ratio", (rf.get("traffic") / rf["algorithmic_bytes_per_tick"]) if rf.get("traffic") and rf.get("algorithmic_bytes_per_tick") else None),
+                     ("ms_per_step", r.get("ms_per_step") if r else None)) if v is not None} if rf else {"error": (r or {}).get("error", "not measured")}
+        shapes = {"cfg3_n4096 (headline)": {"frac": round(out["roofline"]["frac"], 4), "frac_events": round(out["roofline"]["frac_events"], 4),
+                                             "frac_trace": out["roofline"].get("frac_trace"), "ms_per_step": round(out["ms_per_step"], 5)}}
+        for r in out.get("other_configs") or []:
+            shapes[r.get("shape") or r.get("name", "?")] = brief(r)
+        if cfg4 is not None:
+            shapes["configs4 (process group, gather under the next tick)"] = brief(cfg4)
+        if out.get("c_abi_multi") is not None:
+            shapes["c_abi_multi (wf_hip_multi_*, gather behind every tick)"] = brief(out["c_abi_multi"])
+        if out.get("pcie_inclusive"):
+            shapes["pcie_inclusive (host-fed headline)"] = {"spectra_per_s": round(out["pcie_inclusive"]["value"]), "host_GBps": round(out["pcie_inclusive"]["host_GBps"], 2)}
+        summary = {"scaling_point": out["config"]["scaling_point"], "frac_of_8TBps_by_shape": shapes}
+        out["roofline"]["summary"] = summary
+        out["summary"] = summary  # (last key: survives a truncated head)
         print(json.dumps(out), flush=True)
     if dist is not None:
         if cfg4 is not None and "error" in cfg4:

@@ -1,5 +1,6 @@
 """CPU-side unit tests (no GPU): synthetic-audio hash, host tables of the product vs the oracle,
 the kernel's phase functions run in the wavefront emulator vs the oracle, C-ABI export list."""
+import sys
 import ctypes as C
 import re
 import subprocess
@@ -673,3 +674,76 @@ def test_no_fusable_rounding_intrinsics_in_device_code():
             if re.search(r"__f(add|sub)_rn\s*\([^;]*__fmul_rn|__fmul_rn\s*\([^;]*__f(add|sub)_rn", code):
                 bad.append(f"{f.name}:{n}: {line.strip()}")
     assert not bad, "products feeding sums through rounding intrinsics (they fuse):\n" + "\n".join(bad)
+
+
+# ---- evidence guards and the node check's verdicts ---------------------------------------------------
+BENCH_SHAPE_KEYS = None
+
+
+def _bench_shape_keys():
+    """the profile keys bench.py's line looks up: the headline's and shape_list()'s last column"""
+    global BENCH_SHAPE_KEYS
+    if BENCH_SHAPE_KEYS is None:
+        sys.path.insert(0, str(ROOT))
+        import bench
+        import waveform_amd as wf
+        BENCH_SHAPE_KEYS = ["cfg3_n4096"] + [s[5] for s in bench.shape_list(wf)]
+    return BENCH_SHAPE_KEYS
+
+
+def test_every_bench_shape_has_a_committed_profile_of_the_newest_round():
+    """bench.py replays roofline.traffic from profiles/rNN*_<shape>_pmc.json (PMC counters need rocprofv3 passes of their own).  A
+    shape without a summary -- or with one from an older evidence set than the others -- silently reports traffic null in the
+    driver's line: every shape bench.py names must have a summary, all of the newest set, each with a kernel name, HBM bytes per
+    launch and a tick span.  (That the `kernel` strings are the kernels that RUN is checked where there is a device:
+    tests/test_gpu_fullsize.py::test_committed_profiles_are_of_the_kernels_that_run.)"""
+    import json
+    keys = _bench_shape_keys()
+    tags = sorted({p.name.split("_")[0] for k in keys for p in (ROOT / "profiles").glob(f"r*_{k}_pmc.json")})
+    assert tags, "no committed rocprofv3 summaries"
+    newest = tags[-1]
+    for k in keys:
+        p = ROOT / "profiles" / f"{newest}_{k}_pmc.json"
+        assert p.exists(), f"{k}: no summary in the newest evidence set ({newest}); bench.py would replay an older one or report traffic null"
+        d = json.loads(p.read_text())
+        assert d.get("kernel") and d.get("hbm_bytes_per_launch", 0) > 0 and (d.get("trace") or {}).get("tick_span_ns", 0) > 0, (k, {x: d.get(x) for x in ("kernel", "hbm_bytes_per_launch")})
+
+
+def test_bench_line_puts_the_baseline_shapes_first():
+    """the driver keeps the head of the standard keys and the last 8 KB of stdout: BASELINE shapes first, the reference-range extras last"""
+    keys = _bench_shape_keys()
+    assert keys[:4] == ["cfg3_n4096", "cfg4_n16384_bars", "cfg5shape_8192streams_barsonly", "cfg2_batch"] and keys[-2:] == ["n65536", "n800_mixed_radix"], keys
+
+
+def test_node_check_names_every_reason():
+    """tools/node_check.py exits non-zero with ONE LINE PER REASON: RCCL refuses the device list, peer access denied on a pair,
+    a device more than 10 % slower than the best, a wrong gathered copy -- and none on a clean node"""
+    sys.path.insert(0, str(ROOT))
+    from tools import node_check
+    ok_run = {"leg": "default", "transport_asked": "default", "transport": "rccl", "transport_note": "", "devices": [0, 1, 2, 3], "verified": True,
+              "devices_with_a_wrong_copy": [], "ms_per_tick_without_gather": {"max": 0.111, "per_device": [0.110, 0.111, 0.109, 0.110]}}
+    peers = [{"from": a, "to": b, "can_access": True, "enable_rc": 0, "ok": True} for a in range(4) for b in range(4) if a != b]
+    assert node_check.reasons({"peer_access": peers, "runs": [ok_run]}, 4) == []
+    # RCCL refused: the default leg fell back to peer copies, the library's text says why
+    r = dict(ok_run, transport="peer", transport_note="ncclCommInitAll failed: unhandled system error")
+    why = node_check.reasons({"peer_access": peers, "runs": [r]}, 4)
+    assert len(why) == 1 and "RCCL refuses the device list [0, 1, 2, 3]" in why[0] and "ncclCommInitAll failed" in why[0]
+    # ... or the leg that asked for it by name failed outright
+    r = {"leg": "rccl, one channel", "transport_asked": "rccl", "devices": [0, 1, 2, 3], "error": "WF_HIP_MULTI_TRANSPORT=rccl: librccl.so not loadable: x", "verified": False}
+    why = node_check.reasons({"peer_access": peers, "runs": [r]}, 4)
+    assert len(why) == 1 and "RCCL refuses the device list" in why[0] and "librccl.so not loadable" in why[0]
+    # peer access denied on one ordered pair
+    bad = [dict(p, can_access=False, enable_rc=-1, ok=False) if (p["from"], p["to"]) == (2, 3) else p for p in peers]
+    why = node_check.reasons({"peer_access": bad, "runs": [ok_run]}, 4)
+    assert len(why) == 1 and "device 2 cannot address device 3" in why[0]
+    # one device 15 % slower than the best
+    r = dict(ok_run, ms_per_tick_without_gather={"max": 0.1265, "per_device": [0.110, 0.1265, 0.109, 0.110]})
+    why = node_check.reasons({"peer_access": peers, "runs": [r]}, 4)
+    assert len(why) == 1 and "device 1 takes 126.5 us per tick, 16 % more than the best device (109.0 us)" in why[0], why
+    # two shards on ONE device (the 1-GPU rehearsal of the peer legs) share it: no spread verdict there
+    r = dict(ok_run, devices=[0, 0], ms_per_tick_without_gather={"max": 0.2, "per_device": [0.1, 0.2]})
+    assert node_check.reasons({"peer_access": [], "runs": [r]}, 1) == []
+    # a wrong copy; a host-fed device that failed
+    r = dict(ok_run, devices_with_a_wrong_copy=[3], verified=False)
+    why = node_check.reasons({"peer_access": peers, "runs": [r], "host_fed": {"verified": False, "per_device": [{"device": 1, "error": "hipHostMalloc failed"}]}}, 4)
+    assert len(why) == 2 and "device indices [3]" in why[0] and "host-fed leg: device 1: hipHostMalloc failed" in why[1]

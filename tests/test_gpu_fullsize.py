@@ -272,6 +272,12 @@ def test_bars_gather_world1_and_self_launching_bench():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert 1 <= line["n_gpus"] <= 8
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    # the scaling point travels in a standard key (config) and again as the line's LAST key (the driver keeps the standard keys whole
+    # and the last 8 KB of stdout)
+    sp = line["config"]["scaling_point"]
+    assert sp["n"] == line["n_gpus"] and sp["spectra_per_s"] == line["value"] and list(line)[-1] == "summary" and line["summary"]["scaling_point"] == sp
+    if sp["n"] == 1:
+        assert sp["efficiency_vs_n1"] == 1.0
 
 
 def test_bench_multi_rank_path_with_the_collective():
@@ -304,6 +310,10 @@ def test_bench_multi_rank_path_with_the_collective():
     assert "error" not in c4, c4
     assert c4["verified"] is True and c4["streams_total"] == 2 * 8192 and len(c4["device_ms_per_tick"]["per_rank"]) == 2
     assert "all_gather" in c4["collective"]
+    sp = line["config"]["scaling_point"]  # N = 2: the N = 1 point is rank 0 alone in the same process group
+    assert sp["n"] == 2 and sp["n1_spectra_per_s"] > 0 and 0.05 < sp["efficiency_vs_n1"] < 1.5 and "rank 0 alone" in sp["n1_how"]
+    assert list(line)[-1] == "summary" and "configs4 (process group, gather under the next tick)" in line["summary"]["frac_of_8TBps_by_shape"]
+    assert line["roofline"]["summary"] == line["summary"]
 
 
 def test_roctx_ranges_are_opt_in_and_change_nothing():
@@ -710,3 +720,27 @@ def test_waveform_batch_with_per_stream_timestamps_and_paused_streams():
             m.set_stream_audio_ts(np.zeros(2, np.uint64))   # not a waveform batch
         with pytest.raises(wf.WfHipError):
             m.waveform_ts()
+
+
+def test_committed_profiles_are_of_the_kernels_that_run():
+    """bench.py replays roofline.traffic and the trace span from the newest committed profiles/rNN*_<shape>_pmc.json, but only when
+    its `kernel` string equals wf_hip_kernel_name() of the handle that runs (a summary of a kernel that no longer runs is not
+    replayed: traffic null).  For every shape bench.py names: a handle created with that shape's configuration must report the
+    kernel the newest committed summary was taken on -- a kernel change without a re-profile fails HERE instead of dropping
+    roofline.traffic from the driver's line."""
+    import json
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import bench
+    ema = dict(stereo=1, slope=1.0, window=wf.WINDOW["hann"], tsmoothing=wf.TSMOOTH["exponential"], gravity=0.65)
+    shapes = [("cfg3_n4096", wf.Config.defaults(fft_size=4096, **ema), 4096)] + [(s[5], s[1], s[2]) for s in bench.shape_list(wf)]
+    for key, cfg, streams in shapes:
+        with wf.SpectrumBatch(cfg, streams, ring_frames=cfg.fft_size + 1600) as b:
+            live = b.kernel_name()
+        files = sorted((root / "profiles").glob(f"r*_{key}_pmc.json"))
+        assert files, f"{key}: no committed summary"
+        d = json.loads(files[-1].read_text())
+        assert d.get("kernel") == live, f"{key}: {files[-1].name} was taken on '{d.get('kernel')}', the library runs '{live}': re-profile (tools/gpu_round.sh)"
+        assert bench.pmc_profile(key, live) is not None

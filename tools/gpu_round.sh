@@ -16,11 +16,11 @@ tail -c 600 $O/bench_$TAG.json | head -c 600; echo
 # headline shape: full counter set; the other shapes: durations + HBM bytes
 python tools/warmup_curve.py 40 > $O/warmup_$TAG.txt 2>&1
 bash tools/profile_gpu.sh ${TAG}_cfg3 1000 "--warmup 500" > /dev/null 2>&1   # the default bench.py run: same ring depth, same ticks
-WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 0" bash tools/profile_gpu.sh ${TAG}_cfg3_8192streams > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py cfg3_8192streams" bash tools/profile_gpu.sh ${TAG}_cfg3_8192streams > /dev/null 2>&1
 WF_PMC_SET=short bash tools/profile_gpu.sh ${TAG}_cfg3_16384streams 250 "--streams 16384 --warmup 250" > /dev/null 2>&1
-WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 3" bash tools/profile_gpu.sh ${TAG}_cfg2 > /dev/null 2>&1
-WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 2" bash tools/profile_gpu.sh ${TAG}_cfg4 > /dev/null 2>&1
-WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py 4" bash tools/profile_gpu.sh ${TAG}_cfg5shape > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py cfg2_batch" bash tools/profile_gpu.sh ${TAG}_cfg2 > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py cfg4_n16384_bars" bash tools/profile_gpu.sh ${TAG}_cfg4 > /dev/null 2>&1
+WF_PMC_SET=short WF_PROFILE_CMD="python $R/tools/shape_bench.py cfg5shape_8192streams_barsonly" bash tools/profile_gpu.sh ${TAG}_cfg5shape > /dev/null 2>&1
 # the kernels further from the roofline: durations (rocprofv3 --kernel-trace --stats) and HBM bytes (FETCH_SIZE / WRITE_SIZE in
 # passes of their own), one summary each
 for J in "plugindefaults:python $R/tools/quick_case.py plugin_defaults" "n32768:python $R/tools/quick_bench.py 32768:512" \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/valu_per_wave.sh SHAPE lib.so ... -- VALU / SALU / LDS / VMEM instructions per wavefront of the tick kernel, one rocprofv3
-# counter pass per library build; WF_VPW_CMD="python tools/shape_bench.py 4" replaces the quick_bench command (development aid: what a phase costs, with the -DWF_EXP_CUT_AT builds of tools/variant.sh)
+# counter pass per library build; WF_VPW_CMD="python tools/shape_bench.py cfg5shape_8192streams_barsonly" replaces the quick_bench command (development aid: what a phase costs, with the -DWF_EXP_CUT_AT builds of tools/variant.sh)
 SHAPE=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
