@@ -359,3 +359,20 @@ def test_node_check_runs_and_verifies():
     for run in out["runs"]:
         assert run["verified"] and run["gather_alone_us"] > 0 and len(run["ms_per_tick_with_gather"]["per_device"]) == len(run["devices"]), run
         assert "gather_costs_per_tick_us" in run and "leg" in run
+
+
+def test_node_check_runs_on_this_box():
+    """tools/node_check.py, the first thing to run on a multi-GPU node: here with the devices this box has (the peer legs put two
+    shards on one device where there is one) and the host-fed leg -- exit code 0, "ready", no reason lines, a GB/s figure per device.
+    (Its verdicts -- RCCL refuses the device list, peer access denied, a slow device -- are unit-tested on fabricated results in
+    tests/test_cpu_units.py::test_node_check_names_every_reason.)"""
+    import json
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "node_check.py"), "--ticks", "20", "--streams-per-device", "512", "--host-fed", "--host-fed-streams", "256"],
+                       capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert line, (r.stdout[-500:], r.stderr[-2000:])
+    d = json.loads(line[-1])
+    assert r.returncode == 0 and d["ready"] and d["reasons"] == [], (r.returncode, d.get("reasons"), r.stderr[-1500:])
+    assert len(d["runs"]) == 6 and all(x.get("verified") for x in d["runs"])
+    hf = d["host_fed"]
+    assert hf["verified"] and len(hf["per_device"]) == d["devices_used"] and all(x["host_GBps"] > 0 for x in hf["per_device"])
