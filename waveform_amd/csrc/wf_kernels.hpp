@@ -157,7 +157,17 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // MRS (with MR; containers of one, two and four wavefronts): the mixed-radix instantiation for plans of the radices 2 ... 12 (N = 800
 // as 5 x 10 x 8, 960 as 5 x 12 x 8 ...).  Without the large in-register DFTs the kernel fits 96 registers -- five waves per SIMD instead
 // of four, and the tick of these sizes scales with the spectra in flight (profiles/r04g_n800_phases.txt).
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false>
+// DISP: what the instantiation can display.  0: every layout (bars in the prefix-sum, piece and segment layouts, curves, the Gaussian
+// filter) behind run-time flags -- the general kernel.  1: bars in the prefix-sum layout and nothing else (the host picks it when the
+// handle's display is exactly that: a.bar.out != nullptr, ps_lanes > 0).  2: no display (a.bar.out == nullptr).  The run-time flags
+// cost the paths that do not take them: the allocator serves the worst path and the table requests of the unused layouts stay in the
+// instruction stream (profiles/r05j_bars_ps_park_cuts.txt: entering the display branch alone 0.720 -> 0.688).
+// MIR: the instantiation that also serves wf_hip_set_bars_mirrors (every bar store repeated into up to eight further buffers,
+// BarArgs::out2_delta).  Eight conditional stores at every output site and sixteen scalar registers of offsets: carried by every
+// kernel (round 5) they cost the two-spectra kernels that never use them 0.5-2.4 % (profiles/r06h_mirror_instantiation_ab.txt:
+// headline 0.7855 -> 0.7893, bars-only 0.623 -> 0.638) -- the handle launches this instantiation only while mirror buffers are
+// set.  The split kernels (one spectrum per workgroup, N >= 8192) keep the stores in their only instantiation: MIRROR below.
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false, bool MIR = false, int DISP = 0>
 __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
     static_assert(!MRS || (MR && G::T <= 256 && G::P > 8), "the small-radix instantiation belongs to the containers of one, two and four wavefronts");
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                   "staged tables: window + pass-1 twiddles must fit the workgroup's exchange buffers");
     static_assert(!SPLIT || SPW == 1, "split mode: one spectrum per workgroup");
     static_assert(DEC == 0 || (!SPLIT && G::T == 64 && (G::R1 >> DEC) >= 1 && (G::M >> DEC) >= 64), "decimated path: one-wavefront geometry");
+    constexpr bool MIRROR = MIR || SPLIT;                   // this instantiation stores into wf_hip_set_bars_mirrors' buffers
     constexpr int MO_C = G::M >> DEC;                       // bins per output row (power-of-two paths)
     using RG = RowG<DEC ? MO_C / 4 : G::T, DEC ? 4 : G::P>; // threads x bins per thread that own the output rows
     constexpr int RP = RG::P;
@@ -184,7 +195,10 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     // (formed where they are used, not held from here: two lane masks across the whole kernel were four scalar registers too many
     // for the 2048-sample kernel, whose spill slot then took it over 128 vector registers)
     constexpr bool PS_OK = !BLU && DEC == 0 && !BOTH;
-#define WF_PS_MODE (PS_OK && a.bar.out != nullptr && a.bar.ps_lanes > 0)
+    static_assert(DISP == 0 || PS_OK, "display-specific instantiations: the power-of-two kernels");
+    // (with a display-specific instantiation the tests below are compile-time constants and the other layouts' code is gone)
+    const bool has_display = DISP == 1 ? true : DISP == 2 ? false : (a.bar.out != nullptr);
+#define WF_PS_MODE (PS_OK && (DISP == 1 || (DISP == 0 && a.bar.out != nullptr && a.bar.ps_lanes > 0)))
 #define WF_PS_FINISHER (WF_PS_MODE && (t >> 6) == 0)
     // Prologue: nothing here may wait for memory before the window fetch is in flight.  The spectrum index is clamped
     // (no branch), stream/channel come from a shift (cap_ch is 1 or 2), and the two per-stream words (write position,
@@ -276,7 +290,8 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     // few words where they are used instead of holding them from here)
     BarPre bar_pre_early{0, 0, 1, 0, 0, 0, -1};
     if constexpr(!(BLU && !MR))
-        bar_pre_early = bars_preload<G, true, PS_OK>(a.bar, t);
+        if constexpr(DISP == 0)
+            bar_pre_early = bars_preload<G, true, PS_OK>(a.bar, t);
     const bool wave_nz = __any(nz) != 0;
     WF_STAMP(1);
     bool wave_below = true;
@@ -473,8 +488,9 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     BarEntries<G> bar_entries;
     bar_entries.base = 0;
     if constexpr(COEF_EARLY) {
-        bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
-        if(!process && a.bar.out != nullptr)
+        if constexpr(DISP != 2)
+            bars_fetch_entries<G, PS_OK, DISP == 1>(a.bar, t, bar_entries, WF_PS_FINISHER);
+        if(!process && has_display)
             wait_vmem_all(); // (the rare path that skips P4 and its wait)
     }
     if(process) {
@@ -537,14 +553,14 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 if(dup)
                     fill_row<RG, BLU>(rows + (size_t)MO, t, a.db_min, NB);
             }
-            if(a.bar.out != nullptr) {
+            if(has_display) {
                 // what render_bars makes of rows of DB_MIN: every bar at border_bottom
                 float *bo = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
                 if(a.bar.pre_out != nullptr && t < (dup ? 2 : 1))
                     a.bar.pre_out[(size_t)stream * a.bar.disp_ch + ch + t] = a.bar.border_bottom;
                 for(int i = t; i < a.bar.num_bars * (dup ? 2 : 1); i += T) {
                     bo[i] = a.bar.border_bottom;
-                    if constexpr(!BLU) // (the Bluestein / mixed-radix instantiations, at their register caps, do not serve wf_hip_set_bars_mirror)
+                    if constexpr(!BLU && MIRROR) // (the Bluestein / mixed-radix instantiations, at their register caps, do not serve wf_hip_set_bars_mirrors)
 #pragma unroll
                         for(int j = 0; j < 8; ++j)
                             if(j < a.bar.out2_n)
@@ -596,15 +612,15 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     // execute in order), and checks the count before it parks its part of the row: by then the dB math has passed and the
     // others have long arrived.  (Mono mixdown inside one workgroup has barriers of its own between
     // the last reads and here.)
-    const bool count_arrivals = T > 64 && a.bar.out != nullptr && (SPLIT || !mono_mix) && !BOTH;
+    const bool count_arrivals = T > 64 && has_display && (SPLIT || !mono_mix) && !BOTH;
     if(count_arrivals) {
         asm volatile("" ::: "memory");
         if(lane == 0)
             __hip_atomic_fetch_add(arrivals, 1, WF_ARRIVE_ORDER_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // the bar tables of this thread: requested here so that their L2 latency runs under the dB math and the row stores
-    if constexpr(!COEF_EARLY)
-        bars_fetch_entries<G, PS_OK>(a.bar, t, bar_entries, WF_PS_FINISHER);
+    if constexpr(!COEF_EARLY && DISP != 2)
+        bars_fetch_entries<G, PS_OK, DISP == 1>(a.bar, t, bar_entries, WF_PS_FINISHER);
     if constexpr(WF_DEFER_STATE && !BLU && DEC == 0) {
         if(process && !mono_mix)
             p4_store_state<G>(a, t, ts, mag); // behind the table requests (p4_split_smooth<.., DEFER>)
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
 #define WF_TAIL_PRIO 0
 #endif
     // the further bars buffers (BarArgs::out2_delta) of a spectrum whose displayed row(s) this tick leaves as they are: copied over
-    if(!BLU && a.bar.out != nullptr && a.bar.out2_n > 0 && active && ch < a.bar.disp_ch) {
+    if(!BLU && MIRROR && has_display && a.bar.out2_n > 0 && active && ch < a.bar.disp_ch) {
         const bool have_row_ = do_db && !(mono_mix && ch == 1);
         const bool reset_ = hidden && !was_silent && ch < (stereo ? 2u : 1u);
         if(!have_row_ && !reset_) { // (uniform over the spectrum)
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
             }
         }
     }
-    if(a.bar.out != nullptr && !WF_EXP_NO_TAIL) {
+    if(has_display && !WF_EXP_NO_TAIL) {
         // The display phase runs with raised issue priority: what is left of the workgroup's life is a short serial stretch (one
         // wavefront per spectrum at the end) that holds the workgroup's LDS, and on a SIMD shared with three wavefronts in their
         // transform passes every instruction of it otherwise waits its turn
@@ -735,13 +751,15 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
                 WF_STAMP(15);
                 if(ps_finisher) {
                     float *out0 = a.bar.out + ((size_t)stream * a.bar.disp_ch + ch) * a.bar.num_bars;
-                    const BarArgs bar_row = [&] { BarArgs b = a.bar; if(b.pre_out) b.pre_out += (size_t)stream * a.bar.disp_ch + ch; return b; }();
+                    const BarArgs bar_row = [&] { BarArgs b = a.bar; if(!MIRROR) b.out2_n = 0; if(b.pre_out) b.pre_out += (size_t)stream * a.bar.disp_ch + ch; return b; }();
                     ps_finish<G, RG>(bar_row, bar_entries, dbl, MO, lane, have_row, out0, dup_row ? out0 + a.bar.num_bars : nullptr);
                 }
                 WF_STAMP(13);
                 return;
             }
         }
+        if constexpr(DISP == 1)
+            return; // (unreachable: WF_PS_MODE is a constant here -- the other layouts are not compiled in)
         if(have_row && row_thread)
             store_row<RG, BLU>(dbl, t, d, NB);
         if(a.bar.curve == 2 && have_row && t == 0) // the Catmull-Rom taps of the last points reach bins M and M + 1 (dropped by the reference)
@@ -762,7 +780,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         // (and BarArgs::pre_out points at the entry of the row being finished: the stream's only row when the threads of both spectra share it)
         const BarArgs bar_row = [&] {
             BarArgs b = a.bar;
-            if(BLU)
+            if(BLU || !MIRROR)
                 b.out2_n = 0;
             if(b.pre_out)
                 b.pre_out += (size_t)stream * a.bar.disp_ch + (BOTH ? 0u : ch);

@@ -17,6 +17,89 @@ namespace {
 
 using wf::host::fail;
 
+// The power-of-two kernels come in display-specific instantiations (spectrum_tick_kernel<.., MIR, DISP>, wf_kernels.hpp): what a
+// launch needs is known on the host -- no display at all (DISP 2), bars in the prefix-sum layout and nothing else (DISP 1), anything
+// else (DISP 0); with MIR the stores into wf_hip_set_bars_mirrors' buffers.  One launch = one of them, picked here.
+inline int display_kind(const wf::TickArgs &a)
+{
+#ifdef WF_DEV_BUILD
+    static const bool off = getenv("WF_HIP_DISP") && atoi(getenv("WF_HIP_DISP")) == 0; // (A/B aid: the general instantiation for everything)
+    if(off)
+        return 0;
+#endif
+    if(a.bar.out == nullptr)
+        return 2;
+    return (a.bar.ps_lanes > 0 && a.bar.curve == 0) ? 1 : 0;
+}
+template<class G, int SPW, bool ALIGNED, bool SPLIT, int DEC, bool TLDS, bool BOTH, bool MIR, int DISP>
+void launch_pow2_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const wf::TickArgs &a)
+{
+    hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, ALIGNED, SPLIT, DEC, TLDS, false, BOTH, false, false, MIR, DISP>), grid, block, lds, st, a);
+}
+// SPECIAL: whether this family has display-specific instantiations at all (the curve-sharing and decimated kernels keep the general one)
+template<class G, int SPW, bool SPLIT, int DEC, bool TLDS, bool BOTH, bool SPECIAL>
+void launch_pow2(dim3 grid, dim3 block, size_t lds, hipStream_t st, const wf::TickArgs &a, bool aligned)
+{
+    constexpr bool SPLIT_MIR = SPLIT; // (the split kernels serve the mirrors in their only instantiation: spectrum_tick_kernel's MIRROR)
+    const bool mir = !SPLIT_MIR && a.bar.out2_n > 0;
+    const int disp = SPECIAL ? display_kind(a) : 0;
+#define WF_L(AL, MIR_, DISP_) launch_pow2_one<G, SPW, AL, SPLIT, DEC, TLDS, BOTH, MIR_, DISP_>(grid, block, lds, st, a)
+    if constexpr(SPECIAL) {
+        if(disp == 2) {
+            if(aligned) WF_L(true, false, 2); else WF_L(false, false, 2);
+            return;
+        }
+        if(disp == 1) {
+            if constexpr(SPLIT_MIR) {
+                if(aligned) WF_L(true, false, 1); else WF_L(false, false, 1);
+            } else if(mir) {
+                if(aligned) WF_L(true, true, 1); else WF_L(false, true, 1);
+            } else {
+                if(aligned) WF_L(true, false, 1); else WF_L(false, false, 1);
+            }
+            return;
+        }
+    }
+    if constexpr(SPLIT_MIR) {
+        if(aligned) WF_L(true, false, 0); else WF_L(false, false, 0);
+    } else if(mir) {
+        if constexpr(DEC > 0)
+            WF_L(false, true, 0); // (the decimated sizes: the scalar fetch for both alignments)
+        else {
+            if(aligned) WF_L(true, true, 0); else WF_L(false, true, 0);
+        }
+    } else {
+        if(aligned) WF_L(true, false, 0); else WF_L(false, false, 0);
+    }
+#undef WF_L
+}
+template<class G, int SPW, bool SPLIT, int DEC, bool TLDS, bool BOTH, bool SPECIAL>
+int setup_pow2_lds(wf_hip *h, int lds)
+{
+#define WF_A(AL, MIR_, DISP_)                                                                                                                  \
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, AL, SPLIT, DEC, TLDS, false, BOTH, false, false, MIR_, DISP_>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+    WF_A(true, false, 0);
+    WF_A(false, false, 0);
+    if constexpr(!SPLIT) {
+        WF_A(false, true, 0);
+        if constexpr(DEC == 0)
+            WF_A(true, true, 0);
+    }
+    if constexpr(SPECIAL) {
+        WF_A(true, false, 1);
+        WF_A(false, false, 1);
+        WF_A(true, false, 2);
+        WF_A(false, false, 2);
+        if constexpr(!SPLIT) {
+            WF_A(true, true, 1);
+            WF_A(false, true, 1);
+        }
+    }
+#undef WF_A
+    return WF_HIP_OK;
+}
+
 template<class G> void launch_tick_split(wf_hip *h, const wf::TickArgs &a0, bool aligned)
 {
     const dim3 block(G::T);
@@ -26,20 +109,14 @@ template<class G> void launch_tick_split(wf_hip *h, const wf::TickArgs &a0, bool
         wf::TickArgs a = a0;
         a.split_ch = h->split_mono ? (uint32_t)(1 - pass) : 0xffffffffu;
         const dim3 grid(h->split_mono ? a.stream_count : a.stream_count * a.cap_ch);
-        if(aligned)
-            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, true, true>), grid, block, lds, h->launch_stream, a);
-        else
-            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 1, false, true>), grid, block, lds, h->launch_stream, a);
+        launch_pow2<G, 1, true, 0, false, false, true>(grid, block, lds, h->launch_stream, a, aligned);
     }
 }
 
 template<class G> int setup_launch_split(wf_hip *h)
 {
     const int lds = (int)wf::tick_lds_bytes<G, 1>();
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 1, true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 1, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_TRY_RC((setup_pow2_lds<G, 1, true, 0, false, false, true>(h, lds)));
     h->launch = &launch_tick_split<G>;
     h->wg_lds = (uint32_t)lds;
     h->wg_threads = (uint32_t)G::T;
@@ -57,19 +134,13 @@ template<class G, int DEC> void launch_tick_dec(wf_hip *h, const wf::TickArgs &a
     const uint32_t n_spec = a.stream_count * a.cap_ch;
     const dim3 grid((n_spec + 1) / 2), block(G::T * 2);
     const size_t lds = wf::tick_lds_bytes<G, 2>();
-    if(aligned)
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, true, false, DEC>), grid, block, lds, h->launch_stream, a);
-    else
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, 2, false, false, DEC>), grid, block, lds, h->launch_stream, a);
+    launch_pow2<G, 2, false, DEC, false, false, false>(grid, block, lds, h->launch_stream, a, aligned);
 }
 
 template<class G, int DEC> int setup_launch_dec(wf_hip *h)
 {
     const int lds = (int)wf::tick_lds_bytes<G, 2>();
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 2, true, false, DEC>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, 2, false, false, DEC>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_TRY_RC((setup_pow2_lds<G, 2, false, DEC, false, false, false>(h, lds)));
     h->launch = &launch_tick_dec<G, DEC>;
     h->wg_lds = (uint32_t)lds;
     h->wg_threads = (uint32_t)G::T * 2u;
@@ -180,19 +251,13 @@ template<class G, int SPW, bool TLDS, bool BOTH = false> void launch_tick(wf_hip
     const uint32_t n_spec = a.stream_count * a.cap_ch;
     const dim3 grid((n_spec + SPW - 1) / SPW), block(G::T * SPW);
     const size_t lds = wf::tick_lds_bytes<G, SPW>();
-    if(aligned)
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS, false, BOTH>), grid, block, lds, h->launch_stream, a);
-    else
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS, false, BOTH>), grid, block, lds, h->launch_stream, a);
+    launch_pow2<G, SPW, false, 0, TLDS, BOTH, !BOTH>(grid, block, lds, h->launch_stream, a, aligned);
 }
 
 template<class G, int SPW, bool TLDS, bool BOTH = false> int setup_launch_impl(wf_hip *h)
 {
     const int lds = (int)wf::tick_lds_bytes<G, SPW>();
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, true, false, 0, TLDS, false, BOTH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, false, 0, TLDS, false, BOTH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_TRY_RC((setup_pow2_lds<G, SPW, false, 0, TLDS, BOTH, !BOTH>(h, lds)));
     h->launch = &launch_tick<G, SPW, TLDS, BOTH>;
     h->wg_lds = (uint32_t)lds;
     h->wg_threads = (uint32_t)(G::T * SPW);

@@ -1621,10 +1621,19 @@ template<class G> struct BarEntries {
     f4 coef[CMAX];
     int base;
 };
-template<class G, bool PS_OK = true> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be, bool finisher = false)
+template<class G, bool PS_OK = true, bool PS_ONLY = false> WF_DEV void bars_fetch_entries(const BarArgs &b, int t, BarEntries<G> &be, bool finisher = false)
 {
     constexpr int T = G::T;
     be.base = 0;
+    if constexpr(PS_ONLY) { // (the instantiation displays bars in the prefix-sum layout and nothing else: spectrum_tick_kernel<.., DISP = 1>)
+        if(finisher) { // wave-uniform
+            const float *p = b.ps_tab + (size_t)(t & 63) * 4;
+            WF_UNROLL
+            for(int c = 0; c < 3; ++c)
+                be.coef[c] = ld4(p + c * 256);
+        }
+        return;
+    }
     if constexpr(!PS_OK) { // (the instantiation never runs the prefix-sum layout -- the Bluestein / mixed-radix kernels at their register caps)
         if(b.out == nullptr || b.num_segs == 0)
             return;
