@@ -435,7 +435,7 @@ def test_power_of_two_kernels_do_not_spill():
     seen = seen_mixed = seen_small = 0
     for res in results:
         for name, scratch, vgprs in res:
-            m = re.search(r"ELb([01])ELb([01])ELb([01])ELb([01])ELb[01]ELi[012]EEEvNS_8TickArgsE$", name)  # <.., BLU, BOTH, MR, MRS, MIR, DISP>
+            m = re.search(r"ELb([01])ELb([01])ELb([01])ELb([01])ELb[01]ELi[012]ELi[0-8]EEEvNS_8TickArgsE$", name)  # <.., BLU, BOTH, MR, MRS, MIR, DISP, PLAN>
             assert m, name
             blu, mixed, small = m.group(1) == "1", m.group(3) == "1", m.group(4) == "1"
             if blu and not mixed:

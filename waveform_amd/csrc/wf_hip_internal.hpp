@@ -102,6 +102,7 @@ struct wf_hip {
     size_t big_out_lds = 0;          // dynamic LDS of big_outputs_kernel
     int *d_big_task = nullptr, *d_big_bar_task = nullptr; // BarArgs::big_task / big_bar_task
     int big_num_tasks = 0;
+    int mr_plan_id = 0;              // spectrum_tick_kernel's PLAN: the compile-time mixed-radix plan of this size (0: the run-time plan)
     int interp_shape[2] = {0, 0};    // {tab.interp_radius, tab.interp_taps} (WF_HIP_TABLE_INTERP_SHAPE)
     float *d_bars = nullptr;
     float *d_bars_pre = nullptr;    // BarArgs::pre_out: [n_streams][disp_ch], mirrored displays only

@@ -162,12 +162,15 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // handle's display is exactly that: a.bar.out != nullptr, ps_lanes > 0).  2: no display (a.bar.out == nullptr).  The run-time flags
 // cost the paths that do not take them: the allocator serves the worst path and the table requests of the unused layouts stay in the
 // instruction stream (profiles/r05j_bars_ps_park_cuts.txt: entering the display branch alone 0.720 -> 0.688).
+// PLAN (with MRS): the mixed-radix instantiation of ONE compile-time plan (mr_fixed_plan below: the sizes the plugin picks by itself) --
+// the run-time plan's dispatch over every radix, which sets the register allocation of the instantiation that carries it, is not
+// compiled in.  0: every fixed plan of the container behind run-time tests, then the run-time plan.
 // MIR: the instantiation that also serves wf_hip_set_bars_mirrors (every bar store repeated into up to eight further buffers,
 // BarArgs::out2_delta).  Eight conditional stores at every output site and sixteen scalar registers of offsets: carried by every
 // kernel (round 5) they cost the two-spectra kernels that never use them 0.5-2.4 % (profiles/r06h_mirror_instantiation_ab.txt:
 // headline 0.7855 -> 0.7893, bars-only 0.623 -> 0.638) -- the handle launches this instantiation only while mirror buffers are
 // set.  The split kernels (one spectrum per workgroup, N >= 8192) keep the stores in their only instantiation: MIRROR below.
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false, bool MIR = false, int DISP = 0>
+template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false, bool MIR = false, int DISP = 0, int PLAN = 0>
 __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
 {
     static_assert(!MRS || (MR && G::T <= 256 && G::P > 8), "the small-radix instantiation belongs to the containers of one, two and four wavefronts");
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
     // (formed where they are used, not held from here: two lane masks across the whole kernel were four scalar registers too many
     // for the 2048-sample kernel, whose spill slot then took it over 128 vector registers)
     constexpr bool PS_OK = !BLU && DEC == 0 && !BOTH;
-    static_assert(DISP == 0 || PS_OK, "display-specific instantiations: the power-of-two kernels");
+    static_assert(DISP != 1 || PS_OK, "the prefix-sum bars belong to the power-of-two kernels");
     // (with a display-specific instantiation the tests below are compile-time constants and the other layouts' code is gone)
     const bool has_display = DISP == 1 ? true : DISP == 2 ? false : (a.bar.out != nullptr);
 #define WF_PS_MODE (PS_OK && (DISP == 1 || (DISP == 0 && a.bar.out != nullptr && a.bar.ps_lanes > 0)))
@@ -381,7 +384,24 @@ __global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8
         // compile-time constants (mr_transform_fixed): N = 800 0.430 -> 0.462 of the HBM peak at 8192 streams, 0.316 -> 0.358 at 2048.
         auto plan_is = [&](int r0, int r1, int r2) { return a.mr.passes == 3 && a.mr.radix[0] == r0 && a.mr.radix[1] == r1 && a.mr.radix[2] == r2; };
         auto sp_sync = [] { spectrum_sync<G>(); };
-        if(MRS && WF_MR_FIXED_PLANS && G::N == 2048 && plan_is(5, 10, 8)) // 800
+        static_assert(PLAN == 0 || (MRS && ((G::N == 2048 && PLAN >= 1 && PLAN <= 4) || (G::N == 4096 && PLAN >= 5 && PLAN <= 8))), "a fixed plan belongs to its container's small-radix instantiation");
+        if constexpr(PLAN == 1) // 800
+            mr_transform_fixed<G, 5, 10, 8>(a.mr, process, t, lds, sp_sync);
+        else if constexpr(PLAN == 2) // 960
+            mr_transform_fixed<G, 5, 12, 8>(a.mr, process, t, lds, sp_sync);
+        else if constexpr(PLAN == 3) // 720
+            mr_transform_fixed<G, 10, 6, 6>(a.mr, process, t, lds, sp_sync);
+        else if constexpr(PLAN == 4) // 880
+            mr_transform_fixed<G, 11, 5, 8>(a.mr, process, t, lds, sp_sync);
+        else if constexpr(PLAN == 5) // 1600
+            mr_transform_fixed<G, 10, 8, 10>(a.mr, process, t, lds, sp_sync);
+        else if constexpr(PLAN == 6) // 1920
+            mr_transform_fixed<G, 10, 8, 12>(a.mr, process, t, lds, sp_sync);
+        else if constexpr(PLAN == 7) // 2000
+            mr_transform_fixed<G, 10, 10, 10>(a.mr, process, t, lds, sp_sync);
+        else if constexpr(PLAN == 8) // 1760
+            mr_transform_fixed<G, 10, 8, 11>(a.mr, process, t, lds, sp_sync);
+        else if(MRS && WF_MR_FIXED_PLANS && G::N == 2048 && plan_is(5, 10, 8)) // 800
             mr_transform_fixed<G, 5, 10, 8>(a.mr, process, t, lds, sp_sync);
         else if(MRS && WF_MR_FIXED_PLANS && G::N == 2048 && plan_is(5, 12, 8)) // 960
             mr_transform_fixed<G, 5, 12, 8>(a.mr, process, t, lds, sp_sync);

@@ -481,9 +481,67 @@ template<class G, bool SMALL = false, class Sync> WF_DEV void mr_transform(const
 // A plan known at compile time (three passes R0 x R1 x R2): the same pass functions with every length, stride and trip count a
 // constant -- the divisions by the stride become multiplications, the loops over a thread's butterflies unroll, no dispatch on the
 // radix.  For the sizes the plugin picks by itself (sample_rate / fps & -16).
+// One pass of a compile-time plan IN PLACE (one wavefront per spectrum): every butterfly of this thread is read first (NB / 64
+// rounds of R points in registers), then all of them are transformed and written back into the SAME buffer at their Stockham
+// positions.  LDS operations of a wavefront execute in order and nobody else touches the spectrum's buffer, so the reads of every
+// lane are in front of the writes of every lane without a barrier.  Half the exchange buffer of the two-halves form: 3.3 instead of
+// 6.4 KB per spectrum at N = 800 -- more spectra per CU, which is what these sizes scale with (profiles/r04g_n800_phases.txt).
+template<int T, int R, bool TW, int NB, int NS> WF_DEV void mr_pass_inplace(bool process, cf *buf, const cf *tw, int t)
+{
+    constexpr int ROUNDS = (NB + T - 1) / T;
+    cf v[ROUNDS][R];
+    if(process) {
+        WF_UNROLL
+        for(int r = 0; r < ROUNDS; ++r) {
+            const int j = t + r * T;
+            if(ROUNDS * T == NB || j < NB)
+                mr_butterfly<R, TW>(buf, tw, j, NB, NS, v[r]);
+        }
+    }
+    wave_fence();
+    if(process) {
+        WF_UNROLL
+        for(int r = 0; r < ROUNDS; ++r) {
+            const int j = t + r * T;
+            if(ROUNDS * T == NB || j < NB) {
+                const int base = TW ? (j / NS) * NS * R + (j % NS) : j * R;
+                WF_UNROLL
+                for(int k = 0; k < R; ++k)
+                    lds_st2(buf, base + k * NS, v[r][k]);
+            }
+        }
+    }
+    wave_fence();
+}
+template<class G, int R0, int R1, int R2> WF_DEV void mr_transform_fixed_inplace(const MrPlan &p, bool process, int t, cf *lds)
+{
+    static_assert(G::T == 64, "in place: one wavefront per spectrum");
+    constexpr int np = R0 * R1 * R2;
+    wave_fence(); // the fetch has written the points
+    mr_pass_inplace<G::T, R0, false, np / R0, 1>(process, lds, nullptr, t);
+    mr_pass_inplace<G::T, R1, true, np / R1, R0>(process, lds, p.tw, t);
+    // the last pass: one butterfly per thread at most, Z[k] into the four-plane layout (mr_z_addr) of the same buffer
+    static_assert(R0 * R1 <= G::T, "the last pass of a compile-time plan has one butterfly per thread at most");
+    cf v[R2];
+    const bool mine = process && t < R0 * R1;
+    if(mine)
+        mr_butterfly<R2, true>(lds, p.tw + R1 * R0, t, R0 * R1, R0 * R1, v);
+    wave_fence();
+    if(mine) {
+        WF_UNROLL
+        for(int k = 0; k < R2; ++k)
+            lds_st2(lds, mr_z_addr(p, t + k * R0 * R1), v[k]);
+    }
+    wave_fence();
+}
 template<class G, int R0, int R1, int R2, class Sync> WF_DEV void mr_transform_fixed(const MrPlan &p, bool process, int t, cf *lds, Sync sync)
 {
     constexpr int np = R0 * R1 * R2;
+    if constexpr(G::T == 64 && R0 * R1 <= G::T) { // (one wavefront per spectrum: in place -- the host sizes the buffer accordingly, setup_launch_blu)
+        (void)sync;
+        mr_transform_fixed_inplace<G, R0, R1, R2>(p, process, t, lds);
+        return;
+    }
     constexpr int H = (np + 15) & ~15; // wf::mr_exchange_half
     sync();
     if(process)

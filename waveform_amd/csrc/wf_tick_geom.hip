@@ -162,7 +162,28 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> void l
         wf::TickArgs a = a0;
         a.split_ch = two ? (uint32_t)(1 - pass) : 0xffffffffu;
         const dim3 grid(two ? a.stream_count : (n_spec + SPW - 1) / SPW);
-        hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS>), grid, block, lds, h->launch_stream, a);
+        // (no display: the instantiation without any display code -- spectrum_tick_kernel<.., DISP = 2>; the sizes with a
+        // compile-time plan: the instantiation of that plan alone -- <.., PLAN>, wf_hip::mr_plan_id)
+        const bool nodisp = MRS && display_kind(a) == 2; // (the small-radix instantiation only: N = 4160 on the all-radix one measured -1.8 %)
+#define WF_LP(PLAN_)                                                                                                                                            \
+    do {                                                                                                                                                       \
+        if(nodisp)                                                                                                                                             \
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 2, PLAN_>), grid, block, lds, h->launch_stream, a); \
+        else                                                                                                                                                   \
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 0, PLAN_>), grid, block, lds, h->launch_stream, a); \
+    } while(0)
+        if constexpr(MRS && (G::N == 2048 || G::N == 4096)) {
+            constexpr int P0 = G::N == 2048 ? 1 : 5; // the container's four fixed plans (spectrum_tick_kernel's PLAN)
+            switch(h->mr_plan_id - P0) {
+            case 0: WF_LP(P0); break;
+            case 1: WF_LP(P0 + 1); break;
+            case 2: WF_LP(P0 + 2); break;
+            case 3: WF_LP(P0 + 3); break;
+            default: WF_LP(0); break;
+            }
+        } else
+            WF_LP(0);
+#undef WF_LP
     }
 }
 
@@ -220,11 +241,41 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> int se
     // on the same instantiation may need all of it)
     WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->mr_plan_id = 0;
+    if constexpr(MRS && (G::N == 2048 || G::N == 4096)) {
+        // the sizes the plugin picks by itself run their plan as compile-time constants, in an instantiation of their own
+        static const int fixed[8][3] = {{5, 10, 8}, {5, 12, 8}, {10, 6, 6}, {11, 5, 8}, {10, 8, 10}, {10, 8, 12}, {10, 10, 10}, {10, 8, 11}};
+        constexpr int P0 = G::N == 2048 ? 1 : 5;
+        for(int i = 0; i < 4 && h->mr_passes == 3; ++i)
+            if(h->mr_radix[0] == fixed[P0 - 1 + i][0] && h->mr_radix[1] == fixed[P0 - 1 + i][1] && h->mr_radix[2] == fixed[P0 - 1 + i][2])
+                h->mr_plan_id = P0 + i;
+#ifdef WF_DEV_BUILD
+        if(const char *e = std::getenv("WF_HIP_MR_PLAN_KERNEL")) // 0: the instantiation that carries every plan (A/B)
+            if(e[0] == '0')
+                h->mr_plan_id = 0;
+#endif
+#define WF_AP(PLAN_)                                                                                                                                          \
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 0, PLAN_>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                                                       \
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 2, PLAN_>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+        WF_AP(P0);
+        WF_AP(P0 + 1);
+        WF_AP(P0 + 2);
+        WF_AP(P0 + 3);
+#undef WF_AP
+    }
     if constexpr(MR) {
         // the spectrum's exchange buffer by the transform's size, not the container's (MrPlan::lds_cf): room for more spectra per CU
         h->mr_half = (int)wf::mr_exchange_half(h->N / 2);
         h->mr_lds_cf = (int)wf::mr_exchange_cf(h->N / 2, (uint32_t)G::LDS_CF);
         h->mr_s3 = h->mr_half / 4 + 4;
+        // the compile-time plans of the one-wavefront container run IN PLACE (mr_transform_fixed_inplace): without a display -- whose
+        // planner has sized its staging by the two-halves buffer already -- the spectrum needs its points and the four-plane result only
+        if(G::T == 64 && h->mr_plan_id != 0 && h->num_bars == 0)
+            h->mr_lds_cf = std::min(h->mr_lds_cf, std::max(h->mr_half, 4 * h->mr_s3));
         lds -= SPW * ((int)G::LDS_CF - h->mr_lds_cf) * (int)sizeof(wf::cf);
     }
     h->launch = &launch_tick_blu<G, SPW, SPLIT, MR, MRS>;
