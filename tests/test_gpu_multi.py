@@ -123,14 +123,20 @@ def test_gather_runs_under_the_next_tick_and_is_double_buffered():
         assert all(np.array_equal(x, last[0]) for x in last) and np.array_equal(last[0], m.bars())
 
 
-@pytest.mark.parametrize("n_fft,devices", [(4096, [0]), (4096, [0, 0, 0]), (800, [0, 0, 0]), (800, [0]), (48000, [0, 0])])
-def test_ticks_between_gathers_leave_the_gathered_result_alone(n_fft, devices):
+@pytest.mark.parametrize("n_fft,devices,mirror", [(4096, [0], "1"), (4096, [0], None), (4096, [0, 0, 0], None), (4096, [0, 0, 0], "send"), (800, [0, 0, 0], "1"),
+                                                  (800, [0], None), (48000, [0, 0], None)])
+def test_ticks_between_gathers_leave_the_gathered_result_alone(n_fft, devices, mirror, monkeypatch):
     """The contract of include/wf_hip.h: a gathered result stays valid until the FIRST tick after the NEXT gather -- whatever the
     number of ticks between two gathers, and whichever path the size takes: where the tick kernels write the send buffers / the
     results themselves (power-of-two sizes; round 5 switched buffers with every TICK, so the second tick after a gather overwrote
     the result being read) and where the bars are copied behind the tick (sizes that are not powers of two -- N = 800, the
     plugin's automatic size, mixed radix -- and sizes beyond a CU's LDS: wf_hip_set_bars_mirrors answers UNSUPPORTED and the group
-    picks the copy for that handle)."""
+    picks the copy for that handle).  `mirror`: WF_HIP_MULTI_MIRROR -- by default the kernels write only where that saves peer
+    copies (every device addresses every other); "1" / "send" make them write the result / the send buffers too."""
+    if mirror is None:
+        monkeypatch.delenv("WF_HIP_MULTI_MIRROR", raising=False)
+    else:
+        monkeypatch.setenv("WF_HIP_MULTI_MIRROR", mirror)
     have = wf.device_count()
     devices = [(i % have) for i in range(len(devices))]
     cfg = _cfg(fft_size=n_fft)
@@ -373,6 +379,6 @@ def test_node_check_runs_on_this_box():
     assert line, (r.stdout[-500:], r.stderr[-2000:])
     d = json.loads(line[-1])
     assert r.returncode == 0 and d["ready"] and d["reasons"] == [], (r.returncode, d.get("reasons"), r.stderr[-1500:])
-    assert len(d["runs"]) == 6 and all(x.get("verified") for x in d["runs"])
+    assert len(d["runs"]) == 7 and all(x.get("verified") for x in d["runs"])
     hf = d["host_fed"]
     assert hf["verified"] and len(hf["per_device"]) == d["devices_used"] and all(x["host_GBps"] > 0 for x in hf["per_device"])

@@ -49,7 +49,7 @@ if __name__ == "__main__":
     print(json.dumps({"shape": "cfg5 per-GPU shape, world 1, torch process", "frac_of_8TBps": res}), flush=True)
     res = {"wf_hip_multi, kernel writes the gathered buffer": [], "wf_hip_multi, copy behind the tick": []}
     for _ in range(reps):
-        for name, env in (("wf_hip_multi, kernel writes the gathered buffer", {}), ("wf_hip_multi, copy behind the tick", {"WF_HIP_MULTI_MIRROR": "0"})):
+        for name, env in (("wf_hip_multi, kernel writes the gathered buffer", {"WF_HIP_MULTI_MIRROR": "1"}), ("wf_hip_multi, copy behind the tick", {"WF_HIP_MULTI_MIRROR": "0"})):
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multi_bench.py")], capture_output=True, text=True, env=dict(os.environ, **env))
             lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
             if r.returncode == 0 and lines:

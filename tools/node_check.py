@@ -3,7 +3,8 @@
 devices and the links between them, runs BASELINE configs[4]'s shape through the C ABI's multi-device group (wf_hip_multi_*) over
 every device, one leg per process -- the default transport (ncclAllGather of the dlopen()ed librccl.so where the devices are
 distinct); RCCL with its channel count capped at one and at two (how many CUs the collective's kernels take from a tick that
-fills them in whole rounds); RCCL with the gather stream on a hardware queue of its own; the peer transport with the tick
+fills them in whole rounds); RCCL with the gather stream on a hardware queue of its own; the default transport with the tick kernels
+writing the send buffers (no copy behind the tick: equal or slower on one device, for a node to decide); the peer transport with the tick
 kernels storing their slice into every device's result (no kernel, no copy in the exchange) and with copies behind the tick --
 and prints ONE JSON object: per-device tick times with and without the gather and their difference per leg, the gather's own
 time, the link type / hop count and the peer-access answer of every device pair, and whether every device's gathered copy equals
@@ -213,6 +214,7 @@ LEGS = [
     ("rccl, one channel", "rccl", {"NCCL_MAX_NCHANNELS": "1"}),
     ("rccl, two channels", "rccl", {"NCCL_MAX_NCHANNELS": "2"}),
     ("rccl, gather stream on a hardware queue of its own", "rccl", {"WF_HIP_MULTI_GATHER_PRIORITY": "high"}),
+    ("default transport, the tick kernels write the send buffers themselves", None, {"WF_HIP_MULTI_MIRROR": "1"}),
     ("peer, the tick kernels store into every device's result", "peer", {}),
     ("peer, copies behind the tick", "peer", {"WF_HIP_MULTI_MIRROR": "send"}),
 ]

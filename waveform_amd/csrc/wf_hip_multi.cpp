@@ -592,6 +592,13 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
         // no copy, no kernel on the gather streams at all.  The batches whose display comes from a kernel of its own keep the copy
         // behind the tick (WF_HIP_MULTI_MIRROR=0: the copy for everybody, =send: no direct peer stores; A/B aids)
         if(rc == WF_HIP_OK) {
+            // Which shards' tick kernels write the exchange's buffers themselves (wf_hip_set_bars_mirrors) instead of a device copy
+            // behind the tick: by default only where that saves the PEER copies -- every device addresses every other, the slices
+            // go straight into every device's result.  Into a send buffer (RCCL; peer copies) or the one device's own result the
+            // kernel-side stores bought nothing once the kernels came in display-specific instantiations: the copy behind the tick
+            // 0.651 against 0.618 through this group, 0.649 against 0.650 from a torch process (profiles/r06o_gather_mirror_one_ab.txt).
+            // WF_HIP_MULTI_MIRROR: 1 = the kernels write wherever they can (round 5's default), send = that without the direct peer
+            // stores, 0 = the copy for everybody (A/B aids).
             const char *e = std::getenv("WF_HIP_MULTI_MIRROR");
             bool all_peer = m->transport == Transport::PEER && m->n <= 8 && !(e && std::strcmp(e, "send") == 0);
             for(uint32_t i = 0; i < m->n && all_peer; ++i) // hipDeviceEnablePeerAccess succeeded (or had before) on device i for device j
@@ -601,7 +608,7 @@ int wf_hip_multi_create(const wf_config *cfg, const int *devices, uint32_t n_dev
                 m->transport_note = "peer access is not enabled between every pair of devices: the bars travel by hipMemcpyPeerAsync";
             rc = run_all(m, [m, e, all_peer](uint32_t i) {
                 Shard &s = *m->shard[i];
-                if(e && e[0] == '0')
+                if(e ? e[0] == '0' : !all_peer)
                     return (int)WF_HIP_OK;
                 int mrc;
                 if(all_peer) {
