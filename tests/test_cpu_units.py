@@ -435,9 +435,13 @@ def test_power_of_two_kernels_do_not_spill():
     seen = seen_mixed = seen_small = 0
     for res in results:
         for name, scratch, vgprs in res:
-            m = re.search(r"ELb([01])ELb([01])ELb([01])ELb([01])ELb[01]ELi[012]ELi[0-8]EEEvNS_8TickArgsE$", name)  # <.., BLU, BOTH, MR, MRS, MIR, DISP, PLAN>
+            # wf::Variant{spw, aligned, split, dec, tlds, blu, both, mr, mrs, mir, disp, plan} as the mangled name spells it: the
+            # members in order, trailing zeros left out
+            m = re.search(r"XtlNS_7VariantE((?:L[ib]\d+E)*)E+vNS_8TickArgsE$", name)
             assert m, name
-            blu, mixed, small = m.group(1) == "1", m.group(3) == "1", m.group(4) == "1"
+            vals = [int(x) for x in re.findall(r"L[ib](\d+)E", m.group(1))]
+            vals += [0] * (12 - len(vals))
+            blu, mixed, small = vals[5] == 1, vals[7] == 1, vals[8] == 1
             if blu and not mixed:
                 continue  # Bluestein: the compatibility path, a few spills tolerated (bounded by the next test)
             if small:     # the one-wavefront container's small-radix instantiation: five waves per SIMD, 96 registers, three words parked
@@ -474,9 +478,9 @@ def test_compatibility_path_kernels_stay_near_their_register_budget(tmp_path):
 #include "wf_host_tables.hpp"
 #include "wf_kernels.hpp"
 #include "wf_big.hpp"
-template __global__ void wf::spectrum_tick_kernel<wf::G2048, 2, false, false, 0, false, true, false>(wf::TickArgs);
-template __global__ void wf::spectrum_tick_kernel<wf::G4096, 2, false, false, 0, false, true, false>(wf::TickArgs);
-template __global__ void wf::spectrum_tick_kernel<wf::G16384, 1, false, true, 0, false, true, false>(wf::TickArgs);
+template __global__ void wf::spectrum_tick_kernel<wf::G2048, wf::Variant{.spw = 2, .blu = true}>(wf::TickArgs);
+template __global__ void wf::spectrum_tick_kernel<wf::G4096, wf::Variant{.spw = 2, .blu = true}>(wf::TickArgs);
+template __global__ void wf::spectrum_tick_kernel<wf::G16384, wf::Variant{.spw = 1, .split = true, .blu = true}>(wf::TickArgs);
 template __global__ void wf::big_whole_kernel<true>(wf::TickArgs);
 template __global__ void wf::big_whole_kernel<false>(wf::TickArgs);
 template __global__ void wf::big_epilogue_kernel<1>(wf::TickArgs);

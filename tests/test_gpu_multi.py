@@ -352,16 +352,17 @@ def test_the_c_example_runs(tmp_path):
 
 def test_node_check_runs_and_verifies():
     """tools/node_check.py -- what gets run first on a node nobody could rehearse on: every device; one process per leg (default
-    transport, RCCL with one and two channels, RCCL with the gather stream on a queue of its own, the peer transport with direct
-    stores and with copies); per-device times with and without the gather, their difference, the gather alone, the links; exit
+    transport, RCCL with one and two channels, RCCL with the gather stream on a queue of its own, the default transport with the
+    tick kernels writing the send buffers, the peer transport with direct stores and with copies); per-device times with and without the gather, their difference, the gather alone, the links; exit
     code 0 only if every leg's gathered copies verified"""
     import json
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "node_check.py"), "--streams-per-device", "1024", "--ticks", "40"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["devices_used"] == wf.device_count() and len(out["runs"]) == 6
-    assert [run["transport"] for run in out["runs"]][1:] == ["rccl", "rccl", "rccl", "peer", "peer"]
+    assert out["devices_used"] == wf.device_count() and len(out["runs"]) == 7
+    # (legs: default, rccl x 3, the default transport with kernel-side stores, peer x 2)
+    assert [run["transport"] for run in out["runs"]][1:4] == ["rccl", "rccl", "rccl"] and [run["transport"] for run in out["runs"]][5:] == ["peer", "peer"]
     for run in out["runs"]:
         assert run["verified"] and run["gather_alone_us"] > 0 and len(run["ms_per_tick_with_gather"]["per_device"]) == len(run["devices"]), run
         assert "gather_costs_per_tick_us" in run and "leg" in run

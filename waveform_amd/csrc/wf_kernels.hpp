@@ -1,6 +1,6 @@
 // wf_kernels.hpp -- gfx950 kernels of libwaveform_hip.so (device code only; hipcc).
 //
-//   spectrum_tick_kernel<G, SPW, ALIGNED>   the fused per-tick pass: ring fetch -> window -> r2c FFT
+//   spectrum_tick_kernel<G, Variant>        the fused per-tick pass: ring fetch -> window -> r2c FFT
 //                                           in LDS -> |X| -> slope -> temporal smoothing -> dBFS
 //                                           (-> volume normalisation -> roll-off -> bars / curve), one HBM
 //                                           pass.  Replaces WAVSource*::tick_spectrum (reference
@@ -170,9 +170,31 @@ template<class G, int SPW> constexpr size_t tick_lds_bytes()
 // kernel (round 5) they cost the two-spectra kernels that never use them 0.5-2.4 % (profiles/r06h_mirror_instantiation_ab.txt:
 // headline 0.7855 -> 0.7893, bars-only 0.623 -> 0.638) -- the handle launches this instantiation only while mirror buffers are
 // set.  The split kernels (one spectrum per workgroup, N >= 8192) keep the stores in their only instantiation: MIRROR below.
-template<class G, int SPW, bool ALIGNED, bool SPLIT = false, int DEC = 0, bool TLDS = false, bool BLU = false, bool BOTH = false, bool MR = false, bool MRS = false, bool MIR = false, int DISP = 0, int PLAN = 0>
-__global__ __launch_bounds__(G::T *SPW, MRS ? WF_WPS_2048_MRS : (BLU && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G)) void spectrum_tick_kernel(const TickArgs a)
+// Which of the kernel's variants an instantiation is: ONE template argument with named fields (a C++20 structural type; call sites
+// read `Variant{.spw = 2, .aligned = true, .disp = 2}`), each field described in the comments above.
+struct Variant {
+    int spw = 2;          // SPW: spectra per workgroup (2: the channels of a stream share it)
+    bool aligned = false; // ALIGNED: the window starts on a 16-byte boundary of the ring for every stream (16-byte fetch)
+    bool split = false;   // SPLIT
+    int dec = 0;          // DEC
+    bool tlds = false;    // TLDS
+    bool blu = false;     // BLU
+    bool both = false;    // BOTH
+    bool mr = false;      // MR
+    bool mrs = false;     // MRS
+    bool mir = false;     // MIR
+    int disp = 0;         // DISP
+    int plan = 0;         // PLAN
+};
+template<class G, Variant V> constexpr int tick_waves_per_simd()
 {
+    return V.mrs ? WF_WPS_2048_MRS : (V.blu && G::P > 8 && G::T <= 64) ? WF_WPS_2048_BLU : WF_WAVES_PER_SIMD(G);
+}
+template<class G, Variant V>
+__global__ __launch_bounds__(V.spw * G::T, (tick_waves_per_simd<G, V>())) void spectrum_tick_kernel(const TickArgs a)
+{
+    constexpr int SPW = V.spw, DEC = V.dec, DISP = V.disp, PLAN = V.plan;
+    constexpr bool ALIGNED = V.aligned, SPLIT = V.split, TLDS = V.tlds, BLU = V.blu, BOTH = V.both, MR = V.mr, MRS = V.mrs, MIR = V.mir;
     static_assert(!MRS || (MR && G::T <= 256 && G::P > 8), "the small-radix instantiation belongs to the containers of one, two and four wavefronts");
     static_assert(!BOTH || (SPW == 2 && !SPLIT && DEC == 0 && !BLU), "shared curve row: two spectra per workgroup, power-of-two sizes");
     static_assert(!BLU || (DEC == 0 && !TLDS && !ALIGNED), "Bluestein path: scalar fetch, no decimation, no staged tables");

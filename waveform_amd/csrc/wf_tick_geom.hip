@@ -34,7 +34,8 @@ inline int display_kind(const wf::TickArgs &a)
 template<class G, int SPW, bool ALIGNED, bool SPLIT, int DEC, bool TLDS, bool BOTH, bool MIR, int DISP>
 void launch_pow2_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const wf::TickArgs &a)
 {
-    hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, ALIGNED, SPLIT, DEC, TLDS, false, BOTH, false, false, MIR, DISP>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .aligned = ALIGNED, .split = SPLIT, .dec = DEC, .tlds = TLDS, .both = BOTH, .mir = MIR, .disp = DISP}>), grid,
+                       block, lds, st, a);
 }
 // SPECIAL: whether this family has display-specific instantiations at all (the curve-sharing and decimated kernels keep the general one)
 template<class G, int SPW, bool SPLIT, int DEC, bool TLDS, bool BOTH, bool SPECIAL>
@@ -77,7 +78,8 @@ template<class G, int SPW, bool SPLIT, int DEC, bool TLDS, bool BOTH, bool SPECI
 int setup_pow2_lds(wf_hip *h, int lds)
 {
 #define WF_A(AL, MIR_, DISP_)                                                                                                                  \
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, AL, SPLIT, DEC, TLDS, false, BOTH, false, false, MIR_, DISP_>), \
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(                                                                          \
+                                          &wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .aligned = AL, .split = SPLIT, .dec = DEC, .tlds = TLDS, .both = BOTH, .mir = MIR_, .disp = DISP_}>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     WF_A(true, false, 0);
     WF_A(false, false, 0);
@@ -168,9 +170,9 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> void l
 #define WF_LP(PLAN_)                                                                                                                                            \
     do {                                                                                                                                                       \
         if(nodisp)                                                                                                                                             \
-            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 2, PLAN_>), grid, block, lds, h->launch_stream, a); \
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .split = SPLIT, .blu = true, .mr = MR, .mrs = MRS, .disp = 2, .plan = PLAN_}>), grid, block, lds, h->launch_stream, a); \
         else                                                                                                                                                   \
-            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 0, PLAN_>), grid, block, lds, h->launch_stream, a); \
+            hipLaunchKernelGGL((wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .split = SPLIT, .blu = true, .mr = MR, .mrs = MRS, .plan = PLAN_}>), grid, block, lds, h->launch_stream, a); \
     } while(0)
         if constexpr(MRS && (G::N == 2048 || G::N == 4096)) {
             constexpr int P0 = G::N == 2048 ? 1 : 5; // the container's four fixed plans (spectrum_tick_kernel's PLAN)
@@ -239,9 +241,9 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> int se
     int lds = (int)wf::tick_lds_bytes<G, SPW>();
     // (the attribute belongs to the kernel, not to this handle: always the container's size -- another handle of another fft size
     // on the same instantiation may need all of it)
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS>),
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .split = SPLIT, .blu = true, .mr = MR, .mrs = MRS}>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 2>),
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .split = SPLIT, .blu = true, .mr = MR, .mrs = MRS, .disp = 2}>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     h->mr_plan_id = 0;
     if constexpr(MRS && (G::N == 2048 || G::N == 4096)) {
@@ -257,9 +259,9 @@ template<class G, int SPW, bool SPLIT, bool MR = false, bool MRS = false> int se
                 h->mr_plan_id = 0;
 #endif
 #define WF_AP(PLAN_)                                                                                                                                          \
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 0, PLAN_>), \
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .split = SPLIT, .blu = true, .mr = MR, .mrs = MRS, .plan = PLAN_}>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                                                       \
-    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, SPW, false, SPLIT, 0, false, true, false, MR, MRS, false, 2, PLAN_>), \
+    WF_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wf::spectrum_tick_kernel<G, wf::Variant{.spw = SPW, .split = SPLIT, .blu = true, .mr = MR, .mrs = MRS, .disp = 2, .plan = PLAN_}>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds))
         WF_AP(P0);
         WF_AP(P0 + 1);
