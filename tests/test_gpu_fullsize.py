@@ -69,37 +69,46 @@ def _reference_ticks(cfg, stream_ids, ticks, hop, keep, bars=False):
     return np.stack(rows), (np.stack(bar_rows) if bars else None)
 
 
-# cfg3's checked streams: the first and last 32 of the batch, the 32 around the boundary between the
-# two concurrent launches wf_hip_tick issues ("lanes": streams [0, 2048) and [2048, 4096)), and one block in the middle of each
-CFG3_BLOCKS = ((0, 32), (1008, 32), (2032, 32), (3056, 32), (4064, 32))
+# cfg3's checked streams: the first and last 32 of the batch, the 32 around every boundary between the
+# concurrent launches wf_hip_tick issues ("lanes": lane l runs streams [4096 l / lanes, 4096 (l + 1) / lanes) -- three since round 6,
+# two before), and one block in the middle of each lane
+def cfg3_blocks(lanes, streams=4096):
+    blocks = [(0, 32), (streams - 32, 32)]
+    for l in range(lanes):
+        lo, hi = streams * l // lanes, streams * (l + 1) // lanes
+        if l > 0:
+            blocks.append((lo - 16, 32))
+        blocks.append(((lo + hi) // 2 - 16, 32))
+    return tuple(sorted(set(blocks)))
 
 
 def test_cfg3_full_batch_spot_checks_and_determinism():
     """configs[2]: 4096 stereo streams, FFT 4096, EMA + slope.  Device-generated audio (wf_synth) for every stream; 16 warm-up
     ticks (the EMA settles) + 8 checked ticks.  Against the oracle on every checked tick: the first and last 32 streams of the
-    batch, streams 2032-2063 -- the batch is ticked as two concurrent launches split at stream 2048 --
-    and a block in the middle of either launch; two identical batches must agree bit for bit."""
+    batch, the 32 streams around every boundary between the concurrent launches the batch is ticked as (three slices since round 6)
+    and a block in the middle of every launch; two identical batches must agree bit for bit."""
     cfg = wf.Config.defaults(fft_size=4096, stereo=1, slope=1.0)
     streams, warm, checked, hop = 4096, 16, 8, 800
     ticks = warm + checked
-    ids = [s for first, n in CFG3_BLOCKS for s in range(first, first + n)]
-    res = []
+    res, blocks = [], None
     for rep in range(2):
         got = []
         with wf.SpectrumBatch(cfg, streams, ring_frames=4096 + hop * (ticks + 1)) as b:
-            assert b.launches_per_tick() == 2, "the lane boundary this test straddles"
+            assert b.launches_per_tick() >= 2, "the lane boundaries this test straddles"
+            blocks = cfg3_blocks(b.launches_per_tick(), streams)
             b.push_synth(SEED, 0, hop * ticks)
             for t in range(ticks):
                 b.tick(delay_frames=hop * (ticks - 1 - t))
                 if t >= warm:
-                    got.append(np.concatenate([b.decibels(first, n) for first, n in CFG3_BLOCKS]))
+                    got.append(np.concatenate([b.decibels(first, n) for first, n in blocks]))
             full = b.decibels()
         res.append((np.stack(got, axis=1), full))
     assert np.array_equal(res[0][1], res[1][1]), "two identical runs differ: the kernel is not deterministic"
     assert np.array_equal(res[0][0], res[1][0])
+    ids = [s for first, n in blocks for s in range(first, first + n)]
     want, _ = _oracle_ticks(cfg, ids, ticks, hop, checked)
     for k in range(checked):
-        assert_db_close(res[0][0][:, k], want[:, k], f"cfg3 full batch vs oracle, tick {warm + k} (first/last 32 streams, lane boundary, mid-lane)", deep=True)
+        assert_db_close(res[0][0][:, k], want[:, k], f"cfg3 full batch vs oracle, tick {warm + k} (first/last 32 streams, lane boundaries, mid-lane)", deep=True)
     assert np.all(np.isfinite(res[0][1]))
     # one block -- the 32 streams across the lane boundary -- against the reference itself (libwfref.so, generic class), not its restatement
     blk = [i for i, sid in enumerate(ids) if 2032 <= sid < 2064]
