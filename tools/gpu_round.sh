@@ -33,4 +33,18 @@ for J in "plugindefaults:python $R/tools/quick_case.py plugin_defaults" "n32768:
 done
 bash tools/size_sweep.sh $TAG > /dev/null 2>&1
 python tools/node_check.py > $O/node_check_$TAG.json 2> $O/node_check_$TAG.err
-ls $O/prof   # then, back home: bash tools/summarize_round.sh $TAG
+ls $O/prof
+# The raw rocprofv3 output of seventeen shapes exceeds what gpurun copies back (64 MiB): summarised HERE into profiles/TAG_* (the files
+# that get committed), which travel home in gpurun_out/profiles_TAG/; the raw passes stay on the box.
+python - <<PY
+import json
+lines = [l for l in open("$O/bench_$TAG.json").read().splitlines() if l.startswith("{")]
+if lines:
+    open("profiles/${TAG}_bench_line.json", "w").write(lines[-1] + "\n")
+PY
+bash tools/summarize_round.sh $TAG
+python tools/profiles_summary.py $TAG > /dev/null 2>&1
+mkdir -p $O/profiles_$TAG
+cp profiles/${TAG}_* $O/profiles_$TAG/ 2>/dev/null
+rm -rf $O/prof
+du -sh $O

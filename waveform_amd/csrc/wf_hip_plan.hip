@@ -787,9 +787,10 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
         const uint32_t per_cu = std::max(1u, std::min(h->wg_lds ? (160u * 1024u) / h->wg_lds : 16u, h->wg_threads ? 1024u / h->wg_threads : 16u));
         const uint32_t round = per_cu * (uint32_t)std::max(prop.multiProcessorCount, 1);
         int lanes = wgs >= 2u * round ? 2 : 1;
-        if(wgs >= 3u * round && wgs < 6u * round && !h->blu && h->M >= 2048)
+        if(wgs >= 3u * round && wgs < 6u * round && !h->blu && h->M >= 2048 && !(h->split && h->num_bars))
             lanes = 3; // round 6, the display-specific kernels (shorter workgroups): three to five rounds of workgroups as three slices --
-                       // headline 0.813 -> 0.824, N = 16384 x 1024 streams 0.710 -> 0.719, with bars +-0; eight rounds (8192 streams) -0.4 %
+                       // headline 0.813 -> 0.824, N = 4096 with bars 0.766 -> 0.777, N = 16384 x 1024 streams 0.710 -> 0.719 (with bars +-0: the split
+                       // kernels with a display keep two); eight rounds (8192 streams) -0.4 %
                        // without a display, +1 % with bars: two there (profiles/r06w_lanes_slim_kernels.txt)
         if(h->M <= 512 && !h->cfg.meter && !h->cfg.waveform && wgs >= 6u * round)
             lanes = 3; // the one-wavefront 8-point geometry in long launches: 0.714-0.717 against 0.682-0.683 of the HBM peak at
