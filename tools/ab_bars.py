@@ -17,6 +17,8 @@ SHAPES = [
     ("1024x16384 bars", dict(fft_size=1024, stereo=1, slope=1.0, bars=1, interp_mode=1), 16384, 0),
     ("8192x2048 bars", dict(fft_size=8192, stereo=1, slope=1.0, bars=1, interp_mode=1), 2048, 0),
     ("32768x512 bars", dict(fft_size=32768, stereo=1, slope=1.0, bars=1, interp_mode=1), 512, 0),
+    ("plugin defaults 4096x4096 mono + Catmull-Rom curve", dict(fft_size=4096, stereo=0, slope=1.0, curve=1, interp_mode=2), 4096, 0),
+    ("4096x4096 stereo + Lanczos curve", dict(fft_size=4096, stereo=1, slope=1.0, curve=1, interp_mode=1), 4096, 0),
 ]
 
 

@@ -4,7 +4,7 @@
 # they are event timings, not rocprofv3 profiles.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 O=gpurun_out/${1:-r02}_sizes.jsonl; mkdir -p gpurun_out; : > $O
-for S in 128:16384 256:16384 512:16384 1024:16384 2048:8192 4096:4096 8192:2048 16384:1024 32768:512 65536:256 800:8192 4160:2048 8000:1024 16400:256 32000:256 48000:256 48016:256 65424:256; do
+for S in 128:16384 256:16384 512:16384 1024:16384 2048:8192 4096:4096 8192:2048 16384:1024 32768:512 65536:256 800:8192 800:32768 960:8192 1600:8192 4160:2048 8000:1024 16400:256 32000:256 48000:256 48016:256 65424:256; do
   python tools/quick_bench.py $S 2>/dev/null >> $O; done
 for S in 1024:16384 2048:8192 4096:4096 8192:2048 16384:1024 32768:512 65536:256; do
   WF_BENCH_BARS=1 python tools/quick_bench.py $S 2>/dev/null | sed 's/^{/{"bars": "26 Lanczos bars per row", /' >> $O; done

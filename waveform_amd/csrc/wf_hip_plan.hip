@@ -792,9 +792,12 @@ int wf_hip_create(const wf_config *cfg, int device, uint32_t max_streams, uint32
                        // headline 0.813 -> 0.824, N = 4096 with bars 0.766 -> 0.777, N = 16384 x 1024 streams 0.710 -> 0.719 (with bars +-0: the split
                        // kernels with a display keep two); eight rounds (8192 streams) -0.4 %
                        // without a display, +1 % with bars: two there (profiles/r06w_lanes_slim_kernels.txt)
+        if(wgs >= 6u * round && !h->blu && h->M >= 2048 && !h->split && h->num_bars)
+            lanes = 3; // longer batches with a bars display: +0.4 ... +1.4 % in four sweeps (8192 streams, bars-only ticks 0.677 -> 0.6815; r06w, r06y)
         if(h->M <= 512 && !h->cfg.meter && !h->cfg.waveform && wgs >= 6u * round)
             lanes = 3; // the one-wavefront 8-point geometry in long launches: 0.714-0.717 against 0.682-0.683 of the HBM peak at
-                       // 16384 streams (steady state, r02j); +-2 % on every other geometry
+                       // 16384 streams (steady state, r02j; N = 512 x 16384 streams 0.614 -> 0.636, r06y); from three rounds on instead:
+                       // N = 512 x 8192 streams 0.519 -> 0.508 (profiles/r06y_lanes_rule_ab.txt)
         if(per_cu == 1 && wgs >= 2u * round)
             lanes = 3; // one workgroup per CU (32768 samples): fetch, transform and the end of the tick take turns inside a CU, and the
                        // launches of three slices drift apart: 256 streams 0.465 -> 0.513 (two) -> 0.533 (three), 2048 streams 0.472 -> 0.470 -> 0.495
